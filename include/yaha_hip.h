@@ -1,0 +1,191 @@
+/* yaha_hip.h -- C-ABI of the MI355X-native hot path of YAHA (seed join -> clumps -> banded affine-gap DP ->
+ * score/split).  Plain pointers and sizes only; no torch, no C++ types.
+ *
+ * The reference (GregoryFaust/yaha v0.1.83) has no plugin/FFI seam: its hot path is the body of the per-read
+ * loop in src/Query.c:306-497, which calls (all declared in src/Math.h)
+ *     findFragmentsSort        Math.h:554   (QueryMatch.c:52)     -> ygpu stage A1+A2
+ *     processFragmentsGapped   Math.h:555   (QueryMatch.c:224)    -> ygpu stage A3+A4
+ *     postProcessClumps        Math.h:539   (QueryMatch.c:306)    -> ygpu stage A5..A8
+ *       alignClump/scoreClump  Math.h:537-538, findAGS* Math.h:401-410, extendClump* Math.h:535-536
+ * on one QueryState_t (Math.h:587-666) per thread.  This header is the *batched* replacement of that loop
+ * body: a whole batch of reads is handed over, and for every read the clump list that postProcessClumps
+ * leaves in QS->clumps (head -> tail order, QueryMatch.c:309-330) comes back, ready for the host's
+ * postFilterBySimilarity / printClump stages.
+ *
+ * Conventions: every function returns 0 on success or a negative YGPU_E* code; nothing ever calls exit().
+ * The caller owns inputs until the call returns.  Results are owned by the context and stay valid until the
+ * next ygpu_run on that context.  One context per device, one host thread per context (mirrors one
+ * QueryState_t per thread, Query.c:642-684).
+ */
+#ifndef YAHA_HIP_H
+#define YAHA_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YGPU_OK            0
+#define YGPU_EINVAL      (-1)   /* bad argument / unsupported parameter range            */
+#define YGPU_ENODEV      (-2)   /* no HIP device / HIP runtime error                     */
+#define YGPU_ENOMEM      (-3)   /* device or host allocation failed                      */
+#define YGPU_EOVERFLOW   (-4)   /* a device arena overflowed even after regrowth         */
+#define YGPU_EINTERNAL   (-5)
+
+/* Alignment parameters: the subset of AlignmentArgs_t (Math.h:257-334) the hot path reads, after
+ * postProcessAlignmentArgs (AlignArgs.c:108-169) has filled the derived ones. */
+typedef struct ygpu_params {
+    int32_t wordLen;        /* -L, from the index header (Query.c:603)                         */
+    int32_t maxHits;        /* min(-H, index header maxHits) (Query.c:604-610)                 */
+    int32_t bandWidth;      /* -BW                                                             */
+    int32_t maxGap;         /* -G                                                              */
+    int32_t maxIntron;      /* -I, default = maxGap (AlignArgs.c:111)                          */
+    int32_t minMatch;       /* -M                                                              */
+    int32_t maxDesert;      /* -MD                                                             */
+    int32_t minNonOverlap;  /* = OQCMinNonOverlap = -MNO, default minMatch (AlignArgs.c:115-125) */
+    int32_t minRawScore;    /* -R, default = minMatch (AlignArgs.c:113)                        */
+    int32_t minExtLength;   /* derived (AlignArgs.c:141-149); 5 at defaults                    */
+    int32_t GOCost, GECost, RCost, MScore, XCutoff;
+    float   minIdentity;    /* -P, kept as float on purpose (Math.h:292, AlignHelpers.c:359)   */
+} ygpu_params;
+
+/* Borrowed, read-only view of the loaded .nib2 bases and index (Query.c:565-626). */
+typedef struct ygpu_index_view {
+    const uint8_t  *bases;        /* AAs->basePtr: 4-bit codes, two per byte, high nibble first */
+    uint64_t        n_base_bytes;
+    uint32_t        maxROff;      /* AAs->maxROff (BaseSeq.c:121-125)                           */
+    const uint32_t *startingOffs; /* 4^wordLen + 1 entries                                      */
+    const uint32_t *ROA;          /* totalMatches entries                                       */
+    uint32_t        totalMatches;
+    int32_t         wordLen;
+} ygpu_index_view;
+
+/* A batch of reads: forward-strand 4-bit codes, one per byte (QS->forwardCodeBuf, Query.c:161-163);
+ * read i occupies codes[offsets[i] .. offsets[i+1]).  The reverse complement (Query.c:164-167) is derived
+ * on the device. */
+typedef struct ygpu_read_batch {
+    uint32_t        n_reads;
+    const uint8_t  *codes;
+    const uint64_t *offsets;      /* n_reads + 1 */
+} ygpu_read_batch;
+
+/* Edit operations are packed (len | opcode << 16), opcode one of 'M','R','I','D' (Math.h:353-360). */
+#define YGPU_OP_LEN(x)  ((uint32_t)(x) & 0xFFFFu)
+#define YGPU_OP_CODE(x) ((char)(((uint32_t)(x) >> 16) & 0xFFu))
+#define YGPU_OP_MAKE(code, len) (((uint32_t)(uint8_t)(code) << 16) | ((uint32_t)(len) & 0xFFFFu))
+
+/* One scored clump = the single SFragment + EditOpList + Clump_t fields (Math.h:448-456,512-527).
+ * Offsets are strand-local exactly as in the reference (FragsClumps.inl:355-365 converts later). */
+typedef struct ygpu_clump {
+    uint32_t sro;          /* frag.startRefOff                       */
+    uint16_t sqo, eqo;     /* frag.startQueryOff / endQueryOff       */
+    uint16_t refLen;       /* frag.refLen (SUINT)                    */
+    uint16_t totScore;     /* Clump_t::totScore (QOFF!)              */
+    uint16_t totLength, matchedBases, mismatchedBases, gapBases;
+    uint8_t  status;       /* clumpReversed 0x01 | Aligned 0x04 | Scored 0x08 | Split 0x10 */
+    uint8_t  reserved;
+    uint32_t op_start;     /* first op of this clump in ygpu_result_batch::ops */
+    uint32_t n_ops;
+} ygpu_clump;
+
+/* Work counters (per batch) used for the algorithmic-bytes figure of SURVEY.md 8(d). */
+typedef struct ygpu_counters {
+    uint64_t kmer_lookups, hits, fragments, regions, clumps_formed, clumps_scored;
+    uint64_t dp_ext_calls, dp_ext_rows, dp_ext_cells;
+    uint64_t dp_gap_calls, dp_gap_rows, dp_gap_cells;
+    uint64_t perfect_ext_bases, ref_bases_touched, ops_out, splits;
+} ygpu_counters;
+
+typedef struct ygpu_result_batch {
+    uint32_t          n_reads;
+    const uint32_t   *clump_start;   /* n_reads + 1; clumps of read i = [clump_start[i], clump_start[i+1]) in
+                                        QS->clumps head->tail order after postProcessClumps */
+    const ygpu_clump *clumps;
+    const uint32_t   *ops;
+    uint64_t          n_clumps, n_ops;
+    ygpu_counters     counters;
+} ygpu_result_batch;
+
+typedef struct ygpu_ctx ygpu_ctx;
+
+/* Create a context on HIP device `device`: copies the index view into HBM (replicated per GPU; reads shard
+ * across GPUs, no collective).  Replaces the per-thread makeQueryState/initializeQueries (QueryState.c:36-104). */
+int  ygpu_init(int device, const ygpu_index_view *index, const ygpu_params *params, ygpu_ctx **out);
+void ygpu_destroy(ygpu_ctx *ctx);
+const char *ygpu_last_error(const ygpu_ctx *ctx);
+
+/* Stage reads into HBM (H2D).  Separate from ygpu_run so that a benchmark can time the hot path with inputs
+ * already resident. */
+int  ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *batch);
+/* Run the whole hot path (A1..A10) on the resident batch; results stay in HBM. */
+int  ygpu_run(ygpu_ctx *ctx);
+/* Copy results of the last ygpu_run to host memory owned by the context. */
+int  ygpu_collect(ygpu_ctx *ctx, ygpu_result_batch *out);
+/* Elapsed device time of the last ygpu_run in milliseconds, total and per kernel family (HIP events on the
+ * context's stream). names/ms arrays are owned by the context. */
+int  ygpu_last_timing(ygpu_ctx *ctx, float *total_ms, int *n_stages, const char *const **names, const float **ms);
+
+/* ---- stage-level entry points (what golden vectors are replayed against) ------------------------------ */
+
+/* Fragment_t (Math.h:448-456) as produced by findFragmentsSort, plus the owning read/strand. */
+typedef struct ygpu_fragment {
+    uint32_t startRefOff;
+    uint16_t startQueryOff, endQueryOff;
+    uint16_t refLen;
+    uint16_t reserved;
+    uint32_t read_strand;    /* read * 2 + strand */
+} ygpu_fragment;
+
+/* A1+A2 for the resident batch: fragments sorted by (read, strand, diag, SQO). Output owned by ctx. */
+int  ygpu_seed_join(ygpu_ctx *ctx, const ygpu_fragment **frags, uint64_t *n_frags);
+
+/* A3+A4 on the fragments of the last ygpu_seed_join: per clump (in creation order per read/strand) the
+ * ordered fragment list before alignClump. clump_frag_start has n_clumps+1 entries. */
+int  ygpu_chain(ygpu_ctx *ctx, const ygpu_fragment **clump_frags, const uint32_t **clump_frag_start,
+                const uint32_t **clump_read_strand, uint64_t *n_clumps);
+
+/* One DP call of findAffineGapScore (SW.cpp:798-1208) through its wrappers (SW.cpp:462-547). */
+enum { YGPU_DP_FULL = 0, YGPU_DP_BANDED = 1, YGPU_DP_EXT_FWD = 2, YGPU_DP_EXT_REV = 3 };
+typedef struct ygpu_dp_problem {
+    uint32_t read;      /* index into the resident batch              */
+    uint8_t  strand;    /* 0 forward codes, 1 reverse-complement      */
+    uint8_t  mode;      /* YGPU_DP_*                                   */
+    uint16_t qOff;      /* as passed to the reference wrapper          */
+    uint16_t qLen;
+    uint16_t rLen;      /* FULL/BANDED only                            */
+    uint32_t rOff;
+} ygpu_dp_problem;
+typedef struct ygpu_dp_result {
+    int32_t  score;
+    uint16_t addedQLen, addedRLen;  /* extensions only */
+    uint32_t op_start, n_ops;       /* ops in list order (head..tail) as the wrapper would merge them */
+} ygpu_dp_result;
+int  ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n,
+                   const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops);
+
+/* ---- host stages around the hot path (SURVEY.md 8(f) rows restated on the host) ------------------------
+ * A session owns what processQueryFile (Query.c:551-709) sets up: parsed arguments, the mmap'ed .nib2 and
+ * index, the query reader.  argv is the reference's own command line (`-x index -q reads -osh out ...`). */
+typedef struct yaha_session yaha_session;
+int  yaha_session_open(int argc, const char *const *argv, yaha_session **out);
+void yaha_session_close(yaha_session *s);
+const char *yaha_session_error(const yaha_session *s);
+int  yaha_session_params(const yaha_session *s, ygpu_params *p);
+int  yaha_session_index_view(const yaha_session *s, ygpu_index_view *v);
+/* SAM header (@HD/@SQ/@PG, AlignOutput.c:30-111); text owned by the session. */
+int  yaha_session_header(yaha_session *s, const char **text, size_t *len);
+/* Read up to max_reads queries (readNextQuery, Query.c:102-228); b->n_reads == 0 at end of input.
+ * The batch stays valid until the next call. */
+int  yaha_session_next_batch(yaha_session *s, uint32_t max_reads, ygpu_read_batch *b);
+/* Post-filter (OQC/FBS/dedup/MAPQ, GraphPath.cpp:897-1174) and format (printClump, AlignOutput.c:115-321)
+ * the hot-path results of the current batch; text owned by the session until the next call. */
+int  yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **text, size_t *len);
+/* `yaha -g genome.fa [-L k] [-S s] [-H h]`: writes genome.nib2 and genome.X<LL>_<SS>_<HHHHH>S (Main.c:554-628). */
+int  yaha_build_index(int argc, const char *const *argv);
+/* The complete command-line program (index creation or query alignment on the GPU). */
+int  yaha_main(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

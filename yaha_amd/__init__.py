@@ -1,0 +1,225 @@
+"""yaha_amd -- Python mirror (ctypes) of the C-ABI in include/yaha_hip.h.
+
+The product is the shared library ``yaha_amd/csrc/libyaha_hip.so`` (hand-written HIP kernels for gfx950 plus
+the host stages) and the ``yaha`` command line next to it.  This module only loads it and mirrors the
+structs; it never falls back to anything else: if the library is missing, importing the bindings raises.
+PyTorch is not needed here (bench.py uses it for torch.distributed plumbing only).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libyaha_hip.so")
+CLI_PATH = os.path.join(_HERE, "csrc", "yaha")
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "wordLen", "maxHits", "bandWidth", "maxGap", "maxIntron", "minMatch", "maxDesert", "minNonOverlap",
+        "minRawScore", "minExtLength", "GOCost", "GECost", "RCost", "MScore", "XCutoff")] + [("minIdentity", C.c_float)]
+
+
+class IndexView(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("n_base_bytes", C.c_uint64), ("maxROff", C.c_uint32),
+                ("startingOffs", C.c_void_p), ("ROA", C.c_void_p), ("totalMatches", C.c_uint32), ("wordLen", C.c_int32)]
+
+
+class ReadBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("codes", C.c_void_p), ("offsets", C.c_void_p)]
+
+
+class Clump(C.Structure):
+    _fields_ = [("sro", C.c_uint32), ("sqo", C.c_uint16), ("eqo", C.c_uint16), ("refLen", C.c_uint16),
+                ("totScore", C.c_uint16), ("totLength", C.c_uint16), ("matchedBases", C.c_uint16),
+                ("mismatchedBases", C.c_uint16), ("gapBases", C.c_uint16), ("status", C.c_uint8),
+                ("reserved", C.c_uint8), ("op_start", C.c_uint32), ("n_ops", C.c_uint32)]
+
+
+COUNTER_NAMES = ("kmer_lookups", "hits", "fragments", "regions", "clumps_formed", "clumps_scored",
+                 "dp_ext_calls", "dp_ext_rows", "dp_ext_cells", "dp_gap_calls", "dp_gap_rows", "dp_gap_cells",
+                 "perfect_ext_bases", "ref_bases_touched", "ops_out", "splits")
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_NAMES]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in COUNTER_NAMES}
+
+
+class ResultBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("clump_start", C.POINTER(C.c_uint32)), ("clumps", C.POINTER(Clump)),
+                ("ops", C.POINTER(C.c_uint32)), ("n_clumps", C.c_uint64), ("n_ops", C.c_uint64), ("counters", Counters)]
+
+
+class Fragment(C.Structure):
+    _fields_ = [("startRefOff", C.c_uint32), ("startQueryOff", C.c_uint16), ("endQueryOff", C.c_uint16),
+                ("refLen", C.c_uint16), ("reserved", C.c_uint16), ("read_strand", C.c_uint32)]
+
+
+class DPProblem(C.Structure):
+    _fields_ = [("read", C.c_uint32), ("strand", C.c_uint8), ("mode", C.c_uint8), ("qOff", C.c_uint16),
+                ("qLen", C.c_uint16), ("rLen", C.c_uint16), ("rOff", C.c_uint32)]
+
+
+class DPResult(C.Structure):
+    _fields_ = [("score", C.c_int32), ("addedQLen", C.c_uint16), ("addedRLen", C.c_uint16),
+                ("op_start", C.c_uint32), ("n_ops", C.c_uint32)]
+
+
+DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
+
+EXPORTS = (
+    "ygpu_init", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_last_timing",
+    "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch",
+    "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
+    "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit",
+    "yaha_build_index", "yaha_main")
+
+_lib = None
+
+
+def lib():
+    """Load libyaha_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(or make -C yaha_amd/csrc); there is no fallback path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ygpu_last_error.restype = C.c_char_p
+        L.yaha_session_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(L, name)
+        _lib = L
+    return _lib
+
+
+def _argv(args):
+    arr = (C.c_char_p * len(args))(*[a.encode() if isinstance(a, str) else a for a in args])
+    return len(args), arr
+
+
+def build_index(args):
+    """`yaha -g genome.fa [-L k] [-S s] [-H h]` (reference Main.c:554-628)."""
+    n, arr = _argv(args)
+    rc = lib().yaha_build_index(n, arr)
+    if rc != 0:
+        raise RuntimeError("yaha_build_index%r failed: %d" % (tuple(args), rc))
+
+
+class Session:
+    """Host stages around the hot path: argument parsing, .nib2/index mapping, read batching, OQC + SAM."""
+
+    def __init__(self, args):
+        self._h = C.c_void_p()
+        n, arr = _argv(args)
+        rc = lib().yaha_session_open(n, arr, C.byref(self._h))
+        if rc != 0:
+            msg = lib().yaha_session_error(self._h).decode() if self._h else "bad arguments"
+            raise RuntimeError("yaha_session_open failed: %d %s" % (rc, msg))
+        self.params = Params()
+        lib().yaha_session_params(self._h, C.byref(self.params))
+        self.index = IndexView()
+        lib().yaha_session_index_view(self._h, C.byref(self.index))
+
+    def header(self):
+        t, n = C.c_char_p(), C.c_size_t()
+        lib().yaha_session_header(self._h, C.byref(t), C.byref(n))
+        return C.string_at(t, n.value).decode()
+
+    def next_batch(self, max_reads):
+        b = ReadBatch()
+        lib().yaha_session_next_batch(self._h, max_reads, C.byref(b))
+        return b
+
+    def emit(self, result):
+        t, n = C.c_char_p(), C.c_size_t()
+        rc = lib().yaha_session_emit(self._h, C.byref(result), C.byref(t), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("yaha_session_emit failed: %d" % rc)
+        return C.string_at(t, n.value).decode()
+
+    def close(self):
+        if self._h:
+            lib().yaha_session_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Context:
+    """One device context = the reference's per-thread QueryState, batched (include/yaha_hip.h)."""
+
+    def __init__(self, index_view, params, device=0):
+        self._h = C.c_void_p()
+        rc = lib().ygpu_init(device, C.byref(index_view), C.byref(params), C.byref(self._h))
+        if rc != 0:
+            msg = lib().ygpu_last_error(self._h).decode() if self._h else ""
+            raise RuntimeError("ygpu_init failed: %d %s (the HIP path is mandatory; there is no CPU fallback)" % (rc, msg))
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %d %s" % (what, rc, lib().ygpu_last_error(self._h).decode()))
+
+    def upload(self, batch):
+        self._check(lib().ygpu_upload(self._h, C.byref(batch)), "ygpu_upload")
+
+    def run(self):
+        self._check(lib().ygpu_run(self._h), "ygpu_run")
+
+    def collect(self):
+        r = ResultBatch()
+        self._check(lib().ygpu_collect(self._h, C.byref(r)), "ygpu_collect")
+        return r
+
+    def timing(self):
+        tot, n = C.c_float(), C.c_int()
+        names, ms = C.POINTER(C.c_char_p)(), C.POINTER(C.c_float)()
+        self._check(lib().ygpu_last_timing(self._h, C.byref(tot), C.byref(n), C.byref(names), C.byref(ms)), "ygpu_last_timing")
+        return tot.value, {names[i].decode(): ms[i] for i in range(n.value)}
+
+    def seed_join(self):
+        f, n = C.POINTER(Fragment)(), C.c_uint64()
+        self._check(lib().ygpu_seed_join(self._h, C.byref(f), C.byref(n)), "ygpu_seed_join")
+        return f, n.value
+
+    def chain(self):
+        f, s, rs, n = C.POINTER(Fragment)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.c_uint64()
+        self._check(lib().ygpu_chain(self._h, C.byref(f), C.byref(s), C.byref(rs), C.byref(n)), "ygpu_chain")
+        return f, s, rs, n.value
+
+    def dp_batch(self, problems):
+        arr = (DPProblem * len(problems))(*problems)
+        res, ops, nops = C.POINTER(DPResult)(), C.POINTER(C.c_uint32)(), C.c_uint64()
+        self._check(lib().ygpu_dp_batch(self._h, arr, len(problems), C.byref(res), C.byref(ops), C.byref(nops)), "ygpu_dp_batch")
+        return res, ops, nops.value
+
+    def close(self):
+        if self._h:
+            lib().ygpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def result_records(r):
+    """Flatten a ResultBatch into plain Python tuples (for bit-exact comparisons in tests)."""
+    out = []
+    for i in range(r.n_reads):
+        rec = []
+        for k in range(r.clump_start[i], r.clump_start[i + 1]):
+            c = r.clumps[k]
+            ops = tuple((r.ops[c.op_start + j] & 0xFFFF, chr((r.ops[c.op_start + j] >> 16) & 0xFF)) for j in range(c.n_ops))
+            rec.append((c.sro, c.sqo, c.eqo, c.refLen, c.totScore, c.totLength, c.matchedBases, c.mismatchedBases,
+                        c.gapBases, c.status, ops))
+        out.append(rec)
+    return out

@@ -1,0 +1,199 @@
+// pipeline.cpp -- the batching host that replaces the reference's per-read loop (Query.c:255-543) and its
+// run driver (Query.c:551-709): read a batch of queries, hand it to the device hot path through the C-ABI
+// (ygpu_upload / ygpu_run / ygpu_collect), post-filter and format on host threads, write in input order.
+// With -gpus N one context per device is driven by its own host thread; batches are dealt round-robin and the
+// output is re-ordered by batch ticket, so the text equals a `-t 1` run of the reference.
+#include "yaha_host.h"
+#include <cstring>
+#include <cstdlib>
+#include <thread>
+#include <atomic>
+#include <mutex>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <sys/stat.h>
+
+using namespace yaha;
+
+struct yaha_session {
+    Args args; Genome genome; IndexFile index; ReadReader reader; std::string err, header, text;
+    std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
+    bool readerOpen = false;
+};
+
+namespace yaha {
+
+static bool fileNewerThan(const std::string &f1, const std::string &f2)      // FileHelpers.c:127-146
+{
+    struct stat s1, s2;
+    if (stat(f1.c_str(), &s1) != 0) return false;
+    if (stat(f2.c_str(), &s2) != 0) return true;
+    return s1.st_mtime > s2.st_mtime;
+}
+
+int runIndex(Args &a, FILE *log)                                              // Main.c:587-628
+{
+    if (a.wordLen > 15) { fprintf(log, "Word Length (-L) for index creation is currently restricted to < 16.\n"); return 1; }
+    if (a.skipDist < 1 || a.skipDist > a.wordLen) { fprintf(log, "Skip Distance (-S) for index creation must be between 1 and WordLength (inclusive).\n"); return 1; }
+    size_t dot = a.gfileName.rfind('.'); std::string ext = dot == std::string::npos ? "" : a.gfileName.substr(dot);
+    bool fasta = (ext == ".fna" || ext == ".fa" || ext == ".fasta");
+    if (!fasta && ext != ".nib2") { fprintf(log, "Expecting a \".fa\", \".fna\", \".fasta\", or \".nib2\" genome file.\n"); return 1; }
+    char oext[32]; snprintf(oext, sizeof oext, ".X%02d_%02d_%05dS", a.wordLen, a.skipDist, a.maxHits);
+    std::string root = a.gfileName.substr(0, dot), nib2 = fasta ? root + ".nib2" : a.gfileName, xfile = root + oext, err;
+    if (fasta) {
+        if (fileNewerThan(a.gfileName, nib2)) {
+            fprintf(log, "Compressing %s into %s.\n", a.gfileName.c_str(), nib2.c_str());
+            std::vector<uint8_t> img;
+            if (!compressFasta(a.gfileName.c_str(), img, err) || !writeFile(nib2.c_str(), img.data(), img.size(), err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
+            fprintf(log, "Finished compressing %s, now forming index.\n", nib2.c_str());
+        } else fprintf(log, "%s already exists.  Creating the index file.\n", nib2.c_str());
+    }
+    fprintf(log, "Creating index file %s.\n", xfile.c_str());
+    Genome g; if (!loadNib2(nib2.c_str(), g, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
+    std::vector<uint32_t> image;
+    buildIndex(g, a.wordLen, a.skipDist, a.maxHits, image, log);
+    if (!writeFile(xfile.c_str(), image.data(), image.size() * 4, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
+    fprintf(log, "Index %s created.\n", xfile.c_str());
+    return 0;
+}
+
+static bool sessionLoad(yaha_session *s)
+{
+    Args &a = s->args;
+    if (!loadNib2(a.gfileName.c_str(), s->genome, s->err)) return false;
+    if (!loadIndex(a.xfileName.c_str(), s->index, s->err)) return false;
+    a.wordLen = s->index.wordLen;                                            // Query.c:603-610
+    if (s->index.maxHits < a.maxHits) {
+        fprintf(stderr, "WARNING: Index file made with maxHits of %d, while %d specified for this query run.\nMimimum of two (%d) will be used.\n", s->index.maxHits, a.maxHits, s->index.maxHits);
+        a.maxHits = s->index.maxHits;
+    }
+    s->reader.maxQueryLength = a.maxQueryLength; s->reader.wordLen = a.wordLen;
+    if (!s->reader.open(a.qfileName.c_str(), s->err)) return false;
+    s->readerOpen = true; a.fastq = s->reader.fastq;
+    s->header = samHeader(a, s->genome);
+    return true;
+}
+
+static void formatBatch(yaha_session *s, const ygpu_result_batch *r, std::string &text)
+{
+    const Args &a = s->args; const uint32_t n = r->n_reads;
+    std::vector<std::string> parts(n);
+    std::atomic<uint32_t> next(0);
+    auto work = [&]() {
+        std::vector<OutClump> oc;
+        for (;;) {
+            uint32_t i = next.fetch_add(1); if (i >= n) break;
+            uint32_t c0 = r->clump_start[i], c1 = r->clump_start[i + 1]; int primaryCount = 0;
+            postFilter(a, s->genome, s->reads[i], r->clumps + c0, c1 - c0, r->ops, oc, primaryCount);
+            for (auto &o : oc) printClump(a, s->genome, s->reads[i], o, primaryCount, parts[i]);
+        }
+    };
+    int nt = std::max(1, a.numThreads); std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work(); for (auto &x : th) x.join();
+    size_t tot = 0; for (auto &p : parts) tot += p.size();
+    text.clear(); text.reserve(tot); for (auto &p : parts) text += p;
+}
+
+int runQueries(Args &a, FILE *log)
+{
+    std::unique_ptr<yaha_session> S(new yaha_session); S->args = a;
+    if (!sessionLoad(S.get())) { fprintf(log, "%s\n", S->err.c_str()); return 1; }
+    Args &A = S->args;
+    FILE *out = (A.ofileName == "stdout") ? stdout : fopen(A.ofileName.c_str(), "w");
+    if (!out) { fprintf(log, "Failure to open output file: %s.\n", A.ofileName.c_str()); return 1; }
+    fputs(S->header.c_str(), out);
+    ygpu_params P; paramsFromArgs(A, P);
+    ygpu_index_view V; yaha_session_index_view(S.get(), &V);
+    const int ngpu = std::max(1, A.gpus);
+    std::vector<ygpu_ctx *> ctx(ngpu, nullptr);
+    for (int d = 0; d < ngpu; d++) {
+        int rc = ygpu_init(A.device + d, &V, &P, &ctx[d]);
+        if (rc != 0) { fprintf(log, "ygpu_init(device %d) failed: %d %s\n", A.device + d, rc, ctx[d] ? ygpu_last_error(ctx[d]) : ""); return 1; }
+    }
+    // One worker per device.  The reader is serial (as in the reference, Query.c:105-214); a ticket orders output.
+    struct Batch { uint64_t ticket; std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets; };
+    std::mutex rdMu, outMu; std::condition_variable outCv; uint64_t nextTicket = 0, nextOut = 0; bool eof = false; int rcAll = 0;
+    std::map<uint64_t, std::string> done;
+    auto readBatch = [&](Batch &b) -> bool {
+        std::lock_guard<std::mutex> lk(rdMu);
+        if (eof) return false;
+        b.reads.clear(); b.codes.clear(); b.offsets.assign(1, 0);
+        Read r;
+        while ((int)b.reads.size() < A.batchReads && S->reader.next(r)) { b.codes.insert(b.codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); b.offsets.push_back(b.codes.size()); b.reads.push_back(std::move(r)); }
+        if ((int)b.reads.size() < A.batchReads) eof = true;
+        if (b.reads.empty()) return false;
+        b.ticket = nextTicket++; return true;
+    };
+    auto worker = [&](int d) {
+        yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs; local.genome.maxROff = S->genome.maxROff;
+        Batch b;
+        while (readBatch(b)) {
+            ygpu_read_batch rb{(uint32_t)b.reads.size(), b.codes.data(), b.offsets.data()}; ygpu_result_batch res;
+            int rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc == 0) rc = ygpu_collect(ctx[d], &res);
+            std::string text;
+            if (rc != 0) { fprintf(log, "device %d: hot path failed (%d): %s\n", d, rc, ygpu_last_error(ctx[d])); rcAll = 1; }
+            else { local.reads.swap(b.reads); formatBatch(&local, &res, text); local.reads.swap(b.reads); }
+            std::unique_lock<std::mutex> lk(outMu);
+            done[b.ticket] = std::move(text);
+            while (!done.empty() && done.begin()->first == nextOut) { fputs(done.begin()->second.c_str(), out); done.erase(done.begin()); nextOut++; }
+        }
+    };
+    std::vector<std::thread> th; for (int d = 1; d < ngpu; d++) th.emplace_back(worker, d);
+    worker(0); for (auto &x : th) x.join();
+    for (auto &kv : done) fputs(kv.second.c_str(), out);
+    for (auto c : ctx) ygpu_destroy(c);
+    if (out != stdout) fclose(out); else fflush(out);
+    return rcAll;
+}
+}  // namespace yaha
+
+// ---- C-ABI --------------------------------------------------------------------------------------------------
+extern "C" {
+int yaha_session_open(int argc, const char *const *argv, yaha_session **out)
+{
+    *out = nullptr; yaha_session *s = new yaha_session;
+    std::vector<char *> av; av.push_back((char *)"yaha"); for (int i = 0; i < argc; i++) av.push_back((char *)argv[i]);
+    int rc = parseArgs((int)av.size(), av.data(), s->args);
+    if (rc != 0 || !s->args.query) { delete s; return YGPU_EINVAL; }
+    *out = s;
+    if (!sessionLoad(s)) return YGPU_EINVAL;
+    return 0;
+}
+void yaha_session_close(yaha_session *s) { if (!s) return; if (s->readerOpen) s->reader.close(); delete s; }
+const char *yaha_session_error(const yaha_session *s) { return s ? s->err.c_str() : "null session"; }
+int yaha_session_params(const yaha_session *s, ygpu_params *p) { paramsFromArgs(s->args, *p); return 0; }
+int yaha_session_index_view(const yaha_session *s, ygpu_index_view *v)
+{
+    v->bases = s->genome.bases; v->n_base_bytes = s->genome.nBaseBytes; v->maxROff = s->genome.maxROff;
+    v->startingOffs = s->index.SO; v->ROA = s->index.ROA; v->totalMatches = s->index.totalMatches; v->wordLen = s->index.wordLen; return 0;
+}
+int yaha_session_header(yaha_session *s, const char **text, size_t *len) { *text = s->header.c_str(); *len = s->header.size(); return 0; }
+int yaha_session_next_batch(yaha_session *s, uint32_t max_reads, ygpu_read_batch *b)
+{
+    s->reads.clear(); s->codes.clear(); s->offsets.assign(1, 0);
+    Read r;
+    while (s->reads.size() < max_reads && s->reader.next(r)) { s->codes.insert(s->codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); s->offsets.push_back(s->codes.size()); s->reads.push_back(std::move(r)); }
+    b->n_reads = (uint32_t)s->reads.size(); b->codes = s->codes.data(); b->offsets = s->offsets.data(); return 0;
+}
+int yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **text, size_t *len)
+{
+    if (r->n_reads != s->reads.size()) { s->err = "result batch does not match the current read batch"; return YGPU_EINVAL; }
+    formatBatch(s, r, s->text); *text = s->text.c_str(); *len = s->text.size(); return 0;
+}
+int yaha_build_index(int argc, const char *const *argv)
+{
+    Args a; std::vector<char *> av; av.push_back((char *)"yaha"); for (int i = 0; i < argc; i++) av.push_back((char *)argv[i]);
+    int rc = parseArgs((int)av.size(), av.data(), a); if (rc != 0 || !a.index) return YGPU_EINVAL;
+    return runIndex(a, stderr) == 0 ? 0 : YGPU_EINVAL;
+}
+int yaha_main(int argc, char **argv)
+{
+    fprintf(stderr, "YAHA (MI355X hot path) compatible with version 0.1.83\n");
+    Args a; int rc = parseArgs(argc, argv, a);
+    if (rc != 0) return rc - 1;
+    if (a.query) return runQueries(a, stderr);
+    return runIndex(a, stderr);
+}
+}

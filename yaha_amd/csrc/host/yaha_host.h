@@ -1,0 +1,99 @@
+// yaha_host.h -- host side of the MI355X-native YAHA hot path: everything the reference does *around* the
+// per-read hot loop (file formats, argument handling, FASTA/FASTQ reading, OQC/FBS post-filter, SAM/Blast8
+// output).  These stages are SURVEY.md 8(f) "next" rows restated on the host so that `yaha -x .. -q ..` keeps
+// producing bit-identical output; the hot path itself (8(a) A1..A10) lives in ../device and is reached only
+// through include/yaha_hip.h.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../../include/yaha_hip.h"
+
+namespace yaha {
+
+// ---- 4-bit code tables (data contract, reference Math.c:141-157) -----------------------------------------
+extern const uint8_t kFourBitCodes[128];
+extern const char    kFourBitChars[16];
+extern const uint8_t kFourBitCompCodes[16];
+inline uint8_t map8to4(int c) { return kFourBitCodes[c & 127]; }
+inline uint8_t get4(const uint8_t *bases, uint32_t off) { uint8_t b = bases[off >> 1]; return (off & 1) ? (b & 0xF) : (uint8_t)(b >> 4); }
+
+// ---- Marsaglia xorshift RNG (reference Math.c:238-343) ----------------------------------------------------
+struct RandState { uint32_t s[5]; };
+void     randInitDefault(RandState &r);
+uint32_t randBits(RandState &r);
+void     randSample(RandState &r, const uint32_t *in, int inLen, uint32_t *out, int outLen);
+
+// ---- memory-mapped read-only file -----------------------------------------------------------------------
+struct MMap { void *ptr = nullptr; size_t size = 0; int fd = -1; bool open(const char *path, std::string &err); void close(); ~MMap() { close(); } };
+
+// ---- .nib2 genome (reference Compress.c, BaseSeq.c) -----------------------------------------------------
+struct BaseSeq { std::string name; uint32_t start; uint32_t length; };      // start in BASES (already normalised)
+struct Genome {
+    MMap map; std::vector<uint8_t> owned;              // either mapped file or in-memory image
+    const uint8_t *bases = nullptr; uint64_t nBaseBytes = 0;
+    std::vector<BaseSeq> seqs; uint32_t maxROff = 0;
+    int findSeq(uint32_t off) const;                   // findBaseSequenceNum, BaseSeq.c:81-90
+};
+bool compressFasta(const char *fastaPath, std::vector<uint8_t> &nib2Image, std::string &err);   // Compress.c:220-329
+bool parseNib2(const uint8_t *img, size_t size, Genome &g, std::string &err);                   // Compress.c:76-134
+bool loadNib2(const char *path, Genome &g, std::string &err);
+bool writeFile(const char *path, const void *data, size_t size, std::string &err);             // mode 0744, FileHelpers.c:279
+
+// ---- index (reference Index.c:49-335, Query.c:596-626) --------------------------------------------------
+struct IndexFile {
+    MMap map; std::vector<uint32_t> owned;
+    int wordLen = 0; int maxHits = 0; uint32_t totalMatches = 0; const uint32_t *SO = nullptr; const uint32_t *ROA = nullptr;
+};
+// builds the complete file image {-1, wordLen, maxHits, total} + SO[4^L+1] + ROA[total]
+bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, std::vector<uint32_t> &image, FILE *log);
+bool parseIndex(const uint32_t *img, size_t bytes, IndexFile &ix, std::string &err);
+bool loadIndex(const char *path, IndexFile &ix, std::string &err);
+
+// ---- arguments (reference AlignArgs.c, Main.c) -----------------------------------------------------------
+struct Args {
+    std::string gfileName, xfileName, qfileName = "stdin", ofileName; bool haveG = false, haveX = false, haveO = false;
+    int numThreads = 1; bool fastq = false;
+    int wordLen = 15, skipDist = 1, maxHits = -1;
+    int maxGap = 50, maxIntron = -1, minMatch = 25; float minIdentity = 0.9f; int bandWidth = 5, maxDesert = 50, minRawScore = -1, minNonOverlap = -1;
+    bool affineGapScoring = true; int GOCost = 5, GECost = 2, RCost = 3, MScore = 1, XCutoff = 25; int minExtLength = 0;
+    bool OQC = true; int OQCMinNonOverlap = -1, BPCost = 5, maxBPLog = 5; bool FBS = false; float FBS_PSLength = 0.90f, FBS_PSScore = 0.90f;
+    int maxQueryLength = 32000; bool verbose = false, outputBlast8 = false, outputSAM = true, hardClip = true;
+    // extensions of this implementation (not in the reference CLI)
+    int batchReads = 4096; int device = 0; int gpus = 1;
+    bool query = false, index = true;
+};
+void postProcessArgs(Args &a, bool query);                                  // AlignArgs.c:108-169
+// returns 0 to continue, >0 exit code+1 to stop (usage / error)
+int  parseArgs(int argc, char **argv, Args &a);                            // Main.c:187-565
+void paramsFromArgs(const Args &a, ygpu_params &p);
+std::string samHeader(const Args &a, const Genome &g);                      // AlignOutput.c:30-111
+
+// ---- reads (reference Query.c:63-228, QueryState.c:172-187) ---------------------------------------------
+struct Read {
+    std::string id; std::string fwd, rev; std::vector<uint8_t> fwdCodes, revCodes; std::string qual;
+    int len() const { return (int)fwd.size(); }
+};
+struct ReadReader {
+    FILE *f = nullptr; bool fastq = false; int maxQueryLength = 32000; int wordLen = 15; bool ownFile = false;
+    bool open(const char *path, std::string &err);       // peeks '>' / '@' (Query.c:63-74)
+    bool next(Read &r);                                   // readNextQuery; false at EOF
+    void close();
+};
+void seedFromRead(const Read &r, RandState &rs);          // generateRandomSeed
+
+// ---- post filter + output (reference GraphPath.cpp:294-1175, AlignOutput.c:115-321) ---------------------
+struct OutClump {                                        // one clump as it reaches printClump
+    ygpu_clump c; const uint32_t *ops;                   // ops[0..c.n_ops)
+    uint8_t status; uint8_t mapQuality = 255; uint16_t numSecondaries = 0, matchedPrimary = 0;
+};
+// clumps: QS->clumps head->tail after postProcessClumps.  Result: print order.  primaryCount = QS->primaryCount.
+void postFilter(const Args &a, const Genome &g, const Read &r, const ygpu_clump *clumps, uint32_t n, const uint32_t *ops,
+                std::vector<OutClump> &out, int &primaryCount);
+void printClump(const Args &a, const Genome &g, const Read &r, const OutClump &oc, int primaryCount, std::string &out);
+
+// ---- whole-run driver (replacement of processQueryFile, Query.c:551-709) --------------------------------
+int runQueries(Args &a, FILE *log);
+int runIndex(Args &a, FILE *log);
+}  // namespace yaha
