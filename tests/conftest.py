@@ -1,0 +1,68 @@
+"""Shared fixtures.  `-m "not gpu"` runs on the CPU container (oracle vs golden vectors, host logic, C-ABI
+exports); `-m gpu` tests are the parity tests proper and call the HIP path through the C-ABI."""
+import ctypes as C
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+
+
+def _build():
+    lib = os.path.join(ROOT, "yaha_amd", "csrc", "libyaha_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(ROOT, "yaha_amd", "csrc", "yaha")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "yaha_amd", "csrc"), "-j8"])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    sim = os.path.join(ROOT, "tools", "yaha_sim")
+    if not os.path.exists(sim):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", sim, os.path.join(ROOT, "tools", "yaha_sim.cpp")])
+
+
+@pytest.fixture(scope="session")
+def meta():
+    return json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+@pytest.fixture(scope="session")
+def work(tmp_path_factory):
+    """Scratch directory holding the unpacked golden inputs and the index built by THIS repo's indexer."""
+    _build()
+    import yaha_amd as ya
+    d = str(tmp_path_factory.mktemp("yaha"))
+    for f in os.listdir(GOLDEN):
+        if f.endswith(".gz") and not f.endswith(".out.gz"):
+            with gzip.open(os.path.join(GOLDEN, f), "rb") as g, open(os.path.join(d, f[:-3]), "wb") as o:
+                shutil.copyfileobj(g, o)
+    ya.build_index(["-g", os.path.join(d, "genome_small.fa"), "-L", "11"])
+    return d
+
+
+@pytest.fixture(scope="session")
+def index11(work):
+    return os.path.join(work, "genome_small.X11_01_65525S")
+
+
+def golden_lines(name):
+    with gzip.open(os.path.join(GOLDEN, name + ".out.gz"), "rb") as g:
+        return g.read().decode().split("\n")
+
+
+def strip_pg(text):
+    return [l for l in text.split("\n") if not l.startswith("@PG")]
+
+
+def oflag_args(oflag):
+    return [oflag, "stdout"]

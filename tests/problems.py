@@ -1,0 +1,44 @@
+"""Helpers that derive realistic DP problems (gap fills between chained fragments, X-drop extensions from clump
+ends) from the oracle's chain stage, used by the CPU lane-model test and the GPU dp_batch parity test."""
+import ctypes as C
+import random
+
+import numpy as np
+
+import oracle
+import yaha_amd as ya
+
+COMP = [2, 3, 0, 1, 4, 12, 7, 6, 9, 8, 15, 11, 5, 13, 14, 10]
+
+
+def batch_arrays(s, b):
+    nb = s.index.n_base_bytes
+    bases = np.ctypeslib.as_array(C.cast(s.index.bases, C.POINTER(C.c_uint8)), shape=(nb,))
+    offs = np.ctypeslib.as_array(C.cast(b.offsets, C.POINTER(C.c_uint64)), shape=(b.n_reads + 1,))
+    codes = np.ctypeslib.as_array(C.cast(b.codes, C.POINTER(C.c_uint8)), shape=(int(offs[-1]),))
+    return bases, offs, codes
+
+
+def dp_problems_from_chain(s, b, limit=2000, seed=1):
+    P = s.params
+    offs = np.ctypeslib.as_array(C.cast(b.offsets, C.POINTER(C.c_uint64)), shape=(b.n_reads + 1,))
+    probs = []
+    for rs, frags in oracle.chain(s.index, P, b):
+        read, strand = rs >> 1, rs & 1
+        qlen = int(offs[read + 1] - offs[read])
+        for a, bb in zip(frags, frags[1:]):
+            qg = max(bb[1] - a[2] - 1, 0)
+            ero = a[0] + a[3] - 1
+            rg = max(bb[0] - ero - 1, 0)
+            if qg > 0 and rg > 0 and not (qg == 1 and rg == 1):
+                mode = ya.DP_BANDED if abs(qg - rg) + 2 * P.bandWidth + 1 < rg else ya.DP_FULL
+                probs.append(ya.DPProblem(read, strand, mode, a[2] + 1, qg, rg, ero + 1))
+        f0, fn = frags[0], frags[-1]
+        if f0[1] >= 5 and f0[0] >= 1:
+            probs.append(ya.DPProblem(read, strand, ya.DP_EXT_REV, f0[1] - 1, min(f0[1], f0[0]), 0, f0[0] - 1))
+        ero = fn[0] + fn[3] - 1
+        fl = min(qlen - 1 - fn[2], s.index.maxROff - ero)
+        if fl >= 5:
+            probs.append(ya.DPProblem(read, strand, ya.DP_EXT_FWD, fn[2] + 1, fl, 0, ero + 1))
+    random.Random(seed).shuffle(probs)
+    return probs[:limit]

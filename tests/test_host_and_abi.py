@@ -1,0 +1,66 @@
+"""CPU tier: host logic and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import yaha_amd as ya
+from conftest import ROOT
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    hdr = open(os.path.join(ROOT, "include", "yaha_hip.h")).read()
+    declared = set(re.findall(r"\b(ygpu_[a-z_]+|yaha_[a-z_]+)\s*\(", hdr))
+    declared -= {"ygpu_ctx", "yaha_session"}
+    assert declared, "no declarations parsed"
+    L = ya.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libyaha_hip.so does not export " + name
+    assert set(ya.EXPORTS) == declared
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(ya.Clump) == 32 and C.sizeof(ya.Fragment) == 16 and C.sizeof(ya.DPProblem) == 16 and C.sizeof(ya.DPResult) == 16
+    assert C.sizeof(ya.Params) == 64 and C.sizeof(ya.Counters) == 128
+
+
+def test_derived_parameters_follow_the_reference_defaults(work, index11):
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
+        p = s.params
+        assert (p.wordLen, p.maxHits, p.bandWidth, p.maxGap, p.maxIntron, p.minMatch, p.maxDesert) == (11, 650, 5, 50, 50, 25, 50)
+        assert (p.minNonOverlap, p.minRawScore, p.minExtLength, p.GOCost, p.GECost, p.RCost, p.MScore, p.XCutoff) == (25, 25, 5, 5, 2, 3, 1, 25)
+        assert abs(p.minIdentity - 0.9) < 1e-6 and p.minIdentity != 0.9      # float, not double
+        assert "@HD\tVN:1.0" in s.header() and "@SQ\tSN:chr1" in s.header()
+
+
+def test_reader_rules(work, index11, tmp_path):
+    q = tmp_path / "odd.fa"
+    q.write_text(">first read with spaces\nACGTACGTACGTACGTACGTAC\nGTACGTNNACGT\n>tooshort\nACGT\n>" + "x" * 250 + "\nACGTACGTACGTACGTACGTACGTACGT\n>last\nacgtacgtacgtacgtacgtacgt")
+    with ya.Session(["-x", index11, "-q", str(q)]) as s:
+        b = s.next_batch(100)
+        assert b.n_reads == 3                      # the 4-base read is skipped (Query.c:207-211)
+        offs = C.cast(b.offsets, C.POINTER(C.c_uint64))
+        assert [offs[i + 1] - offs[i] for i in range(3)] == [34, 28, 24]
+        codes = C.cast(b.codes, C.POINTER(C.c_uint8))
+        assert [codes[i] for i in range(4)] == [2, 1, 3, 0] and codes[28] == 4      # A C G T ; N
+
+
+def test_context_creation_fails_loudly_without_a_gpu_or_with_bad_params(work, index11):
+    import torch
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
+        if not torch.cuda.is_available():
+            with pytest.raises(RuntimeError):
+                ya.Context(s.index, s.params)
+        p = ya.Params.from_buffer_copy(s.params)
+        p.bandWidth = 40
+        with pytest.raises(RuntimeError):
+            ya.Context(s.index, p)
+
+
+def test_cli_index_then_usage(work, tmp_path):
+    import subprocess
+    r = subprocess.run([ya.CLI_PATH], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"Usage" in r.stderr
+    r = subprocess.run([ya.CLI_PATH, "-x", "nonexistent.X11_01_65525S", "-q", "none.fa"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0

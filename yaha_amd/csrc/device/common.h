@@ -1,0 +1,79 @@
+// common.h -- shared device-side definitions for the gfx950 hot path (wave64, CDNA4).
+// Everything here is written for 64-wide wavefronts; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../../include/yaha_hip.h"
+
+#define YD_WORST   (-(0x7fffff00))          // reference DPWorstScore, SW.cpp:356
+#define YD_BIAS    (1 << 24)                 // keeps (score + BIAS) positive and below 2^25 (checked in ygpu_init)
+#define YD_WAVE    64
+
+enum { stReversed = 0x01, stAligned = 0x04, stScored = 0x08, stSplit = 0x10 };   // FragsClumps.inl:235-240
+enum { OP_M = 0, OP_R = 1, OP_D = 2, OP_I = 3 };
+
+struct DevParams {
+    int wordLen, maxHits, bandWidth, maxGap, maxIntron, minMatch, maxDesert, minNonOverlap, minRawScore, minExtLength;
+    int GO, GE, RC, MS, X; float minIdentity;
+    uint32_t maxROff, totalMatches;
+};
+
+struct DevFrag { uint32_t sro; uint16_t sqo, eqo; uint16_t refLen; uint16_t used; uint32_t rs; };   // = ygpu_fragment (16 B)
+
+// per-batch device view handed to the kernels
+struct DevBatch {
+    const uint8_t  *fwd, *rev;     // 4-bit codes, one per byte, both strands, same offsets
+    const uint32_t *readOff;       // nReads + 1
+    uint32_t nReads;
+};
+
+struct DevCounters { unsigned long long v[16]; };   // same order as ygpu_counters
+enum { C_KMER = 0, C_HITS, C_FRAGS, C_REGIONS, C_FORMED, C_SCORED, C_EXT_CALLS, C_EXT_ROWS, C_EXT_CELLS, C_GAP_CALLS, C_GAP_ROWS, C_GAP_CELLS, C_PERFECT, C_TOUCHED, C_OPS, C_SPLITS };
+
+// ---- wave64 helpers ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int  laneId() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int  uni(int v) { return __builtin_amdgcn_readfirstlane(v); }            // make a wave-uniform value scalar
+__device__ __forceinline__ unsigned uniU(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int  bcast(int v, int srcLane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(srcLane)); }
+
+// DPP row/wave shifts would be cheaper; these use ds_bpermute (any distance, full wave).  See DESIGN.md (tuning list).
+__device__ __forceinline__ unsigned waveMaxU(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { unsigned t = (unsigned)__shfl_xor((int)v, d, 64); v = v > t ? v : t; }
+    return v;
+}
+__device__ __forceinline__ int waveMaxI(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { int t = __shfl_xor(v, d, 64); v = v > t ? v : t; }
+    return v;
+}
+__device__ __forceinline__ int waveSumI(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// exclusive prefix max over lanes (identity 0)
+__device__ __forceinline__ unsigned waveExclMaxU(unsigned v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned t = (unsigned)__shfl_up((int)v, d, 64); if (lane >= d) v = v > t ? v : t; }
+    unsigned e = (unsigned)__shfl_up((int)v, 1, 64);
+    return lane == 0 ? 0u : e;
+}
+
+__device__ __forceinline__ uint8_t ref4(const uint8_t *bases, uint32_t off)          // getFrom4Code, Math.c:180-188
+{ uint8_t b = bases[off >> 1]; return (off & 1) ? (uint8_t)(b & 0xF) : (uint8_t)(b >> 4); }
+
+__device__ __forceinline__ int      fragQLen(int sqo, int eqo) { return 1 + eqo - sqo; }
+__device__ __forceinline__ uint32_t absDiffU(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+__device__ __forceinline__ uint32_t gapI(int lo, int hi) { return hi > lo ? (uint32_t)(hi - lo) - 1u : 0u; }      // calcGap, FragsClumps.inl:158
+__device__ __forceinline__ uint32_t gapU(uint32_t lo, uint32_t hi) { return hi > lo ? (hi - lo) - 1u : 0u; }
+__device__ __forceinline__ uint32_t ovlI(int lo, int hi) { return lo >= hi ? (uint32_t)(lo - hi) + 1u : 0u; }     // calcOverlap :159
+__device__ __forceinline__ uint32_t ovlU(uint32_t lo, uint32_t hi) { return lo >= hi ? (lo - hi) + 1u : 0u; }
+
+__device__ __forceinline__ uint32_t opMake(int code, int len) { return ((uint32_t)code << 16) | ((uint32_t)len & 0xFFFFu); }  // code = OP_*
+__device__ __forceinline__ int      opCode(uint32_t o) { return (int)(o >> 16); }
+__device__ __forceinline__ int      opLen(uint32_t o) { return (int)(o & 0xFFFFu); }

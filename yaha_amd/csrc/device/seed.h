@@ -1,0 +1,152 @@
+// seed.h -- stages A1 + A2 on the device: k-mer hashing of both strands, hash-table lookup, hit enumeration,
+// (read, strand, diagonal, query offset) sort and coalescing into fragments (reference Query.c:341-412,
+// QueryMatch.c:52-121, QueryHeap.inl:70-134), then diagonal-region boundaries (QueryMatch.c:146-158).
+// The reference merges the per-k-mer hit lists through a binary heap; its output is just the sorted multiset of
+// (diag << 32 | qo) keys, so a device radix sort of the batch-wide keys (read*2+strand in the top bits) gives the
+// identical fragment array.  HBM-bound integer/byte work: coalesced streams + random 8-byte table probes.
+#pragma once
+#include "common.h"
+
+__constant__ unsigned char kComp4[16] = {2, 3, 0, 1, 4, 12, 7, 6, 9, 8, 15, 11, 5, 13, 14, 10};   // fourBitCompCodes, Math.c:156
+
+// reverse-complement codes (Query.c:161-167): one workgroup per read
+__global__ void k_revcomp(const uint8_t *fwd, uint8_t *rev, const uint32_t *readOff, uint32_t nReads)
+{
+    const uint32_t r = blockIdx.x; if (r >= nReads) return;
+    const uint32_t o = readOff[r], n = readOff[r + 1] - o;
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) rev[o + k] = kComp4[fwd[o + n - 1 - k] & 0xF];
+}
+
+// A1: one workgroup per (read, strand); thread per k-mer start.  posS/posC are indexed by kmerOff[rs] + i.
+__global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const uint32_t *ROA, const uint32_t *kmerOff,
+                              uint32_t *posS, uint32_t *posC, uint32_t *posRsI, DevCounters *ctr)
+{
+    const uint32_t rs = blockIdx.x; const uint32_t read = rs >> 1;
+    const uint32_t o = B.readOff[read]; const int qlen = (int)(B.readOff[read + 1] - o);
+    const int L = P.wordLen, nPos = qlen - L + 1;
+    if (nPos <= 0) return;
+    const uint8_t *codes = ((rs & 1u) ? B.rev : B.fwd) + o;
+    const uint32_t base = kmerOff[rs];
+    unsigned lookups = 0;
+    for (int i = threadIdx.x; i < nPos; i += blockDim.x) {
+        uint32_t h = 0; bool bad = false;
+        for (int k = 0; k < L; k++) { uint32_t c = codes[i + k]; bad |= c > 3; h = (h << 2) | (c & 3u); }
+        uint32_t s = 0, cnt = 0;
+        if (!bad) {                                                               // Query.c:391-405
+            s = SO[h]; cnt = SO[h + 1] - s; lookups++;
+            if (cnt > (uint32_t)P.maxHits) cnt = 0;
+            if (cnt) {                                                            // QueryMatch.c:56-69: wrapping diagonals / read past the list
+                uint32_t w = 0;
+                while (s + w < P.totalMatches && ROA[s + w] < (uint32_t)i) w++;
+                uint32_t eff = (w < cnt) ? cnt : w + 1;
+                if (s + eff > P.totalMatches) eff = P.totalMatches - s;
+                cnt = eff;
+            }
+        }
+        posS[base + i] = s; posC[base + i] = cnt; posRsI[base + i] = (rs << 15) | (uint32_t)i;
+    }
+    if (lookups) atomicAdd(&ctr->v[C_KMER], (unsigned long long)lookups);
+}
+
+// A2a: thread per hit -> 64-bit key  rs(17) | diag(32) | qo(15)
+__global__ void k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nHits) return;
+    uint32_t lo = 0, hi = nKmers;                                                 // largest g with hitOff[g] <= t
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= t) lo = mid; else hi = mid; }
+    const uint32_t g = lo, j = t - hitOff[g], rsi = posRsI[g];
+    const uint32_t i = rsi & 0x7FFFu, rs = rsi >> 15;
+    const uint32_t roff = ROA[posS[g] + j];
+    keys[t] = ((unsigned long long)rs << 47) | ((unsigned long long)(uint32_t)(roff - i) << 15) | (unsigned long long)i;
+}
+
+// A2b: fragment heads.  A hit starts a new fragment when (read,strand) or diagonal changes or the k-mer neither overlaps
+// nor abuts the previous one (QueryMatch.c:99).
+__global__ void k_frag_heads(const unsigned long long *keys, uint32_t nHits, int wordLen, uint32_t *isHead)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nHits) return;
+    uint32_t head = 1;
+    if (t > 0) {
+        const unsigned long long a = keys[t - 1], b = keys[t];
+        if ((a >> 15) == (b >> 15)) { const uint32_t qa = (uint32_t)(a & 0x7FFFu), qb = (uint32_t)(b & 0x7FFFu); head = qb > qa + (uint32_t)wordLen; }
+    }
+    isHead[t] = head;
+}
+// A2c: one thread per hit; run starts write the fragment start, run ends write its end (QueryMatch.c:101-118)
+__global__ void k_frag_build(const unsigned long long *keys, const uint32_t *isHead, const uint32_t *fragIdx /* exclusive scan of isHead */,
+                             uint32_t nHits, int wordLen, DevFrag *frags)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nHits) return;
+    const unsigned long long k = keys[t];
+    const uint32_t qo = (uint32_t)(k & 0x7FFFu), diag = (uint32_t)(k >> 15), rs = (uint32_t)(k >> 47);
+    const uint32_t f = fragIdx[t] + isHead[t] - 1u;                               // index of the fragment this hit belongs to
+    if (isHead[t]) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
+    const bool last = (t + 1 == nHits) || isHead[t + 1];
+    if (last) frags[f].eqo = (uint16_t)(qo + (uint32_t)wordLen - 1u);
+}
+__global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nFrags) return;
+    frags[f].refLen = (uint16_t)(1 + (int)frags[f].eqo - (int)frags[f].sqo);      // setRefLen, FragsClumps.inl:44-47
+}
+
+// A3: region heads: consecutive fragments of one (read,strand) whose diagonals differ by <= maxGap (QueryMatch.c:146-158)
+__global__ void k_region_heads(const DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *isHead)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nFrags) return;
+    uint32_t head = 1;
+    if (f > 0) {
+        const DevFrag a = frags[f - 1], b = frags[f];
+        if (a.rs == b.rs) { const uint32_t da = a.sro - (uint32_t)a.sqo, db = b.sro - (uint32_t)b.sqo; head = absDiffU(da, db) > (uint32_t)maxGap; }
+    }
+    isHead[f] = head;
+}
+// regStart[r] = first fragment of region r (regIdx = exclusive scan of isHead); regStart[nRegions] = nFrags set by host
+__global__ void k_region_starts(const uint32_t *isHead, const uint32_t *regIdx, uint32_t nFrags, uint32_t *regStart)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nFrags) return;
+    if (isHead[f]) regStart[regIdx[f]] = f;
+}
+// multi-fragment region list + largest region
+__global__ void k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nRegions) return;
+    const uint32_t n = regStart[r + 1] - regStart[r];
+    if (n >= 2) { unsigned p = atomicAdd(nMulti, 1u); multiList[p] = r; atomicMax(maxN, n); }
+}
+// order[base[region] + seq] = clump index  (rank of a root clump = creation order)
+__global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, const uint32_t *regionBase, uint32_t *order)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nClumps) return;
+    order[regionBase[clumps[c].region] + clumps[c].seq] = c;
+}
+// final layout: clump ci of root r with push number p goes to rootBase[r] + (pushCount[r] - 1 - p)
+__global__ void k_out_layout(const uint32_t *outRoot, const uint32_t *outPush, const uint32_t *rootBase, const unsigned int *rootPushCount, uint32_t nOut, uint32_t *dstIdx)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nOut) return;
+    const uint32_t r = outRoot[c];
+    dstIdx[c] = rootBase[r] + (rootPushCount[r] - 1u - outPush[c]);
+}
+__global__ void k_out_scatter(const ygpu_clump *src, const uint32_t *dstIdx, uint32_t nOut, ygpu_clump *dst)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nOut) return;
+    dst[dstIdx[c]] = src[c];
+}
+// clumps per read: root r belongs to read (clumps[order[r]].rs >> 1)
+__global__ void k_read_counts(const ChainClumpRec *clumps, const uint32_t *order, const unsigned int *rootPushCount, uint32_t nRoots, unsigned int *readCount)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nRoots) return;
+    const unsigned n = rootPushCount[r];
+    if (n) atomicAdd(&readCount[clumps[order[r]].rs >> 1], n);
+}

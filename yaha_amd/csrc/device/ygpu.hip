@@ -1,14 +1,436 @@
-// placeholder -- replaced by the real device implementation
-#include "../../../include/yaha_hip.h"
-extern "C" {
-int  ygpu_init(int, const ygpu_index_view *, const ygpu_params *, ygpu_ctx **out) { *out = nullptr; return YGPU_ENODEV; }
-void ygpu_destroy(ygpu_ctx *) {}
-const char *ygpu_last_error(const ygpu_ctx *) { return "not implemented"; }
-int  ygpu_upload(ygpu_ctx *, const ygpu_read_batch *) { return YGPU_ENODEV; }
-int  ygpu_run(ygpu_ctx *) { return YGPU_ENODEV; }
-int  ygpu_collect(ygpu_ctx *, ygpu_result_batch *) { return YGPU_ENODEV; }
-int  ygpu_last_timing(ygpu_ctx *, float *, int *, const char *const **, const float **) { return YGPU_ENODEV; }
-int  ygpu_seed_join(ygpu_ctx *, const ygpu_fragment **, uint64_t *) { return YGPU_ENODEV; }
-int  ygpu_chain(ygpu_ctx *, const ygpu_fragment **, const uint32_t **, const uint32_t **, uint64_t *) { return YGPU_ENODEV; }
-int  ygpu_dp_batch(ygpu_ctx *, const ygpu_dp_problem *, uint32_t, const ygpu_dp_result **, const uint32_t **, uint64_t *) { return YGPU_ENODEV; }
+// ygpu.hip -- device context, stage orchestration and the C-ABI of include/yaha_hip.h.
+//
+// HBM layout per context (one per GPU; reads shard across GPUs, index replicated, no collective):
+//   index   : packed 4-bit reference, startingOffs[4^L+1], ROA[totalMatches]           (resident for the whole run)
+//   batch   : forward + reverse-complement codes (1 B/base), read offsets, k-mer offsets
+//   stage arenas, grown on demand and reused across batches:
+//     A1  posS/posC/posRsI per k-mer  -> exclusive scan -> hit offsets
+//     A2  64-bit hit keys (double buffer for the radix sort) -> fragment array (16 B each)
+//     A3  region starts, multi-fragment region list
+//     A4  clump records + clump fragment lists (atomic arenas), per-region counts -> creation-order ranks
+//     A5-8 per-wave scratch (trace strip, DP temp list, frame stack with edit-list buffers), output arenas
+//   results : clump records in QS->clumps order, ops arena, clump_start per read
+// Every stage is a handful of launches on one stream; sizes that the next stage needs cross the PCIe as single words.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <algorithm>
+#include "chain.h"
+#include "seed.h"
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
+
+namespace {
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes, bool keep = false, hipStream_t st = 0)
+    {
+        if (bytes <= cap) return 0;
+        size_t ncap = bytes + bytes / 4 + 256; void *np = nullptr;
+        if (hipMalloc(&np, ncap) != hipSuccess) return -1;
+        if (keep && p && cap) { hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st); hipStreamSynchronize(st); }
+        if (p) hipFree(p);
+        p = np; cap = ncap; return 0;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_N = 16 };
+enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_N };
+const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout"};
+}  // namespace
+
+struct ygpu_ctx {
+    int device = 0; hipStream_t stream = nullptr; DevParams P{}; std::string err; int nCU = 256;
+    DevBuf dBases, dSO, dROA;
+    // batch
+    uint32_t nReads = 0; int maxQ = 0; uint64_t totalBases = 0; uint32_t nKmers = 0;
+    std::vector<uint32_t> hReadOff, hKmerOff;
+    DevBuf dFwd, dRev, dReadOff, dKmerOff;
+    // arenas
+    DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, regionCount, regionBase;
+    DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
+    DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
+    // stage state
+    uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, maxN = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
+    int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
+    // host results
+    std::vector<uint32_t> hClumpStart, hOps, hClumpFragStart, hClumpRS, hDpOps; std::vector<ygpu_clump> hClumps; std::vector<ygpu_fragment> hFrags, hClumpFrags;
+    std::vector<ygpu_dp_result> hDpRes; ygpu_counters hCounters{};
+    // timing
+    hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N];
+};
+
+static DevBatch devBatch(ygpu_ctx *c) { DevBatch b; b.fwd = c->dFwd.as<uint8_t>(); b.rev = c->dRev.as<uint8_t>(); b.readOff = c->dReadOff.as<uint32_t>(); b.nReads = c->nReads; return b; }
+static inline unsigned gridFor(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+static int cubScan(ygpu_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    size_t bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
+    if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp.p, bytes, in, out, (int)n, ctx->stream));
+    return 0;
 }
+#define ENSURE(buf, bytes) do { if ((buf).ensure(bytes)) { ctx->err = "hipMalloc failed for " #buf; return YGPU_ENOMEM; } } while (0)
+#define EV0(t) hipEventRecord(ctx->ev[t][0], ctx->stream)
+#define EV1(t) hipEventRecord(ctx->ev[t][1], ctx->stream)
+
+static int fetchU32(ygpu_ctx *ctx, const void *dptr, uint32_t *out, size_t n = 1)
+{ HIPCHK(hipMemcpyAsync(out, dptr, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
+
+// ---- A1 + A2 (+ fragment array) --------------------------------------------------------------------------------
+static int stageSeed(ygpu_ctx *ctx)
+{
+    const uint32_t n = ctx->nReads, K = ctx->nKmers; DevBatch B = devBatch(ctx);
+    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 4 * CNT_N, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->ctr.p, 0, sizeof(DevCounters), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
+    ctx->nHits = ctx->nFrags = ctx->nRegions = ctx->nMulti = ctx->maxN = ctx->nClumps = ctx->nClumpFrags = ctx->nOut = ctx->nOutOps = 0;
+    for (int t = 0; t < T_N; t++) ctx->ms[t] = 0;
+    if (K == 0 || n == 0) return 0;
+    EV0(T_SEED);
+    ENSURE(ctx->posS, 4ull * (K + 1)); ENSURE(ctx->posC, 4ull * (K + 1)); ENSURE(ctx->posRsI, 4ull * (K + 1)); ENSURE(ctx->hitOff, 4ull * (K + 1));
+    HIPCHK(hipMemsetAsync(ctx->posC.p, 0, 4ull * (K + 1), ctx->stream));
+    hipLaunchKernelGGL(k_kmer_lookup, dim3(2 * n), dim3(128), 0, ctx->stream, ctx->P, B, ctx->dSO.as<uint32_t>(), ctx->dROA.as<uint32_t>(), ctx->dKmerOff.as<uint32_t>(),
+                       ctx->posS.as<uint32_t>(), ctx->posC.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), ctx->ctr.as<DevCounters>());
+    int rc = cubScan(ctx, ctx->posC.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), K + 1); if (rc) return rc;
+    EV1(T_SEED);
+    uint32_t H = 0; rc = fetchU32(ctx, ctx->hitOff.as<uint32_t>() + K, &H); if (rc) return rc;
+    ctx->nHits = H;
+    if (H == 0) return 0;
+    if (H > 0x7FFFFFF0u) { ctx->err = "too many seed hits in one batch; use a smaller batch"; return YGPU_EOVERFLOW; }
+    EV0(T_SORT);
+    ENSURE(ctx->keysA, 8ull * H); ENSURE(ctx->keysB, 8ull * H);
+    hipLaunchKernelGGL(k_expand_hits, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->dROA.as<uint32_t>(), ctx->posS.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), K, H, ctx->keysA.as<unsigned long long>());
+    {
+        int rsBits = 1; while ((1u << rsBits) < 2 * n) rsBits++;
+        size_t bytes = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 0, 47 + rsBits, ctx->stream));
+        if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(ctx->cubTemp.p, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 0, 47 + rsBits, ctx->stream));
+    }
+    EV1(T_SORT);
+    EV0(T_FRAGS);
+    ENSURE(ctx->isHead, 4ull * (H + 1)); ENSURE(ctx->scanOut, 4ull * (H + 1));
+    HIPCHK(hipMemsetAsync((uint32_t *)ctx->isHead.p + H, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_frag_heads, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, ctx->isHead.as<uint32_t>());
+    rc = cubScan(ctx, ctx->isHead.as<uint32_t>(), ctx->scanOut.as<uint32_t>(), H + 1); if (rc) return rc;
+    uint32_t F = 0; rc = fetchU32(ctx, ctx->scanOut.as<uint32_t>() + H, &F); if (rc) return rc;
+    ctx->nFrags = F;
+    ENSURE(ctx->frags, 16ull * (F + 1));
+    return 0;
+}
+static int buildFrags(ygpu_ctx *ctx)       // (re)creates the fragment array from the sorted keys: the chain stage trims it in place
+{
+    const uint32_t H = ctx->nHits, F = ctx->nFrags;
+    if (!H) return 0;
+    hipLaunchKernelGGL(k_frag_build, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), ctx->isHead.as<uint32_t>(), ctx->scanOut.as<uint32_t>(), H, ctx->P.wordLen, ctx->frags.as<DevFrag>());
+    hipLaunchKernelGGL(k_frag_finish, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F);
+    return 0;
+}
+
+// ---- A3 + A4 ------------------------------------------------------------------------------------------------------
+static int stageChain(ygpu_ctx *ctx)
+{
+    const uint32_t F = ctx->nFrags; DevBatch B = devBatch(ctx);
+    if (!F) return 0;
+    int rc;
+    // region boundaries (uses a second head/scan pair sized by F; the hit-level pair is still needed by buildFrags on a retry)
+    ENSURE(ctx->regStart, 4ull * (F + 2)); ENSURE(ctx->multiList, 4ull * (F + 1)); ENSURE(ctx->regionCount, 4ull * (F + 2)); ENSURE(ctx->regionBase, 4ull * (F + 2));
+    DevBuf &rHead = ctx->rootPush, &rScan = ctx->rootBase;           // borrowed as temporaries (not yet in use at this point)
+    ENSURE(rHead, 4ull * (F + 1)); ENSURE(rScan, 4ull * (F + 1));
+    HIPCHK(hipMemsetAsync((uint32_t *)rHead.p + F, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_region_heads, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, rHead.as<uint32_t>());
+    rc = cubScan(ctx, rHead.as<uint32_t>(), rScan.as<uint32_t>(), F + 1); if (rc) return rc;
+    uint32_t R = 0; rc = fetchU32(ctx, rScan.as<uint32_t>() + F, &R); if (rc) return rc;
+    ctx->nRegions = R;
+    hipLaunchKernelGGL(k_region_starts, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, rHead.as<uint32_t>(), rScan.as<uint32_t>(), F, ctx->regStart.as<uint32_t>());
+    HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *cnt = ctx->counters.as<uint32_t>();
+    HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_region_classify, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN);
+    uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NMULTI, two, 2); if (rc) return rc;
+    ctx->nMulti = two[0]; ctx->maxN = two[1];
+    EV1(T_FRAGS);
+
+    EV0(T_CHAIN);
+    uint32_t clumpCap = F + R / 2 + 1024, fragCap = 2 * F + 1024;
+    const unsigned waves = (unsigned)std::min<uint64_t>(std::max<uint32_t>(ctx->nMulti, 1u), (uint64_t)ctx->nCU * 8);
+    for (int attempt = 0;; attempt++) {
+        ENSURE(ctx->clumps, sizeof(ChainClumpRec) * (uint64_t)clumpCap); ENSURE(ctx->clumpFrags, 16ull * fragCap);
+        const int maxN = (int)std::max<uint32_t>(ctx->maxN, 2u);
+        const size_t per = chainScratchBytes(maxN, ctx->maxQ);
+        ENSURE(ctx->scratchChain, per * waves);
+        HIPCHK(hipMemsetAsync(cnt + CNT_CLUMPS, 0, 12, ctx->stream));          // clumps, cfrags, qchain
+        HIPCHK(hipMemsetAsync(ctx->regionCount.p, 0, 4ull * (R + 1), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
+        ChainArgs A; A.P = ctx->P; A.B = B; A.frags = ctx->frags.as<DevFrag>(); A.regStart = ctx->regStart.as<uint32_t>(); A.nRegions = R;
+        A.multiList = ctx->multiList.as<uint32_t>(); A.nMulti = ctx->nMulti; A.queueHead = cnt + CNT_QCHAIN;
+        A.scratch = ctx->scratchChain.as<uint8_t>(); A.scratchPerWave = per; A.maxN = maxN; A.maxQ = ctx->maxQ;
+        A.clumps = ctx->clumps.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.counts = cnt + CNT_CLUMPS; A.clumpCap = clumpCap; A.fragCap = fragCap;
+        A.regionClumpCount = ctx->regionCount.as<uint32_t>(); A.errFlag = ctx->errFlag.as<int>(); A.ctr = ctx->ctr.as<DevCounters>();
+        hipLaunchKernelGGL(k_regions_single, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, A);
+        if (ctx->nMulti) hipLaunchKernelGGL(k_chain, dim3(waves), dim3(64), 0, ctx->stream, A);
+        uint32_t got[2]; rc = fetchU32(ctx, cnt + CNT_CLUMPS, got, 2); if (rc) return rc;
+        uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+        if (ef == 0) { ctx->nClumps = got[0]; ctx->nClumpFrags = got[1]; break; }
+        if (attempt >= 6) { ctx->err = "chain stage: arena overflow persists"; return YGPU_EOVERFLOW; }
+        clumpCap *= 2; fragCap *= 2;                                           // grow and redo: the fragment array was modified in place
+        rc = buildFrags(ctx); if (rc) return rc;
+    }
+    // creation-order rank of every root clump
+    rc = cubScan(ctx, ctx->regionCount.as<uint32_t>(), ctx->regionBase.as<uint32_t>(), R + 1); if (rc) return rc;
+    ENSURE(ctx->order, 4ull * (ctx->nClumps + 1));
+    if (ctx->nClumps) hipLaunchKernelGGL(k_clump_order, dim3(gridFor(ctx->nClumps, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->nClumps, ctx->regionBase.as<uint32_t>(), ctx->order.as<uint32_t>());
+    EV1(T_CHAIN);
+    return 0;
+}
+
+static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap)
+{ front = 2 * ctx->maxQ + 8 * ctx->P.bandWidth + 64; listCap = 2 * front + 3 * ctx->maxQ + 1024; genCap = 1024; }
+
+// ---- A5..A8 + layout ---------------------------------------------------------------------------------------------
+static int stageAlign(ygpu_ctx *ctx)
+{
+    const uint32_t n = ctx->nReads, NC = ctx->nClumps; DevBatch B = devBatch(ctx); int rc;
+    uint32_t *cnt = ctx->counters.as<uint32_t>();
+    ENSURE(ctx->readCount, 4ull * (n + 1)); ENSURE(ctx->readStart, 4ull * (n + 1));
+    HIPCHK(hipMemsetAsync(ctx->readCount.p, 0, 4ull * (n + 1), ctx->stream));
+    ctx->nOut = ctx->nOutOps = 0;
+    if (NC) {
+        EV0(T_ALIGN);
+        int listCap, front, genCap; alignDims(ctx, listCap, front, genCap);
+        const size_t per = alignScratchBytes(ctx->maxQ, listCap, genCap);
+        size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
+        uint64_t maxWaves = std::max<uint64_t>(64, (uint64_t)((freeB + ctx->scratchAlign.cap) * 6 / 10) / per);
+        const unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * 8), maxWaves);
+        ENSURE(ctx->scratchAlign, per * waves);
+        ENSURE(ctx->clumpFrags0, 16ull * (ctx->nClumpFrags + 1));
+        HIPCHK(hipMemcpyAsync(ctx->clumpFrags0.p, ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
+        ENSURE(ctx->rootPush, 4ull * (NC + 1)); ENSURE(ctx->rootBase, 4ull * (NC + 1));
+        uint32_t outClumpCap = NC + NC / 2 + 1024; uint32_t outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + ctx->totalBases / 2 + 65536);
+        for (int attempt = 0;; attempt++) {
+            ENSURE(ctx->outClumps, sizeof(ygpu_clump) * (uint64_t)outClumpCap); ENSURE(ctx->outClumps2, sizeof(ygpu_clump) * (uint64_t)outClumpCap);
+            ENSURE(ctx->outOps, 4ull * outOpsCap); ENSURE(ctx->outRoot, 4ull * outClumpCap); ENSURE(ctx->outPush, 4ull * outClumpCap); ENSURE(ctx->dstIdx, 4ull * outClumpCap);
+            HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 12, ctx->stream));      // qalign, outclumps, outops
+            HIPCHK(hipMemsetAsync(ctx->rootPush.p, 0, 4ull * (NC + 1), ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
+            AlignArgs A; A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = B; A.order = ctx->order.as<uint32_t>(); A.nRoots = NC;
+            A.clumps = ctx->clumps.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.queueHead = cnt + CNT_QALIGN;
+            A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per; A.maxQ = ctx->maxQ; A.listCap = listCap; A.front = front; A.genCap = genCap;
+            A.outClumps = ctx->outClumps.as<ygpu_clump>(); A.outOps = ctx->outOps.as<uint32_t>(); A.outRoot = ctx->outRoot.as<uint32_t>(); A.outPush = ctx->outPush.as<uint32_t>();
+            A.outCounts = cnt + CNT_OUTCLUMPS; A.outClumpCap = outClumpCap; A.outOpsCap = outOpsCap; A.rootPushCount = ctx->rootPush.as<unsigned int>();
+            A.ctr = ctx->ctr.as<DevCounters>(); A.errFlag = ctx->errFlag.as<int>();
+            hipLaunchKernelGGL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
+            uint32_t got[2]; rc = fetchU32(ctx, cnt + CNT_OUTCLUMPS, got, 2); if (rc) return rc;
+            uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+            if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
+            if (ef != YERR_OUT || attempt >= 6) { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
+            outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
+            HIPCHK(hipMemcpyAsync(ctx->clumpFrags.p, ctx->clumpFrags0.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_SCORED, 0, 8 * (16 - C_SCORED), ctx->stream));
+        }
+        EV1(T_ALIGN);
+        EV0(T_LAYOUT);
+        rc = cubScan(ctx, ctx->rootPush.as<uint32_t>(), ctx->rootBase.as<uint32_t>(), NC + 1); if (rc) return rc;
+        if (ctx->nOut) {
+            hipLaunchKernelGGL(k_out_layout, dim3(gridFor(ctx->nOut, 256)), dim3(256), 0, ctx->stream, ctx->outRoot.as<uint32_t>(), ctx->outPush.as<uint32_t>(), ctx->rootBase.as<uint32_t>(), ctx->rootPush.as<unsigned int>(), ctx->nOut, ctx->dstIdx.as<uint32_t>());
+            hipLaunchKernelGGL(k_out_scatter, dim3(gridFor(ctx->nOut, 256)), dim3(256), 0, ctx->stream, ctx->outClumps.as<ygpu_clump>(), ctx->dstIdx.as<uint32_t>(), ctx->nOut, ctx->outClumps2.as<ygpu_clump>());
+        }
+        hipLaunchKernelGGL(k_read_counts, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->order.as<uint32_t>(), ctx->rootPush.as<unsigned int>(), NC, ctx->readCount.as<unsigned int>());
+    }
+    rc = cubScan(ctx, ctx->readCount.as<uint32_t>(), ctx->readStart.as<uint32_t>(), n + 1); if (rc) return rc;
+    if (NC) EV1(T_LAYOUT);
+    return 0;
+}
+
+static int runTo(ygpu_ctx *ctx, int stage)
+{
+    int rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->stageDone < 1) { rc = stageSeed(ctx); if (rc) return rc; EV0(T_FRAGS); rc = buildFrags(ctx); if (rc) return rc; if (!ctx->nFrags) EV1(T_FRAGS); ctx->stageDone = 1; }
+    if (stage >= 2 && ctx->stageDone < 2) { if (ctx->nFrags) { rc = stageChain(ctx); if (rc) return rc; } ctx->stageDone = 2; }
+    if (stage >= 3 && ctx->stageDone < 3) { rc = stageAlign(ctx); if (rc) return rc; ctx->stageDone = 3; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" {
+
+int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_ctx **out)
+{
+    *out = nullptr;
+    if (!ix || !p) return YGPU_EINVAL;
+    ygpu_ctx *ctx = new ygpu_ctx; *out = ctx; ctx->device = device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { ctx->err = "no HIP device visible: the hot path needs an MI355X (there is no CPU fallback)"; return YGPU_ENODEV; }
+    if (device < 0 || device >= ndev) { ctx->err = "device index out of range"; return YGPU_ENODEV; }
+    // supported parameter ranges of the wave-parallel DP (dp_wave.h)
+    long big = 32000L * std::max(std::max(p->MScore, p->RCost), p->GECost) + p->GOCost + 128L * p->GECost;
+    if (p->wordLen < 1 || p->wordLen > 15 || ix->wordLen != p->wordLen) { ctx->err = "wordLen must be 1..15 and match the index"; return YGPU_EINVAL; }
+    if (p->bandWidth < 0 || 4 * p->bandWidth + 1 > 64) { ctx->err = "bandWidth > 15 is not supported by the wave-parallel extension kernel"; return YGPU_EINVAL; }
+    if (p->maxGap < 0 || p->maxGap > 16383 || p->maxIntron < 0 || p->maxHits < 0 || p->maxHits > 65525) { ctx->err = "maxGap/maxIntron/maxHits out of range"; return YGPU_EINVAL; }
+    if (p->MScore < 0 || p->RCost < 0 || p->GECost < 0 || p->GOCost < 0 || big >= (1L << 23)) { ctx->err = "scoring parameters out of the supported range"; return YGPU_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreate(&ctx->stream));
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
+    DevParams &P = ctx->P;
+    P.wordLen = p->wordLen; P.maxHits = p->maxHits; P.bandWidth = p->bandWidth; P.maxGap = p->maxGap; P.maxIntron = p->maxIntron; P.minMatch = p->minMatch; P.maxDesert = p->maxDesert;
+    P.minNonOverlap = p->minNonOverlap; P.minRawScore = p->minRawScore; P.minExtLength = p->minExtLength & 0xFF; P.GO = p->GOCost; P.GE = p->GECost; P.RC = p->RCost; P.MS = p->MScore; P.X = p->XCutoff;
+    P.minIdentity = p->minIdentity; P.maxROff = ix->maxROff; P.totalMatches = ix->totalMatches;
+    const uint64_t HT = 1ull << (2 * ix->wordLen);
+    ENSURE(ctx->dBases, ix->n_base_bytes + 64); ENSURE(ctx->dSO, 4 * (HT + 1)); ENSURE(ctx->dROA, 4ull * ix->totalMatches + 64);
+    HIPCHK(hipMemsetAsync(ctx->dBases.p, 0xEE, ctx->dBases.cap, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->dBases.p, ix->bases, ix->n_base_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->dSO.p, ix->startingOffs, 4 * (HT + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->dROA.p, ix->ROA, 4ull * ix->totalMatches, hipMemcpyHostToDevice, ctx->stream));
+    ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void ygpu_destroy(ygpu_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->stream) {
+        hipSetDevice(ctx->device);
+        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->isHead, &ctx->scanOut,
+                         &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
+                         &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
+                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps};
+        for (auto b : all) b->release();
+        for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
+        hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+const char *ygpu_last_error(const ygpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
+{
+    if (!ctx || !ctx->stream || !b) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = b->n_reads;
+    if (n > 65536) { ctx->err = "at most 65536 reads per batch"; return YGPU_EINVAL; }
+    ctx->nReads = n; ctx->stageDone = 0; ctx->hReadOff.assign(n + 1, 0); ctx->hKmerOff.assign(2 * n + 1, 0); ctx->maxQ = 0;
+    const uint64_t base0 = n ? b->offsets[0] : 0;
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t len = b->offsets[i + 1] - b->offsets[i];
+        if (len > 32000) { ctx->err = "read longer than 32000 bases"; return YGPU_EINVAL; }
+        ctx->hReadOff[i + 1] = (uint32_t)(b->offsets[i + 1] - base0);
+        ctx->maxQ = std::max(ctx->maxQ, (int)len);
+        uint32_t np = len >= (uint64_t)ctx->P.wordLen ? (uint32_t)(len - ctx->P.wordLen + 1) : 0;
+        ctx->hKmerOff[2 * i] = k; k += np; ctx->hKmerOff[2 * i + 1] = k; k += np;
+    }
+    ctx->hKmerOff[2 * n] = k; ctx->nKmers = k; ctx->totalBases = n ? b->offsets[n] - base0 : 0;
+    if (ctx->totalBases > 0x7FFFFFF0ull) { ctx->err = "batch larger than 2 Gbases"; return YGPU_EINVAL; }
+    ENSURE(ctx->dFwd, ctx->totalBases + 64); ENSURE(ctx->dRev, ctx->totalBases + 64); ENSURE(ctx->dReadOff, 4ull * (n + 1)); ENSURE(ctx->dKmerOff, 4ull * (2 * n + 1));
+    if (n) {
+        HIPCHK(hipMemcpyAsync(ctx->dFwd.p, b->codes + base0, ctx->totalBases, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->dReadOff.p, ctx->hReadOff.data(), 4ull * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->dKmerOff.p, ctx->hKmerOff.data(), 4ull * (2 * n + 1), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_revcomp, dim3(n), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->dReadOff.as<uint32_t>(), n);
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ygpu_run(ygpu_ctx *ctx)
+{
+    if (!ctx || !ctx->stream) return YGPU_EINVAL;
+    ctx->stageDone = 0;
+    int rc = runTo(ctx, 3); if (rc) return rc;
+    ctx->totalMs = 0;
+    for (int t = 0; t < T_N; t++) { float m = 0; if (hipEventElapsedTime(&m, ctx->ev[t][0], ctx->ev[t][1]) == hipSuccess) ctx->ms[t] = m; else ctx->ms[t] = 0; ctx->totalMs += ctx->ms[t]; }
+    return 0;
+}
+
+int ygpu_collect(ygpu_ctx *ctx, ygpu_result_batch *out)
+{
+    if (!ctx || !out || ctx->stageDone < 3) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->nReads;
+    ctx->hClumpStart.assign(n + 1, 0); ctx->hClumps.resize(ctx->nOut); ctx->hOps.resize(ctx->nOutOps);
+    HIPCHK(hipMemcpyAsync(ctx->hClumpStart.data(), ctx->readStart.p, 4ull * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nOut) HIPCHK(hipMemcpyAsync(ctx->hClumps.data(), ctx->outClumps2.p, sizeof(ygpu_clump) * (uint64_t)ctx->nOut, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nOutOps) HIPCHK(hipMemcpyAsync(ctx->hOps.data(), ctx->outOps.p, 4ull * ctx->nOutOps, hipMemcpyDeviceToHost, ctx->stream));
+    DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags; dc.v[C_REGIONS] = ctx->nRegions;
+    memcpy(&ctx->hCounters, dc.v, sizeof(ygpu_counters));
+    out->n_reads = n; out->clump_start = ctx->hClumpStart.data(); out->clumps = ctx->hClumps.data(); out->ops = ctx->hOps.data();
+    out->n_clumps = ctx->nOut; out->n_ops = ctx->nOutOps; out->counters = ctx->hCounters;
+    return 0;
+}
+
+int ygpu_last_timing(ygpu_ctx *ctx, float *total_ms, int *n_stages, const char *const **names, const float **ms)
+{
+    if (!ctx) return YGPU_EINVAL;
+    if (total_ms) *total_ms = ctx->totalMs; if (n_stages) *n_stages = T_N; if (names) *names = ctx->names; if (ms) *ms = ctx->ms;
+    return 0;
+}
+
+int ygpu_seed_join(ygpu_ctx *ctx, const ygpu_fragment **frags, uint64_t *n_frags)
+{
+    if (!ctx || !ctx->stream) return YGPU_EINVAL;
+    ctx->stageDone = 0; int rc = runTo(ctx, 1); if (rc) return rc;
+    ctx->hFrags.resize(ctx->nFrags);
+    if (ctx->nFrags) HIPCHK(hipMemcpy(ctx->hFrags.data(), ctx->frags.p, 16ull * ctx->nFrags, hipMemcpyDeviceToHost));
+    for (auto &f : ctx->hFrags) f.reserved = 0;
+    *frags = ctx->hFrags.data(); *n_frags = ctx->nFrags; return 0;
+}
+
+int ygpu_chain(ygpu_ctx *ctx, const ygpu_fragment **clump_frags, const uint32_t **clump_frag_start, const uint32_t **clump_read_strand, uint64_t *n_clumps)
+{
+    if (!ctx || !ctx->stream) return YGPU_EINVAL;
+    ctx->stageDone = 0; int rc = runTo(ctx, 2); if (rc) return rc;
+    const uint32_t NC = ctx->nClumps;
+    std::vector<ChainClumpRec> recs(NC); std::vector<uint32_t> order(NC); std::vector<ygpu_fragment> cf(ctx->nClumpFrags);
+    if (NC) {
+        HIPCHK(hipMemcpy(recs.data(), ctx->clumps.p, sizeof(ChainClumpRec) * (uint64_t)NC, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(order.data(), ctx->order.p, 4ull * NC, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cf.data(), ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToHost));
+    }
+    ctx->hClumpFrags.clear(); ctx->hClumpFragStart.assign(1, 0); ctx->hClumpRS.clear();
+    for (uint32_t r = 0; r < NC; r++) {
+        const ChainClumpRec &c = recs[order[r]];
+        for (uint32_t k = 0; k < c.nFrags; k++) { ygpu_fragment f = cf[c.fragOff + k]; f.reserved = 0; f.read_strand = c.rs; ctx->hClumpFrags.push_back(f); }
+        ctx->hClumpFragStart.push_back((uint32_t)ctx->hClumpFrags.size()); ctx->hClumpRS.push_back(c.rs);
+    }
+    *clump_frags = ctx->hClumpFrags.data(); *clump_frag_start = ctx->hClumpFragStart.data(); *clump_read_strand = ctx->hClumpRS.data(); *n_clumps = NC;
+    return 0;
+}
+
+int ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops)
+{
+    if (!ctx || !ctx->stream || !ctx->nReads) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    for (uint32_t k = 0; k < n; k++) if (problems[k].read >= ctx->nReads || problems[k].mode > 3) { ctx->err = "bad DP problem"; return YGPU_EINVAL; }
+    uint32_t *cnt = ctx->counters.as<uint32_t>();
+    int listCap, front, genCap; alignDims(ctx, listCap, front, genCap); listCap = 64;     // no frame stack needed here
+    const size_t per = alignScratchBytes(ctx->maxQ, listCap, genCap);
+    const unsigned waves = (unsigned)std::min<uint64_t>(std::max<uint32_t>(n, 1u), (uint64_t)ctx->nCU * 4);
+    uint32_t opsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)n * (2ull * ctx->maxQ + 64));
+    ENSURE(ctx->scratchAlign, per * waves); ENSURE(ctx->dpProbs, sizeof(ygpu_dp_problem) * (uint64_t)(n + 1)); ENSURE(ctx->dpRes, sizeof(ygpu_dp_result) * (uint64_t)(n + 1)); ENSURE(ctx->dpOps, 4ull * opsCap + 64);
+    HIPCHK(hipMemcpyAsync(ctx->dpProbs.p, problems, sizeof(ygpu_dp_problem) * (uint64_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(cnt + CNT_QDP, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->dpRes.p, 0, sizeof(ygpu_dp_result) * (uint64_t)(n + 1), ctx->stream));
+    DPBatchArgs A; A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = devBatch(ctx); A.probs = ctx->dpProbs.as<ygpu_dp_problem>(); A.n = n; A.queueHead = cnt + CNT_QDP;
+    A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per; A.maxQ = ctx->maxQ; A.listCap = listCap; A.genCap = genCap;
+    A.res = ctx->dpRes.as<ygpu_dp_result>(); A.ops = ctx->dpOps.as<uint32_t>(); A.opsCount = cnt + CNT_DPOPS; A.opsCap = opsCap; A.errFlag = ctx->errFlag.as<int>();
+    if (n) hipLaunchKernelGGL(k_dp_batch, dim3(waves), dim3(64), 0, ctx->stream, A);
+    uint32_t no = 0, ef = 0; int rc = fetchU32(ctx, cnt + CNT_DPOPS, &no); if (rc) return rc; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+    if (ef) { char b[64]; snprintf(b, sizeof b, "dp batch failed with device error %u", ef); ctx->err = b; return YGPU_EINTERNAL; }
+    ctx->hDpRes.resize(n); ctx->hDpOps.resize(no);
+    if (n) HIPCHK(hipMemcpy(ctx->hDpRes.data(), ctx->dpRes.p, sizeof(ygpu_dp_result) * (uint64_t)n, hipMemcpyDeviceToHost));
+    if (no) HIPCHK(hipMemcpy(ctx->hDpOps.data(), ctx->dpOps.p, 4ull * no, hipMemcpyDeviceToHost));
+    *results = ctx->hDpRes.data(); *ops = ctx->hDpOps.data(); *n_ops = no;
+    return 0;
+}
+}  // extern "C"
