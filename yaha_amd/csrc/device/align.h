@@ -133,6 +133,7 @@ struct Aligner {
     __device__ DPOut runDP(int mode, uint32_t rOff, int rLen, int qOff, int qLen)
     {
         DPOut o = dpWave(P, A.bases, q, mode, rOff, rLen, qOff, qLen, S);
+        o.score = uni(o.score); o.addedQ = uni(o.addedQ); o.addedR = uni(o.addedR); o.nOps = uni(o.nOps); o.rows = uni(o.rows); o.cells = uni(o.cells);
         if (mode >= YGPU_DP_EXT_FWD) { extCalls++; extRows += o.rows; extCells += o.cells; touched += o.rows + 4 * P.bandWidth + 1; }
         else { gapCalls++; gapRows += o.rows; gapCells += o.cells; touched += rLen; }
         return o;
@@ -146,7 +147,7 @@ struct Aligner {
         int initAGS = o.score; if (initAGS <= 0) { aQ = aR = 0; return 0; }
         int QLen = 0, RLen = 0, AGS = score, maxAGS = score, maxItem = -1, maxQLen = 0, maxRLen = 0, nT = o.nOps;
         for (int k = 0; k < o.nOps; k++) {
-            uint32_t op = dpOp(S, o, false, k); int code = opCode(op), len = opLen(op);
+            uint32_t op = uniU(dpOp(S, o, false, k)); int code = opCode(op), len = opLen(op);
             if (code == OP_M) { QLen += len; RLen += len; AGS += P.MS * len; }
             else if (code == OP_R) { QLen += len; RLen += len; AGS -= P.RC * len; }
             else if (code == OP_I) { QLen += len; AGS -= (P.GO + P.GE * len); }
@@ -168,7 +169,7 @@ struct Aligner {
         if (o.score <= 0) { aQ = aR = 0; return 0; }
         int QLen = 0, RLen = 0, AGS = 0, maxAGS = 0, startItem = -1;
         for (int k = 0; k < o.nOps; k++) {
-            uint32_t op = dpOp(S, o, true, k); int code = opCode(op), len = opLen(op);
+            uint32_t op = uniU(dpOp(S, o, true, k)); int code = opCode(op), len = opLen(op);
             if (code == OP_M) { QLen += len; RLen += len; AGS += P.MS * len; }
             else if (code == OP_R) { QLen += len; RLen += len; AGS -= P.RC * len; }
             else if (code == OP_I) { QLen += len; AGS -= (P.GO + P.GE * len); }
@@ -324,12 +325,13 @@ struct Aligner {
         int sm = -1, smm = 0, sg = 0, sl = 0, ss = 0;
         enum { ST_SCORE, ST_SPLIT_ENTER, ST_SPLIT_TAIL, ST_SPLIT_CORE, ST_RETURN } state = ST_SCORE;
         int guard = 0;
-        while (!err) {
+        while (!UNI_B(err != 0)) {
             if (++guard > 100000) { err = YERR_DEPTH; break; }
+            state = (decltype(state))uni((int)state); depth = uni(depth);
             uint32_t *b = buf(depth);
             if (state == ST_SCORE) {
-                if (f.status & stScored) { state = ST_RETURN; continue; }
-                int r = scoreList(f, b, sm, smm, sg, sl, ss);
+                if (UNI_B(f.status & stScored)) { state = ST_RETURN; continue; }
+                int r = uni(scoreList(f, b, sm, smm, sg, sl, ss));
                 if (r == 1) { splits++; f.wS = f.sqo; f.wE = f.eqo; state = ST_SPLIT_ENTER; }      // splitClump, AlignHelpers.c:561-579
                 else state = ST_RETURN;
                 continue;
@@ -349,7 +351,7 @@ struct Aligner {
                 }
                 AGS = maxAGS; matches = mism = ins = del = 0; int maxMatch = 0;
                 for (int k = maxItem; k >= 0; k--) {
-                    uint32_t op = b[f.start + k]; int code = opCode(op), len = opLen(op);
+                    uint32_t op = uniU(b[f.start + k]); int code = opCode(op), len = opLen(op);
                     if (code == OP_M) { matches += len; AGS -= P.MS * len; if (len > maxMatch) maxMatch = len; } else if (code == OP_R) { mism += len; AGS += P.RC * len; }
                     else if (code == OP_I) { ins += len; AGS += (P.GO + P.GE * len); } else { del += len; AGS += (P.GO + P.GE * len); }
                     if (AGS <= 0) { minItem = k; sQO = (eQO - (matches + mism + ins - 1)) & 0xFFFF; sRO = eRO - (uint32_t)(matches + mism + del - 1); break; }
@@ -424,14 +426,16 @@ __global__ void __launch_bounds__(64) k_align(AlignArgs A)
     const unsigned wave = blockIdx.x;
     WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
     Aligner al(A, M);
+    const unsigned nRoots = uniU(A.nRoots);
     for (;;) {
-        unsigned r = 0;
-        if (laneId() == 0) r = atomicAdd(A.queueHead, 1u);
-        r = uniU(r);
-        if (r >= A.nRoots) break;
+        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }     // a lane left the wave-uniform flow: fail loudly
+        unsigned t = 0;
+        if (laneId() == 0) t = atomicAdd(A.queueHead, 1u);
+        const unsigned r = uniU(t);
+        if (r >= nRoots) break;
         al.processRoot(r);
         if (laneId() == 0) A.rootPushCount[r] = al.pushes;
-        if (al.err) { if (laneId() == 0) atomicCAS(A.errFlag, 0, al.err); break; }
+        if (UNI_B(al.err != 0)) { if (laneId() == 0) atomicCAS(A.errFlag, 0, al.err); break; }
     }
     al.flushCounters();
 }
@@ -447,16 +451,21 @@ __global__ void __launch_bounds__(64) k_dp_batch(DPBatchArgs A)
     const int lane = laneId();
     WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
     int err = 0; WaveScratch S; S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
+    const unsigned nProb = uniU(A.n);
     for (;;) {
-        unsigned r = 0; if (lane == 0) r = atomicAdd(A.queueHead, 1u); r = uniU(r);
-        if (r >= A.n) break;
+        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
+        unsigned t = 0; if (lane == 0) t = atomicAdd(A.queueHead, 1u);
+        const unsigned r = uniU(t);
+        if (r >= nProb) break;
         const ygpu_dp_problem p = A.probs[r];
+        YDBG("k_dp_batch r %u mode %d\n", r, (int)p.mode);
         const uint32_t r0 = A.B.readOff[p.read]; const uint8_t *q = (p.strand ? A.B.rev : A.B.fwd) + r0;
         DPOut o = dpWave(A.P, A.bases, q, p.mode, p.rOff, p.rLen, p.qOff, p.qLen, S);
-        if (err) { if (lane == 0) atomicCAS(A.errFlag, 0, err); break; }
-        const bool rev = p.mode == YGPU_DP_EXT_REV; unsigned oi = 0; const int n = o.score != 0 || p.mode < YGPU_DP_EXT_FWD ? o.nOps : 0;
+        YDBG("dp done score %d nOps %d err %d\n", o.score, o.nOps, err);
+        if (UNI_B(err != 0)) { if (lane == 0) atomicCAS(A.errFlag, 0, err); break; }
+        const bool rev = p.mode == YGPU_DP_EXT_REV; unsigned oi = 0; const int n = uni(o.score != 0 || p.mode < YGPU_DP_EXT_FWD ? o.nOps : 0);
         if (lane == 0) oi = atomicAdd(A.opsCount, (unsigned)n); oi = uniU(oi);
-        if (oi + (unsigned)n > A.opsCap) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_OUT); break; }
+        if (UNI_B(oi + (unsigned)n > A.opsCap)) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_OUT); break; }
         const char codes[4] = {'M', 'R', 'D', 'I'};
         for (int k = lane; k < n; k += 64) { uint32_t op = dpOp(S, o, rev, k); A.ops[oi + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
         if (lane == 0) { ygpu_dp_result rr; rr.score = o.score; rr.addedQLen = (uint16_t)o.addedQ; rr.addedRLen = (uint16_t)o.addedR; rr.op_start = oi; rr.n_ops = (uint32_t)n; A.res[r] = rr; }

@@ -38,7 +38,7 @@ __device__ inline bool emitChainClump(const ChainArgs &A, uint32_t rs, uint32_t 
     ci = uniU(ci); fi = uniU(fi);
     if (ci >= A.clumpCap || fi + (unsigned)m > A.fragCap) return false;
     int id = head;
-    for (int k = 0; k < m; k++) { DevFrag f = list[id]; f.used = 0; f.rs = rs; A.clumpFrags[fi + k] = f; id = nx[id]; }
+    for (int k = 0; k < m; k++) { DevFrag f = list[id]; f.used = 0; f.rs = rs; A.clumpFrags[fi + k] = f; id = uni(nx[id]); }
     if (lane == 0) { ChainClumpRec r; r.rs = rs; r.fragOff = fi; r.nFrags = (uint32_t)m; r.region = region; r.seq = seq; r.matched = (uint32_t)matched; A.clumps[ci] = r; }
     return true;
 }
@@ -88,10 +88,13 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A)
     const int lane = laneId(); const DevParams &P = A.P;
     ChainMem M = carveChain(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxN);
     unsigned formed = 0;
+    const unsigned nMulti = uniU(A.nMulti);
     for (;;) {
-        unsigned w = 0; if (lane == 0) w = atomicAdd(A.queueHead, 1u); w = uniU(w);
-        if (w >= A.nMulti) break;
-        const uint32_t reg = A.multiList[w]; const uint32_t s = A.regStart[reg], e = A.regStart[reg + 1]; const int n0 = (int)(e - s);
+        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
+        unsigned t = 0; if (lane == 0) t = atomicAdd(A.queueHead, 1u);
+        const unsigned w = uniU(t);
+        if (w >= nMulti) break;
+        const uint32_t reg = uniU(A.multiList[w]); const uint32_t s = uniU(A.regStart[reg]), e = uniU(A.regStart[reg + 1]); const int n0 = (int)(e - s);
         const uint32_t rs = A.frags[s].rs; const uint32_t read = rs >> 1; const int qlen = (int)(A.B.readOff[read + 1] - A.B.readOff[read]);
         if (n0 > A.maxN) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_CHAIN); break; }
         for (int k = lane; k <= qlen; k += 64) M.cov[k] = 0;                       // setCoverage(QS, 0, queryLen, FALSE), GraphPath.cpp:276
@@ -171,8 +174,8 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A)
             // ---- processBestFragmentPath (:134-146): insertFragment front to back with overlap trimming (AlignHelpers.c:60-90)
             int head = -1, tail = -1, m = 0, matched = 0;
             {
-                for (int cur = bestNode; cur >= 0; cur = M.prev[cur]) {
-                    const uint32_t fi = M.sidx[cur];
+                for (int cur = uni(bestNode); cur >= 0; cur = uni(M.prev[cur])) {
+                    const uint32_t fi = uniU(M.sidx[cur]);
                     DevFrag f1 = A.frags[fi];
                     if (head >= 0) {
                         DevFrag f2 = M.L[head];
@@ -191,9 +194,10 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A)
                     head = id;
                 }
             }
-            if (matched < P.minMatch) break;                                       // resetClump -> empty -> region finished (:142-143, 281-285)
+            if (UNI_B(matched < P.minMatch)) break;                                       // resetClump -> empty -> region finished (:142-143, 281-285)
             cleanUpList(P, M.L, M.nx, M.pv, head, tail);
-            int mm = 0; for (int id = head; id >= 0; id = M.nx[id]) mm++;
+            head = uni(head); tail = uni(tail);
+            int mm = 0; for (int id = head; id >= 0; id = uni(M.nx[id])) mm++;
             const DevFrag first = M.L[head], last = M.L[tail];
             const int cSQO = first.sqo, cLen = (1 + (int)last.eqo - (int)first.sqo) & 0xFFFF;
             for (int k = lane; k < cLen; k += 64) if (cSQO + k <= qlen) M.cov[cSQO + k] = 1;      // setCoverage, :287
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A)
             seq++; formed++;
         }
         if (lane == 0) A.regionClumpCount[reg] = seq;
-        if (fail) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_CHAIN); break; }
+        if (UNI_B(fail)) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_CHAIN); break; }
     }
     if (lane == 0 && formed) atomicAdd(&A.ctr->v[C_FORMED], (unsigned long long)formed);
 }

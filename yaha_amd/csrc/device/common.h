@@ -34,6 +34,9 @@ enum { C_KMER = 0, C_HITS, C_FRAGS, C_REGIONS, C_FORMED, C_SCORED, C_EXT_CALLS, 
 __device__ __forceinline__ int  laneId() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int  uni(int v) { return __builtin_amdgcn_readfirstlane(v); }            // make a wave-uniform value scalar
 __device__ __forceinline__ unsigned uniU(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+// wave-uniform condition -> scalar branch.  Every branch of wave-uniform control flow goes through this: a vector-masked
+// loop exit lets single lanes drop out of a loop (and out of the lane-0 queue pop) if anything ever differs between lanes.
+#define UNI_B(c) (__builtin_amdgcn_readfirstlane((c) ? 1 : 0) != 0)
 __device__ __forceinline__ int  bcast(int v, int srcLane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(srcLane)); }
 
 // DPP row/wave shifts would be cheaper; these use ds_bpermute (any distance, full wave).  See DESIGN.md (tuning list).

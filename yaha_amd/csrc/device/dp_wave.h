@@ -16,6 +16,11 @@
 // tests/wave_dp_model.py is the lane-level model of exactly this algorithm, checked against the oracle on the CPU.
 #pragma once
 #include "common.h"
+#ifdef YD_DEBUG
+#define YDBG(...) do { if (laneId() == 0 && blockIdx.x == 0) printf(__VA_ARGS__); } while (0)
+#else
+#define YDBG(...) do { } while (0)
+#endif
 
 struct DPOut { int score, addedQ, addedR, nOps, rows, cells; };   // ops are left in S.tmpOps in EMISSION order (see dpOp)
 
@@ -25,7 +30,7 @@ struct WaveScratch {
     int      *gen;    int genCap;         // generic path rows: 3 * (genCap + 3) ints
     int      *err;                        // wave-local sticky error code (0 = ok)
 };
-enum { YERR_TRACE = 1, YERR_TMPOPS = 2, YERR_GEN = 3, YERR_ARENA = 4, YERR_DEPTH = 5, YERR_OUT = 6, YERR_CHAIN = 7 };
+enum { YERR_TRACE = 1, YERR_TMPOPS = 2, YERR_GEN = 3, YERR_ARENA = 4, YERR_DEPTH = 5, YERR_OUT = 6, YERR_CHAIN = 7, YERR_EXEC = 8 };
 
 // k-th op of the last DP result in LIST order (head..tail).  The traceback emits from the alignment's far end towards
 // the anchor; the reference adds each op to the front (forward) or to the back (reverse), SW.cpp:1182-1195.
@@ -39,7 +44,7 @@ __device__ __noinline__ DPOut dpGeneric(const DevParams &P, const uint8_t *__res
                                         int bandwidth, int left, int right, int W, const WaveScratch &S)
 {
     DPOut out = {0, 0, 0, 0, 0, 0};
-    const int GO = P.GO, GE = P.GE, RC = P.RC, MS = P.MS;
+    const int GO = uni(P.GO), GE = uni(P.GE), RC = uni(P.RC), MS = uni(P.MS), maxIntron = uni(P.maxIntron), maxGapP = uni(P.maxGap), XC = uni(P.X);
     if ((long)(qLen + 1) * W > (long)S.traceRows * 64) { *S.err = YERR_TRACE; return out; }
     if (W > S.genCap) { *S.err = YERR_GEN; return out; }
     int *PV = S.gen + 1, *PF = S.gen + (S.genCap + 3), *PI = S.gen + 2 * (S.genCap + 3);
@@ -64,21 +69,21 @@ __device__ __noinline__ DPOut dpGeneric(const DevParams &P, const uint8_t *__res
             endCol = min(left + rLen - i, W - 1);
         } else PVCol = -(GO + i * GE);
         int rowMax = YD_WORST;
-        int qc = q[rev ? qOff + 1 - i : qOff + i - 1];
+        int qc = uni((int)q[rev ? qOff + 1 - i : qOff + i - 1]);
         int rRow = banded ? i - left - 1 : 0;
         out.rows++;
         for (int j = startCol; j <= endCol; j++) {
             int RM = banded ? j : j - 1, IO = RM + 1, op;
-            V = PV[RM];
+            V = uni(PV[RM]);
             int ridx = banded ? rRow + j : j - 1;
-            int rc = ref4(bases, rev ? rOff - (uint32_t)ridx : rOff + (uint32_t)ridx);
+            int rc = uni((int)ref4(bases, rev ? rOff - (uint32_t)ridx : rOff + (uint32_t)ridx));
             if (qc == rc) { V += MS; op = OP_M; } else { V -= RC; op = OP_R; }
             int len = 0;
             int CE = PECol - GE, NE = PVCol - (GO + GE);
-            if (CE >= NE && (PDCol + 1) <= P.maxIntron) { PECol = CE; PDCol = PDCol + 1; } else { PECol = NE; PDCol = 1; }
+            if (CE >= NE && (PDCol + 1) <= maxIntron) { PECol = CE; PDCol = PDCol + 1; } else { PECol = NE; PDCol = 1; }
             if (ext ? (PECol >= V) : (PECol > V)) { V = PECol; op = OP_D; len = PDCol; }
-            int F, I, CF = PF[IO] - GE, NF = PV[IO] - (GO + GE);
-            if (CF >= NF && (PI[IO] + 1) <= P.maxGap) { F = CF; I = PI[IO] + 1; } else { F = NF; I = 1; }
+            int F, I, CF = uni(PF[IO]) - GE, NF = uni(PV[IO]) - (GO + GE); const int pio = uni(PI[IO]);
+            if (CF >= NF && (pio + 1) <= maxGapP) { F = CF; I = pio + 1; } else { F = NF; I = 1; }
             if (ext ? (F >= V) : (F > V)) { V = F; op = OP_I; len = I; }
             PF[j] = F; PI[j] = I;
             T[rowOffset + j] = (uint16_t)(op | (len << 2));
@@ -87,7 +92,7 @@ __device__ __noinline__ DPOut dpGeneric(const DevParams &P, const uint8_t *__res
             if (banded) PV[j] = V; else PV[j - 1] = PVCol;
             PVCol = V; out.cells++;
         }
-        if (ext && rowMax < (maxScore - P.X)) break;
+        if (ext && rowMax < (maxScore - XC)) break;
         if (!banded) PV[endCol] = V;
     }
     int retval = ext ? maxScore : V;
@@ -95,14 +100,15 @@ __device__ __noinline__ DPOut dpGeneric(const DevParams &P, const uint8_t *__res
     out.score = retval;
     if (ext) { out.addedQ = maxi; out.addedR = maxi + (maxj - bandwidth); }
     int x = maxj; long rowBase = (long)maxi * W;
-    uint16_t cell = T[rowBase + x];
+    unsigned cell = uniU((unsigned)T[rowBase + x]);
     int prev = cell == TR_U ? -1 : (cell & 3), opLenAcc = 0, n = 0;
-    while (cell != TR_U) {
+    for (int guard = 0; cell != TR_U; guard++) {
+        if (guard > 200000) { *S.err = YERR_TRACE; out.score = 0; return out; }
         int code = cell & 3, len = cell >> 2;
         if (banded) { if (code == OP_D) x -= len; else if (code == OP_I) { x += len; rowBase -= (long)len * W; } else { rowBase -= W; len = 1; } }
         else        { if (code == OP_D) x -= len; else if (code == OP_I) { rowBase -= (long)len * W; } else { x -= 1; rowBase -= W; len = 1; } }
         if (prev != code) { if (n < S.tmpCap) S.tmpOps[n] = opMake(prev, opLenAcc); n++; prev = code; opLenAcc = len; } else opLenAcc += len;
-        cell = T[rowBase + x];
+        cell = uniU((unsigned)T[rowBase + x]);
     }
     if (n < S.tmpCap) S.tmpOps[n] = opMake(prev, opLenAcc); n++;
     if (n > S.tmpCap) { *S.err = YERR_TMPOPS; out.score = 0; n = 0; }
@@ -115,24 +121,28 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
                                      uint32_t rOff, int rLenArg, int qOff, int qLenArg, const WaveScratch &S)
 {
     const int lane = laneId();
-    const int GO = P.GO, GE = P.GE, RC = P.RC, MS = P.MS, maxGap = P.maxGap;
+    const int GO = uni(P.GO), GE = uni(P.GE), RC = uni(P.RC), MS = uni(P.MS), maxGap = uni(P.maxGap), XC = uni(P.X), bwP = uni(P.bandWidth), maxIntron = uni(P.maxIntron);
+    const uint32_t maxROff = uniU(P.maxROff);
+    mode = uni(mode); rOff = uniU(rOff); qOff = uni(qOff);
     const bool ext = mode >= YGPU_DP_EXT_FWD, rev = mode == YGPU_DP_EXT_REV, banded = mode != YGPU_DP_FULL;
     DPOut out = {0, 0, 0, 0, 0, 0};
     int qLen = uni(qLenArg), rLen = uni(rLenArg), bandwidth = 0, left = 0, right = 0;
     if (ext) {                                                              // findAGSExtension, SW.cpp:479-516
         if (qLen <= 0) return out;
-        bandwidth = 2 * P.bandWidth;
+        bandwidth = 2 * bwP;
         uint32_t rl = (uint32_t)(qLen + bandwidth);
         if (rev && rl > rOff) { rl = rOff + 1; qLen = (int)rl - bandwidth; if (qLen <= 0) return out; }
-        if (!rev && (rOff + rl) > P.maxROff) { rl = P.maxROff - rOff; qLen = (int)rl - bandwidth; if (qLen <= 0) return out; }
+        if (!rev && (rOff + rl) > maxROff) { rl = maxROff - rOff; qLen = (int)rl - bandwidth; if (qLen <= 0) return out; }
         qLen &= 0xFFFF; rLen = (int)(rl & 0xFFFF);                           // SUINT parameters of findAffineGapScore
         left = right = bandwidth;
     } else if (banded) {                                                    // SW.cpp:853-871
-        bandwidth = P.bandWidth;
+        bandwidth = bwP;
         if (rLen > qLen) { right = bandwidth + (rLen - qLen); left = bandwidth; } else { left = bandwidth + (qLen - rLen); right = bandwidth; }
     }
+    qLen = uni(qLen); rLen = uni(rLen); left = uni(left); right = uni(right);
     const int W = banded ? left + right + 1 : rLen + 1;
-    if (W > 64 || (W - 1) > P.maxIntron) return dpGeneric(P, bases, q, banded, ext, rev, rOff, rLen, qOff, qLen, bandwidth, left, right, W, S);
+    YDBG("dpWave mode %d qLen %d rLen %d W %d left %d right %d\n", mode, qLen, rLen, W, left, right);
+    if (W > 64 || (W - 1) > maxIntron) return dpGeneric(P, bases, q, banded, ext, rev, rOff, rLen, qOff, qLen, bandwidth, left, right, W, S);
     if (qLen + 1 > S.traceRows) { *S.err = YERR_TRACE; return out; }
 
     auto loadRef = [&](int idx) -> int { return (idx >= 0 && idx < rLen) ? (int)ref4(bases, rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx) : 0xFF; };
@@ -181,8 +191,9 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
             const unsigned rk = waveMaxU(active ? (((unsigned)(V + YD_BIAS) << 6) | (unsigned)(63 - lane)) : 0u);
             int rv = YD_WORST, rj = 0;
             if (rk) { rv = (int)(rk >> 6) - YD_BIAS; rj = 63 - (int)(rk & 63u); }
+            rv = uni(rv); rj = uni(rj);
             if (rv > maxScore) { maxScore = rv; maxi = i; maxj = rj; }
-            if (rv < maxScore - P.X) break;
+            if (rv < maxScore - XC) break;
         }
         if (banded) {                                                       // slide the reference window by one base
             const int ni = i + right;                                      // index the top lane needs for row i+1
@@ -193,9 +204,10 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
         }
     }
     out.rows = rows; out.cells = cells;
+    YDBG("rows done %d cells %d maxScore %d maxi %d maxj %d\n", rows, cells, maxScore, maxi, maxj);
     int y, x, score;
     if (ext) { if (maxScore <= 0) return out; y = maxi; x = maxj; score = maxScore; out.addedQ = maxi; out.addedR = maxi + (maxj - bandwidth); }
-    else { y = qLen; x = banded ? right : W - 1; score = bcast(PV, lastEc); }
+    else { y = qLen; x = banded ? right : W - 1; score = bcast(PV, uni(lastEc)); }
     out.score = score;
     __threadfence_block();                                                  // other lanes' trace cells become visible to every lane
     // ---- traceback (wave-uniform), SW.cpp:1138-1195; boundary cells are synthesised ----
@@ -207,11 +219,12 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
             if (yy == 0) { if (xx == 0) { code = -1; len = 0; } else { code = OP_D; len = xx; } return; }
             if (xx == 0) { code = OP_I; len = yy; return; }
         }
-        const unsigned c = trace[yy * 64 + xx]; code = (int)(c & 3u); len = (int)(c >> 2);
+        const unsigned c = uniU((unsigned)trace[yy * 64 + xx]); code = (int)(c & 3u); len = (int)(c >> 2);
     };
     int code, len; cellAt(y, x, code, len);
     int prev = code, acc = 0, n = 0;
-    while (code >= 0) {
+    for (int guard = 0; code >= 0; guard++) {
+        if (guard > 200000 || y < 0 || x < 0 || x > 63) { *S.err = YERR_TRACE; out.score = 0; out.nOps = 0; return out; }
         if (banded) { if (code == OP_D) x -= len; else if (code == OP_I) { x += len; y -= len; } else { y -= 1; len = 1; } }
         else        { if (code == OP_D) x -= len; else if (code == OP_I) { y -= len; } else { x -= 1; y -= 1; len = 1; } }
         if (prev != code) { if (n < S.tmpCap) S.tmpOps[n] = opMake(prev, acc); n++; prev = code; acc = len; } else acc += len;
