@@ -94,6 +94,11 @@ static int cmdGenome(int argc, char **argv)
     int nruns = atoi(argval(argc, argv, "--nrun", "1"));
     int lowc = atoi(argval(argc, argv, "--lowcomplex", "2"));
     bool equal = argflag(argc, argv, "--equal");
+    // number of repeat sub-families: copies per family (and so seed hits per read) scale with total / families;
+    // the defaults are calibrated so that a 1 kbp read yields ~10 k seed hits at -H 650
+    int nAlu = atoi(argval(argc, argv, "--alu-families", "0")), nL1 = atoi(argval(argc, argv, "--l1-families", "0"));
+    if (nAlu <= 0) nAlu = (int)std::max<uint64_t>(6, total / 2500000);
+    if (nL1 <= 0) nL1 = (int)std::max<uint64_t>(2, total / 8000000);
     Rng r(seed);
     Genome g;
     // hg18-like length ratios (chr1..chrN descending), odd lengths to exercise the X padding
@@ -107,8 +112,8 @@ static int cmdGenome(int argc, char **argv)
         g.seqs.push_back(std::move(s));
     }
     // repeat families
-    std::vector<std::string> alu;   for (int f = 0; f < 6; f++) { std::string c(300, 'A'); for (auto &ch : c) ch = randBase(r, 0.55); alu.push_back(c); }
-    std::vector<std::string> l1;    for (int f = 0; f < 2; f++) { std::string c(6000, 'A'); for (auto &ch : c) ch = randBase(r, 0.40); l1.push_back(c); }
+    std::vector<std::string> alu;   for (int f = 0; f < nAlu; f++) { std::string c(300, 'A'); for (auto &ch : c) ch = randBase(r, 0.55); alu.push_back(c); }
+    std::vector<std::string> l1;    for (int f = 0; f < nL1; f++) { std::string c(6000, 'A'); for (auto &ch : c) ch = randBase(r, 0.40); l1.push_back(c); }
     uint64_t target = (uint64_t)(repFrac * total), placed = 0;
     while (placed < target) {
         int si = (int)r.below(nseq); std::string &s = g.seqs[si];

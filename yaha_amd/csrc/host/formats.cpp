@@ -163,19 +163,36 @@ template <class Visit> void scanKmers(const Genome &g, int wordLen, int skipDist
 }
 }  // namespace
 
-bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, std::vector<uint32_t> &image, FILE *log)
+// 4^15 counters are 4.3 GB: back them with transparent huge pages, otherwise first-touch page faults dominate the build
+bool IndexImage::alloc(size_t n)
+{
+    release(); words = n; bytes = (n * 4 + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1);
+    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) { bytes = 0; words = 0; return false; }
+    madvise(m, bytes, MADV_HUGEPAGE); p = (uint32_t *)m; return true;
+}
+void IndexImage::release() { if (p) munmap(p, bytes); p = nullptr; bytes = 0; words = 0; }
+
+struct HugeU32 {
+    uint32_t *p = nullptr; size_t bytes = 0;
+    explicit HugeU32(size_t n) { bytes = (n * 4 + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1); void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0); if (m != MAP_FAILED) { madvise(m, bytes, MADV_HUGEPAGE); p = (uint32_t *)m; } }
+    ~HugeU32() { if (p) munmap(p, bytes); }
+    uint32_t &operator[](size_t i) { return p[i]; }
+};
+
+bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, IndexImage &image, FILE *log)
 {
     const uint64_t HT = 1ull << (2 * wordLen);
-    std::vector<uint32_t> counts(HT, 0);
+    HugeU32 counts(HT);
+    if (!counts.p) return false;
     scanKmers(g, wordLen, skipDist, [&](uint32_t h, uint32_t) { counts[h]++; });
     uint32_t total = 0; for (uint64_t i = 0; i < HT; i++) total += counts[i];
-    image.assign(4 + HT + 1 + (uint64_t)total, 0);
+    if (!image.alloc(4 + HT + 1 + (uint64_t)total)) return false;
     image[0] = 0xFFFFFFFFu; image[1] = (uint32_t)wordLen; image[2] = (uint32_t)maxHits; image[3] = total;
-    uint32_t *SO = image.data() + 4, *ROA = SO + HT + 1;
+    uint32_t *SO = image.p + 4, *ROA = SO + HT + 1;
     { uint32_t off = 0; for (uint64_t i = 0; i < HT; i++) { SO[i] = off; off += counts[i]; } SO[HT] = total; }
-    std::fill(counts.begin(), counts.end(), 0);
+    memset(counts.p, 0, HT * 4);
     scanKmers(g, wordLen, skipDist, [&](uint32_t h, uint32_t off) { uint32_t lim = SO[h + 1] - SO[h]; if (counts[h] < lim) { ROA[SO[h] + counts[h]] = off; counts[h]++; } });
-    counts.clear(); counts.shrink_to_fit();
     // third pass: sample k-mers with more than maxHits occurrences (Index.c:271-315)
     RandState rs; randInitDefault(rs);
     if (log) fprintf(log, "Randomly Sampling hits for %d-mers that occur more than %d times in the reference.\n", wordLen, maxHits);
@@ -189,7 +206,7 @@ bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, std::ve
         SO[i] = newTotal; newTotal += lim;
     }
     SO[HT] = newTotal; image[3] = newTotal;
-    image.resize(4 + HT + 1 + (uint64_t)newTotal);
+    image.words = 4 + HT + 1 + (uint64_t)newTotal;
     if (log) fprintf(log, "%u %d-mers had more than %d hits.\n", over, wordLen, maxHits);
     return true;
 }

@@ -51,9 +51,9 @@ int runIndex(Args &a, FILE *log)                                              //
     }
     fprintf(log, "Creating index file %s.\n", xfile.c_str());
     Genome g; if (!loadNib2(nib2.c_str(), g, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
-    std::vector<uint32_t> image;
-    buildIndex(g, a.wordLen, a.skipDist, a.maxHits, image, log);
-    if (!writeFile(xfile.c_str(), image.data(), image.size() * 4, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
+    IndexImage image;
+    if (!buildIndex(g, a.wordLen, a.skipDist, a.maxHits, image, log)) { fprintf(log, "Insufficient memory to build the index.\n"); return 1; }
+    if (!writeFile(xfile.c_str(), image.p, image.words * 4, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
     fprintf(log, "Index %s created.\n", xfile.c_str());
     return 0;
 }

@@ -46,8 +46,9 @@ struct IndexFile {
     MMap map; std::vector<uint32_t> owned;
     int wordLen = 0; int maxHits = 0; uint32_t totalMatches = 0; const uint32_t *SO = nullptr; const uint32_t *ROA = nullptr;
 };
-// builds the complete file image {-1, wordLen, maxHits, total} + SO[4^L+1] + ROA[total]
-bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, std::vector<uint32_t> &image, FILE *log);
+// builds the complete file image {-1, wordLen, maxHits, total} + SO[4^L+1] + ROA[total] (huge-page backed: 4.3 GB at L=15)
+struct IndexImage { uint32_t *p = nullptr; size_t words = 0, bytes = 0; bool alloc(size_t n); void release(); uint32_t &operator[](size_t i) { return p[i]; } ~IndexImage() { release(); } };
+bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, IndexImage &image, FILE *log);
 bool parseIndex(const uint32_t *img, size_t bytes, IndexFile &ix, std::string &err);
 bool loadIndex(const char *path, IndexFile &ix, std::string &err);
 
