@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libyaha_hip.so")
+LIB_PATH = os.environ.get("YAHA_HIP_LIB", os.path.join(_HERE, "csrc", "libyaha_hip.so"))   # override only for diagnostic builds
 CLI_PATH = os.path.join(_HERE, "csrc", "yaha")
 
 

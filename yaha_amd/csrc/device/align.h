@@ -57,6 +57,7 @@ __device__ inline WaveMem carveScratch(uint8_t *p, int maxQ, int listCap, int ge
 // ---- exact-match extension: 64 bases per step (extendFragment{Forward,Backward}ToStopPerfectly, AlignExtFrag.cpp:30-48)
 __device__ inline int perfectFwd(const uint8_t *bases, const uint8_t *q, int qOff0, uint32_t rOff0, int len)
 {
+    PROF_T0();
     const int lane = laneId(); int count = 0;
     while (count < len) {
         int k = count + lane;
@@ -65,10 +66,12 @@ __device__ inline int perfectFwd(const uint8_t *bases, const uint8_t *q, int qOf
         if (bad) { count += __ffsll((long long)bad) - 1; break; }
         count += 64;
     }
+    PROF_ADD(PF_PERFECT);
     return uni(count);
 }
 __device__ inline int perfectBack(const uint8_t *bases, const uint8_t *q, int qOff0, uint32_t rOff0, int len)
 {
+    PROF_T0();
     const int lane = laneId(); int count = 0;
     while (count < len) {
         int k = count + lane;
@@ -77,6 +80,7 @@ __device__ inline int perfectBack(const uint8_t *bases, const uint8_t *q, int qO
         if (bad) { count += __ffsll((long long)bad) - 1; break; }
         count += 64;
     }
+    PROF_ADD(PF_PERFECT);
     return uni(count);
 }
 
@@ -87,9 +91,9 @@ struct Aligner {
     unsigned extCalls, extRows, extCells, gapCalls, gapRows, gapCells, perfect, touched, opsOut, splits, scored;
     uint32_t rootRank; unsigned pushes;
 
-    __device__ Aligner(const AlignArgs &a, WaveMem m) : A(a), P(a.P), M(m), err(0), q(nullptr), qlen(0), lane(laneId()),
+    __device__ Aligner(const AlignArgs &a, WaveMem m, uint16_t *ldsTrace) : A(a), P(a.P), M(m), err(0), q(nullptr), qlen(0), lane(laneId()),
         extCalls(0), extRows(0), extCells(0), gapCalls(0), gapRows(0), gapCells(0), perfect(0), touched(0), opsOut(0), splits(0), scored(0), rootRank(0), pushes(0)
-    { S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err; }
+    { S.ldsTrace = ldsTrace; S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err; }
 
     __device__ uint32_t *buf(int depth) const { return M.arena + (size_t)depth * A.listCap; }
     __device__ int gapCost(int len) const { return len > 0 ? -(P.GO + len * P.GE) : 0; }
@@ -262,6 +266,8 @@ struct Aligner {
 
     // scoreClump, AlignHelpers.c:302-366.  returns 0 = done (scored or rejected), 1 = needs splitClump
     __device__ int scoreList(Frame &f, const uint32_t *b, int &oMatches, int &oMism, int &oGap, int &oLen, int &oScore)
+    { PROF_T0(); int rr_ = scoreListImpl(f, b, oMatches, oMism, oGap, oLen, oScore); PROF_ADD(PF_SCORE); return rr_; }
+    __device__ int scoreListImpl(Frame &f, const uint32_t *b, int &oMatches, int &oMism, int &oGap, int &oLen, int &oScore)
     {
         int AGS = 0, maxAGS = 0, matches = 0, mism = 0, ins = 0, del = 0; const int n = f.len, aligned = f.score;
         for (int base = 0; base < n; base += 64) {
@@ -298,6 +304,7 @@ struct Aligner {
 
     __device__ void emit(const Frame &f, const uint32_t *b, int matches, int mism, int gap, int totLen, int totScore)
     {
+        PROF_T0();
         unsigned ci = 0, oi = 0;
         if (lane == 0) { ci = atomicAdd(&A.outCounts[0], 1u); oi = atomicAdd(&A.outCounts[1], (unsigned)f.len); }
         ci = uniU(ci); oi = uniU(oi);
@@ -310,6 +317,7 @@ struct Aligner {
             A.outClumps[ci] = c; A.outRoot[ci] = rootRank; A.outPush[ci] = pushes;
         }
         pushes++; scored++; opsOut += (unsigned)f.len;
+        PROF_ADD(PF_EMIT);
     }
 
     // The whole life of one root clump.
@@ -425,7 +433,9 @@ __global__ void __launch_bounds__(64) k_align(AlignArgs A)
 {
     const unsigned wave = blockIdx.x;
     WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
-    Aligner al(A, M);
+    __shared__ uint16_t sTrace[YD_LDS_CELLS];
+    Aligner al(A, M, sTrace);
+    PROF_INIT();
     const unsigned nRoots = uniU(A.nRoots);
     for (;;) {
         if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }     // a lane left the wave-uniform flow: fail loudly
@@ -433,11 +443,12 @@ __global__ void __launch_bounds__(64) k_align(AlignArgs A)
         if (laneId() == 0) t = atomicAdd(A.queueHead, 1u);
         const unsigned r = uniU(t);
         if (r >= nRoots) break;
-        al.processRoot(r);
+        { PROF_T0(); al.processRoot(r); PROF_ADD(PF_ROOT); PROF_CNT(PF_ROOTS); }
         if (laneId() == 0) A.rootPushCount[r] = al.pushes;
         if (UNI_B(al.err != 0)) { if (laneId() == 0) atomicCAS(A.errFlag, 0, al.err); break; }
     }
     al.flushCounters();
+    PROF_FLUSH();
 }
 
 // ---- stage-level test entry: a batch of independent DP calls (ygpu_dp_batch) -------------------------------------------
@@ -450,7 +461,8 @@ __global__ void __launch_bounds__(64) k_dp_batch(DPBatchArgs A)
 {
     const int lane = laneId();
     WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
-    int err = 0; WaveScratch S; S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
+    __shared__ uint16_t sTrace[YD_LDS_CELLS];
+    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
     const unsigned nProb = uniU(A.n);
     for (;;) {
         if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }

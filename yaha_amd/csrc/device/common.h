@@ -12,6 +12,12 @@
 enum { stReversed = 0x01, stAligned = 0x04, stScored = 0x08, stSplit = 0x10 };   // FragsClumps.inl:235-240
 enum { OP_M = 0, OP_R = 1, OP_D = 2, OP_I = 3 };
 
+// explicit address spaces: a generic (flat) store also counts on lgkmcnt and forces a full wait per DP row
+#define YD_GLOBAL __attribute__((address_space(1)))
+#define YD_LDS    __attribute__((address_space(3)))
+template <class T> __device__ __forceinline__ YD_GLOBAL T *toGlobal(T *p) { return (YD_GLOBAL T *)p; }
+#define YD_LDS_CELLS 5120            // uint16 trace cells kept in LDS per wavefront (10 KB): 160 rows of a 21-wide extension strip
+
 struct DevParams {
     int wordLen, maxHits, bandWidth, maxGap, maxIntron, minMatch, maxDesert, minNonOverlap, minRawScore, minExtLength;
     int GO, GE, RC, MS, X; float minIdentity;
@@ -39,7 +45,25 @@ __device__ __forceinline__ unsigned uniU(unsigned v) { return (unsigned)__builti
 #define UNI_B(c) (__builtin_amdgcn_readfirstlane((c) ? 1 : 0) != 0)
 __device__ __forceinline__ int  bcast(int v, int srcLane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(srcLane)); }
 
-// DPP row/wave shifts would be cheaper; these use ds_bpermute (any distance, full wave).  See DESIGN.md (tuning list).
+// ---- DPP (data-parallel primitives) cross-lane moves: VALU-rate, no LDS crossbar round trip ---------------------
+// gfx9/CDNA dpp_ctrl encodings: row_shr:n 0x110+n, wave_shl:1 0x130, wave_shr:1 0x138, row_bcast:15 0x142, row_bcast:31 0x143
+template <int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ int dppMov(int oldv, int src)
+{ return __builtin_amdgcn_update_dpp(oldv, src, CTRL, ROWMASK, 0xf, false); }
+__device__ __forceinline__ int laneUp1(int v, int fill) { return dppMov<0x138>(fill, v); }     // lane i <- lane i-1 (lane 0 <- fill)
+__device__ __forceinline__ int laneDown1(int v, int fill) { return dppMov<0x130>(fill, v); }   // lane i <- lane i+1 (lane 63 <- fill)
+// inclusive prefix max over the 64 lanes (identity 0): row_shr 1,2,4,8 inside rows of 16, then row_bcast 15 / 31
+__device__ __forceinline__ unsigned waveInclMaxU(unsigned v)
+{
+    unsigned t;
+    t = (unsigned)dppMov<0x111>(0, (int)v); v = v > t ? v : t;
+    t = (unsigned)dppMov<0x112>(0, (int)v); v = v > t ? v : t;
+    t = (unsigned)dppMov<0x114>(0, (int)v); v = v > t ? v : t;
+    t = (unsigned)dppMov<0x118>(0, (int)v); v = v > t ? v : t;
+    t = (unsigned)dppMov<0x142, 0xa>(0, (int)v); v = v > t ? v : t;
+    t = (unsigned)dppMov<0x143, 0xc>(0, (int)v); v = v > t ? v : t;
+    return v;
+}
+// The ds_bpermute forms below are kept for code that is not on the per-row critical path.
 __device__ __forceinline__ unsigned waveMaxU(unsigned v)
 {
 #pragma unroll
@@ -60,12 +84,9 @@ __device__ __forceinline__ int waveSumI(int v)
 }
 // exclusive prefix max over lanes (identity 0)
 __device__ __forceinline__ unsigned waveExclMaxU(unsigned v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { unsigned t = (unsigned)__shfl_up((int)v, d, 64); if (lane >= d) v = v > t ? v : t; }
-    unsigned e = (unsigned)__shfl_up((int)v, 1, 64);
-    return lane == 0 ? 0u : e;
-}
+{ (void)lane; return (unsigned)laneUp1((int)waveInclMaxU(v), 0); }
+// maximum over all lanes, returned as a scalar
+__device__ __forceinline__ unsigned waveTotalMaxU(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)waveInclMaxU(v), 63); }
 
 __device__ __forceinline__ uint8_t ref4(const uint8_t *bases, uint32_t off)          // getFrom4Code, Math.c:180-188
 { uint8_t b = bases[off >> 1]; return (off & 1) ? (uint8_t)(b & 0xF) : (uint8_t)(b >> 4); }

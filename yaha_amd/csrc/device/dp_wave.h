@@ -16,6 +16,24 @@
 // tests/wave_dp_model.py is the lane-level model of exactly this algorithm, checked against the oracle on the CPU.
 #pragma once
 #include "common.h"
+// ---- optional in-kernel cycle accounting (diagnostic build only: make PROF=1) ----
+#ifdef YD_PROF
+__device__ unsigned long long gProf[16];
+enum { PF_ROOT = 0, PF_DPROWS, PF_TRACEBACK, PF_PERFECT, PF_SCORE, PF_EMIT, PF_SPLIT, PF_MERGE, PF_DPCALLS, PF_ROOTS };
+// per-wave accumulation in LDS (one wavefront per workgroup), flushed once per kernel: the instrumentation must not contend
+__shared__ unsigned long long sProf[16];
+#define PROF_INIT() do { if (laneId() < 16) sProf[laneId()] = 0; } while (0)
+#define PROF_FLUSH() do { if (laneId() < 16 && sProf[laneId()]) atomicAdd(&gProf[laneId()], sProf[laneId()]); } while (0)
+#define PROF_T0() unsigned long long pf_t0_ = clock64()
+#define PROF_ADD(slot) do { unsigned long long pf_t1_ = clock64(); if (laneId() == 0) sProf[slot] += pf_t1_ - pf_t0_; pf_t0_ = pf_t1_; } while (0)
+#define PROF_CNT(slot) do { if (laneId() == 0) sProf[slot] += 1ull; } while (0)
+#else
+#define PROF_INIT() do { } while (0)
+#define PROF_FLUSH() do { } while (0)
+#define PROF_T0() do { } while (0)
+#define PROF_ADD(slot) do { } while (0)
+#define PROF_CNT(slot) do { } while (0)
+#endif
 #ifdef YD_DEBUG
 #define YDBG(...) do { if (laneId() == 0 && blockIdx.x == 0) printf(__VA_ARGS__); } while (0)
 #else
@@ -25,7 +43,8 @@
 struct DPOut { int score, addedQ, addedR, nOps, rows, cells; };   // ops are left in S.tmpOps in EMISSION order (see dpOp)
 
 struct WaveScratch {
-    uint16_t *trace;  int traceRows;      // traceRows * 64 cells
+    uint16_t *trace;  int traceRows;      // traceRows * 64 cells (HBM/L2)
+    uint16_t *ldsTrace;                   // YD_LDS_CELLS cells of LDS: the first rows of every strip live here
     uint32_t *tmpOps; int tmpCap;         // DP result, emission order
     int      *gen;    int genCap;         // generic path rows: 3 * (genCap + 3) ints
     int      *err;                        // wave-local sticky error code (0 = ok)
@@ -35,7 +54,7 @@ enum { YERR_TRACE = 1, YERR_TMPOPS = 2, YERR_GEN = 3, YERR_ARENA = 4, YERR_DEPTH
 // k-th op of the last DP result in LIST order (head..tail).  The traceback emits from the alignment's far end towards
 // the anchor; the reference adds each op to the front (forward) or to the back (reverse), SW.cpp:1182-1195.
 __device__ __forceinline__ uint32_t dpOp(const WaveScratch &S, const DPOut &o, bool reverse, int k)
-{ return S.tmpOps[reverse ? k : (o.nOps - 1 - k)]; }
+{ return toGlobal(S.tmpOps)[reverse ? k : (o.nOps - 1 - k)]; }
 
 #define TR_U 0xFFFFu
 
@@ -44,6 +63,7 @@ __device__ __noinline__ DPOut dpGeneric(const DevParams &P, const uint8_t *__res
                                         int bandwidth, int left, int right, int W, const WaveScratch &S)
 {
     DPOut out = {0, 0, 0, 0, 0, 0};
+    PROF_T0();
     const int GO = uni(P.GO), GE = uni(P.GE), RC = uni(P.RC), MS = uni(P.MS), maxIntron = uni(P.maxIntron), maxGapP = uni(P.maxGap), XC = uni(P.X);
     if ((long)(qLen + 1) * W > (long)S.traceRows * 64) { *S.err = YERR_TRACE; return out; }
     if (W > S.genCap) { *S.err = YERR_GEN; return out; }
@@ -113,6 +133,7 @@ __device__ __noinline__ DPOut dpGeneric(const DevParams &P, const uint8_t *__res
     if (n < S.tmpCap) S.tmpOps[n] = opMake(prev, opLenAcc); n++;
     if (n > S.tmpCap) { *S.err = YERR_TMPOPS; out.score = 0; n = 0; }
     out.nOps = n;
+    PROF_ADD(PF_TRACEBACK);
     return out;
 }
 
@@ -145,8 +166,16 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
     if (W > 64 || (W - 1) > maxIntron) return dpGeneric(P, bases, q, banded, ext, rev, rOff, rLen, qOff, qLen, bandwidth, left, right, W, S);
     if (qLen + 1 > S.traceRows) { *S.err = YERR_TRACE; return out; }
 
-    auto loadRef = [&](int idx) -> int { return (idx >= 0 && idx < rLen) ? (int)ref4(bases, rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx) : 0xFF; };
-    auto loadQ   = [&](int t) -> int { return (t < qLen) ? (int)q[rev ? qOff - t : qOff + t] : 0xFE; };
+    YD_GLOBAL const uint8_t *gBases = toGlobal(bases), *gQ = toGlobal(q);
+    YD_GLOBAL uint16_t *trace = toGlobal(S.trace);
+    YD_LDS uint16_t *lds = (YD_LDS uint16_t *)S.ldsTrace;
+    const int Wp = W <= 32 ? 32 : 64, ldsRows = YD_LDS_CELLS / Wp;      // rows [0, ldsRows) of the strip are kept in LDS
+    auto loadRef = [&](int idx) -> int {
+        int v = 0xFF;
+        if (idx >= 0 && idx < rLen) { uint32_t off = rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx; uint32_t b = gBases[off >> 1]; v = (int)((off & 1u) ? (b & 0xFu) : (b >> 4)); }
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(v));             // consume the load here, so that no wait lands at the row-loop header
+        return v; };
+    auto loadQ   = [&](int t) -> int { int v = (t < qLen) ? (int)gQ[rev ? qOff - t : qOff + t] : 0xFE; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(v)); return v; };
 
     int PV, PF, PI = 0, rc;
     if (banded) { PV = lane == left ? 0 : (lane > left ? -(GO + (lane - left) * GE) : YD_WORST); PF = lane == left ? 0 : YD_WORST; rc = loadRef(lane - left); }
@@ -154,8 +183,8 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
     int rbuf = loadRef(lane), rcb = 0;          // stream of reference bases for the top lane of the strip
     int qbuf = loadQ(lane), qcb = 0;            // stream of query bases, one per row
     int maxScore = YD_WORST, maxi = 0, maxj = 0, lastEc = 0;
-    uint16_t *trace = S.trace;
     int rows = 0, cells = 0;
+    PROF_T0(); PROF_CNT(PF_DPCALLS);
     for (int i = 1; i <= qLen; ++i) {
         int sc, ec, bl;
         if (banded) { sc = left + 1 - i; bl = sc > 0 ? sc - 1 : -1; if (sc < 0) sc = 0; ec = min(left + rLen - i, W - 1); }
@@ -166,9 +195,9 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
         const bool active = lane >= sc && lane <= ec;
         int diag, upV, upF, upI;
         if (banded) {
-            diag = PV; upV = __shfl_down(PV, 1, 64); upF = __shfl_down(PF, 1, 64); upI = __shfl_down(PI, 1, 64);
+            diag = PV; upV = laneDown1(PV, YD_WORST); upF = laneDown1(PF, YD_WORST); upI = laneDown1(PI, 0);
             if (lane >= W - 1) { upV = YD_WORST; upF = YD_WORST; upI = 0; }
-        } else { diag = __shfl_up(PV, 1, 64); upV = PV; upF = PF; upI = PI; }
+        } else { diag = laneUp1(PV, YD_WORST); upV = PV; upF = PF; upI = PI; }
         const bool isM = (rc == qc);
         const int G = diag + (isM ? MS : -RC);
         const int CF = upF - GE, NF = upV - (GO + GE);
@@ -184,11 +213,13 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
         int V = G, op = isM ? OP_M : OP_R, len = 0;
         if (ext ? (E >= V) : (E > V)) { V = E; op = OP_D; len = D; }
         if (ext ? (F >= V) : (F > V)) { V = F; op = OP_I; len = I; }
-        if (active) { trace[i * 64 + lane] = (uint16_t)(op | (len << 2)); PV = V; PF = F; PI = I; }
+        if (active) { PV = V; PF = F; PI = I; }
+        if (i < ldsRows) { if (active) lds[i * Wp + lane] = (uint16_t)(op | (len << 2)); }
+        else if (active) trace[i * 64 + lane] = (uint16_t)(op | (len << 2));
         if (lane == bl) PV = bval;
         rows++; cells += (ec >= sc) ? (ec - sc + 1) : 0; if (ec >= sc) lastEc = ec;
         if (ext) {
-            const unsigned rk = waveMaxU(active ? (((unsigned)(V + YD_BIAS) << 6) | (unsigned)(63 - lane)) : 0u);
+            const unsigned rk = waveTotalMaxU(active ? (((unsigned)(V + YD_BIAS) << 6) | (unsigned)(63 - lane)) : 0u);
             int rv = YD_WORST, rj = 0;
             if (rk) { rv = (int)(rk >> 6) - YD_BIAS; rj = 63 - (int)(rk & 63u); }
             rv = uni(rv); rj = uni(rj);
@@ -199,11 +230,12 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
             const int ni = i + right;                                      // index the top lane needs for row i+1
             if (ni >= rcb + 64) { rcb += 64; rbuf = loadRef(rcb + lane); }
             const int nb = bcast(rbuf, ni - rcb);
-            rc = __shfl_down(rc, 1, 64);
+            rc = laneDown1(rc, 0xFF);
             if (lane == W - 1) rc = nb;
         }
     }
     out.rows = rows; out.cells = cells;
+    PROF_ADD(PF_DPROWS);
     YDBG("rows done %d cells %d maxScore %d maxi %d maxj %d\n", rows, cells, maxScore, maxi, maxj);
     int y, x, score;
     if (ext) { if (maxScore <= 0) return out; y = maxi; x = maxj; score = maxScore; out.addedQ = maxi; out.addedR = maxi + (maxj - bandwidth); }
@@ -219,19 +251,21 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
             if (yy == 0) { if (xx == 0) { code = -1; len = 0; } else { code = OP_D; len = xx; } return; }
             if (xx == 0) { code = OP_I; len = yy; return; }
         }
-        const unsigned c = uniU((unsigned)trace[yy * 64 + xx]); code = (int)(c & 3u); len = (int)(c >> 2);
+        const unsigned c = uniU(yy < ldsRows ? (unsigned)lds[yy * Wp + xx] : (unsigned)trace[yy * 64 + xx]); code = (int)(c & 3u); len = (int)(c >> 2);
     };
+    YD_GLOBAL uint32_t *gTmp = toGlobal(S.tmpOps);
     int code, len; cellAt(y, x, code, len);
     int prev = code, acc = 0, n = 0;
     for (int guard = 0; code >= 0; guard++) {
         if (guard > 200000 || y < 0 || x < 0 || x > 63) { *S.err = YERR_TRACE; out.score = 0; out.nOps = 0; return out; }
         if (banded) { if (code == OP_D) x -= len; else if (code == OP_I) { x += len; y -= len; } else { y -= 1; len = 1; } }
         else        { if (code == OP_D) x -= len; else if (code == OP_I) { y -= len; } else { x -= 1; y -= 1; len = 1; } }
-        if (prev != code) { if (n < S.tmpCap) S.tmpOps[n] = opMake(prev, acc); n++; prev = code; acc = len; } else acc += len;
+        if (prev != code) { if (n < S.tmpCap) gTmp[n] = opMake(prev, acc); n++; prev = code; acc = len; } else acc += len;
         cellAt(y, x, code, len);
     }
-    if (n < S.tmpCap) S.tmpOps[n] = opMake(prev, acc); n++;
+    if (n < S.tmpCap) gTmp[n] = opMake(prev, acc); n++;
     if (n > S.tmpCap) { *S.err = YERR_TMPOPS; out.score = 0; n = 0; }
     out.nOps = n;
+    PROF_ADD(PF_TRACEBACK);
     return out;
 }

@@ -159,7 +159,7 @@ static int stageChain(ygpu_ctx *ctx)
 
     EV0(T_CHAIN);
     uint32_t clumpCap = F + R / 2 + 1024, fragCap = 2 * F + 1024;
-    const unsigned waves = (unsigned)std::min<uint64_t>(std::max<uint32_t>(ctx->nMulti, 1u), (uint64_t)ctx->nCU * 8);
+    const unsigned waves = (unsigned)std::min<uint64_t>(std::max<uint32_t>(ctx->nMulti, 1u), (uint64_t)ctx->nCU * 24);     // latency-bound serial work: 6 waves per SIMD
     for (int attempt = 0;; attempt++) {
         ENSURE(ctx->clumps, sizeof(ChainClumpRec) * (uint64_t)clumpCap); ENSURE(ctx->clumpFrags, 16ull * fragCap);
         const int maxN = (int)std::max<uint32_t>(ctx->maxN, 2u);
@@ -207,7 +207,7 @@ static int stageAlign(ygpu_ctx *ctx)
         const size_t per = alignScratchBytes(ctx->maxQ, listCap, genCap);
         size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
         uint64_t maxWaves = std::max<uint64_t>(64, (uint64_t)((freeB + ctx->scratchAlign.cap) * 6 / 10) / per);
-        const unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * 8), maxWaves);
+        const unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * 12), maxWaves);      // 3 waves per SIMD (137 VGPRs)
         ENSURE(ctx->scratchAlign, per * waves);
         ENSURE(ctx->clumpFrags0, 16ull * (ctx->nClumpFrags + 1));
         HIPCHK(hipMemcpyAsync(ctx->clumpFrags0.p, ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
@@ -225,7 +225,15 @@ static int stageAlign(ygpu_ctx *ctx)
             A.outClumps = ctx->outClumps.as<ygpu_clump>(); A.outOps = ctx->outOps.as<uint32_t>(); A.outRoot = ctx->outRoot.as<uint32_t>(); A.outPush = ctx->outPush.as<uint32_t>();
             A.outCounts = cnt + CNT_OUTCLUMPS; A.outClumpCap = outClumpCap; A.outOpsCap = outOpsCap; A.rootPushCount = ctx->rootPush.as<unsigned int>();
             A.ctr = ctx->ctr.as<DevCounters>(); A.errFlag = ctx->errFlag.as<int>();
+#ifdef YD_PROF
+            { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); }
+#endif
             hipLaunchKernelGGL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
+#ifdef YD_PROF
+            { hipStreamSynchronize(ctx->stream); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
+              const char *nm[10] = {"root_total", "dp_rows", "traceback", "perfect_ext", "score", "emit", "split", "merge", "dp_calls", "roots"};
+              fprintf(stderr, "[YD_PROF] waves %u:", waves); for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", nm[i], z[i]); fprintf(stderr, "\n"); }
+#endif
             uint32_t got[2]; rc = fetchU32(ctx, cnt + CNT_OUTCLUMPS, got, 2); if (rc) return rc;
             uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
             if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
