@@ -34,6 +34,28 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def owner_of(ticket, world):
+    """Batches (tickets) are dealt round-robin to ranks / devices; reads are independent units."""
+    return ticket % world
+
+
+def merge_by_ticket(per_rank_parts):
+    """Ordered merge of the ranks' outputs: identical to the single-rank (`-t 1`) order."""
+    allp = {}
+    for d in per_rank_parts:
+        allp.update(d)
+    return "".join(allp[k] for k in sorted(allp))
+
+
+def max_over_ranks(value, dist, device="cuda"):
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def ensure_inputs(cache, genome_mbp, seed):
     """Genome FASTA + .nib2 + index in the cache directory (built once per node, reused by every rank/run)."""
     import yaha_amd as ya
@@ -159,10 +181,7 @@ def main():
             t = time.time(); r = ctx.collect(); t_down = time.time() - t
             counters = r.counters.as_dict()
             n_clumps = int(r.n_clumps)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, dist)
     if rank != 0:
         if dist is not None:
             dist.barrier()
