@@ -114,18 +114,21 @@ __global__ void k_region_starts(const uint32_t *isHead, const uint32_t *regIdx, 
     if (isHead[f]) regStart[regIdx[f]] = f;
 }
 // multi-fragment region list + largest region
-__global__ void k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN)
+// multiList: regions with 2..64 fragments (k_chain); bigList: more than 64 (k_chain_big)
+__global__ void k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nRegions) return;
     const uint32_t n = regStart[r + 1] - regStart[r];
-    if (n >= 2) { unsigned p = atomicAdd(nMulti, 1u); multiList[p] = r; atomicMax(maxN, n); }
+    if (n > 64) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }
+    else if (n >= 2) { unsigned p = atomicAdd(nMulti, 1u); multiList[p] = r; }
 }
 // order[base[region] + seq] = clump index  (rank of a root clump = creation order)
 __global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, const uint32_t *regionBase, uint32_t *order)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nClumps) return;
+    if (clumps[c].nFrags == 0xFFFFFFFFu) return;                              // unused slot of a wave's reservation chunk
     order[regionBase[clumps[c].region] + clumps[c].seq] = c;
 }
 // final layout: clump ci of root r with push number p goes to rootBase[r] + (pushCount[r] - 1 - p)

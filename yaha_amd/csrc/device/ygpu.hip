@@ -38,7 +38,7 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_N = 16 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_N = 16 };
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_N };
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout"};
 }  // namespace
@@ -51,11 +51,11 @@ struct ygpu_ctx {
     std::vector<uint32_t> hReadOff, hKmerOff;
     DevBuf dFwd, dRev, dReadOff, dKmerOff;
     // arenas
-    DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, regionCount, regionBase;
+    DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     // stage state
-    uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, maxN = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
+    uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
     // host results
     std::vector<uint32_t> hClumpStart, hOps, hClumpFragStart, hClumpRS, hDpOps; std::vector<ygpu_clump> hClumps; std::vector<ygpu_fragment> hFrags, hClumpFrags;
@@ -140,7 +140,7 @@ static int stageChain(ygpu_ctx *ctx)
     if (!F) return 0;
     int rc;
     // region boundaries (uses a second head/scan pair sized by F; the hit-level pair is still needed by buildFrags on a retry)
-    ENSURE(ctx->regStart, 4ull * (F + 2)); ENSURE(ctx->multiList, 4ull * (F + 1)); ENSURE(ctx->regionCount, 4ull * (F + 2)); ENSURE(ctx->regionBase, 4ull * (F + 2));
+    ENSURE(ctx->regStart, 4ull * (F + 2)); ENSURE(ctx->multiList, 4ull * (F + 1)); ENSURE(ctx->bigList, 4ull * (F / 64 + 2)); ENSURE(ctx->regionCount, 4ull * (F + 2)); ENSURE(ctx->regionBase, 4ull * (F + 2));
     DevBuf &rHead = ctx->rootPush, &rScan = ctx->rootBase;           // borrowed as temporaries (not yet in use at this point)
     ENSURE(rHead, 4ull * (F + 1)); ENSURE(rScan, 4ull * (F + 1));
     HIPCHK(hipMemsetAsync((uint32_t *)rHead.p + F, 0, 4, ctx->stream));
@@ -151,21 +151,25 @@ static int stageChain(ygpu_ctx *ctx)
     hipLaunchKernelGGL(k_region_starts, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, rHead.as<uint32_t>(), rScan.as<uint32_t>(), F, ctx->regStart.as<uint32_t>());
     HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
     uint32_t *cnt = ctx->counters.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_region_classify, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN);
+    HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NBIG, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_region_classify, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN, ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG);
     uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NMULTI, two, 2); if (rc) return rc;
     ctx->nMulti = two[0]; ctx->maxN = two[1];
+    rc = fetchU32(ctx, cnt + CNT_NBIG, &ctx->nBig); if (rc) return rc;
     EV1(T_FRAGS);
 
     EV0(T_CHAIN);
-    uint32_t clumpCap = F + R / 2 + 1024, fragCap = 2 * F + 1024;
+    uint32_t clumpCap = F + R / 2 + 1024 + 32 * (ctx->nCU * 27 + 64), fragCap = 2 * F + 1024 + 256 * (ctx->nCU * 27 + 64);   // + one open chunk per wave
     const unsigned waves = (unsigned)std::min<uint64_t>(std::max<uint32_t>(ctx->nMulti, 1u), (uint64_t)ctx->nCU * 24);     // latency-bound serial work: 6 waves per SIMD
+    const unsigned wavesBig = (unsigned)std::min<uint64_t>(std::max<uint32_t>(ctx->nBig, 1u), (uint64_t)ctx->nCU * 3);        // 40 KB of LDS each
     for (int attempt = 0;; attempt++) {
         ENSURE(ctx->clumps, sizeof(ChainClumpRec) * (uint64_t)clumpCap); ENSURE(ctx->clumpFrags, 16ull * fragCap);
         const int maxN = (int)std::max<uint32_t>(ctx->maxN, 2u);
         const size_t per = chainScratchBytes(maxN, ctx->maxQ);
-        ENSURE(ctx->scratchChain, per * waves);
+        ENSURE(ctx->scratchChain, per * wavesBig);
         HIPCHK(hipMemsetAsync(cnt + CNT_CLUMPS, 0, 12, ctx->stream));          // clumps, cfrags, qchain
+        HIPCHK(hipMemsetAsync(cnt + CNT_QBIG, 0, 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->clumps.p, 0xFF, sizeof(ChainClumpRec) * (uint64_t)clumpCap, ctx->stream));        // invalid until written
         HIPCHK(hipMemsetAsync(ctx->regionCount.p, 0, 4ull * (R + 1), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
         ChainArgs A; A.P = ctx->P; A.B = B; A.frags = ctx->frags.as<DevFrag>(); A.regStart = ctx->regStart.as<uint32_t>(); A.nRegions = R;
@@ -175,17 +179,19 @@ static int stageChain(ygpu_ctx *ctx)
         A.regionClumpCount = ctx->regionCount.as<uint32_t>(); A.errFlag = ctx->errFlag.as<int>(); A.ctr = ctx->ctr.as<DevCounters>();
         hipLaunchKernelGGL(k_regions_single, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, A);
         if (ctx->nMulti) hipLaunchKernelGGL(k_chain, dim3(waves), dim3(64), 0, ctx->stream, A);
+        if (ctx->nBig) hipLaunchKernelGGL(k_chain_big, dim3(wavesBig), dim3(64), 0, ctx->stream, A, ctx->bigList.as<uint32_t>(), ctx->nBig, cnt + CNT_QBIG);
         uint32_t got[2]; rc = fetchU32(ctx, cnt + CNT_CLUMPS, got, 2); if (rc) return rc;
         uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
-        if (ef == 0) { ctx->nClumps = got[0]; ctx->nClumpFrags = got[1]; break; }
+        if (ef == 0 && got[0] <= clumpCap && got[1] <= fragCap) { ctx->nClumpSlots = got[0]; ctx->nClumpFrags = got[1]; break; }
         if (attempt >= 6) { ctx->err = "chain stage: arena overflow persists"; return YGPU_EOVERFLOW; }
         clumpCap *= 2; fragCap *= 2;                                           // grow and redo: the fragment array was modified in place
         rc = buildFrags(ctx); if (rc) return rc;
     }
     // creation-order rank of every root clump
     rc = cubScan(ctx, ctx->regionCount.as<uint32_t>(), ctx->regionBase.as<uint32_t>(), R + 1); if (rc) return rc;
+    rc = fetchU32(ctx, ctx->regionBase.as<uint32_t>() + R, &ctx->nClumps); if (rc) return rc;          // clumps actually formed (slots minus chunk slack)
     ENSURE(ctx->order, 4ull * (ctx->nClumps + 1));
-    if (ctx->nClumps) hipLaunchKernelGGL(k_clump_order, dim3(gridFor(ctx->nClumps, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->nClumps, ctx->regionBase.as<uint32_t>(), ctx->order.as<uint32_t>());
+    if (ctx->nClumpSlots) hipLaunchKernelGGL(k_clump_order, dim3(gridFor(ctx->nClumpSlots, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->nClumpSlots, ctx->regionBase.as<uint32_t>(), ctx->order.as<uint32_t>());
     EV1(T_CHAIN);
     return 0;
 }
@@ -308,7 +314,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
     if (ctx->stream) {
         hipSetDevice(ctx->device);
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->isHead, &ctx->scanOut,
-                         &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
+                         &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
                          &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps};
         for (auto b : all) b->release();
@@ -399,9 +405,9 @@ int ygpu_chain(ygpu_ctx *ctx, const ygpu_fragment **clump_frags, const uint32_t 
     if (!ctx || !ctx->stream) return YGPU_EINVAL;
     ctx->stageDone = 0; int rc = runTo(ctx, 2); if (rc) return rc;
     const uint32_t NC = ctx->nClumps;
-    std::vector<ChainClumpRec> recs(NC); std::vector<uint32_t> order(NC); std::vector<ygpu_fragment> cf(ctx->nClumpFrags);
+    std::vector<ChainClumpRec> recs(ctx->nClumpSlots); std::vector<uint32_t> order(NC); std::vector<ygpu_fragment> cf(ctx->nClumpFrags);
     if (NC) {
-        HIPCHK(hipMemcpy(recs.data(), ctx->clumps.p, sizeof(ChainClumpRec) * (uint64_t)NC, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(recs.data(), ctx->clumps.p, sizeof(ChainClumpRec) * (uint64_t)ctx->nClumpSlots, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(order.data(), ctx->order.p, 4ull * NC, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(cf.data(), ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToHost));
     }
