@@ -256,10 +256,33 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
     YD_GLOBAL uint32_t *gTmp = toGlobal(S.tmpOps);
     int code, len; cellAt(y, x, code, len);
     int prev = code, acc = 0, n = 0;
+    // The path is mostly straight runs of M/R cells (same strip column in banded mode, the diagonal in full mode).  64 cells of
+    // the run are examined per step: lane l looks at the cell l rows up; a ballot finds where the run ends and which cells
+    // are replacements; the run-length encoding of that bit string is scalar work.  Only D/I and boundary cells take the
+    // one-cell path below.  Same emission rule as the reference loop (SW.cpp:1154-1195).
     for (int guard = 0; code >= 0; guard++) {
         if (guard > 200000 || y < 0 || x < 0 || x > 63) { *S.err = YERR_TRACE; out.score = 0; out.nOps = 0; return out; }
-        if (banded) { if (code == OP_D) x -= len; else if (code == OP_I) { x += len; y -= len; } else { y -= 1; len = 1; } }
-        else        { if (code == OP_D) x -= len; else if (code == OP_I) { y -= len; } else { x -= 1; y -= 1; len = 1; } }
+        if (code <= OP_R) {
+            const int yy = y - lane, xx = banded ? x : x - lane;
+            bool valid = yy >= 1 && (banded ? (xx != left - yy) : (xx >= 1));
+            unsigned c = 3u;
+            if (valid) c = yy < ldsRows ? (unsigned)lds[yy * Wp + xx] : (unsigned)trace[yy * 64 + xx];
+            const bool isMR = valid && (c & 3u) < 2u;
+            const unsigned long long stop = __ballot(!isMR), rb = __ballot(isMR && (c & 3u) == (unsigned)OP_R);
+            const int run = stop ? __builtin_ctzll(stop) : 64;          // >= 1: the current cell is M or R
+            for (int pos = 0; pos < run; ) {
+                const int bit = (int)((rb >> pos) & 1ull);
+                const unsigned long long rest = (bit ? ~rb : rb) >> pos;
+                int seg = rest ? __builtin_ctzll(rest) : 64; if (seg > run - pos) seg = run - pos;
+                const int cd = bit ? OP_R : OP_M;
+                if (prev != cd) { if (n < S.tmpCap) gTmp[n] = opMake(prev, acc); n++; prev = cd; acc = seg; } else acc += seg;
+                pos += seg;
+            }
+            y -= run; if (!banded) x -= run;
+            cellAt(y, x, code, len);
+            continue;
+        }
+        if (code == OP_D) x -= len; else y -= len, x += banded ? len : 0;  // D: back along the row; I: up `len` rows
         if (prev != code) { if (n < S.tmpCap) gTmp[n] = opMake(prev, acc); n++; prev = code; acc = len; } else acc += len;
         cellAt(y, x, code, len);
     }
