@@ -134,6 +134,34 @@ struct Aligner {
         len += cnt; __threadfence_block();
     }
 
+    // the same two merges with the source already in list order in HBM (ext_lanes.h results)
+    __device__ void mergeBackSrc(uint32_t *b, int start, int &len, const uint32_t *src, int cnt)
+    {
+        if (cnt <= 0) return;
+        int t0 = 0;
+        if (len > 0) {
+            uint32_t last = b[start + len - 1], first = uniU(src[0]);
+            if (opCode(last) == opCode(first)) { b[start + len - 1] = opMake(opCode(last), (opLen(last) + opLen(first)) & 0xFFFF); t0 = 1; }
+        }
+        const int n = cnt - t0;
+        if (start + len + n > A.listCap) { err = YERR_ARENA; return; }
+        for (int k = lane; k < n; k += 64) b[start + len + k] = src[t0 + k];
+        len += n; __threadfence_block();
+    }
+    __device__ void mergeFrontSrc(uint32_t *b, int &start, int &len, const uint32_t *src, int cnt)
+    {
+        if (cnt <= 0) return;
+        int t1 = cnt;
+        if (len > 0) {
+            uint32_t first = b[start], last = uniU(src[cnt - 1]);
+            if (opCode(first) == opCode(last)) { b[start] = opMake(opCode(first), (opLen(first) + opLen(last)) & 0xFFFF); t1--; }
+        }
+        if (start - t1 < 0) { err = YERR_ARENA; return; }
+        start -= t1;
+        for (int k = lane; k < t1; k += 64) b[start + k] = src[k];
+        len += t1; __threadfence_block();
+    }
+
     __device__ DPOut runDP(int mode, uint32_t rOff, int rLen, int qOff, int qLen)
     {
         DPOut o = dpWave(P, A.bases, q, mode, rOff, rLen, qOff, qLen, S);
@@ -188,9 +216,10 @@ struct Aligner {
     }
 
     // extendClumpForwardReverseTemplated<goBack,goForw,goCarefully>, AlignExtFrag.cpp:64-144
-    __device__ void extendClump(Frame &f, uint32_t *b, bool goBack, bool goForw, bool carefully)
+    // first half: exact-match extensions (lines 76-107); returns the lengths still open for the DP extensions
+    __device__ void extendPerfect(Frame &f, uint32_t *b, bool goBack, bool goForw, int &backLen, int &forwLen)
     {
-        int score = f.score, backLen = 0, forwLen = 0;
+        int score = f.score; backLen = 0; forwLen = 0;
         if (goBack) {
             uint32_t bl = (uint32_t)f.sqo < f.sro ? (uint32_t)f.sqo : f.sro; backLen = (int)bl;
             if (backLen > 0) {
@@ -206,7 +235,12 @@ struct Aligner {
                 if (m > 0) { int li = f.start + f.len - 1; b[li] = opMake(opCode(b[li]), (opLen(b[li]) + m) & 0xFFFF); score += m * P.MS; forwLen -= m; f.eqo += m; f.refLen = (f.refLen + m) & 0xFFFF; }
             }
         }
-        int aQ = 0, aR = 0;
+        f.score = score; backLen = uni(backLen); forwLen = uni(forwLen);
+    }
+    __device__ void extendClump(Frame &f, uint32_t *b, bool goBack, bool goForw, bool carefully)
+    {
+        int backLen, forwLen; extendPerfect(f, b, goBack, goForw, backLen, forwLen);
+        int score = f.score, aQ = 0, aR = 0;
         if (goBack && backLen >= P.minExtLength) {
             int ns;
             if (carefully) ns = backCarefully(f, b, f.sro - 1u, (f.sqo - 1) & 0xFFFF, backLen & 0xFFFF, score, aQ, aR);
@@ -223,7 +257,8 @@ struct Aligner {
     }
 
     // alignClump, AlignHelpers.c:205-272 (+ makeAndAlignSFragmentToFillGap AlignExtFrag.cpp:164-234, collapseSFragments :274-300)
-    __device__ void alignRoot(const ChainClumpRec &rec, Frame &f)
+    // everything of alignClump before extendClumpForwardReverse
+    __device__ void alignRootPre(const ChainClumpRec &rec, Frame &f)
     {
         DevFrag *F = A.clumpFrags + rec.fragOff; const int n = (int)rec.nFrags;
         for (int k = 1; k < n; k++) {
@@ -259,8 +294,12 @@ struct Aligner {
         const DevFrag f0 = F[0], fn = F[n - 1];
         f.sro = f0.sro; f.sqo = f0.sqo; f.eqo = fn.eqo; f.refLen = (int)((1u + ero(fn.sro, fn.refLen) - f0.sro) & 0xFFFFu);
         f.score = total; f.status = (rec.rs & 1u) ? stReversed : 0; f.phase = PH_NONE;
+    }
+    __device__ void alignRoot(const ChainClumpRec &rec, Frame &f)
+    {
+        alignRootPre(rec, f);
         if (err) return;
-        extendClump(f, b, true, true, false);
+        extendClump(f, buf(0), true, true, false);
         f.status |= stAligned;
     }
 
@@ -327,8 +366,19 @@ struct Aligner {
         const uint32_t read = rec.rs >> 1; const uint32_t r0 = A.B.readOff[read];
         qlen = (int)(A.B.readOff[read + 1] - r0); q = ((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0;
         rootRank = rank; pushes = 0;
-        Frame f; int depth = 0;
+        Frame f;
         alignRoot(rec, f);
+        finishRoot(f);
+    }
+    __device__ void setRead(const ChainClumpRec &rec)
+    {
+        const uint32_t read = rec.rs >> 1; const uint32_t r0 = A.B.readOff[read];
+        qlen = (int)(A.B.readOff[read + 1] - r0); q = ((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0;
+    }
+    // scoreClump / splitClump state machine on an aligned clump (frame 0)
+    __device__ void finishRoot(Frame f)
+    {
+        int depth = 0;
         // per-frame results of the last scoreList
         int sm = -1, smm = 0, sg = 0, sl = 0, ss = 0;
         enum { ST_SCORE, ST_SPLIT_ENTER, ST_SPLIT_TAIL, ST_SPLIT_CORE, ST_RETURN } state = ST_SCORE;

@@ -1,0 +1,379 @@
+// ext_lanes.h -- the X-drop extensions of alignClump (reference extendClumpForwardReverse -> findAGSForward/BackwardExtension
+// -> findAffineGapScore<banded, extension>, AlignExtFrag.cpp:109-141, SW.cpp:479-516, 798-1208) as ONE PROBLEM PER LANE.
+//
+// These two calls per root clump are >90 % of all DP cells of the hot path, and their strip is narrow (W = 4*BW + 1 = 21
+// columns for the default -BW 5), so columns-as-lanes (dp_wave.h) leaves 2/3 of the wave idle and pays a cross-lane scan
+// per row.  Here every lane runs the reference's sequential recurrence for its own problem with the whole strip
+// (PV/PF/PI of 21 columns) in registers: no cross-lane traffic at all, the serial E/D chain is just program order, the
+// run caps (maxIntron / maxGap) are applied exactly.  Lanes pull new problems from a queue as they finish (X-drop makes
+// the lengths very uneven), one wave-aggregated atomic per refill.
+//
+//   k_ext_rows   forward pass.  Per row and lane: 1 query byte, 1 reference nibble, 21 cells, one 12-byte trace row
+//                (4 bits per cell: op | E-run-continues | F-run-continues) into the problem's HBM strip.
+//   k_ext_trace  lane per problem: walks the trace (run lengths are recovered from the continue bits), two passes
+//                (count, then write into one batch-wide op arena in list order).
+//
+// The kernel is specialised for the default band (-BW 5: bandwidth 10, W = 21, origin column 10) and needs maxGap >= 10.
+// The reference's boundary insertions V(i, left - i) = -(GO + i*GE) are not special-cased: with PF(0, left) = -GO the
+// ordinary F recurrence produces exactly that chain (F = -(GO + i*GE), I = i, op I), and every cell left of it stays at
+// the "worst" sentinel, so all 21 columns run the same code on every row.  Cells outside [startCol, endCol] are only
+// masked out of the row maximum.  Wider bands, and all gap-fill and "careful" calls, stay on dp_wave.h.
+#pragma once
+#include "align.h"
+
+#define YD_LW 21                               // register columns of the lane kernel = strip width for -BW 5
+#define YD_LBAND 10                            // extension bandwidth 2 * BW = columns left and right of the origin
+#define YD_LWORST (-(1 << 28))                 // sentinel: far below any reachable score (|score| < 2^23), no overflow when it decays
+
+struct ExtProb { uint32_t qBase, rOff; uint16_t qOff, qLen; uint32_t flags; };           // 16 B; qBase = offset of the read in fwd/rev
+enum { XP_STRAND = 1, XP_REV = 2, XP_VALID = 4 };
+struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, rLen, pad0, pad1; };       // 32 B; maxj in register columns
+
+struct ExtArgs {
+    DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
+    const ExtProb *probs; uint32_t nProb; const unsigned long long *stripOff; unsigned long long stripBase;
+    uint32_t *trace;                            // 3 dwords per row
+    ExtRes *res; unsigned int *queue; DevCounters *ctr;
+    uint32_t *ops; unsigned int *opsCount; uint32_t opsCap; int *errFlag;
+};
+
+__global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
+{
+    const int lane = laneId();
+    const int GO = A.P.GO, GE = A.P.GE, GOE = A.P.GO + A.P.GE, RC = A.P.RC, MS = A.P.MS, XC = A.P.X, maxIntron = A.P.maxIntron, maxGap = A.P.maxGap;
+    constexpr int bandwidth = YD_LBAND, leftR = YD_LBAND;
+    const uint32_t maxROff = A.P.maxROff;
+    YD_GLOBAL const uint8_t *gBases = toGlobal(A.bases);
+    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+
+    // The strip state lives in registers and is written by the row code only (a fresh problem selects its row-0 values at
+    // the top of its first row): one definition per loop iteration keeps the register allocator from duplicating it.
+    int PV[YD_LW], PF[YD_LW], PI[YD_LW];
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+    int p = -1, i = 0, qLen = 0, rLen = 0, maxScore = YD_LWORST, maxi = 0, maxj = 0, qStep = 0, qcNext = 0;
+    uint32_t rOff = 0; bool rev = false, done = false, fresh = false;
+    YD_GLOBAL const uint8_t *q = toGlobal(A.fwd); YD_GLOBAL uint32_t *strip = toGlobal(A.trace);
+    unsigned calls = 0, rows = 0, cells = 0;
+#pragma unroll
+    for (int j = 0; j < YD_LW; j++) { PV[j] = YD_LWORST; PF[j] = YD_LWORST; PI[j] = 0; }
+
+    // Pool of claimed problems: lane l holds entry l, completely set up (clamped lengths, first reference window, first
+    // query base), so that handing an entry to an idle lane is eight cross-lane moves and no memory latency.  One atomic
+    // and one round of dependent loads per 64 problems.
+    unsigned poolBase = 0; int poolCount = 0, poolNext = 0; bool exhausted = false;
+    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, eSLo = 0, eSHi = 0;
+    // deferred stores (see the row code)
+    bool pendRow = false; YD_GLOBAL uint32_t *pendAddr = toGlobal(A.trace); uint32_t pt0 = 0, pt1 = 0, pt2 = 0; int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0;
+
+    for (;;) {
+        // ---- refill: until every lane is busy or nothing is left ----
+        for (;;) {
+            const unsigned long long need = __ballot(p < 0 && !done);
+            if (!need) break;
+            if (poolNext >= poolCount) {                                     // wave-uniform: claim and set up the next 64 problems
+                unsigned base = 0;
+                if (!exhausted) { if (lane == 0) base = atomicAdd(A.queue, 64u); base = uniU(base); if (base >= A.nProb) exhausted = true; }
+                if (exhausted) { if (p < 0) done = true; break; }
+                poolBase = base; poolCount = (int)min(64u, A.nProb - base); poolNext = 0;
+                eLens = 0;
+                if (lane < poolCount) {
+                    const unsigned np = base + (unsigned)lane;
+                    const ExtProb pr = A.probs[np];
+                    int ql = 0; uint32_t rl = 0; const bool rv_ = (pr.flags & XP_REV) != 0;
+                    if (pr.flags & XP_VALID) {                              // findAGSExtension, SW.cpp:479-516
+                        calls++;
+                        ql = pr.qLen;
+                        rl = (uint32_t)(ql + bandwidth);
+                        if (rv_ && rl > pr.rOff) { rl = pr.rOff + 1; ql = (int)rl - bandwidth; }
+                        if (!rv_ && (pr.rOff + rl) > maxROff) { rl = maxROff - pr.rOff; ql = (int)rl - bandwidth; }
+                        if (ql > 0) { ql &= 0xFFFF; rl &= 0xFFFF; }
+                    }
+                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0; A.res[np] = r; }
+                    else {
+                        eLens = (uint32_t)ql | (rl << 16); eROff = pr.rOff; eQ = pr.qBase + pr.qOff;
+                        YD_GLOBAL const uint8_t *qp = toGlobal((pr.flags & XP_STRAND) ? A.rev : A.fwd) + eQ;
+                        eMisc = (pr.flags & 3u) | ((uint32_t)qp[0] << 8);
+                        const unsigned long long so = A.stripOff[np] - A.stripBase; eSLo = (uint32_t)so; eSHi = (uint32_t)(so >> 32);
+                        // reference window of row 1: register column c holds reference index c - leftR
+                        eW1 = 0; eW2 = 0;
+                        for (int c = leftR; c < YD_LW; c++) {
+                            const int idx = c - leftR; uint32_t nib = 15u;
+                            if (idx < (int)rl) { const uint32_t off = rv_ ? pr.rOff - (uint32_t)idx : pr.rOff + (uint32_t)idx; const uint32_t b = gBases[off >> 1]; nib = (off & 1u) ? (b & 15u) : (b >> 4); }
+                            const uint32_t sh = (uint32_t)(c & 7) * 4u;
+                            if (c < 16) eW1 |= nib << sh; else eW2 |= nib << sh;
+                        }
+                    }
+                }
+            }
+            // the k-th idle lane takes entry poolNext + k
+            const int nNeed = __builtin_popcountll(need), avail = poolCount - poolNext;
+            const int e = poolNext + __builtin_popcountll(need & lanesBelow);
+            const bool take = (p < 0 && !done) && e < poolCount;
+            const int src = take ? e : lane;
+            const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
+            const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64), gSLo = (uint32_t)__shfl((int)eSLo, src, 64), gSHi = (uint32_t)__shfl((int)eSHi, src, 64);
+            if (take && gLens != 0u) {
+                p = (int)(poolBase + (unsigned)e); qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
+                rev = (gMisc & XP_REV) != 0; rOff = gROff; fresh = true;
+                q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu);
+                strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 3ull;
+                w0 = 0; w1 = gW1; w2 = gW2;
+            }
+            poolNext += nNeed < avail ? nNeed : avail;
+        }
+        if (__ballot(p >= 0) == 0ull) break;
+
+        // ---- one DP row in every lane (lanes without a problem run on idle state; their stores are masked) ----
+        // All memory operations of an iteration are issued here at the top: the previous row's trace cells and a finished
+        // problem's result (both deferred), and the loads the row needs at its END (next query base, next reference base).
+        // The wait the compiler puts at the loop header then finds them ~1000 instructions old.
+        if (pendRow) { pendAddr[0] = pt0; pendAddr[1] = pt1; pendAddr[2] = pt2; pendRow = false; }
+        if (pendRes >= 0) {
+            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0;
+            A.res[pendRes] = r; pendRes = -1;
+        }
+        const bool busy = p >= 0;
+        ++i;
+        const int qc = qcNext;
+        { const int ni = i < qLen ? i : (qLen > 0 ? qLen - 1 : 0); qcNext = (int)q[ni * qStep]; }   // next row's query base
+        uint32_t nbByte, nbOdd;                                                                     // next row's top reference base (index i + right)
+        { const int idx = i + bandwidth; const bool in = busy && idx < rLen; const uint32_t off = in ? (rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx) : 0u;
+          nbByte = gBases[off >> 1]; nbOdd = in ? (off & 1u) : 2u; }
+        int sc = leftR + 1 - i; if (sc < 0) sc = 0;
+        int ec = leftR + rLen - i; if (ec > YD_LW - 1) ec = YD_LW - 1;
+        const uint32_t am = ec >= sc ? ((2u << ec) - 1u) & ~((1u << sc) - 1u) : 0u;
+        if (busy) { rows++; cells += ec >= sc ? (unsigned)(ec - sc + 1) : 0u; }
+        int PVCol = YD_LWORST, PE = YD_LWORST, PD = 0;
+        uint32_t t0 = 0, t1 = 0, t2 = 0, rowKey = 0;
+        // predecessor row of column 0 (row 0 of a fresh problem: SW.cpp:905-935 with PF(0, left) = -GO, see the header)
+        int dV = fresh ? YD_LWORST : PV[0];
+#pragma unroll
+        for (int j = 0; j < YD_LW; j++) {
+            const uint32_t wsrc = j < 8 ? w0 : (j < 16 ? w1 : w2);
+            const int rc = (int)((wsrc >> ((j & 7) * 4)) & 15u);
+            const bool eq = rc == qc;
+            int V = dV + (eq ? MS : -RC);
+            const int CE = PE - GE, NE = PVCol - GOE;
+            const bool cE = CE >= NE && PD < maxIntron;
+            PE = cE ? CE : NE; PD = cE ? PD + 1 : 1;
+            const bool tE = PE >= V; V = tE ? PE : V;
+            int upV, upF, upI;
+            if (j + 1 < YD_LW) {
+                const int k = j + 1;
+                const int iV = k == leftR ? 0 : (k > leftR ? -(GO + (k - leftR) * GE) : YD_LWORST), iF = k == leftR ? -GO : YD_LWORST;
+                upV = fresh ? iV : PV[k]; upF = fresh ? iF : PF[k]; upI = fresh ? 0 : PI[k];
+            } else { upV = YD_LWORST; upF = YD_LWORST; upI = 0; }
+            const int CF = upF - GE, NF = upV - GOE;
+            const bool cF = CF >= NF && upI < maxGap;
+            const int F = cF ? CF : NF, I = cF ? upI + 1 : 1;
+            const bool tF = F >= V; V = tF ? F : V;
+            uint32_t nib = eq ? (uint32_t)OP_M : (uint32_t)OP_R; nib = tE ? (uint32_t)OP_D : nib; nib = tF ? (uint32_t)OP_I : nib;
+            nib |= (cE ? 4u : 0u) | (cF ? 8u : 0u);
+            if (j < 8) t0 |= nib << ((j & 7) * 4); else if (j < 16) t1 |= nib << ((j & 7) * 4); else t2 |= nib << ((j & 7) * 4);
+            // row-major first maximum over the real cells: key = (V + BIAS) << 5 | (31 - j)
+            const uint32_t key = (((uint32_t)(V + YD_BIAS)) << 5 | (uint32_t)(31 - j)) & (uint32_t)(-(int)((am >> j) & 1u));
+            rowKey = key > rowKey ? key : rowKey;
+            PV[j] = V; PF[j] = F; PI[j] = I; PVCol = V;
+            dV = upV;                                                        // the next column's diagonal predecessor
+        }
+        fresh = false;
+        if (busy) { pendRow = true; pendAddr = strip + (size_t)(i - 1) * 3u; pt0 = t0; pt1 = t1; pt2 = t2; }
+        int rv = YD_LWORST, rj = 0;
+        if (rowKey) { rv = (int)(rowKey >> 5) - YD_BIAS; rj = 31 - (int)(rowKey & 31u); }
+        if (rv > maxScore) { maxScore = rv; maxi = i; maxj = rj; }
+        // slide the window: column c takes column c+1, the top column takes the new base
+        const uint32_t nb = nbOdd == 2u ? 15u : (nbOdd ? (nbByte & 15u) : (nbByte >> 4));
+        w0 = (w0 >> 4) | (w1 << 28); w1 = (w1 >> 4) | (w2 << 28); w2 = (w2 >> 4) | (nb << 16);
+        if (busy && (rv < maxScore - XC || i >= qLen)) {
+            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj;
+            p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
+        }
+    }
+    // the last deferred stores
+    if (pendRow) { pendAddr[0] = pt0; pendAddr[1] = pt1; pendAddr[2] = pt2; }
+    if (pendRes >= 0) {
+        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0;
+        A.res[pendRes] = r;
+    }
+    // work counters
+    unsigned c0 = (unsigned)waveSumI((int)calls), c1 = (unsigned)waveSumI((int)rows);
+    unsigned long long cc = cells;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { cc += (unsigned long long)__shfl_xor((long long)cc, d, 64); }
+    if (lane == 0) {
+        unsigned long long *c = A.ctr->v;
+        atomicAdd(&c[C_EXT_CALLS], (unsigned long long)c0); atomicAdd(&c[C_EXT_ROWS], (unsigned long long)c1); atomicAdd(&c[C_EXT_CELLS], cc);
+        atomicAdd(&c[C_TOUCHED], (unsigned long long)c1 + (unsigned long long)c0 * (unsigned long long)(4 * A.P.bandWidth + 1));
+    }
+}
+
+// ---- traceback, lane per problem (SW.cpp:1138-1195) -----------------------------------------------------------------
+struct ExtRowBits { uint32_t a, b, c; };
+__device__ __forceinline__ ExtRowBits extLoadRow(YD_GLOBAL const uint32_t *strip, int y) { ExtRowBits r; YD_GLOBAL const uint32_t *t = strip + (size_t)(y - 1) * 3u; r.a = t[0]; r.b = t[1]; r.c = t[2]; return r; }
+__device__ __forceinline__ uint32_t extNib(const ExtRowBits &r, int x) { const uint32_t w = x < 8 ? r.a : (x < 16 ? r.b : r.c); return (w >> ((x & 7) * 4)) & 15u; }
+
+// Walks from (y, x) back to the origin (0, leftR).  Emission order = far end first; list position of emission k is k for
+// the backward extension (ops are added to the back, SW.cpp:1190) and n-1-k for the forward one (added to the front).
+template <bool WRITE>
+__device__ __forceinline__ int extWalk(YD_GLOBAL const uint32_t *strip, int y, int x, int leftR, uint32_t *out, int nTotal, bool rev)
+{
+    int prev = -1, acc = 0, n = 0;
+    auto flush = [&]() { if (WRITE) out[rev ? n : nTotal - 1 - n] = opMake(prev, acc); n++; };
+    auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
+    for (int guard = 0; guard < 70000; guard++) {
+        if (y <= 0) { if (x > leftR) put(OP_D, x - leftR); break; }
+        if (x < 0 || x >= YD_LW) break;
+        ExtRowBits r = extLoadRow(strip, y);
+        const uint32_t nib = extNib(r, x); const int op = (int)(nib & 3u);
+        if (op < OP_D) { put(op, 1); y -= 1; }
+        else if (op == OP_D) {
+            int run = 1, xx = x;
+            while (extNib(r, xx) & 4u) { xx--; if (xx < 0) break; run++; }
+            put(OP_D, run); x -= run;
+        } else {
+            int run = 1, yy = y, xx = x; uint32_t nb2 = nib;
+            while (nb2 & 8u) { yy--; xx++; if (yy <= 0 || xx >= YD_LW) break; run++; const ExtRowBits r2 = extLoadRow(strip, yy); nb2 = extNib(r2, xx); }
+            put(OP_I, run); y -= run; x += run;
+        }
+    }
+    if (prev >= 0) flush();
+    return n;
+}
+
+__global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
+{
+    const int lane = laneId();
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int leftR = YD_LBAND;
+    ExtRes r; r.score = 0; bool live = false; bool rev = false; YD_GLOBAL const uint32_t *strip = nullptr;
+    if (p < A.nProb) { r = A.res[p]; live = r.score > 0; }
+    int n = 0;
+    if (live) {
+        rev = (A.probs[p].flags & XP_REV) != 0;
+        strip = toGlobal(A.trace) + (A.stripOff[p] - A.stripBase) * 3ull;
+        n = extWalk<false>(strip, r.maxi, r.maxj, leftR, nullptr, 0, rev);
+    }
+    // wave-aggregated reservation in the op arena
+    int incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const int total = __shfl(incl, 63, 64);
+    unsigned base = 0;
+    if (total > 0) {
+        if (lane == 63) base = atomicAdd(A.opsCount, (unsigned)total);
+        base = (unsigned)__shfl((int)base, 63, 64);
+        if ((unsigned long long)base + (unsigned)total > (unsigned long long)A.opsCap) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_OUT); return; }
+    }
+    if (live) {
+        const uint32_t off = base + (uint32_t)(incl - n);
+        extWalk<true>(strip, r.maxi, r.maxj, leftR, A.ops + off, n, rev);
+        r.opsOff = off; r.nOps = (uint32_t)n; A.res[p] = r;
+    }
+}
+
+// ---- phase 1 / phase 3 around the lane kernels: wave per root -------------------------------------------------------
+struct RootState { Frame f; uint32_t listOff; int backLen, forwLen; };
+struct PhaseArgs {
+    RootState *state; uint32_t *stateOps; unsigned int *stateOpsCount; uint32_t stateOpsCap;
+    ExtProb *probs; unsigned long long *rowsBound;      // 2 per root
+    const ExtRes *res; const uint32_t *extOps;
+};
+#define YD_STATE_CHUNK 2048
+
+// alignClump up to and including the exact-match extensions; leaves the two X-drop extension problems for k_ext_rows
+__global__ void __launch_bounds__(64) k_align_p1(AlignArgs A, PhaseArgs X)
+{
+    const unsigned wave = blockIdx.x; const int lane = laneId();
+    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
+    __shared__ uint16_t sTrace[YD_LDS_CELLS];
+    Aligner al(A, M, sTrace);
+    PROF_INIT();
+    const unsigned nRoots = uniU(A.nRoots);
+    unsigned chunkPos = 0, chunkEnd = 0;                                     // this wave's reservation in stateOps
+    for (;;) {
+        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(A.queueHead, 4u);
+        const unsigned r0 = uniU(t);
+        if (r0 >= nRoots) break;
+        const unsigned r1 = min(r0 + 4u, nRoots);
+        for (unsigned r = r0; r < r1; r++) {
+            const ChainClumpRec rec = A.clumps[A.order[r]];
+            al.setRead(rec); al.rootRank = r; al.pushes = 0;
+            Frame f; al.alignRootPre(rec, f);
+            int backLen = 0, forwLen = 0;
+            if (!UNI_B(al.err != 0)) al.extendPerfect(f, al.buf(0), true, true, backLen, forwLen);
+            if (UNI_B(al.err != 0)) break;
+            const unsigned need = (unsigned)uni(f.len);
+            if (chunkPos + need > chunkEnd) {
+                const unsigned want = need > YD_STATE_CHUNK ? need : YD_STATE_CHUNK; unsigned b = 0;
+                if (lane == 0) b = atomicAdd(X.stateOpsCount, want);
+                b = uniU(b); chunkPos = b; chunkEnd = b + want;
+                if (chunkEnd > X.stateOpsCap) { al.err = YERR_OUT; break; }
+            }
+            const uint32_t *b = al.buf(0);
+            for (int k = lane; k < f.len; k += 64) X.stateOps[chunkPos + k] = b[f.start + k];
+            if (lane == 0) {
+                RootState s; s.f = f; s.listOff = chunkPos; s.backLen = backLen; s.forwLen = forwLen; X.state[r] = s;
+                const uint32_t qBase = A.B.readOff[rec.rs >> 1]; const uint32_t strand = (rec.rs & 1u) ? XP_STRAND : 0u;
+                const bool vb = backLen >= A.P.minExtLength, vf = forwLen >= A.P.minExtLength;
+                ExtProb pb; pb.qBase = qBase; pb.rOff = f.sro - 1u; pb.qOff = (uint16_t)((f.sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF); pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
+                ExtProb pf; pf.qBase = qBase; pf.rOff = Aligner::ero(f.sro, f.refLen) + 1u; pf.qOff = (uint16_t)((f.eqo + 1) & 0xFFFF); pf.qLen = (uint16_t)(forwLen & 0xFFFF); pf.flags = strand | (vf ? XP_VALID : 0u);
+                X.probs[2 * (size_t)r] = pb; X.probs[2 * (size_t)r + 1] = pf;
+                X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)pb.qLen : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)pf.qLen : 0ull;
+            }
+            chunkPos += need;
+        }
+        if (UNI_B(al.err != 0)) { if (lane == 0) atomicCAS(A.errFlag, 0, al.err); break; }
+    }
+    al.flushCounters();
+    PROF_FLUSH();
+}
+
+// merge the extension results, then scoreClump / splitClump as in k_align
+__global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
+{
+    const unsigned wave = blockIdx.x; const int lane = laneId();
+    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
+    __shared__ uint16_t sTrace[YD_LDS_CELLS];
+    Aligner al(A, M, sTrace);
+    PROF_INIT();
+    const unsigned nRoots = uniU(A.nRoots);
+    for (;;) {
+        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(A.queueHead, 4u);
+        const unsigned r0 = uniU(t);
+        if (r0 >= nRoots) break;
+        const unsigned r1 = min(r0 + 4u, nRoots);
+        for (unsigned r = r0; r < r1; r++) {
+            const ChainClumpRec rec = A.clumps[A.order[r]];
+            al.setRead(rec); al.rootRank = r; al.pushes = 0;
+            Frame f = X.state[r].f; const uint32_t listOff = uniU(X.state[r].listOff);
+            f.start = uni(f.start); f.len = uni(f.len);
+            uint32_t *b = al.buf(0);
+            for (int k = lane; k < f.len; k += 64) b[f.start + k] = X.stateOps[listOff + k];
+            __threadfence_block();
+            const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
+            int score = f.score;
+            if (UNI_B(rb.score > 0)) {                                      // AlignExtFrag.cpp:112-125
+                const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
+                al.mergeFrontSrc(b, f.start, f.len, X.extOps + rb.opsOff, (int)rb.nOps);
+                score += rb.score; f.sqo = (f.sqo - aQ) & 0xFFFF; f.sro -= (uint32_t)aR; f.refLen = (f.refLen + aR) & 0xFFFF;
+            }
+            if (UNI_B(rf.score > 0)) {                                      // AlignExtFrag.cpp:128-141
+                const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
+                al.mergeBackSrc(b, f.start, f.len, X.extOps + rf.opsOff, (int)rf.nOps);
+                score += rf.score; f.eqo = (f.eqo + aQ) & 0xFFFF; f.refLen = (f.refLen + aR) & 0xFFFF;
+            }
+            f.score = uni(score); f.sqo = uni(f.sqo); f.eqo = uni(f.eqo); f.refLen = uni(f.refLen); f.sro = uniU(f.sro);
+            f.status |= stAligned;
+            if (!UNI_B(al.err != 0)) al.finishRoot(f);
+            if (lane == 0) A.rootPushCount[r] = al.pushes;
+            if (UNI_B(al.err != 0)) break;
+        }
+        if (UNI_B(al.err != 0)) { if (lane == 0) atomicCAS(A.errFlag, 0, al.err); break; }
+    }
+    al.flushCounters();
+    PROF_FLUSH();
+}

@@ -17,9 +17,11 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include "chain.h"
 #include "seed.h"
+#include "ext_lanes.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
 
@@ -38,9 +40,10 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_N = 16 };
-enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_N };
-const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout"};
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_N = 16 };
+// the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
+enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_N };
+const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split"};
 }  // namespace
 
 struct ygpu_ctx {
@@ -54,6 +57,8 @@ struct ygpu_ctx {
     DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
+    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extOps, extTrace;
+    bool evUsed[16] = {false}; double traceT = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -75,8 +80,20 @@ static int cubScan(ygpu_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n)
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp.p, bytes, in, out, (int)n, ctx->stream));
     return 0;
 }
+static int cubScan64(ygpu_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint32_t n)
+{
+    size_t bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
+    if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp.p, bytes, in, out, (int)n, ctx->stream));
+    return 0;
+}
+#include <chrono>
+static double nowMs() { using namespace std::chrono; return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count(); }
+static const bool kTrace = getenv("YGPU_TRACE") != nullptr;
+#define TRACE(what) do { if (kTrace) { hipStreamSynchronize(ctx->stream); double t_ = nowMs(); fprintf(stderr, "[ygpu] %-28s %9.3f ms\n", what, t_ - ctx->traceT); ctx->traceT = t_; } } while (0)
 #define ENSURE(buf, bytes) do { if ((buf).ensure(bytes)) { ctx->err = "hipMalloc failed for " #buf; return YGPU_ENOMEM; } } while (0)
-#define EV0(t) hipEventRecord(ctx->ev[t][0], ctx->stream)
+#define EV0(t) (ctx->evUsed[t] = true, hipEventRecord(ctx->ev[t][0], ctx->stream))
 #define EV1(t) hipEventRecord(ctx->ev[t][1], ctx->stream)
 
 static int fetchU32(ygpu_ctx *ctx, const void *dptr, uint32_t *out, size_t n = 1)
@@ -90,7 +107,7 @@ static int stageSeed(ygpu_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->ctr.p, 0, sizeof(DevCounters), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
     ctx->nHits = ctx->nFrags = ctx->nRegions = ctx->nMulti = ctx->maxN = ctx->nClumps = ctx->nClumpFrags = ctx->nOut = ctx->nOutOps = 0;
-    for (int t = 0; t < T_N; t++) ctx->ms[t] = 0;
+    for (int t = 0; t < T_N; t++) { ctx->ms[t] = 0; ctx->evUsed[t] = false; }
     if (K == 0 || n == 0) return 0;
     EV0(T_SEED);
     ENSURE(ctx->posS, 4ull * (K + 1)); ENSURE(ctx->posC, 4ull * (K + 1)); ENSURE(ctx->posRsI, 4ull * (K + 1)); ENSURE(ctx->hitOff, 4ull * (K + 1));
@@ -199,6 +216,94 @@ static int stageChain(ygpu_ctx *ctx)
 static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap)
 { front = 2 * ctx->maxQ + 8 * ctx->P.bandWidth + 64; listCap = 2 * front + 3 * ctx->maxQ + 1024; genCap = 1024; }
 
+
+// alignClump with the two X-drop extensions of every root done one problem per lane (ext_lanes.h):
+//   k_align_p1 (wave/root: gap fills, exact-match extensions) -> scan of the strip sizes -> k_ext_rows + k_ext_trace
+//   (lane/problem, in chunks that fit the trace memory) -> k_align_p3 (wave/root: merge, scoreClump/splitClump).
+// returns -2 when an arena was too small (the caller grows and redoes the stage)
+static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, uint32_t stateOpsCap, uint32_t &extOpsCap)
+{
+    const uint32_t NC = ctx->nClumps; const uint32_t nProb = 2 * NC; int rc;
+    uint32_t *cnt = ctx->counters.as<uint32_t>();
+    ENSURE(ctx->rootState, sizeof(RootState) * (uint64_t)NC); ENSURE(ctx->stateOps, 4ull * stateOpsCap); ENSURE(ctx->extProbs, sizeof(ExtProb) * (uint64_t)nProb);
+    ENSURE(ctx->rowsBound, 8ull * (nProb + 1)); ENSURE(ctx->stripOff, 8ull * (nProb + 1)); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nProb); ENSURE(ctx->extOps, 4ull * extOpsCap);
+    HIPCHK(hipMemsetAsync(cnt + CNT_STATEOPS, 0, 12, ctx->stream));            // stateops, extops, qext
+    HIPCHK(hipMemsetAsync((unsigned long long *)ctx->rowsBound.p + nProb, 0, 8, ctx->stream));
+    PhaseArgs X; X.state = ctx->rootState.as<RootState>(); X.stateOps = ctx->stateOps.as<uint32_t>(); X.stateOpsCount = cnt + CNT_STATEOPS; X.stateOpsCap = stateOpsCap;
+    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = ctx->extOps.as<uint32_t>();
+    TRACE("lanes: ensure");
+    EV0(T_P1);
+    hipLaunchKernelGGL(k_align_p1, dim3(waves), dim3(64), 0, ctx->stream, A, X);
+    rc = cubScan64(ctx, ctx->rowsBound.as<unsigned long long>(), ctx->stripOff.as<unsigned long long>(), nProb + 1); if (rc) return rc;
+    EV1(T_P1);
+    TRACE("lanes: p1+scan");
+    unsigned long long totalRows = 0;
+    HIPCHK(hipMemcpyAsync(&totalRows, ctx->stripOff.as<unsigned long long>() + nProb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+    if (ef == YERR_OUT) return -2;
+    if (ef) return 0;                                                         // reported by the caller
+    // trace memory: 12 B per row; split the problem range when it does not fit
+    size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
+    const unsigned long long budgetRows = std::max<unsigned long long>(1ull << 20, (unsigned long long)((freeB + ctx->extTrace.cap) * 8 / 10) / 12ull);
+    std::vector<uint32_t> cuts; cuts.push_back(0);
+    if (totalRows > budgetRows) {
+        ctx->hStripOff.resize(nProb + 1);
+        HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        uint32_t p0 = 0;
+        while (p0 < nProb) {
+            const unsigned long long lim = ctx->hStripOff[p0] + budgetRows;
+            uint32_t p1 = (uint32_t)(std::upper_bound(ctx->hStripOff.begin() + p0, ctx->hStripOff.end(), lim) - ctx->hStripOff.begin()) - 1;
+            if (p1 <= p0) { ctx->err = "not enough device memory for one extension trace strip"; return YGPU_ENOMEM; }
+            cuts.push_back(p1); p0 = p1;
+        }
+    } else cuts.push_back(nProb);
+    unsigned long long chunkRowsMax = 0;
+    if (cuts.size() == 2) chunkRowsMax = totalRows; else for (size_t c = 0; c + 1 < cuts.size(); c++) chunkRowsMax = std::max(chunkRowsMax, ctx->hStripOff[cuts[c + 1]] - ctx->hStripOff[cuts[c]]);
+    TRACE("lanes: cuts");
+    ENSURE(ctx->extTrace, 12ull * chunkRowsMax + 256);
+    TRACE("lanes: ensure trace");
+    if (kTrace) fprintf(stderr, "[ygpu] totalRows %llu budgetRows %llu chunks %zu\n", totalRows, budgetRows, cuts.size() - 1);
+    ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
+    E.trace = ctx->extTrace.as<uint32_t>(); E.queue = cnt + CNT_QEXT; E.ctr = ctx->ctr.as<DevCounters>();
+    E.ops = ctx->extOps.as<uint32_t>(); E.opsCount = cnt + CNT_EXTOPS; E.opsCap = extOpsCap; E.errFlag = ctx->errFlag.as<int>();
+    uint32_t opsBefore = 0;
+    for (size_t c = 0; c + 1 < cuts.size(); c++) {
+        const uint32_t p0 = cuts[c], p1 = cuts[c + 1];
+        E.probs = ctx->extProbs.as<ExtProb>() + p0; E.nProb = p1 - p0; E.stripOff = ctx->stripOff.as<unsigned long long>() + p0;
+        E.stripBase = cuts.size() == 2 ? 0ull : ctx->hStripOff[p0]; E.res = ctx->extRes.as<ExtRes>() + p0;
+        HIPCHK(hipMemsetAsync(cnt + CNT_QEXT, 0, 4, ctx->stream));
+        if (c == 0) EV0(T_XROWS);
+        int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_ext_rows, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
+        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)E.nProb + 255) / 256, (uint64_t)ctx->nCU * perCU);
+        hipLaunchKernelGGL(k_ext_rows, dim3(blocks), dim3(256), 0, ctx->stream, E);
+        TRACE("lanes: ext_rows");
+        if (c + 2 == cuts.size()) EV1(T_XROWS);
+        if (c == 0) EV0(T_XTRACE);
+        for (int tries = 0;; tries++) {                                       // the op arena grows to the exact need and only the traceback is redone
+            E.ops = ctx->extOps.as<uint32_t>(); E.opsCap = extOpsCap;
+            hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(E.nProb, 256)), dim3(256), 0, ctx->stream, E);
+            uint32_t used = 0; rc = fetchU32(ctx, cnt + CNT_EXTOPS, &used); if (rc) return rc;
+            rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+            if (ef != YERR_OUT) { opsBefore = used; break; }
+            if (tries >= 2 || used <= extOpsCap) { ctx->err = "extension op arena overflow persists"; return YGPU_EOVERFLOW; }
+            extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)used + (uint64_t)(cuts.size() > 2 ? used : used / 8) + 65536);
+            if (ctx->extOps.ensure(4ull * extOpsCap, true, ctx->stream)) { ctx->err = "hipMalloc failed for extOps"; return YGPU_ENOMEM; }
+            HIPCHK(hipMemcpyAsync(cnt + CNT_EXTOPS, &opsBefore, 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
+        }
+        TRACE("lanes: ext_trace");
+        if (c + 2 == cuts.size()) EV1(T_XTRACE);
+        if (ef) return 0;
+    }
+    X.extOps = ctx->extOps.as<uint32_t>();
+    HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
+    EV0(T_P3);
+    hipLaunchKernelGGL(k_align_p3, dim3(waves), dim3(64), 0, ctx->stream, A, X);
+    EV1(T_P3);
+    TRACE("lanes: p3");
+    return 0;
+}
+
 // ---- A5..A8 + layout ---------------------------------------------------------------------------------------------
 static int stageAlign(ygpu_ctx *ctx)
 {
@@ -208,6 +313,7 @@ static int stageAlign(ygpu_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->readCount.p, 0, 4ull * (n + 1), ctx->stream));
     ctx->nOut = ctx->nOutOps = 0;
     if (NC) {
+        TRACE("before align");
         EV0(T_ALIGN);
         int listCap, front, genCap; alignDims(ctx, listCap, front, genCap);
         const size_t per = alignScratchBytes(ctx->maxQ, listCap, genCap);
@@ -218,6 +324,10 @@ static int stageAlign(ygpu_ctx *ctx)
         ENSURE(ctx->clumpFrags0, 16ull * (ctx->nClumpFrags + 1));
         HIPCHK(hipMemcpyAsync(ctx->clumpFrags0.p, ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
         ENSURE(ctx->rootPush, 4ull * (NC + 1)); ENSURE(ctx->rootBase, 4ull * (NC + 1));
+        // the default band runs its X-drop extensions one problem per lane (ext_lanes.h); other bands stay on the wave kernel
+        const bool useLanes = ctx->laneExt && ctx->P.bandWidth == 5 && ctx->P.maxGap >= YD_LBAND;
+        uint32_t stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 4ull * NC + 4ull * ctx->nClumpFrags + (uint64_t)waves * YD_STATE_CHUNK + 65536);
+        uint32_t extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, std::max<uint64_t>(40ull * NC + (1u << 20), ctx->extOps.cap / 4));
         uint32_t outClumpCap = NC + NC / 2 + 1024; uint32_t outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + ctx->totalBases / 2 + 65536);
         for (int attempt = 0;; attempt++) {
             ENSURE(ctx->outClumps, sizeof(ygpu_clump) * (uint64_t)outClumpCap); ENSURE(ctx->outClumps2, sizeof(ygpu_clump) * (uint64_t)outClumpCap);
@@ -234,20 +344,25 @@ static int stageAlign(ygpu_ctx *ctx)
 #ifdef YD_PROF
             { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); }
 #endif
-            hipLaunchKernelGGL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
+            bool laneOverflow = false;
+            if (!useLanes) hipLaunchKernelGGL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
+            else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, extOpsCap); if (rc == -2) laneOverflow = true; else if (rc) return rc; }
 #ifdef YD_PROF
             { hipStreamSynchronize(ctx->stream); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
               const char *nm[10] = {"root_total", "dp_rows", "traceback", "perfect_ext", "score", "emit", "split", "merge", "dp_calls", "roots"};
               fprintf(stderr, "[YD_PROF] waves %u:", waves); for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", nm[i], z[i]); fprintf(stderr, "\n"); }
 #endif
-            uint32_t got[2]; rc = fetchU32(ctx, cnt + CNT_OUTCLUMPS, got, 2); if (rc) return rc;
-            uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+            uint32_t got[2] = {0, 0}, ef = 0;
+            if (laneOverflow) ef = YERR_OUT;
+            else { rc = fetchU32(ctx, cnt + CNT_OUTCLUMPS, got, 2); if (rc) return rc; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc; }
             if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
             if (ef != YERR_OUT || attempt >= 6) { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
             outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
+            stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap); extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * extOpsCap);
             HIPCHK(hipMemcpyAsync(ctx->clumpFrags.p, ctx->clumpFrags0.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_SCORED, 0, 8 * (16 - C_SCORED), ctx->stream));
         }
+        TRACE("align: fetch");
         EV1(T_ALIGN);
         EV0(T_LAYOUT);
         rc = cubScan(ctx, ctx->rootPush.as<uint32_t>(), ctx->rootBase.as<uint32_t>(), NC + 1); if (rc) return rc;
@@ -316,7 +431,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps};
+                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extOps, &ctx->extTrace};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         hipStreamDestroy(ctx->stream);
@@ -361,7 +476,10 @@ int ygpu_run(ygpu_ctx *ctx)
     ctx->stageDone = 0;
     int rc = runTo(ctx, 3); if (rc) return rc;
     ctx->totalMs = 0;
-    for (int t = 0; t < T_N; t++) { float m = 0; if (hipEventElapsedTime(&m, ctx->ev[t][0], ctx->ev[t][1]) == hipSuccess) ctx->ms[t] = m; else ctx->ms[t] = 0; ctx->totalMs += ctx->ms[t]; }
+    for (int t = 0; t < T_N; t++) {
+        float m = 0; ctx->ms[t] = (ctx->evUsed[t] && hipEventElapsedTime(&m, ctx->ev[t][0], ctx->ev[t][1]) == hipSuccess) ? m : 0;
+        if (t < T_TOP) ctx->totalMs += ctx->ms[t];
+    }
     return 0;
 }
 
