@@ -215,7 +215,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_align", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "algorithmic_bytes_per_read": B, "kernel_ms_per_launch": align_ms, "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) / (align_ms * 1e-3) if align_ms > 0 else 0.0},
         "stage_ms_per_step": {k2: v / steps for k2, v in stage_ms.items()},
-        "per_read": {k2: counters[k2] / n_reads for k2 in ("hits", "fragments", "clumps_formed", "clumps_scored", "dp_ext_calls", "dp_ext_cells", "dp_gap_cells", "ref_bases_touched")},
+        "per_read": {k2: counters[k2] / n_reads for k2 in ("hits", "fragments", "clumps_formed", "clumps_scored", "dp_ext_calls", "dp_ext_rows", "dp_ext_cells", "dp_gap_calls", "dp_gap_rows", "dp_gap_cells", "splits", "ops_out", "ref_bases_touched")},
         "pcie": {"upload_s": t_up, "collect_s": t_down, "clumps": n_clumps},
     }
     if world == 1 and not args.no_cpu_baseline:

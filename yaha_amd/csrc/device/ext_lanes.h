@@ -271,109 +271,3 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
     }
 }
 
-// ---- phase 1 / phase 3 around the lane kernels: wave per root -------------------------------------------------------
-struct RootState { Frame f; uint32_t listOff; int backLen, forwLen; };
-struct PhaseArgs {
-    RootState *state; uint32_t *stateOps; unsigned int *stateOpsCount; uint32_t stateOpsCap;
-    ExtProb *probs; unsigned long long *rowsBound;      // 2 per root
-    const ExtRes *res; const uint32_t *extOps;
-};
-#define YD_STATE_CHUNK 2048
-
-// alignClump up to and including the exact-match extensions; leaves the two X-drop extension problems for k_ext_rows
-__global__ void __launch_bounds__(64) k_align_p1(AlignArgs A, PhaseArgs X)
-{
-    const unsigned wave = blockIdx.x; const int lane = laneId();
-    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
-    __shared__ uint16_t sTrace[YD_LDS_CELLS];
-    Aligner al(A, M, sTrace);
-    PROF_INIT();
-    const unsigned nRoots = uniU(A.nRoots);
-    unsigned chunkPos = 0, chunkEnd = 0;                                     // this wave's reservation in stateOps
-    for (;;) {
-        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
-        unsigned t = 0;
-        if (lane == 0) t = atomicAdd(A.queueHead, 4u);
-        const unsigned r0 = uniU(t);
-        if (r0 >= nRoots) break;
-        const unsigned r1 = min(r0 + 4u, nRoots);
-        for (unsigned r = r0; r < r1; r++) {
-            const ChainClumpRec rec = A.clumps[A.order[r]];
-            al.setRead(rec); al.rootRank = r; al.pushes = 0;
-            Frame f; al.alignRootPre(rec, f);
-            int backLen = 0, forwLen = 0;
-            if (!UNI_B(al.err != 0)) al.extendPerfect(f, al.buf(0), true, true, backLen, forwLen);
-            if (UNI_B(al.err != 0)) break;
-            const unsigned need = (unsigned)uni(f.len);
-            if (chunkPos + need > chunkEnd) {
-                const unsigned want = need > YD_STATE_CHUNK ? need : YD_STATE_CHUNK; unsigned b = 0;
-                if (lane == 0) b = atomicAdd(X.stateOpsCount, want);
-                b = uniU(b); chunkPos = b; chunkEnd = b + want;
-                if (chunkEnd > X.stateOpsCap) { al.err = YERR_OUT; break; }
-            }
-            const uint32_t *b = al.buf(0);
-            for (int k = lane; k < f.len; k += 64) X.stateOps[chunkPos + k] = b[f.start + k];
-            if (lane == 0) {
-                RootState s; s.f = f; s.listOff = chunkPos; s.backLen = backLen; s.forwLen = forwLen; X.state[r] = s;
-                const uint32_t qBase = A.B.readOff[rec.rs >> 1]; const uint32_t strand = (rec.rs & 1u) ? XP_STRAND : 0u;
-                const bool vb = backLen >= A.P.minExtLength, vf = forwLen >= A.P.minExtLength;
-                ExtProb pb; pb.qBase = qBase; pb.rOff = f.sro - 1u; pb.qOff = (uint16_t)((f.sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF); pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
-                ExtProb pf; pf.qBase = qBase; pf.rOff = Aligner::ero(f.sro, f.refLen) + 1u; pf.qOff = (uint16_t)((f.eqo + 1) & 0xFFFF); pf.qLen = (uint16_t)(forwLen & 0xFFFF); pf.flags = strand | (vf ? XP_VALID : 0u);
-                X.probs[2 * (size_t)r] = pb; X.probs[2 * (size_t)r + 1] = pf;
-                X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)pb.qLen : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)pf.qLen : 0ull;
-            }
-            chunkPos += need;
-        }
-        if (UNI_B(al.err != 0)) { if (lane == 0) atomicCAS(A.errFlag, 0, al.err); break; }
-    }
-    al.flushCounters();
-    PROF_FLUSH();
-}
-
-// merge the extension results, then scoreClump / splitClump as in k_align
-__global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
-{
-    const unsigned wave = blockIdx.x; const int lane = laneId();
-    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
-    __shared__ uint16_t sTrace[YD_LDS_CELLS];
-    Aligner al(A, M, sTrace);
-    PROF_INIT();
-    const unsigned nRoots = uniU(A.nRoots);
-    for (;;) {
-        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
-        unsigned t = 0;
-        if (lane == 0) t = atomicAdd(A.queueHead, 4u);
-        const unsigned r0 = uniU(t);
-        if (r0 >= nRoots) break;
-        const unsigned r1 = min(r0 + 4u, nRoots);
-        for (unsigned r = r0; r < r1; r++) {
-            const ChainClumpRec rec = A.clumps[A.order[r]];
-            al.setRead(rec); al.rootRank = r; al.pushes = 0;
-            Frame f = X.state[r].f; const uint32_t listOff = uniU(X.state[r].listOff);
-            f.start = uni(f.start); f.len = uni(f.len);
-            uint32_t *b = al.buf(0);
-            for (int k = lane; k < f.len; k += 64) b[f.start + k] = X.stateOps[listOff + k];
-            __threadfence_block();
-            const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
-            int score = f.score;
-            if (UNI_B(rb.score > 0)) {                                      // AlignExtFrag.cpp:112-125
-                const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-                al.mergeFrontSrc(b, f.start, f.len, X.extOps + rb.opsOff, (int)rb.nOps);
-                score += rb.score; f.sqo = (f.sqo - aQ) & 0xFFFF; f.sro -= (uint32_t)aR; f.refLen = (f.refLen + aR) & 0xFFFF;
-            }
-            if (UNI_B(rf.score > 0)) {                                      // AlignExtFrag.cpp:128-141
-                const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-                al.mergeBackSrc(b, f.start, f.len, X.extOps + rf.opsOff, (int)rf.nOps);
-                score += rf.score; f.eqo = (f.eqo + aQ) & 0xFFFF; f.refLen = (f.refLen + aR) & 0xFFFF;
-            }
-            f.score = uni(score); f.sqo = uni(f.sqo); f.eqo = uni(f.eqo); f.refLen = uni(f.refLen); f.sro = uniU(f.sro);
-            f.status |= stAligned;
-            if (!UNI_B(al.err != 0)) al.finishRoot(f);
-            if (lane == 0) A.rootPushCount[r] = al.pushes;
-            if (UNI_B(al.err != 0)) break;
-        }
-        if (UNI_B(al.err != 0)) { if (lane == 0) atomicCAS(A.errFlag, 0, al.err); break; }
-    }
-    al.flushCounters();
-    PROF_FLUSH();
-}

@@ -1,0 +1,497 @@
+// phase_lanes.h -- everything of the per-root work around the X-drop extensions (ext_lanes.h), for the default band:
+//
+//   phase 1 = alignClump up to the extensions (AlignHelpers.c:205-272, AlignExtFrag.cpp:164-234)
+//     k_joint_counts   joints (fragment pairs) per root clump -> scan -> joint slots
+//     k_p1_joints      lane per root: the exact-match extensions of every joint, then the joint's gap is classified:
+//                      nothing / one D, I or R op / pure diagonal (see below) / a DP problem (sort key = strip width, rows)
+//     [radix sort of the DP joints by size, so that the lanes of a wave run problems of the same shape]
+//     k_gap_lanes      lane per DP joint: gapDPLane (the sequential recurrence, strip state in LDS)
+//     k_gap_wave       wave per DP joint for the few that exceed gapDPLane's limits (dp_wave.h)
+//     k_p1_assemble    lane per root: edit list = M ops + joint ops, the clump's exact-match end extensions, the two
+//                      X-drop extension problems for k_ext_rows
+//   phase 3 = the tail of extendClumpForwardReverse + scoreClump / splitClump (AlignExtFrag.cpp:112-141, AlignHelpers.c:302-579)
+//     k_p3_lanes       lane per root: merge the extension results, scoreClump; accepted clumps are written by their lane
+//     k_align_p3       wave per root for the roots that need splitClump (align.h state machine)
+//
+// "Pure diagonal": an equal-length gap of g bases whose diagonal has mm mismatches needs no DP when
+//     mm * (MS + RC) <= MS + 2 * (GO + GE):
+// every gapped path aligns at most g-1 pairs and opens at least one insertion and one deletion, so it scores at most
+// MS*(g-1) - 2*(GO+GE), which is <= the diagonal's score at every prefix; the reference's DP (ties go to the diagonal: E and F
+// win only with '>', SW.cpp:1036-1060) then returns exactly the diagonal.  Its work counters are charged as the reference
+// would have counted them.
+#pragma once
+#include "ext_lanes.h"
+
+struct RootState { Frame f; uint32_t listOff; int backLen, forwLen; };
+enum { JK_NONE = 0, JK_D, JK_I, JK_R, JK_DIAG, JK_DP };
+struct JointRec {                                           // 32 B
+    uint32_t nsro, qBase; uint16_t nsqo, qGap, rGap; uint8_t kind, flags;   // flags: bit0 strand, bit1 banded
+    uint32_t opsOff; uint16_t nOps, pad; int32_t score; uint32_t cells;
+};
+struct PhaseArgs {
+    RootState *state; uint32_t *stateOps; unsigned int *stateOpsCount; uint32_t stateOpsCap;
+    ExtProb *probs; unsigned long long *rowsBound;      // 2 per root
+    const ExtRes *res; const uint32_t *extOps;
+    uint32_t *slowList; unsigned int *slowCount;        // roots (k_p3_lanes) or joints (k_gap_lanes) handed to the wave kernels
+    int useList;                                        // k_align_p3: take roots from slowList[0 .. *slowCount)
+    // joints
+    uint32_t *jointCount; const uint32_t *jointBase; JointRec *joints; uint32_t nJoints;
+    uint32_t *sortKeys, *sortVals; const uint32_t *sortedVals; unsigned int *nDP;
+    uint32_t *gapOps; unsigned int *gapOpsCount; uint32_t gapOpsCap;
+    uint8_t *gapScratch;                                // YD_GAP_SCRATCH bytes per k_gap_lanes thread (trace strip + op list of gapDPLane)
+};
+
+// ---- wave helpers ----
+__device__ __forceinline__ unsigned waveSumU(unsigned v) { return (unsigned)waveSumI((int)v); }
+// rank of this lane among the set lanes of `mask`, and one atomicAdd of the total by the first set lane
+__device__ __forceinline__ unsigned waveReserve(unsigned long long mask, unsigned int *counter, int lane, unsigned each = 1u)
+{
+    if (!mask) return 0u;
+    const int first = __builtin_ctzll(mask); unsigned base = 0;
+    if (lane == first) base = atomicAdd(counter, each * (unsigned)__builtin_popcountll(mask));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
+    return base + each * (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+}
+
+
+// ---- gap-fill DP of one lane (findAGSAlignment / findAGSAlignmentBanded, SW.cpp:462-477, 798-1208) ---------------------------
+// The sequential recurrence, one problem per lane: strip state (PV/PF/PI, up to 33 columns) and the reference segment in
+// LDS laid out [column][lane] (bank = lane, conflict-free whatever column each lane is at), trace cells (op | run << 2) in
+// a lane-private HBM strip, traceback as the reference's.  Handles W <= 32, qLen <= 64, rLen <= 64; anything larger stays
+// on the wave kernel.  Returns the ops in emission order (far end first) in tmp[0..nOps).
+#define YD_GW 32
+#define YD_GAP_SCRATCH (((YD_GROWS + 1) * YD_GW * 2 + (2 * YD_GROWS + 64) * 4 + 255) & ~255)
+#define YD_GROWS 64
+struct GapLaneMem { int *pv, *pf, *pi; uint8_t *ref; uint16_t *T; uint32_t *tmp; };   // LDS pointers already offset by lane (stride 64); T, tmp in HBM
+__device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uint8_t *gB, YD_GLOBAL const uint8_t *q, bool banded,
+                                         uint32_t rOff, int rLen, int qOff, int qLen, const GapLaneMem &M, int &nOps, unsigned &cellsOut)
+{
+    const int GO = P.GO, GE = P.GE, RC = P.RC, MS = P.MS, maxIntron = P.maxIntron, maxGapP = P.maxGap;
+    int left = 0, right = 0;
+    if (banded) { const int bw = P.bandWidth; if (rLen > qLen) { right = bw + (rLen - qLen); left = bw; } else { left = bw + (qLen - rLen); right = bw; } }
+    const int W = banded ? left + right + 1 : rLen + 1;
+    int *PV = M.pv, *PF = M.pf, *PI = M.pi; uint16_t *T = M.T;
+#define GPV(j) PV[(j) * 64]
+#define GPF(j) PF[(j) * 64]
+#define GPI(j) PI[(j) * 64]
+    for (int t = 0; t < rLen; t++) { const uint32_t off = rOff + (uint32_t)t; const uint32_t b = gB[off >> 1]; M.ref[t * 64] = (uint8_t)((off & 1u) ? (b & 15u) : (b >> 4)); }
+    int startInit;
+    T[0] = (uint16_t)TR_U;
+    if (banded) { startInit = left + 1; T[left] = (uint16_t)TR_U; GPF(W) = YD_WORST; GPV(W) = YD_WORST; GPI(W) = 0; } else startInit = 1;
+    { int dc = 1; for (int j = startInit; j < W; j++) { T[j] = (uint16_t)(OP_D | (dc << 2)); GPV(j) = -(GO + dc * GE); dc++; GPF(j) = YD_WORST; GPI(j) = 0; } }
+    GPF(startInit - 1) = 0; GPI(startInit - 1) = 0; GPV(startInit - 1) = 0;
+    { const int endInit = banded ? left : qLen; for (int i = 1; i <= endInit && i <= qLen; i++) { const int lo = banded ? left - i : 0; T[i * YD_GW + lo] = (uint16_t)(OP_I | (i << 2)); } }
+    int V = 0, PVCol = YD_WORST, startCol = 1, endCol = W - 1; unsigned cells = 0;
+    for (int i = 1; i <= qLen; i++) {
+        int PDCol = 0, PECol = YD_WORST;
+        if (banded) {
+            startCol = left + 1 - i;
+            if (startCol <= 0) { startCol = 0; PVCol = YD_WORST; } else { PVCol = -(GO + i * GE); GPV(startCol - 1) = PVCol; }
+            endCol = min(left + rLen - i, W - 1);
+        } else PVCol = -(GO + i * GE);
+        const int qc = (int)q[qOff + i - 1];
+        const int rRow = banded ? i - left - 1 : 0;
+        for (int j = startCol; j <= endCol; j++) {
+            const int RM = banded ? j : j - 1, IO = RM + 1; int op;
+            V = GPV(RM);
+            const int rc = (int)M.ref[(banded ? rRow + j : j - 1) * 64];
+            if (qc == rc) { V += MS; op = OP_M; } else { V -= RC; op = OP_R; }
+            int len = 0;
+            const int CE = PECol - GE, NE = PVCol - (GO + GE);
+            if (CE >= NE && (PDCol + 1) <= maxIntron) { PECol = CE; PDCol = PDCol + 1; } else { PECol = NE; PDCol = 1; }
+            if (PECol > V) { V = PECol; op = OP_D; len = PDCol; }
+            int F, I; const int CF = GPF(IO) - GE, NF = GPV(IO) - (GO + GE), pio = GPI(IO);
+            if (CF >= NF && (pio + 1) <= maxGapP) { F = CF; I = pio + 1; } else { F = NF; I = 1; }
+            if (F > V) { V = F; op = OP_I; len = I; }
+            GPF(j) = F; GPI(j) = I;
+            T[i * YD_GW + j] = (uint16_t)(op | (len << 2));
+            if (banded) GPV(j) = V; else GPV(j - 1) = PVCol;
+            PVCol = V; cells++;
+        }
+        if (!banded) GPV(endCol) = V;
+    }
+    cellsOut = cells;
+    // traceback from the end cell (SW.cpp:1138-1195)
+    int x = banded ? right : W - 1, y = qLen;
+    unsigned cell = T[y * YD_GW + x];
+    int prev = cell == TR_U ? -1 : (int)(cell & 3u), acc = 0, n = 0;
+    for (int guard = 0; cell != TR_U && guard < 4096; guard++) {
+        const int code = (int)(cell & 3u); int len = (int)(cell >> 2);
+        if (banded) { if (code == OP_D) x -= len; else if (code == OP_I) { x += len; y -= len; } else { y -= 1; len = 1; } }
+        else        { if (code == OP_D) x -= len; else if (code == OP_I) { y -= len; } else { x -= 1; y -= 1; len = 1; } }
+        if (prev != code) { M.tmp[n] = opMake(prev, acc); n++; prev = code; acc = len; } else acc += len;
+        if (y < 0 || x < 0 || x >= YD_GW + 1 || n >= 2 * YD_GROWS + 60) break;
+        cell = T[y * YD_GW + x];
+    }
+    M.tmp[n] = opMake(prev, acc); n++;
+    nOps = n;
+#undef GPV
+#undef GPF
+#undef GPI
+    return V;
+}
+
+
+__global__ void k_joint_counts(AlignArgs A, PhaseArgs X)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < A.nRoots) X.jointCount[r] = A.clumps[A.order[r]].nFrags - 1u;
+    if (r == A.nRoots) X.jointCount[r] = 0u;
+}
+
+// lane per root: exact-match extensions of every joint (AlignHelpers.c:216-232), then the gap's kind (AlignExtFrag.cpp:190-231)
+__global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
+{
+    const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < A.nRoots; const DevParams &P = A.P;
+    unsigned perfect = 0, touched = 0, nDP = 0;
+    if (live) {
+        const ChainClumpRec rec = A.clumps[A.order[r]]; const int n = (int)rec.nFrags;
+        if (n > 1) {
+            const uint32_t read = rec.rs >> 1, r0 = A.B.readOff[read];
+            YD_GLOBAL const uint8_t *q = toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0; YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
+            auto refAt = [&](uint32_t off) -> uint32_t { const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
+            DevFrag *F = A.clumpFrags + rec.fragOff; const uint32_t jb = X.jointBase[r];
+            DevFrag cur = F[0];
+            for (int k = 1; k < n; k++) {
+                DevFrag nxt = F[k];
+                int gap = (int)min(gapI(cur.eqo, nxt.sqo), gapU(cur.sro + (uint32_t)cur.refLen - 1u, nxt.sro));
+                { int c = 0; while (c < gap && (uint32_t)q[(int)nxt.sqo - 1 - c] == refAt(nxt.sro - 1u - (uint32_t)c)) c++;
+                  perfect += c; touched += c + (c < gap);
+                  if (c > 0) { nxt.sqo = (uint16_t)(nxt.sqo - c); nxt.sro -= (uint32_t)c; nxt.refLen = (uint16_t)(nxt.refLen + c); } gap -= c; }
+                { const uint32_t eRO = cur.sro + (uint32_t)cur.refLen - 1u; int c = 0; while (c < gap && (uint32_t)q[(int)cur.eqo + 1 + c] == refAt(eRO + 1u + (uint32_t)c)) c++;
+                  perfect += c; touched += c + (c < gap);
+                  if (c > 0) { cur.eqo = (uint16_t)(cur.eqo + c); cur.refLen = (uint16_t)(cur.refLen + c); } }
+                F[k - 1] = cur;
+                const uint32_t eRO = cur.sro + (uint32_t)cur.refLen - 1u;
+                const int qGap = (int)(gapI(cur.eqo, nxt.sqo) & 0xFFFF), rGap = (int)(gapU(eRO, nxt.sro) & 0xFFFF);
+                JointRec j; j.nsro = eRO + 1u; j.qBase = r0; j.nsqo = (uint16_t)((cur.eqo + 1) & 0xFFFF); j.qGap = (uint16_t)qGap; j.rGap = (uint16_t)rGap;
+                j.flags = (uint8_t)(rec.rs & 1u); j.opsOff = 0; j.nOps = 0; j.pad = 0; j.score = 0; j.cells = 0; j.kind = JK_NONE;
+                uint32_t key = 0xFFFFFFFFu;
+                if (qGap == 0 && rGap == 0) { }
+                else if (qGap == 0) j.kind = JK_D;
+                else if (rGap == 0) j.kind = JK_I;
+                else if (rGap == 1 && qGap == 1) j.kind = JK_R;
+                else {
+                    const int lenDiff = qGap > rGap ? qGap - rGap : rGap - qGap;
+                    const bool banded = lenDiff + P.bandWidth * 2 + 1 < rGap;
+                    j.flags |= banded ? 2u : 0u; j.kind = JK_DP;
+                    if (qGap == rGap) {
+                        int mm = 0;
+                        for (int t = 0; t < qGap; t++) mm += (uint32_t)q[(int)cur.eqo + 1 + t] != refAt(eRO + 1u + (uint32_t)t);
+                        if (mm * (P.MS + P.RC) <= P.MS + 2 * (P.GO + P.GE)) { j.kind = JK_DIAG; j.score = P.MS * (qGap - mm) - P.RC * mm; }
+                    }
+                    if (j.kind == JK_DP) { const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1; key = ((uint32_t)min(W, 0xFFFF) << 16) | (uint32_t)qGap; nDP++; }
+                }
+                X.joints[jb + (uint32_t)(k - 1)] = j; X.sortKeys[jb + (uint32_t)(k - 1)] = key; X.sortVals[jb + (uint32_t)(k - 1)] = jb + (uint32_t)(k - 1);
+                cur = nxt;
+            }
+            F[n - 1] = cur;
+        }
+    }
+    perfect = waveSumU(perfect); touched = waveSumU(touched); nDP = waveSumU(nDP);
+    if (lane == 0 && (perfect | touched | nDP)) {
+        atomicAdd(&A.ctr->v[C_PERFECT], (unsigned long long)perfect); atomicAdd(&A.ctr->v[C_TOUCHED], (unsigned long long)touched);
+        if (nDP) atomicAdd(X.nDP, nDP);
+    }
+}
+
+// lane per DP joint, in size order.  Persistent 64-thread blocks (LDS: 29 KB each).
+__global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
+{
+    __shared__ int sPV[YD_GW + 1][64], sPF[YD_GW + 1][64], sPI[YD_GW + 1][64];
+    __shared__ uint8_t sRef[YD_GROWS][64];
+    const int lane = laneId(); const DevParams &P = A.P;
+    GapLaneMem GM; GM.pv = &sPV[0][lane]; GM.pf = &sPF[0][lane]; GM.pi = &sPI[0][lane]; GM.ref = &sRef[0][lane];
+    { uint8_t *sp = X.gapScratch + (size_t)(blockIdx.x * 64u + (unsigned)lane) * YD_GAP_SCRATCH; GM.T = (uint16_t *)sp; GM.tmp = (uint32_t *)(sp + (YD_GROWS + 1) * YD_GW * 2); }
+    YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
+    const uint32_t nDP = *X.nDP;
+    for (uint32_t base = blockIdx.x * 64u; base < nDP; base += gridDim.x * 64u) {
+        const uint32_t t = base + (uint32_t)lane; const bool live = t < nDP;
+        int nT = 0, score = 0; unsigned cells = 0; bool tooBig = false; uint32_t ji = 0;
+        if (live) {
+            ji = X.sortedVals[t]; const JointRec j = X.joints[ji];
+            const bool banded = (j.flags & 2u) != 0; const int qGap = j.qGap, rGap = j.rGap;
+            const int lenDiff = qGap > rGap ? qGap - rGap : rGap - qGap;
+            const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1;
+            if (W > YD_GW || qGap > YD_GROWS || rGap > YD_GROWS) tooBig = true;
+            else {
+                YD_GLOBAL const uint8_t *q = toGlobal((j.flags & 1u) ? A.B.rev : A.B.fwd) + j.qBase;
+                score = gapDPLane(P, gB, q, banded, j.nsro, rGap, (int)j.nsqo, qGap, GM, nT, cells);
+            }
+        }
+        { const unsigned long long mm = __ballot(tooBig); const unsigned sl = waveReserve(mm, X.slowCount, lane); if (tooBig) X.slowList[sl] = ji; }
+        // op slots: wave prefix sum of nT
+        int incl = nT;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+        const int total = __shfl(incl, 63, 64); unsigned ob = 0;
+        if (lane == 63 && total) ob = atomicAdd(X.gapOpsCount, (unsigned)total);
+        ob = (unsigned)__shfl((int)ob, 63, 64);
+        if (live && !tooBig) {
+            const unsigned off = ob + (unsigned)(incl - nT);
+            if ((unsigned long long)off + (unsigned)nT > (unsigned long long)X.gapOpsCap) atomicCAS(A.errFlag, 0, (int)YERR_OUT);
+            else {
+                for (int k = 0; k < nT; k++) X.gapOps[off + k] = GM.tmp[nT - 1 - k];           // list order
+                JointRec *jp = X.joints + ji; jp->opsOff = off; jp->nOps = (uint16_t)nT; jp->score = score; jp->cells = cells;
+            }
+        }
+    }
+}
+
+// wave per DP joint (dp_wave.h) for the joints beyond gapDPLane's limits
+__global__ void __launch_bounds__(64) k_gap_wave(AlignArgs A, PhaseArgs X)
+{
+    const int lane = laneId();
+    WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
+    __shared__ uint16_t sTrace[YD_LDS_CELLS];
+    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
+    const unsigned n = uniU(*X.slowCount);
+    for (;;) {
+        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
+        unsigned t = 0; if (lane == 0) t = atomicAdd(A.queueHead, 1u);
+        const unsigned i = uniU(t);
+        if (i >= n) break;
+        const uint32_t ji = uniU(X.slowList[i]); const JointRec j = X.joints[ji];
+        const uint8_t *q = ((j.flags & 1u) ? A.B.rev : A.B.fwd) + j.qBase;
+        DPOut o = dpWave(A.P, A.bases, q, (j.flags & 2u) ? YGPU_DP_BANDED : YGPU_DP_FULL, j.nsro, (int)j.rGap, (int)j.nsqo, (int)j.qGap, S);
+        if (UNI_B(err != 0)) { if (lane == 0) atomicCAS(A.errFlag, 0, err); break; }
+        const int nT = uni(o.nOps); unsigned ob = 0;
+        if (lane == 0) ob = atomicAdd(X.gapOpsCount, (unsigned)nT); ob = uniU(ob);
+        if (UNI_B((unsigned long long)ob + (unsigned)nT > (unsigned long long)X.gapOpsCap)) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_OUT); break; }
+        for (int k = lane; k < nT; k += 64) X.gapOps[ob + k] = dpOp(S, o, false, k);
+        if (lane == 0) { JointRec *jp = X.joints + ji; jp->opsOff = ob; jp->nOps = (uint16_t)nT; jp->score = uni(o.score); jp->cells = (uint32_t)uni(o.cells); }
+    }
+}
+
+// lane per root: the edit list, the clump's fragment, its exact-match end extensions (AlignExtFrag.cpp:76-107), the
+// two X-drop extension problems
+__global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
+{
+    const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < A.nRoots; const DevParams &P = A.P;
+    ChainClumpRec rec; rec.nFrags = 0; rec.rs = 0; rec.fragOff = 0;
+    if (live) rec = A.clumps[A.order[r]];
+    const int n = (int)rec.nFrags; const uint32_t jb = live ? X.jointBase[r] : 0u;
+    // exact upper bound of the list length
+    unsigned want = 0;
+    if (live) { want = (unsigned)n + 1u; for (int k = 0; k + 1 < n; k++) { const JointRec &j = X.joints[jb + (uint32_t)k]; want += j.kind == JK_DP ? (unsigned)j.nOps : (j.kind == JK_DIAG ? (unsigned)j.qGap : (j.kind != JK_NONE ? 1u : 0u)); } }
+    unsigned incl = want;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned t = (unsigned)__shfl_up((int)incl, d, 64); if (lane >= d) incl += t; }
+    const unsigned total = (unsigned)__shfl((int)incl, 63, 64); unsigned base = 0;
+    if (lane == 63 && total) base = atomicAdd(X.stateOpsCount, total);
+    base = (unsigned)__shfl((int)base, 63, 64);
+    const unsigned slot = base + incl - want;
+    unsigned perfect = 0, touched = 0, gapCalls = 0, gapRows = 0, gapCells = 0;
+    if (live) {
+        if ((unsigned long long)slot + want > (unsigned long long)X.stateOpsCap) atomicCAS(A.errFlag, 0, (int)YERR_OUT);
+        else {
+            const uint32_t read = rec.rs >> 1, r0 = A.B.readOff[read]; const int qlen = (int)(A.B.readOff[read + 1] - r0);
+            YD_GLOBAL const uint8_t *q = toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0; YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
+            auto refAt = [&](uint32_t off) -> uint32_t { const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
+            const DevFrag *F = A.clumpFrags + rec.fragOff;
+            uint32_t *ops = X.stateOps + slot; int nOut = 0, pc = -1, pl = 0, score = 0;
+            auto put = [&](int code, int len) { if (pc == code) { pl = (pl + len) & 0xFFFF; return; } if (pc >= 0) { ops[nOut] = opMake(pc, pl); nOut++; } pc = code; pl = len & 0xFFFF; };
+            const DevFrag firstF = F[0]; DevFrag cur = firstF;
+            for (int k = 1; k <= n; k++) {
+                { const int ql = fragQLen(cur.sqo, cur.eqo); put(OP_M, ql); score += P.MS * ql; }
+                if (k == n) break;
+                const JointRec j = X.joints[jb + (uint32_t)(k - 1)]; const int qGap = j.qGap, rGap = j.rGap;
+                if (j.kind == JK_D) { put(OP_D, rGap); score -= P.GO + rGap * P.GE; }
+                else if (j.kind == JK_I) { put(OP_I, qGap); score -= P.GO + qGap * P.GE; }
+                else if (j.kind == JK_R) { put(OP_R, 1); score -= P.RC; }
+                else if (j.kind == JK_DIAG) {
+                    const int g = qGap;
+                    for (int t = 0; t < g; t++) put((uint32_t)q[(int)j.nsqo + t] == refAt(j.nsro + (uint32_t)t) ? OP_M : OP_R, 1);
+                    score += j.score; gapCalls++; gapRows += (unsigned)g; touched += (unsigned)g;
+                    if (P.bandWidth * 2 + 1 < g) { const int bw = P.bandWidth, W = 2 * bw + 1; for (int i = 1; i <= g; i++) { int sc = bw + 1 - i; if (sc < 0) sc = 0; int ec = bw + g - i; if (ec > W - 1) ec = W - 1; if (ec >= sc) gapCells += (unsigned)(ec - sc + 1); } }
+                    else gapCells += (unsigned)(g * g);
+                } else if (j.kind == JK_DP) {
+                    for (int t = 0; t < (int)j.nOps; t++) { const uint32_t op = X.gapOps[j.opsOff + (uint32_t)t]; put(opCode(op), opLen(op)); }
+                    score += j.score; gapCalls++; gapRows += (unsigned)qGap; gapCells += j.cells; touched += (unsigned)rGap;
+                }
+                cur = F[k];
+            }
+            uint32_t sro = firstF.sro; int sqo = firstF.sqo, eqo = cur.eqo; int refLen = (int)((1u + (cur.sro + (uint32_t)cur.refLen - 1u) - firstF.sro) & 0xFFFFu);
+            int firstAdd = 0;
+            int backLen = (int)((uint32_t)sqo < sro ? (uint32_t)sqo : sro), forwLen;
+            if (backLen > 0) {
+                int m = 0; while (m < backLen && (uint32_t)q[sqo - 1 - m] == refAt(sro - 1u - (uint32_t)m)) m++;
+                perfect += m; touched += m + (m < backLen);
+                if (m > 0) { firstAdd = m; score += m * P.MS; backLen -= m; sqo -= m; sro -= (uint32_t)m; refLen = (refLen + m) & 0xFFFF; }
+            }
+            {
+                const uint32_t eRO = sro + (uint32_t)refLen - 1u;
+                const uint32_t qrem = (uint32_t)(((qlen - 1) - eqo) & 0xFFFF), rrem = P.maxROff - eRO;
+                forwLen = (int)(qrem < rrem ? qrem : rrem);
+                if (forwLen > 0) {
+                    int m = 0; while (m < forwLen && (uint32_t)q[eqo + 1 + m] == refAt(eRO + 1u + (uint32_t)m)) m++;
+                    perfect += m; touched += m + (m < forwLen);
+                    if (m > 0) { pl = (pl + m) & 0xFFFF; score += m * P.MS; forwLen -= m; eqo += m; refLen = (refLen + m) & 0xFFFF; }
+                }
+            }
+            if (nOut == 0) pl = (pl + firstAdd) & 0xFFFF;
+            ops[nOut] = opMake(pc, pl); nOut++;
+            if (nOut > 1 && firstAdd) ops[0] = opMake(opCode(ops[0]), (opLen(ops[0]) + firstAdd) & 0xFFFF);
+            RootState s; memset(&s, 0, sizeof s);
+            s.f.sro = sro; s.f.sqo = sqo; s.f.eqo = eqo; s.f.refLen = refLen; s.f.score = score; s.f.status = (rec.rs & 1u) ? stReversed : 0; s.f.phase = PH_NONE; s.f.start = A.front; s.f.len = nOut;
+            s.listOff = slot; s.backLen = backLen; s.forwLen = forwLen;
+            X.state[r] = s;
+            const uint32_t strand = (rec.rs & 1u) ? XP_STRAND : 0u; const bool vb = backLen >= P.minExtLength, vf = forwLen >= P.minExtLength;
+            ExtProb pb; pb.qBase = r0; pb.rOff = sro - 1u; pb.qOff = (uint16_t)((sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF); pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
+            ExtProb pf; pf.qBase = r0; pf.rOff = sro + (uint32_t)refLen; pf.qOff = (uint16_t)((eqo + 1) & 0xFFFF); pf.qLen = (uint16_t)(forwLen & 0xFFFF); pf.flags = strand | (vf ? XP_VALID : 0u);
+            X.probs[2 * (size_t)r] = pb; X.probs[2 * (size_t)r + 1] = pf;
+            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)pb.qLen : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)pf.qLen : 0ull;
+        }
+    }
+    perfect = waveSumU(perfect); touched = waveSumU(touched); gapCalls = waveSumU(gapCalls); gapRows = waveSumU(gapRows); gapCells = waveSumU(gapCells);
+    if (lane == 0 && (perfect | touched | gapCalls)) {
+        unsigned long long *c = A.ctr->v;
+        atomicAdd(&c[C_PERFECT], (unsigned long long)perfect); atomicAdd(&c[C_TOUCHED], (unsigned long long)touched);
+        if (gapCalls) { atomicAdd(&c[C_GAP_CALLS], (unsigned long long)gapCalls); atomicAdd(&c[C_GAP_ROWS], (unsigned long long)gapRows); atomicAdd(&c[C_GAP_CELLS], (unsigned long long)gapCells); }
+    }
+}
+
+// Phase 3 for roots that scoreClump accepts or rejects without a split (AlignHelpers.c:302-366): the merged edit list
+// [backward extension ops][phase-1 ops][forward extension ops] is scanned in place; accepted clumps are written out by
+// their lane.  A root that needs splitClump goes to slowList for k_align_p3.
+struct MergedOps {
+    const uint32_t *a, *b, *c; int na, nb, nc; int jab, jbc;      // junction merges (mergeEOLToFront / mergeEOLToBack, SW.cpp:151-261)
+    __device__ int count() const { return (na - jab) + nb + (nc - jbc); }
+    __device__ uint32_t at(int k) const
+    {
+        const int ka = na - jab;
+        if (k < ka) return a[k];
+        k -= ka;
+        if (k < nb) {
+            uint32_t op = b[k]; int len = opLen(op);
+            if (k == 0 && jab) len += opLen(a[na - 1]);
+            if (k == nb - 1 && jbc) len += opLen(c[0]);
+            return opMake(opCode(op), len & 0xFFFF);
+        }
+        return c[k - nb + jbc];
+    }
+};
+__global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
+{
+    const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < A.nRoots; const DevParams &P = A.P;
+    int verdict = -1;                                  // -1 none, 0 rejected, 1 split needed, 2 scored
+    MergedOps L; L.a = L.b = L.c = nullptr; L.na = L.nb = L.nc = L.jab = L.jbc = 0;
+    uint32_t sro = 0; int sqo = 0, eqo = 0, refLen = 0, status = 0, n = 0;
+    int matches = 0, mism = 0, ins = 0, del = 0, AGS = 0;
+    if (live) {
+        const RootState *S = X.state + r;
+        sro = S->f.sro; sqo = S->f.sqo; eqo = S->f.eqo; refLen = S->f.refLen; status = S->f.status; int score = S->f.score;
+        L.b = X.stateOps + S->listOff; L.nb = S->f.len;
+        const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
+        if (rb.score > 0) {                                                  // AlignExtFrag.cpp:112-125
+            const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
+            L.a = X.extOps + rb.opsOff; L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[L.na - 1]) == opCode(L.b[0])) ? 1 : 0;
+            score += rb.score; sqo = (sqo - aQ) & 0xFFFF; sro -= (uint32_t)aR; refLen = (refLen + aR) & 0xFFFF;
+        }
+        if (rf.score > 0) {                                                  // AlignExtFrag.cpp:128-141
+            const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
+            L.c = X.extOps + rf.opsOff; L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
+            score += rf.score; eqo = (eqo + aQ) & 0xFFFF; refLen = (refLen + aR) & 0xFFFF;
+        }
+        status |= stAligned;
+        // scoreClump
+        n = L.count(); const int aligned = score; int maxAGS = 0; verdict = 0;
+        for (int k = 0; k < n; k++) {
+            const uint32_t op = L.at(k); const int code = opCode(op), len = opLen(op);
+            if (code == OP_M) { matches += len; AGS += P.MS * len; } else if (code == OP_R) { mism += len; AGS -= P.RC * len; }
+            else if (code == OP_I) { ins += len; AGS -= (P.GO + P.GE * len); } else { del += len; AGS -= (P.GO + P.GE * len); }
+            if (AGS <= 0 || (AGS >= aligned && k != n - 1)) { verdict = 1; break; }
+            if (AGS > maxAGS) maxAGS = AGS;
+        }
+        if (verdict == 0) {
+            if (matches >= P.minRawScore && maxAGS > AGS) verdict = 1;
+            else if (matches >= P.minRawScore) {
+                const int tot = (matches + mism + ins + del) & 0xFFFF;
+                const double percent = (double)(matches & 0xFFFF) / (double)tot;
+                if (!(percent < (double)P.minIdentity)) verdict = 2;
+            }
+        }
+    }
+    { const unsigned long long sm = __ballot(verdict == 1); const unsigned slot = waveReserve(sm, X.slowCount, lane); if (verdict == 1) X.slowList[slot] = r; }
+    // emit the accepted clumps (emit() in align.h)
+    const bool acc = verdict == 2;
+    const unsigned long long am = __ballot(acc);
+    unsigned nOpsTot = 0;
+    if (am) {
+        const unsigned ci = waveReserve(am, &A.outCounts[0], lane);
+        int incl = acc ? n : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int total = __shfl(incl, 63, 64); unsigned ob = 0;
+        if (lane == 63) ob = atomicAdd(&A.outCounts[1], (unsigned)total);
+        ob = (unsigned)__shfl((int)ob, 63, 64);
+        const unsigned oi = ob + (unsigned)(incl - (acc ? n : 0));
+        if (acc) {
+            if (ci >= A.outClumpCap || (unsigned long long)oi + (unsigned)n > (unsigned long long)A.outOpsCap) atomicCAS(A.errFlag, 0, (int)YERR_OUT);
+            else {
+                const char codes[4] = {'M', 'R', 'D', 'I'};
+                for (int k = 0; k < n; k++) { const uint32_t op = L.at(k); A.outOps[oi + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
+                ygpu_clump c; c.sro = sro; c.sqo = (uint16_t)sqo; c.eqo = (uint16_t)eqo; c.refLen = (uint16_t)refLen; c.totScore = (uint16_t)(AGS & 0xFFFF);
+                c.totLength = (uint16_t)((matches + mism + ins + del) & 0xFFFF); c.matchedBases = (uint16_t)(matches & 0xFFFF); c.mismatchedBases = (uint16_t)(mism & 0xFFFF);
+                c.gapBases = (uint16_t)((ins + del) & 0xFFFF); c.status = (uint8_t)(status | stScored); c.reserved = 0; c.op_start = oi; c.n_ops = (uint32_t)n;
+                A.outClumps[ci] = c; A.outRoot[ci] = r; A.outPush[ci] = 0;
+                A.rootPushCount[r] = 1; nOpsTot = (unsigned)n;
+            }
+        }
+    }
+    const unsigned nAcc = (unsigned)__builtin_popcountll(am); nOpsTot = waveSumU(nOpsTot);
+    if (lane == 0 && nAcc) { atomicAdd(&A.ctr->v[C_SCORED], (unsigned long long)nAcc); atomicAdd(&A.ctr->v[C_OPS], (unsigned long long)nOpsTot); }
+}
+
+
+// merge the extension results, then scoreClump / splitClump as in k_align
+__global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
+{
+    const unsigned wave = blockIdx.x; const int lane = laneId();
+    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
+    __shared__ uint16_t sTrace[YD_LDS_CELLS];
+    Aligner al(A, M, sTrace);
+    PROF_INIT();
+    const unsigned nRoots = X.useList ? uniU(*X.slowCount) : uniU(A.nRoots);
+    for (;;) {
+        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(A.queueHead, 4u);
+        const unsigned r0 = uniU(t);
+        if (r0 >= nRoots) break;
+        const unsigned r1 = min(r0 + 4u, nRoots);
+        for (unsigned ri = r0; ri < r1; ri++) {
+            const unsigned r = X.useList ? uniU(X.slowList[ri]) : ri;
+            const ChainClumpRec rec = A.clumps[A.order[r]];
+            al.setRead(rec); al.rootRank = r; al.pushes = 0;
+            Frame f = X.state[r].f; const uint32_t listOff = uniU(X.state[r].listOff);
+            f.start = uni(f.start); f.len = uni(f.len);
+            uint32_t *b = al.buf(0);
+            for (int k = lane; k < f.len; k += 64) b[f.start + k] = X.stateOps[listOff + k];
+            __threadfence_block();
+            const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
+            int score = f.score;
+            if (UNI_B(rb.score > 0)) {                                      // AlignExtFrag.cpp:112-125
+                const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
+                al.mergeFrontSrc(b, f.start, f.len, X.extOps + rb.opsOff, (int)rb.nOps);
+                score += rb.score; f.sqo = (f.sqo - aQ) & 0xFFFF; f.sro -= (uint32_t)aR; f.refLen = (f.refLen + aR) & 0xFFFF;
+            }
+            if (UNI_B(rf.score > 0)) {                                      // AlignExtFrag.cpp:128-141
+                const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
+                al.mergeBackSrc(b, f.start, f.len, X.extOps + rf.opsOff, (int)rf.nOps);
+                score += rf.score; f.eqo = (f.eqo + aQ) & 0xFFFF; f.refLen = (f.refLen + aR) & 0xFFFF;
+            }
+            f.score = uni(score); f.sqo = uni(f.sqo); f.eqo = uni(f.eqo); f.refLen = uni(f.refLen); f.sro = uniU(f.sro);
+            f.status |= stAligned;
+            if (!UNI_B(al.err != 0)) al.finishRoot(f);
+            if (lane == 0) A.rootPushCount[r] = al.pushes;
+            if (UNI_B(al.err != 0)) break;
+        }
+        if (UNI_B(al.err != 0)) { if (lane == 0) atomicCAS(A.errFlag, 0, al.err); break; }
+    }
+    al.flushCounters();
+    PROF_FLUSH();
+}

@@ -21,7 +21,7 @@
 #include <algorithm>
 #include "chain.h"
 #include "seed.h"
-#include "ext_lanes.h"
+#include "phase_lanes.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
 
@@ -40,7 +40,7 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_N = 16 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_GAPOPS, CNT_N = 20 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_N };
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split"};
@@ -57,7 +57,7 @@ struct ygpu_ctx {
     DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
-    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extOps, extTrace;
+    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extOps, extTrace, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
     bool evUsed[16] = {false}; double traceT = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
@@ -221,22 +221,50 @@ static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap)
 //   k_align_p1 (wave/root: gap fills, exact-match extensions) -> scan of the strip sizes -> k_ext_rows + k_ext_trace
 //   (lane/problem, in chunks that fit the trace memory) -> k_align_p3 (wave/root: merge, scoreClump/splitClump).
 // returns -2 when an arena was too small (the caller grows and redoes the stage)
-static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, uint32_t stateOpsCap, uint32_t &extOpsCap)
+static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, uint32_t stateOpsCap, uint32_t &extOpsCap, uint32_t gapOpsPerJoint)
 {
     const uint32_t NC = ctx->nClumps; const uint32_t nProb = 2 * NC; int rc;
     uint32_t *cnt = ctx->counters.as<uint32_t>();
     ENSURE(ctx->rootState, sizeof(RootState) * (uint64_t)NC); ENSURE(ctx->stateOps, 4ull * stateOpsCap); ENSURE(ctx->extProbs, sizeof(ExtProb) * (uint64_t)nProb);
     ENSURE(ctx->rowsBound, 8ull * (nProb + 1)); ENSURE(ctx->stripOff, 8ull * (nProb + 1)); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nProb); ENSURE(ctx->extOps, 4ull * extOpsCap);
-    HIPCHK(hipMemsetAsync(cnt + CNT_STATEOPS, 0, 12, ctx->stream));            // stateops, extops, qext
+    ENSURE(ctx->slowList, 4ull * (NC + 1));
+    HIPCHK(hipMemsetAsync(cnt + CNT_STATEOPS, 0, 16, ctx->stream));            // stateops, extops, qext, slow
+    HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->rowsBound.p + nProb, 0, 8, ctx->stream));
     PhaseArgs X; X.state = ctx->rootState.as<RootState>(); X.stateOps = ctx->stateOps.as<uint32_t>(); X.stateOpsCount = cnt + CNT_STATEOPS; X.stateOpsCap = stateOpsCap;
     X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = ctx->extOps.as<uint32_t>();
     TRACE("lanes: ensure");
+    X.slowList = ctx->slowList.as<uint32_t>(); X.slowCount = cnt + CNT_SLOW; X.useList = 1;
     EV0(T_P1);
-    hipLaunchKernelGGL(k_align_p1, dim3(waves), dim3(64), 0, ctx->stream, A, X);
+    // joints of all roots
+    ENSURE(ctx->jointCount, 4ull * (NC + 2)); ENSURE(ctx->jointBase, 4ull * (NC + 2));
+    X.jointCount = ctx->jointCount.as<uint32_t>(); X.jointBase = ctx->jointBase.as<uint32_t>();
+    hipLaunchKernelGGL(k_joint_counts, dim3(gridFor(NC + 1, 256)), dim3(256), 0, ctx->stream, A, X);
+    rc = cubScan(ctx, ctx->jointCount.as<uint32_t>(), ctx->jointBase.as<uint32_t>(), NC + 1); if (rc) return rc;
+    uint32_t J = 0; rc = fetchU32(ctx, ctx->jointBase.as<uint32_t>() + NC, &J); if (rc) return rc;
+    const uint32_t gapOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)gapOpsPerJoint * J + (1u << 20));
+    ENSURE(ctx->joints, sizeof(JointRec) * (uint64_t)(J + 1)); ENSURE(ctx->sortKeys, 4ull * (J + 1)); ENSURE(ctx->sortVals, 4ull * (J + 1)); ENSURE(ctx->sortKeys2, 4ull * (J + 1)); ENSURE(ctx->sortVals2, 4ull * (J + 1));
+    ENSURE(ctx->gapOps, 4ull * gapOpsCap); ENSURE(ctx->slowList, 4ull * (std::max(NC, J) + 1));
+    X.slowList = ctx->slowList.as<uint32_t>();
+    X.joints = ctx->joints.as<JointRec>(); X.nJoints = J; X.sortKeys = ctx->sortKeys.as<uint32_t>(); X.sortVals = ctx->sortVals.as<uint32_t>(); X.sortedVals = ctx->sortVals2.as<uint32_t>();
+    X.nDP = cnt + CNT_NDP; X.gapOps = ctx->gapOps.as<uint32_t>(); X.gapOpsCount = cnt + CNT_GAPOPS; X.gapOpsCap = gapOpsCap;
+    HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 8, ctx->stream));                  // ndp, gapops
+    if (J) {
+        hipLaunchKernelGGL(k_p1_joints, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
+        size_t bytes = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
+        if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
+        const unsigned gBlocks = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 5);      // 29 KB of LDS per 64-thread block
+        ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * gBlocks); X.gapScratch = ctx->gapScratch.as<uint8_t>();
+        hipLaunchKernelGGL(k_gap_lanes, dim3(gBlocks), dim3(64), 0, ctx->stream, A, X);
+        hipLaunchKernelGGL(k_gap_wave, dim3(std::min(waves, 512u)), dim3(64), 0, ctx->stream, A, X);
+    }
+    hipLaunchKernelGGL(k_p1_assemble, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
     rc = cubScan64(ctx, ctx->rowsBound.as<unsigned long long>(), ctx->stripOff.as<unsigned long long>(), nProb + 1); if (rc) return rc;
     EV1(T_P1);
     TRACE("lanes: p1+scan");
+    if (kTrace) { uint32_t v[3] = {0, 0, 0}; fetchU32(ctx, cnt + CNT_SLOW, &v[0]); fetchU32(ctx, cnt + CNT_NDP, &v[1], 2); fprintf(stderr, "[ygpu] roots %u, joints %u, DP joints %u (wave fallback %u), gap ops %u\n", NC, J, v[1], v[0], v[2]); }
     unsigned long long totalRows = 0;
     HIPCHK(hipMemcpyAsync(&totalRows, ctx->stripOff.as<unsigned long long>() + nProb, 8, hipMemcpyDeviceToHost, ctx->stream));
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
@@ -297,10 +325,13 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     }
     X.extOps = ctx->extOps.as<uint32_t>();
     HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(cnt + CNT_SLOW, 0, 4, ctx->stream));
     EV0(T_P3);
+    hipLaunchKernelGGL(k_p3_lanes, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
     hipLaunchKernelGGL(k_align_p3, dim3(waves), dim3(64), 0, ctx->stream, A, X);
     EV1(T_P3);
     TRACE("lanes: p3");
+    if (kTrace) { uint32_t sc = 0; fetchU32(ctx, cnt + CNT_SLOW, &sc); fprintf(stderr, "[ygpu] roots %u, need splitClump (wave phase 3) %u\n", NC, sc); }
     return 0;
 }
 
@@ -326,7 +357,8 @@ static int stageAlign(ygpu_ctx *ctx)
         ENSURE(ctx->rootPush, 4ull * (NC + 1)); ENSURE(ctx->rootBase, 4ull * (NC + 1));
         // the default band runs its X-drop extensions one problem per lane (ext_lanes.h); other bands stay on the wave kernel
         const bool useLanes = ctx->laneExt && ctx->P.bandWidth == 5 && ctx->P.maxGap >= YD_LBAND;
-        uint32_t stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 4ull * NC + 4ull * ctx->nClumpFrags + (uint64_t)waves * YD_STATE_CHUNK + 65536);
+        uint32_t stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + 8ull * ctx->nClumpFrags + 65536);
+        uint32_t gapOpsPerJoint = 16;
         uint32_t extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, std::max<uint64_t>(40ull * NC + (1u << 20), ctx->extOps.cap / 4));
         uint32_t outClumpCap = NC + NC / 2 + 1024; uint32_t outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + ctx->totalBases / 2 + 65536);
         for (int attempt = 0;; attempt++) {
@@ -346,7 +378,7 @@ static int stageAlign(ygpu_ctx *ctx)
 #endif
             bool laneOverflow = false;
             if (!useLanes) hipLaunchKernelGGL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
-            else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, extOpsCap); if (rc == -2) laneOverflow = true; else if (rc) return rc; }
+            else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, extOpsCap, gapOpsPerJoint); if (rc == -2) laneOverflow = true; else if (rc) return rc; }
 #ifdef YD_PROF
             { hipStreamSynchronize(ctx->stream); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
               const char *nm[10] = {"root_total", "dp_rows", "traceback", "perfect_ext", "score", "emit", "split", "merge", "dp_calls", "roots"};
@@ -358,7 +390,7 @@ static int stageAlign(ygpu_ctx *ctx)
             if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
             if (ef != YERR_OUT || attempt >= 6) { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
             outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
-            stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap); extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * extOpsCap);
+            gapOpsPerJoint *= 2; stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap); extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * extOpsCap);
             HIPCHK(hipMemcpyAsync(ctx->clumpFrags.p, ctx->clumpFrags0.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_SCORED, 0, 8 * (16 - C_SCORED), ctx->stream));
         }
@@ -431,7 +463,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extOps, &ctx->extTrace};
+                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extOps, &ctx->extTrace, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         hipStreamDestroy(ctx->stream);
