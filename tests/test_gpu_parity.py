@@ -78,6 +78,22 @@ def test_every_golden_run_matches_on_the_device(work, index11, meta):
         assert mine == golden_lines(name), "HIP path differs from the reference on " + name
 
 
+# Parameter corners of the lane pipeline (-BW 5): run caps that bind inside the 21-column strip (k_ext_rows<true>), maxGap just
+# at the lane kernels' limit, scoring where the pure-diagonal shortcut of phase 1 is wide (cheap mismatches) or never applies
+# (expensive mismatches), a tight X-drop.  device_pipeline() asserts device == oracle per batch (records and work counters);
+# when the reference binary travelled with the snapshot its SAM is the referee as well.
+@pytest.mark.parametrize("reads,extra", [
+    ("r1k.fa", ["-G", "12"]), ("rchim.fa", ["-G", "20", "-I", "11"]), ("r10k.fa", ["-G", "10"]), ("r1k.fa", ["-G", "9"]),
+    ("rchim.fa", ["-RC", "1", "-GOC", "9", "-GEC", "3"]), ("r1k.fa", ["-RC", "9", "-GOC", "1", "-GEC", "1"]), ("r10k.fa", ["-X", "6", "-MS", "2"]),
+    ("rq.fq", ["-G", "21", "-I", "20"])])
+def test_lane_pipeline_parameter_corners(work, index11, reads, extra, tmp_path):
+    mine = device_pipeline(index11, os.path.join(work, reads), "-osh", extra, batch=700)
+    if oracle.have_reference() and "-I" not in extra:          # -I exists in experimental builds of the reference only
+        ref_out = str(tmp_path / "ref.sam")
+        oracle.run_reference(["-x", index11, "-q", os.path.join(work, reads), "-osh", ref_out] + list(extra))
+        assert mine == strip_pg(open(ref_out).read())
+
+
 def test_cli_drop_in(work, index11, tmp_path):
     out = str(tmp_path / "o.sam")
     subprocess.check_call([ya.CLI_PATH, "-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", out, "-FBS", "Y", "-t", "4", "-batch", "64"], stderr=subprocess.DEVNULL)

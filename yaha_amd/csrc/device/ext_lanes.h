@@ -37,6 +37,9 @@ struct ExtArgs {
     uint32_t *ops; unsigned int *opsCount; uint32_t opsCap; int *errFlag;
 };
 
+// CAPS = false when neither run cap can bind inside a 21-column strip (maxGap >= 21 and maxIntron >= 21: a run spans at most 20
+// columns): the run-length state (PI, PD) is then dead and is compiled out.
+template <bool CAPS>
 __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
 {
     const int lane = laneId();
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     int PV[YD_LW], PF[YD_LW], PI[YD_LW];
     uint32_t w0 = 0, w1 = 0, w2 = 0;
     int p = -1, i = 0, qLen = 0, rLen = 0, maxScore = YD_LWORST, maxi = 0, maxj = 0, qStep = 0, qcNext = 0;
-    uint32_t rOff = 0; bool rev = false, done = false, fresh = false;
+    uint32_t rOff = 0; bool rev = false, done = false;
     YD_GLOBAL const uint8_t *q = toGlobal(A.fwd); YD_GLOBAL uint32_t *strip = toGlobal(A.trace);
     unsigned calls = 0, rows = 0, cells = 0;
 #pragma unroll
@@ -112,9 +115,17 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             const int src = take ? e : lane;
             const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
             const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64), gSLo = (uint32_t)__shfl((int)eSLo, src, 64), gSHi = (uint32_t)__shfl((int)eSHi, src, 64);
-            if (take && gLens != 0u) {
+            const bool init = take && gLens != 0u;
+            // row 0 of the strip (SW.cpp:905-935; PF(0, left) = -GO, see the header) for the lanes that start a problem: plain selects,
+            // so that the state registers have one definition here and one in the row code
+#pragma unroll
+            for (int j = 0; j < YD_LW; j++) {
+                const int iV = j == leftR ? 0 : (j > leftR ? -(GO + (j - leftR) * GE) : YD_LWORST), iF = j == leftR ? -GO : YD_LWORST;
+                PV[j] = init ? iV : PV[j]; PF[j] = init ? iF : PF[j]; if (CAPS) PI[j] = init ? 0 : PI[j];
+            }
+            if (init) {
                 p = (int)(poolBase + (unsigned)e); qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
-                rev = (gMisc & XP_REV) != 0; rOff = gROff; fresh = true;
+                rev = (gMisc & XP_REV) != 0; rOff = gROff;
                 q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu);
                 strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 3ull;
                 w0 = 0; w1 = gW1; w2 = gW2;
@@ -145,8 +156,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         if (busy) { rows++; cells += ec >= sc ? (unsigned)(ec - sc + 1) : 0u; }
         int PVCol = YD_LWORST, PE = YD_LWORST, PD = 0;
         uint32_t t0 = 0, t1 = 0, t2 = 0, rowKey = 0;
-        // predecessor row of column 0 (row 0 of a fresh problem: SW.cpp:905-935 with PF(0, left) = -GO, see the header)
-        int dV = fresh ? YD_LWORST : PV[0];
+        int dV = PV[0];
 #pragma unroll
         for (int j = 0; j < YD_LW; j++) {
             const uint32_t wsrc = j < 8 ? w0 : (j < 16 ? w1 : w2);
@@ -154,30 +164,26 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             const bool eq = rc == qc;
             int V = dV + (eq ? MS : -RC);
             const int CE = PE - GE, NE = PVCol - GOE;
-            const bool cE = CE >= NE && PD < maxIntron;
-            PE = cE ? CE : NE; PD = cE ? PD + 1 : 1;
+            const bool cE = CE >= NE && (!CAPS || PD < maxIntron);
+            PE = cE ? CE : NE; if (CAPS) PD = cE ? PD + 1 : 1;
             const bool tE = PE >= V; V = tE ? PE : V;
             int upV, upF, upI;
-            if (j + 1 < YD_LW) {
-                const int k = j + 1;
-                const int iV = k == leftR ? 0 : (k > leftR ? -(GO + (k - leftR) * GE) : YD_LWORST), iF = k == leftR ? -GO : YD_LWORST;
-                upV = fresh ? iV : PV[k]; upF = fresh ? iF : PF[k]; upI = fresh ? 0 : PI[k];
-            } else { upV = YD_LWORST; upF = YD_LWORST; upI = 0; }
+            if (j + 1 < YD_LW) { upV = PV[j + 1]; upF = PF[j + 1]; upI = PI[j + 1]; } else { upV = YD_LWORST; upF = YD_LWORST; upI = 0; }
             const int CF = upF - GE, NF = upV - GOE;
-            const bool cF = CF >= NF && upI < maxGap;
-            const int F = cF ? CF : NF, I = cF ? upI + 1 : 1;
+            const bool cF = CF >= NF && (!CAPS || upI < maxGap);
+            const int F = cF ? CF : NF, I = CAPS ? (cF ? upI + 1 : 1) : 0;
             const bool tF = F >= V; V = tF ? F : V;
             uint32_t nib = eq ? (uint32_t)OP_M : (uint32_t)OP_R; nib = tE ? (uint32_t)OP_D : nib; nib = tF ? (uint32_t)OP_I : nib;
             nib |= (cE ? 4u : 0u) | (cF ? 8u : 0u);
-            if (j < 8) t0 |= nib << ((j & 7) * 4); else if (j < 16) t1 |= nib << ((j & 7) * 4); else t2 |= nib << ((j & 7) * 4);
+            if (j < 8) { t0 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t0)); } else if (j < 16) { t1 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t1)); } else { t2 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t2)); }   // pinned: the condition masks die here
             // row-major first maximum over the real cells: key = (V + BIAS) << 5 | (31 - j)
             const uint32_t key = (((uint32_t)(V + YD_BIAS)) << 5 | (uint32_t)(31 - j)) & (uint32_t)(-(int)((am >> j) & 1u));
             rowKey = key > rowKey ? key : rowKey;
             PV[j] = V; PF[j] = F; PI[j] = I; PVCol = V;
             dV = upV;                                                        // the next column's diagonal predecessor
+            __builtin_amdgcn_sched_barrier(0);                               // keep the cells in program order: their many condition masks stay short-lived
         }
-        fresh = false;
-        if (busy) { pendRow = true; pendAddr = strip + (size_t)(i - 1) * 3u; pt0 = t0; pt1 = t1; pt2 = t2; }
+        pendRow = busy; pendAddr = strip + (size_t)(i - 1) * 3u; pt0 = t0; pt1 = t1; pt2 = t2;     // unconditional: nothing for the compiler to sink
         int rv = YD_LWORST, rj = 0;
         if (rowKey) { rv = (int)(rowKey >> 5) - YD_BIAS; rj = 31 - (int)(rowKey & 31u); }
         if (rv > maxScore) { maxScore = rv; maxi = i; maxj = rj; }

@@ -301,9 +301,11 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         E.stripBase = cuts.size() == 2 ? 0ull : ctx->hStripOff[p0]; E.res = ctx->extRes.as<ExtRes>() + p0;
         HIPCHK(hipMemsetAsync(cnt + CNT_QEXT, 0, 4, ctx->stream));
         if (c == 0) EV0(T_XROWS);
-        int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_ext_rows, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
+        const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
+        auto rowsKernel = caps ? k_ext_rows<true> : k_ext_rows<false>;
+        int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
         const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)E.nProb + 255) / 256, (uint64_t)ctx->nCU * perCU);
-        hipLaunchKernelGGL(k_ext_rows, dim3(blocks), dim3(256), 0, ctx->stream, E);
+        hipLaunchKernelGGL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, E);
         TRACE("lanes: ext_rows");
         if (c + 2 == cuts.size()) EV1(T_XROWS);
         if (c == 0) EV0(T_XTRACE);
