@@ -25,6 +25,7 @@
 #define YD_LBAND 10                            // extension bandwidth 2 * BW = columns left and right of the origin
 #define YD_LWORST (-(1 << 28))                 // sentinel: far below any reachable score (|score| < 2^23), no overflow when it decays
 
+typedef uint32_t yd_u32x4 __attribute__((ext_vector_type(4)));
 struct ExtProb { uint32_t qBase, rOff; uint16_t qOff, qLen; uint32_t flags; };           // 16 B; qBase = offset of the read in fwd/rev
 enum { XP_STRAND = 1, XP_REV = 2, XP_VALID = 4 };
 struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, rLen, pad0, pad1; };       // 32 B; maxj in register columns
@@ -32,9 +33,10 @@ struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, rLen, pad0, pad1; 
 struct ExtArgs {
     DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
     const ExtProb *probs; uint32_t nProb; const unsigned long long *stripOff; unsigned long long stripBase;
-    uint32_t *trace;                            // 3 dwords per row
+    uint32_t *trace;                            // 128-byte blocks of 10 rows (3 dwords each, 2 dwords of padding); stripOff counts blocks
     ExtRes *res; unsigned int *queue; DevCounters *ctr;
-    uint32_t *ops; unsigned int *opsCount; uint32_t opsCap; int *errFlag;
+    uint32_t *ops; uint32_t opsCap; int *errFlag;
+    uint32_t *opsBound; const uint32_t *opsBase;   // per problem: slot size 2*maxi+24 (0 when nothing was added), and its exclusive scan
 };
 
 // CAPS = false when neither run cap can bind inside a 21-column strip (maxGap >= 21 and maxIntron >= 21: a run spans at most 20
@@ -42,6 +44,7 @@ struct ExtArgs {
 template <bool CAPS>
 __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
 {
+    __shared__ uint32_t sBlk[32][256];          // per lane: the current 10-row trace block, [dword][thread] (conflict-free for any row slot)
     const int lane = laneId();
     const int GO = A.P.GO, GE = A.P.GE, GOE = A.P.GO + A.P.GE, RC = A.P.RC, MS = A.P.MS, XC = A.P.X, maxIntron = A.P.maxIntron, maxGap = A.P.maxGap;
     constexpr int bandwidth = YD_LBAND, leftR = YD_LBAND;
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     unsigned poolBase = 0; int poolCount = 0, poolNext = 0; bool exhausted = false;
     uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, eSLo = 0, eSHi = 0;
     // deferred stores (see the row code)
-    bool pendRow = false; YD_GLOBAL uint32_t *pendAddr = toGlobal(A.trace); uint32_t pt0 = 0, pt1 = 0, pt2 = 0; int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0;
+    bool pendFlush = false; YD_GLOBAL uint32_t *pendBlk = toGlobal(A.trace); int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0;
 
     for (;;) {
         // ---- refill: until every lane is busy or nothing is left ----
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                         if (!rv_ && (pr.rOff + rl) > maxROff) { rl = maxROff - pr.rOff; ql = (int)rl - bandwidth; }
                         if (ql > 0) { ql &= 0xFFFF; rl &= 0xFFFF; }
                     }
-                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0; A.res[np] = r; }
+                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0; A.res[np] = r; A.opsBound[np] = 0u; }
                     else {
                         eLens = (uint32_t)ql | (rl << 16); eROff = pr.rOff; eQ = pr.qBase + pr.qOff;
                         YD_GLOBAL const uint8_t *qp = toGlobal((pr.flags & XP_STRAND) ? A.rev : A.fwd) + eQ;
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                 p = (int)(poolBase + (unsigned)e); qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
                 rev = (gMisc & XP_REV) != 0; rOff = gROff;
                 q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu);
-                strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 3ull;
+                strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 32ull;
                 w0 = 0; w1 = gW1; w2 = gW2;
             }
             poolNext += nNeed < avail ? nNeed : avail;
@@ -138,10 +141,18 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         // All memory operations of an iteration are issued here at the top: the previous row's trace cells and a finished
         // problem's result (both deferred), and the loads the row needs at its END (next query base, next reference base).
         // The wait the compiler puts at the loop header then finds them ~1000 instructions old.
-        if (pendRow) { pendAddr[0] = pt0; pendAddr[1] = pt1; pendAddr[2] = pt2; pendRow = false; }
+        if (pendFlush) {                                                     // a finished 10-row block (or a problem's last, partial one): LDS -> one 128-byte line
+            const int tid = (int)threadIdx.x;
+#pragma unroll
+            for (int d = 0; d < 32; d += 4) {
+                yd_u32x4 v; v.x = sBlk[d][tid]; v.y = sBlk[d + 1][tid]; v.z = sBlk[d + 2][tid]; v.w = sBlk[d + 3][tid];
+                *(YD_GLOBAL yd_u32x4 *)(pendBlk + d) = v;
+            }
+            pendFlush = false;
+        }
         if (pendRes >= 0) {
             ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0;
-            A.res[pendRes] = r; pendRes = -1;
+            A.res[pendRes] = r; A.opsBound[pendRes] = pendScore > 0 ? 2u * (unsigned)pendI + 24u : 0u; pendRes = -1;
         }
         const bool busy = p >= 0;
         ++i;
@@ -183,23 +194,29 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             dV = upV;                                                        // the next column's diagonal predecessor
             __builtin_amdgcn_sched_barrier(0);                               // keep the cells in program order: their many condition masks stay short-lived
         }
-        pendRow = busy; pendAddr = strip + (size_t)(i - 1) * 3u; pt0 = t0; pt1 = t1; pt2 = t2;     // unconditional: nothing for the compiler to sink
+        { const int slot = ((i - 1) % 10) * 3, tid = (int)threadIdx.x;      // this row's cells go to the lane's LDS block
+          sBlk[slot][tid] = t0; sBlk[slot + 1][tid] = t1; sBlk[slot + 2][tid] = t2; }
         int rv = YD_LWORST, rj = 0;
         if (rowKey) { rv = (int)(rowKey >> 5) - YD_BIAS; rj = 31 - (int)(rowKey & 31u); }
         if (rv > maxScore) { maxScore = rv; maxi = i; maxj = rj; }
         // slide the window: column c takes column c+1, the top column takes the new base
         const uint32_t nb = nbOdd == 2u ? 15u : (nbOdd ? (nbByte & 15u) : (nbByte >> 4));
         w0 = (w0 >> 4) | (w1 << 28); w1 = (w1 >> 4) | (w2 << 28); w2 = (w2 >> 4) | (nb << 16);
-        if (busy && (rv < maxScore - XC || i >= qLen)) {
+        const bool fin = busy && (rv < maxScore - XC || i >= qLen);
+        if (busy && (fin || i % 10 == 0)) { pendFlush = true; pendBlk = strip + (size_t)((i - 1) / 10) * 32u; }
+        if (fin) {
             pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj;
             p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
         }
     }
     // the last deferred stores
-    if (pendRow) { pendAddr[0] = pt0; pendAddr[1] = pt1; pendAddr[2] = pt2; }
+    if (pendFlush) {
+        const int tid = (int)threadIdx.x;
+        for (int d = 0; d < 32; d += 4) { yd_u32x4 v; v.x = sBlk[d][tid]; v.y = sBlk[d + 1][tid]; v.z = sBlk[d + 2][tid]; v.w = sBlk[d + 3][tid]; *(YD_GLOBAL yd_u32x4 *)(pendBlk + d) = v; }
+    }
     if (pendRes >= 0) {
         ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0;
-        A.res[pendRes] = r;
+        A.res[pendRes] = r; A.opsBound[pendRes] = pendScore > 0 ? 2u * (unsigned)pendI + 24u : 0u;
     }
     // work counters
     unsigned c0 = (unsigned)waveSumI((int)calls), c1 = (unsigned)waveSumI((int)rows);
@@ -215,16 +232,18 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
 
 // ---- traceback, lane per problem (SW.cpp:1138-1195) -----------------------------------------------------------------
 struct ExtRowBits { uint32_t a, b, c; };
-__device__ __forceinline__ ExtRowBits extLoadRow(YD_GLOBAL const uint32_t *strip, int y) { ExtRowBits r; YD_GLOBAL const uint32_t *t = strip + (size_t)(y - 1) * 3u; r.a = t[0]; r.b = t[1]; r.c = t[2]; return r; }
+__device__ __forceinline__ ExtRowBits extLoadRow(YD_GLOBAL const uint32_t *strip, int y)
+{ ExtRowBits r; YD_GLOBAL const uint32_t *t = strip + (size_t)((y - 1) / 10) * 32u + (size_t)((y - 1) % 10) * 3u; r.a = t[0]; r.b = t[1]; r.c = t[2]; return r; }
 __device__ __forceinline__ uint32_t extNib(const ExtRowBits &r, int x) { const uint32_t w = x < 8 ? r.a : (x < 16 ? r.b : r.c); return (w >> ((x & 7) * 4)) & 15u; }
 
-// Walks from (y, x) back to the origin (0, leftR).  Emission order = far end first; list position of emission k is k for
-// the backward extension (ops are added to the back, SW.cpp:1190) and n-1-k for the forward one (added to the front).
-template <bool WRITE>
-__device__ __forceinline__ int extWalk(YD_GLOBAL const uint32_t *strip, int y, int x, int leftR, uint32_t *out, int nTotal, bool rev)
+// Walks from (y, x) back to the origin (0, leftR) and writes the ops in LIST order into the problem's slot of `cap` entries.
+// Emission order = far end first; the backward extension's list is in emission order (ops are added to the back,
+// SW.cpp:1190), so it fills the slot from its start; the forward extension's list is the reverse (added to the front), so it
+// fills the slot from its end.  Returns the number of ops; `first` = index of the list's head inside the slot.
+__device__ __forceinline__ int extWalk(YD_GLOBAL const uint32_t *strip, int y, int x, int leftR, uint32_t *slot, int cap, bool rev, int &first)
 {
     int prev = -1, acc = 0, n = 0;
-    auto flush = [&]() { if (WRITE) out[rev ? n : nTotal - 1 - n] = opMake(prev, acc); n++; };
+    auto flush = [&]() { if (n < cap) slot[rev ? n : cap - 1 - n] = opMake(prev, acc); n++; };
     auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
     for (int guard = 0; guard < 70000; guard++) {
         if (y <= 0) { if (x > leftR) put(OP_D, x - leftR); break; }
@@ -243,37 +262,29 @@ __device__ __forceinline__ int extWalk(YD_GLOBAL const uint32_t *strip, int y, i
         }
     }
     if (prev >= 0) flush();
+    first = rev ? 0 : cap - n;
     return n;
 }
 
 __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 {
-    const int lane = laneId();
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int leftR = YD_LBAND;
-    ExtRes r; r.score = 0; bool live = false; bool rev = false; YD_GLOBAL const uint32_t *strip = nullptr;
-    if (p < A.nProb) { r = A.res[p]; live = r.score > 0; }
-    int n = 0;
-    if (live) {
-        rev = (A.probs[p].flags & XP_REV) != 0;
-        strip = toGlobal(A.trace) + (A.stripOff[p] - A.stripBase) * 3ull;
-        n = extWalk<false>(strip, r.maxi, r.maxj, leftR, nullptr, 0, rev);
-    }
-    // wave-aggregated reservation in the op arena
-    int incl = n;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-    const int total = __shfl(incl, 63, 64);
-    unsigned base = 0;
-    if (total > 0) {
-        if (lane == 63) base = atomicAdd(A.opsCount, (unsigned)total);
-        base = (unsigned)__shfl((int)base, 63, 64);
-        if ((unsigned long long)base + (unsigned)total > (unsigned long long)A.opsCap) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_OUT); return; }
-    }
-    if (live) {
-        const uint32_t off = base + (uint32_t)(incl - n);
-        extWalk<true>(strip, r.maxi, r.maxj, leftR, A.ops + off, n, rev);
-        r.opsOff = off; r.nOps = (uint32_t)n; A.res[p] = r;
-    }
+    if (p >= A.nProb) return;
+    ExtRes r = A.res[p];
+    if (r.score <= 0) return;
+    const bool rev = (A.probs[p].flags & XP_REV) != 0;
+    YD_GLOBAL const uint32_t *strip = toGlobal(A.trace) + (A.stripOff[p] - A.stripBase) * 32ull;
+    const uint32_t base = A.opsBase[p]; const int cap = (int)A.opsBound[p];
+    if ((unsigned long long)base + (unsigned)cap > (unsigned long long)A.opsCap) { atomicCAS(A.errFlag, 0, (int)YERR_OUT); return; }
+    int first = 0;
+    const int n = extWalk(strip, r.maxi, r.maxj, YD_LBAND, A.ops + base, cap, rev, first);
+    if (n > cap) { atomicCAS(A.errFlag, 0, (int)YERR_TRACE); return; }
+    r.opsOff = base + (uint32_t)first; r.nOps = (uint32_t)n; A.res[p] = r;
 }
 
+// chunked runs: the op offsets of a later chunk are relative to its part of the arena
+__global__ void k_ext_rebase(ExtRes *res, uint32_t n, uint32_t add)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && res[p].score > 0) res[p].opsOff += add;
+}

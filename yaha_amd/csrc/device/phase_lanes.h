@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
             ExtProb pb; pb.qBase = r0; pb.rOff = sro - 1u; pb.qOff = (uint16_t)((sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF); pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
             ExtProb pf; pf.qBase = r0; pf.rOff = sro + (uint32_t)refLen; pf.qOff = (uint16_t)((eqo + 1) & 0xFFFF); pf.qLen = (uint16_t)(forwLen & 0xFFFF); pf.flags = strand | (vf ? XP_VALID : 0u);
             X.probs[2 * (size_t)r] = pb; X.probs[2 * (size_t)r + 1] = pf;
-            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)pb.qLen : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)pf.qLen : 0ull;
+            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)((pb.qLen + 9u) / 10u) : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)((pf.qLen + 9u) / 10u) : 0ull;   // trace blocks of 10 rows
         }
     }
     perfect = waveSumU(perfect); touched = waveSumU(touched); gapCalls = waveSumU(gapCalls); gapRows = waveSumU(gapRows); gapCells = waveSumU(gapCells);

@@ -57,7 +57,7 @@ struct ygpu_ctx {
     DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
-    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extOps, extTrace, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
+    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extOps, extTrace, opsBound, opsBase, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
     bool evUsed[16] = {false}; double traceT = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
@@ -226,7 +226,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     const uint32_t NC = ctx->nClumps; const uint32_t nProb = 2 * NC; int rc;
     uint32_t *cnt = ctx->counters.as<uint32_t>();
     ENSURE(ctx->rootState, sizeof(RootState) * (uint64_t)NC); ENSURE(ctx->stateOps, 4ull * stateOpsCap); ENSURE(ctx->extProbs, sizeof(ExtProb) * (uint64_t)nProb);
-    ENSURE(ctx->rowsBound, 8ull * (nProb + 1)); ENSURE(ctx->stripOff, 8ull * (nProb + 1)); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nProb); ENSURE(ctx->extOps, 4ull * extOpsCap);
+    ENSURE(ctx->rowsBound, 8ull * (nProb + 1)); ENSURE(ctx->stripOff, 8ull * (nProb + 1)); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nProb); (void)extOpsCap;
     ENSURE(ctx->slowList, 4ull * (NC + 1));
     HIPCHK(hipMemsetAsync(cnt + CNT_STATEOPS, 0, 16, ctx->stream));            // stateops, extops, qext, slow
     HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
@@ -270,9 +270,9 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
     if (ef == YERR_OUT) return -2;
     if (ef) return 0;                                                         // reported by the caller
-    // trace memory: 12 B per row; split the problem range when it does not fit
+    // trace memory: 128-byte blocks of 10 rows; split the problem range when it does not fit
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
-    const unsigned long long budgetRows = std::max<unsigned long long>(1ull << 20, (unsigned long long)((freeB + ctx->extTrace.cap) * 8 / 10) / 12ull);
+    const unsigned long long budgetRows = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB + ctx->extTrace.cap) * 7 / 10) / 128ull);
     std::vector<uint32_t> cuts; cuts.push_back(0);
     if (totalRows > budgetRows) {
         ctx->hStripOff.resize(nProb + 1);
@@ -288,43 +288,48 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     unsigned long long chunkRowsMax = 0;
     if (cuts.size() == 2) chunkRowsMax = totalRows; else for (size_t c = 0; c + 1 < cuts.size(); c++) chunkRowsMax = std::max(chunkRowsMax, ctx->hStripOff[cuts[c + 1]] - ctx->hStripOff[cuts[c]]);
     TRACE("lanes: cuts");
-    ENSURE(ctx->extTrace, 12ull * chunkRowsMax + 256);
+    ENSURE(ctx->extTrace, 128ull * chunkRowsMax + 256);
+    ENSURE(ctx->opsBound, 4ull * (nProb + 2)); ENSURE(ctx->opsBase, 4ull * (nProb + 2));
+    HIPCHK(hipMemsetAsync(ctx->opsBound.as<uint32_t>() + nProb, 0, 4, ctx->stream));
     TRACE("lanes: ensure trace");
-    if (kTrace) fprintf(stderr, "[ygpu] totalRows %llu budgetRows %llu chunks %zu\n", totalRows, budgetRows, cuts.size() - 1);
+    if (kTrace) fprintf(stderr, "[ygpu] trace blocks %llu budget %llu chunks %zu\n", totalRows, budgetRows, cuts.size() - 1);
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
     E.trace = ctx->extTrace.as<uint32_t>(); E.queue = cnt + CNT_QEXT; E.ctr = ctx->ctr.as<DevCounters>();
-    E.ops = ctx->extOps.as<uint32_t>(); E.opsCount = cnt + CNT_EXTOPS; E.opsCap = extOpsCap; E.errFlag = ctx->errFlag.as<int>();
-    uint32_t opsBefore = 0;
+    E.errFlag = ctx->errFlag.as<int>(); E.opsBound = ctx->opsBound.as<uint32_t>(); E.opsBase = ctx->opsBase.as<uint32_t>();
+    const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
+    auto rowsKernel = caps ? k_ext_rows<true> : k_ext_rows<false>;
+    int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
+    uint32_t opsUsed = 0;                                                       // op arena filled so far (chunks append)
     for (size_t c = 0; c + 1 < cuts.size(); c++) {
         const uint32_t p0 = cuts[c], p1 = cuts[c + 1];
         E.probs = ctx->extProbs.as<ExtProb>() + p0; E.nProb = p1 - p0; E.stripOff = ctx->stripOff.as<unsigned long long>() + p0;
         E.stripBase = cuts.size() == 2 ? 0ull : ctx->hStripOff[p0]; E.res = ctx->extRes.as<ExtRes>() + p0;
+        E.opsBound = ctx->opsBound.as<uint32_t>() + p0; E.opsBase = ctx->opsBase.as<uint32_t>() + p0;
         HIPCHK(hipMemsetAsync(cnt + CNT_QEXT, 0, 4, ctx->stream));
         if (c == 0) EV0(T_XROWS);
-        const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
-        auto rowsKernel = caps ? k_ext_rows<true> : k_ext_rows<false>;
-        int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
         const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)E.nProb + 255) / 256, (uint64_t)ctx->nCU * perCU);
+        E.ops = nullptr; E.opsCap = 0;
         hipLaunchKernelGGL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, E);
         TRACE("lanes: ext_rows");
         if (c + 2 == cuts.size()) EV1(T_XROWS);
         if (c == 0) EV0(T_XTRACE);
-        for (int tries = 0;; tries++) {                                       // the op arena grows to the exact need and only the traceback is redone
-            E.ops = ctx->extOps.as<uint32_t>(); E.opsCap = extOpsCap;
-            hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(E.nProb, 256)), dim3(256), 0, ctx->stream, E);
-            uint32_t used = 0; rc = fetchU32(ctx, cnt + CNT_EXTOPS, &used); if (rc) return rc;
-            rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
-            if (ef != YERR_OUT) { opsBefore = used; break; }
-            if (tries >= 2 || used <= extOpsCap) { ctx->err = "extension op arena overflow persists"; return YGPU_EOVERFLOW; }
-            extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)used + (uint64_t)(cuts.size() > 2 ? used : used / 8) + 65536);
-            if (ctx->extOps.ensure(4ull * extOpsCap, true, ctx->stream)) { ctx->err = "hipMalloc failed for extOps"; return YGPU_ENOMEM; }
-            HIPCHK(hipMemcpyAsync(cnt + CNT_EXTOPS, &opsBefore, 4, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
-        }
+        // op slots: exclusive scan of the per-problem bounds (the element after the chunk's last problem is borrowed as the total)
+        uint32_t saved = 0;
+        if (p1 < nProb) { HIPCHK(hipMemcpyAsync(&saved, ctx->opsBound.as<uint32_t>() + p1, 4, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipMemsetAsync(ctx->opsBound.as<uint32_t>() + p1, 0, 4, ctx->stream)); }
+        rc = cubScan(ctx, ctx->opsBound.as<uint32_t>() + p0, ctx->opsBase.as<uint32_t>() + p0, E.nProb + 1); if (rc) return rc;
+        uint32_t need = 0; rc = fetchU32(ctx, ctx->opsBase.as<uint32_t>() + p1, &need); if (rc) return rc;
+        if (p1 < nProb) HIPCHK(hipMemcpyAsync(ctx->opsBound.as<uint32_t>() + p1, &saved, 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((uint64_t)opsUsed + need > 0xFFFFFFF0ull) { ctx->err = "extension op arena exceeds 2^32 entries; use a smaller batch"; return YGPU_EOVERFLOW; }
+        if (ctx->extOps.ensure(4ull * ((uint64_t)opsUsed + need) + 256, opsUsed != 0, ctx->stream)) { ctx->err = "hipMalloc failed for extOps"; return YGPU_ENOMEM; }
+        E.ops = ctx->extOps.as<uint32_t>() + opsUsed; E.opsCap = need;
+        hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(E.nProb, 256)), dim3(256), 0, ctx->stream, E);
+        if (opsUsed) hipLaunchKernelGGL(k_ext_rebase, dim3(gridFor(E.nProb, 256)), dim3(256), 0, ctx->stream, E.res, E.nProb, opsUsed);
+        opsUsed += need;
         TRACE("lanes: ext_trace");
         if (c + 2 == cuts.size()) EV1(T_XTRACE);
-        if (ef) return 0;
     }
+    rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+    if (ef) return 0;
     X.extOps = ctx->extOps.as<uint32_t>();
     HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(cnt + CNT_SLOW, 0, 4, ctx->stream));
@@ -465,7 +470,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extOps, &ctx->extTrace, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
+                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extOps, &ctx->extTrace, &ctx->opsBound, &ctx->opsBase, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         hipStreamDestroy(ctx->stream);
