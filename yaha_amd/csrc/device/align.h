@@ -148,17 +148,18 @@ struct Aligner {
         for (int k = lane; k < n; k += 64) b[start + len + k] = src[t0 + k];
         len += n; __threadfence_block();
     }
-    __device__ void mergeFrontSrc(uint32_t *b, int &start, int &len, const uint32_t *src, int cnt)
+    // reversed: list element k of the source is src[cnt-1-k]
+    __device__ void mergeFrontSrc(uint32_t *b, int &start, int &len, const uint32_t *src, int cnt, bool reversed)
     {
         if (cnt <= 0) return;
         int t1 = cnt;
         if (len > 0) {
-            uint32_t first = b[start], last = uniU(src[cnt - 1]);
+            uint32_t first = b[start], last = uniU(src[reversed ? 0 : cnt - 1]);
             if (opCode(first) == opCode(last)) { b[start] = opMake(opCode(first), (opLen(first) + opLen(last)) & 0xFFFF); t1--; }
         }
         if (start - t1 < 0) { err = YERR_ARENA; return; }
         start -= t1;
-        for (int k = lane; k < t1; k += 64) b[start + k] = src[k];
+        for (int k = lane; k < t1; k += 64) b[start + k] = src[reversed ? cnt - 1 - k : k];
         len += t1; __threadfence_block();
     }
 

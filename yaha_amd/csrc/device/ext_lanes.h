@@ -33,10 +33,10 @@ struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, rLen, pad0, pad1; 
 struct ExtArgs {
     DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
     const ExtProb *probs; uint32_t nProb; const unsigned long long *stripOff; unsigned long long stripBase;
+    const uint32_t *order;                      // problem indices in processing order (longest bound first), or nullptr
     uint32_t *trace;                            // 128-byte blocks of 10 rows (3 dwords each, 2 dwords of padding); stripOff counts blocks
     ExtRes *res; unsigned int *queue; DevCounters *ctr;
-    uint32_t *ops; uint32_t opsCap; int *errFlag;
-    uint32_t *opsBound; const uint32_t *opsBase;   // per problem: slot size 2*maxi+24 (0 when nothing was added), and its exclusive scan
+    int *errFlag;
 };
 
 // CAPS = false when neither run cap can bind inside a 21-column strip (maxGap >= 21 and maxIntron >= 21: a run spans at most 20
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     // query base), so that handing an entry to an idle lane is eight cross-lane moves and no memory latency.  One atomic
     // and one round of dependent loads per 64 problems.
     unsigned poolBase = 0; int poolCount = 0, poolNext = 0; bool exhausted = false;
-    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, eSLo = 0, eSHi = 0;
+    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, eSLo = 0, eSHi = 0, ePidx = 0;
     // deferred stores (see the row code)
     bool pendFlush = false; YD_GLOBAL uint32_t *pendBlk = toGlobal(A.trace); int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0;
 
@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                 poolBase = base; poolCount = (int)min(64u, A.nProb - base); poolNext = 0;
                 eLens = 0;
                 if (lane < poolCount) {
-                    const unsigned np = base + (unsigned)lane;
+                    const unsigned np = A.order ? A.order[base + (unsigned)lane] : base + (unsigned)lane;
+                    ePidx = np;
                     const ExtProb pr = A.probs[np];
                     int ql = 0; uint32_t rl = 0; const bool rv_ = (pr.flags & XP_REV) != 0;
                     if (pr.flags & XP_VALID) {                              // findAGSExtension, SW.cpp:479-516
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                         if (!rv_ && (pr.rOff + rl) > maxROff) { rl = maxROff - pr.rOff; ql = (int)rl - bandwidth; }
                         if (ql > 0) { ql &= 0xFFFF; rl &= 0xFFFF; }
                     }
-                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0; A.res[np] = r; A.opsBound[np] = 0u; }
+                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0; A.res[np] = r; }
                     else {
                         eLens = (uint32_t)ql | (rl << 16); eROff = pr.rOff; eQ = pr.qBase + pr.qOff;
                         YD_GLOBAL const uint8_t *qp = toGlobal((pr.flags & XP_STRAND) ? A.rev : A.fwd) + eQ;
@@ -118,6 +119,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             const int src = take ? e : lane;
             const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
             const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64), gSLo = (uint32_t)__shfl((int)eSLo, src, 64), gSHi = (uint32_t)__shfl((int)eSHi, src, 64);
+            const uint32_t gPidx = (uint32_t)__shfl((int)ePidx, src, 64);
             const bool init = take && gLens != 0u;
             // row 0 of the strip (SW.cpp:905-935; PF(0, left) = -GO, see the header) for the lanes that start a problem: plain selects,
             // so that the state registers have one definition here and one in the row code
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                 PV[j] = init ? iV : PV[j]; PF[j] = init ? iF : PF[j]; if (CAPS) PI[j] = init ? 0 : PI[j];
             }
             if (init) {
-                p = (int)(poolBase + (unsigned)e); qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
+                p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
                 rev = (gMisc & XP_REV) != 0; rOff = gROff;
                 q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu);
                 strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 32ull;
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         }
         if (pendRes >= 0) {
             ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0;
-            A.res[pendRes] = r; A.opsBound[pendRes] = pendScore > 0 ? 2u * (unsigned)pendI + 24u : 0u; pendRes = -1;
+            A.res[pendRes] = r; pendRes = -1;
         }
         const bool busy = p >= 0;
         ++i;
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     }
     if (pendRes >= 0) {
         ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0;
-        A.res[pendRes] = r; A.opsBound[pendRes] = pendScore > 0 ? 2u * (unsigned)pendI + 24u : 0u;
+        A.res[pendRes] = r;
     }
     // work counters
     unsigned c0 = (unsigned)waveSumI((int)calls), c1 = (unsigned)waveSumI((int)rows);
@@ -236,24 +238,34 @@ __device__ __forceinline__ ExtRowBits extLoadRow(YD_GLOBAL const uint32_t *strip
 { ExtRowBits r; YD_GLOBAL const uint32_t *t = strip + (size_t)((y - 1) / 10) * 32u + (size_t)((y - 1) % 10) * 3u; r.a = t[0]; r.b = t[1]; r.c = t[2]; return r; }
 __device__ __forceinline__ uint32_t extNib(const ExtRowBits &r, int x) { const uint32_t w = x < 8 ? r.a : (x < 16 ? r.b : r.c); return (w >> ((x & 7) * 4)) & 15u; }
 
-// Walks from (y, x) back to the origin (0, leftR) and writes the ops in LIST order into the problem's slot of `cap` entries.
-// Emission order = far end first; the backward extension's list is in emission order (ops are added to the back,
-// SW.cpp:1190), so it fills the slot from its start; the forward extension's list is the reverse (added to the front), so it
-// fills the slot from its end.  Returns the number of ops; `first` = index of the list's head inside the slot.
-__device__ __forceinline__ int extWalk(YD_GLOBAL const uint32_t *strip, int y, int x, int leftR, uint32_t *slot, int cap, bool rev, int &first)
+// Walks from (y, x) back to the origin (0, leftR).  The ops are written INTO THE STRIP, over rows the walk has already
+// consumed: emission k (far end first) goes to dword E-1-k, E = end of row maxi+1 (the strip has one spare row).  After
+// k rows are consumed at most 2k+1 ops exist (every op but a D needs a row of its own, and two D ops never touch) and
+// 3k+3 dwords are free, so the walk never overwrites a row it still has to read.  The result is the ascending array
+// strip[opsOff .. opsOff+nOps): the forward extension's list in order (ops are added to the front, SW.cpp:1186), the
+// backward extension's list reversed (added to the back, SW.cpp:1190).
+__device__ __forceinline__ int extRowWord(int y) { return ((y - 1) / 10) * 32 + ((y - 1) % 10) * 3; }
+__global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 {
-    int prev = -1, acc = 0, n = 0;
-    auto flush = [&]() { if (n < cap) slot[rev ? n : cap - 1 - n] = opMake(prev, acc); n++; };
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.nProb) return;
+    ExtRes r = A.res[p];
+    if (r.score <= 0) return;
+    YD_GLOBAL uint32_t *strip = toGlobal(A.trace) + (A.stripOff[p] - A.stripBase) * 32ull;
+    constexpr int leftR = YD_LBAND;
+    const int E = extRowWord(r.maxi + 1) + 3;
+    int y = r.maxi, x = r.maxj, prev = -1, acc = 0, n = 0; bool bad = false;
+    auto flush = [&]() { const int w = E - 1 - n; if (w < extRowWord(y + 1)) bad = true; else strip[w] = opMake(prev, acc); n++; };
     auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
     for (int guard = 0; guard < 70000; guard++) {
         if (y <= 0) { if (x > leftR) put(OP_D, x - leftR); break; }
         if (x < 0 || x >= YD_LW) break;
-        ExtRowBits r = extLoadRow(strip, y);
-        const uint32_t nib = extNib(r, x); const int op = (int)(nib & 3u);
+        const ExtRowBits rb = extLoadRow(strip, y);
+        const uint32_t nib = extNib(rb, x); const int op = (int)(nib & 3u);
         if (op < OP_D) { put(op, 1); y -= 1; }
         else if (op == OP_D) {
             int run = 1, xx = x;
-            while (extNib(r, xx) & 4u) { xx--; if (xx < 0) break; run++; }
+            while (extNib(rb, xx) & 4u) { xx--; if (xx < 0) break; run++; }
             put(OP_D, run); x -= run;
         } else {
             int run = 1, yy = y, xx = x; uint32_t nb2 = nib;
@@ -261,30 +273,14 @@ __device__ __forceinline__ int extWalk(YD_GLOBAL const uint32_t *strip, int y, i
             put(OP_I, run); y -= run; x += run;
         }
     }
-    if (prev >= 0) flush();
-    first = rev ? 0 : cap - n;
-    return n;
+    if (prev >= 0) { const int w = E - 1 - n; if (w < (y >= 0 ? extRowWord(y + 1) : 0)) bad = true; else strip[w] = opMake(prev, acc); n++; }
+    if (bad) { atomicCAS(A.errFlag, 0, (int)YERR_TRACE); return; }
+    r.opsOff = (uint32_t)(E - n); r.nOps = (uint32_t)n; A.res[p] = r;
 }
 
-__global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
+// order values are global problem indices; a chunk's kernels index from the chunk's first problem
+__global__ void k_rebase_u32(uint32_t *v, uint32_t n, uint32_t sub)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.nProb) return;
-    ExtRes r = A.res[p];
-    if (r.score <= 0) return;
-    const bool rev = (A.probs[p].flags & XP_REV) != 0;
-    YD_GLOBAL const uint32_t *strip = toGlobal(A.trace) + (A.stripOff[p] - A.stripBase) * 32ull;
-    const uint32_t base = A.opsBase[p]; const int cap = (int)A.opsBound[p];
-    if ((unsigned long long)base + (unsigned)cap > (unsigned long long)A.opsCap) { atomicCAS(A.errFlag, 0, (int)YERR_OUT); return; }
-    int first = 0;
-    const int n = extWalk(strip, r.maxi, r.maxj, YD_LBAND, A.ops + base, cap, rev, first);
-    if (n > cap) { atomicCAS(A.errFlag, 0, (int)YERR_TRACE); return; }
-    r.opsOff = base + (uint32_t)first; r.nOps = (uint32_t)n; A.res[p] = r;
-}
-
-// chunked runs: the op offsets of a later chunk are relative to its part of the arena
-__global__ void k_ext_rebase(ExtRes *res, uint32_t n, uint32_t add)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n && res[p].score > 0) res[p].opsOff += add;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] -= sub;
 }

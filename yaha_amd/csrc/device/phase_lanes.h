@@ -31,13 +31,15 @@ struct JointRec {                                           // 32 B
 struct PhaseArgs {
     RootState *state; uint32_t *stateOps; unsigned int *stateOpsCount; uint32_t stateOpsCap;
     ExtProb *probs; unsigned long long *rowsBound;      // 2 per root
-    const ExtRes *res; const uint32_t *extOps;
+    const ExtRes *res; const uint32_t *trace; const unsigned long long *stripOff; unsigned long long stripBase;   // extension results; their ops live in the trace strips
     uint32_t *slowList; unsigned int *slowCount;        // roots (k_p3_lanes) or joints (k_gap_lanes) handed to the wave kernels
     int useList;                                        // k_align_p3: take roots from slowList[0 .. *slowCount)
+    uint32_t rootBegin;                                 // k_p3_lanes: first root of the chunk (A.nRoots = its end)
     // joints
     uint32_t *jointCount; const uint32_t *jointBase; JointRec *joints; uint32_t nJoints;
     uint32_t *sortKeys, *sortVals; const uint32_t *sortedVals; unsigned int *nDP;
     uint32_t *gapOps; unsigned int *gapOpsCount; uint32_t gapOpsCap;
+    uint32_t *extKeys, *extVals;                        // k_ext_rows takes the problems longest-bound first (keys = 0xFFFF - qLen)
     uint8_t *gapScratch;                                // YD_GAP_SCRATCH bytes per k_gap_lanes thread (trace strip + op list of gapDPLane)
 };
 
@@ -342,7 +344,9 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
             ExtProb pb; pb.qBase = r0; pb.rOff = sro - 1u; pb.qOff = (uint16_t)((sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF); pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
             ExtProb pf; pf.qBase = r0; pf.rOff = sro + (uint32_t)refLen; pf.qOff = (uint16_t)((eqo + 1) & 0xFFFF); pf.qLen = (uint16_t)(forwLen & 0xFFFF); pf.flags = strand | (vf ? XP_VALID : 0u);
             X.probs[2 * (size_t)r] = pb; X.probs[2 * (size_t)r + 1] = pf;
-            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)((pb.qLen + 9u) / 10u) : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)((pf.qLen + 9u) / 10u) : 0ull;   // trace blocks of 10 rows
+            X.extKeys[2 * (size_t)r] = vb ? 0xFFFFu - pb.qLen : 0x10000u; X.extKeys[2 * (size_t)r + 1] = vf ? 0xFFFFu - pf.qLen : 0x10000u;
+            X.extVals[2 * (size_t)r] = 2u * r; X.extVals[2 * (size_t)r + 1] = 2u * r + 1u;
+            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)((pb.qLen + 10u) / 10u) : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)((pf.qLen + 10u) / 10u) : 0ull;   // trace blocks of 10 rows, one spare row
         }
     }
     perfect = waveSumU(perfect); touched = waveSumU(touched); gapCalls = waveSumU(gapCalls); gapRows = waveSumU(gapRows); gapCells = waveSumU(gapCells);
@@ -358,15 +362,16 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
 // their lane.  A root that needs splitClump goes to slowList for k_align_p3.
 struct MergedOps {
     const uint32_t *a, *b, *c; int na, nb, nc; int jab, jbc;      // junction merges (mergeEOLToFront / mergeEOLToBack, SW.cpp:151-261)
+    // a = the backward extension's ops as k_ext_trace leaves them (list order reversed): list element k = a[na-1-k]
     __device__ int count() const { return (na - jab) + nb + (nc - jbc); }
     __device__ uint32_t at(int k) const
     {
         const int ka = na - jab;
-        if (k < ka) return a[k];
+        if (k < ka) return a[na - 1 - k];
         k -= ka;
         if (k < nb) {
             uint32_t op = b[k]; int len = opLen(op);
-            if (k == 0 && jab) len += opLen(a[na - 1]);
+            if (k == 0 && jab) len += opLen(a[0]);
             if (k == nb - 1 && jbc) len += opLen(c[0]);
             return opMake(opCode(op), len & 0xFFFF);
         }
@@ -375,7 +380,7 @@ struct MergedOps {
 };
 __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
 {
-    const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = laneId(); const uint32_t r = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
     int verdict = -1;                                  // -1 none, 0 rejected, 1 split needed, 2 scored
     MergedOps L; L.a = L.b = L.c = nullptr; L.na = L.nb = L.nc = L.jab = L.jbc = 0;
@@ -388,12 +393,12 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
         const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
         if (rb.score > 0) {                                                  // AlignExtFrag.cpp:112-125
             const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-            L.a = X.extOps + rb.opsOff; L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[L.na - 1]) == opCode(L.b[0])) ? 1 : 0;
+            L.a = X.trace + (X.stripOff[2 * (size_t)r] - X.stripBase) * 32ull + rb.opsOff; L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
             score += rb.score; sqo = (sqo - aQ) & 0xFFFF; sro -= (uint32_t)aR; refLen = (refLen + aR) & 0xFFFF;
         }
         if (rf.score > 0) {                                                  // AlignExtFrag.cpp:128-141
             const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-            L.c = X.extOps + rf.opsOff; L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
+            L.c = X.trace + (X.stripOff[2 * (size_t)r + 1] - X.stripBase) * 32ull + rf.opsOff; L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
             score += rf.score; eqo = (eqo + aQ) & 0xFFFF; refLen = (refLen + aR) & 0xFFFF;
         }
         status |= stAligned;
@@ -476,12 +481,12 @@ __global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
             int score = f.score;
             if (UNI_B(rb.score > 0)) {                                      // AlignExtFrag.cpp:112-125
                 const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-                al.mergeFrontSrc(b, f.start, f.len, X.extOps + rb.opsOff, (int)rb.nOps);
+                al.mergeFrontSrc(b, f.start, f.len, X.trace + (X.stripOff[2 * (size_t)r] - X.stripBase) * 32ull + rb.opsOff, (int)rb.nOps, true);
                 score += rb.score; f.sqo = (f.sqo - aQ) & 0xFFFF; f.sro -= (uint32_t)aR; f.refLen = (f.refLen + aR) & 0xFFFF;
             }
             if (UNI_B(rf.score > 0)) {                                      // AlignExtFrag.cpp:128-141
                 const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-                al.mergeBackSrc(b, f.start, f.len, X.extOps + rf.opsOff, (int)rf.nOps);
+                al.mergeBackSrc(b, f.start, f.len, X.trace + (X.stripOff[2 * (size_t)r + 1] - X.stripBase) * 32ull + rf.opsOff, (int)rf.nOps);
                 score += rf.score; f.eqo = (f.eqo + aQ) & 0xFFFF; f.refLen = (f.refLen + aR) & 0xFFFF;
             }
             f.score = uni(score); f.sqo = uni(f.sqo); f.eqo = uni(f.eqo); f.refLen = uni(f.refLen); f.sro = uniU(f.sro);

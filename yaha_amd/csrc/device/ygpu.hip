@@ -25,6 +25,7 @@
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
 
+#define YD_MAX_CHUNK_EV 16
 namespace {
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -57,8 +58,8 @@ struct ygpu_ctx {
     DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
-    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extOps, extTrace, opsBound, opsBase, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; int laneChunks = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -221,18 +222,18 @@ static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap)
 //   k_align_p1 (wave/root: gap fills, exact-match extensions) -> scan of the strip sizes -> k_ext_rows + k_ext_trace
 //   (lane/problem, in chunks that fit the trace memory) -> k_align_p3 (wave/root: merge, scoreClump/splitClump).
 // returns -2 when an arena was too small (the caller grows and redoes the stage)
-static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, uint32_t stateOpsCap, uint32_t &extOpsCap, uint32_t gapOpsPerJoint)
+static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, uint32_t stateOpsCap, uint32_t gapOpsPerJoint)
 {
     const uint32_t NC = ctx->nClumps; const uint32_t nProb = 2 * NC; int rc;
     uint32_t *cnt = ctx->counters.as<uint32_t>();
     ENSURE(ctx->rootState, sizeof(RootState) * (uint64_t)NC); ENSURE(ctx->stateOps, 4ull * stateOpsCap); ENSURE(ctx->extProbs, sizeof(ExtProb) * (uint64_t)nProb);
-    ENSURE(ctx->rowsBound, 8ull * (nProb + 1)); ENSURE(ctx->stripOff, 8ull * (nProb + 1)); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nProb); (void)extOpsCap;
+    ENSURE(ctx->rowsBound, 8ull * (nProb + 1)); ENSURE(ctx->stripOff, 8ull * (nProb + 1)); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nProb);
     ENSURE(ctx->slowList, 4ull * (NC + 1));
     HIPCHK(hipMemsetAsync(cnt + CNT_STATEOPS, 0, 16, ctx->stream));            // stateops, extops, qext, slow
     HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->rowsBound.p + nProb, 0, 8, ctx->stream));
     PhaseArgs X; X.state = ctx->rootState.as<RootState>(); X.stateOps = ctx->stateOps.as<uint32_t>(); X.stateOpsCount = cnt + CNT_STATEOPS; X.stateOpsCap = stateOpsCap;
-    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = ctx->extOps.as<uint32_t>();
+    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.trace = nullptr; X.stripOff = nullptr; X.stripBase = 0; X.rootBegin = 0;
     TRACE("lanes: ensure");
     X.slowList = ctx->slowList.as<uint32_t>(); X.slowCount = cnt + CNT_SLOW; X.useList = 1;
     EV0(T_P1);
@@ -260,6 +261,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         hipLaunchKernelGGL(k_gap_lanes, dim3(gBlocks), dim3(64), 0, ctx->stream, A, X);
         hipLaunchKernelGGL(k_gap_wave, dim3(std::min(waves, 512u)), dim3(64), 0, ctx->stream, A, X);
     }
+    ENSURE(ctx->extKeys, 4ull * (nProb + 1)); ENSURE(ctx->extVals, 4ull * (nProb + 1)); ENSURE(ctx->extKeys2, 4ull * (nProb + 1)); ENSURE(ctx->extOrder, 4ull * (nProb + 1));
+    X.extKeys = ctx->extKeys.as<uint32_t>(); X.extVals = ctx->extVals.as<uint32_t>();
     hipLaunchKernelGGL(k_p1_assemble, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
     rc = cubScan64(ctx, ctx->rowsBound.as<unsigned long long>(), ctx->stripOff.as<unsigned long long>(), nProb + 1); if (rc) return rc;
     EV1(T_P1);
@@ -270,75 +273,79 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
     if (ef == YERR_OUT) return -2;
     if (ef) return 0;                                                         // reported by the caller
-    // trace memory: 128-byte blocks of 10 rows; split the problem range when it does not fit
+    // Trace memory: 128-byte blocks of 10 rows.  The roots are processed in chunks: k_ext_rows of chunk c+1 (VALU-bound, main
+    // stream) overlaps the latency-bound tail of chunk c (traceback, scoreClump/emit, splitClump waves; second stream).  When
+    // the strips do not fit in memory the chunks reuse one buffer and run back to back instead.
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
-    const unsigned long long budgetRows = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB + ctx->extTrace.cap) * 7 / 10) / 128ull);
-    std::vector<uint32_t> cuts; cuts.push_back(0);
-    if (totalRows > budgetRows) {
+    const unsigned long long budget = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB + ctx->extTrace.cap) * 7 / 10) / 128ull);
+    std::vector<uint32_t> cuts; cuts.push_back(0);                            // root indices
+    const bool fits = totalRows <= budget;
+    if (fits) {
+        const uint32_t K = (ctx->laneChunks > 0) ? (uint32_t)ctx->laneChunks : 1u;      // measured: every k_ext_rows launch ends in a drain of long problems, so more chunks lose more than the overlap gains
+        for (uint32_t c = 1; c <= K; c++) { uint32_t r1 = (uint32_t)((uint64_t)NC * c / K); if (r1 > cuts.back()) cuts.push_back(r1); }
+    } else {
         ctx->hStripOff.resize(nProb + 1);
         HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
-        uint32_t p0 = 0;
-        while (p0 < nProb) {
-            const unsigned long long lim = ctx->hStripOff[p0] + budgetRows;
-            uint32_t p1 = (uint32_t)(std::upper_bound(ctx->hStripOff.begin() + p0, ctx->hStripOff.end(), lim) - ctx->hStripOff.begin()) - 1;
-            if (p1 <= p0) { ctx->err = "not enough device memory for one extension trace strip"; return YGPU_ENOMEM; }
-            cuts.push_back(p1); p0 = p1;
+        uint32_t r0 = 0;
+        while (r0 < NC) {
+            uint32_t lo = r0 + 1, hi = NC;                                    // largest r1 with strips(r0 .. r1) <= budget
+            if (ctx->hStripOff[2 * (size_t)lo] - ctx->hStripOff[2 * (size_t)r0] > budget) { ctx->err = "not enough device memory for one root's extension trace strips"; return YGPU_ENOMEM; }
+            while (lo < hi) { uint32_t mid = lo + (hi - lo + 1) / 2; if (ctx->hStripOff[2 * (size_t)mid] - ctx->hStripOff[2 * (size_t)r0] <= budget) lo = mid; else hi = mid - 1; }
+            cuts.push_back(lo); r0 = lo;
         }
-    } else cuts.push_back(nProb);
-    unsigned long long chunkRowsMax = 0;
-    if (cuts.size() == 2) chunkRowsMax = totalRows; else for (size_t c = 0; c + 1 < cuts.size(); c++) chunkRowsMax = std::max(chunkRowsMax, ctx->hStripOff[cuts[c + 1]] - ctx->hStripOff[cuts[c]]);
+    }
+    const size_t nChunks = cuts.size() - 1;
+    unsigned long long chunkMax = 0;
+    if (fits) chunkMax = totalRows; else for (size_t c = 0; c < nChunks; c++) chunkMax = std::max(chunkMax, ctx->hStripOff[2 * (size_t)cuts[c + 1]] - ctx->hStripOff[2 * (size_t)cuts[c]]);
     TRACE("lanes: cuts");
-    ENSURE(ctx->extTrace, 128ull * chunkRowsMax + 256);
-    ENSURE(ctx->opsBound, 4ull * (nProb + 2)); ENSURE(ctx->opsBase, 4ull * (nProb + 2));
-    HIPCHK(hipMemsetAsync(ctx->opsBound.as<uint32_t>() + nProb, 0, 4, ctx->stream));
+    ENSURE(ctx->extTrace, 128ull * chunkMax + 256);
+    ENSURE(ctx->chunkCnt, 16ull * (nChunks + 1));
+    HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 16ull * (nChunks + 1), ctx->stream));
     TRACE("lanes: ensure trace");
-    if (kTrace) fprintf(stderr, "[ygpu] trace blocks %llu budget %llu chunks %zu\n", totalRows, budgetRows, cuts.size() - 1);
+    if (kTrace) fprintf(stderr, "[ygpu] trace blocks %llu budget %llu chunks %zu %s\n", totalRows, budget, nChunks, fits ? "(pipelined)" : "(sequential, one buffer)");
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
-    E.trace = ctx->extTrace.as<uint32_t>(); E.queue = cnt + CNT_QEXT; E.ctr = ctx->ctr.as<DevCounters>();
-    E.errFlag = ctx->errFlag.as<int>(); E.opsBound = ctx->opsBound.as<uint32_t>(); E.opsBase = ctx->opsBase.as<uint32_t>();
+    E.trace = ctx->extTrace.as<uint32_t>(); E.ctr = ctx->ctr.as<DevCounters>(); E.errFlag = ctx->errFlag.as<int>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
     auto rowsKernel = caps ? k_ext_rows<true> : k_ext_rows<false>;
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
-    uint32_t opsUsed = 0;                                                       // op arena filled so far (chunks append)
-    for (size_t c = 0; c + 1 < cuts.size(); c++) {
-        const uint32_t p0 = cuts[c], p1 = cuts[c + 1];
-        E.probs = ctx->extProbs.as<ExtProb>() + p0; E.nProb = p1 - p0; E.stripOff = ctx->stripOff.as<unsigned long long>() + p0;
-        E.stripBase = cuts.size() == 2 ? 0ull : ctx->hStripOff[p0]; E.res = ctx->extRes.as<ExtRes>() + p0;
-        E.opsBound = ctx->opsBound.as<uint32_t>() + p0; E.opsBase = ctx->opsBase.as<uint32_t>() + p0;
-        HIPCHK(hipMemsetAsync(cnt + CNT_QEXT, 0, 4, ctx->stream));
-        if (c == 0) EV0(T_XROWS);
-        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)E.nProb + 255) / 256, (uint64_t)ctx->nCU * perCU);
-        E.ops = nullptr; E.opsCap = 0;
+    const bool overlap = fits && nChunks > 1;
+    hipStream_t sTail = overlap ? ctx->stream2 : ctx->stream;
+    X.trace = ctx->extTrace.as<uint32_t>(); X.stripOff = ctx->stripOff.as<unsigned long long>();
+    uint32_t *cc = ctx->chunkCnt.as<uint32_t>();
+    EV0(T_XROWS);
+    for (size_t c = 0; c < nChunks; c++) {
+        const uint32_t r0 = cuts[c], r1 = cuts[c + 1], p0 = 2 * r0, np = 2 * (r1 - r0);
+        const unsigned long long sb = fits ? 0ull : ctx->hStripOff[p0];
+        E.probs = ctx->extProbs.as<ExtProb>() + p0; E.nProb = np; E.stripOff = ctx->stripOff.as<unsigned long long>() + p0; E.stripBase = sb; E.res = ctx->extRes.as<ExtRes>() + p0;
+        E.queue = cc + 4 * c;
+        {   // longest bound first: the launch's drain phase is then left with short problems only
+            size_t bytes = 0; uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 17, ctx->stream));
+            if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, 17, ctx->stream));
+            hipLaunchKernelGGL(k_rebase_u32, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, v1, np, p0);
+            E.order = v1;
+        }
+        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + 255) / 256, (uint64_t)ctx->nCU * perCU);
         hipLaunchKernelGGL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, E);
-        TRACE("lanes: ext_rows");
-        if (c + 2 == cuts.size()) EV1(T_XROWS);
-        if (c == 0) EV0(T_XTRACE);
-        // op slots: exclusive scan of the per-problem bounds (the element after the chunk's last problem is borrowed as the total)
-        uint32_t saved = 0;
-        if (p1 < nProb) { HIPCHK(hipMemcpyAsync(&saved, ctx->opsBound.as<uint32_t>() + p1, 4, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipMemsetAsync(ctx->opsBound.as<uint32_t>() + p1, 0, 4, ctx->stream)); }
-        rc = cubScan(ctx, ctx->opsBound.as<uint32_t>() + p0, ctx->opsBase.as<uint32_t>() + p0, E.nProb + 1); if (rc) return rc;
-        uint32_t need = 0; rc = fetchU32(ctx, ctx->opsBase.as<uint32_t>() + p1, &need); if (rc) return rc;
-        if (p1 < nProb) HIPCHK(hipMemcpyAsync(ctx->opsBound.as<uint32_t>() + p1, &saved, 4, hipMemcpyHostToDevice, ctx->stream));
-        if ((uint64_t)opsUsed + need > 0xFFFFFFF0ull) { ctx->err = "extension op arena exceeds 2^32 entries; use a smaller batch"; return YGPU_EOVERFLOW; }
-        if (ctx->extOps.ensure(4ull * ((uint64_t)opsUsed + need) + 256, opsUsed != 0, ctx->stream)) { ctx->err = "hipMalloc failed for extOps"; return YGPU_ENOMEM; }
-        E.ops = ctx->extOps.as<uint32_t>() + opsUsed; E.opsCap = need;
-        hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(E.nProb, 256)), dim3(256), 0, ctx->stream, E);
-        if (opsUsed) hipLaunchKernelGGL(k_ext_rebase, dim3(gridFor(E.nProb, 256)), dim3(256), 0, ctx->stream, E.res, E.nProb, opsUsed);
-        opsUsed += need;
-        TRACE("lanes: ext_trace");
-        if (c + 2 == cuts.size()) EV1(T_XTRACE);
+        if (c + 1 == nChunks) EV1(T_XROWS);
+        if (overlap) { HIPCHK(hipEventRecord(ctx->evChunk[c % YD_MAX_CHUNK_EV], ctx->stream)); HIPCHK(hipStreamWaitEvent(sTail, ctx->evChunk[c % YD_MAX_CHUNK_EV], 0)); }
+        else TRACE("lanes: ext_rows");
+        // the chunk's tail
+        if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], sTail); }
+        hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(np, 256)), dim3(256), 0, sTail, E);
+        if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_XTRACE][1], sTail);
+        if (!overlap) TRACE("lanes: ext_trace");
+        AlignArgs Ac = A; Ac.nRoots = r1; Ac.queueHead = cc + 4 * c + 1;
+        PhaseArgs Xc = X; Xc.stripBase = sb; Xc.rootBegin = r0; Xc.slowList = ctx->slowList.as<uint32_t>() + r0; Xc.slowCount = cc + 4 * c + 2; Xc.useList = 1;
+        if (c == 0) { ctx->evUsed[T_P3] = true; hipEventRecord(ctx->ev[T_P3][0], sTail); }
+        hipLaunchKernelGGL(k_p3_lanes, dim3(gridFor(r1 - r0, 256)), dim3(256), 0, sTail, Ac, Xc);
+        hipLaunchKernelGGL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, sTail, Ac, Xc);
+        if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_P3][1], sTail);
+        if (!overlap) TRACE("lanes: p3");
     }
-    rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
-    if (ef) return 0;
-    X.extOps = ctx->extOps.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
-    HIPCHK(hipMemsetAsync(cnt + CNT_SLOW, 0, 4, ctx->stream));
-    EV0(T_P3);
-    hipLaunchKernelGGL(k_p3_lanes, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
-    hipLaunchKernelGGL(k_align_p3, dim3(waves), dim3(64), 0, ctx->stream, A, X);
-    EV1(T_P3);
-    TRACE("lanes: p3");
-    if (kTrace) { uint32_t sc = 0; fetchU32(ctx, cnt + CNT_SLOW, &sc); fprintf(stderr, "[ygpu] roots %u, need splitClump (wave phase 3) %u\n", NC, sc); }
+    if (overlap) { HIPCHK(hipEventRecord(ctx->evTail, sTail)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0)); }
+    TRACE("lanes: chunks done");
     return 0;
 }
 
@@ -366,7 +373,6 @@ static int stageAlign(ygpu_ctx *ctx)
         const bool useLanes = ctx->laneExt && ctx->P.bandWidth == 5 && ctx->P.maxGap >= YD_LBAND;
         uint32_t stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + 8ull * ctx->nClumpFrags + 65536);
         uint32_t gapOpsPerJoint = 16;
-        uint32_t extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, std::max<uint64_t>(40ull * NC + (1u << 20), ctx->extOps.cap / 4));
         uint32_t outClumpCap = NC + NC / 2 + 1024; uint32_t outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + ctx->totalBases / 2 + 65536);
         for (int attempt = 0;; attempt++) {
             ENSURE(ctx->outClumps, sizeof(ygpu_clump) * (uint64_t)outClumpCap); ENSURE(ctx->outClumps2, sizeof(ygpu_clump) * (uint64_t)outClumpCap);
@@ -385,7 +391,7 @@ static int stageAlign(ygpu_ctx *ctx)
 #endif
             bool laneOverflow = false;
             if (!useLanes) hipLaunchKernelGGL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
-            else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, extOpsCap, gapOpsPerJoint); if (rc == -2) laneOverflow = true; else if (rc) return rc; }
+            else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, gapOpsPerJoint); if (rc == -2) laneOverflow = true; else if (rc) return rc; }
 #ifdef YD_PROF
             { hipStreamSynchronize(ctx->stream); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
               const char *nm[10] = {"root_total", "dp_rows", "traceback", "perfect_ext", "score", "emit", "split", "merge", "dp_calls", "roots"};
@@ -397,7 +403,7 @@ static int stageAlign(ygpu_ctx *ctx)
             if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
             if (ef != YERR_OUT || attempt >= 6) { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
             outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
-            gapOpsPerJoint *= 2; stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap); extOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * extOpsCap);
+            gapOpsPerJoint *= 2; stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap);
             HIPCHK(hipMemcpyAsync(ctx->clumpFrags.p, ctx->clumpFrags0.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_SCORED, 0, 8 * (16 - C_SCORED), ctx->stream));
         }
@@ -444,7 +450,10 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     if (p->maxGap < 0 || p->maxGap > 16383 || p->maxIntron < 0 || p->maxHits < 0 || p->maxHits > 65525) { ctx->err = "maxGap/maxIntron/maxHits out of range"; return YGPU_EINVAL; }
     if (p->MScore < 0 || p->RCost < 0 || p->GECost < 0 || p->GOCost < 0 || big >= (1L << 23)) { ctx->err = "scoring parameters out of the supported range"; return YGPU_EINVAL; }
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreate(&ctx->stream));
+    HIPCHK(hipStreamCreate(&ctx->stream)); HIPCHK(hipStreamCreate(&ctx->stream2));
+    for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evTail, hipEventDisableTiming));
+    if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
     DevParams &P = ctx->P;
@@ -470,9 +479,11 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extOps, &ctx->extTrace, &ctx->opsBound, &ctx->opsBase, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
+                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
+        for (int i = 0; i < YD_MAX_CHUNK_EV; i++) hipEventDestroy(ctx->evChunk[i]);
+        hipEventDestroy(ctx->evTail); hipStreamDestroy(ctx->stream2);
         hipStreamDestroy(ctx->stream);
     }
     delete ctx;
