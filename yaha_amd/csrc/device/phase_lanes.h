@@ -57,14 +57,19 @@ __device__ __forceinline__ unsigned waveReserve(unsigned long long mask, unsigne
 
 
 // ---- gap-fill DP of one lane (findAGSAlignment / findAGSAlignmentBanded, SW.cpp:462-477, 798-1208) ---------------------------
-// The sequential recurrence, one problem per lane: strip state (PV/PF/PI, up to 33 columns) and the reference segment in
-// LDS laid out [column][lane] (bank = lane, conflict-free whatever column each lane is at), trace cells (op | run << 2) in
-// a lane-private HBM strip, traceback as the reference's.  Handles W <= 32, qLen <= 64, rLen <= 64; anything larger stays
-// on the wave kernel.  Returns the ops in emission order (far end first) in tmp[0..nOps).
-#define YD_GW 32
-#define YD_GAP_SCRATCH (((YD_GROWS + 1) * YD_GW * 2 + (2 * YD_GROWS + 64) * 4 + 255) & ~255)
-#define YD_GROWS 64
-struct GapLaneMem { int *pv, *pf, *pi; uint8_t *ref; uint16_t *T; uint32_t *tmp; };   // LDS pointers already offset by lane (stride 64); T, tmp in HBM
+// The sequential recurrence, one problem per lane: strip state (PV/PF int32, PI uint8, GW+1 columns) and the reference
+// segment in LDS laid out [column][lane] (conflict-free whatever column each lane is at), trace cells (op | run << 2, one
+// byte) in a lane-private HBM strip written four cells per store, traceback as the reference's.  Two instances: GW = 16
+// (14 KB of LDS per wave: most gaps) and GW = 32 (23 KB).  Limits: W <= GW, qLen <= 62, rLen <= 64; anything larger
+// goes to the wave kernel.  Returns the ops in emission order (far end first) in tmp[0..nOps).
+#define YD_GROWS 60
+#define YD_GREF 64
+#define YD_GQW 16                                // dwords of query codes (60 + alignment slack)
+#define YD_GRW 10                                // dwords of packed reference (64 bases + alignment slack)
+#define YD_GAP_SCRATCH 3072                    // per lane: (YD_GROWS + 1) * 32 trace bytes + 192 ops
+#define TR_U8 0xFFu
+struct GapLaneMem { int *pv, *pf; uint8_t *pi; uint32_t *refw, *qw; uint8_t *T; uint32_t *tmp; };   // LDS pointers already offset by lane (stride 64); T, tmp in HBM
+template <int GW>
 __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uint8_t *gB, YD_GLOBAL const uint8_t *q, bool banded,
                                          uint32_t rOff, int rLen, int qOff, int qLen, const GapLaneMem &M, int &nOps, unsigned &cellsOut)
 {
@@ -72,41 +77,65 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
     int left = 0, right = 0;
     if (banded) { const int bw = P.bandWidth; if (rLen > qLen) { right = bw + (rLen - qLen); left = bw; } else { left = bw + (qLen - rLen); right = bw; } }
     const int W = banded ? left + right + 1 : rLen + 1;
-    int *PV = M.pv, *PF = M.pf, *PI = M.pi; uint16_t *T = M.T;
+    int *PV = M.pv, *PF = M.pf; uint8_t *PI = M.pi; YD_GLOBAL uint8_t *T = toGlobal(M.T); YD_GLOBAL uint32_t *T32 = (YD_GLOBAL uint32_t *)T;
 #define GPV(j) PV[(j) * 64]
 #define GPF(j) PF[(j) * 64]
 #define GPI(j) PI[(j) * 64]
-    for (int t = 0; t < rLen; t++) { const uint32_t off = rOff + (uint32_t)t; const uint32_t b = gB[off >> 1]; M.ref[t * 64] = (uint8_t)((off & 1u) ? (b & 15u) : (b >> 4)); }
-    int startInit;
-    T[0] = (uint16_t)TR_U;
-    if (banded) { startInit = left + 1; T[left] = (uint16_t)TR_U; GPF(W) = YD_WORST; GPV(W) = YD_WORST; GPI(W) = 0; } else startInit = 1;
-    { int dc = 1; for (int j = startInit; j < W; j++) { T[j] = (uint16_t)(OP_D | (dc << 2)); GPV(j) = -(GO + dc * GE); dc++; GPF(j) = YD_WORST; GPI(j) = 0; } }
+    // both sequences come in as whole dwords issued back to back (one memory round trip each), then live in LDS
+    const uint32_t rByte0 = (rOff >> 1) & ~3u; const int rNib0 = (int)(rOff - 2u * rByte0);             // nibble index of base 0 inside the dwords
+    { YD_GLOBAL const uint32_t *g = (YD_GLOBAL const uint32_t *)(gB + rByte0); uint32_t w[YD_GRW];
+#pragma unroll
+      for (int k = 0; k < YD_GRW; k++) w[k] = g[k];
+#pragma unroll
+      for (int k = 0; k < YD_GRW; k++) M.refw[k * 64] = w[k]; }
+    const size_t qAddr = (size_t)(q + qOff); const int qSkew = (int)(qAddr & 3u);
+    { YD_GLOBAL const uint32_t *g = (YD_GLOBAL const uint32_t *)(qAddr - (size_t)qSkew); uint32_t w[YD_GQW];
+#pragma unroll
+      for (int k = 0; k < YD_GQW; k++) w[k] = g[k];
+#pragma unroll
+      for (int k = 0; k < YD_GQW; k++) M.qw[k * 64] = w[k]; }
+    auto refAt = [&](int t) -> int { const int nb = rNib0 + t; const uint32_t w = M.refw[(nb >> 3) * 64]; return (int)((w >> (8 * ((nb >> 1) & 3) + ((nb & 1) ? 0 : 4))) & 15u); };
+    auto qAt = [&](int t) -> int { const int bb = qSkew + t; return (int)((M.qw[(bb >> 2) * 64] >> (8 * (bb & 3))) & 0xFFu); };
+    // row 0 (SW.cpp:905-935): U at the origin, deletions to its right
+    const int startInit = banded ? left + 1 : 1;
+    if (banded) { GPF(W) = YD_WORST; GPV(W) = YD_WORST; GPI(W) = 0; }
+    {
+        uint32_t acc = 0;
+        for (int j = 0; j < W; j++) {
+            uint32_t cell = 0;
+            if (j == startInit - 1) cell = TR_U8; else if (j >= startInit) { const int dc = j - startInit + 1; cell = (uint32_t)(OP_D | (dc << 2)); GPV(j) = -(GO + dc * GE); GPF(j) = YD_WORST; GPI(j) = 0; }
+            acc |= cell << (8 * (j & 3));
+            if ((j & 3) == 3 || j == W - 1) { T32[j >> 2] = acc; acc = 0; }
+        }
+    }
     GPF(startInit - 1) = 0; GPI(startInit - 1) = 0; GPV(startInit - 1) = 0;
-    { const int endInit = banded ? left : qLen; for (int i = 1; i <= endInit && i <= qLen; i++) { const int lo = banded ? left - i : 0; T[i * YD_GW + lo] = (uint16_t)(OP_I | (i << 2)); } }
     int V = 0, PVCol = YD_WORST, startCol = 1, endCol = W - 1; unsigned cells = 0;
     for (int i = 1; i <= qLen; i++) {
-        int PDCol = 0, PECol = YD_WORST;
+        int PDCol = 0, PECol = YD_WORST, bl = -1;                           // bl = the row's boundary insertion cell (SW.cpp:937-949)
         if (banded) {
             startCol = left + 1 - i;
-            if (startCol <= 0) { startCol = 0; PVCol = YD_WORST; } else { PVCol = -(GO + i * GE); GPV(startCol - 1) = PVCol; }
+            if (startCol <= 0) { startCol = 0; PVCol = YD_WORST; } else { PVCol = -(GO + i * GE); GPV(startCol - 1) = PVCol; bl = startCol - 1; }
             endCol = min(left + rLen - i, W - 1);
-        } else PVCol = -(GO + i * GE);
-        const int qc = (int)q[qOff + i - 1];
+        } else { PVCol = -(GO + i * GE); bl = 0; }
+        const int qc = qAt(i - 1);
         const int rRow = banded ? i - left - 1 : 0;
+        uint32_t acc = bl >= 0 ? (uint32_t)(OP_I | (i << 2)) << (8 * (bl & 3)) : 0u;
+        if (bl >= 0 && ((bl & 3) == 3 || startCol > endCol)) { T32[(i * GW + bl) >> 2] = acc; acc = 0; }
         for (int j = startCol; j <= endCol; j++) {
             const int RM = banded ? j : j - 1, IO = RM + 1; int op;
             V = GPV(RM);
-            const int rc = (int)M.ref[(banded ? rRow + j : j - 1) * 64];
+            const int rc = refAt(banded ? rRow + j : j - 1);
             if (qc == rc) { V += MS; op = OP_M; } else { V -= RC; op = OP_R; }
             int len = 0;
             const int CE = PECol - GE, NE = PVCol - (GO + GE);
             if (CE >= NE && (PDCol + 1) <= maxIntron) { PECol = CE; PDCol = PDCol + 1; } else { PECol = NE; PDCol = 1; }
             if (PECol > V) { V = PECol; op = OP_D; len = PDCol; }
-            int F, I; const int CF = GPF(IO) - GE, NF = GPV(IO) - (GO + GE), pio = GPI(IO);
+            int F, I; const int CF = GPF(IO) - GE, NF = GPV(IO) - (GO + GE), pio = (int)GPI(IO);
             if (CF >= NF && (pio + 1) <= maxGapP) { F = CF; I = pio + 1; } else { F = NF; I = 1; }
             if (F > V) { V = F; op = OP_I; len = I; }
-            GPF(j) = F; GPI(j) = I;
-            T[i * YD_GW + j] = (uint16_t)(op | (len << 2));
+            GPF(j) = F; GPI(j) = (uint8_t)I;
+            acc |= (uint32_t)(op | (len << 2)) << (8 * (j & 3));
+            if ((j & 3) == 3 || j == endCol) { T32[(i * GW + j) >> 2] = acc; acc = 0; }
             if (banded) GPV(j) = V; else GPV(j - 1) = PVCol;
             PVCol = V; cells++;
         }
@@ -115,24 +144,23 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
     cellsOut = cells;
     // traceback from the end cell (SW.cpp:1138-1195)
     int x = banded ? right : W - 1, y = qLen;
-    unsigned cell = T[y * YD_GW + x];
-    int prev = cell == TR_U ? -1 : (int)(cell & 3u), acc = 0, n = 0;
-    for (int guard = 0; cell != TR_U && guard < 4096; guard++) {
+    unsigned cell = T[y * GW + x];
+    int prev = cell == TR_U8 ? -1 : (int)(cell & 3u), acc2 = 0, n = 0;
+    for (int guard = 0; cell != TR_U8 && guard < 4096; guard++) {
         const int code = (int)(cell & 3u); int len = (int)(cell >> 2);
         if (banded) { if (code == OP_D) x -= len; else if (code == OP_I) { x += len; y -= len; } else { y -= 1; len = 1; } }
         else        { if (code == OP_D) x -= len; else if (code == OP_I) { y -= len; } else { x -= 1; y -= 1; len = 1; } }
-        if (prev != code) { M.tmp[n] = opMake(prev, acc); n++; prev = code; acc = len; } else acc += len;
-        if (y < 0 || x < 0 || x >= YD_GW + 1 || n >= 2 * YD_GROWS + 60) break;
-        cell = T[y * YD_GW + x];
+        if (prev != code) { M.tmp[n] = opMake(prev, acc2); n++; prev = code; acc2 = len; } else acc2 += len;
+        if (y < 0 || x < 0 || x >= GW || n >= 190) break;
+        cell = T[y * GW + x];
     }
-    M.tmp[n] = opMake(prev, acc); n++;
+    M.tmp[n] = opMake(prev, acc2); n++;
     nOps = n;
 #undef GPV
 #undef GPF
 #undef GPI
     return V;
 }
-
 
 __global__ void k_joint_counts(AlignArgs A, PhaseArgs X)
 {
@@ -146,7 +174,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
 {
     const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
-    unsigned perfect = 0, touched = 0, nDP = 0;
+    unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0;
     if (live) {
         const ChainClumpRec rec = A.clumps[A.order[r]]; const int n = (int)rec.nFrags;
         if (n > 1) {
@@ -183,7 +211,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
                         for (int t = 0; t < qGap; t++) mm += (uint32_t)q[(int)cur.eqo + 1 + t] != refAt(eRO + 1u + (uint32_t)t);
                         if (mm * (P.MS + P.RC) <= P.MS + 2 * (P.GO + P.GE)) { j.kind = JK_DIAG; j.score = P.MS * (qGap - mm) - P.RC * mm; }
                     }
-                    if (j.kind == JK_DP) { const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1; key = ((uint32_t)min(W, 0xFFFF) << 16) | (uint32_t)qGap; nDP++; }
+                    if (j.kind == JK_DP) { const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1; key = ((uint32_t)min(W, 0xFFFF) << 16) | (uint32_t)qGap; nDP++; nDP16 += W <= 16; }
                 }
                 X.joints[jb + (uint32_t)(k - 1)] = j; X.sortKeys[jb + (uint32_t)(k - 1)] = key; X.sortVals[jb + (uint32_t)(k - 1)] = jb + (uint32_t)(k - 1);
                 cur = nxt;
@@ -191,35 +219,38 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
             F[n - 1] = cur;
         }
     }
-    perfect = waveSumU(perfect); touched = waveSumU(touched); nDP = waveSumU(nDP);
+    perfect = waveSumU(perfect); touched = waveSumU(touched); nDP = waveSumU(nDP); nDP16 = waveSumU(nDP16);
     if (lane == 0 && (perfect | touched | nDP)) {
         atomicAdd(&A.ctr->v[C_PERFECT], (unsigned long long)perfect); atomicAdd(&A.ctr->v[C_TOUCHED], (unsigned long long)touched);
-        if (nDP) atomicAdd(X.nDP, nDP);
+        if (nDP) { atomicAdd(X.nDP, nDP); atomicAdd(X.nDP + 1, nDP16); }
     }
 }
 
-// lane per DP joint, in size order.  Persistent 64-thread blocks (LDS: 29 KB each).
+// lane per DP joint, in size order (key = strip width, rows).  Persistent 64-thread blocks.  The GW = 16 instance takes the
+// sorted joints [0, n16), the GW = 32 instance [n16, nDP)  (X.nDP[0] = nDP, X.nDP[1] = n16, counted by k_p1_joints).
+template <int GW>
 __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
 {
-    __shared__ int sPV[YD_GW + 1][64], sPF[YD_GW + 1][64], sPI[YD_GW + 1][64];
-    __shared__ uint8_t sRef[YD_GROWS][64];
+    __shared__ int sPV[GW + 1][64], sPF[GW + 1][64];
+    __shared__ uint8_t sPI[GW + 1][64]; __shared__ uint32_t sRefW[YD_GRW][64], sQW[YD_GQW][64];
     const int lane = laneId(); const DevParams &P = A.P;
-    GapLaneMem GM; GM.pv = &sPV[0][lane]; GM.pf = &sPF[0][lane]; GM.pi = &sPI[0][lane]; GM.ref = &sRef[0][lane];
-    { uint8_t *sp = X.gapScratch + (size_t)(blockIdx.x * 64u + (unsigned)lane) * YD_GAP_SCRATCH; GM.T = (uint16_t *)sp; GM.tmp = (uint32_t *)(sp + (YD_GROWS + 1) * YD_GW * 2); }
+    GapLaneMem GM; GM.pv = &sPV[0][lane]; GM.pf = &sPF[0][lane]; GM.pi = &sPI[0][lane]; GM.refw = &sRefW[0][lane]; GM.qw = &sQW[0][lane];
+    { uint8_t *sp = X.gapScratch + (size_t)(blockIdx.x * 64u + (unsigned)lane) * YD_GAP_SCRATCH; GM.T = sp; GM.tmp = (uint32_t *)(sp + (YD_GROWS + 1) * 32); }
     YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
-    const uint32_t nDP = *X.nDP;
-    for (uint32_t base = blockIdx.x * 64u; base < nDP; base += gridDim.x * 64u) {
-        const uint32_t t = base + (uint32_t)lane; const bool live = t < nDP;
+    const uint32_t nAll = X.nDP[0], n16 = X.nDP[1];
+    const uint32_t tBegin = GW == 16 ? 0u : n16, tEnd = GW == 16 ? n16 : nAll;
+    for (uint32_t base = tBegin + blockIdx.x * 64u; base < tEnd; base += gridDim.x * 64u) {
+        const uint32_t t = base + (uint32_t)lane; const bool live = t < tEnd;
         int nT = 0, score = 0; unsigned cells = 0; bool tooBig = false; uint32_t ji = 0;
         if (live) {
             ji = X.sortedVals[t]; const JointRec j = X.joints[ji];
             const bool banded = (j.flags & 2u) != 0; const int qGap = j.qGap, rGap = j.rGap;
             const int lenDiff = qGap > rGap ? qGap - rGap : rGap - qGap;
             const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1;
-            if (W > YD_GW || qGap > YD_GROWS || rGap > YD_GROWS) tooBig = true;
+            if (W > GW || qGap > YD_GROWS || rGap > YD_GREF) tooBig = true;
             else {
                 YD_GLOBAL const uint8_t *q = toGlobal((j.flags & 1u) ? A.B.rev : A.B.fwd) + j.qBase;
-                score = gapDPLane(P, gB, q, banded, j.nsro, rGap, (int)j.nsqo, qGap, GM, nT, cells);
+                score = gapDPLane<GW>(P, gB, q, banded, j.nsro, rGap, (int)j.nsqo, qGap, GM, nT, cells);
             }
         }
         { const unsigned long long mm = __ballot(tooBig); const unsigned sl = waveReserve(mm, X.slowCount, lane); if (tooBig) X.slowList[sl] = ji; }

@@ -41,7 +41,7 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_GAPOPS, CNT_N = 20 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_N = 20 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_N };
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split"};
@@ -249,16 +249,17 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     X.slowList = ctx->slowList.as<uint32_t>();
     X.joints = ctx->joints.as<JointRec>(); X.nJoints = J; X.sortKeys = ctx->sortKeys.as<uint32_t>(); X.sortVals = ctx->sortVals.as<uint32_t>(); X.sortedVals = ctx->sortVals2.as<uint32_t>();
     X.nDP = cnt + CNT_NDP; X.gapOps = ctx->gapOps.as<uint32_t>(); X.gapOpsCount = cnt + CNT_GAPOPS; X.gapOpsCap = gapOpsCap;
-    HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 8, ctx->stream));                  // ndp, gapops
+    HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 12, ctx->stream));                 // ndp, ndp16, gapops
     if (J) {
         hipLaunchKernelGGL(k_p1_joints, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
         size_t bytes = 0;
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
         if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
-        const unsigned gBlocks = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 5);      // 29 KB of LDS per 64-thread block
-        ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * gBlocks); X.gapScratch = ctx->gapScratch.as<uint8_t>();
-        hipLaunchKernelGGL(k_gap_lanes, dim3(gBlocks), dim3(64), 0, ctx->stream, A, X);
+        const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 6);   // 17 / 26 KB of LDS per 64-thread block
+        ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
+        hipLaunchKernelGGL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        hipLaunchKernelGGL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
         hipLaunchKernelGGL(k_gap_wave, dim3(std::min(waves, 512u)), dim3(64), 0, ctx->stream, A, X);
     }
     ENSURE(ctx->extKeys, 4ull * (nProb + 1)); ENSURE(ctx->extVals, 4ull * (nProb + 1)); ENSURE(ctx->extKeys2, 4ull * (nProb + 1)); ENSURE(ctx->extOrder, 4ull * (nProb + 1));
@@ -267,7 +268,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     rc = cubScan64(ctx, ctx->rowsBound.as<unsigned long long>(), ctx->stripOff.as<unsigned long long>(), nProb + 1); if (rc) return rc;
     EV1(T_P1);
     TRACE("lanes: p1+scan");
-    if (kTrace) { uint32_t v[3] = {0, 0, 0}; fetchU32(ctx, cnt + CNT_SLOW, &v[0]); fetchU32(ctx, cnt + CNT_NDP, &v[1], 2); fprintf(stderr, "[ygpu] roots %u, joints %u, DP joints %u (wave fallback %u), gap ops %u\n", NC, J, v[1], v[0], v[2]); }
+    if (kTrace) { uint32_t v[3] = {0, 0, 0}; fetchU32(ctx, cnt + CNT_SLOW, &v[0]); uint32_t w[3] = {0, 0, 0}; fetchU32(ctx, cnt + CNT_NDP, w, 3); v[1] = w[0]; v[2] = w[2]; fprintf(stderr, "[ygpu] roots %u, joints %u, DP joints %u (W<=16: %u, wave fallback %u), gap ops %u\n", NC, J, v[1], w[1], v[0], v[2]); }
     unsigned long long totalRows = 0;
     HIPCHK(hipMemcpyAsync(&totalRows, ctx->stripOff.as<unsigned long long>() + nProb, 8, hipMemcpyDeviceToHost, ctx->stream));
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
@@ -509,7 +510,7 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
     }
     ctx->hKmerOff[2 * n] = k; ctx->nKmers = k; ctx->totalBases = n ? b->offsets[n] - base0 : 0;
     if (ctx->totalBases > 0x7FFFFFF0ull) { ctx->err = "batch larger than 2 Gbases"; return YGPU_EINVAL; }
-    ENSURE(ctx->dFwd, ctx->totalBases + 64); ENSURE(ctx->dRev, ctx->totalBases + 64); ENSURE(ctx->dReadOff, 4ull * (n + 1)); ENSURE(ctx->dKmerOff, 4ull * (2 * n + 1));
+    ENSURE(ctx->dFwd, ctx->totalBases + 256); ENSURE(ctx->dRev, ctx->totalBases + 256);   /* slack: lane kernels read whole dwords around a segment */ ENSURE(ctx->dReadOff, 4ull * (n + 1)); ENSURE(ctx->dKmerOff, 4ull * (2 * n + 1));
     if (n) {
         HIPCHK(hipMemcpyAsync(ctx->dFwd.p, b->codes + base0, ctx->totalBases, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->dReadOff.p, ctx->hReadOff.data(), 4ull * (n + 1), hipMemcpyHostToDevice, ctx->stream));
