@@ -14,7 +14,7 @@ reads that is already resident in HBM; results stay in HBM.  Reads shard across 
 reads per GPU), the index is replicated per GPU, there is no data-path collective: torch.distributed is used
 for the barrier and the max-over-ranks only.
 
-Adds to the JSON line:  "roofline" for the dominant kernel (k_align: DP + extension + score/split) from HIP events
+Adds to the JSON line:  "roofline" for the dominant kernel (k_ext_rows: the X-drop extension rows) from HIP events
 on the stream it is launched on, and "cpu_baseline": the real reference binary (oracle/_ref/yaha -t <cores>) -- or,
 where that is absent, the oracle port -- timed on a bounded sample of the same reads on this box's host cores.
 """
@@ -196,14 +196,26 @@ def main():
     Lq = n_bases / n_reads
     B = Lq + 16 * (Lq - k + 1) + 4 * counters["hits"] / n_reads + counters["ref_bases_touched"] / n_reads / 2 + (24 * counters["clumps_scored"] + 3 * counters["ops_out"]) / n_reads
     align_ms = stage_ms.get("align_dp", 0.0) / steps
-    achieved = (B * n_reads / (align_ms * 1e-3)) / 1e9 if align_ms > 0 else 0.0
-    traffic = None
+    # Dominant kernel (profiles/): k_ext_rows, the X-drop extension rows, one problem per lane.  Its ALGORITHMIC bytes per launch
+    # (DESIGN.md section 5): per computed row 1 query code + half a byte of packed reference + 12 B of trace cells (21 x 4 bit),
+    # per problem a 16-byte descriptor and a 32-byte result.  Duration = HIP events around its launch(es) on its stream.
+    rows_ms = stage_ms.get("ext_rows", 0.0) / steps
+    if rows_ms > 0:
+        kname, kernel_ms = "k_ext_rows", rows_ms
+        kbytes = 13.5 * counters["dp_ext_rows"] + 48.0 * counters["dp_ext_calls"]
+    else:                                                    # other band widths run the wave-per-root kernel
+        kname, kernel_ms = "k_align", align_ms
+        kbytes = B * n_reads
+    achieved = (kbytes / (kernel_ms * 1e-3)) / 1e9 if kernel_ms > 0 else 0.0
+    traffic, pmc = None, None
     pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pj):
         try:
-            traffic = json.load(open(pj)).get("k_align_hbm_bytes_per_launch")
+            pmc = json.load(open(pj))
+            if pmc.get("reads_per_gpu") == n_reads and pmc.get("kernel") == kname:
+                traffic = pmc.get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            traffic, pmc = None, None
     out = {
         "metric": "aligned reads/s (whole node), 1 000 bp reads, OQC mode hot path", "value": value, "unit": "reads/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
@@ -212,8 +224,13 @@ def main():
         "config": {"workload": "synthetic hg18-like genome %d Mbp (24 seqs, 45%% repeats), index -L 15 -S 1 -H 65525, %d x %d bp reads per GPU at %.1f%% divergence, defaults -BW 5 -G 50 -H 650 -M 25 -X 25, hot path A1..A10 with inputs resident in HBM"
                    % (args.genome_mbp, n_reads, args.read_len, 100 * args.div),
                    "reads_per_gpu": n_reads, "read_len": args.read_len, "parallelism": "reads sharded x%d, index replicated, no collective" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_align", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                     "algorithmic_bytes_per_read": B, "kernel_ms_per_launch": align_ms, "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) / (align_ms * 1e-3) if align_ms > 0 else 0.0},
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": kbytes, "kernel_ms_per_launch": kernel_ms,
+                     "cell_updates_per_s": counters["dp_ext_cells"] / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
+                     "note": "integer DP: the kernel is bound by vector-ALU issue, not HBM (see DESIGN.md section 6 and profiles/)",
+                     "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "valu_issue_frac", "fetch_bytes_per_launch", "write_bytes_per_launch", "source") if k2 in pmc} if pmc and traffic is not None else None)},
+        "path": {"algorithmic_bytes_per_read": B, "hbm_frac_whole_path": value * B / (8.0e12 * world),
+                 "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) * steps * world / dt},
         "stage_ms_per_step": {k2: v / steps for k2, v in stage_ms.items()},
         "per_read": {k2: counters[k2] / n_reads for k2 in ("hits", "fragments", "clumps_formed", "clumps_scored", "dp_ext_calls", "dp_ext_rows", "dp_ext_cells", "dp_gap_calls", "dp_gap_rows", "dp_gap_cells", "splits", "ops_out", "ref_bases_touched")},
         "pcie": {"upload_s": t_up, "collect_s": t_down, "clumps": n_clumps},

@@ -347,6 +347,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     }
     if (overlap) { HIPCHK(hipEventRecord(ctx->evTail, sTail)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0)); }
     TRACE("lanes: chunks done");
+    if (kTrace) { unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gP3Stat), sizeof z); fprintf(stderr, "[ygpu] split roots %llu: no child frames %llu (single split %llu), child frames %llu, splits %llu, careful DPs %llu, nothing emitted %llu\n", z[0], z[1], z[2], z[3], z[4], z[5], z[6]); memset(z, 0, sizeof z); hipMemcpyToSymbol(HIP_SYMBOL(gP3Stat), z, sizeof z); }
     return 0;
 }
 
