@@ -98,12 +98,12 @@ __device__ inline void cleanUpList(const DevParams &P, DevFrag *L, int *nx, int 
 // which is what the reference's in-place edit of fragArray amounts to within one region.
 struct ChainLds { DevFrag L[64]; int nx[64], pv[64]; };
 
-__device__ inline uint32_t chainSmall(const ChainArgs &A, ChainAlloc &al, ChainLds &T, uint32_t reg, uint32_t s, int n0, uint32_t rs, bool &fail)
+// `f` = this lane's fragment of the region (lane < n0), loaded by the caller ahead of time
+__device__ inline uint32_t chainSmall(const ChainArgs &A, ChainAlloc &al, ChainLds &T, uint32_t reg, uint32_t s, int n0, uint32_t rs, DevFrag f, bool &fail)
 {
     const DevParams &P = A.P; const int lane = laneId();
     const int MS = uni(P.MS), GO = uni(P.GO), GE = uni(P.GE), maxGap = uni(P.maxGap), maxDesert = uni(P.maxDesert), minMatch = uni(P.minMatch), minLeft = uni(P.minNonOverlap) - 1;
-    DevFrag f; f.sro = 0; f.sqo = 0; f.eqo = 0; f.refLen = 0; f.used = 1; f.rs = rs;
-    if (lane < n0) f = A.frags[s + lane];
+    if (lane >= n0) { f.sro = 0; f.sqo = 0; f.eqo = 0; f.refLen = 0; f.used = 1; f.rs = rs; }
     int fsro = (int)f.sro, fsqo = f.sqo, feqo = f.eqo, frl = f.refLen; bool used = lane >= n0 || f.used != 0;
     int ivS = 0, ivL = 0, nIv = 0;                                   // coverage intervals
     uint32_t seq = 0;
@@ -347,10 +347,17 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A)
         const unsigned w0 = uniU(t);
         if (w0 >= nMulti) break;
         bool failS = false;
-        for (unsigned w = w0; w < w0 + 8u && w < nMulti && !failS; w++) {
-            const uint32_t reg = uniU(A.multiList[w]); const uint32_t s = uniU(A.regStart[reg]), e = uniU(A.regStart[reg + 1]); const int n0 = (int)(e - s);
-            const uint32_t rs = uniU(A.frags[s].rs);
-            const uint32_t seqS = chainSmall(A, al, sT, reg, s, n0, rs, failS);
+        // the headers of the eight regions in one round of loads (lane k: region k), each region's fragments one region ahead
+        const unsigned cntR = min(8u, nMulti - w0);
+        uint32_t hReg = 0, hS = 0, hE = 0, hRs = 0;
+        if ((unsigned)lane < cntR) { hReg = A.multiList[w0 + (unsigned)lane]; hS = A.regStart[hReg]; hE = A.regStart[hReg + 1]; hRs = A.frags[hS].rs; }
+        DevFrag fNext; fNext.sro = 0; fNext.sqo = 0; fNext.eqo = 0; fNext.refLen = 0; fNext.used = 1; fNext.rs = 0;
+        { const uint32_t s0 = (uint32_t)bcast((int)hS, 0), e0 = (uint32_t)bcast((int)hE, 0); if ((uint32_t)lane < e0 - s0) fNext = A.frags[s0 + (uint32_t)lane]; }
+        for (unsigned k = 0; k < cntR && !failS; k++) {
+            const uint32_t reg = (uint32_t)bcast((int)hReg, (int)k), s = (uint32_t)bcast((int)hS, (int)k), e = (uint32_t)bcast((int)hE, (int)k), rs = (uint32_t)bcast((int)hRs, (int)k); const int n0 = (int)(e - s);
+            const DevFrag fCur = fNext;
+            if (k + 1 < cntR) { const uint32_t s1 = (uint32_t)bcast((int)hS, (int)k + 1), e1 = (uint32_t)bcast((int)hE, (int)k + 1); if ((uint32_t)lane < e1 - s1) fNext = A.frags[s1 + (uint32_t)lane]; }
+            const uint32_t seqS = chainSmall(A, al, sT, reg, s, n0, rs, fCur, failS);
             if (lane == 0) A.regionClumpCount[reg] = seqS;
             formed += seqS; failS = UNI_B(failS);
         }

@@ -48,17 +48,36 @@ __global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const
     if (lookups) atomicAdd(&ctr->v[C_KMER], (unsigned long long)lookups);
 }
 
-// A2a: thread per hit -> 64-bit key  rs(17) | diag(32) | qo(15)
-__global__ void k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
+// A2a: thread per hit -> 64-bit key  rs(17) | diag(32) | qo(15).  A block owns 1024 consecutive hits; they belong to at most
+// 1025 consecutive k-mers, whose offsets are staged in LDS: one global binary search per block, then LDS-only searches.
+#define YD_EXPAND_HITS 1024
+__global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nHits) return;
-    uint32_t lo = 0, hi = nKmers;                                                 // largest g with hitOff[g] <= t
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= t) lo = mid; else hi = mid; }
-    const uint32_t g = lo, j = t - hitOff[g], rsi = posRsI[g];
-    const uint32_t i = rsi & 0x7FFFu, rs = rsi >> 15;
-    const uint32_t roff = ROA[posS[g] + j];
-    keys[t] = ((unsigned long long)rs << 47) | ((unsigned long long)(uint32_t)(roff - i) << 15) | (unsigned long long)i;
+    __shared__ uint32_t sOff[YD_EXPAND_HITS + 2]; __shared__ uint32_t sG0;
+    const uint32_t t0 = blockIdx.x * YD_EXPAND_HITS;
+    if (threadIdx.x == 0) {                                                       // largest g with hitOff[g] <= t0
+        uint32_t lo = 0, hi = nKmers;
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= t0) lo = mid; else hi = mid; }
+        sG0 = lo;
+    }
+    __syncthreads();
+    const uint32_t g0 = sG0, span = min(nKmers + 1u - g0, (uint32_t)YD_EXPAND_HITS + 2u);          // hitOff has nKmers + 1 entries
+    for (uint32_t k = threadIdx.x; k < span; k += blockDim.x) sOff[k] = hitOff[g0 + k];
+    __syncthreads();
+    for (uint32_t t = t0 + threadIdx.x; t < min(t0 + (uint32_t)YD_EXPAND_HITS, nHits); t += blockDim.x) {
+        uint32_t lo = 0, hi = span;                                                // largest k with sOff[k] <= t (k-mers without hits repeat an offset)
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sOff[mid] <= t) lo = mid; else hi = mid; }
+        uint32_t g = g0 + lo;
+        if (lo == span - 1u && g + 1u < nKmers) {                                  // long run of k-mers without hits: the window ended early
+            uint32_t l2 = g, h2 = nKmers;
+            while (h2 - l2 > 1) { uint32_t mid = (l2 + h2) >> 1; if (hitOff[mid] <= t) l2 = mid; else h2 = mid; }
+            g = l2;
+        }
+        const uint32_t j = t - hitOff[g], rsi = posRsI[g];
+        const uint32_t i = rsi & 0x7FFFu, rs = rsi >> 15;
+        const uint32_t roff = ROA[posS[g] + j];
+        keys[t] = ((unsigned long long)rs << 47) | ((unsigned long long)(uint32_t)(roff - i) << 15) | (unsigned long long)i;
+    }
 }
 
 // A2b: fragment heads.  A hit starts a new fragment when (read,strand) or diagonal changes or the k-mer neither overlaps
@@ -117,11 +136,17 @@ __global__ void k_region_starts(const uint32_t *isHead, const uint32_t *regIdx, 
 // multiList: regions with 2..64 fragments (k_chain); bigList: more than 64 (k_chain_big)
 __global__ void k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nRegions) return;
-    const uint32_t n = regStart[r + 1] - regStart[r];
-    if (n > 64) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }
-    else if (n >= 2) { unsigned p = atomicAdd(nMulti, 1u); multiList[p] = r; }
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63);
+    const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
+    const bool big = n > 64, multi = n >= 2 && !big;
+    if (big) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }        // rare
+    const unsigned long long m = __ballot(multi);                            // one atomic per wavefront
+    if (m) {
+        const int first = __builtin_ctzll(m); unsigned base = 0;
+        if (lane == first) base = atomicAdd(nMulti, (unsigned)__builtin_popcountll(m));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
+        if (multi) multiList[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
+    }
 }
 // order[base[region] + seq] = clump index  (rank of a root clump = creation order)
 __global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, const uint32_t *regionBase, uint32_t *order)
