@@ -133,12 +133,12 @@ __global__ void k_region_starts(const uint32_t *isHead, const uint32_t *regIdx, 
     if (isHead[f]) regStart[regIdx[f]] = f;
 }
 // multi-fragment region list + largest region
-// multiList: regions with 2..64 fragments (k_chain); bigList: more than 64 (k_chain_big)
-__global__ void k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig)
+// smallList: regions with 2..8 fragments (k_chain_lanes); multiList: 9..64 (k_chain); bigList: more than 64 (k_chain_big)
+__global__ void k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned int *nSmall)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63);
     const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
-    const bool big = n > 64, multi = n >= 2 && !big;
+    const bool big = n > 64, small = n >= 2 && n <= 8, multi = n > 8 && !big;
     if (big) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }        // rare
     const unsigned long long m = __ballot(multi);                            // one atomic per wavefront
     if (m) {
@@ -146,6 +146,13 @@ __global__ void k_region_classify(const uint32_t *regStart, uint32_t nRegions, u
         if (lane == first) base = atomicAdd(nMulti, (unsigned)__builtin_popcountll(m));
         base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
         if (multi) multiList[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
+    }
+    const unsigned long long ms = __ballot(small);
+    if (ms) {
+        const int first = __builtin_ctzll(ms); unsigned base = 0;
+        if (lane == first) base = atomicAdd(nSmall, (unsigned)__builtin_popcountll(ms));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
+        if (small) smallList[base + (unsigned)__builtin_popcountll(ms & ((1ull << lane) - 1ull))] = r;
     }
 }
 // order[base[region] + seq] = clump index  (rank of a root clump = creation order)
