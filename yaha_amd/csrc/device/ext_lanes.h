@@ -245,6 +245,7 @@ __device__ __forceinline__ uint32_t extNib(const ExtRowBits &r, int x) { const u
 // strip[opsOff .. opsOff+nOps): the forward extension's list in order (ops are added to the front, SW.cpp:1186), the
 // backward extension's list reversed (added to the back, SW.cpp:1190).
 __device__ __forceinline__ int extRowWord(int y) { return ((y - 1) / 10) * 32 + ((y - 1) % 10) * 3; }
+#define YD_TRACE_DEPTH 8
 __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,25 +256,46 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
     constexpr int leftR = YD_LBAND;
     const int E = extRowWord(r.maxi + 1) + 3;
     int y = r.maxi, x = r.maxj, prev = -1, acc = 0, n = 0; bool bad = false;
-    auto flush = [&]() { const int w = E - 1 - n; if (w < extRowWord(y + 1)) bad = true; else strip[w] = opMake(prev, acc); n++; };
+    // w = word offset of row y inside the strip, rr = its row inside the 10-row block (kept incrementally: no divisions in the loops)
+    int rr = (y - 1) % 10, w = ((y - 1) / 10) * 32 + rr * 3;
+    auto flush = [&]() { const int wp = E - 1 - n; if (wp < w + 3) bad = true; else strip[wp] = opMake(prev, acc); n++; };   // rows above row y are consumed
     auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
-    for (int guard = 0; guard < 70000; guard++) {
-        if (y <= 0) { if (x > leftR) put(OP_D, x - leftR); break; }
-        if (x < 0 || x >= YD_LW) break;
-        const ExtRowBits rb = extLoadRow(strip, y);
-        const uint32_t nib = extNib(rb, x); const int op = (int)(nib & 3u);
-        if (op < OP_D) { put(op, 1); y -= 1; }
-        else if (op == OP_D) {
+    auto stepUp = [&](int &ww, int &r2) { if (r2 == 0) { r2 = 9; ww -= 5; } else { r2--; ww -= 3; } };                        // one row towards the origin
+    // The kernel is bound by the latency of dependent loads (one per path cell).  Most of a path is straight runs of M / R cells
+    // in one column, so the cells of the next YD_TRACE_DEPTH rows in column x are fetched together (one dword each) and consumed in turn.
+    for (int guard = 0; guard < 70000 && y > 0 && x >= 0 && x < YD_LW; guard++) {
+        const int ws = x >> 3, sh = (x & 7) * 4;
+        uint32_t d[YD_TRACE_DEPTH];
+        { int wk = w, rk = rr;
+#pragma unroll
+          for (int k = 0; k < YD_TRACE_DEPTH; k++) { d[k] = strip[wk + ws]; if (y > k + 1) stepUp(wk, rk); } }
+        uint32_t nib = (d[0] >> sh) & 15u; int took = 0;
+#pragma unroll
+        for (int k = 0; k < YD_TRACE_DEPTH; k++) {
+            nib = (d[k] >> sh) & 15u;
+            const int op = (int)(nib & 3u);
+            if (op >= OP_D || y <= 0) break;
+            if (prev != op) { if (prev >= 0) flush(); prev = op; acc = 1; } else acc++;
+            y--; stepUp(w, rr); took++;
+        }
+        if (took == YD_TRACE_DEPTH || y <= 0) continue;                                   // still in a straight run (or at the origin row)
+        if ((nib & 3u) == (uint32_t)OP_D) {                                  // deletion run: walk the continue bits along the row
+            ExtRowBits rb; rb.a = strip[w]; rb.b = strip[w + 1]; rb.c = strip[w + 2];
             int run = 1, xx = x;
             while (extNib(rb, xx) & 4u) { xx--; if (xx < 0) break; run++; }
             put(OP_D, run); x -= run;
-        } else {
-            int run = 1, yy = y, xx = x; uint32_t nb2 = nib;
-            while (nb2 & 8u) { yy--; xx++; if (yy <= 0 || xx >= YD_LW) break; run++; const ExtRowBits r2 = extLoadRow(strip, yy); nb2 = extNib(r2, xx); }
-            put(OP_I, run); y -= run; x += run;
+        } else {                                                            // insertion run: walk the continue bits up and to the right
+            int run = 1, yy = y, xx = x, ww = w, q2 = rr; uint32_t nb2 = nib;
+            while (nb2 & 8u) {
+                yy--; xx++; if (yy <= 0 || xx >= YD_LW) break;
+                run++; stepUp(ww, q2);
+                nb2 = (strip[ww + (xx >> 3)] >> ((xx & 7) * 4)) & 15u;
+            }
+            put(OP_I, run); for (int t = 0; t < run; t++) stepUp(w, rr); y -= run; x += run;
         }
     }
-    if (prev >= 0) { const int w = E - 1 - n; if (w < (y >= 0 ? extRowWord(y + 1) : 0)) bad = true; else strip[w] = opMake(prev, acc); n++; }
+    if (y <= 0 && x > leftR) put(OP_D, x - leftR);                           // row 0: deletions back to the origin (SW.cpp:905-935)
+    if (prev >= 0) { const int wp = E - 1 - n; if (wp < 0) bad = true; else strip[wp] = opMake(prev, acc); n++; }
     if (bad) { atomicCAS(A.errFlag, 0, (int)YERR_TRACE); return; }
     r.opsOff = (uint32_t)(E - n); r.nOps = (uint32_t)n; A.res[p] = r;
 }
