@@ -84,7 +84,6 @@ __device__ inline int perfectBack(const uint8_t *bases, const uint8_t *q, int qO
     return uni(count);
 }
 
-__device__ unsigned long long gP3Stat[16];      // diagnostics (YGPU_TRACE): split-path shapes
 struct Aligner {
     const AlignArgs &A; const DevParams &P; WaveMem M; WaveScratch S; int err;
     const uint8_t *q; int qlen; int lane;
@@ -380,7 +379,7 @@ struct Aligner {
     // scoreClump / splitClump state machine on an aligned clump (frame 0)
     __device__ void finishRoot(Frame f)
     {
-        int depth = 0; int dPush = 0, dSplits = 0, dEmit = 0, dDP0 = (int)extCalls;
+        int depth = 0;
         // per-frame results of the last scoreList
         int sm = -1, smm = 0, sg = 0, sl = 0, ss = 0;
         enum { ST_SCORE, ST_SPLIT_ENTER, ST_SPLIT_TAIL, ST_SPLIT_CORE, ST_RETURN } state = ST_SCORE;
@@ -392,7 +391,7 @@ struct Aligner {
             if (state == ST_SCORE) {
                 if (UNI_B(f.status & stScored)) { state = ST_RETURN; continue; }
                 int r = uni(scoreList(f, b, sm, smm, sg, sl, ss));
-                if (r == 1) { splits++; dSplits++; f.wS = f.sqo; f.wE = f.eqo; state = ST_SPLIT_ENTER; }      // splitClump, AlignHelpers.c:561-579
+                if (r == 1) { splits++; f.wS = f.sqo; f.wE = f.eqo; state = ST_SPLIT_ENTER; }      // splitClump, AlignHelpers.c:561-579
                 else state = ST_RETURN;
                 continue;
             }
@@ -428,7 +427,7 @@ struct Aligner {
                         __threadfence_block();
                         Frame c; c.status = f.status & stReversed; c.sqo = f.cSqo; c.eqo = (sQO - 1) & 0xFFFF; c.sro = f.cSro; c.refLen = (int)((1u + (sRO - 1u) - f.cSro) & 0xFFFFu);
                         c.score = 0; c.wS = f.wS; c.wE = f.wE; c.start = A.front; c.len = minItem; c.phase = PH_NONE;
-                        f.phase = PH_AFTER_HEAD; M.frames[depth] = f; depth++; dPush++; f = c; state = ST_SPLIT_ENTER; continue;
+                        f.phase = PH_AFTER_HEAD; M.frames[depth] = f; depth++; f = c; state = ST_SPLIT_ENTER; continue;
                     }
                 }
                 state = ST_SPLIT_TAIL; continue;
@@ -446,7 +445,7 @@ struct Aligner {
                         Frame c; c.status = f.status & stReversed; c.sqo = (f.eQO + 1) & 0xFFFF; c.eqo = f.cEqo; c.sro = f.eRO + 1u;
                         c.refLen = (int)((1u + ero(f.cSro, f.cRefLen) - (f.eRO + 1u)) & 0xFFFFu);
                         c.score = 0; c.wS = f.wS; c.wE = f.wE; c.start = A.front; c.len = tl; c.phase = PH_NONE;
-                        f.phase = PH_AFTER_TAIL; M.frames[depth] = f; depth++; dPush++; f = c; state = ST_SPLIT_ENTER; continue;
+                        f.phase = PH_AFTER_TAIL; M.frames[depth] = f; depth++; f = c; state = ST_SPLIT_ENTER; continue;
                     }
                 }
                 state = ST_SPLIT_CORE; continue;
@@ -463,7 +462,6 @@ struct Aligner {
             }
             // ST_RETURN: this frame is finished
             if (depth == 0) { if (f.status & stScored) emit(f, b, sm, smm, sg, sl, ss);
-                if (lane == 0 && dSplits) { atomicAdd(&gP3Stat[0], 1ull); if (dPush == 0) atomicAdd(&gP3Stat[1], 1ull); if (dPush == 0 && dSplits == 1) atomicAdd(&gP3Stat[2], 1ull); atomicAdd(&gP3Stat[3], (unsigned long long)dPush); atomicAdd(&gP3Stat[4], (unsigned long long)dSplits); atomicAdd(&gP3Stat[5], (unsigned long long)((int)extCalls - dDP0)); if (pushes == 0) atomicAdd(&gP3Stat[6], 1ull); }
                 break; }
             if (f.status & stScored) { f.status |= stSplit | stAligned; emit(f, b, sm, smm, sg, sl, ss); }
             depth--; f = M.frames[depth];

@@ -16,6 +16,8 @@ enum { OP_M = 0, OP_R = 1, OP_D = 2, OP_I = 3 };
 #define YD_GLOBAL __attribute__((address_space(1)))
 #define YD_LDS    __attribute__((address_space(3)))
 template <class T> __device__ __forceinline__ YD_GLOBAL T *toGlobal(T *p) { return (YD_GLOBAL T *)p; }
+#define YD_LBAND 10                 // extension bandwidth 2 * BW of the lane kernels (-BW 5): columns left and right of the origin
+#define YD_MEMO 12                  // careful-extension problems listed per split root
 #define YD_LDS_CELLS 5120            // uint16 trace cells kept in LDS per wavefront (10 KB): 160 rows of a 21-wide extension strip
 
 struct DevParams {

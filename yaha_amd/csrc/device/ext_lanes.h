@@ -22,20 +22,19 @@
 #include "align.h"
 
 #define YD_LW 21                               // register columns of the lane kernel = strip width for -BW 5
-#define YD_LBAND 10                            // extension bandwidth 2 * BW = columns left and right of the origin
 #define YD_LWORST (-(1 << 28))                 // sentinel: far below any reachable score (|score| < 2^23), no overflow when it decays
 
 typedef uint32_t yd_u32x4 __attribute__((ext_vector_type(4)));
 struct ExtProb { uint32_t qBase, rOff; uint16_t qOff, qLen; uint32_t flags; };           // 16 B; qBase = offset of the read in fwd/rev
 enum { XP_STRAND = 1, XP_REV = 2, XP_VALID = 4 };
-struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, rLen, pad0, pad1; };       // 32 B; maxj in register columns
+struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, rLen, rows, cells; };       // 32 B; maxj in register columns; rows/cells = work of this call
 
 struct ExtArgs {
     DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
     const ExtProb *probs; uint32_t nProb; const unsigned long long *stripOff; unsigned long long stripBase;
     const uint32_t *order;                      // problem indices in processing order (longest bound first), or nullptr
     uint32_t *trace;                            // 128-byte blocks of 10 rows (3 dwords each, 2 dwords of padding); stripOff counts blocks
-    ExtRes *res; unsigned int *queue; DevCounters *ctr;
+    ExtRes *res; unsigned int *queue; DevCounters *ctr;      // ctr == nullptr: the consumer of the results accounts for the work (careful extensions)
     int *errFlag;
 };
 
@@ -69,7 +68,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     unsigned poolBase = 0; int poolCount = 0, poolNext = 0; bool exhausted = false;
     uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, eSLo = 0, eSHi = 0, ePidx = 0;
     // deferred stores (see the row code)
-    bool pendFlush = false; YD_GLOBAL uint32_t *pendBlk = toGlobal(A.trace); int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0;
+    bool pendFlush = false; YD_GLOBAL uint32_t *pendBlk = toGlobal(A.trace); int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pCells = 0;
 
     for (;;) {
         // ---- refill: until every lane is busy or nothing is left ----
@@ -95,7 +94,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                         if (!rv_ && (pr.rOff + rl) > maxROff) { rl = maxROff - pr.rOff; ql = (int)rl - bandwidth; }
                         if (ql > 0) { ql &= 0xFFFF; rl &= 0xFFFF; }
                     }
-                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0; A.res[np] = r; }
+                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.rLen = 0; r.rows = r.cells = 0; A.res[np] = r; }
                     else {
                         eLens = (uint32_t)ql | (rl << 16); eROff = pr.rOff; eQ = pr.qBase + pr.qOff;
                         YD_GLOBAL const uint8_t *qp = toGlobal((pr.flags & XP_STRAND) ? A.rev : A.fwd) + eQ;
@@ -130,7 +129,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             }
             if (init) {
                 p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
-                rev = (gMisc & XP_REV) != 0; rOff = gROff;
+                rev = (gMisc & XP_REV) != 0; rOff = gROff; pCells = 0;
                 q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu);
                 strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 32ull;
                 w0 = 0; w1 = gW1; w2 = gW2;
@@ -153,7 +152,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             pendFlush = false;
         }
         if (pendRes >= 0) {
-            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0;
+            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.rows = pendRows; r.cells = pendCells;
             A.res[pendRes] = r; pendRes = -1;
         }
         const bool busy = p >= 0;
@@ -166,7 +165,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         int sc = leftR + 1 - i; if (sc < 0) sc = 0;
         int ec = leftR + rLen - i; if (ec > YD_LW - 1) ec = YD_LW - 1;
         const uint32_t am = ec >= sc ? ((2u << ec) - 1u) & ~((1u << sc) - 1u) : 0u;
-        if (busy) { rows++; cells += ec >= sc ? (unsigned)(ec - sc + 1) : 0u; }
+        if (busy) { const unsigned nc = ec >= sc ? (unsigned)(ec - sc + 1) : 0u; rows++; cells += nc; pCells += nc; }
         int PVCol = YD_LWORST, PE = YD_LWORST, PD = 0;
         uint32_t t0 = 0, t1 = 0, t2 = 0, rowKey = 0;
         int dV = PV[0];
@@ -207,7 +206,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         const bool fin = busy && (rv < maxScore - XC || i >= qLen);
         if (busy && (fin || i % 10 == 0)) { pendFlush = true; pendBlk = strip + (size_t)((i - 1) / 10) * 32u; }
         if (fin) {
-            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj;
+            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i; pendCells = pCells;
             p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
         }
     }
@@ -217,7 +216,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         for (int d = 0; d < 32; d += 4) { yd_u32x4 v; v.x = sBlk[d][tid]; v.y = sBlk[d + 1][tid]; v.z = sBlk[d + 2][tid]; v.w = sBlk[d + 3][tid]; *(YD_GLOBAL yd_u32x4 *)(pendBlk + d) = v; }
     }
     if (pendRes >= 0) {
-        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.pad0 = r.pad1 = 0;
+        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.rows = pendRows; r.cells = pendCells;
         A.res[pendRes] = r;
     }
     // work counters
@@ -225,7 +224,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     unsigned long long cc = cells;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { cc += (unsigned long long)__shfl_xor((long long)cc, d, 64); }
-    if (lane == 0) {
+    if (lane == 0 && A.ctr) {
         unsigned long long *c = A.ctr->v;
         atomicAdd(&c[C_EXT_CALLS], (unsigned long long)c0); atomicAdd(&c[C_EXT_ROWS], (unsigned long long)c1); atomicAdd(&c[C_EXT_CELLS], cc);
         atomicAdd(&c[C_TOUCHED], (unsigned long long)c1 + (unsigned long long)c0 * (unsigned long long)(4 * A.P.bandWidth + 1));

@@ -35,6 +35,9 @@ struct PhaseArgs {
     uint32_t *slowList; unsigned int *slowCount;        // roots (k_p3_lanes) or joints (k_gap_lanes) handed to the wave kernels
     int useList;                                        // k_align_p3: take roots from slowList[0 .. *slowCount)
     uint32_t rootBegin;                                 // k_p3_lanes: first root of the chunk (A.nRoots = its end)
+    // splitClump in lanes (split_lanes.h): the careful extensions of the split roots are listed by k_p3_lanes, computed by a second
+    // k_ext_rows / k_ext_trace round, and consumed by k_split_lanes
+    uint32_t *memoKeys; unsigned int *memoCount; ExtProb *probs2; unsigned long long *rowsBound2; unsigned int *nProb2; uint32_t probs2Cap;
     // joints
     uint32_t *jointCount; const uint32_t *jointBase; JointRec *joints; uint32_t nJoints;
     uint32_t *sortKeys, *sortVals; const uint32_t *sortedVals; unsigned int *nDP;
@@ -409,6 +412,84 @@ struct MergedOps {
         return c[k - nb + jbc];
     }
 };
+// Which careful extensions will splitClump ask for?  The frames it visits (the root, then recursively the head and tail
+// remainders that still hold a seed-length match, AlignHelpers.c:374-557) and their cores depend only on the edit list as it is
+// before any careful extension, so their X-drop problems (direction, rOff, qOff, qLen) can be listed ahead of time and run
+// through the lane kernels.  k_split_lanes takes a stored result only when its own arguments match one exactly; a root with
+// a request that is not in its list (a re-split after an extension, deeper recursion) goes to the wave kernel instead.
+struct PredFrame { int start, len, sqo, eqo, refLen; uint32_t sro; int phase, minItem, maxItem, sQO, eQO; uint32_t sRO, eRO; };
+__device__ inline int predictCarefulDPs(const DevParams &P, const MergedOps &L, int n0, int sqo0, int eqo0, uint32_t sro0, int refLen0,
+                                        YD_GLOBAL const uint8_t *q, int qlen, YD_GLOBAL const uint8_t *gB, ExtProb *out, uint32_t qBase, uint32_t strand)
+{
+    auto refAt = [&](uint32_t off) -> uint32_t { const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
+    PredFrame st[5]; int depth = 0, nOut = 0; const int wS = sqo0, wE = eqo0;
+    PredFrame f; f.start = 0; f.len = n0; f.sqo = sqo0; f.eqo = eqo0; f.sro = sro0; f.refLen = refLen0; f.phase = 0;
+    for (int guard = 0; guard < 64; guard++) {
+        if (f.phase == 0) {                                                  // splitClumpHelper: the best-scoring core
+            int matches = 0, mism = 0, ins = 0, del = 0, AGS = 0, maxAGS = -10000, maxItem = -1, minItem = -1, eQO = 0, sQO = 0; uint32_t eRO = 0, sRO = 0;
+            for (int k = 0; k < f.len; k++) {
+                const uint32_t op = L.at(f.start + k); const int code = opCode(op), len = opLen(op); int ns;
+                if (code == OP_M) { matches += len; ns = P.MS * len; } else if (code == OP_R) { mism += len; ns = -(P.RC * len); }
+                else if (code == OP_I) { ins += len; ns = -(P.GO + P.GE * len); } else { del += len; ns = -(P.GO + P.GE * len); }
+                AGS += ns; if (AGS < 0) AGS = 0;
+                if (AGS > maxAGS) { maxAGS = AGS; maxItem = k; eQO = (f.sqo + matches + mism + ins - 1) & 0xFFFF; eRO = f.sro + (uint32_t)(matches + mism + del) - 1u; }
+            }
+            AGS = maxAGS; matches = mism = ins = del = 0; int maxMatch = 0;
+            for (int k = maxItem; k >= 0; k--) {
+                const uint32_t op = L.at(f.start + k); const int code = opCode(op), len = opLen(op);
+                if (code == OP_M) { matches += len; AGS -= P.MS * len; if (len > maxMatch) maxMatch = len; } else if (code == OP_R) { mism += len; AGS += P.RC * len; }
+                else if (code == OP_I) { ins += len; AGS += (P.GO + P.GE * len); } else { del += len; AGS += (P.GO + P.GE * len); }
+                if (AGS <= 0) { minItem = k; sQO = (eQO - (matches + mism + ins - 1)) & 0xFFFF; sRO = eRO - (uint32_t)(matches + mism + del - 1); break; }
+            }
+            if (maxMatch < P.wordLen || minItem < 0) f.phase = 4;
+            else {
+                f.minItem = minItem; f.maxItem = maxItem; f.sQO = sQO; f.eQO = eQO; f.sRO = sRO; f.eRO = eRO; f.phase = 1;
+                bool has = false;
+                if (minItem != 0) for (int k = 0; k < minItem && !has; k++) { const uint32_t op = L.at(f.start + k); has = opCode(op) == OP_M && opLen(op) >= P.wordLen; }
+                if (has) {
+                    if (depth >= 5) return nOut;
+                    PredFrame c; c.start = f.start; c.len = minItem; c.sqo = f.sqo; c.eqo = (sQO - 1) & 0xFFFF; c.sro = f.sro; c.refLen = (int)((1u + (sRO - 1u) - f.sro) & 0xFFFFu); c.phase = 0;
+                    st[depth++] = f; f = c;
+                }
+            }
+            continue;
+        }
+        if (f.phase == 1) {                                                  // tail remainder
+            f.phase = 2;
+            const int t0 = f.maxItem + 1, tl = f.len - t0; bool has = false;
+            if (f.maxItem != f.len - 1) for (int k = 0; k < tl && !has; k++) { const uint32_t op = L.at(f.start + t0 + k); has = opCode(op) == OP_M && opLen(op) >= P.wordLen; }
+            if (has) {
+                if (depth >= 5) return nOut;
+                PredFrame c; c.start = f.start + t0; c.len = tl; c.sqo = (f.eQO + 1) & 0xFFFF; c.eqo = f.eqo; c.sro = f.eRO + 1u;
+                c.refLen = (int)((1u + (f.sro + (uint32_t)f.refLen - 1u) - (f.eRO + 1u)) & 0xFFFFu); c.phase = 0;
+                st[depth++] = f; f = c;
+            }
+            continue;
+        }
+        if (f.phase == 2) {                                                  // the core's careful extensions (extendClump, AlignExtFrag.cpp:64-156)
+            int sqo = f.sQO, eqo = f.eQO, refLen = (int)((1u + f.eRO - f.sRO) & 0xFFFFu); uint32_t sro = f.sRO;
+            const bool cutB = f.sQO != wS, cutF = f.eQO != wE;
+            const bool goBack = cutB, goForw = cutF || !cutB;                // sic: forward also when neither end was cut
+            if (goBack) {
+                int backLen = (int)((uint32_t)sqo < sro ? (uint32_t)sqo : sro);
+                if (backLen > 0) { int m = 0; while (m < backLen && (uint32_t)q[sqo - 1 - m] == refAt(sro - 1u - (uint32_t)m)) m++; backLen -= m; sqo -= m; sro -= (uint32_t)m; refLen = (refLen + m) & 0xFFFF; }
+                if (backLen >= P.minExtLength && nOut < YD_MEMO) { ExtProb p; p.qBase = qBase; p.rOff = sro - 1u; p.qOff = (uint16_t)((sqo - 1) & 0xFFFF); p.qLen = (uint16_t)(backLen & 0xFFFF); p.flags = strand | XP_REV | XP_VALID; out[nOut++] = p; }
+            }
+            if (goForw) {
+                const uint32_t eRO = sro + (uint32_t)refLen - 1u;
+                const uint32_t qrem = (uint32_t)(((qlen - 1) - eqo) & 0xFFFF), rrem = P.maxROff - eRO;
+                int forwLen = (int)(qrem < rrem ? qrem : rrem);
+                if (forwLen > 0) { int m = 0; while (m < forwLen && (uint32_t)q[eqo + 1 + m] == refAt(eRO + 1u + (uint32_t)m)) m++; forwLen -= m; eqo += m; refLen = (refLen + m) & 0xFFFF; }
+                if (forwLen >= P.minExtLength && nOut < YD_MEMO) { ExtProb p; p.qBase = qBase; p.rOff = sro + (uint32_t)refLen; p.qOff = (uint16_t)((eqo + 1) & 0xFFFF); p.qLen = (uint16_t)(forwLen & 0xFFFF); p.flags = strand | XP_VALID; out[nOut++] = p; }
+            }
+            f.phase = 4; continue;
+        }
+        if (depth == 0) break;                                               // frame done
+        f = st[--depth];
+    }
+    return nOut;
+}
+
 __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
 {
     const int lane = laneId(); const uint32_t r = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,7 +532,36 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
             }
         }
     }
-    { const unsigned long long sm = __ballot(verdict == 1); const unsigned slot = waveReserve(sm, X.slowCount, lane); if (verdict == 1) X.slowList[slot] = r; }
+    {
+        const unsigned long long sm = __ballot(verdict == 1); const unsigned slot = waveReserve(sm, X.slowCount, lane);
+        ExtProb pp[YD_MEMO]; int np = 0;
+        if (verdict == 1) {
+            X.slowList[slot] = r;
+            if (X.probs2) {
+                const ChainClumpRec rec = A.clumps[A.order[r]]; const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
+                np = predictCarefulDPs(P, L, n, sqo, eqo, sro, refLen, toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0, qlen, toGlobal(A.bases), pp, r0, (rec.rs & 1u) ? XP_STRAND : 0u);
+            }
+        }
+        if (X.probs2) {
+            int incl = np;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+            const int total = __shfl(incl, 63, 64); unsigned pb = 0;
+            if (lane == 63 && total) pb = atomicAdd(X.nProb2, (unsigned)total);
+            pb = (unsigned)__shfl((int)pb, 63, 64);
+            if (verdict == 1) {
+                const unsigned first = pb + (unsigned)(incl - np); int kept = 0;
+                for (int k = 0; k < np; k++) {
+                    const unsigned idx = first + (unsigned)k; if (idx >= X.probs2Cap) break;
+                    X.probs2[idx] = pp[k]; X.rowsBound2[idx] = (unsigned long long)((pp[k].qLen + 10u) / 10u);
+                    uint32_t *key = X.memoKeys + ((size_t)slot * YD_MEMO + (size_t)k) * 3;
+                    key[0] = pp[k].rOff; key[1] = (uint32_t)pp[k].qOff | ((uint32_t)pp[k].qLen << 16); key[2] = ((pp[k].flags & XP_REV) ? 1u : 0u) | (idx << 1);
+                    kept++;
+                }
+                X.memoCount[slot] = (unsigned)kept;
+            }
+        }
+    }
     // emit the accepted clumps (emit() in align.h)
     const bool acc = verdict == 2;
     const unsigned long long am = __ballot(acc);

@@ -23,6 +23,7 @@
 #include "chain_lanes.h"
 #include "seed.h"
 #include "phase_lanes.h"
+#include "split_lanes.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
 
@@ -59,8 +60,8 @@ struct ygpu_ctx {
     DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
-    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; int laneChunks = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; int laneChunks = 0; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -82,12 +83,13 @@ static int cubScan(ygpu_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n)
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp.p, bytes, in, out, (int)n, ctx->stream));
     return 0;
 }
-static int cubScan64(ygpu_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint32_t n)
+static int cubScan64(ygpu_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint32_t n, hipStream_t st = nullptr)
 {
+    if (!st) st = ctx->stream;
     size_t bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
-    if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp.p, bytes, in, out, (int)n, ctx->stream));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
+    if (ctx->cubTemp2.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp2.p, bytes, in, out, (int)n, st));
     return 0;
 }
 #include <chrono>
@@ -343,14 +345,48 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         AlignArgs Ac = A; Ac.nRoots = r1; Ac.queueHead = cc + 4 * c + 1;
         PhaseArgs Xc = X; Xc.stripBase = sb; Xc.rootBegin = r0; Xc.slowList = ctx->slowList.as<uint32_t>() + r0; Xc.slowCount = cc + 4 * c + 2; Xc.useList = 1;
         if (c == 0) { ctx->evUsed[T_P3] = true; hipEventRecord(ctx->ev[T_P3][0], sTail); }
-        hipLaunchKernelGGL(k_p3_lanes, dim3(gridFor(r1 - r0, 256)), dim3(256), 0, sTail, Ac, Xc);
-        hipLaunchKernelGGL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, sTail, Ac, Xc);
+        const uint32_t nr = r1 - r0, cap2 = nr / 4 + 1024;
+        if (ctx->splitLanes) {
+            ENSURE(ctx->memoKeys, 12ull * YD_MEMO * (nr + 1)); ENSURE(ctx->memoCount, 4ull * (nr + 1)); ENSURE(ctx->probs2, sizeof(ExtProb) * (uint64_t)cap2);
+            ENSURE(ctx->rowsBound2, 8ull * (cap2 + 1)); ENSURE(ctx->stripOff2, 8ull * (cap2 + 1)); ENSURE(ctx->extRes2, sizeof(ExtRes) * (uint64_t)cap2); ENSURE(ctx->fallList, 4ull * (nr + 1));
+            HIPCHK(hipMemsetAsync(ctx->memoCount.p, 0, 4ull * (nr + 1), sTail)); HIPCHK(hipMemsetAsync(ctx->rowsBound2.p, 0, 8ull * (cap2 + 1), sTail));
+            Xc.memoKeys = ctx->memoKeys.as<uint32_t>(); Xc.memoCount = ctx->memoCount.as<unsigned int>(); Xc.probs2 = ctx->probs2.as<ExtProb>(); Xc.rowsBound2 = ctx->rowsBound2.as<unsigned long long>();
+            Xc.nProb2 = cc + 8 * c + 3; Xc.probs2Cap = cap2;
+        } else { Xc.memoKeys = nullptr; Xc.memoCount = nullptr; Xc.probs2 = nullptr; Xc.rowsBound2 = nullptr; Xc.nProb2 = nullptr; Xc.probs2Cap = 0; }
+        hipLaunchKernelGGL(k_p3_lanes, dim3(gridFor(nr, 256)), dim3(256), 0, sTail, Ac, Xc);
+        PhaseArgs Xw = Xc;                                                    // what k_align_p3 gets: all split roots, or only those k_split_lanes gives back
+        if (ctx->splitLanes) {
+            // splitClump in lanes: the careful extensions the split roots will ask for go through a second k_ext_rows / k_ext_trace round
+            rc = cubScan64(ctx, ctx->rowsBound2.as<unsigned long long>(), ctx->stripOff2.as<unsigned long long>(), cap2 + 1, sTail); if (rc) return rc;
+            uint32_t three[3] = {0, 0, 0}; unsigned long long blocks2 = 0;       // slow roots, predicted problems
+            HIPCHK(hipMemcpyAsync(three, cc + 8 * c + 2, 8, hipMemcpyDeviceToHost, sTail));
+            HIPCHK(hipMemcpyAsync(&blocks2, ctx->stripOff2.as<unsigned long long>() + cap2, 8, hipMemcpyDeviceToHost, sTail)); HIPCHK(hipStreamSynchronize(sTail));
+            const uint32_t nSlow = three[0], n2 = std::min(three[1], cap2);
+            if (kTrace) fprintf(stderr, "[ygpu] split roots %u, careful extensions listed %u (trace blocks %llu)\n", nSlow, n2, blocks2);
+            if (nSlow) {
+                ExtArgs E2 = E;
+                if (n2) {
+                    ENSURE(ctx->extTrace2, 128ull * blocks2 + 256);
+                    E2.probs = ctx->probs2.as<ExtProb>(); E2.nProb = n2; E2.stripOff = ctx->stripOff2.as<unsigned long long>(); E2.stripBase = 0;
+                    E2.order = nullptr; E2.trace = ctx->extTrace2.as<uint32_t>(); E2.res = ctx->extRes2.as<ExtRes>(); E2.queue = cc + 8 * c + 4; E2.ctr = nullptr;   // counted by k_split_lanes
+                    hipLaunchKernelGGL(rowsKernel, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, (uint64_t)ctx->nCU * perCU)), dim3(256), 0, sTail, E2);
+                    hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, E2);
+                }
+                ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
+                SplitArgs Sx; Sx.scratch = ctx->splitScratch.as<uint8_t>(); Sx.memoKeys = ctx->memoKeys.as<uint32_t>(); Sx.memoCount = ctx->memoCount.as<unsigned int>();
+                Sx.res2 = ctx->extRes2.as<ExtRes>(); Sx.trace2 = ctx->extTrace2.as<uint32_t>(); Sx.stripOff2 = ctx->stripOff2.as<unsigned long long>(); Sx.nProb2 = n2;
+                Sx.fallList = ctx->fallList.as<uint32_t>(); Sx.fallCount = cc + 8 * c + 5; Sx.nSlots = nSlow;
+                hipLaunchKernelGGL(k_split_lanes, dim3(gridFor(nSlow, 64)), dim3(64), 0, sTail, Ac, Xc, Sx);
+                Xw.slowList = ctx->fallList.as<uint32_t>(); Xw.slowCount = cc + 8 * c + 5;
+                if (kTrace) { uint32_t fc = 0; HIPCHK(hipMemcpyAsync(&fc, cc + 8 * c + 5, 4, hipMemcpyDeviceToHost, sTail)); HIPCHK(hipStreamSynchronize(sTail)); unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gFallWhy), sizeof w8); fprintf(stderr, "[ygpu] roots left to the wave kernel %u (other %u, DP not listed %u, second split %u, depth/list %u)\n", fc, w8[0], w8[1], w8[2], w8[3]); memset(w8, 0, sizeof w8); hipMemcpyToSymbol(HIP_SYMBOL(gFallWhy), w8, sizeof w8); }
+            }
+        }
+        hipLaunchKernelGGL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, sTail, Ac, Xw);
         if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_P3][1], sTail);
         if (!overlap) TRACE("lanes: p3");
     }
     if (overlap) { HIPCHK(hipEventRecord(ctx->evTail, sTail)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0)); }
     TRACE("lanes: chunks done");
-    if (kTrace) { unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gP3Stat), sizeof z); fprintf(stderr, "[ygpu] split roots %llu: no child frames %llu (single split %llu), child frames %llu, splits %llu, careful DPs %llu, nothing emitted %llu\n", z[0], z[1], z[2], z[3], z[4], z[5], z[6]); memset(z, 0, sizeof z); hipMemcpyToSymbol(HIP_SYMBOL(gP3Stat), z, sizeof z); }
     return 0;
 }
 
@@ -369,7 +405,8 @@ static int stageAlign(ygpu_ctx *ctx)
         const size_t per = alignScratchBytes(ctx->maxQ, listCap, genCap);
         size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
         uint64_t maxWaves = std::max<uint64_t>(64, (uint64_t)((freeB + ctx->scratchAlign.cap) * 6 / 10) / per);
-        const unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * 12), maxWaves);      // 3 waves per SIMD (137 VGPRs)
+        const unsigned wavesPerCU = ctx->alignWavesPerCU > 0 ? (unsigned)ctx->alignWavesPerCU : 12u;
+        const unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * wavesPerCU), maxWaves);      // 3 waves per SIMD (137 VGPRs)
         ENSURE(ctx->scratchAlign, per * waves);
         ENSURE(ctx->clumpFrags0, 16ull * (ctx->nClumpFrags + 1));
         HIPCHK(hipMemcpyAsync(ctx->clumpFrags0.p, ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
@@ -459,6 +496,8 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evTail, hipEventDisableTiming));
     if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
+    if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
+    if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
     DevParams &P = ctx->P;
@@ -484,7 +523,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
+                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->splitScratch, &ctx->fallList, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         for (int i = 0; i < YD_MAX_CHUNK_EV; i++) hipEventDestroy(ctx->evChunk[i]);
