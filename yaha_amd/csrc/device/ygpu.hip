@@ -128,11 +128,13 @@ static int stageSeed(ygpu_ctx *ctx)
     ENSURE(ctx->keysA, 8ull * H); ENSURE(ctx->keysB, 8ull * H);
     hipLaunchKernelGGL(k_expand_hits, dim3(gridFor(H, YD_EXPAND_HITS)), dim3(256), 0, ctx->stream, ctx->dROA.as<uint32_t>(), ctx->posS.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), K, H, ctx->keysA.as<unsigned long long>());
     {
+        // The sort is stable and k_expand_hits writes the hits of one (read, strand) in ascending query offset (k-mers in order, each
+        // k-mer's reference offsets ascending), so two hits of one diagonal are already in qo order: the low 15 key bits need no pass.
         int rsBits = 1; while ((1u << rsBits) < 2 * n) rsBits++;
         size_t bytes = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 0, 47 + rsBits, ctx->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 15, 47 + rsBits, ctx->stream));
         if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(ctx->cubTemp.p, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 0, 47 + rsBits, ctx->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(ctx->cubTemp.p, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 15, 47 + rsBits, ctx->stream));
     }
     EV1(T_SORT);
     EV0(T_FRAGS);
