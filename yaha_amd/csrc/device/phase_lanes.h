@@ -69,7 +69,8 @@ __device__ __forceinline__ unsigned waveReserve(unsigned long long mask, unsigne
 #define YD_GREF 64
 #define YD_GQW 16                                // dwords of query codes (60 + alignment slack)
 #define YD_GRW 10                                // dwords of packed reference (64 bases + alignment slack)
-#define YD_GAP_SCRATCH 3072                    // per lane: (YD_GROWS + 1) * 32 trace bytes + 192 ops
+#define YD_GAP_SCRATCH 3072                    // per lane: (YD_GROWS + 1) * 32 trace bytes + 192 ops; a wave's 64 strips are interleaved dword by dword,
+                                               // so that lanes at the same cell of their (size-sorted) problems store to one line
 #define TR_U8 0xFFu
 struct GapLaneMem { int *pv, *pf; uint8_t *pi; uint32_t *refw, *qw; uint8_t *T; uint32_t *tmp; };   // LDS pointers already offset by lane (stride 64); T, tmp in HBM
 template <int GW>
@@ -80,7 +81,7 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
     int left = 0, right = 0;
     if (banded) { const int bw = P.bandWidth; if (rLen > qLen) { right = bw + (rLen - qLen); left = bw; } else { left = bw + (qLen - rLen); right = bw; } }
     const int W = banded ? left + right + 1 : rLen + 1;
-    int *PV = M.pv, *PF = M.pf; uint8_t *PI = M.pi; YD_GLOBAL uint8_t *T = toGlobal(M.T); YD_GLOBAL uint32_t *T32 = (YD_GLOBAL uint32_t *)T;
+    int *PV = M.pv, *PF = M.pf; uint8_t *PI = M.pi; YD_GLOBAL uint32_t *T32 = (YD_GLOBAL uint32_t *)toGlobal(M.T);
 #define GPV(j) PV[(j) * 64]
 #define GPF(j) PF[(j) * 64]
 #define GPI(j) PI[(j) * 64]
@@ -108,7 +109,7 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
             uint32_t cell = 0;
             if (j == startInit - 1) cell = TR_U8; else if (j >= startInit) { const int dc = j - startInit + 1; cell = (uint32_t)(OP_D | (dc << 2)); GPV(j) = -(GO + dc * GE); GPF(j) = YD_WORST; GPI(j) = 0; }
             acc |= cell << (8 * (j & 3));
-            if ((j & 3) == 3 || j == W - 1) { T32[j >> 2] = acc; acc = 0; }
+            if ((j & 3) == 3 || j == W - 1) { T32[(j >> 2) * 64] = acc; acc = 0; }
         }
     }
     GPF(startInit - 1) = 0; GPI(startInit - 1) = 0; GPV(startInit - 1) = 0;
@@ -123,7 +124,7 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
         const int qc = qAt(i - 1);
         const int rRow = banded ? i - left - 1 : 0;
         uint32_t acc = bl >= 0 ? (uint32_t)(OP_I | (i << 2)) << (8 * (bl & 3)) : 0u;
-        if (bl >= 0 && ((bl & 3) == 3 || startCol > endCol)) { T32[(i * GW + bl) >> 2] = acc; acc = 0; }
+        if (bl >= 0 && ((bl & 3) == 3 || startCol > endCol)) { T32[((i * GW + bl) >> 2) * 64] = acc; acc = 0; }
         for (int j = startCol; j <= endCol; j++) {
             const int RM = banded ? j : j - 1, IO = RM + 1; int op;
             V = GPV(RM);
@@ -138,7 +139,7 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
             if (F > V) { V = F; op = OP_I; len = I; }
             GPF(j) = F; GPI(j) = (uint8_t)I;
             acc |= (uint32_t)(op | (len << 2)) << (8 * (j & 3));
-            if ((j & 3) == 3 || j == endCol) { T32[(i * GW + j) >> 2] = acc; acc = 0; }
+            if ((j & 3) == 3 || j == endCol) { T32[((i * GW + j) >> 2) * 64] = acc; acc = 0; }
             if (banded) GPV(j) = V; else GPV(j - 1) = PVCol;
             PVCol = V; cells++;
         }
@@ -147,17 +148,18 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
     cellsOut = cells;
     // traceback from the end cell (SW.cpp:1138-1195)
     int x = banded ? right : W - 1, y = qLen;
-    unsigned cell = T[y * GW + x];
+    auto cellAt = [&](int yy, int xx) -> unsigned { const int c = yy * GW + xx; return (T32[(c >> 2) * 64] >> (8 * (c & 3))) & 0xFFu; };
+    unsigned cell = cellAt(y, x);
     int prev = cell == TR_U8 ? -1 : (int)(cell & 3u), acc2 = 0, n = 0;
     for (int guard = 0; cell != TR_U8 && guard < 4096; guard++) {
         const int code = (int)(cell & 3u); int len = (int)(cell >> 2);
         if (banded) { if (code == OP_D) x -= len; else if (code == OP_I) { x += len; y -= len; } else { y -= 1; len = 1; } }
         else        { if (code == OP_D) x -= len; else if (code == OP_I) { y -= len; } else { x -= 1; y -= 1; len = 1; } }
-        if (prev != code) { M.tmp[n] = opMake(prev, acc2); n++; prev = code; acc2 = len; } else acc2 += len;
+        if (prev != code) { M.tmp[n * 64] = opMake(prev, acc2); n++; prev = code; acc2 = len; } else acc2 += len;
         if (y < 0 || x < 0 || x >= GW || n >= 190) break;
-        cell = T[y * GW + x];
+        cell = cellAt(y, x);
     }
-    M.tmp[n] = opMake(prev, acc2); n++;
+    M.tmp[n * 64] = opMake(prev, acc2); n++;
     nOps = n;
 #undef GPV
 #undef GPF
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
     __shared__ uint8_t sPI[GW + 1][64]; __shared__ uint32_t sRefW[YD_GRW][64], sQW[YD_GQW][64];
     const int lane = laneId(); const DevParams &P = A.P;
     GapLaneMem GM; GM.pv = &sPV[0][lane]; GM.pf = &sPF[0][lane]; GM.pi = &sPI[0][lane]; GM.refw = &sRefW[0][lane]; GM.qw = &sQW[0][lane];
-    { uint8_t *sp = X.gapScratch + (size_t)(blockIdx.x * 64u + (unsigned)lane) * YD_GAP_SCRATCH; GM.T = sp; GM.tmp = (uint32_t *)(sp + (YD_GROWS + 1) * 32); }
+    { uint32_t *sp = (uint32_t *)(X.gapScratch + (size_t)blockIdx.x * 64u * YD_GAP_SCRATCH) + lane; GM.T = (uint8_t *)sp; GM.tmp = sp + (size_t)((YD_GROWS + 1) * 32 / 4) * 64; }
     YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
     const uint32_t nAll = X.nDP[0], n16 = X.nDP[1];
     const uint32_t tBegin = GW == 16 ? 0u : n16, tEnd = GW == 16 ? n16 : nAll;
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
             const unsigned off = ob + (unsigned)(incl - nT);
             if ((unsigned long long)off + (unsigned)nT > (unsigned long long)X.gapOpsCap) atomicCAS(A.errFlag, 0, (int)YERR_OUT);
             else {
-                for (int k = 0; k < nT; k++) X.gapOps[off + k] = GM.tmp[nT - 1 - k];           // list order
+                for (int k = 0; k < nT; k++) X.gapOps[off + k] = GM.tmp[(nT - 1 - k) * 64];    // list order
                 JointRec *jp = X.joints + ji; jp->opsOff = off; jp->nOps = (uint16_t)nT; jp->score = score; jp->cells = cells;
             }
         }
