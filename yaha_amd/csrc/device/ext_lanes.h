@@ -40,7 +40,9 @@ struct ExtArgs {
 
 // CAPS = false when neither run cap can bind inside a 21-column strip (maxGap >= 21 and maxIntron >= 21: a run spans at most 20
 // columns): the run-length state (PI, PD) is then dead and is compiled out.
-template <bool CAPS>
+// SECOND = the careful-extension round of splitClump (split_lanes.h): same code, its own kernel name in profiles, work counted by
+// the consumer of the results.
+template <bool CAPS, bool SECOND>
 __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
 {
     __shared__ uint32_t sBlk[32][256];          // per lane: the current 10-row trace block, [dword][thread] (conflict-free for any row slot)
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     unsigned long long cc = cells;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { cc += (unsigned long long)__shfl_xor((long long)cc, d, 64); }
-    if (lane == 0 && A.ctr) {
+    if (lane == 0 && !SECOND && A.ctr) {
         unsigned long long *c = A.ctr->v;
         atomicAdd(&c[C_EXT_CALLS], (unsigned long long)c0); atomicAdd(&c[C_EXT_ROWS], (unsigned long long)c1); atomicAdd(&c[C_EXT_CELLS], cc);
         atomicAdd(&c[C_TOUCHED], (unsigned long long)c1 + (unsigned long long)c0 * (unsigned long long)(4 * A.P.bandWidth + 1));

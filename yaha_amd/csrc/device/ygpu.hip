@@ -314,7 +314,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
     E.trace = ctx->extTrace.as<uint32_t>(); E.ctr = ctx->ctr.as<DevCounters>(); E.errFlag = ctx->errFlag.as<int>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
-    auto rowsKernel = caps ? k_ext_rows<true> : k_ext_rows<false>;
+    auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
+    auto rowsKernel2 = caps ? k_ext_rows<true, true> : k_ext_rows<false, true>;
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     const bool overlap = fits && nChunks > 1;
     hipStream_t sTail = overlap ? ctx->stream2 : ctx->stream;
@@ -379,7 +380,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                         HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp2.p, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, sTail));
                     }
                     E2.order = ctx->vals2b.as<uint32_t>(); E2.trace = ctx->extTrace2.as<uint32_t>(); E2.res = ctx->extRes2.as<ExtRes>(); E2.queue = cc + 8 * c + 4; E2.ctr = nullptr;   // counted by k_split_lanes
-                    hipLaunchKernelGGL(rowsKernel, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, (uint64_t)ctx->nCU * perCU)), dim3(256), 0, sTail, E2);
+                    hipLaunchKernelGGL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, (uint64_t)ctx->nCU * perCU)), dim3(256), 0, sTail, E2);
                     hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, E2);
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
