@@ -393,22 +393,27 @@ __global__ void __launch_bounds__(64) k_chain_big(ChainArgs A, const uint32_t *b
 }
 
 // single-fragment regions: a clump iff refLen >= minMatch (QueryMatch.c:281-290); one allocation per wavefront
-__global__ void k_regions_single(ChainArgs A)
+// One atomic pair per 256-thread block (a single L2 word takes only ~88 atomics/us; there are ~10^5 waves here).
+__global__ void __launch_bounds__(256) k_regions_single(ChainArgs A)
 {
-    const uint32_t reg = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId();
+    __shared__ unsigned sCnt[4], sBase[2];
+    const uint32_t reg = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId(), wv = (int)(threadIdx.x >> 6);
     bool make = false; DevFrag f; f.refLen = 0; f.rs = 0;
     if (reg < A.nRegions) {
         const uint32_t s = A.regStart[reg], e = A.regStart[reg + 1];
         if (e - s == 1) { f = A.frags[s]; make = (int)f.refLen >= A.P.minMatch; A.regionClumpCount[reg] = make ? 1u : 0u; }
     }
     const unsigned long long m = __ballot(make);
-    if (!m) return;
-    const unsigned n = (unsigned)__popcll(m), first = (unsigned)__builtin_ctzll(m);
-    unsigned cb = 0, fb = 0;
-    if ((unsigned)lane == first) { cb = atomicAdd(&A.counts[0], n); fb = atomicAdd(&A.counts[1], n); atomicAdd(&A.ctr->v[C_FORMED], (unsigned long long)n); }
-    cb = (unsigned)__shfl((int)cb, (int)first, 64); fb = (unsigned)__shfl((int)fb, (int)first, 64);
+    if (lane == 0) sCnt[wv] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned n = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
+        if (n) { sBase[0] = atomicAdd(&A.counts[0], n); sBase[1] = atomicAdd(&A.counts[1], n); atomicAdd(&A.ctr->v[C_FORMED], (unsigned long long)n); }
+    }
+    __syncthreads();
     if (make) {
-        const unsigned k = (unsigned)__popcll(m & ((1ull << lane) - 1ull)); const unsigned ci = cb + k, fi = fb + k;
+        unsigned before = 0; for (int k = 0; k < wv; k++) before += sCnt[k];
+        const unsigned k = before + (unsigned)__popcll(m & ((1ull << lane) - 1ull)); const unsigned ci = sBase[0] + k, fi = sBase[1] + k;
         if (ci >= A.clumpCap || fi >= A.fragCap) { atomicCAS(A.errFlag, 0, (int)YERR_CHAIN); return; }
         DevFrag g = f; g.used = 0; A.clumpFrags[fi] = g;
         ChainClumpRec r; r.rs = f.rs; r.fragOff = fi; r.nFrags = 1; r.region = reg; r.seq = 0; r.matched = f.refLen; A.clumps[ci] = r;

@@ -134,26 +134,25 @@ __global__ void k_region_starts(const uint32_t *isHead, const uint32_t *regIdx, 
 }
 // multi-fragment region list + largest region
 // smallList: regions with 2..8 fragments (k_chain_lanes); multiList: 9..64 (k_chain); bigList: more than 64 (k_chain_big)
-__global__ void k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned int *nSmall)
+__global__ void __launch_bounds__(256) k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned int *nSmall)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63);
+    __shared__ unsigned sM[4], sS[4], sBase[2];                              // one atomic per list and 256-thread block
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
     const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
     const bool big = n > 64, small = n >= 2 && n <= 8, multi = n > 8 && !big;
     if (big) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }        // rare
-    const unsigned long long m = __ballot(multi);                            // one atomic per wavefront
-    if (m) {
-        const int first = __builtin_ctzll(m); unsigned base = 0;
-        if (lane == first) base = atomicAdd(nMulti, (unsigned)__builtin_popcountll(m));
-        base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
-        if (multi) multiList[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
+    const unsigned long long mm = __ballot(multi), ms = __ballot(small);
+    if (lane == 0) { sM[wv] = (unsigned)__builtin_popcountll(mm); sS[wv] = (unsigned)__builtin_popcountll(ms); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tm = sM[0] + sM[1] + sM[2] + sM[3], ts = sS[0] + sS[1] + sS[2] + sS[3];
+        sBase[0] = tm ? atomicAdd(nMulti, tm) : 0u; sBase[1] = ts ? atomicAdd(nSmall, ts) : 0u;
     }
-    const unsigned long long ms = __ballot(small);
-    if (ms) {
-        const int first = __builtin_ctzll(ms); unsigned base = 0;
-        if (lane == first) base = atomicAdd(nSmall, (unsigned)__builtin_popcountll(ms));
-        base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
-        if (small) smallList[base + (unsigned)__builtin_popcountll(ms & ((1ull << lane) - 1ull))] = r;
-    }
+    __syncthreads();
+    unsigned bm = 0, bs = 0; for (int k = 0; k < wv; k++) { bm += sM[k]; bs += sS[k]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (multi) multiList[sBase[0] + bm + (unsigned)__builtin_popcountll(mm & below)] = r;
+    if (small) smallList[sBase[1] + bs + (unsigned)__builtin_popcountll(ms & below)] = r;
 }
 // order[base[region] + seq] = clump index  (rank of a root clump = creation order)
 __global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, const uint32_t *regionBase, uint32_t *order)
