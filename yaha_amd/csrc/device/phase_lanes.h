@@ -59,6 +59,18 @@ __device__ __forceinline__ unsigned waveReserve(unsigned long long mask, unsigne
 }
 
 
+// Work counters of a 256-thread block: the waves add their (wave-reduced) values to LDS, then one atomic per counter and
+// block instead of one per wave (the counters are single L2 words).  Every thread of the block must call it.
+template <int N> __device__ __forceinline__ void blockCounters(unsigned long long *const (&dst)[N], const unsigned (&val)[N])
+{
+    __shared__ unsigned sAcc[N];
+    if (threadIdx.x < (unsigned)N) sAcc[threadIdx.x] = 0;
+    __syncthreads();
+    if (laneId() == 0) { for (int k = 0; k < N; k++) if (val[k]) atomicAdd(&sAcc[k], val[k]); }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)N && sAcc[threadIdx.x]) atomicAdd(dst[threadIdx.x], (unsigned long long)sAcc[threadIdx.x]);
+}
+
 // ---- gap-fill DP of one lane (findAGSAlignment / findAGSAlignmentBanded, SW.cpp:462-477, 798-1208) ---------------------------
 // The sequential recurrence, one problem per lane: strip state (PV/PF int32, PI uint8, GW+1 columns) and the reference
 // segment in LDS laid out [column][lane] (conflict-free whatever column each lane is at), trace cells (op | run << 2, one
@@ -225,10 +237,8 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
         }
     }
     perfect = waveSumU(perfect); touched = waveSumU(touched); nDP = waveSumU(nDP); nDP16 = waveSumU(nDP16);
-    if (lane == 0 && (perfect | touched | nDP)) {
-        atomicAdd(&A.ctr->v[C_PERFECT], (unsigned long long)perfect); atomicAdd(&A.ctr->v[C_TOUCHED], (unsigned long long)touched);
-        if (nDP) { atomicAdd(X.nDP, nDP); atomicAdd(X.nDP + 1, nDP16); }
-    }
+    { unsigned long long *const dst[2] = {&A.ctr->v[C_PERFECT], &A.ctr->v[C_TOUCHED]}; const unsigned val[2] = {perfect, touched}; blockCounters<2>(dst, val); }
+    if (lane == 0 && nDP) { atomicAdd(X.nDP, nDP); atomicAdd(X.nDP + 1, nDP16); }
 }
 
 // lane per DP joint, in size order (key = strip width, rows).  Persistent 64-thread blocks.  The GW = 16 instance takes the
@@ -386,11 +396,8 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
         }
     }
     perfect = waveSumU(perfect); touched = waveSumU(touched); gapCalls = waveSumU(gapCalls); gapRows = waveSumU(gapRows); gapCells = waveSumU(gapCells);
-    if (lane == 0 && (perfect | touched | gapCalls)) {
-        unsigned long long *c = A.ctr->v;
-        atomicAdd(&c[C_PERFECT], (unsigned long long)perfect); atomicAdd(&c[C_TOUCHED], (unsigned long long)touched);
-        if (gapCalls) { atomicAdd(&c[C_GAP_CALLS], (unsigned long long)gapCalls); atomicAdd(&c[C_GAP_ROWS], (unsigned long long)gapRows); atomicAdd(&c[C_GAP_CELLS], (unsigned long long)gapCells); }
-    }
+    { unsigned long long *c = A.ctr->v; unsigned long long *const dst[5] = {&c[C_PERFECT], &c[C_TOUCHED], &c[C_GAP_CALLS], &c[C_GAP_ROWS], &c[C_GAP_CELLS]};
+      const unsigned val[5] = {perfect, touched, gapCalls, gapRows, gapCells}; blockCounters<5>(dst, val); }
 }
 
 // Phase 3 for roots that scoreClump accepts or rejects without a split (AlignHelpers.c:302-366): the merged edit list
