@@ -71,6 +71,20 @@ template <int N> __device__ __forceinline__ void blockCounters(unsigned long lon
     if (threadIdx.x < (unsigned)N && sAcc[threadIdx.x]) atomicAdd(dst[threadIdx.x], (unsigned long long)sAcc[threadIdx.x]);
 }
 
+// Arena space for a 256-thread block: the waves' totals meet in LDS, one atomic per block; returns this wave's base.
+// Every thread of the block must call it.
+__device__ __forceinline__ unsigned blockReserve(unsigned int *counter, unsigned waveTotal)
+{
+    __shared__ unsigned sTot[4], sBase;
+    const int wv = (int)(threadIdx.x >> 6);
+    if (laneId() == 0) sTot[wv] = waveTotal;
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned t = sTot[0] + sTot[1] + sTot[2] + sTot[3]; sBase = t ? atomicAdd(counter, t) : 0u; }
+    __syncthreads();
+    unsigned b = sBase; for (int k = 0; k < wv; k++) b += sTot[k];
+    return b;
+}
+
 // ---- gap-fill DP of one lane (findAGSAlignment / findAGSAlignmentBanded, SW.cpp:462-477, 798-1208) ---------------------------
 // The sequential recurrence, one problem per lane: strip state (PV/PF int32, PI uint8, GW+1 columns) and the reference
 // segment in LDS laid out [column][lane] (conflict-free whatever column each lane is at), trace cells (op | run << 2, one
@@ -327,9 +341,8 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
     unsigned incl = want;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { unsigned t = (unsigned)__shfl_up((int)incl, d, 64); if (lane >= d) incl += t; }
-    const unsigned total = (unsigned)__shfl((int)incl, 63, 64); unsigned base = 0;
-    if (lane == 63 && total) base = atomicAdd(X.stateOpsCount, total);
-    base = (unsigned)__shfl((int)base, 63, 64);
+    const unsigned total = (unsigned)__shfl((int)incl, 63, 64);
+    const unsigned base = blockReserve(X.stateOpsCount, total);
     const unsigned slot = base + incl - want;
     unsigned perfect = 0, touched = 0, gapCalls = 0, gapRows = 0, gapCells = 0;
     if (live) {
