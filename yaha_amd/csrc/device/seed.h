@@ -80,6 +80,13 @@ __global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const 
     }
 }
 
+// segment offsets of the hit sort: the hits of (read, strand) rs are [hitOff[kmerOff[rs]], hitOff[kmerOff[rs + 1]])
+__global__ void k_seg_offsets(const uint32_t *kmerOff, const uint32_t *hitOff, uint32_t nSeg, uint32_t *segOff)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= nSeg) segOff[s] = hitOff[kmerOff[s]];
+}
+
 // A2b: fragment heads.  A hit starts a new fragment when (read,strand) or diagonal changes or the k-mer neither overlaps
 // nor abuts the previous one (QueryMatch.c:99).
 __global__ void k_frag_heads(const unsigned long long *keys, uint32_t nHits, int wordLen, uint32_t *isHead)

@@ -57,11 +57,11 @@ struct ygpu_ctx {
     std::vector<uint32_t> hReadOff, hKmerOff;
     DevBuf dFwd, dRev, dReadOff, dKmerOff;
     // arenas
-    DevBuf posS, posC, posRsI, hitOff, keysA, keysB, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
+    DevBuf posS, posC, posRsI, hitOff, keysA, keysB, segOff, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; int laneChunks = 0; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -130,11 +130,22 @@ static int stageSeed(ygpu_ctx *ctx)
     {
         // The sort is stable and k_expand_hits writes the hits of one (read, strand) in ascending query offset (k-mers in order, each
         // k-mer's reference offsets ascending), so two hits of one diagonal are already in qo order: the low 15 key bits need no pass.
+        // The hits of one (read, strand) are one segment: a segmented sort on the 32 diagonal bits only (short segments are sorted
+        // inside one workgroup, one pass over HBM) instead of a batch-wide sort that also has to order the (read, strand) bits.
+        if (ctx->segSort) {
+            ENSURE(ctx->segOff, 4ull * (2 * n + 2));
+            hipLaunchKernelGGL(k_seg_offsets, dim3(gridFor(2 * n + 1, 256)), dim3(256), 0, ctx->stream, ctx->dKmerOff.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), 2 * n, ctx->segOff.as<uint32_t>());
+            size_t bytes = 0;
+            HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, (int)(2 * n), ctx->segOff.as<uint32_t>(), ctx->segOff.as<uint32_t>() + 1, 15, 47, ctx->stream));
+            if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+            HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, (int)(2 * n), ctx->segOff.as<uint32_t>(), ctx->segOff.as<uint32_t>() + 1, 15, 47, ctx->stream));
+        } else {
         int rsBits = 1; while ((1u << rsBits) < 2 * n) rsBits++;
         size_t bytes = 0;
         HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 15, 47 + rsBits, ctx->stream));
         if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
         HIPCHK(hipcub::DeviceRadixSort::SortKeys(ctx->cubTemp.p, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 15, 47 + rsBits, ctx->stream));
+        }
     }
     EV1(T_SORT);
     EV0(T_FRAGS);
@@ -507,6 +518,7 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evTail, hipEventDisableTiming));
     if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
+    if (const char *e = getenv("YGPU_SEG_SORT")) ctx->segSort = atoi(e);
     if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
     if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -531,7 +543,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
     if (!ctx) return;
     if (ctx->stream) {
         hipSetDevice(ctx->device);
-        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->isHead, &ctx->scanOut,
+        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
                          &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
