@@ -164,10 +164,11 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         uint32_t nbByte, nbOdd;                                                                     // next row's top reference base (index i + right)
         { const int idx = i + bandwidth; const bool in = busy && idx < rLen; const uint32_t off = in ? (rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx) : 0u;
           nbByte = gBases[off >> 1]; nbOdd = in ? (off & 1u) : 2u; }
+        // Real cells of row i: columns startCol = max(left + 1 - i, 0) .. endCol.  findAGSExtension always passes rLen = qLen + 2*BW
+        // (both clamps keep that relation, SW.cpp:499-516), so endCol = min(left + rLen - i, W - 1) = W - 1 on every row i <= qLen:
+        // only the first `left` rows have cells to keep out of the row maximum, and only in the columns left of the origin.
         int sc = leftR + 1 - i; if (sc < 0) sc = 0;
-        int ec = leftR + rLen - i; if (ec > YD_LW - 1) ec = YD_LW - 1;
-        const uint32_t am = ec >= sc ? ((2u << ec) - 1u) & ~((1u << sc) - 1u) : 0u;
-        if (busy) { const unsigned nc = ec >= sc ? (unsigned)(ec - sc + 1) : 0u; rows++; cells += nc; pCells += nc; }
+        if (busy) { const unsigned nc = (unsigned)(YD_LW - sc); rows++; cells += nc; pCells += nc; }
         int PVCol = YD_LWORST, PE = YD_LWORST, PD = 0;
         uint32_t t0 = 0, t1 = 0, t2 = 0, rowKey = 0;
         int dV = PV[0];
@@ -191,7 +192,8 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             nib |= (cE ? 4u : 0u) | (cF ? 8u : 0u);
             if (j < 8) { t0 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t0)); } else if (j < 16) { t1 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t1)); } else { t2 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t2)); }   // pinned: the condition masks die here
             // row-major first maximum over the real cells: key = (V + BIAS) << 5 | (31 - j)
-            const uint32_t key = (((uint32_t)(V + YD_BIAS)) << 5 | (uint32_t)(31 - j)) & (uint32_t)(-(int)((am >> j) & 1u));
+            uint32_t key = ((uint32_t)(V + YD_BIAS)) << 5 | (uint32_t)(31 - j);
+            if (j < leftR) key = j >= sc ? key : 0u;
             rowKey = key > rowKey ? key : rowKey;
             PV[j] = V; PF[j] = F; PI[j] = I; PVCol = V;
             dV = upV;                                                        // the next column's diagonal predecessor
