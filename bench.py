@@ -10,7 +10,9 @@ calibrated to ~12 k seed hits and ~1.7 M X-drop cells per 1 kbp read, SURVEY.md 
 reference's defaults (-L 15 -S 1 -H 65525) by this repo's byte-identical indexer, and 1 000 bp reads with the
 realised divergence of the bundled "E05" sets (1.7 %).  One step = one pass of the whole hot path (A1..A10:
 k-mer lookup, seed join, chain DP, banded affine-gap DP + X-drop extension, score/split) over one batch of
-reads that is already resident in HBM; results stay in HBM.  Reads shard across ranks (weak scaling, fixed
+reads that is already resident in HBM; results stay in HBM.  Every rank drives --contexts (default 2) device contexts on its
+GPU, one host thread each, which take the K timed steps from a common counter: two batches are in flight per GPU, so that one
+context's latency-bound stages overlap the other's compute (contexts share nothing but the read-only index image).  Reads shard across ranks (weak scaling, fixed
 reads per GPU), the index is replicated per GPU, there is no data-path collective: torch.distributed is used
 for the barrier and the max-over-ranks only.
 
@@ -133,6 +135,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contexts", type=int, default=2, help="device contexts (batches in flight) per GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -160,27 +163,54 @@ def main():
     fa, idx = ensure_inputs(cache, args.genome_mbp, args.seed)
     reads_path = make_reads(cache, fa, "g%dm" % args.genome_mbp, args.reads_per_gpu, args.read_len, args.div, 1000 + rank)
 
+    import threading
     with ya.Session(["-x", idx, "-q", reads_path]) as s:
         b = s.next_batch(args.reads_per_gpu)
         n_reads = b.n_reads
         offs = C.cast(b.offsets, C.POINTER(C.c_uint64))
         n_bases = int(offs[n_reads] - offs[0])
-        with ya.Context(s.index, s.params, device=local) as ctx:
-            t = time.time(); ctx.upload(b); t_up = time.time() - t
+        # args.contexts device contexts on this GPU (they share the index image), one host thread each; every step is one pass of
+        # the whole hot path over the batch by ONE context, and the contexts take the K steps from a common counter: while one
+        # is in a latency-bound stage the other one's kernels fill the device.
+        ctxs = [ya.Context(s.index, s.params, device=local)]
+        for _ in range(1, max(1, args.contexts)):
+            ctxs.append(ya.Context(s.index, s.params, device=local, parent=ctxs[0]))
+        t = time.time()
+        for c in ctxs:
+            c.upload(b)
+        t_up = (time.time() - t) / len(ctxs)
+        for c in ctxs:
             for _ in range(args.warmup):
-                ctx.run()
-            barrier()
-            t0 = time.time()
-            stage_ms = {}
-            for _ in range(args.steps):
-                ctx.run()                                   # synchronous: returns when the results are complete in HBM
-                for k, v in ctx.timing()[1].items():
-                    stage_ms[k] = stage_ms.get(k, 0.0) + v
-            barrier()
-            dt = time.time() - t0
-            t = time.time(); r = ctx.collect(); t_down = time.time() - t
-            counters = r.counters.as_dict()
-            n_clumps = int(r.n_clumps)
+                c.run()
+        stage_ms = {}
+        lock = threading.Lock()
+        todo = [args.steps]
+
+        def stepper(c):
+            while True:
+                with lock:
+                    if todo[0] <= 0:
+                        return
+                    todo[0] -= 1
+                c.run()                                     # synchronous: returns when the results are complete in HBM
+                tm = c.timing()[1]
+                with lock:
+                    for k, v in tm.items():
+                        stage_ms[k] = stage_ms.get(k, 0.0) + v
+        barrier()
+        t0 = time.time()
+        th = [threading.Thread(target=stepper, args=(c,)) for c in ctxs]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        barrier()
+        dt = time.time() - t0
+        t = time.time(); r = ctxs[0].collect(); t_down = time.time() - t
+        counters = r.counters.as_dict()
+        n_clumps = int(r.n_clumps)
+        for c in reversed(ctxs):
+            c.close()
     dt = max_over_ranks(dt, dist)
     if rank != 0:
         if dist is not None:
@@ -223,7 +253,7 @@ def main():
         "bases_per_s": value * Lq,
         "config": {"workload": "synthetic hg18-like genome %d Mbp (24 seqs, 45%% repeats), index -L 15 -S 1 -H 65525, %d x %d bp reads per GPU at %.1f%% divergence, defaults -BW 5 -G 50 -H 650 -M 25 -X 25, hot path A1..A10 with inputs resident in HBM"
                    % (args.genome_mbp, n_reads, args.read_len, 100 * args.div),
-                   "reads_per_gpu": n_reads, "read_len": args.read_len, "parallelism": "reads sharded x%d, index replicated, no collective" % world},
+                   "reads_per_gpu": n_reads, "read_len": args.read_len, "parallelism": "reads sharded x%d, index replicated, no collective; %d contexts (batches in flight) per GPU" % (world, max(1, args.contexts))},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "algorithmic_bytes_per_launch": kbytes, "kernel_ms_per_launch": kernel_ms,
                      "cell_updates_per_s": counters["dp_ext_cells"] / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,

@@ -111,6 +111,11 @@ typedef struct ygpu_ctx ygpu_ctx;
 /* Create a context on HIP device `device`: copies the index view into HBM (replicated per GPU; reads shard
  * across GPUs, no collective).  Replaces the per-thread makeQueryState/initializeQueries (QueryState.c:36-104). */
 int  ygpu_init(int device, const ygpu_index_view *index, const ygpu_params *params, ygpu_ctx **out);
+/* A further context on the same device sharing the parent's index image (no second upload; the parent must outlive it).  Two
+ * contexts per GPU, one host thread and one stream of batches each, overlap one context's latency-bound stages and host work
+ * with the other's compute -- the counterpart of running the reference with more threads than one per core is not needed:
+ * there is no shared mutable state between contexts (as between the reference's per-thread QueryStates, Query.c:642-684). */
+int  ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out);
 void ygpu_destroy(ygpu_ctx *ctx);
 const char *ygpu_last_error(const ygpu_ctx *ctx);
 

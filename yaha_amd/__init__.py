@@ -70,7 +70,7 @@ class DPResult(C.Structure):
 DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
 
 EXPORTS = (
-    "ygpu_init", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_last_timing",
+    "ygpu_init", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_last_timing",
     "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch",
     "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
     "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit",
@@ -155,9 +155,12 @@ class Session:
 class Context:
     """One device context = the reference's per-thread QueryState, batched (include/yaha_hip.h)."""
 
-    def __init__(self, index_view, params, device=0):
+    def __init__(self, index_view, params, device=0, parent=None):
         self._h = C.c_void_p()
-        rc = lib().ygpu_init(device, C.byref(index_view), C.byref(params), C.byref(self._h))
+        if parent is not None:                      # second context on the parent's device, sharing its index image
+            rc = lib().ygpu_clone(parent._h, C.byref(self._h))
+        else:
+            rc = lib().ygpu_init(device, C.byref(index_view), C.byref(params), C.byref(self._h))
         if rc != 0:
             msg = lib().ygpu_last_error(self._h).decode() if self._h else ""
             raise RuntimeError("ygpu_init failed: %d %s (the HIP path is mandatory; there is no CPU fallback)" % (rc, msg))

@@ -61,7 +61,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -497,6 +497,21 @@ static int runTo(ygpu_ctx *ctx, int stage)
     return 0;
 }
 
+static int initCommon(ygpu_ctx *ctx, int device)
+{
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreate(&ctx->stream)); HIPCHK(hipStreamCreate(&ctx->stream2));
+    for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evTail, hipEventDisableTiming));
+    if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
+    if (const char *e = getenv("YGPU_SEG_SORT")) ctx->segSort = atoi(e);
+    if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
+    if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
+    return 0;
+}
+
 extern "C" {
 
 int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_ctx **out)
@@ -513,16 +528,7 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     if (p->bandWidth < 0 || 4 * p->bandWidth + 1 > 64) { ctx->err = "bandWidth > 15 is not supported by the wave-parallel extension kernel"; return YGPU_EINVAL; }
     if (p->maxGap < 0 || p->maxGap > 16383 || p->maxIntron < 0 || p->maxHits < 0 || p->maxHits > 65525) { ctx->err = "maxGap/maxIntron/maxHits out of range"; return YGPU_EINVAL; }
     if (p->MScore < 0 || p->RCost < 0 || p->GECost < 0 || p->GOCost < 0 || big >= (1L << 23)) { ctx->err = "scoring parameters out of the supported range"; return YGPU_EINVAL; }
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreate(&ctx->stream)); HIPCHK(hipStreamCreate(&ctx->stream2));
-    for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evTail, hipEventDisableTiming));
-    if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
-    if (const char *e = getenv("YGPU_SEG_SORT")) ctx->segSort = atoi(e);
-    if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
-    if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
-    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
+    { int rc0 = initCommon(ctx, device); if (rc0) return rc0; }
     DevParams &P = ctx->P;
     P.wordLen = p->wordLen; P.maxHits = p->maxHits; P.bandWidth = p->bandWidth; P.maxGap = p->maxGap; P.maxIntron = p->maxIntron; P.minMatch = p->minMatch; P.maxDesert = p->maxDesert;
     P.minNonOverlap = p->minNonOverlap; P.minRawScore = p->minRawScore; P.minExtLength = p->minExtLength & 0xFF; P.GO = p->GOCost; P.GE = p->GECost; P.RC = p->RCost; P.MS = p->MScore; P.X = p->XCutoff;
@@ -538,11 +544,29 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     return 0;
 }
 
+/* A second context on the same device that shares the parent's index image in HBM (nothing is uploaded again).  Two contexts on
+ * one GPU, each driven by its own host thread with its own batches, keep the device busy while one of them is in a latency-bound
+ * stage or waiting for its host.  The parent must outlive its clones. */
+int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
+{
+    *out = nullptr;
+    if (!parent || !parent->stream) return YGPU_EINVAL;
+    ygpu_ctx *ctx = new ygpu_ctx; *out = ctx; ctx->device = parent->device;
+    int rc = initCommon(ctx, parent->device); if (rc) return rc;
+    ctx->P = parent->P;
+    ctx->dBases.p = parent->dBases.p; ctx->dBases.cap = parent->dBases.cap; ctx->dSO.p = parent->dSO.p; ctx->dSO.cap = parent->dSO.cap; ctx->dROA.p = parent->dROA.p; ctx->dROA.cap = parent->dROA.cap;
+    ctx->sharedIndex = true;
+    ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 void ygpu_destroy(ygpu_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->stream) {
         hipSetDevice(ctx->device);
+        if (ctx->sharedIndex) { ctx->dBases.p = nullptr; ctx->dBases.cap = 0; ctx->dSO.p = nullptr; ctx->dSO.cap = 0; ctx->dROA.p = nullptr; ctx->dROA.cap = 0; }
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,

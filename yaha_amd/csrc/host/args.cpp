@@ -1,7 +1,7 @@
 // args.cpp -- command line, defaults and derived parameters.  Same option names, defaults, value checks and
 // file-name derivation as the reference CLI (Main.c:187-565, AlignArgs.c:27-169) so that
 // `yaha -g genome.fa` / `yaha -x index -q reads ...` keep working unchanged.  Extra options of this
-// implementation: -gpus N (shard batches over N devices), -device D, -batch N (reads per device batch).
+// implementation: -gpus N (shard batches over N devices), -ctx M (contexts per device), -device D, -batch N (reads per device batch).
 #include "yaha_host.h"
 #include <cstring>
 #include <cstdlib>
@@ -16,7 +16,7 @@ static void usage(FILE *o)
           "  yaha -g genome.{fa|fna|fasta|nib2} [-H maxHits (65525)] [-L wordLen (15)] [-S skipDist (1)]\n\n"
           "Query alignment (hot path on MI355X):\n"
           "  yaha -x indexFile [-q queryFile|(stdin)] [-o8|(-osh)|-oss outFile|(stdout)] [-t hostThreads (1)]\n"
-          "       [-gpus N (1)] [-device D (0)] [-batch readsPerBatch (4096)]\n"
+          "       [-gpus N (1)] [-ctx contextsPerGpu (2)] [-device D (0)] [-batch readsPerBatch (4096)]\n"
           "  general : [-BW 5] [-G 50] [-H 650] [-M 25] [-MD 50] [-P 0.9] [-X 25]\n"
           "  scoring : [-AGS Y|N] [-GEC 2] [-GOC 5] [-MS 1] [-RC 3]\n"
           "  OQC     : [-OQC Y|N] [-BP 5] [-MGDP 5] [-MNO minMatch]   FBS: [-FBS Y|N] [-PRL 0.9] [-PSS 0.9]\n"
@@ -81,6 +81,7 @@ int parseArgs(int argc, char **argv, Args &a)
         else if (is("-I")) { if (!parseInt(val(), "-I", a.maxIntron)) return 2; }          // experimental builds of the reference, Main.c:418-435
         else if (is("-R")) { if (!parseInt(val(), "-R", a.minRawScore)) return 2; }
         else if (is("-gpus")) { if (!parseInt(val(), "-gpus", a.gpus)) return 2; }
+        else if (is("-ctx")) { if (!parseInt(val(), "-ctx", a.ctxPerGpu)) return 2; }
         else if (is("-device")) { if (!parseInt(val(), "-device", a.device)) return 2; }
         else if (is("-batch")) { if (!parseInt(val(), "-batch", a.batchReads)) return 2; }
         else { fprintf(stderr, "%s is not a valid option.\n\n", k); usage(stderr); return 2; }

@@ -106,13 +106,16 @@ int runQueries(Args &a, FILE *log)
     fputs(S->header.c_str(), out);
     ygpu_params P; paramsFromArgs(A, P);
     ygpu_index_view V; yaha_session_index_view(S.get(), &V);
-    const int ngpu = std::max(1, A.gpus);
+    // -gpus N devices x -ctx M contexts per device (default 2: while one context's batch is in a latency-bound device stage, or in
+    // OQC / SAM formatting on its host thread, the other one's batch computes).  Contexts of one device share its index image.
+    const int perDev = std::max(1, A.ctxPerGpu), ngpu = std::max(1, A.gpus) * perDev;
     std::vector<ygpu_ctx *> ctx(ngpu, nullptr);
     for (int d = 0; d < ngpu; d++) {
-        int rc = ygpu_init(A.device + d, &V, &P, &ctx[d]);
-        if (rc != 0) { fprintf(log, "ygpu_init(device %d) failed: %d %s\n", A.device + d, rc, ctx[d] ? ygpu_last_error(ctx[d]) : ""); return 1; }
+        const int dev = A.device + d / perDev;
+        int rc = (d % perDev == 0) ? ygpu_init(dev, &V, &P, &ctx[d]) : ygpu_clone(ctx[d - d % perDev], &ctx[d]);
+        if (rc != 0) { fprintf(log, "ygpu_init(device %d) failed: %d %s\n", dev, rc, ctx[d] ? ygpu_last_error(ctx[d]) : ""); return 1; }
     }
-    // One worker per device.  The reader is serial (as in the reference, Query.c:105-214); a ticket orders output.
+    // One worker per context.  The reader is serial (as in the reference, Query.c:105-214); a ticket orders output.
     struct Batch { uint64_t ticket; std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets; };
     std::mutex rdMu, outMu; std::condition_variable outCv; uint64_t nextTicket = 0, nextOut = 0; bool eof = false; int rcAll = 0;
     std::map<uint64_t, std::string> done;
@@ -143,7 +146,7 @@ int runQueries(Args &a, FILE *log)
     std::vector<std::thread> th; for (int d = 1; d < ngpu; d++) th.emplace_back(worker, d);
     worker(0); for (auto &x : th) x.join();
     for (auto &kv : done) fputs(kv.second.c_str(), out);
-    for (auto c : ctx) ygpu_destroy(c);
+    for (int d = ngpu - 1; d >= 0; d--) ygpu_destroy(ctx[d]);                 // clones before their parents
     if (out != stdout) fclose(out); else fflush(out);
     return rcAll;
 }
