@@ -94,6 +94,30 @@ def test_lane_pipeline_parameter_corners(work, index11, reads, extra, tmp_path):
         assert mine == strip_pg(open(ref_out).read())
 
 
+def test_two_contexts_in_flight_match_one(work, index11):
+    # ygpu_clone: a second context on the same device sharing the index image; two host threads step them concurrently
+    import threading
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r10k.fa")]) as s1, ya.Session(["-x", index11, "-q", os.path.join(work, "rchim.fa")]) as s2:
+        b1, b2 = s1.next_batch(400), s2.next_batch(400)
+        with ya.Context(s1.index, s1.params) as solo:
+            solo.upload(b1); solo.run(); exp1 = ya.result_records(solo.collect())
+            solo.upload(b2); solo.run(); exp2 = ya.result_records(solo.collect())
+        with ya.Context(s1.index, s1.params) as a:
+            b = ya.Context(s1.index, s1.params, parent=a)
+            got = {}
+
+            def work_on(ctx, batch, key):
+                for _ in range(3):
+                    ctx.upload(batch); ctx.run(); got[key] = ya.result_records(ctx.collect())
+            th = [threading.Thread(target=work_on, args=(a, b1, 1)), threading.Thread(target=work_on, args=(b, b2, 2))]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            b.close()
+        assert got[1] == exp1 and got[2] == exp2
+
+
 def test_cli_drop_in(work, index11, tmp_path):
     out = str(tmp_path / "o.sam")
     subprocess.check_call([ya.CLI_PATH, "-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", out, "-FBS", "Y", "-t", "4", "-batch", "64"], stderr=subprocess.DEVNULL)
@@ -102,6 +126,10 @@ def test_cli_drop_in(work, index11, tmp_path):
     # the golden was written with -oss; redo with the matching flag
     subprocess.check_call([ya.CLI_PATH, "-x", index11, "-q", os.path.join(work, "rchim.fa"), "-oss", out, "-FBS", "Y"], stderr=subprocess.DEVNULL)
     assert strip_pg(open(out).read()) == ref
+    # one context per GPU and three give the same output as the default two (batch tickets order the output)
+    for nctx in ("1", "3"):
+        subprocess.check_call([ya.CLI_PATH, "-x", index11, "-q", os.path.join(work, "rchim.fa"), "-oss", out, "-FBS", "Y", "-ctx", nctx, "-batch", "50"], stderr=subprocess.DEVNULL)
+        assert strip_pg(open(out).read()) == ref
     assert len(mine) == len(ref)
 
 
