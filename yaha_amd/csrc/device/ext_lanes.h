@@ -33,6 +33,7 @@ struct ExtArgs {
     DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
     const ExtProb *probs; uint32_t nProb; const unsigned long long *stripOff; unsigned long long stripBase;
     const uint32_t *order;                      // problem indices in processing order (longest bound first), or nullptr
+    unsigned long long *clock;                  // optional: [0] = earliest start, [1] = latest end of the launch in wall_clock64() ticks (100 MHz)
     uint32_t *trace;                            // 128-byte blocks of 10 rows (3 dwords each, 2 dwords of padding); stripOff counts blocks
     ExtRes *res; unsigned int *queue; DevCounters *ctr;      // ctr == nullptr: the consumer of the results accounts for the work (careful extensions)
     int *errFlag;
@@ -46,6 +47,7 @@ template <bool CAPS, bool SECOND>
 __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
 {
     __shared__ uint32_t sBlk[32][256];          // per lane: the current 10-row trace block, [dword][thread] (conflict-free for any row slot)
+    if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());
     const int lane = laneId();
     const int GO = A.P.GO, GE = A.P.GE, GOE = A.P.GO + A.P.GE, RC = A.P.RC, MS = A.P.MS, XC = A.P.X, maxIntron = A.P.maxIntron, maxGap = A.P.maxGap;
     constexpr int bandwidth = YD_LBAND, leftR = YD_LBAND;
@@ -223,6 +225,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.rows = pendRows; r.cells = pendCells;
         A.res[pendRes] = r;
     }
+    if (!SECOND && A.clock && lane == 0) atomicMax(&A.clock[1], (unsigned long long)wall_clock64());
     // work counters
     unsigned c0 = (unsigned)waveSumI((int)calls), c1 = (unsigned)waveSumI((int)rows);
     unsigned long long cc = cells;

@@ -45,8 +45,8 @@ struct DevBuf {
 };
 enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_N = 24 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
-enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_N };
-const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split"};
+enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_N };
+const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split", "ext_rows_device_clock"};
 }  // namespace
 
 struct ygpu_ctx {
@@ -61,7 +61,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -323,6 +323,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     TRACE("lanes: ensure trace");
     if (kTrace) fprintf(stderr, "[ygpu] trace blocks %llu budget %llu chunks %zu %s\n", totalRows, budget, nChunks, fits ? "(pipelined)" : "(sequential, one buffer)");
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
+    ENSURE(ctx->rowsClock, 16); { const unsigned long long init[2] = {~0ull, 0ull}; HIPCHK(hipMemcpyAsync(ctx->rowsClock.p, init, 16, hipMemcpyHostToDevice, ctx->stream)); }
+    E.clock = ctx->rowsClock.as<unsigned long long>();
     E.trace = ctx->extTrace.as<uint32_t>(); E.ctr = ctx->ctr.as<DevCounters>(); E.errFlag = ctx->errFlag.as<int>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
     auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
@@ -408,6 +410,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         if (!overlap) TRACE("lanes: p3");
     }
     if (overlap) { HIPCHK(hipEventRecord(ctx->evTail, sTail)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0)); }
+    HIPCHK(hipMemcpyAsync(ctx->hRowsClock, ctx->rowsClock.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     TRACE("lanes: chunks done");
     return 0;
 }
@@ -570,7 +573,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
+                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         for (int i = 0; i < YD_MAX_CHUNK_EV; i++) hipEventDestroy(ctx->evChunk[i]);
@@ -619,6 +622,7 @@ int ygpu_run(ygpu_ctx *ctx)
     ctx->totalMs = 0;
     for (int t = 0; t < T_N; t++) {
         float m = 0; ctx->ms[t] = (ctx->evUsed[t] && hipEventElapsedTime(&m, ctx->ev[t][0], ctx->ev[t][1]) == hipSuccess) ? m : 0;
+        if (t == T_XROWS_DEV) ctx->ms[t] = (ctx->evUsed[T_XROWS] && ctx->hRowsClock[1] > ctx->hRowsClock[0] && ctx->hRowsClock[0] != ~0ull) ? (float)((double)(ctx->hRowsClock[1] - ctx->hRowsClock[0]) / 1.0e5) : 0;   // 100 MHz ticks -> ms
         if (t < T_TOP) ctx->totalMs += ctx->ms[t];
     }
     return 0;
