@@ -1,9 +1,16 @@
+"""End-to-end timing of the yaha command line on the bench genome (run on the GPU box after bench.py has built the cache)."""
 import subprocess, time, sys, os
-R="/tmp/yaha_bench_cache/g100m_n16384_l1000_s1000.fa"; X="/tmp/yaha_bench_cache/g100m_s42.X15_01_65525S"
-outs=[]
-for t in (8, 32, 64):
-    o="/tmp/out_%d.sam"%t; s=time.time()
-    subprocess.run([os.path.join(os.environ["GRAFT_REPO_ROOT"],"yaha_amd/csrc/yaha"),"-x",X,"-q",R,"-osh",o,"-t",str(t),"-batch","8192"],stderr=subprocess.DEVNULL,check=True)
-    dt=time.time()-s; print("t=%d wall %.2f s -> %.0f reads/s end to end (incl. index mmap+upload)"%(t,dt,16384/dt)); outs.append(o)
-a=[l for l in open(outs[0]) if not l.startswith("@PG")]; b=[l for l in open(outs[2]) if not l.startswith("@PG")]
-print("identical minus @PG:", a==b, len(a))
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+X = "/tmp/yaha_bench_cache/g100m_s42.X15_01_65525S"; G = "/tmp/yaha_bench_cache/g100m_s42.fa"
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+R = "/tmp/yaha_bench_cache/cli_reads_%d.fa" % N
+if not os.path.exists(R):
+    subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome", G, "--out", R, "--seed", "77", "--n", str(N), "--len", "1000", "--div", "0.017"])
+outs = []
+for extra in (["-t", "64", "-ctx", "2", "-batch", "16384"], ["-t", "64", "-ctx", "1", "-batch", "16384"], ["-t", "8", "-ctx", "2", "-batch", "16384"]):
+    o = "/tmp/out_%d.sam" % len(outs); s = time.time()
+    subprocess.run([os.path.join(root, "yaha_amd/csrc/yaha"), "-x", X, "-q", R, "-osh", o] + extra, stderr=subprocess.DEVNULL, check=True)
+    dt = time.time() - s; print(" ".join(extra), ": wall %.2f s -> %.0f reads/s end to end (process start, index mmap + upload included)" % (dt, N / dt)); outs.append(o)
+a = [l for l in open(outs[0]) if not l.startswith("@PG")]
+for o in outs[1:]:
+    print("identical minus @PG:", a == [l for l in open(o) if not l.startswith("@PG")])

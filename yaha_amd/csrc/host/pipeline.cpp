@@ -7,6 +7,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <thread>
+#include <chrono>
 #include <atomic>
 #include <mutex>
 #include <condition_variable>
@@ -131,13 +132,18 @@ int runQueries(Args &a, FILE *log)
     };
     auto worker = [&](int d) {
         yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs; local.genome.maxROff = S->genome.maxROff;
-        Batch b;
-        while (readBatch(b)) {
+        Batch b; const bool timing = getenv("YAHA_TIMING") != nullptr;
+        auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (;;) {
+            const double t0 = now();
+            if (!readBatch(b)) break;
+            const double t1 = now();
             ygpu_read_batch rb{(uint32_t)b.reads.size(), b.codes.data(), b.offsets.data()}; ygpu_result_batch res;
-            int rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc == 0) rc = ygpu_collect(ctx[d], &res);
+            int rc = ygpu_upload(ctx[d], &rb); const double t2 = now(); if (rc == 0) rc = ygpu_run(ctx[d]); const double t3 = now(); if (rc == 0) rc = ygpu_collect(ctx[d], &res); const double t4 = now();
             std::string text;
             if (rc != 0) { fprintf(log, "device %d: hot path failed (%d): %s\n", d, rc, ygpu_last_error(ctx[d])); rcAll = 1; }
             else { local.reads.swap(b.reads); formatBatch(&local, &res, text); local.reads.swap(b.reads); }
+            if (timing) fprintf(stderr, "[yaha] ctx %d ticket %llu: %zu reads  read %.1f  upload %.1f  device %.1f  collect %.1f  format %.1f ms\n", d, (unsigned long long)b.ticket, b.reads.size(), t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
             std::unique_lock<std::mutex> lk(outMu);
             done[b.ticket] = std::move(text);
             while (!done.empty() && done.begin()->first == nextOut) { fputs(done.begin()->second.c_str(), out); done.erase(done.begin()); nextOut++; }
