@@ -7,7 +7,7 @@ R = "/tmp/yaha_bench_cache/cli_reads_%d.fa" % N
 if not os.path.exists(R):
     subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome", G, "--out", R, "--seed", "77", "--n", str(N), "--len", "1000", "--div", "0.017"])
 outs = []
-for extra in (["-t", "64", "-ctx", "2", "-batch", "16384"], ["-t", "64", "-ctx", "1", "-batch", "16384"], ["-t", "8", "-ctx", "2", "-batch", "16384"]):
+for extra in (["-t", "16", "-ctx", "2"], ["-t", "16", "-ctx", "1"], ["-t", "16", "-ctx", "2", "-batch", "16384"]):
     o = "/tmp/out_%d.sam" % len(outs); s = time.time()
     subprocess.run([os.path.join(root, "yaha_amd/csrc/yaha"), "-x", X, "-q", R, "-osh", o] + extra, stderr=subprocess.DEVNULL, check=True)
     dt = time.time() - s; print(" ".join(extra), ": wall %.2f s -> %.0f reads/s end to end (process start, index mmap + upload included)" % (dt, N / dt)); outs.append(o)

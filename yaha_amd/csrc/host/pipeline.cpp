@@ -121,14 +121,19 @@ int runQueries(Args &a, FILE *log)
     std::mutex rdMu, outMu; std::condition_variable outCv; uint64_t nextTicket = 0, nextOut = 0; bool eof = false; int rcAll = 0;
     std::map<uint64_t, std::string> done;
     auto readBatch = [&](Batch &b) -> bool {
-        std::lock_guard<std::mutex> lk(rdMu);
-        if (eof) return false;
-        b.reads.clear(); b.codes.clear(); b.offsets.assign(1, 0);
-        Read r;
-        while ((int)b.reads.size() < A.batchReads && S->reader.next(r)) { b.codes.insert(b.codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); b.offsets.push_back(b.codes.size()); b.reads.push_back(std::move(r)); }
-        if ((int)b.reads.size() < A.batchReads) eof = true;
-        if (b.reads.empty()) return false;
-        b.ticket = nextTicket++; return true;
+        {   // only the text scan of the input stream is serial; code conversion and batch packing run outside the lock
+            std::lock_guard<std::mutex> lk(rdMu);
+            if (eof) return false;
+            b.reads.clear();
+            Read r;
+            while ((int)b.reads.size() < A.batchReads && S->reader.nextRaw(r)) b.reads.push_back(std::move(r));
+            if ((int)b.reads.size() < A.batchReads) eof = true;
+            if (b.reads.empty()) return false;
+            b.ticket = nextTicket++;
+        }
+        b.codes.clear(); b.offsets.assign(1, 0);
+        for (auto &r : b.reads) { ReadReader::finish(r); b.codes.insert(b.codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); b.offsets.push_back(b.codes.size()); }
+        return true;
     };
     auto worker = [&](int d) {
         yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs; local.genome.maxROff = S->genome.maxROff;

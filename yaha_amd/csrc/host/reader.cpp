@@ -22,7 +22,9 @@ void ReadReader::close() { if (f && ownFile) fclose(f); f = nullptr; }
 static void readToChar(FILE *in, char fchar, bool precNL)            // Query.c:52-61
 { char prev = 0; for (;;) { int c = getc_unlocked(in); if ((c == fchar && (!precNL || prev == '\n')) || c == EOF) return; prev = (char)c; } }
 
-bool ReadReader::next(Read &r)                                       // readNextQuery, Query.c:102-228
+// The text part of readNextQuery (Query.c:102-228): id, sequence, quality.  Serial by nature (one input stream); the code
+// conversion of the sequence (finish) is left to the caller so that it can run outside the reader lock.
+bool ReadReader::nextRaw(Read &r)
 {
     for (;;) {
         r.id.clear(); int charCount = 0;
@@ -68,14 +70,19 @@ bool ReadReader::next(Read &r)                                       // readNext
         if (n > 0 && n < wordLen) { fprintf(stderr, "Query length must be at least wordlen bases long. Query will be skipped.\n"); fail = true; }
         if (fail) continue;
         if (n == 0) return false;
-        r.fwdCodes.resize(n); r.revCodes.resize(n); r.rev.resize(n);
-        for (int k = 0; k < n; k++) {
-            uint8_t code = map8to4((unsigned char)r.fwd[k]); r.fwdCodes[k] = code;
-            uint8_t rc = kFourBitCompCodes[code]; r.revCodes[n - 1 - k] = rc; r.rev[n - 1 - k] = kFourBitChars[rc];
-        }
         return true;
     }
 }
+void ReadReader::finish(Read &r)                                     // Query.c:161-167: 4-bit codes of both strands, reverse-complement text
+{
+    const int n = (int)r.fwd.size();
+    r.fwdCodes.resize(n); r.revCodes.resize(n); r.rev.resize(n);
+    for (int k = 0; k < n; k++) {
+        uint8_t code = map8to4((unsigned char)r.fwd[k]); r.fwdCodes[k] = code;
+        uint8_t rc = kFourBitCompCodes[code]; r.revCodes[n - 1 - k] = rc; r.rev[n - 1 - k] = kFourBitChars[rc];
+    }
+}
+bool ReadReader::next(Read &r) { if (!nextRaw(r)) return false; finish(r); return true; }
 
 void seedFromRead(const Read &r, RandState &rs)                      // generateRandomSeed, QueryState.c:172-187
 {

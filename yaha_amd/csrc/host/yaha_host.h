@@ -79,7 +79,7 @@ struct Read {
 struct ReadReader {
     FILE *f = nullptr; bool fastq = false; int maxQueryLength = 32000; int wordLen = 15; bool ownFile = false;
     bool open(const char *path, std::string &err);       // peeks '>' / '@' (Query.c:63-74)
-    bool next(Read &r);                                   // readNextQuery; false at EOF
+    bool next(Read &r); bool nextRaw(Read &r); static void finish(Read &r);                                   // readNextQuery; false at EOF
     void close();
 };
 void seedFromRead(const Read &r, RandState &rs);          // generateRandomSeed
