@@ -4,20 +4,24 @@
 // These two calls per root clump are >90 % of all DP cells of the hot path, and their strip is narrow (W = 4*BW + 1 = 21
 // columns for the default -BW 5), so columns-as-lanes (dp_wave.h) leaves 2/3 of the wave idle and pays a cross-lane scan
 // per row.  Here every lane runs the reference's sequential recurrence for its own problem with the whole strip
-// (PV/PF/PI of 21 columns) in registers: no cross-lane traffic at all, the serial E/D chain is just program order, the
-// run caps (maxIntron / maxGap) are applied exactly.  Lanes pull new problems from a queue as they finish (X-drop makes
-// the lengths very uneven), one wave-aggregated atomic per refill.
+// (PV/PF[/PI] of 21 columns) in registers: no cross-lane traffic at all, the serial E/D chain is just program order, the
+// run caps (maxIntron / maxGap) are applied exactly (compiled out when they cannot bind inside 21 columns).
 //
-//   k_ext_rows   forward pass.  Per row and lane: 1 query byte, 1 reference nibble, 21 cells, one 12-byte trace row
-//                (4 bits per cell: op | E-run-continues | F-run-continues) into the problem's HBM strip.
-//   k_ext_trace  lane per problem: walks the trace (run lengths are recovered from the continue bits), two passes
-//                (count, then write into one batch-wide op arena in list order).
+//   k_ext_rows   forward pass, persistent lanes.  Per row and lane: 1 query code, 1 reference nibble, 21 cells, 12 bytes of
+//                trace (4 bits per cell: op | E-run-continues | F-run-continues).  Lanes take new problems from a per-wave
+//                pool of 64 pre-loaded problems (one atomic and one round of loads per 64), longest row bound first.
+//                Trace rows are staged in LDS and leave as whole 128-byte blocks of 10 rows; all global stores of an
+//                iteration are issued at its top.  It also stamps its own start / end time (wall_clock64) for bench.py.
+//   k_ext_trace  lane per problem: walks the 4-bit cells back to the origin (run lengths are recovered from the continue
+//                bits; the next 8 rows of a straight run are fetched together) and writes the ops INTO THE STRIP, over
+//                rows the walk has already consumed.
 //
 // The kernel is specialised for the default band (-BW 5: bandwidth 10, W = 21, origin column 10) and needs maxGap >= 10.
 // The reference's boundary insertions V(i, left - i) = -(GO + i*GE) are not special-cased: with PF(0, left) = -GO the
 // ordinary F recurrence produces exactly that chain (F = -(GO + i*GE), I = i, op I), and every cell left of it stays at
-// the "worst" sentinel, so all 21 columns run the same code on every row.  Cells outside [startCol, endCol] are only
-// masked out of the row maximum.  Wider bands, and all gap-fill and "careful" calls, stay on dp_wave.h.
+// the "worst" sentinel, so all 21 columns run the same code on every row.  Only the columns left of the origin have to be
+// kept out of the row maximum, and only in the first rows; the right edge is always inside the band (rLen = qLen + 2*BW).
+// Other bands, and all gap-fill calls, are elsewhere (align.h / dp_wave.h, phase_lanes.h).
 #pragma once
 #include "align.h"
 

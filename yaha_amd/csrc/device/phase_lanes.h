@@ -5,13 +5,16 @@
 //     k_p1_joints      lane per root: the exact-match extensions of every joint, then the joint's gap is classified:
 //                      nothing / one D, I or R op / pure diagonal (see below) / a DP problem (sort key = strip width, rows)
 //     [radix sort of the DP joints by size, so that the lanes of a wave run problems of the same shape]
-//     k_gap_lanes      lane per DP joint: gapDPLane (the sequential recurrence, strip state in LDS)
+//     k_gap_lanes<GW>  lane per DP joint: gapDPLane (the sequential recurrence, strip state and both sequences in LDS)
 //     k_gap_wave       wave per DP joint for the few that exceed gapDPLane's limits (dp_wave.h)
 //     k_p1_assemble    lane per root: edit list = M ops + joint ops, the clump's exact-match end extensions, the two
 //                      X-drop extension problems for k_ext_rows
 //   phase 3 = the tail of extendClumpForwardReverse + scoreClump / splitClump (AlignExtFrag.cpp:112-141, AlignHelpers.c:302-579)
-//     k_p3_lanes       lane per root: merge the extension results, scoreClump; accepted clumps are written by their lane
-//     k_align_p3       wave per root for the roots that need splitClump (align.h state machine)
+//     k_p3_lanes       lane per root: merge the extension results, scoreClump; accepted clumps are written by their lane;
+//                      for a root that needs splitClump the careful extensions it will ask for are listed (predictCarefulDPs)
+//     [second k_ext_rows / k_ext_trace round on those problems]
+//     k_split_lanes    (split_lanes.h) lane per split root: the splitClump state machine on the stored results
+//     k_align_p3       wave per root (align.h state machine) for whatever k_split_lanes gives back
 //
 // "Pure diagonal": an equal-length gap of g bases whose diagonal has mm mismatches needs no DP when
 //     mm * (MS + RC) <= MS + 2 * (GO + GE):

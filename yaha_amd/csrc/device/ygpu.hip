@@ -1,6 +1,6 @@
 // ygpu.hip -- device context, stage orchestration and the C-ABI of include/yaha_hip.h.
 //
-// HBM layout per context (one per GPU; reads shard across GPUs, index replicated, no collective):
+// HBM layout per context (one or more per GPU -- ygpu_clone shares the index image; reads shard across contexts and GPUs, no collective):
 //   index   : packed 4-bit reference, startingOffs[4^L+1], ROA[totalMatches]           (resident for the whole run)
 //   batch   : forward + reverse-complement codes (1 B/base), read offsets, k-mer offsets
 //   stage arenas, grown on demand and reused across batches:
@@ -8,7 +8,9 @@
 //     A2  64-bit hit keys (double buffer for the radix sort) -> fragment array (16 B each)
 //     A3  region starts, multi-fragment region list
 //     A4  clump records + clump fragment lists (atomic arenas), per-region counts -> creation-order ranks
-//     A5-8 per-wave scratch (trace strip, DP temp list, frame stack with edit-list buffers), output arenas
+//     A5-8 default band: joint records + gap-op arena, root states + phase-1 lists, extension problems / results, extension trace
+//          strips (128 B per 10 rows, sized by row bound; the extension ops are written into them), split-root scratch;
+//          general path and leftovers: per-wave scratch (trace strip, DP temp list, frame stack with edit-list buffers); output arenas
 //   results : clump records in QS->clumps order, ops arena, clump_start per read
 // Every stage is a handful of launches on one stream; sizes that the next stage needs cross the PCIe as single words.
 #include <hip/hip_runtime.h>
