@@ -94,6 +94,17 @@ def test_lane_pipeline_parameter_corners(work, index11, reads, extra, tmp_path):
         assert mine == strip_pg(open(ref_out).read())
 
 
+@pytest.mark.parametrize("budget", ["3000", "40000"])
+def test_trace_memory_chunks(work, index11, meta, budget, monkeypatch):
+    # When the extension trace strips of a batch do not fit in device memory the roots are processed in chunks that reuse one
+    # buffer (long reads, big batches).  YGPU_TRACE_BUDGET_BLOCKS (read at ygpu_init) forces that path on small inputs.
+    monkeypatch.setenv("YGPU_TRACE_BUDGET_BLOCKS", budget)
+    for name in ("r10k_default", "rchim_default", "r1k_default"):
+        run = meta["runs"][name]
+        mine = device_pipeline(index11, os.path.join(work, run["reads"]), run["oflag"], run["extra"], batch=400)
+        assert mine == golden_lines(name), "chunked trace path differs from the reference on " + name
+
+
 def test_two_contexts_in_flight_match_one(work, index11):
     # ygpu_clone: a second context on the same device sharing the index image; two host threads step them concurrently
     import threading

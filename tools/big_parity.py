@@ -1,0 +1,21 @@
+"""One-off validation at the bench workload's scale: the whole `yaha` command line of this repo against the real reference binary
+(oracle/_ref/yaha) on the bench genome (100 Mbp, -L 15) -- SAM identical minus @PG.  Run on the GPU box after bench.py built the cache."""
+import os, subprocess, sys, time
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+X = "/tmp/yaha_bench_cache/g100m_s42.X15_01_65525S"; G = "/tmp/yaha_bench_cache/g100m_s42.fa"
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+for tag, extra in (("1kbp", ["--len", "1000", "--div", "0.017", "--chimeric", "0.05"]), ("10kbp", ["--len", "10000", "--div", "0.034"]), ("150bp", ["--len", "150", "--div", "0.01"])):
+    n = N if tag == "1kbp" else (N // 16 if tag == "10kbp" else N * 2)
+    R = "/tmp/yaha_bench_cache/parity_%s_%d.fa" % (tag, n)
+    subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome", G, "--out", R, "--seed", "4242", "--n", str(n)] + extra)
+    t = time.time(); subprocess.run([os.path.join(root, "oracle/_ref/yaha"), "-x", X, "-q", R, "-osh", "/tmp/ref.sam", "-t", "256"], stderr=subprocess.DEVNULL, check=True); tr = time.time() - t
+    t = time.time(); subprocess.run([os.path.join(root, "yaha_amd/csrc/yaha"), "-x", X, "-q", R, "-osh", "/tmp/mine.sam", "-t", "32"], stderr=subprocess.DEVNULL, check=True); tm = time.time() - t
+    a = [l for l in open("/tmp/ref.sam") if not l.startswith("@PG")]; b = [l for l in open("/tmp/mine.sam") if not l.startswith("@PG")]
+    # the reference writes reads in thread-completion order with -t > 1 (Query.c:457-466): compare the header in order, the records as a multiset
+    ha, hb = [l for l in a if l.startswith("@")], [l for l in b if l.startswith("@")]
+    a, b = sorted(l for l in a if not l.startswith("@")), sorted(l for l in b if not l.startswith("@"))
+    print("%s: %d reads, %d SAM records, header identical=%s, records identical (as a multiset)=%s   reference %.1f s (256 threads), this repo %.1f s" % (tag, n, len(a), ha == hb, a == b, tr, tm))
+    if a != b:
+        print("records only in one of them:", len(set(a) ^ set(b)))
+        for k, (u, v) in enumerate(zip(a, b)):
+            if u != v: print("first difference at line", k, "\n ref :", u[:300], "\n mine:", v[:300]); break

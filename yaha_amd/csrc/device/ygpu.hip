@@ -63,7 +63,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -298,7 +298,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     // stream) overlaps the latency-bound tail of chunk c (traceback, scoreClump/emit, splitClump waves; second stream).  When
     // the strips do not fit in memory the chunks reuse one buffer and run back to back instead.
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
-    const unsigned long long budget = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB + ctx->extTrace.cap) * 7 / 10) / 128ull);
+    unsigned long long budget = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB + ctx->extTrace.cap) * 7 / 10) / 128ull);
+    if (ctx->traceBudgetBlocks > 0) budget = (unsigned long long)ctx->traceBudgetBlocks;     // test hook: force the chunked path
     std::vector<uint32_t> cuts; cuts.push_back(0);                            // root indices
     const bool fits = totalRows <= budget;
     if (fits) {
@@ -320,8 +321,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     if (fits) chunkMax = totalRows; else for (size_t c = 0; c < nChunks; c++) chunkMax = std::max(chunkMax, ctx->hStripOff[2 * (size_t)cuts[c + 1]] - ctx->hStripOff[2 * (size_t)cuts[c]]);
     TRACE("lanes: cuts");
     ENSURE(ctx->extTrace, 128ull * chunkMax + 256);
-    ENSURE(ctx->chunkCnt, 16ull * (nChunks + 1));
-    HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 16ull * (nChunks + 1), ctx->stream));
+    ENSURE(ctx->chunkCnt, 32ull * (nChunks + 1));                            // 8 words per chunk: queues and counts of its kernels
+    HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 32ull * (nChunks + 1), ctx->stream));
     TRACE("lanes: ensure trace");
     if (kTrace) fprintf(stderr, "[ygpu] trace blocks %llu budget %llu chunks %zu %s\n", totalRows, budget, nChunks, fits ? "(pipelined)" : "(sequential, one buffer)");
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
@@ -341,7 +342,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         const uint32_t r0 = cuts[c], r1 = cuts[c + 1], p0 = 2 * r0, np = 2 * (r1 - r0);
         const unsigned long long sb = fits ? 0ull : ctx->hStripOff[p0];
         E.probs = ctx->extProbs.as<ExtProb>() + p0; E.nProb = np; E.stripOff = ctx->stripOff.as<unsigned long long>() + p0; E.stripBase = sb; E.res = ctx->extRes.as<ExtRes>() + p0;
-        E.queue = cc + 4 * c;
+        E.queue = cc + 8 * c;
         {   // longest bound first: the launch's drain phase is then left with short problems only
             size_t bytes = 0; uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 17, ctx->stream));
@@ -360,8 +361,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(np, 256)), dim3(256), 0, sTail, E);
         if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_XTRACE][1], sTail);
         if (!overlap) TRACE("lanes: ext_trace");
-        AlignArgs Ac = A; Ac.nRoots = r1; Ac.queueHead = cc + 4 * c + 1;
-        PhaseArgs Xc = X; Xc.stripBase = sb; Xc.rootBegin = r0; Xc.slowList = ctx->slowList.as<uint32_t>() + r0; Xc.slowCount = cc + 4 * c + 2; Xc.useList = 1;
+        AlignArgs Ac = A; Ac.nRoots = r1; Ac.queueHead = cc + 8 * c + 1;
+        PhaseArgs Xc = X; Xc.stripBase = sb; Xc.rootBegin = r0; Xc.slowList = ctx->slowList.as<uint32_t>() + r0; Xc.slowCount = cc + 8 * c + 2; Xc.useList = 1;
         if (c == 0) { ctx->evUsed[T_P3] = true; hipEventRecord(ctx->ev[T_P3][0], sTail); }
         const uint32_t nr = r1 - r0, cap2 = nr / 4 + 1024;
         if (ctx->splitLanes) {
@@ -509,6 +510,7 @@ static int initCommon(ygpu_ctx *ctx, int device)
     for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evTail, hipEventDisableTiming));
     if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
+    if (const char *e = getenv("YGPU_TRACE_BUDGET_BLOCKS")) ctx->traceBudgetBlocks = atoll(e);
     if (const char *e = getenv("YGPU_SEG_SORT")) ctx->segSort = atoi(e);
     if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
     if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
