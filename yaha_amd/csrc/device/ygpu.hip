@@ -299,6 +299,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     // the strips do not fit in memory the chunks reuse one buffer and run back to back instead.
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
     unsigned long long budget = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB + ctx->extTrace.cap) * 7 / 10) / 128ull);
+    budget = std::min<unsigned long long>(budget, (96ull << 30) / 128ull);    // at most 96 GB of strips per context: leaves room for a second context, bounds the first-use allocation
     if (ctx->traceBudgetBlocks > 0) budget = (unsigned long long)ctx->traceBudgetBlocks;     // test hook: force the chunked path
     std::vector<uint32_t> cuts; cuts.push_back(0);                            // root indices
     const bool fits = totalRows <= budget;
