@@ -4,9 +4,12 @@ import os, subprocess, sys, time
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
 X = "/tmp/yaha_bench_cache/g100m_s42.X15_01_65525S"; G = "/tmp/yaha_bench_cache/g100m_s42.fa"
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-for tag, extra in (("1kbp", ["--len", "1000", "--div", "0.017", "--chimeric", "0.05"]), ("10kbp", ["--len", "10000", "--div", "0.034"]), ("150bp", ["--len", "150", "--div", "0.01"])):
-    n = N if tag == "1kbp" else (N // 16 if tag == "10kbp" else N * 2)
-    R = "/tmp/yaha_bench_cache/parity_%s_%d.fa" % (tag, n)
+SETS = (("1kbp", ["--len", "1000", "--div", "0.017", "--chimeric", "0.05"], 1.0), ("10kbp", ["--len", "10000", "--div", "0.034"], 1 / 16), ("150bp", ["--len", "150", "--div", "0.01"], 2.0),
+        ("fastq_N_edges_jitter", ["--len", "800", "--div", "0.05", "--fastq", "--withN", "0.3", "--edges", "--len-jitter", "700", "--chimeric", "0.1"], 0.25),
+        ("30kbp", ["--len", "30000", "--div", "0.034", "--chimeric", "0.3"], 1 / 128))
+for tag, extra, frac in SETS:
+    n = max(16, int(N * frac))
+    R = "/tmp/yaha_bench_cache/parity_%s_%d.%s" % (tag, n, "fq" if "--fastq" in extra else "fa")
     subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome", G, "--out", R, "--seed", "4242", "--n", str(n)] + extra)
     t = time.time(); subprocess.run([os.path.join(root, "oracle/_ref/yaha"), "-x", X, "-q", R, "-osh", "/tmp/ref.sam", "-t", "256"], stderr=subprocess.DEVNULL, check=True); tr = time.time() - t
     t = time.time(); subprocess.run([os.path.join(root, "yaha_amd/csrc/yaha"), "-x", X, "-q", R, "-osh", "/tmp/mine.sam", "-t", "32"], stderr=subprocess.DEVNULL, check=True); tm = time.time() - t
