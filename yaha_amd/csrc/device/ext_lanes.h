@@ -25,6 +25,7 @@
 #pragma once
 #include "align.h"
 
+#define YD_REFILL_MIN 4                        // idle lanes of a wave before it runs a refill pass
 #define YD_LW 21                               // register columns of the lane kernel = strip width for -BW 5
 #define YD_LWORST (-(1 << 28))                 // sentinel: far below any reachable score (|score| < 2^23), no overflow when it decays
 
@@ -78,11 +79,14 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     // deferred stores (see the row code)
     bool pendFlush = false; YD_GLOBAL uint32_t *pendBlk = toGlobal(A.trace); int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pCells = 0;
 
+    bool firstFill = true;
     for (;;) {
         // ---- refill: until every lane is busy or nothing is left ----
         for (;;) {
             const unsigned long long need = __ballot(p < 0 && !done);
             if (!need) break;
+            // a refill pass costs ~100 wave instructions whatever the number of lanes it serves: wait until a few are idle
+            if (__builtin_popcountll(need) < YD_REFILL_MIN && __ballot(p >= 0) != 0ull && !firstFill) break;
             if (poolNext >= poolCount) {                                     // wave-uniform: claim and set up the next 64 problems
                 unsigned base = 0;
                 if (!exhausted) { if (lane == 0) base = atomicAdd(A.queue, 64u); base = uniU(base); if (base >= A.nProb) exhausted = true; }
@@ -144,6 +148,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             }
             poolNext += nNeed < avail ? nNeed : avail;
         }
+        firstFill = false;
         if (__ballot(p >= 0) == 0ull) break;
 
         // ---- one DP row in every lane (lanes without a problem run on idle state; their stores are masked) ----
