@@ -10,7 +10,7 @@
 //   k_ext_rows   forward pass, persistent lanes.  Per row and lane: 1 query code, 1 reference nibble, 21 cells, 12 bytes of
 //                trace (4 bits per cell: op | E-run-continues | F-run-continues).  Lanes take new problems from a per-wave
 //                pool of 64 pre-loaded problems (one atomic and one round of loads per 64), longest row bound first.
-//                Trace rows are staged in LDS and leave as whole 128-byte blocks of 8 rows; all global stores of an
+//                Trace rows are staged in LDS and leave as whole 128-byte blocks of 10 rows; all global stores of an
 //                iteration are issued at its top.  It also stamps its own start / end time (wall_clock64) for bench.py.
 //   k_ext_trace  lane per problem: walks the 4-bit cells back to the origin (run lengths are recovered from the continue
 //                bits; the next 8 rows of a straight run are fetched together) and writes the ops INTO THE STRIP, over
@@ -39,7 +39,7 @@ struct ExtArgs {
     const ExtProb *probs; uint32_t nProb; const unsigned long long *stripOff; unsigned long long stripBase;
     const uint32_t *order;                      // problem indices in processing order (longest bound first), or nullptr
     unsigned long long *clock;                  // optional: [0] = earliest start, [1] = latest end of the launch in wall_clock64() ticks (100 MHz)
-    uint32_t *trace;                            // 128-byte blocks of 8 rows (16 bytes each); stripOff counts blocks
+    uint32_t *trace;                            // 128-byte blocks of 10 rows (3 dwords each, 2 dwords of padding); stripOff counts blocks
     ExtRes *res; unsigned int *queue; DevCounters *ctr;      // ctr == nullptr: the consumer of the results accounts for the work (careful extensions)
     int *errFlag;
 };
@@ -51,7 +51,8 @@ struct ExtArgs {
 template <bool CAPS, bool SECOND>
 __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
 {
-    __shared__ uint32_t sBlk[32][256];          // per lane: the current 8-row trace block, [dword][thread] (conflict-free for any row slot)
+    __shared__ uint32_t sBlk[32][256];          // per lane: the current 10-row trace block, [dword][thread] (conflict-free for any row slot)
+    __shared__ uint32_t sList[4][3][64];        // per wave: the blocks to write out (owner thread, destination)
     if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());
     const int lane = laneId();
     const int GO = A.P.GO, GE = A.P.GE, GOE = A.P.GO + A.P.GE, RC = A.P.RC, MS = A.P.MS, XC = A.P.X, maxIntron = A.P.maxIntron, maxGap = A.P.maxGap;
@@ -79,6 +80,32 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     // deferred stores (see the row code)
     bool pendFlush = false; YD_GLOBAL uint32_t *pendBlk = toGlobal(A.trace); int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pCells = 0;
 
+    // Finished blocks leave the wave together: the lanes that have one list it in LDS, then eight lanes write each block, 16 bytes apiece, so
+    // that a store instruction carries whole 128-byte lines (a lane writing its own block alone sends eight 16-byte pieces in eight instructions).
+    auto flushBlocks = [&]() {
+        const unsigned long long f = __ballot(pendFlush);
+        const int n = __builtin_popcountll(f);
+        if (n == 0) return;
+        const int tid = (int)threadIdx.x, wv = tid >> 6;
+        if (pendFlush) {
+            const int r = __builtin_popcountll(f & lanesBelow); const unsigned long long a = (unsigned long long)pendBlk;
+            sList[wv][0][r] = (uint32_t)tid; sList[wv][1][r] = (uint32_t)a; sList[wv][2][r] = (uint32_t)(a >> 32);
+            pendFlush = false;
+        }
+        __builtin_amdgcn_wave_barrier();                                     // LDS operations of a wave execute in order; keep the compiler from moving them
+        const uint32_t *flat = &sBlk[0][0];
+        const int piece = lane & 7;
+        for (int g0 = 0; g0 * 8 < n; g0 += 2) {                              // two groups of eight blocks per pass: their LDS reads overlap
+            uint32_t b[2]; unsigned long long a[2]; yd_u32x4 v[2]; bool on[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) { const int e = (g0 + t) * 8 + (lane >> 3); on[t] = e < n; const int ee = on[t] ? e : 0; b[t] = sList[wv][0][ee]; a[t] = (unsigned long long)sList[wv][1][ee] | ((unsigned long long)sList[wv][2][ee] << 32); }
+#pragma unroll
+            for (int t = 0; t < 2; t++) { v[t].x = flat[b[t] + (piece * 4 + 0) * 256]; v[t].y = flat[b[t] + (piece * 4 + 1) * 256]; v[t].z = flat[b[t] + (piece * 4 + 2) * 256]; v[t].w = flat[b[t] + (piece * 4 + 3) * 256]; }
+#pragma unroll
+            for (int t = 0; t < 2; t++) if (on[t]) *(YD_GLOBAL yd_u32x4 *)((YD_GLOBAL uint32_t *)a[t] + piece * 4) = v[t];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     bool firstFill = true;
     for (;;) {
         // ---- refill: until every lane is busy or nothing is left ----
@@ -155,15 +182,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         // All memory operations of an iteration are issued here at the top: the previous row's trace cells and a finished
         // problem's result (both deferred), and the loads the row needs at its END (next query base, next reference base).
         // The wait the compiler puts at the loop header then finds them ~1000 instructions old.
-        if (pendFlush) {                                                     // a finished 8-row block (or a problem's last, partial one): LDS -> one 128-byte line
-            const int tid = (int)threadIdx.x;
-#pragma unroll
-            for (int d = 0; d < 32; d += 4) {
-                yd_u32x4 v; v.x = sBlk[d][tid]; v.y = sBlk[d + 1][tid]; v.z = sBlk[d + 2][tid]; v.w = sBlk[d + 3][tid];
-                *(YD_GLOBAL yd_u32x4 *)(pendBlk + d) = v;
-            }
-            pendFlush = false;
-        }
+        flushBlocks();                                                       // deferred from the previous row
         if (pendRes >= 0) {
             ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.rows = pendRows; r.cells = pendCells;
             A.res[pendRes] = r; pendRes = -1;
@@ -210,7 +229,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             dV = upV;                                                        // the next column's diagonal predecessor
             __builtin_amdgcn_sched_barrier(0);                               // keep the cells in program order: their many condition masks stay short-lived
         }
-        { const int slot = ((i - 1) & 7) * 4, tid = (int)threadIdx.x;       // this row's cells go to the lane's LDS block (16-byte rows)
+        { const int slot = ((i - 1) % 10) * 3, tid = (int)threadIdx.x;      // this row's cells go to the lane's LDS block
           sBlk[slot][tid] = t0; sBlk[slot + 1][tid] = t1; sBlk[slot + 2][tid] = t2; }
         int rv = YD_LWORST, rj = 0;
         if (rowKey) { rv = (int)(rowKey >> 5) - YD_BIAS; rj = 31 - (int)(rowKey & 31u); }
@@ -219,17 +238,14 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         const uint32_t nb = nbOdd == 2u ? 15u : (nbOdd ? (nbByte & 15u) : (nbByte >> 4));
         w0 = (w0 >> 4) | (w1 << 28); w1 = (w1 >> 4) | (w2 << 28); w2 = (w2 >> 4) | (nb << 16);
         const bool fin = busy && (rv < maxScore - XC || i >= qLen);
-        if (busy && (fin || (i & 7) == 0)) { pendFlush = true; pendBlk = strip + (size_t)((i - 1) >> 3) * 32u; }
+        if (busy && (fin || i % 10 == 0)) { pendFlush = true; pendBlk = strip + (size_t)((i - 1) / 10) * 32u; }
         if (fin) {
             pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i; pendCells = pCells;
             p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
         }
     }
     // the last deferred stores
-    if (pendFlush) {
-        const int tid = (int)threadIdx.x;
-        for (int d = 0; d < 32; d += 4) { yd_u32x4 v; v.x = sBlk[d][tid]; v.y = sBlk[d + 1][tid]; v.z = sBlk[d + 2][tid]; v.w = sBlk[d + 3][tid]; *(YD_GLOBAL yd_u32x4 *)(pendBlk + d) = v; }
-    }
+    flushBlocks();
     if (pendRes >= 0) {
         ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.rows = pendRows; r.cells = pendCells;
         A.res[pendRes] = r;
@@ -248,21 +264,10 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
 }
 
 // ---- traceback, lane per problem (SW.cpp:1138-1195) -----------------------------------------------------------------
-// Two cell formats.  k_ext_rows: 4 bits per cell, 8 cells per dword: op | E-run continues << 2 | F-run continues << 3.
-// k_ext_rows16 (ext_lanes16.h): 5 bits per cell, 3 cells per halfword, first cell highest: bit0 = E did not win, bit1 = F did not win,
-// bit2 = E-run did not continue, bit3 = F-run did not continue, bit4 = mismatch.  extCell() returns the first format's nibble for either.
-template <bool F5> __device__ __forceinline__ int extCellWord(int x) { return F5 ? (x / 3) >> 1 : x >> 3; }
-template <bool F5> __device__ __forceinline__ int extCellShift(int x) { return F5 ? ((x / 3) & 1) * 16 + (2 - x % 3) * 5 : (x & 7) * 4; }
-template <bool F5> __device__ __forceinline__ uint32_t extCell(uint32_t word, int sh)
-{
-    if (!F5) return (word >> sh) & 15u;
-    const uint32_t c = (word >> sh) & 31u;
-    const uint32_t op = !(c & 2u) ? (uint32_t)OP_I : (!(c & 1u) ? (uint32_t)OP_D : ((c & 16u) ? (uint32_t)OP_R : (uint32_t)OP_M));
-    return op | ((c & 4u) ? 0u : 4u) | ((c & 8u) ? 0u : 8u);
-}
-struct ExtRowBits { uint32_t w[4]; };
-template <bool F5> __device__ __forceinline__ uint32_t extNib(const ExtRowBits &r, int x)
-{ const int k = extCellWord<F5>(x); const uint32_t w = k == 0 ? r.w[0] : (k == 1 ? r.w[1] : (k == 2 ? r.w[2] : r.w[3])); return extCell<F5>(w, extCellShift<F5>(x)); }
+struct ExtRowBits { uint32_t a, b, c; };
+__device__ __forceinline__ ExtRowBits extLoadRow(YD_GLOBAL const uint32_t *strip, int y)
+{ ExtRowBits r; YD_GLOBAL const uint32_t *t = strip + (size_t)((y - 1) / 10) * 32u + (size_t)((y - 1) % 10) * 3u; r.a = t[0]; r.b = t[1]; r.c = t[2]; return r; }
+__device__ __forceinline__ uint32_t extNib(const ExtRowBits &r, int x) { const uint32_t w = x < 8 ? r.a : (x < 16 ? r.b : r.c); return (w >> ((x & 7) * 4)) & 15u; }
 
 // Walks from (y, x) back to the origin (0, leftR).  The ops are written INTO THE STRIP, over rows the walk has already
 // consumed: emission k (far end first) goes to dword E-1-k, E = end of row maxi+1 (the strip has one spare row).  After
@@ -270,9 +275,8 @@ template <bool F5> __device__ __forceinline__ uint32_t extNib(const ExtRowBits &
 // 3k+3 dwords are free, so the walk never overwrites a row it still has to read.  The result is the ascending array
 // strip[opsOff .. opsOff+nOps): the forward extension's list in order (ops are added to the front, SW.cpp:1186), the
 // backward extension's list reversed (added to the back, SW.cpp:1190).
-__device__ __forceinline__ int extRowWord(int y) { return (y - 1) * 4; }     // 16-byte rows, 8 to a 128-byte block
+__device__ __forceinline__ int extRowWord(int y) { return ((y - 1) / 10) * 32 + ((y - 1) % 10) * 3; }
 #define YD_TRACE_DEPTH 8
-template <bool F5>
 __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,25 +285,25 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
     if (r.score <= 0) return;
     YD_GLOBAL uint32_t *strip = toGlobal(A.trace) + (A.stripOff[p] - A.stripBase) * 32ull;
     constexpr int leftR = YD_LBAND;
-    const int E = extRowWord(r.maxi + 1) + 4;
+    const int E = extRowWord(r.maxi + 1) + 3;
     int y = r.maxi, x = r.maxj, prev = -1, acc = 0, n = 0; bool bad = false;
-    // w = word offset of row y inside the strip
-    int rr = 0, w = (y - 1) * 4;
-    auto flush = [&]() { const int wp = E - 1 - n; if (wp < w + 4) bad = true; else strip[wp] = opMake(prev, acc); n++; };   // rows above row y are consumed
+    // w = word offset of row y inside the strip, rr = its row inside the 10-row block (kept incrementally: no divisions in the loops)
+    int rr = (y - 1) % 10, w = ((y - 1) / 10) * 32 + rr * 3;
+    auto flush = [&]() { const int wp = E - 1 - n; if (wp < w + 3) bad = true; else strip[wp] = opMake(prev, acc); n++; };   // rows above row y are consumed
     auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
-    auto stepUp = [&](int &ww, int &r2) { (void)r2; ww -= 4; };                                                               // one row towards the origin
+    auto stepUp = [&](int &ww, int &r2) { if (r2 == 0) { r2 = 9; ww -= 5; } else { r2--; ww -= 3; } };                        // one row towards the origin
     // The kernel is bound by the latency of dependent loads (one per path cell).  Most of a path is straight runs of M / R cells
     // in one column, so the cells of the next YD_TRACE_DEPTH rows in column x are fetched together (one dword each) and consumed in turn.
     for (int guard = 0; guard < 70000 && y > 0 && x >= 0 && x < YD_LW; guard++) {
-        const int ws = extCellWord<F5>(x), sh = extCellShift<F5>(x);
+        const int ws = x >> 3, sh = (x & 7) * 4;
         uint32_t d[YD_TRACE_DEPTH];
         { int wk = w, rk = rr;
 #pragma unroll
           for (int k = 0; k < YD_TRACE_DEPTH; k++) { d[k] = strip[wk + ws]; if (y > k + 1) stepUp(wk, rk); } }
-        uint32_t nib = extCell<F5>(d[0], sh); int took = 0;
+        uint32_t nib = (d[0] >> sh) & 15u; int took = 0;
 #pragma unroll
         for (int k = 0; k < YD_TRACE_DEPTH; k++) {
-            nib = extCell<F5>(d[k], sh);
+            nib = (d[k] >> sh) & 15u;
             const int op = (int)(nib & 3u);
             if (op >= OP_D || y <= 0) break;
             if (prev != op) { if (prev >= 0) flush(); prev = op; acc = 1; } else acc++;
@@ -307,16 +311,16 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
         }
         if (took == YD_TRACE_DEPTH || y <= 0) continue;                                   // still in a straight run (or at the origin row)
         if ((nib & 3u) == (uint32_t)OP_D) {                                  // deletion run: walk the continue bits along the row
-            ExtRowBits rb; rb.w[0] = strip[w]; rb.w[1] = strip[w + 1]; rb.w[2] = strip[w + 2]; rb.w[3] = F5 ? strip[w + 3] : 0u;
+            ExtRowBits rb; rb.a = strip[w]; rb.b = strip[w + 1]; rb.c = strip[w + 2];
             int run = 1, xx = x;
-            while (extNib<F5>(rb, xx) & 4u) { xx--; if (xx < 0) break; run++; }
+            while (extNib(rb, xx) & 4u) { xx--; if (xx < 0) break; run++; }
             put(OP_D, run); x -= run;
         } else {                                                            // insertion run: walk the continue bits up and to the right
             int run = 1, yy = y, xx = x, ww = w, q2 = rr; uint32_t nb2 = nib;
             while (nb2 & 8u) {
                 yy--; xx++; if (yy <= 0 || xx >= YD_LW) break;
                 run++; stepUp(ww, q2);
-                nb2 = extCell<F5>(strip[ww + extCellWord<F5>(xx)], extCellShift<F5>(xx));
+                nb2 = (strip[ww + (xx >> 3)] >> ((xx & 7) * 4)) & 15u;
             }
             put(OP_I, run); for (int t = 0; t < run; t++) stepUp(w, rr); y -= run; x += run;
         }

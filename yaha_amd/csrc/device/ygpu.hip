@@ -9,7 +9,7 @@
 //     A3  region starts, multi-fragment region list
 //     A4  clump records + clump fragment lists (atomic arenas), per-region counts -> creation-order ranks
 //     A5-8 default band: joint records + gap-op arena, root states + phase-1 lists, extension problems / results, extension trace
-//          strips (128 B per 8 rows, sized by row bound; the extension ops are written into them), split-root scratch;
+//          strips (128 B per 10 rows, sized by row bound; the extension ops are written into them), split-root scratch;
 //          general path and leftovers: per-wave scratch (trace strip, DP temp list, frame stack with edit-list buffers); output arenas
 //   results : clump records in QS->clumps order, ops arena, clump_start per read
 // Every stage is a handful of launches on one stream; sizes that the next stage needs cross the PCIe as single words.
@@ -26,7 +26,6 @@
 #include "seed.h"
 #include "phase_lanes.h"
 #include "split_lanes.h"
-#include "ext_lanes16.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
 
@@ -64,7 +63,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int rows16 = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -295,7 +294,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
     if (ef == YERR_OUT) return -2;
     if (ef) return 0;                                                         // reported by the caller
-    // Trace memory: 128-byte blocks of 8 rows.  The roots are processed in chunks: k_ext_rows of chunk c+1 (VALU-bound, main
+    // Trace memory: 128-byte blocks of 10 rows.  The roots are processed in chunks: k_ext_rows of chunk c+1 (VALU-bound, main
     // stream) overlaps the latency-bound tail of chunk c (traceback, scoreClump/emit, splitClump waves; second stream).  When
     // the strips do not fit in memory the chunks reuse one buffer and run back to back instead.
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
@@ -332,13 +331,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     E.clock = ctx->rowsClock.as<unsigned long long>();
     E.trace = ctx->extTrace.as<uint32_t>(); E.ctr = ctx->ctr.as<DevCounters>(); E.errFlag = ctx->errFlag.as<int>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
-    // two problems per lane in packed 16-bit arithmetic (ext_lanes16.h) when every score of the batch fits: maxima up to MS * (longest read),
-    // real cells no lower than about -(RC + X + 2 * (GO + 21 * GE)), sentinel -16000; otherwise (or with binding run caps) the 32-bit kernel
-    const bool pk16 = ctx->rows16 && !caps && (long long)ctx->P.MS * ctx->maxQ <= 15000 && ctx->P.RC + ctx->P.X + 2 * (ctx->P.GO + 21 * ctx->P.GE) + 10 * ctx->P.MS <= 8000;
-    void (*rowsKernel)(ExtArgs) = pk16 ? k_ext_rows16<false> : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
-    void (*rowsKernel2)(ExtArgs) = pk16 ? k_ext_rows16<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
-    void (*traceKernel)(ExtArgs) = pk16 ? k_ext_trace<true> : k_ext_trace<false>;
-    const unsigned perBlock = pk16 ? 512u : 256u;                             // problems in flight per 256-thread block
+    auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
+    auto rowsKernel2 = caps ? k_ext_rows<true, true> : k_ext_rows<false, true>;
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     const bool overlap = fits && nChunks > 1;
     hipStream_t sTail = overlap ? ctx->stream2 : ctx->stream;
@@ -358,33 +352,14 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             hipLaunchKernelGGL(k_rebase_u32, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, v1, np, p0);
             E.order = v1;
         }
-        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + perBlock - 1) / perBlock, (uint64_t)ctx->nCU * perCU);
+        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + 255) / 256, (uint64_t)ctx->nCU * perCU);
         hipLaunchKernelGGL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, E);
         if (c + 1 == nChunks) EV1(T_XROWS);
-        if (ctx->rows16 == 2 && pk16) {                                       // debug: the same problems through the 32-bit kernel, results compared on the host
-            std::vector<ExtRes> a(np), b(np); std::vector<ExtProb> pr(np);
-            hipLaunchKernelGGL(traceKernel, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E);
-            HIPCHK(hipMemcpyAsync(a.data(), E.res, sizeof(ExtRes) * (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipMemcpyAsync(pr.data(), E.probs, sizeof(ExtProb) * (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
-            ExtArgs Ed = E; Ed.queue = cc + 8 * c + 6; Ed.ctr = nullptr; Ed.clock = nullptr;
-            hipLaunchKernelGGL((k_ext_rows<false, true>), dim3(blocks), dim3(256), 0, ctx->stream, Ed);
-            hipLaunchKernelGGL(k_ext_trace<false>, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, Ed);
-            HIPCHK(hipMemcpyAsync(b.data(), E.res, sizeof(ExtRes) * (size_t)np, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
-            size_t bad = 0; uint32_t maxRowsA = 0, maxRowsB = 0;
-            for (uint32_t i = 0; i < np; i++) {
-                maxRowsA = std::max(maxRowsA, a[i].rows); maxRowsB = std::max(maxRowsB, b[i].rows);
-                const bool diff = a[i].score != b[i].score || a[i].maxi != b[i].maxi || a[i].maxj != b[i].maxj || a[i].rows != b[i].rows || a[i].nOps != b[i].nOps;
-                if (diff && bad++ < 12) fprintf(stderr, "[rows16] problem %u (flags %u qLen %u rOff %u): 16-bit score %d at (%d,%d) rows %u ops %u | 32-bit score %d at (%d,%d) rows %u ops %u\n", i, pr[i].flags, pr[i].qLen, pr[i].rOff,
-                                                a[i].score, a[i].maxi, a[i].maxj, a[i].rows, a[i].nOps, b[i].score, b[i].maxi, b[i].maxj, b[i].rows, b[i].nOps);
-            }
-            fprintf(stderr, "[rows16] %u problems, %zu differ; longest run %u rows (16-bit) %u rows (32-bit)\n", np, bad, maxRowsA, maxRowsB);
-            hipLaunchKernelGGL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, (Ed.queue = cc + 8 * c + 7, Ed));      // leave the 16-bit results in place for the tail
-        }
         if (overlap) { HIPCHK(hipEventRecord(ctx->evChunk[c % YD_MAX_CHUNK_EV], ctx->stream)); HIPCHK(hipStreamWaitEvent(sTail, ctx->evChunk[c % YD_MAX_CHUNK_EV], 0)); }
         else TRACE("lanes: ext_rows");
         // the chunk's tail
         if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], sTail); }
-        hipLaunchKernelGGL(traceKernel, dim3(gridFor(np, 256)), dim3(256), 0, sTail, E);
+        hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(np, 256)), dim3(256), 0, sTail, E);
         if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_XTRACE][1], sTail);
         if (!overlap) TRACE("lanes: ext_trace");
         AlignArgs Ac = A; Ac.nRoots = r1; Ac.queueHead = cc + 8 * c + 1;
@@ -422,8 +397,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                         HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp2.p, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, sTail));
                     }
                     E2.order = ctx->vals2b.as<uint32_t>(); E2.trace = ctx->extTrace2.as<uint32_t>(); E2.res = ctx->extRes2.as<ExtRes>(); E2.queue = cc + 8 * c + 4; E2.ctr = nullptr;   // counted by k_split_lanes
-                    hipLaunchKernelGGL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + perBlock - 1) / perBlock, (uint64_t)ctx->nCU * perCU)), dim3(256), 0, sTail, E2);
-                    hipLaunchKernelGGL(traceKernel, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, E2);
+                    hipLaunchKernelGGL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, (uint64_t)ctx->nCU * perCU)), dim3(256), 0, sTail, E2);
+                    hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, E2);
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
                 SplitArgs Sx; Sx.scratch = ctx->splitScratch.as<uint8_t>(); Sx.memoKeys = ctx->memoKeys.as<uint32_t>(); Sx.memoCount = ctx->memoCount.as<unsigned int>();
@@ -539,7 +514,6 @@ static int initCommon(ygpu_ctx *ctx, int device)
     if (const char *e = getenv("YGPU_TRACE_BUDGET_BLOCKS")) ctx->traceBudgetBlocks = atoll(e);
     if (const char *e = getenv("YGPU_SEG_SORT")) ctx->segSort = atoi(e);
     if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
-    if (const char *e = getenv("YGPU_ROWS16")) ctx->rows16 = atoi(e);
     if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
