@@ -105,6 +105,19 @@ def test_trace_memory_chunks(work, index11, meta, budget, monkeypatch):
         assert mine == golden_lines(name), "chunked trace path differs from the reference on " + name
 
 
+@pytest.mark.parametrize("mode", [("1", None), ("2", "16384"), ("2", "700"), ("2", "3000")])
+def test_hit_sort_paths(work, index11, meta, mode, monkeypatch):
+    # A2's sort: library segmented sort (YGPU_SEG_SORT=1), or one workgroup per (read, strand) in size classes with the library sort for the
+    # segments above YGPU_SEGSORT_MAX hits -- lowered here so that the 10 kbp reads' segments take every class and the long-segment path.
+    monkeypatch.setenv("YGPU_SEG_SORT", mode[0])
+    if mode[1]:
+        monkeypatch.setenv("YGPU_SEGSORT_MAX", mode[1])
+    for name in ("r10k_default", "r1k_default"):
+        run = meta["runs"][name]
+        mine = device_pipeline(index11, os.path.join(work, run["reads"]), run["oflag"], run["extra"], batch=400)
+        assert mine == golden_lines(name), "hit sort path %r differs from the reference on %s" % (mode, name)
+
+
 def test_two_contexts_in_flight_match_one(work, index11):
     # ygpu_clone: a second context on the same device sharing the index image; two host threads step them concurrently
     import threading

@@ -1,0 +1,44 @@
+// segsort.h -- A2: the hits of one (read, strand) sorted inside one workgroup.
+//
+// The join of A2 (findFragmentsSort, QueryMatch.c:52-121 with the heap of QueryHeap.inl:70-134) is the multiset of hits in ascending
+// (diagonal, query offset) order.  k_expand_hits (seed.h) writes the hits of one (read, strand) -- one segment, a few thousand 64-bit keys --
+// in ascending query offset, so a STABLE sort on the 32 diagonal bits [15, 47) of the key finishes the job.  A segment of up to 16 384 keys
+// fits in a workgroup's registers and LDS: one read and one write of HBM per key instead of the library's digit passes over global memory.
+// Longer segments (repeat-rich reads) are left to hipcub::DeviceSegmentedRadixSort through begin/end arrays that are empty for all others.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocprim/block/block_load.hpp>
+#include <rocprim/block/block_store.hpp>
+#include <rocprim/block/block_radix_sort.hpp>
+#include <cstdint>
+
+#define YD_SEGSORT_MAX 16384u
+
+template <unsigned BS, unsigned IPT>
+__global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segOff, uint32_t lo, uint32_t hi)
+{
+    using Load = rocprim::block_load<unsigned long long, BS, IPT, rocprim::block_load_method::block_load_transpose>;
+    using Store = rocprim::block_store<unsigned long long, BS, IPT, rocprim::block_store_method::block_store_transpose>;
+    using Sort = rocprim::block_radix_sort<unsigned long long, BS, IPT>;
+    __shared__ union { typename Load::storage_type load; typename Store::storage_type store; typename Sort::storage_type sort; } st;
+    const uint32_t b = segOff[blockIdx.x], len = segOff[blockIdx.x + 1] - b;
+    if (len <= lo || len > hi) return;                                       // another launch's size class (or nothing to do)
+    unsigned long long keys[IPT];
+    // blocked arrangement = the order the hits were written in; the padding keys sort last and, the sort being stable, stay behind real keys with the same bits
+    Load().load(in + b, keys, len, ~0ull, st.load);
+    __syncthreads();
+    Sort().sort(keys, st.sort, 15, 47);
+    __syncthreads();
+    Store().store(out + b, keys, len, st.store);
+}
+
+// begin/end offsets for the library's segmented sort: the segments too long for k_seg_sort, every other segment empty
+__global__ void k_seg_big(const uint32_t *segOff, uint32_t nSeg, uint32_t maxLen, uint32_t *bigB, uint32_t *bigE, unsigned int *nBig)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nSeg) return;
+    const uint32_t b = segOff[s], e = segOff[s + 1];
+    const bool big = e - b > maxLen;
+    bigB[s] = big ? b : 0u; bigE[s] = big ? e : 0u;
+    if (big) atomicAdd(nBig, 1u);
+}

@@ -24,6 +24,7 @@
 #include "chain.h"
 #include "chain_lanes.h"
 #include "seed.h"
+#include "segsort.h"
 #include "phase_lanes.h"
 #include "split_lanes.h"
 
@@ -45,7 +46,7 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_N = 24 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_SEGBIG, CNT_N = 24 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_N };
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split", "ext_rows_device_clock"};
@@ -59,11 +60,12 @@ struct ygpu_ctx {
     std::vector<uint32_t> hReadOff, hKmerOff;
     DevBuf dFwd, dRev, dReadOff, dKmerOff;
     // arenas
+    DevBuf bigB, bigE;
     DevBuf posS, posC, posRsI, hitOff, keysA, keysB, segOff, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 1; int splitLanes = 1; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -137,10 +139,32 @@ static int stageSeed(ygpu_ctx *ctx)
         if (ctx->segSort) {
             ENSURE(ctx->segOff, 4ull * (2 * n + 2));
             hipLaunchKernelGGL(k_seg_offsets, dim3(gridFor(2 * n + 1, 256)), dim3(256), 0, ctx->stream, ctx->dKmerOff.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), 2 * n, ctx->segOff.as<uint32_t>());
+            if (ctx->segSort >= 2) {
+                // segments of up to 16 384 hits: one workgroup each (segsort.h), in four size classes; every launch covers all segments and a
+                // workgroup whose segment belongs to another class leaves at once
+                const unsigned long long *in = ctx->keysA.as<unsigned long long>(); unsigned long long *out = ctx->keysB.as<unsigned long long>(); const uint32_t *so = ctx->segOff.as<uint32_t>();
+                ENSURE(ctx->bigB, 4ull * (2 * n + 1)); ENSURE(ctx->bigE, 4ull * (2 * n + 1));
+                uint32_t *cntBig = ctx->counters.as<uint32_t>() + CNT_SEGBIG;
+                HIPCHK(hipMemsetAsync(cntBig, 0, 4, ctx->stream));
+                const uint32_t mx = ctx->segSortMax;                                  // YD_SEGSORT_MAX; lower only to drive the long-segment path in tests
+                hipLaunchKernelGGL(k_seg_big, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, 2 * n, mx, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), cntBig);
+                if (mx > 8192u) hipLaunchKernelGGL((k_seg_sort<1024, 16>), dim3(2 * n), dim3(1024), 0, ctx->stream, in, out, so, 8192u, std::min(mx, 16384u));
+                if (mx > 4096u) hipLaunchKernelGGL((k_seg_sort<512, 16>), dim3(2 * n), dim3(512), 0, ctx->stream, in, out, so, 4096u, std::min(mx, 8192u));
+                if (mx > 1024u) hipLaunchKernelGGL((k_seg_sort<256, 16>), dim3(2 * n), dim3(256), 0, ctx->stream, in, out, so, 1024u, std::min(mx, 4096u));
+                hipLaunchKernelGGL((k_seg_sort<128, 8>), dim3(2 * n), dim3(128), 0, ctx->stream, in, out, so, 0u, std::min(mx, 1024u));
+                uint32_t nBig = 0; rc = fetchU32(ctx, cntBig, &nBig); if (rc) return rc;
+                if (nBig) {
+                    size_t bytes = 0;
+                    HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, in, out, (int)H, (int)(2 * n), ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), 15, 47, ctx->stream));
+                    if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+                    HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, in, out, (int)H, (int)(2 * n), ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), 15, 47, ctx->stream));
+                }
+            } else {
             size_t bytes = 0;
             HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, (int)(2 * n), ctx->segOff.as<uint32_t>(), ctx->segOff.as<uint32_t>() + 1, 15, 47, ctx->stream));
             if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
             HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, (int)(2 * n), ctx->segOff.as<uint32_t>(), ctx->segOff.as<uint32_t>() + 1, 15, 47, ctx->stream));
+            }
         } else {
         int rsBits = 1; while ((1u << rsBits) < 2 * n) rsBits++;
         size_t bytes = 0;
@@ -397,7 +421,10 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                         HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp2.p, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, sTail));
                     }
                     E2.order = ctx->vals2b.as<uint32_t>(); E2.trace = ctx->extTrace2.as<uint32_t>(); E2.res = ctx->extRes2.as<ExtRes>(); E2.queue = cc + 8 * c + 4; E2.ctr = nullptr;   // counted by k_split_lanes
-                    hipLaunchKernelGGL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, (uint64_t)ctx->nCU * perCU)), dim3(256), 0, sTail, E2);
+                    {   // a small launch: a few problems per lane, so its length is set by the lanes' chains of problems, not by the chip's throughput.  One wave
+                        // per SIMD runs a row 2.4x faster than three sharing it (a lone wave issues every ~5 cycles) and gives every lane more problems to balance.
+                        const uint64_t blocks2 = ctx->rows2PerCU > 0 ? (uint64_t)ctx->rows2PerCU : (uint64_t)ctx->nCU;
+                        hipLaunchKernelGGL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, blocks2)), dim3(256), 0, sTail, E2); }
                     hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, E2);
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
@@ -513,7 +540,9 @@ static int initCommon(ygpu_ctx *ctx, int device)
     if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
     if (const char *e = getenv("YGPU_TRACE_BUDGET_BLOCKS")) ctx->traceBudgetBlocks = atoll(e);
     if (const char *e = getenv("YGPU_SEG_SORT")) ctx->segSort = atoi(e);
+    if (const char *e = getenv("YGPU_SEGSORT_MAX")) { long v = atol(e); if (v >= 1 && v <= (long)YD_SEGSORT_MAX) ctx->segSortMax = (uint32_t)v; }
     if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
+    if (const char *e = getenv("YGPU_ROWS2_PER_CU")) ctx->rows2PerCU = atoi(e);
     if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
@@ -575,7 +604,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
     if (ctx->stream) {
         hipSetDevice(ctx->device);
         if (ctx->sharedIndex) { ctx->dBases.p = nullptr; ctx->dBases.cap = 0; ctx->dSO.p = nullptr; ctx->dSO.cap = 0; ctx->dROA.p = nullptr; ctx->dROA.cap = 0; }
-        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->isHead, &ctx->scanOut,
+        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
                          &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
