@@ -12,6 +12,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <map>
+#include <deque>
 #include <memory>
 #include <sys/stat.h>
 
@@ -76,7 +77,9 @@ static bool sessionLoad(yaha_session *s)
     return true;
 }
 
-static void formatBatch(yaha_session *s, const ygpu_result_batch *r, std::string &text)
+// OQC/FBS filter + SAM text of one batch.  nt > 1: the reads of the batch are shared out to nt threads (the ctypes/Session path, one
+// batch at a time); the command line formats whole batches on a pool of threads instead (runQueries) and passes nt = 1.
+static void formatBatch(yaha_session *s, const ygpu_result_batch *r, std::string &text, int nt)
 {
     const Args &a = s->args; const uint32_t n = r->n_reads;
     std::vector<std::string> parts(n);
@@ -90,12 +93,23 @@ static void formatBatch(yaha_session *s, const ygpu_result_batch *r, std::string
             for (auto &o : oc) printClump(a, s->genome, s->reads[i], o, primaryCount, parts[i]);
         }
     };
-    int nt = std::max(1, a.numThreads); std::vector<std::thread> th;
+    std::vector<std::thread> th;
     for (int t = 1; t < nt; t++) th.emplace_back(work);
     work(); for (auto &x : th) x.join();
     size_t tot = 0; for (auto &p : parts) tot += p.size();
     text.clear(); text.reserve(tot); for (auto &p : parts) text += p;
 }
+
+namespace {
+// a bounded hand-over queue between pipeline stages
+template <class T> struct StageQueue {
+    std::mutex mu; std::condition_variable cvPush, cvPop; std::deque<T> q; size_t cap; int producers;
+    StageQueue(size_t c, int np) : cap(c), producers(np) {}
+    void push(T &&v) { std::unique_lock<std::mutex> lk(mu); cvPush.wait(lk, [&] { return q.size() < cap; }); q.push_back(std::move(v)); cvPop.notify_one(); }
+    bool pop(T &v) { std::unique_lock<std::mutex> lk(mu); cvPop.wait(lk, [&] { return !q.empty() || producers == 0; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); cvPush.notify_one(); return true; }
+    void producerDone() { std::lock_guard<std::mutex> lk(mu); if (--producers == 0) cvPop.notify_all(); }
+};
+}  // namespace
 
 int runQueries(Args &a, FILE *log)
 {
@@ -107,8 +121,8 @@ int runQueries(Args &a, FILE *log)
     fputs(S->header.c_str(), out);
     ygpu_params P; paramsFromArgs(A, P);
     ygpu_index_view V; yaha_session_index_view(S.get(), &V);
-    // -gpus N devices x -ctx M contexts per device (default 2: while one context's batch is in a latency-bound device stage, or in
-    // OQC / SAM formatting on its host thread, the other one's batch computes).  Contexts of one device share its index image.
+    // -gpus N devices x -ctx M contexts per device (default 2: while one context's batch is in a latency-bound device stage the other
+    // one's batch computes).  Contexts of one device share its index image.
     const int perDev = std::max(1, A.ctxPerGpu), ngpu = std::max(1, A.gpus) * perDev;
     std::vector<ygpu_ctx *> ctx(ngpu, nullptr);
     for (int d = 0; d < ngpu; d++) {
@@ -116,49 +130,88 @@ int runQueries(Args &a, FILE *log)
         int rc = (d % perDev == 0) ? ygpu_init(dev, &V, &P, &ctx[d]) : ygpu_clone(ctx[d - d % perDev], &ctx[d]);
         if (rc != 0) { fprintf(log, "ygpu_init(device %d) failed: %d %s\n", dev, rc, ctx[d] ? ygpu_last_error(ctx[d]) : ""); return 1; }
     }
-    // One worker per context.  The reader is serial (as in the reference, Query.c:105-214); a ticket orders output.
-    struct Batch { uint64_t ticket; std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets; };
-    std::mutex rdMu, outMu; std::condition_variable outCv; uint64_t nextTicket = 0, nextOut = 0; bool eof = false; int rcAll = 0;
+    // Three stages, batches handed over through bounded queues, a ticket ordering the output (= the reference's -t 1 order):
+    //   readers    (2 threads)         scan the input text (serial, under a lock, as in the reference, Query.c:105-214), then convert to codes
+    //                                  and pack the batch outside the lock;
+    //   contexts   (1 thread each)     upload, run the hot path, collect, copy the results out of the context's buffers;
+    //   formatters (-t threads)        OQC/FBS filter and SAM text of one whole batch each; whoever completes the next ticket writes.
+    // So the device never waits for parsing or formatting unless those stages as a whole are slower than it.
+    struct Batch { uint64_t ticket = 0; std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
+                   std::vector<uint32_t> clumpStart, ops; std::vector<ygpu_clump> clumps; uint64_t nClumps = 0, nOps = 0; bool failed = false; double tRead = 0, tDev = 0; };
+    typedef std::unique_ptr<Batch> BatchP;
+    // -t is the reference's thread count and is echoed in @PG; the formatter pool takes that many threads, and at least a few (the reference's
+    // default of 1 would make SAM formatting, ~25 us of CPU a read, the limit at a tenth of the device's rate)
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nReaders = 2, nFmt = std::max(std::max(1, A.numThreads), std::min(8, std::max(1, hw / 4)));
+    StageQueue<BatchP> inQ((size_t)ngpu + 2, nReaders), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu);
+    std::mutex rdMu, outMu; uint64_t nextTicket = 0, nextOut = 0; bool eof = false; std::atomic<int> rcAll(0);
     std::map<uint64_t, std::string> done;
-    auto readBatch = [&](Batch &b) -> bool {
-        {   // only the text scan of the input stream is serial; code conversion and batch packing run outside the lock
-            std::lock_guard<std::mutex> lk(rdMu);
-            if (eof) return false;
-            b.reads.clear();
-            Read r;
-            while ((int)b.reads.size() < A.batchReads && S->reader.nextRaw(r)) b.reads.push_back(std::move(r));
-            if ((int)b.reads.size() < A.batchReads) eof = true;
-            if (b.reads.empty()) return false;
-            b.ticket = nextTicket++;
-        }
-        b.codes.clear(); b.offsets.assign(1, 0);
-        for (auto &r : b.reads) { ReadReader::finish(r); b.codes.insert(b.codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); b.offsets.push_back(b.codes.size()); }
-        return true;
-    };
-    auto worker = [&](int d) {
-        yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs; local.genome.maxROff = S->genome.maxROff;
-        Batch b; const bool timing = getenv("YAHA_TIMING") != nullptr;
-        auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool timing = getenv("YAHA_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto reader = [&]() {
         for (;;) {
+            BatchP b(new Batch); const double t0 = now();
+            {
+                std::lock_guard<std::mutex> lk(rdMu);
+                if (eof) break;
+                Read r;
+                while ((int)b->reads.size() < A.batchReads && S->reader.nextRaw(r)) b->reads.push_back(std::move(r));
+                if ((int)b->reads.size() < A.batchReads) eof = true;
+                if (b->reads.empty()) break;
+                b->ticket = nextTicket++;
+            }
+            b->offsets.assign(1, 0);
+            for (auto &r : b->reads) { ReadReader::finish(r); b->codes.insert(b->codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); b->offsets.push_back(b->codes.size()); }
+            b->tRead = now() - t0;
+            inQ.push(std::move(b));
+        }
+        inQ.producerDone();
+    };
+    auto device = [&](int d) {
+        BatchP b;
+        while (inQ.pop(b)) {
             const double t0 = now();
-            if (!readBatch(b)) break;
-            const double t1 = now();
-            ygpu_read_batch rb{(uint32_t)b.reads.size(), b.codes.data(), b.offsets.data()}; ygpu_result_batch res;
-            int rc = ygpu_upload(ctx[d], &rb); const double t2 = now(); if (rc == 0) rc = ygpu_run(ctx[d]); const double t3 = now(); if (rc == 0) rc = ygpu_collect(ctx[d], &res); const double t4 = now();
-            std::string text;
-            if (rc != 0) { fprintf(log, "device %d: hot path failed (%d): %s\n", d, rc, ygpu_last_error(ctx[d])); rcAll = 1; }
-            else { local.reads.swap(b.reads); formatBatch(&local, &res, text); local.reads.swap(b.reads); }
-            if (timing) fprintf(stderr, "[yaha] ctx %d ticket %llu: %zu reads  read %.1f  upload %.1f  device %.1f  collect %.1f  format %.1f ms\n", d, (unsigned long long)b.ticket, b.reads.size(), t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
+            ygpu_read_batch rb{(uint32_t)b->reads.size(), b->codes.data(), b->offsets.data()}; ygpu_result_batch res;
+            int rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc == 0) rc = ygpu_collect(ctx[d], &res);
+            if (rc != 0) { fprintf(log, "device %d: hot path failed (%d): %s\n", d, rc, ygpu_last_error(ctx[d])); rcAll = 1; b->failed = true; }
+            else {   // the context's result buffers are reused by its next batch
+                b->clumpStart.assign(res.clump_start, res.clump_start + res.n_reads + 1); b->clumps.assign(res.clumps, res.clumps + res.n_clumps); b->ops.assign(res.ops, res.ops + res.n_ops);
+                b->nClumps = res.n_clumps; b->nOps = res.n_ops;
+            }
+            std::vector<uint8_t>().swap(b->codes);
+            b->tDev = now() - t0;
+            fmtQ.push(std::move(b));
+        }
+        fmtQ.producerDone();
+    };
+    auto formatter = [&]() {
+        yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs; local.genome.maxROff = S->genome.maxROff;
+        BatchP b;
+        while (fmtQ.pop(b)) {
+            const double t0 = now(); std::string text;
+            if (!b->failed) {
+                ygpu_result_batch res; memset(&res, 0, sizeof res);
+                res.n_reads = (uint32_t)b->reads.size(); res.clump_start = b->clumpStart.data(); res.clumps = b->clumps.data(); res.ops = b->ops.data(); res.n_clumps = b->nClumps; res.n_ops = b->nOps;
+                local.reads.swap(b->reads); formatBatch(&local, &res, text, 1); local.reads.swap(b->reads);
+            }
+            if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  read+convert %.1f  device (upload, run, collect, copy) %.1f  format %.1f ms\n", (unsigned long long)b->ticket, b->reads.size(), b->tRead, b->tDev, now() - t0);
             std::unique_lock<std::mutex> lk(outMu);
-            done[b.ticket] = std::move(text);
+            done[b->ticket] = std::move(text);
             while (!done.empty() && done.begin()->first == nextOut) { fputs(done.begin()->second.c_str(), out); done.erase(done.begin()); nextOut++; }
         }
     };
-    std::vector<std::thread> th; for (int d = 1; d < ngpu; d++) th.emplace_back(worker, d);
-    worker(0); for (auto &x : th) x.join();
+    const double tStart = now();
+    if (timing) fprintf(stderr, "[yaha] contexts ready\n");
+    std::vector<std::thread> th;
+    for (int i = 0; i < nReaders; i++) th.emplace_back(reader);
+    for (int d = 0; d < ngpu; d++) th.emplace_back(device, d);
+    for (int i = 0; i < nFmt; i++) th.emplace_back(formatter);
+    for (auto &x : th) x.join();
     for (auto &kv : done) fputs(kv.second.c_str(), out);
+    const double tDone = now();
     for (int d = ngpu - 1; d >= 0; d--) ygpu_destroy(ctx[d]);                 // clones before their parents
     if (out != stdout) fclose(out); else fflush(out);
+    if (timing) fprintf(stderr, "[yaha] batches %.1f ms, teardown %.1f ms\n", tDone - tStart, now() - tDone);
     return rcAll;
 }
 }  // namespace yaha
@@ -194,7 +247,7 @@ int yaha_session_next_batch(yaha_session *s, uint32_t max_reads, ygpu_read_batch
 int yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **text, size_t *len)
 {
     if (r->n_reads != s->reads.size()) { s->err = "result batch does not match the current read batch"; return YGPU_EINVAL; }
-    formatBatch(s, r, s->text); *text = s->text.c_str(); *len = s->text.size(); return 0;
+    formatBatch(s, r, s->text, std::max(1, s->args.numThreads)); *text = s->text.c_str(); *len = s->text.size(); return 0;
 }
 int yaha_build_index(int argc, const char *const *argv)
 {
