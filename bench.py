@@ -263,7 +263,7 @@ def main():
                      "kernel_ms_hip_events": rows_ms, "kernel_ms_device_clock": rows_dev_ms,
                      "cell_updates_per_s": counters["dp_ext_cells"] / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
                      "note": "integer DP: the kernel is bound by vector-ALU issue, not HBM (see DESIGN.md section 6 and profiles/)",
-                     "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "valu_issue_frac", "fetch_bytes_per_launch", "write_bytes_per_launch", "source") if k2 in pmc} if pmc and traffic is not None else None)},
+                     "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "valu_cycles_per_inst", "valu_issue_frac", "fetch_bytes_per_launch", "write_bytes_per_launch", "source") if k2 in pmc} if pmc and traffic is not None else None)},
         "path": {"algorithmic_bytes_per_read": B, "hbm_frac_whole_path": value * B / (8.0e12 * world),
                  "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) * steps * world / dt},
         "stage_ms_per_step": {k2: v / steps for k2, v in stage_ms.items()},

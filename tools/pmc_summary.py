@@ -44,7 +44,8 @@ if emit and kernel:
     valu = biggest("sq", "SQ_INSTS_VALU"); dur_ns = out[k].get("max_ns") or out[k].get("avg_ns", 0.0)
     js = {"kernel": kernel, "reads_per_gpu": reads, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
           "valu_insts_per_launch": valu, "kernel_ns_largest_launch": dur_ns,
+          "valu_cycles_per_inst": (1024 * 2.4 * dur_ns / valu) if valu else None,
           "valu_issue_frac": (valu * 4.0 / (1024 * 2.4 * dur_ns)) if dur_ns else None,
           "sq": {c: biggest("sq", c) for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU")},
-          "source": "rocprofv3 --pmc, separate passes (tools/pmc_pass.sh); FETCH_SIZE x2 per the gfx950 note; valu_issue_frac assumes 1024 SIMDs, 2.4 GHz, 4 cycles per wave64 VALU instruction"}
+          "source": "rocprofv3 --pmc, separate passes (tools/pmc_pass.sh); FETCH_SIZE x2 per the gfx950 note; valu_cycles_per_inst = SIMD cycles (1024 SIMDs, 2.4 GHz) per wave64 VALU instruction over the launch; valu_issue_frac prices every instruction at 4 cycles (tools/micro/pk_rate.hip measures 2.5-2.9 for plain two-operand 32-bit ops and 4.3-4.7 for compares, selects, max and three-operand ops)"}
     json.dump(js, open(emit, "w"), indent=1); print("wrote", emit, js)

@@ -358,6 +358,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
     auto rowsKernel2 = caps ? k_ext_rows<true, true> : k_ext_rows<false, true>;
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
+    if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     const bool overlap = fits && nChunks > 1;
     hipStream_t sTail = overlap ? ctx->stream2 : ctx->stream;
     X.trace = ctx->extTrace.as<uint32_t>(); X.stripOff = ctx->stripOff.as<unsigned long long>();
