@@ -297,19 +297,9 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
     for (int guard = 0; guard < 70000 && y > 0 && x >= 0 && x < YD_LW; guard++) {
         const int ws = x >> 3, sh = (x & 7) * 4;
         uint32_t d[YD_TRACE_DEPTH];
-        int wk = w, rk = rr;
+        { int wk = w, rk = rr;
 #pragma unroll
-        for (int k = 0; k < YD_TRACE_DEPTH; k++) { d[k] = strip[wk + ws]; if (y > k + 1) stepUp(wk, rk); }
-        if (y >= YD_TRACE_DEPTH) {                                           // the common case, all of them matches: one step for the lot
-            uint32_t any = 0;
-#pragma unroll
-            for (int k = 0; k < YD_TRACE_DEPTH; k++) any |= d[k];
-            if (((any >> sh) & 3u) == (uint32_t)OP_M) {
-                if (prev != OP_M) { if (prev >= 0) flush(); prev = OP_M; acc = YD_TRACE_DEPTH; } else acc += YD_TRACE_DEPTH;
-                y -= YD_TRACE_DEPTH; w = wk; rr = rk;                        // (y == 0: the position is not used again)
-                continue;
-            }
-        }
+          for (int k = 0; k < YD_TRACE_DEPTH; k++) { d[k] = strip[wk + ws]; if (y > k + 1) stepUp(wk, rk); } }
         uint32_t nib = (d[0] >> sh) & 15u; int took = 0;
 #pragma unroll
         for (int k = 0; k < YD_TRACE_DEPTH; k++) {
