@@ -79,6 +79,11 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, eSLo = 0, eSHi = 0, ePidx = 0;
     // deferred stores (see the row code)
     bool pendFlush = false; YD_GLOBAL uint32_t *pendBlk = toGlobal(A.trace); int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pCells = 0;
+    // The 10-row trace blocks of all lanes of a wave are in phase: row i of a problem that started when the wave was at row slot `phase` sits in
+    // strip row i - 1 + phase, and every lane writes LDS row slot `wslot` in the same iteration.  All blocks of the wave are then complete in the
+    // same iteration (wslot == 9) and leave together, once every ten rows; a problem that ends in between leaves its partial block behind
+    // (`dirty`), which goes out with the next refill pass or the next common hand-over, whichever comes first.
+    int wslot = 0, phase = 0; bool dirty = false; YD_GLOBAL uint32_t *curBlk = toGlobal(A.trace);
 
     // Finished blocks leave the wave together: the lanes that have one list it in LDS, then eight lanes write each block, 16 bytes apiece, so
     // that a store instruction carries whole 128-byte lines (a lane writing its own block alone sends eight 16-byte pieces in eight instructions).
@@ -114,6 +119,8 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             if (!need) break;
             // a refill pass costs ~100 wave instructions whatever the number of lanes it serves: wait until a few are idle
             if (__builtin_popcountll(need) < YD_REFILL_MIN && __ballot(p >= 0) != 0ull && !firstFill) break;
+            if (p < 0 && dirty) { pendFlush = true; dirty = false; }         // the lanes about to start a problem still hold the last rows of their previous one
+            flushBlocks();
             if (poolNext >= poolCount) {                                     // wave-uniform: claim and set up the next 64 problems
                 unsigned base = 0;
                 if (!exhausted) { if (lane == 0) base = atomicAdd(A.queue, 64u); base = uniU(base); if (base >= A.nProb) exhausted = true; }
@@ -170,7 +177,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                 p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
                 rev = (gMisc & XP_REV) != 0; rOff = gROff; pCells = 0;
                 q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu);
-                strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 32ull;
+                strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 32ull; curBlk = strip; phase = wslot;
                 w0 = 0; w1 = gW1; w2 = gW2;
             }
             poolNext += nNeed < avail ? nNeed : avail;
@@ -184,7 +191,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         // The wait the compiler puts at the loop header then finds them ~1000 instructions old.
         flushBlocks();                                                       // deferred from the previous row
         if (pendRes >= 0) {
-            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.rows = pendRows; r.cells = pendCells;
+            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = pendRows >> 20; r.rows = pendRows & 0xFFFFFu; r.cells = pendCells;      // rLen: the strip row of row 1
             A.res[pendRes] = r; pendRes = -1;
         }
         const bool busy = p >= 0;
@@ -229,7 +236,7 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             dV = upV;                                                        // the next column's diagonal predecessor
             __builtin_amdgcn_sched_barrier(0);                               // keep the cells in program order: their many condition masks stay short-lived
         }
-        { const int slot = ((i - 1) % 10) * 3, tid = (int)threadIdx.x;      // this row's cells go to the lane's LDS block
+        { const int slot = wslot * 3, tid = (int)threadIdx.x;               // this row's cells go to the lane's LDS block (the same row slot in every lane)
           sBlk[slot][tid] = t0; sBlk[slot + 1][tid] = t1; sBlk[slot + 2][tid] = t2; }
         int rv = YD_LWORST, rj = 0;
         if (rowKey) { rv = (int)(rowKey >> 5) - YD_BIAS; rj = 31 - (int)(rowKey & 31u); }
@@ -238,16 +245,18 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         const uint32_t nb = nbOdd == 2u ? 15u : (nbOdd ? (nbByte & 15u) : (nbByte >> 4));
         w0 = (w0 >> 4) | (w1 << 28); w1 = (w1 >> 4) | (w2 << 28); w2 = (w2 >> 4) | (nb << 16);
         const bool fin = busy && (rv < maxScore - XC || i >= qLen);
-        if (busy && (fin || i % 10 == 0)) { pendFlush = true; pendBlk = strip + (size_t)((i - 1) / 10) * 32u; }
+        if (busy) { dirty = true; pendBlk = curBlk; }
+        if (wslot == 9) { pendFlush = dirty; dirty = false; if (busy) curBlk += 32; wslot = 0; } else wslot++;      // wave-uniform
         if (fin) {
-            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i; pendCells = pCells;
+            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i | ((unsigned)phase << 20); pendCells = pCells;
             p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
         }
     }
     // the last deferred stores
+    if (dirty) pendFlush = true;
     flushBlocks();
     if (pendRes >= 0) {
-        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = 0; r.rows = pendRows; r.cells = pendCells;
+        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = pendRows >> 20; r.rows = pendRows & 0xFFFFFu; r.cells = pendCells;
         A.res[pendRes] = r;
     }
     if (!SECOND && A.clock && lane == 0) atomicMax(&A.clock[1], (unsigned long long)wall_clock64());
@@ -285,10 +294,11 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
     if (r.score <= 0) return;
     YD_GLOBAL uint32_t *strip = toGlobal(A.trace) + (A.stripOff[p] - A.stripBase) * 32ull;
     constexpr int leftR = YD_LBAND;
-    const int E = extRowWord(r.maxi + 1) + 3;
+    const int ph = (int)r.rLen;                                              // row i of the problem is strip row i - 1 + ph (k_ext_rows keeps the blocks of a wave in phase)
+    const int E = extRowWord(r.maxi + 1 + ph) + 3;
     int y = r.maxi, x = r.maxj, prev = -1, acc = 0, n = 0; bool bad = false;
     // w = word offset of row y inside the strip, rr = its row inside the 10-row block (kept incrementally: no divisions in the loops)
-    int rr = (y - 1) % 10, w = ((y - 1) / 10) * 32 + rr * 3;
+    int rr = (y - 1 + ph) % 10, w = ((y - 1 + ph) / 10) * 32 + rr * 3;
     auto flush = [&]() { const int wp = E - 1 - n; if (wp < w + 3) bad = true; else strip[wp] = opMake(prev, acc); n++; };   // rows above row y are consumed
     auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
     auto stepUp = [&](int &ww, int &r2) { if (r2 == 0) { r2 = 9; ww -= 5; } else { r2--; ww -= 3; } };                        // one row towards the origin

@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
             X.probs[2 * (size_t)r] = pb; X.probs[2 * (size_t)r + 1] = pf;
             X.extKeys[2 * (size_t)r] = vb ? 0xFFFFu - pb.qLen : 0x10000u; X.extKeys[2 * (size_t)r + 1] = vf ? 0xFFFFu - pf.qLen : 0x10000u;
             X.extVals[2 * (size_t)r] = 2u * r; X.extVals[2 * (size_t)r + 1] = 2u * r + 1u;
-            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)((pb.qLen + 10u) / 10u) : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)((pf.qLen + 10u) / 10u) : 0ull;   // trace blocks of 10 rows, one spare row
+            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)((pb.qLen + 19u) / 10u) : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)((pf.qLen + 19u) / 10u) : 0ull;   // trace blocks of 10 rows: up to 9 rows of phase in front, one spare row behind
         }
     }
     perfect = waveSumU(perfect); touched = waveSumU(touched); gapCalls = waveSumU(gapCalls); gapRows = waveSumU(gapRows); gapCells = waveSumU(gapCells);
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
                 const unsigned first = pb + (unsigned)(incl - np); int kept = 0;
                 for (int k = 0; k < np; k++) {
                     const unsigned idx = first + (unsigned)k; if (idx >= X.probs2Cap) break;
-                    X.probs2[idx] = pp[k]; X.rowsBound2[idx] = (unsigned long long)((pp[k].qLen + 10u) / 10u);
+                    X.probs2[idx] = pp[k]; X.rowsBound2[idx] = (unsigned long long)((pp[k].qLen + 19u) / 10u);
                     uint32_t *key = X.memoKeys + ((size_t)slot * YD_MEMO + (size_t)k) * 3;
                     key[0] = pp[k].rOff; key[1] = (uint32_t)pp[k].qOff | ((uint32_t)pp[k].qLen << 16); key[2] = ((pp[k].flags & XP_REV) ? 1u : 0u) | (idx << 1);
                     kept++;
