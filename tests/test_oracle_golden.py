@@ -68,3 +68,84 @@ def test_live_reference_on_fresh_reads(work, index11, tmp_path):
     ref_out = str(tmp_path / "ref.sam")
     oracle.run_reference(["-x", index11, "-q", reads, "-osh", ref_out, "-FBS", "Y"])
     assert run_oracle_pipeline(index11, reads, "-osh", ["-FBS", "Y"]) == strip_pg(open(ref_out).read())
+
+
+def _reads_of(path, n):
+    out, name, seq = [], None, []
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            if name is not None:
+                out.append((name, "".join(seq)))
+                if len(out) == n:
+                    return out
+            name, seq = line[1:], []
+        else:
+            seq.append(line)
+    out.append((name, "".join(seq)))
+    return out[:n]
+
+
+def _wrap(s, w):
+    return "\n".join(s[i:i + w] for i in range(0, len(s), w))
+
+
+def _quirky_fasta(reads):
+    """Input-format corner cases of readNextQuery (Query.c:102-228), on reads that align so that QNAME and SEQ show up in the SAM."""
+    t = []
+    t.append(">%s with spaces in the id\n%s\n" % (reads[0][0], _wrap(reads[0][1], 60)))          # multi-line, spaces -> '_'
+    t.append(">%s\n%s\n" % ("L" * 230, reads[1][1]))                                             # id longer than 200: truncated
+    t.append(">%s>gt_inside_id\n%s\n" % (reads[2][0], _wrap(reads[2][1].lower(), 70)))           # '>' in the id line, lower case
+    t.append(">tooshort\nACGTAC\n")                                                               # skipped (shorter than wordLen)
+    t.append(">%s\n\n\n%s\n\n" % (reads[3][0], _wrap(reads[3][1], 17)))                           # blank lines inside a record
+    t.append(">%s\n%s" % (reads[4][0], reads[4][1][:400]) + ">" + "%s_cut\n%s\n" % (reads[4][0], reads[4][1][400:]))   # '>' in mid-line starts a record
+    t.append(">%s\r\n%s\r\n" % (reads[5][0], reads[5][1]))                                       # CR is an id character and a base
+    t.append(">toolong\n%s\n" % _wrap("ACGT" * 8001, 80))                                          # 32 004 bases: skipped with a warning
+    t.append(">%s\n%s\n" % (reads[6][0], reads[6][1]))
+    t.append(">%s\n%s" % (reads[7][0], reads[7][1]))                                              # no newline at the end of the input
+    return "".join(t)
+
+
+def _quirky_fastq(reads):
+    q = lambda n, c="I": c * n
+    t = []
+    t.append("@%s\n%s\n+\n%s\n" % (reads[0][0], reads[0][1], "@" + q(len(reads[0][1]) - 1)))      # quality that starts with '@'
+    t.append("@%s extra words\n%s\n+%s\n%s\n" % (reads[1][0], _wrap(reads[1][1], 50), reads[1][0], _wrap(q(len(reads[1][1]), "5"), 50)))   # multi-line, id repeated after '+'
+    t.append("@mismatch\n%s\n+\n%s\n" % (reads[2][1], q(len(reads[2][1]) - 3)))                   # lengths differ: skipped
+    t.append("@%s\n%s\n+\n%s\n" % (reads[3][0], reads[3][1], "".join(chr(33 + (i * 7) % 60) for i in range(len(reads[3][1]))).replace("@", "A")))
+    t.append("@noseq\n\n+\n%s\n" % q(12))                                                          # empty sequence but a quality string: skipped, input goes on
+    t.append("@%s\n%s\n+\n%s" % (reads[4][0], reads[4][1], q(len(reads[4][1]), "#")))             # no newline at the end
+    return "".join(t)
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref/yaha not built")
+@pytest.mark.parametrize("kind", ["fasta", "fastq"])
+@pytest.mark.parametrize("source", ["mmap", "pipe_small_blocks"])
+def test_reader_quirks_match_the_live_reference(work, index11, tmp_path, kind, source, monkeypatch):
+    reads = _reads_of(os.path.join(work, "r1k.fa"), 8)
+    path = str(tmp_path / ("quirks." + ("fa" if kind == "fasta" else "fq")))
+    with open(path, "w", newline="") as f:
+        f.write(_quirky_fasta(reads) if kind == "fasta" else _quirky_fastq(reads))
+    ref_out = str(tmp_path / "ref.sam")
+    _o, err = oracle.run_reference(["-x", index11, "-q", path, "-osh", ref_out])
+    want = strip_pg(open(ref_out, newline="").read())                 # no newline translation: one id ends in a CR
+    assert len([l for l in want if l and not l.startswith("@")]) >= (8 if kind == "fasta" else 4)
+    if source == "mmap":
+        assert run_oracle_pipeline(index11, path, "-osh", [], batch=3) == want
+        return
+    # the same bytes through a FIFO (the streaming source: stdin, pipes), read in blocks far smaller than a record
+    import threading
+    monkeypatch.setenv("YAHA_READ_BLOCK", "97")
+    fifo = str(tmp_path / "in.fifo")
+    os.mkfifo(fifo)
+    data = open(path, "rb").read()
+
+    def feed():
+        with open(fifo, "wb") as w:
+            w.write(data)
+    th = threading.Thread(target=feed)
+    th.start()
+    got = run_oracle_pipeline(index11, fifo, "-osh", [], batch=2)
+    th.join()
+    # the @PG-free output is identical; the reference's file name is in @PG only
+    assert got == want

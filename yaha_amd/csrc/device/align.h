@@ -25,7 +25,7 @@ struct AlignArgs {
     DevParams P; const uint8_t *bases; DevBatch B;
     const uint32_t *order; uint32_t nRoots; const ChainClumpRec *clumps; DevFrag *clumpFrags;
     unsigned int *queueHead;
-    uint8_t *scratch; size_t scratchPerWave; int maxQ, listCap, front, genCap;
+    uint8_t *scratch; size_t scratchPerWave; int maxQ, listCap, front, genCap, traceRows;
     ygpu_clump *outClumps; uint32_t *outOps; uint32_t *outRoot; uint32_t *outPush; unsigned int *outCounts; uint32_t outClumpCap, outOpsCap;
     unsigned int *rootPushCount;
     DevCounters *ctr; int *errFlag;
@@ -33,20 +33,21 @@ struct AlignArgs {
 
 // layout of one wave's scratch
 struct WaveMem { uint16_t *trace; uint32_t *tmpOps; int *gen; uint32_t *arena; Frame *frames; };
-__host__ __device__ inline size_t alignScratchBytes(int maxQ, int listCap, int genCap)
+// traceRows: rows of 64 trace cells (>= maxQ + 2; more when -G / -MD allow gap fills whose strip does not fit that, see alignDims in ygpu.hip)
+__host__ __device__ inline size_t alignScratchBytes(int maxQ, int traceRows, int listCap, int genCap)
 {
     size_t b = 0;
-    b += (size_t)(maxQ + 2) * 64 * 2; b = (b + 255) & ~(size_t)255;
+    b += (size_t)traceRows * 64 * 2; b = (b + 255) & ~(size_t)255;
     b += (size_t)(2 * maxQ + 512) * 4; b = (b + 255) & ~(size_t)255;
     b += (size_t)3 * (genCap + 3) * 4; b = (b + 255) & ~(size_t)255;
     b += (size_t)YD_DEPTH * listCap * 4; b = (b + 255) & ~(size_t)255;
     b += (size_t)YD_DEPTH * sizeof(Frame); b = (b + 255) & ~(size_t)255;
     return b;
 }
-__device__ inline WaveMem carveScratch(uint8_t *p, int maxQ, int listCap, int genCap)
+__device__ inline WaveMem carveScratch(uint8_t *p, int maxQ, int traceRows, int listCap, int genCap)
 {
     WaveMem m; size_t b = 0;
-    m.trace = (uint16_t *)(p + b); b += (size_t)(maxQ + 2) * 64 * 2; b = (b + 255) & ~(size_t)255;
+    m.trace = (uint16_t *)(p + b); b += (size_t)traceRows * 64 * 2; b = (b + 255) & ~(size_t)255;
     m.tmpOps = (uint32_t *)(p + b); b += (size_t)(2 * maxQ + 512) * 4; b = (b + 255) & ~(size_t)255;
     m.gen = (int *)(p + b); b += (size_t)3 * (genCap + 3) * 4; b = (b + 255) & ~(size_t)255;
     m.arena = (uint32_t *)(p + b); b += (size_t)YD_DEPTH * listCap * 4; b = (b + 255) & ~(size_t)255;
@@ -93,7 +94,7 @@ struct Aligner {
 
     __device__ Aligner(const AlignArgs &a, WaveMem m, uint16_t *ldsTrace) : A(a), P(a.P), M(m), err(0), q(nullptr), qlen(0), lane(laneId()),
         extCalls(0), extRows(0), extCells(0), gapCalls(0), gapRows(0), gapCells(0), perfect(0), touched(0), opsOut(0), splits(0), scored(0), rootRank(0), pushes(0)
-    { S.ldsTrace = ldsTrace; S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err; }
+    { S.ldsTrace = ldsTrace; S.trace = M.trace; S.traceRows = A.traceRows; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err; }
 
     __device__ uint32_t *buf(int depth) const { return M.arena + (size_t)depth * A.listCap; }
     __device__ int gapCost(int len) const { return len > 0 ? -(P.GO + len * P.GE) : 0; }
@@ -484,7 +485,7 @@ struct Aligner {
 __global__ void __launch_bounds__(64) k_align(AlignArgs A)
 {
     const unsigned wave = blockIdx.x;
-    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
+    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];
     Aligner al(A, M, sTrace);
     PROF_INIT();
@@ -506,15 +507,15 @@ __global__ void __launch_bounds__(64) k_align(AlignArgs A)
 // ---- stage-level test entry: a batch of independent DP calls (ygpu_dp_batch) -------------------------------------------
 struct DPBatchArgs {
     DevParams P; const uint8_t *bases; DevBatch B; const ygpu_dp_problem *probs; uint32_t n; unsigned int *queueHead;
-    uint8_t *scratch; size_t scratchPerWave; int maxQ, listCap, genCap;
+    uint8_t *scratch; size_t scratchPerWave; int maxQ, listCap, genCap, traceRows;
     ygpu_dp_result *res; uint32_t *ops; unsigned int *opsCount; uint32_t opsCap; int *errFlag;
 };
 __global__ void __launch_bounds__(64) k_dp_batch(DPBatchArgs A)
 {
     const int lane = laneId();
-    WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
+    WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];
-    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
+    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.traceRows; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
     const unsigned nProb = uniU(A.n);
     for (;;) {
         if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }

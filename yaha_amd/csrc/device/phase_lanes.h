@@ -308,9 +308,9 @@ __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
 __global__ void __launch_bounds__(64) k_gap_wave(AlignArgs A, PhaseArgs X)
 {
     const int lane = laneId();
-    WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
+    WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];
-    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.maxQ + 2; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
+    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.traceRows; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
     const unsigned n = uniU(*X.slowCount);
     for (;;) {
         if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
 __global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
 {
     const unsigned wave = blockIdx.x; const int lane = laneId();
-    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.listCap, A.genCap);
+    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];
     Aligner al(A, M, sTrace);
     PROF_INIT();

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include "chain.h"
 #include "chain_lanes.h"
 #include "seed.h"
@@ -29,6 +30,11 @@
 #include "split_lanes.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
+
+// Every kernel launch is followed by a check of the submit status: a launch the runtime rejects (too much LDS, a grid that is too large, a code object
+// for another architecture) would otherwise leave the stage running on unwritten buffers, and the later stream synchronisation reports nothing.
+#define KL(kern, grid, block, shmem, st, ...) do { hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__); hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) { ctx->err = std::string("launch of " #kern " failed: ") + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
 
 #define YD_MAX_CHUNK_EV 16
 namespace {
@@ -49,6 +55,7 @@ struct DevBuf {
 enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_SEGBIG, CNT_N = 24 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_N };
+std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split", "ext_rows_device_clock"};
 }  // namespace
 
@@ -65,7 +72,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -120,7 +127,7 @@ static int stageSeed(ygpu_ctx *ctx)
     EV0(T_SEED);
     ENSURE(ctx->posS, 4ull * (K + 1)); ENSURE(ctx->posC, 4ull * (K + 1)); ENSURE(ctx->posRsI, 4ull * (K + 1)); ENSURE(ctx->hitOff, 4ull * (K + 1));
     HIPCHK(hipMemsetAsync(ctx->posC.p, 0, 4ull * (K + 1), ctx->stream));
-    hipLaunchKernelGGL(k_kmer_lookup, dim3(2 * n), dim3(128), 0, ctx->stream, ctx->P, B, ctx->dSO.as<uint32_t>(), ctx->dROA.as<uint32_t>(), ctx->dKmerOff.as<uint32_t>(),
+    KL(k_kmer_lookup, dim3(2 * n), dim3(128), 0, ctx->stream, ctx->P, B, ctx->dSO.as<uint32_t>(), ctx->dROA.as<uint32_t>(), ctx->dKmerOff.as<uint32_t>(),
                        ctx->posS.as<uint32_t>(), ctx->posC.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), ctx->ctr.as<DevCounters>());
     int rc = cubScan(ctx, ctx->posC.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), K + 1); if (rc) return rc;
     EV1(T_SEED);
@@ -130,7 +137,7 @@ static int stageSeed(ygpu_ctx *ctx)
     if (H > 0x7FFFFFF0u) { ctx->err = "too many seed hits in one batch; use a smaller batch"; return YGPU_EOVERFLOW; }
     EV0(T_SORT);
     ENSURE(ctx->keysA, 8ull * H); ENSURE(ctx->keysB, 8ull * H);
-    hipLaunchKernelGGL(k_expand_hits, dim3(gridFor(H, YD_EXPAND_HITS)), dim3(256), 0, ctx->stream, ctx->dROA.as<uint32_t>(), ctx->posS.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), K, H, ctx->keysA.as<unsigned long long>());
+    KL(k_expand_hits, dim3(gridFor(H, YD_EXPAND_HITS)), dim3(256), 0, ctx->stream, ctx->dROA.as<uint32_t>(), ctx->posS.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), K, H, ctx->keysA.as<unsigned long long>());
     {
         // The sort is stable and k_expand_hits writes the hits of one (read, strand) in ascending query offset (k-mers in order, each
         // k-mer's reference offsets ascending), so two hits of one diagonal are already in qo order: the low 15 key bits need no pass.
@@ -138,7 +145,7 @@ static int stageSeed(ygpu_ctx *ctx)
         // inside one workgroup, one pass over HBM) instead of a batch-wide sort that also has to order the (read, strand) bits.
         if (ctx->segSort) {
             ENSURE(ctx->segOff, 4ull * (2 * n + 2));
-            hipLaunchKernelGGL(k_seg_offsets, dim3(gridFor(2 * n + 1, 256)), dim3(256), 0, ctx->stream, ctx->dKmerOff.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), 2 * n, ctx->segOff.as<uint32_t>());
+            KL(k_seg_offsets, dim3(gridFor(2 * n + 1, 256)), dim3(256), 0, ctx->stream, ctx->dKmerOff.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), 2 * n, ctx->segOff.as<uint32_t>());
             if (ctx->segSort >= 2) {
                 // segments of up to 16 384 hits: one workgroup each (segsort.h), in four size classes; every launch covers all segments and a
                 // workgroup whose segment belongs to another class leaves at once
@@ -147,11 +154,11 @@ static int stageSeed(ygpu_ctx *ctx)
                 uint32_t *cntBig = ctx->counters.as<uint32_t>() + CNT_SEGBIG;
                 HIPCHK(hipMemsetAsync(cntBig, 0, 4, ctx->stream));
                 const uint32_t mx = ctx->segSortMax;                                  // YD_SEGSORT_MAX; lower only to drive the long-segment path in tests
-                hipLaunchKernelGGL(k_seg_big, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, 2 * n, mx, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), cntBig);
-                if (mx > 8192u) hipLaunchKernelGGL((k_seg_sort<1024, 16>), dim3(2 * n), dim3(1024), 0, ctx->stream, in, out, so, 8192u, std::min(mx, 16384u));
-                if (mx > 4096u) hipLaunchKernelGGL((k_seg_sort<512, 16>), dim3(2 * n), dim3(512), 0, ctx->stream, in, out, so, 4096u, std::min(mx, 8192u));
-                if (mx > 1024u) hipLaunchKernelGGL((k_seg_sort<256, 16>), dim3(2 * n), dim3(256), 0, ctx->stream, in, out, so, 1024u, std::min(mx, 4096u));
-                hipLaunchKernelGGL((k_seg_sort<128, 8>), dim3(2 * n), dim3(128), 0, ctx->stream, in, out, so, 0u, std::min(mx, 1024u));
+                KL(k_seg_big, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, 2 * n, mx, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), cntBig);
+                if (mx > 8192u) KL((k_seg_sort<1024, 16>), dim3(2 * n), dim3(1024), 0, ctx->stream, in, out, so, 8192u, std::min(mx, 16384u));
+                if (mx > 4096u) KL((k_seg_sort<512, 16>), dim3(2 * n), dim3(512), 0, ctx->stream, in, out, so, 4096u, std::min(mx, 8192u));
+                if (mx > 1024u) KL((k_seg_sort<256, 16>), dim3(2 * n), dim3(256), 0, ctx->stream, in, out, so, 1024u, std::min(mx, 4096u));
+                KL((k_seg_sort<128, 8>), dim3(2 * n), dim3(128), 0, ctx->stream, in, out, so, 0u, std::min(mx, 1024u));
                 uint32_t nBig = 0; rc = fetchU32(ctx, cntBig, &nBig); if (rc) return rc;
                 if (nBig) {
                     size_t bytes = 0;
@@ -177,7 +184,7 @@ static int stageSeed(ygpu_ctx *ctx)
     EV0(T_FRAGS);
     ENSURE(ctx->isHead, 4ull * (H + 1)); ENSURE(ctx->scanOut, 4ull * (H + 1));
     HIPCHK(hipMemsetAsync((uint32_t *)ctx->isHead.p + H, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_frag_heads, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, ctx->isHead.as<uint32_t>());
+    KL(k_frag_heads, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, ctx->isHead.as<uint32_t>());
     rc = cubScan(ctx, ctx->isHead.as<uint32_t>(), ctx->scanOut.as<uint32_t>(), H + 1); if (rc) return rc;
     uint32_t F = 0; rc = fetchU32(ctx, ctx->scanOut.as<uint32_t>() + H, &F); if (rc) return rc;
     ctx->nFrags = F;
@@ -188,8 +195,8 @@ static int buildFrags(ygpu_ctx *ctx)       // (re)creates the fragment array fro
 {
     const uint32_t H = ctx->nHits, F = ctx->nFrags;
     if (!H) return 0;
-    hipLaunchKernelGGL(k_frag_build, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), ctx->isHead.as<uint32_t>(), ctx->scanOut.as<uint32_t>(), H, ctx->P.wordLen, ctx->frags.as<DevFrag>());
-    hipLaunchKernelGGL(k_frag_finish, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F);
+    KL(k_frag_build, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), ctx->isHead.as<uint32_t>(), ctx->scanOut.as<uint32_t>(), H, ctx->P.wordLen, ctx->frags.as<DevFrag>());
+    KL(k_frag_finish, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F);
     return 0;
 }
 
@@ -204,15 +211,15 @@ static int stageChain(ygpu_ctx *ctx)
     DevBuf &rHead = ctx->rootPush, &rScan = ctx->rootBase;           // borrowed as temporaries (not yet in use at this point)
     ENSURE(rHead, 4ull * (F + 1)); ENSURE(rScan, 4ull * (F + 1));
     HIPCHK(hipMemsetAsync((uint32_t *)rHead.p + F, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_region_heads, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, rHead.as<uint32_t>());
+    KL(k_region_heads, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, rHead.as<uint32_t>());
     rc = cubScan(ctx, rHead.as<uint32_t>(), rScan.as<uint32_t>(), F + 1); if (rc) return rc;
     uint32_t R = 0; rc = fetchU32(ctx, rScan.as<uint32_t>() + F, &R); if (rc) return rc;
     ctx->nRegions = R;
-    hipLaunchKernelGGL(k_region_starts, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, rHead.as<uint32_t>(), rScan.as<uint32_t>(), F, ctx->regStart.as<uint32_t>());
+    KL(k_region_starts, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, rHead.as<uint32_t>(), rScan.as<uint32_t>(), F, ctx->regStart.as<uint32_t>());
     HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
     uint32_t *cnt = ctx->counters.as<uint32_t>();
     HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NBIG, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NSMALL, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_region_classify, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN, ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG, ctx->smallList.as<uint32_t>(), cnt + CNT_NSMALL);
+    KL(k_region_classify, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN, ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG, ctx->smallList.as<uint32_t>(), cnt + CNT_NSMALL);
     uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NMULTI, two, 2); if (rc) return rc;
     ctx->nMulti = two[0]; ctx->maxN = two[1];
     rc = fetchU32(ctx, cnt + CNT_NBIG, &ctx->nBig); if (rc) return rc;
@@ -238,10 +245,10 @@ static int stageChain(ygpu_ctx *ctx)
         A.scratch = ctx->scratchChain.as<uint8_t>(); A.scratchPerWave = per; A.maxN = maxN; A.maxQ = ctx->maxQ;
         A.clumps = ctx->clumps.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.counts = cnt + CNT_CLUMPS; A.clumpCap = clumpCap; A.fragCap = fragCap;
         A.regionClumpCount = ctx->regionCount.as<uint32_t>(); A.errFlag = ctx->errFlag.as<int>(); A.ctr = ctx->ctr.as<DevCounters>();
-        hipLaunchKernelGGL(k_regions_single, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, A);
-        if (ctx->nSmall) hipLaunchKernelGGL(k_chain_lanes, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nSmall, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, A, ctx->smallList.as<uint32_t>(), ctx->nSmall);
-        if (ctx->nMulti) hipLaunchKernelGGL(k_chain, dim3(waves), dim3(64), 0, ctx->stream, A);
-        if (ctx->nBig) hipLaunchKernelGGL(k_chain_big, dim3(wavesBig), dim3(64), 0, ctx->stream, A, ctx->bigList.as<uint32_t>(), ctx->nBig, cnt + CNT_QBIG);
+        KL(k_regions_single, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, A);
+        if (ctx->nSmall) KL(k_chain_lanes, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nSmall, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, A, ctx->smallList.as<uint32_t>(), ctx->nSmall);
+        if (ctx->nMulti) KL(k_chain, dim3(waves), dim3(64), 0, ctx->stream, A);
+        if (ctx->nBig) KL(k_chain_big, dim3(wavesBig), dim3(64), 0, ctx->stream, A, ctx->bigList.as<uint32_t>(), ctx->nBig, cnt + CNT_QBIG);
         uint32_t got[2]; rc = fetchU32(ctx, cnt + CNT_CLUMPS, got, 2); if (rc) return rc;
         uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
         if (ef == 0 && got[0] <= clumpCap && got[1] <= fragCap) { ctx->nClumpSlots = got[0]; ctx->nClumpFrags = got[1]; break; }
@@ -253,13 +260,21 @@ static int stageChain(ygpu_ctx *ctx)
     rc = cubScan(ctx, ctx->regionCount.as<uint32_t>(), ctx->regionBase.as<uint32_t>(), R + 1); if (rc) return rc;
     rc = fetchU32(ctx, ctx->regionBase.as<uint32_t>() + R, &ctx->nClumps); if (rc) return rc;          // clumps actually formed (slots minus chunk slack)
     ENSURE(ctx->order, 4ull * (ctx->nClumps + 1));
-    if (ctx->nClumpSlots) hipLaunchKernelGGL(k_clump_order, dim3(gridFor(ctx->nClumpSlots, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->nClumpSlots, ctx->regionBase.as<uint32_t>(), ctx->order.as<uint32_t>());
+    if (ctx->nClumpSlots) KL(k_clump_order, dim3(gridFor(ctx->nClumpSlots, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->nClumpSlots, ctx->regionBase.as<uint32_t>(), ctx->order.as<uint32_t>());
     EV1(T_CHAIN);
     return 0;
 }
 
-static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap)
-{ front = 2 * ctx->maxQ + 8 * ctx->P.bandWidth + 64; listCap = 2 * front + 3 * ctx->maxQ + 1024; genCap = 1024; }
+// Per-wave scratch of the wave kernels, sized from the parameters.  A gap fill between two chained fragments has min(qGap, rGap) <= maxDesert
+// and |qGap - rGap| <= maxGap (GraphPath.cpp:211-230), so its strip is at most MD + G + 2*BW + 3 columns wide (banded: 2*BW + 1 + |qGap - rGap|,
+// full: rGap + 1) and rows x width <= (MD + 2) * (MD + G + 2*BW + 3) cells; the extensions need (maxQ + 2) rows of 64 cells.
+static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap, int &traceRows)
+{
+    front = 2 * ctx->maxQ + 8 * ctx->P.bandWidth + 64; listCap = 2 * front + 3 * ctx->maxQ + 1024;
+    const long long md = std::min<long long>(ctx->P.maxDesert, 32000), g = std::min<long long>(ctx->P.maxGap, 32000), wMax = md + g + 2 * ctx->P.bandWidth + 3;
+    genCap = (int)std::max<long long>(1024, wMax + 1);
+    traceRows = (int)std::max<long long>(ctx->maxQ + 2, ((md + 2) * wMax + 63) / 64 + 1);
+}
 
 
 // alignClump with the two X-drop extensions of every root done one problem per lane (ext_lanes.h):
@@ -284,7 +299,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     // joints of all roots
     ENSURE(ctx->jointCount, 4ull * (NC + 2)); ENSURE(ctx->jointBase, 4ull * (NC + 2));
     X.jointCount = ctx->jointCount.as<uint32_t>(); X.jointBase = ctx->jointBase.as<uint32_t>();
-    hipLaunchKernelGGL(k_joint_counts, dim3(gridFor(NC + 1, 256)), dim3(256), 0, ctx->stream, A, X);
+    KL(k_joint_counts, dim3(gridFor(NC + 1, 256)), dim3(256), 0, ctx->stream, A, X);
     rc = cubScan(ctx, ctx->jointCount.as<uint32_t>(), ctx->jointBase.as<uint32_t>(), NC + 1); if (rc) return rc;
     uint32_t J = 0; rc = fetchU32(ctx, ctx->jointBase.as<uint32_t>() + NC, &J); if (rc) return rc;
     const uint32_t gapOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)gapOpsPerJoint * J + (1u << 20));
@@ -295,20 +310,20 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     X.nDP = cnt + CNT_NDP; X.gapOps = ctx->gapOps.as<uint32_t>(); X.gapOpsCount = cnt + CNT_GAPOPS; X.gapOpsCap = gapOpsCap;
     HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 12, ctx->stream));                 // ndp, ndp16, gapops
     if (J) {
-        hipLaunchKernelGGL(k_p1_joints, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
+        KL(k_p1_joints, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
         size_t bytes = 0;
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
         if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 6);   // 17 / 26 KB of LDS per 64-thread block
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
-        hipLaunchKernelGGL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
-        hipLaunchKernelGGL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
-        hipLaunchKernelGGL(k_gap_wave, dim3(std::min(waves, 512u)), dim3(64), 0, ctx->stream, A, X);
+        KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
+        KL(k_gap_wave, dim3(std::min(waves, 512u)), dim3(64), 0, ctx->stream, A, X);
     }
     ENSURE(ctx->extKeys, 4ull * (nProb + 1)); ENSURE(ctx->extVals, 4ull * (nProb + 1)); ENSURE(ctx->extKeys2, 4ull * (nProb + 1)); ENSURE(ctx->extOrder, 4ull * (nProb + 1));
     X.extKeys = ctx->extKeys.as<uint32_t>(); X.extVals = ctx->extVals.as<uint32_t>();
-    hipLaunchKernelGGL(k_p1_assemble, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
+    KL(k_p1_assemble, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
     rc = cubScan64(ctx, ctx->rowsBound.as<unsigned long long>(), ctx->stripOff.as<unsigned long long>(), nProb + 1); if (rc) return rc;
     EV1(T_P1);
     TRACE("lanes: p1+scan");
@@ -321,34 +336,43 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     // Trace memory: 128-byte blocks of 10 rows.  The roots are processed in chunks: k_ext_rows of chunk c+1 (VALU-bound, main
     // stream) overlaps the latency-bound tail of chunk c (traceback, scoreClump/emit, splitClump waves; second stream).  When
     // the strips do not fit in memory the chunks reuse one buffer and run back to back instead.
+    // The budget is this context's share of the free memory (the contexts of one device run concurrently and each sees the same free figure); when the
+    // allocation still fails (another process, fragmentation) the budget is halved and the roots take the chunked path instead of failing the batch.
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
-    unsigned long long budget = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB + ctx->extTrace.cap) * 7 / 10) / 128ull);
-    budget = std::min<unsigned long long>(budget, (96ull << 30) / 128ull);    // at most 96 GB of strips per context: leaves room for a second context, bounds the first-use allocation
+    const int nShare = std::max(1, gCtxPerDevice[ctx->device & 63].load());
+    unsigned long long budget = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB / nShare + ctx->extTrace.cap) * 7 / 10) / 128ull);
+    budget = std::min<unsigned long long>(budget, (96ull << 30) / 128ull);    // at most 96 GB of strips per context: bounds the first-use allocation
     if (ctx->traceBudgetBlocks > 0) budget = (unsigned long long)ctx->traceBudgetBlocks;     // test hook: force the chunked path
-    std::vector<uint32_t> cuts; cuts.push_back(0);                            // root indices
-    const bool fits = totalRows <= budget;
-    if (fits) {
-        const uint32_t K = (ctx->laneChunks > 0) ? (uint32_t)ctx->laneChunks : 1u;      // measured: every k_ext_rows launch ends in a drain of long problems, so more chunks lose more than the overlap gains
-        for (uint32_t c = 1; c <= K; c++) { uint32_t r1 = (uint32_t)((uint64_t)NC * c / K); if (r1 > cuts.back()) cuts.push_back(r1); }
-    } else {
-        ctx->hStripOff.resize(nProb + 1);
-        HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
-        uint32_t r0 = 0;
-        while (r0 < NC) {
-            uint32_t lo = r0 + 1, hi = NC;                                    // largest r1 with strips(r0 .. r1) <= budget
-            if (ctx->hStripOff[2 * (size_t)lo] - ctx->hStripOff[2 * (size_t)r0] > budget) { ctx->err = "not enough device memory for one root's extension trace strips"; return YGPU_ENOMEM; }
-            while (lo < hi) { uint32_t mid = lo + (hi - lo + 1) / 2; if (ctx->hStripOff[2 * (size_t)mid] - ctx->hStripOff[2 * (size_t)r0] <= budget) lo = mid; else hi = mid - 1; }
-            cuts.push_back(lo); r0 = lo;
+    std::vector<uint32_t> cuts; bool fits = false, haveStrip = false; size_t nChunks = 0; unsigned long long chunkMax = 0;
+    for (int tries = 0;; tries++) {
+        cuts.assign(1, 0u);                                                   // root indices
+        fits = totalRows <= budget;
+        if (fits) {
+            const uint32_t K = (ctx->laneChunks > 0) ? (uint32_t)ctx->laneChunks : 1u;      // measured: every k_ext_rows launch ends in a drain of long problems, so more chunks lose more than the overlap gains
+            for (uint32_t c = 1; c <= K; c++) { uint32_t r1 = (uint32_t)((uint64_t)NC * c / K); if (r1 > cuts.back()) cuts.push_back(r1); }
+        } else {
+            if (!haveStrip) {
+                ctx->hStripOff.resize(nProb + 1); haveStrip = true;
+                HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+            }
+            uint32_t r0 = 0;
+            while (r0 < NC) {
+                uint32_t lo = r0 + 1, hi = NC;                                // largest r1 with strips(r0 .. r1) <= budget
+                if (ctx->hStripOff[2 * (size_t)lo] - ctx->hStripOff[2 * (size_t)r0] > budget) { ctx->err = "not enough device memory for one root's extension trace strips"; return YGPU_ENOMEM; }
+                while (lo < hi) { uint32_t mid = lo + (hi - lo + 1) / 2; if (ctx->hStripOff[2 * (size_t)mid] - ctx->hStripOff[2 * (size_t)r0] <= budget) lo = mid; else hi = mid - 1; }
+                cuts.push_back(lo); r0 = lo;
+            }
         }
+        nChunks = cuts.size() - 1; chunkMax = 0;
+        if (fits) chunkMax = totalRows; else for (size_t c = 0; c < nChunks; c++) chunkMax = std::max(chunkMax, ctx->hStripOff[2 * (size_t)cuts[c + 1]] - ctx->hStripOff[2 * (size_t)cuts[c]]);
+        if (ctx->extTrace.ensure(128ull * chunkMax + 256) == 0) break;
+        (void)hipGetLastError();                                              // the failed hipMalloc is handled here
+        if (tries >= 5 || ctx->traceBudgetBlocks > 0) { ctx->err = "hipMalloc failed for the extension trace strips"; return YGPU_ENOMEM; }
+        budget = std::max<unsigned long long>(1ull << 16, std::min(budget, chunkMax) / 2);
     }
-    const size_t nChunks = cuts.size() - 1;
-    unsigned long long chunkMax = 0;
-    if (fits) chunkMax = totalRows; else for (size_t c = 0; c < nChunks; c++) chunkMax = std::max(chunkMax, ctx->hStripOff[2 * (size_t)cuts[c + 1]] - ctx->hStripOff[2 * (size_t)cuts[c]]);
-    TRACE("lanes: cuts");
-    ENSURE(ctx->extTrace, 128ull * chunkMax + 256);
+    TRACE("lanes: cuts + trace memory");
     ENSURE(ctx->chunkCnt, 32ull * (nChunks + 1));                            // 8 words per chunk: queues and counts of its kernels
     HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 32ull * (nChunks + 1), ctx->stream));
-    TRACE("lanes: ensure trace");
     if (kTrace) fprintf(stderr, "[ygpu] trace blocks %llu budget %llu chunks %zu %s\n", totalRows, budget, nChunks, fits ? "(pipelined)" : "(sequential, one buffer)");
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
     ENSURE(ctx->rowsClock, 16); { const unsigned long long init[2] = {~0ull, 0ull}; HIPCHK(hipMemcpyAsync(ctx->rowsClock.p, init, 16, hipMemcpyHostToDevice, ctx->stream)); }
@@ -374,17 +398,17 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 17, ctx->stream));
             if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, 17, ctx->stream));
-            hipLaunchKernelGGL(k_rebase_u32, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, v1, np, p0);
+            KL(k_rebase_u32, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, v1, np, p0);
             E.order = v1;
         }
         const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + 255) / 256, (uint64_t)ctx->nCU * perCU);
-        hipLaunchKernelGGL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, E);
+        KL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, E);
         if (c + 1 == nChunks) EV1(T_XROWS);
         if (overlap) { HIPCHK(hipEventRecord(ctx->evChunk[c % YD_MAX_CHUNK_EV], ctx->stream)); HIPCHK(hipStreamWaitEvent(sTail, ctx->evChunk[c % YD_MAX_CHUNK_EV], 0)); }
         else TRACE("lanes: ext_rows");
         // the chunk's tail
         if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], sTail); }
-        hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(np, 256)), dim3(256), 0, sTail, E);
+        KL(k_ext_trace, dim3(gridFor(np, 256)), dim3(256), 0, sTail, E);
         if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_XTRACE][1], sTail);
         if (!overlap) TRACE("lanes: ext_trace");
         AlignArgs Ac = A; Ac.nRoots = r1; Ac.queueHead = cc + 8 * c + 1;
@@ -398,7 +422,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             Xc.memoKeys = ctx->memoKeys.as<uint32_t>(); Xc.memoCount = ctx->memoCount.as<unsigned int>(); Xc.probs2 = ctx->probs2.as<ExtProb>(); Xc.rowsBound2 = ctx->rowsBound2.as<unsigned long long>();
             Xc.nProb2 = cc + 8 * c + 3; Xc.probs2Cap = cap2;
         } else { Xc.memoKeys = nullptr; Xc.memoCount = nullptr; Xc.probs2 = nullptr; Xc.rowsBound2 = nullptr; Xc.nProb2 = nullptr; Xc.probs2Cap = 0; }
-        hipLaunchKernelGGL(k_p3_lanes, dim3(gridFor(nr, 256)), dim3(256), 0, sTail, Ac, Xc);
+        KL(k_p3_lanes, dim3(gridFor(nr, 256)), dim3(256), 0, sTail, Ac, Xc);
         PhaseArgs Xw = Xc;                                                    // what k_align_p3 gets: all split roots, or only those k_split_lanes gives back
         if (ctx->splitLanes) {
             // splitClump in lanes: the careful extensions the split roots will ask for go through a second k_ext_rows / k_ext_trace round
@@ -415,7 +439,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                     E2.probs = ctx->probs2.as<ExtProb>(); E2.nProb = n2; E2.stripOff = ctx->stripOff2.as<unsigned long long>(); E2.stripBase = 0;
                     {   // longest bound first here too: this launch is small and ends when its longest problem ends
                         ENSURE(ctx->keys2a, 4ull * (cap2 + 1)); ENSURE(ctx->keys2b, 4ull * (cap2 + 1)); ENSURE(ctx->vals2a, 4ull * (cap2 + 1)); ENSURE(ctx->vals2b, 4ull * (cap2 + 1));
-                        hipLaunchKernelGGL(k_prob_keys, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, ctx->probs2.as<ExtProb>(), n2, ctx->keys2a.as<uint32_t>(), ctx->vals2a.as<uint32_t>());
+                        KL(k_prob_keys, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, ctx->probs2.as<ExtProb>(), n2, ctx->keys2a.as<uint32_t>(), ctx->vals2a.as<uint32_t>());
                         size_t bytes = 0;
                         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, sTail));
                         if (ctx->cubTemp2.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
@@ -425,19 +449,19 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                     {   // a small launch: a few problems per lane, so its length is set by the lanes' chains of problems, not by the chip's throughput.  One wave
                         // per SIMD runs a row 2.4x faster than three sharing it (a lone wave issues every ~5 cycles) and gives every lane more problems to balance.
                         const uint64_t blocks2 = ctx->rows2PerCU > 0 ? (uint64_t)ctx->rows2PerCU : (uint64_t)ctx->nCU;
-                        hipLaunchKernelGGL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, blocks2)), dim3(256), 0, sTail, E2); }
-                    hipLaunchKernelGGL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, E2);
+                        KL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, blocks2)), dim3(256), 0, sTail, E2); }
+                    KL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, E2);
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
                 SplitArgs Sx; Sx.scratch = ctx->splitScratch.as<uint8_t>(); Sx.memoKeys = ctx->memoKeys.as<uint32_t>(); Sx.memoCount = ctx->memoCount.as<unsigned int>();
                 Sx.res2 = ctx->extRes2.as<ExtRes>(); Sx.trace2 = ctx->extTrace2.as<uint32_t>(); Sx.stripOff2 = ctx->stripOff2.as<unsigned long long>(); Sx.nProb2 = n2;
                 Sx.fallList = ctx->fallList.as<uint32_t>(); Sx.fallCount = cc + 8 * c + 5; Sx.nSlots = nSlow;
-                hipLaunchKernelGGL(k_split_lanes, dim3(gridFor(nSlow, 64)), dim3(64), 0, sTail, Ac, Xc, Sx);
+                KL(k_split_lanes, dim3(gridFor(nSlow, 64)), dim3(64), 0, sTail, Ac, Xc, Sx);
                 Xw.slowList = ctx->fallList.as<uint32_t>(); Xw.slowCount = cc + 8 * c + 5;
                 if (kTrace) { uint32_t fc = 0; HIPCHK(hipMemcpyAsync(&fc, cc + 8 * c + 5, 4, hipMemcpyDeviceToHost, sTail)); HIPCHK(hipStreamSynchronize(sTail)); unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gFallWhy), sizeof w8); fprintf(stderr, "[ygpu] roots left to the wave kernel %u (other %u, DP not listed %u, second split %u, depth/list %u)\n", fc, w8[0], w8[1], w8[2], w8[3]); memset(w8, 0, sizeof w8); hipMemcpyToSymbol(HIP_SYMBOL(gFallWhy), w8, sizeof w8); }
             }
         }
-        hipLaunchKernelGGL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, sTail, Ac, Xw);
+        KL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, sTail, Ac, Xw);
         if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_P3][1], sTail);
         if (!overlap) TRACE("lanes: p3");
     }
@@ -458,10 +482,10 @@ static int stageAlign(ygpu_ctx *ctx)
     if (NC) {
         TRACE("before align");
         EV0(T_ALIGN);
-        int listCap, front, genCap; alignDims(ctx, listCap, front, genCap);
-        const size_t per = alignScratchBytes(ctx->maxQ, listCap, genCap);
+        int listCap, front, genCap, traceRows; alignDims(ctx, listCap, front, genCap, traceRows);
+        const size_t per = alignScratchBytes(ctx->maxQ, traceRows, listCap, genCap);
         size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
-        uint64_t maxWaves = std::max<uint64_t>(64, (uint64_t)((freeB + ctx->scratchAlign.cap) * 6 / 10) / per);
+        uint64_t maxWaves = std::max<uint64_t>(64, (uint64_t)((freeB / std::max(1, gCtxPerDevice[ctx->device & 63].load()) + ctx->scratchAlign.cap) * 6 / 10) / per);
         const unsigned wavesPerCU = ctx->alignWavesPerCU > 0 ? (unsigned)ctx->alignWavesPerCU : 12u;
         const unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * wavesPerCU), maxWaves);      // 3 waves per SIMD (137 VGPRs)
         ENSURE(ctx->scratchAlign, per * waves);
@@ -481,7 +505,7 @@ static int stageAlign(ygpu_ctx *ctx)
             HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
             AlignArgs A; A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = B; A.order = ctx->order.as<uint32_t>(); A.nRoots = NC;
             A.clumps = ctx->clumps.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.queueHead = cnt + CNT_QALIGN;
-            A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per; A.maxQ = ctx->maxQ; A.listCap = listCap; A.front = front; A.genCap = genCap;
+            A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per; A.maxQ = ctx->maxQ; A.listCap = listCap; A.front = front; A.genCap = genCap; A.traceRows = traceRows;
             A.outClumps = ctx->outClumps.as<ygpu_clump>(); A.outOps = ctx->outOps.as<uint32_t>(); A.outRoot = ctx->outRoot.as<uint32_t>(); A.outPush = ctx->outPush.as<uint32_t>();
             A.outCounts = cnt + CNT_OUTCLUMPS; A.outClumpCap = outClumpCap; A.outOpsCap = outOpsCap; A.rootPushCount = ctx->rootPush.as<unsigned int>();
             A.ctr = ctx->ctr.as<DevCounters>(); A.errFlag = ctx->errFlag.as<int>();
@@ -489,7 +513,7 @@ static int stageAlign(ygpu_ctx *ctx)
             { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); }
 #endif
             bool laneOverflow = false;
-            if (!useLanes) hipLaunchKernelGGL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
+            if (!useLanes) KL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
             else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, gapOpsPerJoint); if (rc == -2) laneOverflow = true; else if (rc) return rc; }
 #ifdef YD_PROF
             { hipStreamSynchronize(ctx->stream); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
@@ -511,10 +535,10 @@ static int stageAlign(ygpu_ctx *ctx)
         EV0(T_LAYOUT);
         rc = cubScan(ctx, ctx->rootPush.as<uint32_t>(), ctx->rootBase.as<uint32_t>(), NC + 1); if (rc) return rc;
         if (ctx->nOut) {
-            hipLaunchKernelGGL(k_out_layout, dim3(gridFor(ctx->nOut, 256)), dim3(256), 0, ctx->stream, ctx->outRoot.as<uint32_t>(), ctx->outPush.as<uint32_t>(), ctx->rootBase.as<uint32_t>(), ctx->rootPush.as<unsigned int>(), ctx->nOut, ctx->dstIdx.as<uint32_t>());
-            hipLaunchKernelGGL(k_out_scatter, dim3(gridFor(ctx->nOut, 256)), dim3(256), 0, ctx->stream, ctx->outClumps.as<ygpu_clump>(), ctx->dstIdx.as<uint32_t>(), ctx->nOut, ctx->outClumps2.as<ygpu_clump>());
+            KL(k_out_layout, dim3(gridFor(ctx->nOut, 256)), dim3(256), 0, ctx->stream, ctx->outRoot.as<uint32_t>(), ctx->outPush.as<uint32_t>(), ctx->rootBase.as<uint32_t>(), ctx->rootPush.as<unsigned int>(), ctx->nOut, ctx->dstIdx.as<uint32_t>());
+            KL(k_out_scatter, dim3(gridFor(ctx->nOut, 256)), dim3(256), 0, ctx->stream, ctx->outClumps.as<ygpu_clump>(), ctx->dstIdx.as<uint32_t>(), ctx->nOut, ctx->outClumps2.as<ygpu_clump>());
         }
-        hipLaunchKernelGGL(k_read_counts, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->order.as<uint32_t>(), ctx->rootPush.as<unsigned int>(), NC, ctx->readCount.as<unsigned int>());
+        KL(k_read_counts, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->order.as<uint32_t>(), ctx->rootPush.as<unsigned int>(), NC, ctx->readCount.as<unsigned int>());
     }
     rc = cubScan(ctx, ctx->readCount.as<uint32_t>(), ctx->readStart.as<uint32_t>(), n + 1); if (rc) return rc;
     if (NC) EV1(T_LAYOUT);
@@ -545,6 +569,7 @@ static int initCommon(ygpu_ctx *ctx, int device)
     if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
     if (const char *e = getenv("YGPU_ROWS2_PER_CU")) ctx->rows2PerCU = atoi(e);
     if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
+    gCtxPerDevice[device & 63]++; ctx->counted = true;
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
     return 0;
@@ -602,6 +627,7 @@ int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
 void ygpu_destroy(ygpu_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->counted) gCtxPerDevice[ctx->device & 63]--;
     if (ctx->stream) {
         hipSetDevice(ctx->device);
         if (ctx->sharedIndex) { ctx->dBases.p = nullptr; ctx->dBases.cap = 0; ctx->dSO.p = nullptr; ctx->dSO.cap = 0; ctx->dROA.p = nullptr; ctx->dROA.cap = 0; }
@@ -643,7 +669,7 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
         HIPCHK(hipMemcpyAsync(ctx->dFwd.p, b->codes + base0, ctx->totalBases, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->dReadOff.p, ctx->hReadOff.data(), 4ull * (n + 1), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->dKmerOff.p, ctx->hKmerOff.data(), 4ull * (2 * n + 1), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_revcomp, dim3(n), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->dReadOff.as<uint32_t>(), n);
+        KL(k_revcomp, dim3(n), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->dReadOff.as<uint32_t>(), n);
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -725,8 +751,8 @@ int ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, co
     HIPCHK(hipSetDevice(ctx->device));
     for (uint32_t k = 0; k < n; k++) if (problems[k].read >= ctx->nReads || problems[k].mode > 3) { ctx->err = "bad DP problem"; return YGPU_EINVAL; }
     uint32_t *cnt = ctx->counters.as<uint32_t>();
-    int listCap, front, genCap; alignDims(ctx, listCap, front, genCap); listCap = 64;     // no frame stack needed here
-    const size_t per = alignScratchBytes(ctx->maxQ, listCap, genCap);
+    int listCap, front, genCap, traceRows; alignDims(ctx, listCap, front, genCap, traceRows); listCap = 64;     // no frame stack needed here
+    const size_t per = alignScratchBytes(ctx->maxQ, traceRows, listCap, genCap);
     const unsigned waves = (unsigned)std::min<uint64_t>(std::max<uint32_t>(n, 1u), (uint64_t)ctx->nCU * 4);
     uint32_t opsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)n * (2ull * ctx->maxQ + 64));
     ENSURE(ctx->scratchAlign, per * waves); ENSURE(ctx->dpProbs, sizeof(ygpu_dp_problem) * (uint64_t)(n + 1)); ENSURE(ctx->dpRes, sizeof(ygpu_dp_result) * (uint64_t)(n + 1)); ENSURE(ctx->dpOps, 4ull * opsCap + 64);
@@ -734,9 +760,9 @@ int ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, co
     HIPCHK(hipMemsetAsync(cnt + CNT_QDP, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->dpRes.p, 0, sizeof(ygpu_dp_result) * (uint64_t)(n + 1), ctx->stream));
     DPBatchArgs A; A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = devBatch(ctx); A.probs = ctx->dpProbs.as<ygpu_dp_problem>(); A.n = n; A.queueHead = cnt + CNT_QDP;
-    A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per; A.maxQ = ctx->maxQ; A.listCap = listCap; A.genCap = genCap;
+    A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per; A.maxQ = ctx->maxQ; A.listCap = listCap; A.genCap = genCap; A.traceRows = traceRows;
     A.res = ctx->dpRes.as<ygpu_dp_result>(); A.ops = ctx->dpOps.as<uint32_t>(); A.opsCount = cnt + CNT_DPOPS; A.opsCap = opsCap; A.errFlag = ctx->errFlag.as<int>();
-    if (n) hipLaunchKernelGGL(k_dp_batch, dim3(waves), dim3(64), 0, ctx->stream, A);
+    if (n) KL(k_dp_batch, dim3(waves), dim3(64), 0, ctx->stream, A);
     uint32_t no = 0, ef = 0; int rc = fetchU32(ctx, cnt + CNT_DPOPS, &no); if (rc) return rc; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
     if (ef) { char b[64]; snprintf(b, sizeof b, "dp batch failed with device error %u", ef); ctx->err = b; return YGPU_EINTERNAL; }
     ctx->hDpRes.resize(n); ctx->hDpOps.resize(no);

@@ -80,10 +80,11 @@ int parseArgs(int argc, char **argv, Args &a)
         else if (is("-PSS")) { if (!parseFloat(val(), "-PSS", a.FBS_PSScore)) return 2; }
         else if (is("-I")) { if (!parseInt(val(), "-I", a.maxIntron)) return 2; }          // experimental builds of the reference, Main.c:418-435
         else if (is("-R")) { if (!parseInt(val(), "-R", a.minRawScore)) return 2; }
-        else if (is("-gpus")) { if (!parseInt(val(), "-gpus", a.gpus)) return 2; }
-        else if (is("-ctx")) { if (!parseInt(val(), "-ctx", a.ctxPerGpu)) return 2; }
+        else if (is("-gpus")) { if (!parseInt(val(), "-gpus", a.gpus)) return 2; if (a.gpus < 1) { fprintf(stderr, "-gpus must be at least 1.\n\n"); usage(stderr); return 2; } }
+        else if (is("-ctx")) { if (!parseInt(val(), "-ctx", a.ctxPerGpu)) return 2; if (a.ctxPerGpu < 1 || a.ctxPerGpu > 8) { fprintf(stderr, "-ctx must be between 1 and 8.\n\n"); usage(stderr); return 2; } }
         else if (is("-device")) { if (!parseInt(val(), "-device", a.device)) return 2; }
-        else if (is("-batch")) { if (!parseInt(val(), "-batch", a.batchReads)) return 2; }
+        else if (is("-batch")) { if (!parseInt(val(), "-batch", a.batchReads)) return 2;
+                                 if (a.batchReads < 1 || a.batchReads > 65536) { fprintf(stderr, "-batch must be between 1 and 65536 (reads per device batch).\n\n"); usage(stderr); return 2; } }
         else { fprintf(stderr, "%s is not a valid option.\n\n", k); usage(stderr); return 2; }
     }
     a.query = query; a.index = index && !query;

@@ -118,7 +118,7 @@ int runQueries(Args &a, FILE *log)
     Args &A = S->args;
     FILE *out = (A.ofileName == "stdout") ? stdout : fopen(A.ofileName.c_str(), "w");
     if (!out) { fprintf(log, "Failure to open output file: %s.\n", A.ofileName.c_str()); return 1; }
-    fputs(S->header.c_str(), out);
+    if (fputs(S->header.c_str(), out) < 0) { fprintf(log, "Failure writing the output file.\n"); return 1; }
     ygpu_params P; paramsFromArgs(A, P);
     ygpu_index_view V; yaha_session_index_view(S.get(), &V);
     // -gpus N devices x -ctx M contexts per device (default 2: while one context's batch is in a latency-bound device stage the other
@@ -130,54 +130,63 @@ int runQueries(Args &a, FILE *log)
         int rc = (d % perDev == 0) ? ygpu_init(dev, &V, &P, &ctx[d]) : ygpu_clone(ctx[d - d % perDev], &ctx[d]);
         if (rc != 0) { fprintf(log, "ygpu_init(device %d) failed: %d %s\n", dev, rc, ctx[d] ? ygpu_last_error(ctx[d]) : ""); return 1; }
     }
-    // Three stages, batches handed over through bounded queues, a ticket ordering the output (= the reference's -t 1 order):
-    //   readers    (2 threads)         scan the input text (serial, under a lock, as in the reference, Query.c:105-214), then convert to codes
-    //                                  and pack the batch outside the lock;
+    // Five stages, batches handed over through bounded queues, a ticket ordering the output (= the reference's -t 1 order):
+    //   splitter   (1 thread)          record boundaries of the memory-mapped / block-read input (memchr; reader.cpp) -- the only serial part;
+    //   parsers    (a few threads)     id, sequence, quality, codes, reverse complement and the skip rules of one batch of records;
     //   contexts   (1 thread each)     upload, run the hot path, collect, copy the results out of the context's buffers;
     //   formatters (-t threads)        OQC/FBS filter and SAM text of one whole batch each; whoever completes the next ticket writes.
-    // So the device never waits for parsing or formatting unless those stages as a whole are slower than it.
-    struct Batch { uint64_t ticket = 0; std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
-                   std::vector<uint32_t> clumpStart, ops; std::vector<ygpu_clump> clumps; uint64_t nClumps = 0, nOps = 0; bool failed = false; double tRead = 0, tDev = 0; };
+    // So the device never waits for parsing or formatting unless those stages as a whole are slower than it.  The first failure (a device
+    // error, a write error) stops the run: nothing after the last complete batch before it is written, and the exit code is 1.
+    struct Batch { uint64_t ticket = 0; std::vector<Span> spans; std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
+                   std::vector<uint32_t> clumpStart, ops; std::vector<ygpu_clump> clumps; uint64_t nClumps = 0, nOps = 0; double tRead = 0, tDev = 0; };
     typedef std::unique_ptr<Batch> BatchP;
-    // -t is the reference's thread count and is echoed in @PG; the formatter pool takes that many threads, and at least a few (the reference's
-    // default of 1 would make SAM formatting, ~25 us of CPU a read, the limit at a tenth of the device's rate)
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nReaders = 2, nFmt = std::max(std::max(1, A.numThreads), std::min(8, std::max(1, hw / 4)));
-    StageQueue<BatchP> inQ((size_t)ngpu + 2, nReaders), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu);
-    std::mutex rdMu, outMu; uint64_t nextTicket = 0, nextOut = 0; bool eof = false; std::atomic<int> rcAll(0);
+    // -t is the reference's thread count and is echoed in @PG; the formatter pool takes that many threads, and at least enough for the devices in use
+    // (OQC + SAM text cost ~15-20 us of CPU a read; one MI355X delivers ~0.2 M reads/s)
+    const int hw = std::max(1, (int)std::thread::hardware_concurrency()), nDev = std::max(1, A.gpus);
+    const int nParse = std::max(1, std::min(std::min(8, 2 * nDev), hw / 2)), nFmt = std::max(std::max(1, A.numThreads), std::min(std::max(1, hw / 2), 8 * nDev));
+    StageQueue<BatchP> parseQ((size_t)nParse + 2, 1), inQ((size_t)ngpu + 2, nParse), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu + nParse);
+    std::mutex outMu; uint64_t nextOut = 0; std::atomic<bool> stop(false); std::atomic<int> rcAll(0);
     std::map<uint64_t, std::string> done;
     const bool timing = getenv("YAHA_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto reader = [&]() {
-        for (;;) {
-            BatchP b(new Batch); const double t0 = now();
-            {
-                std::lock_guard<std::mutex> lk(rdMu);
-                if (eof) break;
-                Read r;
-                while ((int)b->reads.size() < A.batchReads && S->reader.nextRaw(r)) b->reads.push_back(std::move(r));
-                if ((int)b->reads.size() < A.batchReads) eof = true;
-                if (b->reads.empty()) break;
-                b->ticket = nextTicket++;
-            }
-            b->offsets.assign(1, 0);
-            for (auto &r : b->reads) { ReadReader::finish(r); b->codes.insert(b->codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); b->offsets.push_back(b->codes.size()); }
-            b->tRead = now() - t0;
-            inQ.push(std::move(b));
+    auto fail = [&](const char *what) { if (!stop.exchange(true)) fprintf(log, "%s -- stopping; the output ends with the last batch completed before this one.\n", what); rcAll = 1; };
+    auto splitter = [&]() {
+        uint64_t ticket = 0;
+        while (!stop) {
+            BatchP b(new Batch);
+            if (S->reader.split.nextSpans((size_t)A.batchReads, b->spans) == 0) break;
+            b->ticket = ticket++;
+            parseQ.push(std::move(b));
         }
-        inQ.producerDone();
+        parseQ.producerDone();
+    };
+    auto parser = [&]() {
+        BatchP b;
+        while (parseQ.pop(b)) {
+            if (!stop) {
+                const double t0 = now();
+                b->reads.reserve(b->spans.size()); b->offsets.assign(1, 0); Read r; size_t bases = 0;
+                for (auto &sp : b->spans) if (parseSpan(sp, S->reader.fastq, S->reader.maxQueryLength, S->reader.wordLen, r)) { bases += r.fwdCodes.size(); b->reads.push_back(std::move(r)); }
+                b->codes.resize(bases); size_t o = 0;
+                for (auto &rd : b->reads) { memcpy(b->codes.data() + o, rd.fwdCodes.data(), rd.fwdCodes.size()); o += rd.fwdCodes.size(); b->offsets.push_back(o); }
+                std::vector<Span>().swap(b->spans);
+                b->tRead = now() - t0;
+            }
+            if (b->reads.empty()) fmtQ.push(std::move(b)); else inQ.push(std::move(b));      // a batch whose records were all skipped still takes its place in the output order
+        }
+        inQ.producerDone(); fmtQ.producerDone();
     };
     auto device = [&](int d) {
         BatchP b;
         while (inQ.pop(b)) {
+            if (stop) continue;
             const double t0 = now();
             ygpu_read_batch rb{(uint32_t)b->reads.size(), b->codes.data(), b->offsets.data()}; ygpu_result_batch res;
             int rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc == 0) rc = ygpu_collect(ctx[d], &res);
-            if (rc != 0) { fprintf(log, "device %d: hot path failed (%d): %s\n", d, rc, ygpu_last_error(ctx[d])); rcAll = 1; b->failed = true; }
-            else {   // the context's result buffers are reused by its next batch
-                b->clumpStart.assign(res.clump_start, res.clump_start + res.n_reads + 1); b->clumps.assign(res.clumps, res.clumps + res.n_clumps); b->ops.assign(res.ops, res.ops + res.n_ops);
-                b->nClumps = res.n_clumps; b->nOps = res.n_ops;
-            }
+            if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, ygpu_last_error(ctx[d])); fail(m); continue; }
+            // the context's result buffers are reused by its next batch
+            b->clumpStart.assign(res.clump_start, res.clump_start + res.n_reads + 1); b->clumps.assign(res.clumps, res.clumps + res.n_clumps); b->ops.assign(res.ops, res.ops + res.n_ops);
+            b->nClumps = res.n_clumps; b->nOps = res.n_ops;
             std::vector<uint8_t>().swap(b->codes);
             b->tDev = now() - t0;
             fmtQ.push(std::move(b));
@@ -188,29 +197,35 @@ int runQueries(Args &a, FILE *log)
         yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs; local.genome.maxROff = S->genome.maxROff;
         BatchP b;
         while (fmtQ.pop(b)) {
+            if (stop) continue;
             const double t0 = now(); std::string text;
-            if (!b->failed) {
+            if (!b->reads.empty()) {
                 ygpu_result_batch res; memset(&res, 0, sizeof res);
                 res.n_reads = (uint32_t)b->reads.size(); res.clump_start = b->clumpStart.data(); res.clumps = b->clumps.data(); res.ops = b->ops.data(); res.n_clumps = b->nClumps; res.n_ops = b->nOps;
                 local.reads.swap(b->reads); formatBatch(&local, &res, text, 1); local.reads.swap(b->reads);
             }
-            if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  read+convert %.1f  device (upload, run, collect, copy) %.1f  format %.1f ms\n", (unsigned long long)b->ticket, b->reads.size(), b->tRead, b->tDev, now() - t0);
+            if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  parse %.1f  device (upload, run, collect, copy) %.1f  format %.1f ms\n", (unsigned long long)b->ticket, b->reads.size(), b->tRead, b->tDev, now() - t0);
             std::unique_lock<std::mutex> lk(outMu);
             done[b->ticket] = std::move(text);
-            while (!done.empty() && done.begin()->first == nextOut) { fputs(done.begin()->second.c_str(), out); done.erase(done.begin()); nextOut++; }
+            while (!stop && !done.empty() && done.begin()->first == nextOut) {
+                const std::string &t = done.begin()->second;
+                if (!t.empty() && fwrite(t.data(), 1, t.size(), out) != t.size()) { fail("Failure writing the output file"); break; }
+                done.erase(done.begin()); nextOut++;
+            }
         }
     };
     const double tStart = now();
-    if (timing) fprintf(stderr, "[yaha] contexts ready\n");
+    if (timing) fprintf(stderr, "[yaha] contexts ready: %d parser, %d formatter threads\n", nParse, nFmt);
     std::vector<std::thread> th;
-    for (int i = 0; i < nReaders; i++) th.emplace_back(reader);
+    th.emplace_back(splitter);
+    for (int i = 0; i < nParse; i++) th.emplace_back(parser);
     for (int d = 0; d < ngpu; d++) th.emplace_back(device, d);
     for (int i = 0; i < nFmt; i++) th.emplace_back(formatter);
     for (auto &x : th) x.join();
-    for (auto &kv : done) fputs(kv.second.c_str(), out);
     const double tDone = now();
     for (int d = ngpu - 1; d >= 0; d--) ygpu_destroy(ctx[d]);                 // clones before their parents
-    if (out != stdout) fclose(out); else fflush(out);
+    if (fflush(out) != 0 || ferror(out)) { if (!stop) fprintf(log, "Failure writing the output file.\n"); rcAll = 1; }
+    if (out != stdout && fclose(out) != 0) { fprintf(log, "Failure closing the output file.\n"); rcAll = 1; }
     if (timing) fprintf(stderr, "[yaha] batches %.1f ms, teardown %.1f ms\n", tDone - tStart, now() - tDone);
     return rcAll;
 }
@@ -241,7 +256,7 @@ int yaha_session_next_batch(yaha_session *s, uint32_t max_reads, ygpu_read_batch
 {
     s->reads.clear(); s->codes.clear(); s->offsets.assign(1, 0);
     Read r;
-    while (s->reads.size() < max_reads && s->reader.next(r)) { s->codes.insert(s->codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); s->offsets.push_back(s->codes.size()); s->reads.push_back(std::move(r)); }
+    while (s->reads.size() < max_reads && s->reader.next(r)) { s->codes.insert(s->codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); s->offsets.push_back(s->codes.size()); s->reads.push_back(std::move(r)); r = Read(); }
     b->n_reads = (uint32_t)s->reads.size(); b->codes = s->codes.data(); b->offsets = s->offsets.data(); return 0;
 }
 int yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **text, size_t *len)

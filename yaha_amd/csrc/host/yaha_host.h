@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include <memory>
 #include "../../../include/yaha_hip.h"
 
 namespace yaha {
@@ -73,13 +74,31 @@ std::string samHeader(const Args &a, const Genome &g);                      // A
 
 // ---- reads (reference Query.c:63-228, QueryState.c:172-187) ---------------------------------------------
 struct Read {
-    std::string id; std::string fwd, rev; std::vector<uint8_t> fwdCodes, revCodes; std::string qual;
+    std::string id; std::string fwd, rev; std::vector<uint8_t> fwdCodes; std::string qual;
     int len() const { return (int)fwd.size(); }
 };
-struct ReadReader {
-    FILE *f = nullptr; bool fastq = false; int maxQueryLength = 32000; int wordLen = 15; bool ownFile = false;
+// One record of the input as byte ranges (offsets from base): produced serially by ReadSplitter, parsed by any thread.
+struct Span { std::shared_ptr<std::vector<char>> hold; const char *base = nullptr; size_t idLen = 0, seq0 = 0, seqEnd = 0, qual0 = 0, qualEnd = 0; };
+// Record boundaries of a FASTA/FASTQ stream (memory-mapped file, or stdin/pipe read in blocks); see reader.cpp for the rules.
+struct ReadSplitter {
+    size_t blockBytes = 32u << 20;                       // streaming sources are read in blocks of this size
+    int fd = -1; bool ownFd = false; const char *mapPtr = nullptr; size_t mapLen = 0;
+    std::shared_ptr<std::vector<char>> chunk; const char *cur = nullptr, *end = nullptr; bool atEof = true, done = true, fastq = false;
     bool open(const char *path, std::string &err);       // peeks '>' / '@' (Query.c:63-74)
-    bool next(Read &r); bool nextRaw(Read &r); static void finish(Read &r);                                   // readNextQuery; false at EOF
+    void close();
+    bool nextSpan(Span &s);                              // false at the end of input (an empty sequence ends it, Query.c:216-217)
+    size_t nextSpans(size_t maxSpans, std::vector<Span> &out);
+    ~ReadSplitter() { close(); }
+  private:
+    void fill(); bool seek(char c, size_t *pos); bool seekNlAt(size_t *pos);
+};
+// id / sequence / quality / codes of one record; false = the record is skipped (with the reference's warning on stderr)
+bool parseSpan(const Span &s, bool fastq, int maxQueryLength, int wordLen, Read &r);
+void finishRead(Read &r);                                // 4-bit codes + reverse-complement text from r.fwd
+struct ReadReader {                                      // sequential reader: one accepted read per call
+    ReadSplitter split; bool fastq = false; int maxQueryLength = 32000; int wordLen = 15;
+    bool open(const char *path, std::string &err);
+    bool next(Read &r);                                  // readNextQuery; false at EOF
     void close();
 };
 void seedFromRead(const Read &r, RandState &rs);          // generateRandomSeed
