@@ -31,6 +31,7 @@ extern "C" {
 #define YGPU_ENOMEM      (-3)   /* device or host allocation failed                      */
 #define YGPU_EOVERFLOW   (-4)   /* a device arena overflowed even after regrowth         */
 #define YGPU_EINTERNAL   (-5)
+#define YGPU_EBUSY       (-6)   /* ygpu_submit while the context's previous ticket is still open */
 
 /* Alignment parameters: the subset of AlignmentArgs_t (Math.h:257-334) the hot path reads, after
  * postProcessAlignmentArgs (AlignArgs.c:108-169) has filled the derived ones. */
@@ -126,6 +127,15 @@ int  ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *batch);
 int  ygpu_run(ygpu_ctx *ctx);
 /* Copy results of the last ygpu_run to host memory owned by the context. */
 int  ygpu_collect(ygpu_ctx *ctx, ygpu_result_batch *out);
+/* Asynchronous form: ygpu_submit hands the batch to the context and returns at once; the context's own worker thread does
+ * upload + run + collect; ygpu_wait blocks until the ticket is complete and returns the results (ygpu_poll: 1 = complete, 0 = still running).
+ * One host thread can so keep several contexts (devices) busy -- the reference needs one thread per QueryState for that (Query.c:642-684).
+ * One open ticket per context: the caller keeps the batch alive until ygpu_wait returns, results stay valid until the next ygpu_submit /
+ * ygpu_run on the context; a second ygpu_submit before ygpu_wait returns YGPU_EBUSY. */
+typedef uint64_t ygpu_ticket;
+int  ygpu_submit(ygpu_ctx *ctx, const ygpu_read_batch *batch, ygpu_ticket *ticket);
+int  ygpu_poll(ygpu_ctx *ctx, ygpu_ticket ticket);
+int  ygpu_wait(ygpu_ctx *ctx, ygpu_ticket ticket, ygpu_result_batch *out);
 /* Elapsed device time of the last ygpu_run in milliseconds, total and per kernel family (HIP events on the
  * context's stream). names/ms arrays are owned by the context. */
 int  ygpu_last_timing(ygpu_ctx *ctx, float *total_ms, int *n_stages, const char *const **names, const float **ms);
@@ -167,6 +177,14 @@ typedef struct ygpu_dp_result {
 } ygpu_dp_result;
 int  ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n,
                    const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops);
+/* The same with the kernel family chosen explicitly.  AUTO = the kernels ygpu_run would use for these parameters: at the default band (-BW 5, -G >= 10)
+ * the lane kernels -- k_ext_rows + k_ext_trace for extensions (findAGSForward/BackwardExtension, SW.cpp:479-533), the pure-diagonal shortcut and
+ * k_gap_lanes / k_gap_wave for gap fills (findAGSAlignment[Banded], SW.cpp:462-475) -- otherwise the wave-per-problem DP.  WAVE = always the
+ * wave-per-problem DP (dp_wave.h).  LANES_CAREFUL = the lane kernels with the k_ext_rows instantiation that serves splitClump's careful extensions
+ * (SW.cpp:553-788 call the same findAGSExtension).  ygpu_dp_batch = AUTO. */
+enum { YGPU_DP_KERNELS_AUTO = 0, YGPU_DP_KERNELS_WAVE = 1, YGPU_DP_KERNELS_LANES = 2, YGPU_DP_KERNELS_LANES_CAREFUL = 3 };
+int  ygpu_dp_batch_ex(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, int kernels,
+                      const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops);
 
 /* ---- host stages around the hot path (SURVEY.md 8(f) rows restated on the host) ------------------------
  * A session owns what processQueryFile (Query.c:551-709) sets up: parsed arguments, the mmap'ed .nib2 and

@@ -42,3 +42,54 @@ def dp_problems_from_chain(s, b, limit=2000, seed=1):
             probs.append(ya.DPProblem(read, strand, ya.DP_EXT_FWD, fn[2] + 1, fl, 0, ero + 1))
     random.Random(seed).shuffle(probs)
     return probs[:limit]
+
+
+def read_fasta(path):
+    names, seqs, cur = [], [], []
+    for line in open(path):
+        if line.startswith(">"):
+            if cur:
+                seqs.append("".join(cur))
+                cur = []
+            names.append(line[1:].split()[0])
+        else:
+            cur.append(line.strip())
+    seqs.append("".join(cur))
+    return names, seqs
+
+
+def write_long_indel_reads(genome_fa, out, n, seed, max_del=1250, junk=0, flank=450):
+    """Reads that carry ONE long deletion (up to max_del reference bases) or insertion, with two substitutions right at the junction so that the
+    seeds stop short of it and the gap between the chained fragments needs a DP whose strip is hundreds of columns wide (needs a large -G);
+    junk > 0 additionally drops that many random query bases into the junction (a gap fill with many rows AND many columns; needs -MD >= junk)."""
+    rnd = random.Random(seed)
+    names, seqs = read_fasta(genome_fa)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+    def mut(s, k):
+        s = list(s)
+        for p in rnd.sample(range(len(s)), k):
+            s[p] = rnd.choice([c for c in "ACGT" if c != s[p]])
+        return "".join(s)
+    with open(out, "w") as f:
+        for i in range(n):
+            si = rnd.randrange(len(seqs))
+            g = seqs[si]
+            d = rnd.randrange(max_del // 2, max_del)
+            fl, fr = flank - 30, flank + 30
+            a = rnd.randrange(0, len(g) - fl - fr - 300 - d)
+            left, right = g[a:a + fl], None
+            if i % 3 != 2:                                       # deletion in the read
+                right = g[a + fl + d:a + fl + d + fr]
+                mid = "".join(rnd.choice("ACGT") for _ in range(junk))
+            else:                                                # insertion in the read
+                right = g[a + fl:a + fl + fr]
+                mid = "".join(rnd.choice("ACGT") for _ in range(d))
+            left = mut(left[:-9], fl // 100) + mut(left[-9:], 2)
+            right = mut(right[:9], 2) + mut(right[9:], fr // 100)
+            s = left + mid + right
+            if "N" in s:
+                s = s.replace("N", "A")
+            if rnd.random() < 0.5:
+                s = "".join(comp[c] for c in reversed(s))
+            f.write(">indel_%s_%d_%d_%d\n%s\n" % (names[si], a, d, i, s))

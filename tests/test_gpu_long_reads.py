@@ -1,0 +1,115 @@
+"""GPU tier, the BASELINE configs that need long reads on a human-like genome at the reference's default seed length (-L 15):
+
+  * config 5 -- CGR-like contigs of ~30 kbp (2..6 rearranged segments: deletions, tandem duplications, inversions, distal pieces) at 0 / 1 / 4 %
+    divergence, run with -OQC Y -FBS Y (testdata/README.txt:25-29), plus one read of exactly 32 000 bases (the longest the reference takes,
+    AlignArgs.c:82) and one of 32 001 (skipped with a warning, Query.c:148-156);
+  * config 3 -- 10 kbp reads at the realised divergence of the bundled "E10" sets (3.4 %).
+
+The whole `yaha` command line of this repo (HIP hot path) against the REAL reference binary when it travelled with the snapshot (oracle/_ref/yaha),
+else against the oracle port.  The reference writes the reads of a multi-threaded run in completion order: records are compared per
+read, in their order within the read; this repo's output must also be in input order.
+"""
+import os
+import subprocess
+
+import pytest
+
+import oracle
+import yaha_amd as ya
+from conftest import ROOT, strip_pg
+
+pytestmark = pytest.mark.gpu
+SIM = os.path.join(ROOT, "tools", "yaha_sim")
+
+
+@pytest.fixture(scope="module")
+def g40(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("g40"))
+    g = os.path.join(d, "g.fa")
+    subprocess.check_call([SIM, "genome", "--seed", "1234", "--out", g, "--seqs", "12", "--len", "40000000", "--repeat-frac", "0.45", "--nrun", "3", "--lowcomplex", "6"])
+    ya.build_index(["-g", g, "-L", "15"])
+    return d, g, os.path.join(d, "g.X15_01_65525S")
+
+
+def by_read(lines):
+    """header lines, {QNAME: [records in order]}, QNAMEs in order of first appearance"""
+    head, recs, order = [], {}, []
+    for l in lines:
+        if not l:
+            continue
+        if l.startswith("@"):
+            head.append(l)
+            continue
+        q = l.split("\t", 1)[0]
+        if q not in recs:
+            recs[q] = []
+            order.append(q)
+        recs[q].append(l)
+    return head, recs, order
+
+
+def referee(index, reads, extra, out):
+    """SAM of the real reference (all host cores) or, without the binary, of the oracle port through the product's host stages."""
+    if oracle.have_reference():
+        oracle.run_reference(["-x", index, "-q", reads, "-osh", out, "-t", str(min(64, os.cpu_count() or 1))] + extra)
+        return strip_pg(open(out, newline="").read())
+    text = []
+    with ya.Session(["-x", index, "-q", reads, "-osh", "stdout"] + extra) as s:
+        text.append(s.header())
+        while True:
+            b = s.next_batch(64)
+            if b.n_reads == 0:
+                break
+            r, _own = oracle.run(s.index, s.params, b, threads=min(64, os.cpu_count() or 1))
+            text.append(s.emit(r))
+    return strip_pg("".join(text))
+
+
+def names_in(path):
+    return [l[1:].split()[0].rstrip("\n") for l in open(path) if l.startswith(">")]
+
+
+def check(index, reads, extra, tmp_path, min_records, skipped=()):
+    mine_out, ref_out = str(tmp_path / "mine.sam"), str(tmp_path / "ref.sam")
+    subprocess.check_call([ya.CLI_PATH, "-x", index, "-q", reads, "-osh", mine_out, "-t", "8", "-batch", "32"] + extra, stderr=subprocess.DEVNULL)
+    mh, mr, morder = by_read(strip_pg(open(mine_out, newline="").read()))
+    rh, rr, _ = by_read(referee(index, reads, extra, ref_out))
+    assert mh == rh
+    assert sum(len(v) for v in rr.values()) >= min_records
+    assert set(mr) == set(rr), "different sets of aligned reads"
+    bad = [q for q in rr if rr[q] != mr[q]]
+    assert not bad, "records differ for %d reads, e.g. %s" % (len(bad), bad[0])
+    pos = {q: i for i, q in enumerate(names_in(reads))}
+    assert [pos[q] for q in morder] == sorted(pos[q] for q in morder), "output is not in input order"
+    for q in skipped:
+        assert q not in mr and q not in rr
+    return mr
+
+
+@pytest.mark.parametrize("div", ["0", "0.01", "0.04"])
+def test_cgr_like_30kbp_contigs_oqc_fbs(g40, tmp_path, div):
+    d, g, index = g40
+    reads = str(tmp_path / "cgr.fa")
+    subprocess.check_call([SIM, "reads", "--genome", g, "--out", reads, "--seed", "77", "--n", "40", "--len", "30000", "--div", div, "--cgr", "5"])
+    skipped = ()
+    if div == "0.01":
+        # the length limits: exactly 32 000 bases is aligned, 32 001 is skipped
+        seq = "".join(l.strip() for l in open(g).read(3000000).split(">")[1].split("\n")[1:])
+        a = next(k for k in range(100000, 2000000, 50000) if "N" not in seq[k:k + 32000])
+        b = next(k for k in range(a + 50000, 2500000, 50000) if "N" not in seq[k:k + 32001])
+        with open(reads, "a") as f:
+            f.write(">len32000\n%s\n>len32001\n%s\n" % (seq[a:a + 32000], seq[b:b + 32001]))
+        skipped = ("len32001",)
+    mr = check(index, reads, ["-OQC", "Y", "-FBS", "Y"], tmp_path, min_records=80, skipped=skipped)
+    if div == "0.01":
+        assert "len32000" in mr and "\t32000M\t" in mr["len32000"][-1]
+    # split contigs: most reads come back as several primary pieces (YP > 1)
+    multi = sum(1 for v in mr.values() if any("YP:i:1" not in l for l in v))
+    assert multi >= 20
+
+
+def test_10kbp_reads_at_default_seed_length(g40, tmp_path):
+    d, g, index = g40
+    reads = str(tmp_path / "r10k.fa")
+    subprocess.check_call([SIM, "reads", "--genome", g, "--out", reads, "--seed", "78", "--n", "192", "--len", "10000", "--div", "0.034"])
+    check(index, reads, [], tmp_path, min_records=192)

@@ -17,25 +17,42 @@ def frag_tuples(f, n):
     return [(f[i].startRefOff, f[i].startQueryOff, f[i].endQueryOff, f[i].refLen, f[i].read_strand) for i in range(n)]
 
 
-@pytest.mark.parametrize("reads,extra", [("r1k.fa", []), ("rchim.fa", ["-GOC", "0", "-GEC", "1"]), ("rq.fq", ["-BW", "7", "-X", "40"]), ("r10k.fa", ["-G", "30", "-BW", "12"])])
+def _dp_check(ctx, probs, exp, kernels):
+    res, ops, nops = ctx.dp_batch(probs, kernels)
+    bad = 0
+    for k, e in enumerate(exp):
+        r = res[k]
+        got = (r.score, r.addedQLen, r.addedRLen, tuple((ops[r.op_start + j] & 0xFFFF, chr((ops[r.op_start + j] >> 16) & 0xFF)) for j in range(r.n_ops)))
+        if got != e:
+            bad += 1
+            if bad <= 3:
+                p = probs[k]
+                print("MISMATCH kernels", kernels, (p.read, p.strand, p.mode, p.qOff, p.qLen, p.rLen, p.rOff), "\n got", got, "\n exp", e)
+    assert bad == 0, "%d of %d DP problems differ (kernel family %d)" % (bad, len(probs), kernels)
+
+
+# Every findAffineGapScore call (SW.cpp:798-1208, through findAGSAlignment[Banded] / findAGS{Forward,Backward}Extension, SW.cpp:462-533), one by one,
+# through EACH kernel family that can compute it: the wave-per-problem DP (dp_wave.h: every band width), and -- at the default band, where ygpu_run uses
+# them for all DP cells -- the lane kernels: k_ext_rows + k_ext_trace, the careful-extension instantiation of k_ext_rows, the pure-diagonal shortcut and
+# k_gap_lanes<16|32> / k_gap_wave.  -G 12 / -I 11 make the run caps bind inside the 21-column strip (k_ext_rows<CAPS>).
+@pytest.mark.parametrize("reads,extra", [("r1k.fa", []), ("rchim.fa", ["-GOC", "0", "-GEC", "1"]), ("rq.fq", ["-BW", "7", "-X", "40"]), ("r10k.fa", ["-G", "30", "-BW", "12"]),
+                                         ("r10k.fa", []), ("rchim.fa", ["-G", "12", "-I", "11"]), ("r1k.fa", ["-RC", "1", "-GOC", "9", "-GEC", "3", "-X", "9"])])
 def test_dp_batch_bit_exact(work, index11, reads, extra):
     with ya.Session(["-x", index11, "-q", os.path.join(work, reads)] + extra) as s:
         b = s.next_batch(200)
         probs = dp_problems_from_chain(s, b, limit=4000, seed=5)
         exp = oracle.dp_batch(s.index, s.params, b, probs)
+        lanes = s.params.bandWidth == 5 and s.params.maxGap >= 10
         with ya.Context(s.index, s.params) as ctx:
             ctx.upload(b)
-            res, ops, nops = ctx.dp_batch(probs)
-            bad = 0
-            for k, e in enumerate(exp):
-                r = res[k]
-                got = (r.score, r.addedQLen, r.addedRLen, tuple((ops[r.op_start + j] & 0xFFFF, chr((ops[r.op_start + j] >> 16) & 0xFF)) for j in range(r.n_ops)))
-                if got != e:
-                    bad += 1
-                    if bad <= 3:
-                        p = probs[k]
-                        print("MISMATCH", (p.read, p.strand, p.mode, p.qOff, p.qLen, p.rLen, p.rOff), "\n got", got, "\n exp", e)
-            assert bad == 0, "%d of %d DP problems differ" % (bad, len(probs))
+            _dp_check(ctx, probs, exp, ya.DP_KERNELS_WAVE)
+            _dp_check(ctx, probs, exp, ya.DP_KERNELS_AUTO)
+            if lanes:
+                _dp_check(ctx, probs, exp, ya.DP_KERNELS_LANES)
+                _dp_check(ctx, probs, exp, ya.DP_KERNELS_LANES_CAREFUL)
+            else:
+                with pytest.raises(RuntimeError):
+                    ctx.dp_batch(probs[:4], ya.DP_KERNELS_LANES)
 
 
 @pytest.mark.parametrize("reads,extra", [("r1k.fa", []), ("rchim.fa", ["-H", "20"]), ("r100.fa", []), ("r10k.fa", [])])
@@ -172,3 +189,42 @@ def test_live_reference_binary_on_fresh_human_like_reads(work, tmp_path):
     out = str(tmp_path / "mine.sam")
     subprocess.check_call([ya.CLI_PATH, "-x", idx, "-q", reads, "-osh", out, "-t", "4"], stderr=subprocess.DEVNULL)
     assert strip_pg(open(out).read()) == strip_pg(open(ref_out).read())
+
+
+# -G / -MD far beyond the goldens: gap fills whose strip is hundreds of columns wide and rows x columns exceeds the extension strip's footprint -- the wave
+# kernels' generic path with its scratch sized from the parameters (ygpu.hip alignDims).  The reference itself behaves oddly out there (16-bit fields
+# overflow); the oracle reproduces it (CPU tier: test_large_gap_parameters_match_the_live_reference) and the device has to as well.
+@pytest.mark.parametrize("extra,max_del,junk,flank", [(["-G", "1300"], 1250, 0, 3200), (["-G", "1300", "-GEC", "1", "-GOC", "2"], 1250, 0, 2000), (["-G", "450", "-MD", "200"], 420, 150, 1500),
+                                                      (["-G", "3000", "-MD", "400", "-BW", "8"], 2900, 300, 3500)])
+def test_large_gap_parameters(work, index11, tmp_path, extra, max_del, junk, flank):
+    from problems import write_long_indel_reads
+    reads = str(tmp_path / "indel.fa")
+    write_long_indel_reads(os.path.join(work, "genome_small.fa"), reads, 40, 11, max_del=max_del, junk=junk, flank=flank)
+    mine = device_pipeline(index11, reads, "-osh", extra, batch=64)
+    if oracle.have_reference():
+        ref_out = str(tmp_path / "ref.sam")
+        oracle.run_reference(["-x", index11, "-q", reads, "-osh", ref_out] + list(extra))
+        assert mine == strip_pg(open(ref_out).read())
+
+
+def test_async_tickets_one_host_thread_two_contexts(work, index11):
+    # ygpu_submit / ygpu_poll / ygpu_wait: this thread keeps two contexts busy; results equal the synchronous calls
+    import time
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r10k.fa")]) as s1, ya.Session(["-x", index11, "-q", os.path.join(work, "rchim.fa")]) as s2:
+        b1, b2 = s1.next_batch(300), s2.next_batch(300)
+        with ya.Context(s1.index, s1.params) as a:
+            a.upload(b1); a.run(); exp1 = ya.result_records(a.collect())
+            a.upload(b2); a.run(); exp2 = ya.result_records(a.collect())
+            b = ya.Context(s1.index, s1.params, parent=a)
+            for _ in range(2):
+                t1, t2 = a.submit(b1), b.submit(b2)
+                with pytest.raises(RuntimeError):
+                    a.submit(b2)                                    # one open ticket per context
+                while not (a.poll(t1) == 1 and b.poll(t2) == 1):
+                    time.sleep(0.001)
+                assert ya.result_records(a.wait(t1)) == exp1 and ya.result_records(b.wait(t2)) == exp2
+            with pytest.raises(RuntimeError):
+                a.wait(t1)                                          # the ticket is closed
+            t = a.submit(b2)
+            assert ya.result_records(a.wait(t)) == exp2             # wait without polling
+            b.close()

@@ -149,3 +149,25 @@ def test_reader_quirks_match_the_live_reference(work, index11, tmp_path, kind, s
     th.join()
     # the @PG-free output is identical; the reference's file name is in @PG only
     assert got == want
+
+
+LARGE_GAP_CASES = [(["-G", "1300"], 1250, 0, 3200), (["-G", "1300", "-GEC", "1", "-GOC", "2"], 1250, 0, 2000), (["-G", "450", "-MD", "200"], 420, 150, 1500), (["-G", "3000", "-MD", "400", "-BW", "8"], 2900, 300, 3500)]
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref/yaha not built")
+@pytest.mark.parametrize("extra,max_del,junk,flank", LARGE_GAP_CASES)
+def test_large_gap_parameters_match_the_live_reference(work, index11, tmp_path, extra, max_del, junk, flank):
+    # -G far beyond the goldens' 80: gap fills whose DP strip is hundreds of columns wide (the wave kernels' generic path on the device).  With the
+    # default gap costs scoreClump splits such an alignment again (a 1 000-base deletion costs 2 005); with -GEC 0 it survives as one 1 000D op.
+    import re
+    from problems import write_long_indel_reads
+    reads = str(tmp_path / "indel.fa")
+    write_long_indel_reads(os.path.join(work, "genome_small.fa"), reads, 40, 11, max_del=max_del, junk=junk, flank=flank)
+    ref_out = str(tmp_path / "ref.sam")
+    oracle.run_reference(["-x", index11, "-q", reads, "-osh", ref_out] + extra)
+    want = strip_pg(open(ref_out).read())
+    with ya.Session(["-x", index11, "-q", reads] + extra) as s:
+        b = s.next_batch(100)
+        r, _own = oracle.run(s.index, s.params, b, threads=4)
+        assert r.counters.dp_gap_cells > 40 * 4000                  # the wide gap fills really ran (strip width ~ the indel's length)
+    assert run_oracle_pipeline(index11, reads, "-osh", extra) == want

@@ -7,10 +7,11 @@
 //       a fraction F of bases overwritten by diverged copies of repeat families (Alu-like 300 bp,
 //       L1-like fragments of a 6 kbp consensus, microsatellites), optional N-runs, odd sequence lengths.
 //   yaha_sim reads  --seed S --genome g.fa --out r.fa --n N --len L --div D [--fastq] [--chimeric P]
-//                   [--withN P] [--edges]
+//                   [--withN P] [--edges] [--cgr K]
 //       wgsim-like reads: uniform position and strand, per-base divergence D with substitutions : indels
 //       = 3.3 : 1 and geometric indel lengths (p = 0.3); names carry the true locus.
 //       --chimeric P : fraction of reads built from two loci (deletion / inversion / distal) for OQC tests.
+//       --cgr K      : every read is a contig of 2 .. K+1 rearranged segments (CGR-like, testdata/README.txt:25-29).
 //       --edges      : additionally emit reads touching offset 0 and the last base of every sequence.
 #include <cstdint>
 #include <cstdio>
@@ -146,6 +147,7 @@ static int cmdReads(int argc, char **argv)
     double withN = atof(argval(argc, argv, "--withN", "0"));
     bool fastq = argflag(argc, argv, "--fastq"), edges = argflag(argc, argv, "--edges");
     int lenJitter = atoi(argval(argc, argv, "--len-jitter", "0"));
+    int cgr = atoi(argval(argc, argv, "--cgr", "0"));          // complex-rearrangement contigs: every read is 2 .. cgr+1 segments (deletions, tandem duplications, inversions, distal pieces)
     Genome g = readFasta(gpath);
     Rng r(seed);
     uint64_t total = 0; for (auto &s : g.seqs) total += s.size();
@@ -161,7 +163,27 @@ static int cmdReads(int argc, char **argv)
     for (uint64_t i = 0; i < n; i++) {
         int L = len + (lenJitter ? (int)r.below(2 * lenJitter + 1) - lenJitter : 0); if (L < 20) L = 20;
         char nm[160]; std::string seq;
-        if (chim > 0 && r.uni() < chim) {
+        if (cgr > 0) {
+            const int nseg = 2 + (int)r.below((uint64_t)cgr); std::vector<int> cut;
+            for (int k = 1; k < nseg; k++) cut.push_back(400 + (int)r.below((uint64_t)std::max(1, L - 800)));
+            cut.push_back(0); cut.push_back(L); std::sort(cut.begin(), cut.end());
+            int s0; size_t p0; pick(L, s0, p0); size_t anchor = p0; std::string all;
+            for (size_t k = 0; k + 1 < cut.size(); k++) {
+                const int pl = cut[k + 1] - cut[k]; if (pl <= 0) continue;
+                const double u = r.uni(); int sj = s0; size_t pj = anchor; bool inv = false;
+                const size_t slen = g.seqs[s0].size();
+                if (k == 0) pj = p0;
+                else if (u < 0.3) pj = std::min(anchor + 200 + r.below(8000), slen - pl);                                  // deletion
+                else if (u < 0.5) pj = anchor > (size_t)pl + 200 ? anchor - std::min<size_t>(anchor, 200 + r.below(3000)) : anchor;   // tandem duplication (steps back)
+                else if (u < 0.75) { pj = std::min(anchor + r.below(5000), slen - pl); inv = true; }                        // inversion
+                else pick(pl, sj, pj);                                                                                   // distal piece
+                if (pj + pl > g.seqs[sj].size()) pj = g.seqs[sj].size() - pl;
+                std::string piece = g.seqs[sj].substr(pj, pl); if (inv) piece = revcomp(piece);
+                all += piece; if (sj == s0) anchor = pj + pl;
+            }
+            seq = div > 0 ? mutate(r, all, div, 1.0 / 4.3) : all;
+            snprintf(nm, sizeof nm, "cgr_%s_%zu_%dseg_%llu", g.names[s0].c_str(), p0, nseg, (unsigned long long)i);
+        } else if (chim > 0 && r.uni() < chim) {
             int L1 = L / 4 + (int)r.below(L / 2), L2 = L - L1; int s1, s2; size_t p1, p2; pick(L1, s1, p1);
             double u = r.uni(); std::string a = g.seqs[s1].substr(p1, L1), b;
             if (u < 0.4 && p1 + L1 + 5000 + L2 < g.seqs[s1].size()) { s2 = s1; p2 = p1 + L1 + 100 + r.below(4000); b = g.seqs[s2].substr(p2, L2); }      // deletion

@@ -68,10 +68,11 @@ class DPResult(C.Structure):
 
 
 DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
+DP_KERNELS_AUTO, DP_KERNELS_WAVE, DP_KERNELS_LANES, DP_KERNELS_LANES_CAREFUL = 0, 1, 2, 3
 
 EXPORTS = (
     "ygpu_init", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_last_timing",
-    "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch",
+    "ygpu_submit", "ygpu_poll", "ygpu_wait", "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch", "ygpu_dp_batch_ex",
     "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
     "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit",
     "yaha_build_index", "yaha_main")
@@ -196,11 +197,24 @@ class Context:
         self._check(lib().ygpu_chain(self._h, C.byref(f), C.byref(s), C.byref(rs), C.byref(n)), "ygpu_chain")
         return f, s, rs, n.value
 
-    def dp_batch(self, problems):
+    def dp_batch(self, problems, kernels=DP_KERNELS_AUTO):
         arr = (DPProblem * len(problems))(*problems)
         res, ops, nops = C.POINTER(DPResult)(), C.POINTER(C.c_uint32)(), C.c_uint64()
-        self._check(lib().ygpu_dp_batch(self._h, arr, len(problems), C.byref(res), C.byref(ops), C.byref(nops)), "ygpu_dp_batch")
+        self._check(lib().ygpu_dp_batch_ex(self._h, arr, len(problems), kernels, C.byref(res), C.byref(ops), C.byref(nops)), "ygpu_dp_batch_ex")
         return res, ops, nops.value
+
+    def submit(self, batch):
+        t = C.c_uint64()
+        self._check(lib().ygpu_submit(self._h, C.byref(batch), C.byref(t)), "ygpu_submit")
+        return t.value
+
+    def poll(self, ticket):
+        return lib().ygpu_poll(self._h, C.c_uint64(ticket))
+
+    def wait(self, ticket):
+        r = ResultBatch()
+        self._check(lib().ygpu_wait(self._h, C.c_uint64(ticket), C.byref(r)), "ygpu_wait")
+        return r
 
     def close(self):
         if self._h:

@@ -22,12 +22,16 @@
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include "chain.h"
 #include "chain_lanes.h"
 #include "seed.h"
 #include "segsort.h"
 #include "phase_lanes.h"
 #include "split_lanes.h"
+#include "dp_stage.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
 
@@ -79,6 +83,8 @@ struct ygpu_ctx {
     // host results
     std::vector<uint32_t> hClumpStart, hOps, hClumpFragStart, hClumpRS, hDpOps; std::vector<ygpu_clump> hClumps; std::vector<ygpu_fragment> hFrags, hClumpFrags;
     std::vector<ygpu_dp_result> hDpRes; ygpu_counters hCounters{};
+    // asynchronous tickets (ygpu_submit / ygpu_wait): one worker thread per context, started on first use
+    std::thread worker; std::mutex aMu; std::condition_variable aCv; const ygpu_read_batch *aBatch = nullptr; uint64_t aTicket = 0; int aRc = 0; bool aOpen = false, aDone = false, aQuit = false; ygpu_result_batch aOut{};
     // timing
     hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N];
 };
@@ -627,6 +633,7 @@ int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
 void ygpu_destroy(ygpu_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->worker.joinable()) { { std::lock_guard<std::mutex> lk(ctx->aMu); ctx->aQuit = true; } ctx->aCv.notify_all(); ctx->worker.join(); }
     if (ctx->counted) gCtxPerDevice[ctx->device & 63]--;
     if (ctx->stream) {
         hipSetDevice(ctx->device);
@@ -707,6 +714,46 @@ int ygpu_collect(ygpu_ctx *ctx, ygpu_result_batch *out)
     return 0;
 }
 
+static void asyncWorker(ygpu_ctx *ctx)
+{
+    std::unique_lock<std::mutex> lk(ctx->aMu);
+    for (;;) {
+        ctx->aCv.wait(lk, [&] { return ctx->aQuit || (ctx->aOpen && !ctx->aDone && ctx->aBatch); });
+        if (ctx->aQuit) return;
+        const ygpu_read_batch *b = ctx->aBatch; ctx->aBatch = nullptr;
+        lk.unlock();
+        int rc = ygpu_upload(ctx, b); if (rc == 0) rc = ygpu_run(ctx); if (rc == 0) rc = ygpu_collect(ctx, &ctx->aOut);
+        lk.lock();
+        ctx->aRc = rc; ctx->aDone = true; ctx->aCv.notify_all();
+    }
+}
+int ygpu_submit(ygpu_ctx *ctx, const ygpu_read_batch *batch, ygpu_ticket *ticket)
+{
+    if (!ctx || !ctx->stream || !batch || !ticket) return YGPU_EINVAL;
+    std::unique_lock<std::mutex> lk(ctx->aMu);
+    if (ctx->aOpen) { ctx->err = "ygpu_submit: the previous ticket has not been waited for"; return YGPU_EBUSY; }
+    if (!ctx->worker.joinable()) ctx->worker = std::thread(asyncWorker, ctx);
+    ctx->aBatch = batch; ctx->aOpen = true; ctx->aDone = false; ctx->aRc = 0; *ticket = ++ctx->aTicket;
+    ctx->aCv.notify_all();
+    return 0;
+}
+int ygpu_poll(ygpu_ctx *ctx, ygpu_ticket ticket)
+{
+    if (!ctx) return YGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->aMu);
+    if (!ctx->aOpen || ticket != ctx->aTicket) return YGPU_EINVAL;
+    return ctx->aDone ? 1 : 0;
+}
+int ygpu_wait(ygpu_ctx *ctx, ygpu_ticket ticket, ygpu_result_batch *out)
+{
+    if (!ctx || !out) return YGPU_EINVAL;
+    std::unique_lock<std::mutex> lk(ctx->aMu);
+    if (!ctx->aOpen || ticket != ctx->aTicket) { ctx->err = "ygpu_wait: no such open ticket"; return YGPU_EINVAL; }
+    ctx->aCv.wait(lk, [&] { return ctx->aDone; });
+    ctx->aOpen = false; *out = ctx->aOut;
+    return ctx->aRc;
+}
+
 int ygpu_last_timing(ygpu_ctx *ctx, float *total_ms, int *n_stages, const char *const **names, const float **ms)
 {
     if (!ctx) return YGPU_EINVAL;
@@ -745,11 +792,10 @@ int ygpu_chain(ygpu_ctx *ctx, const ygpu_fragment **clump_frags, const uint32_t 
     return 0;
 }
 
-int ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops)
+}  // extern "C" (the stage-level DP entry follows its two implementations)
+
+static int dpBatchWave(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops)
 {
-    if (!ctx || !ctx->stream || !ctx->nReads) return YGPU_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
-    for (uint32_t k = 0; k < n; k++) if (problems[k].read >= ctx->nReads || problems[k].mode > 3) { ctx->err = "bad DP problem"; return YGPU_EINVAL; }
     uint32_t *cnt = ctx->counters.as<uint32_t>();
     int listCap, front, genCap, traceRows; alignDims(ctx, listCap, front, genCap, traceRows); listCap = 64;     // no frame stack needed here
     const size_t per = alignScratchBytes(ctx->maxQ, traceRows, listCap, genCap);
@@ -771,4 +817,114 @@ int ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, co
     *results = ctx->hDpRes.data(); *ops = ctx->hDpOps.data(); *n_ops = no;
     return 0;
 }
+
+// The same calls through the kernels ygpu_run uses at the default band (dp_stage.h).  second = the careful-extension instantiation of k_ext_rows.
+static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, bool second, const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops)
+{
+    std::vector<ExtProb> xp; std::vector<uint32_t> xdst; std::vector<unsigned long long> xrows; std::vector<JointRec> jp; std::vector<uint32_t> jdst;
+    uint64_t gapOpsBound = 64;
+    for (uint32_t k = 0; k < n; k++) {
+        const ygpu_dp_problem &p = problems[k]; const uint32_t base = ctx->hReadOff[p.read];
+        if (p.mode >= YGPU_DP_EXT_FWD) {
+            ExtProb e; e.qBase = base; e.rOff = p.rOff; e.qOff = p.qOff; e.qLen = p.qLen; e.flags = (p.strand ? XP_STRAND : 0u) | (p.mode == YGPU_DP_EXT_REV ? XP_REV : 0u) | XP_VALID;
+            xp.push_back(e); xdst.push_back(k); xrows.push_back((unsigned long long)((p.qLen + 19u) / 10u));
+        } else {
+            JointRec j; memset(&j, 0, sizeof j); j.nsro = p.rOff; j.qBase = base; j.nsqo = p.qOff; j.qGap = p.qLen; j.rGap = p.rLen; j.kind = JK_DP; j.flags = (uint8_t)((p.strand ? 1u : 0u) | (p.mode == YGPU_DP_BANDED ? 2u : 0u));
+            jp.push_back(j); jdst.push_back(k); gapOpsBound += (uint64_t)p.qLen + p.rLen + 2;
+        }
+    }
+    const uint32_t nX = (uint32_t)xp.size(), nJ = (uint32_t)jp.size(); int rc;
+    uint32_t *cnt = ctx->counters.as<uint32_t>(); DevBatch B = devBatch(ctx);
+    HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
+    std::vector<ExtRes> hres(nX); std::vector<JointRec> hj(nJ); std::vector<uint32_t> xOff(nX + 1, 0), jOff(nJ + 1, 0);
+    if (nX) {
+        xrows.push_back(0ull);
+        ENSURE(ctx->extProbs, sizeof(ExtProb) * (uint64_t)nX); ENSURE(ctx->rowsBound, 8ull * (nX + 1)); ENSURE(ctx->stripOff, 8ull * (nX + 1)); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nX); ENSURE(ctx->chunkCnt, 64);
+        HIPCHK(hipMemcpyAsync(ctx->extProbs.p, xp.data(), sizeof(ExtProb) * (uint64_t)nX, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->rowsBound.p, xrows.data(), 8ull * (nX + 1), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 64, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->extRes.p, 0, sizeof(ExtRes) * (uint64_t)nX, ctx->stream));
+        rc = cubScan64(ctx, ctx->rowsBound.as<unsigned long long>(), ctx->stripOff.as<unsigned long long>(), nX + 1); if (rc) return rc;
+        unsigned long long blocks = 0; HIPCHK(hipMemcpyAsync(&blocks, ctx->stripOff.as<unsigned long long>() + nX, 8, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (blocks > (32ull << 30) / 128ull) { ctx->err = "too many extension rows in one ygpu_dp_batch call"; return YGPU_EINVAL; }
+        ENSURE(ctx->extTrace, 128ull * blocks + 256);
+        ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>(); E.probs = ctx->extProbs.as<ExtProb>(); E.nProb = nX;
+        E.stripOff = ctx->stripOff.as<unsigned long long>(); E.stripBase = 0; E.order = nullptr; E.clock = nullptr; E.trace = ctx->extTrace.as<uint32_t>(); E.res = ctx->extRes.as<ExtRes>();
+        E.queue = ctx->chunkCnt.as<unsigned int>(); E.ctr = nullptr; E.errFlag = ctx->errFlag.as<int>();
+        const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
+        auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
+        auto rowsKernel2 = caps ? k_ext_rows<true, true> : k_ext_rows<false, true>;
+        int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
+        const unsigned blocksK = (unsigned)std::min<uint64_t>(((uint64_t)nX + 255) / 256, (uint64_t)ctx->nCU * (second ? 1 : perCU));
+        if (second) KL(rowsKernel2, dim3(blocksK), dim3(256), 0, ctx->stream, E); else KL(rowsKernel, dim3(blocksK), dim3(256), 0, ctx->stream, E);
+        KL(k_ext_trace, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, E);
+        HIPCHK(hipMemcpyAsync(hres.data(), ctx->extRes.p, sizeof(ExtRes) * (uint64_t)nX, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t k = 0; k < nX; k++) xOff[k + 1] = xOff[k] + (hres[k].score > 0 ? hres[k].nOps : 0u);
+    }
+    if (nJ) {
+        const uint32_t gapOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, gapOpsBound);
+        ENSURE(ctx->joints, sizeof(JointRec) * (uint64_t)(nJ + 1)); ENSURE(ctx->sortKeys, 4ull * (nJ + 1)); ENSURE(ctx->sortVals, 4ull * (nJ + 1)); ENSURE(ctx->sortVals2, 4ull * (nJ + 1));
+        ENSURE(ctx->gapOps, 4ull * gapOpsCap); ENSURE(ctx->slowList, 4ull * (nJ + 1));
+        HIPCHK(hipMemcpyAsync(ctx->joints.p, jp.data(), sizeof(JointRec) * (uint64_t)nJ, hipMemcpyHostToDevice, ctx->stream));
+        KL(k_dp_classify, dim3(gridFor(nJ, 256)), dim3(256), 0, ctx->stream, ctx->P, ctx->dBases.as<uint8_t>(), ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->joints.as<JointRec>(), nJ, ctx->sortKeys.as<uint32_t>(), ctx->sortVals.as<uint32_t>());
+        std::vector<uint32_t> keys(nJ), idx(nJ);
+        rc = fetchU32(ctx, ctx->sortKeys.p, keys.data(), nJ); if (rc) return rc;
+        for (uint32_t k = 0; k < nJ; k++) idx[k] = k;
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });           // the production path sorts the DP joints by (strip width, rows) as well
+        uint32_t nd[3] = {0, 0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != 0xFFFFFFFFu) { nd[0]++; nd[1] += (keys[k] >> 16) <= 16u; }
+        HIPCHK(hipMemcpyAsync(ctx->sortVals2.p, idx.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(cnt + CNT_NDP, nd, 12, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(cnt + CNT_SLOW, 0, 4, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
+        int listCap, front, genCap, traceRows; alignDims(ctx, listCap, front, genCap, traceRows); listCap = 64;
+        const size_t per = alignScratchBytes(ctx->maxQ, traceRows, listCap, genCap); const unsigned waves = 512;
+        ENSURE(ctx->scratchAlign, per * waves);
+        AlignArgs A; memset(&A, 0, sizeof A); A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = B; A.queueHead = cnt + CNT_QALIGN; A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per;
+        A.maxQ = ctx->maxQ; A.listCap = listCap; A.front = front; A.genCap = genCap; A.traceRows = traceRows; A.ctr = ctx->ctr.as<DevCounters>(); A.errFlag = ctx->errFlag.as<int>();
+        PhaseArgs X; memset(&X, 0, sizeof X); X.joints = ctx->joints.as<JointRec>(); X.nJoints = nJ; X.sortedVals = ctx->sortVals2.as<uint32_t>(); X.nDP = cnt + CNT_NDP;
+        X.gapOps = ctx->gapOps.as<uint32_t>(); X.gapOpsCount = cnt + CNT_GAPOPS; X.gapOpsCap = gapOpsCap; X.slowList = ctx->slowList.as<uint32_t>(); X.slowCount = cnt + CNT_SLOW;
+        const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(nJ, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(nJ, 64), (uint64_t)ctx->nCU * 6);
+        ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
+        KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
+        KL(k_gap_wave, dim3(waves), dim3(64), 0, ctx->stream, A, X);
+        HIPCHK(hipMemcpyAsync(hj.data(), ctx->joints.p, sizeof(JointRec) * (uint64_t)nJ, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t k = 0; k < nJ; k++) jOff[k + 1] = jOff[k] + hj[k].nOps;
+    }
+    uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+    if (ef) { char b[64]; snprintf(b, sizeof b, "dp batch (lane kernels) failed with device error %u", ef); ctx->err = b; return YGPU_EINTERNAL; }
+    const uint32_t totX = xOff[nX], tot = totX + jOff[nJ];
+    for (auto &v : jOff) v += totX;
+    ENSURE(ctx->dpRes, sizeof(ygpu_dp_result) * (uint64_t)(n + 1)); ENSURE(ctx->dpOps, 4ull * tot + 64); ENSURE(ctx->dpProbs, 8ull * (n + 2));
+    uint32_t *dOff = ctx->dpProbs.as<uint32_t>(), *dDst = dOff + (n + 2);       // per-list offsets and destinations (the lists are done one after the other)
+    if (nX) {
+        HIPCHK(hipMemcpyAsync(dOff, xOff.data(), 4ull * nX, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipMemcpyAsync(dDst, xdst.data(), 4ull * nX, hipMemcpyHostToDevice, ctx->stream));
+        KL(k_dp_gather_ext, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, ctx->extProbs.as<ExtProb>(), ctx->extRes.as<ExtRes>(), ctx->stripOff.as<unsigned long long>(), ctx->extTrace.as<uint32_t>(), dOff, dDst, nX,
+           ctx->dpRes.as<ygpu_dp_result>(), ctx->dpOps.as<uint32_t>());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    if (nJ) {
+        HIPCHK(hipMemcpyAsync(dOff, jOff.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipMemcpyAsync(dDst, jdst.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream));
+        KL(k_dp_gather_gap, dim3(gridFor(nJ, 256)), dim3(256), 0, ctx->stream, ctx->P, ctx->dBases.as<uint8_t>(), ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->joints.as<JointRec>(), ctx->gapOps.as<uint32_t>(), dOff, dDst, nJ,
+           ctx->dpRes.as<ygpu_dp_result>(), ctx->dpOps.as<uint32_t>());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->hDpRes.resize(n); ctx->hDpOps.resize(tot);
+    if (n) HIPCHK(hipMemcpy(ctx->hDpRes.data(), ctx->dpRes.p, sizeof(ygpu_dp_result) * (uint64_t)n, hipMemcpyDeviceToHost));
+    if (tot) HIPCHK(hipMemcpy(ctx->hDpOps.data(), ctx->dpOps.p, 4ull * tot, hipMemcpyDeviceToHost));
+    *results = ctx->hDpRes.data(); *ops = ctx->hDpOps.data(); *n_ops = tot;
+    return 0;
+}
+
+extern "C" {
+int ygpu_dp_batch_ex(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, int kernels, const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops)
+{
+    if (!ctx || !ctx->stream || !ctx->nReads || kernels < YGPU_DP_KERNELS_AUTO || kernels > YGPU_DP_KERNELS_LANES_CAREFUL) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    for (uint32_t k = 0; k < n; k++) if (problems[k].read >= ctx->nReads || problems[k].mode > 3) { ctx->err = "bad DP problem"; return YGPU_EINVAL; }
+    const bool useLanes = ctx->laneExt && ctx->P.bandWidth == 5 && ctx->P.maxGap >= YD_LBAND;       // the same choice stageAlign makes
+    if (kernels == YGPU_DP_KERNELS_WAVE || (kernels == YGPU_DP_KERNELS_AUTO && !useLanes)) return dpBatchWave(ctx, problems, n, results, ops, n_ops);
+    if (!useLanes) { ctx->err = "the lane kernels need -BW 5 and -G >= 10"; return YGPU_EINVAL; }
+    return dpBatchLanes(ctx, problems, n, kernels == YGPU_DP_KERNELS_LANES_CAREFUL, results, ops, n_ops);
+}
+int ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops)
+{ return ygpu_dp_batch_ex(ctx, problems, n, YGPU_DP_KERNELS_AUTO, results, ops, n_ops); }
 }  // extern "C"
