@@ -99,7 +99,8 @@ def head_reads(src, dst, n):
 
 
 def cpu_baseline(idx, reads_path, n_reads, cache, target_s):
-    """reference yaha -t <all cores> on a bounded sample; wall time minus a zero-work run (index mmap pre-touch)."""
+    """reference yaha on a bounded sample of the same reads: best of -t {32, 64, 128, all cores} (the reference serialises its readers on a file
+    lock, so more threads than it can feed are slower); wall time minus a zero-work run (index mmap pre-touch)."""
     import oracle
     cores = os.cpu_count() or 1
     if oracle.have_reference():
@@ -110,12 +111,18 @@ def cpu_baseline(idx, reads_path, n_reads, cache, target_s):
         n_probe = min(n_reads, 4 * cores)
         head_reads(reads_path, probe, n_probe)
         t = time.time(); oracle.run_reference(["-x", idx, "-q", probe, "-osh", "/dev/null", "-t", str(cores)]); t_probe = max(time.time() - t - t_zero, 1e-3)
-        n = int(min(n_reads, max(n_probe, target_s * n_probe / t_probe)))
+        threads = sorted(set(t for t in (32, 64, 128, cores) if t <= cores)) or [cores]
+        n = int(min(n_reads, max(n_probe, (target_s / len(threads)) * n_probe / t_probe)))
         sample = os.path.join(cache, "sample.fa")
         head_reads(reads_path, sample, n)
-        t = time.time(); oracle.run_reference(["-x", idx, "-q", sample, "-osh", "/dev/null", "-t", str(cores)]); dt = max(time.time() - t - t_zero, 1e-3)
-        return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
-                "sample": "%d of the same 1 kbp reads, oracle/_ref/yaha -t %d, %.1fs wall minus %.1fs zero-read run" % (n, cores, dt + t_zero, t_zero)}
+        by_t = {}
+        for nt in threads:
+            t = time.time(); oracle.run_reference(["-x", idx, "-q", sample, "-osh", "/dev/null", "-t", str(nt)]); dt = max(time.time() - t - t_zero, 1e-3)
+            by_t[nt] = n / dt
+        best = max(by_t, key=lambda k: by_t[k])
+        return {"value": by_t[best], "unit": "reads/s", "cores": best, "kind": "reference", "host_cores": cores, "reads_per_s_by_threads": {str(k): v for k, v in by_t.items()},
+                "sample": "%d of the same 1 kbp reads, oracle/_ref/yaha (whole program: reader, hot path, OQC, SAM to /dev/null) at -t %s, best = -t %d; wall minus a %.1fs zero-read run"
+                          % (n, "/".join(str(t) for t in threads), best, t_zero)}
     import yaha_amd as ya
     with ya.Session(["-x", idx, "-q", reads_path]) as s:
         b = s.next_batch(min(n_reads, 64 * cores))
@@ -123,18 +130,85 @@ def cpu_baseline(idx, reads_path, n_reads, cache, target_s):
         return {"value": b.n_reads / dt, "unit": "reads/s", "cores": cores, "kind": "port", "sample": "%d reads, oracle/hotpath.cpp on %d threads (hot path only)" % (b.n_reads, cores)}
 
 
+def run_contexts(ctxs, steps, collect=False):
+    """`steps` passes of the hot path shared out to the contexts (one host thread each, a common counter); returns (seconds, summed stage ms)."""
+    import threading
+    stage_ms, lock, todo = {}, threading.Lock(), [steps]
+
+    def stepper(c):
+        while True:
+            with lock:
+                if todo[0] <= 0:
+                    return
+                todo[0] -= 1
+            c.run()                                     # synchronous: returns when the results are complete in HBM
+            if collect:
+                c.collect()                             # D2H of the clump records and edit ops into the context's host buffers
+            tm = c.timing()[1]
+            with lock:
+                for k, v in tm.items():
+                    stage_ms[k] = stage_ms.get(k, 0.0) + v
+    t0 = time.time()
+    th = [threading.Thread(target=stepper, args=(c,)) for c in ctxs]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    return time.time() - t0, stage_ms
+
+
+def side_workload(ya, idx, reads_path, n_reads, device, contexts, steps, label):
+    """The same step on another read length (BASELINE configs 1 and 3), after the timed region: reads resident in HBM, results left in HBM."""
+    with ya.Session(["-x", idx, "-q", reads_path]) as s:
+        b = s.next_batch(n_reads)
+        offs = C.cast(b.offsets, C.POINTER(C.c_uint64))
+        n, bases = b.n_reads, int(offs[b.n_reads] - offs[0])
+        ctxs = [ya.Context(s.index, s.params, device=device)]
+        for _ in range(1, max(1, contexts)):
+            ctxs.append(ya.Context(s.index, s.params, device=device, parent=ctxs[0]))
+        for c in ctxs:
+            c.upload(b)
+            c.run()
+        dt, st = run_contexts(ctxs, steps)
+        cnt = ctxs[0].collect().counters.as_dict()
+        for c in reversed(ctxs):
+            c.close()
+    return {"workload": label, "reads_per_step": n, "steps": steps, "reads_per_s": n * steps / dt, "bases_per_s": bases * steps / dt, "ms_per_step": 1e3 * dt / steps,
+            "k_ext_rows_ms_per_step": st.get("ext_rows_device_clock", 0.0) / steps, "dp_cells_per_read": (cnt["dp_ext_cells"] + cnt["dp_gap_cells"]) / max(n, 1), "hits_per_read": cnt["hits"] / max(n, 1)}
+
+
+def end_to_end(ya, idx, fa, cache, n_reads, seed):
+    """The whole `yaha` command line (process start, index mmap + upload, input parsing, device, OQC, SAM text to a file in /dev/shm)."""
+    reads = make_reads(cache, fa, "e2e", n_reads, 1000, 0.017, seed)
+    out = "/dev/shm/yaha_bench_e2e_%d.sam" % os.getpid()
+    tiny = os.path.join(cache, "tiny.fa")
+    head_reads(reads, tiny, 16)
+    try:
+        subprocess.run([ya.CLI_PATH, "-x", idx, "-q", tiny, "-osh", out], stderr=subprocess.DEVNULL, check=True)      # absorbs the driver's scrubbing of the memory the bench contexts freed
+        t = time.time()
+        subprocess.run([ya.CLI_PATH, "-x", idx, "-q", reads, "-osh", out, "-ctx", "2", "-batch", "8192"], stderr=subprocess.DEVNULL, check=True)
+        dt = time.time() - t
+        nrec = sum(1 for l in open(out) if not l.startswith("@"))
+    finally:
+        if os.path.exists(out):
+            os.remove(out)
+    return {"reads": n_reads, "seconds": dt, "e2e_reads_per_s": n_reads / dt, "sam_records": nrec, "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam -ctx 2 -batch 8192" % n_reads}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads-per-gpu", type=int, default=16384)
     ap.add_argument("--read-len", type=int, default=1000)
     ap.add_argument("--genome-mbp", type=int, default=100)
     ap.add_argument("--div", type=float, default=0.017)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs measured after the timed region (other read lengths, D2H-inclusive rate, command line)")
+    ap.add_argument("--e2e-reads", type=int, default=262144)
     ap.add_argument("--contexts", type=int, default=2, help="device contexts (batches in flight) per GPU")
     args = ap.parse_args()
 
@@ -163,7 +237,6 @@ def main():
     fa, idx = ensure_inputs(cache, args.genome_mbp, args.seed)
     reads_path = make_reads(cache, fa, "g%dm" % args.genome_mbp, args.reads_per_gpu, args.read_len, args.div, 1000 + rank)
 
-    import threading
     with ya.Session(["-x", idx, "-q", reads_path]) as s:
         b = s.next_batch(args.reads_per_gpu)
         n_reads = b.n_reads
@@ -182,33 +255,20 @@ def main():
         for c in ctxs:
             for _ in range(args.warmup):
                 c.run()
-        stage_ms = {}
-        lock = threading.Lock()
-        todo = [args.steps]
-
-        def stepper(c):
-            while True:
-                with lock:
-                    if todo[0] <= 0:
-                        return
-                    todo[0] -= 1
-                c.run()                                     # synchronous: returns when the results are complete in HBM
-                tm = c.timing()[1]
-                with lock:
-                    for k, v in tm.items():
-                        stage_ms[k] = stage_ms.get(k, 0.0) + v
         barrier()
         t0 = time.time()
-        th = [threading.Thread(target=stepper, args=(c,)) for c in ctxs]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
+        _dt_inner, stage_ms = run_contexts(ctxs, args.steps)
         barrier()
         dt = time.time() - t0
+        # ---- after the timed region ----
         t = time.time(); r = ctxs[0].collect(); t_down = time.time() - t
         counters = r.counters.as_dict()
-        n_clumps = int(r.n_clumps)
+        n_clumps = int(r.n_clumps); n_ops = int(r.n_ops)
+        d2h = None
+        if world == 1 and not args.no_extras:
+            dt2, _st = run_contexts(ctxs, args.steps, collect=True)     # every step also copies its results to host memory (the other context computes meanwhile)
+            d2h = {"value_with_d2h": n_reads * args.steps / dt2, "ms_per_step": 1e3 * dt2 / args.steps, "result_bytes_per_step": 32 * n_clumps + 4 * n_ops + 4 * (n_reads + 1)}
+        k = s.params.wordLen
         for c in reversed(ctxs):
             c.close()
     dt = max_over_ranks(dt, dist)
@@ -220,27 +280,27 @@ def main():
     steps = args.steps
     total_reads = world * n_reads * steps
     value = total_reads / dt
-    # algorithmic bytes per read, SURVEY.md 8(d): read codes + 2 strands x 2 u32 table words per k-mer + hit words +
-    # touched reference nibbles + result records
-    k = s.params.wordLen
+    # ALGORITHMIC bytes per read, SURVEY.md 8(d): read codes + 2 strands x 2 u32 table words per k-mer + hit words + touched reference nibbles
+    # (lazy: rows computed + band per call + exact-match bases) + result records; H, R and the records are counted on the device for this input.
     Lq = n_bases / n_reads
     B = Lq + 16 * (Lq - k + 1) + 4 * counters["hits"] / n_reads + counters["ref_bases_touched"] / n_reads / 2 + (24 * counters["clumps_scored"] + 3 * counters["ops_out"]) / n_reads
+    # Dominant kernel (profiles/): k_ext_rows, the X-drop extension rows of all reads of the batch, one problem per lane.  One launch processes the batch's
+    # n_reads reads, so its algorithmic bytes are B x n_reads (SURVEY 8(d)'s per-read figure x the reads of one launch).  Duration: measured live in the
+    # timed region -- HIP events around the launch on its stream (`ext_rows`) and the kernel's own wall_clock64() stamps (`ext_rows_device_clock`); with
+    # two contexts per GPU the event bracket also contains the time the launch queues behind the other context's kernels, so the device-clock duration
+    # (which is what rocprofv3 reports for the kernel, profiles/) is the one used.
     align_ms = stage_ms.get("align_dp", 0.0) / steps
-    # Dominant kernel (profiles/): k_ext_rows, the X-drop extension rows, one problem per lane.  Its ALGORITHMIC bytes per launch
-    # (DESIGN.md section 5): per computed row 1 query code + half a byte of packed reference + 12 B of trace cells (21 x 4 bit),
-    # per problem a 16-byte descriptor and a 32-byte result.  Duration = HIP events around its launch(es) on its stream.
     rows_ms = stage_ms.get("ext_rows", 0.0) / steps
     rows_dev_ms = stage_ms.get("ext_rows_device_clock", 0.0) / steps
     if rows_ms > 0:
-        # The launch is bracketed by HIP events on its stream, and the kernel also stamps wall_clock64() at its first wave's start and
-        # last wave's end.  With two contexts per GPU the event bracket additionally contains the time the launch waits behind the
-        # other context's kernels, so the device-clock duration (the one rocprofv3 reports for the kernel) is the one used.
         kname, kernel_ms = "k_ext_rows", (rows_dev_ms if rows_dev_ms > 0 else rows_ms)
-        kbytes = 13.5 * counters["dp_ext_rows"] + 48.0 * counters["dp_ext_calls"]
+        stream_bytes = 13.5 * counters["dp_ext_rows"] + 48.0 * counters["dp_ext_calls"]     # what the kernel itself streams: per row 1 query code + 1/2 B reference + 12 B of trace cells; 48 B per problem
     else:                                                    # other band widths run the wave-per-root kernel
-        kname, kernel_ms = "k_align", align_ms
-        kbytes = B * n_reads
+        kname, kernel_ms, stream_bytes = "k_align", align_ms, None
+    kbytes = B * n_reads
     achieved = (kbytes / (kernel_ms * 1e-3)) / 1e9 if kernel_ms > 0 else 0.0
+    # HBM traffic of that launch from the PMC counters: bench.py cannot read hardware counters of its own process, so this is the figure of the last
+    # profiling pass of the same command (tools/pmc_pass.sh -> profiles/pmc_latest.json), used only when it was taken on the same batch size and kernel.
     traffic, pmc = None, None
     pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pj):
@@ -248,28 +308,53 @@ def main():
             pmc = json.load(open(pj))
             if pmc.get("reads_per_gpu") == n_reads and pmc.get("kernel") == kname:
                 traffic = pmc.get("hbm_bytes_per_launch")
+            else:
+                pmc = None
         except Exception:
             traffic, pmc = None, None
+    valu = pmc.get("valu_insts_per_launch") if pmc else None
+    simd_cycles = 1024 * 2.4e9 * kernel_ms * 1e-3            # 256 CUs x 4 SIMDs at 2.4 GHz over the launch
     out = {
         "metric": "aligned reads/s (whole node), 1 000 bp reads, OQC mode hot path", "value": value, "unit": "reads/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "bases_per_s": value * Lq,
-        "config": {"workload": "synthetic hg18-like genome %d Mbp (24 seqs, 45%% repeats), index -L 15 -S 1 -H 65525, %d x %d bp reads per GPU at %.1f%% divergence, defaults -BW 5 -G 50 -H 650 -M 25 -X 25, hot path A1..A10 with inputs resident in HBM"
+        "config": {"workload": "BASELINE config 2 shape: synthetic hg18-like genome %d Mbp (24 seqs, 45%% repeats), index -L 15 -S 1 -H 65525, %d x %d bp reads per GPU at %.1f%% divergence, defaults -BW 5 -G 50 -H 650 -M 25 -X 25, hot path A1..A10 with inputs resident in HBM"
                    % (args.genome_mbp, n_reads, args.read_len, 100 * args.div),
                    "reads_per_gpu": n_reads, "read_len": args.read_len, "parallelism": "reads sharded x%d, index replicated, no collective; %d contexts (batches in flight) per GPU" % (world, max(1, args.contexts))},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": kbytes, "kernel_ms_per_launch": kernel_ms,
+                     "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_read": B, "reads_per_launch": n_reads, "kernel_ms_per_launch": kernel_ms,
                      "kernel_ms_hip_events": rows_ms, "kernel_ms_device_clock": rows_dev_ms,
+                     "kernel_stream_bytes_per_launch": stream_bytes, "kernel_stream_frac": (stream_bytes / (kernel_ms * 1e-3) / 8.0e12) if (stream_bytes and kernel_ms > 0) else None,
                      "cell_updates_per_s": counters["dp_ext_cells"] / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
-                     "note": "integer DP: the kernel is bound by vector-ALU issue, not HBM (see DESIGN.md section 6 and profiles/)",
-                     "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "valu_cycles_per_inst", "valu_issue_frac", "fetch_bytes_per_launch", "write_bytes_per_launch", "source") if k2 in pmc} if pmc and traffic is not None else None)},
+                     "valu_frac_nominal": (valu * 2.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
+                     "valu_frac_measured_mix": (valu * 4.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
+                     "note": "integer DP: `frac` follows SURVEY 8(d) (algorithmic bytes of the reads of one launch / kernel time / 8 TB/s) and is ~1% by construction; the kernel is bound by vector-ALU issue: valu_frac_nominal prices each wave64 VALU instruction at the nominal 2 SIMD cycles, valu_frac_measured_mix at the 4 cycles its compare/select/max-heavy mix measures (DESIGN.md section 6); kernel_stream_frac counts the trace cells the kernel writes (an implementation choice, not algorithmic traffic)",
+                     "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch", "lds_bank_conflict_frac", "gpu_busy_cycles", "source") if k2 in pmc} if pmc else None)},
         "path": {"algorithmic_bytes_per_read": B, "hbm_frac_whole_path": value * B / (8.0e12 * world),
                  "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) * steps * world / dt},
         "stage_ms_per_step": {k2: v / steps for k2, v in stage_ms.items()},
         "per_read": {k2: counters[k2] / n_reads for k2 in ("hits", "fragments", "clumps_formed", "clumps_scored", "dp_ext_calls", "dp_ext_rows", "dp_ext_cells", "dp_gap_calls", "dp_gap_rows", "dp_gap_cells", "splits", "ops_out", "ref_bases_touched")},
         "pcie": {"upload_s": t_up, "collect_s": t_down, "clumps": n_clumps},
     }
+    if d2h:
+        out["value_with_d2h"] = d2h["value_with_d2h"]; out["d2h"] = d2h
+    if world == 1 and not args.no_extras:
+        # the same step on BASELINE's other read lengths (configs 1 and 3), and the whole command line (config 2 end to end)
+        wl = []
+        for label, n, length, div, nsteps in (("c1: 100 bp reads, r=0.02 (realised 0.7%)", 65536, 100, 0.007, 4), ("c3: 10 kbp reads, r=0.10 (realised 3.4%)", 1024, 10000, 0.034, 3)):
+            try:
+                wl.append(side_workload(ya, idx, make_reads(cache, fa, "side", n, length, div, 2000), n, local, args.contexts, nsteps, label))
+            except Exception as e:
+                wl.append({"workload": label, "error": str(e)[:200]})
+        wl.insert(1, {"workload": "c2: 1 kbp reads, r=0.05 (realised 1.7%) = the headline", "reads_per_step": n_reads, "steps": steps, "reads_per_s": value, "bases_per_s": value * Lq, "ms_per_step": 1e3 * dt / steps,
+                      "k_ext_rows_ms_per_step": rows_dev_ms})
+        out["workloads"] = wl
+        try:
+            out["end_to_end"] = end_to_end(ya, idx, fa, cache, args.e2e_reads, 3000)
+            out["e2e_reads_per_s"] = out["end_to_end"]["e2e_reads_per_s"]
+        except Exception as e:
+            out["end_to_end"] = {"error": str(e)[:200]}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(idx, reads_path, n_reads, cache, args.cpu_seconds)

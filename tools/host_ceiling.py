@@ -1,0 +1,29 @@
+"""Host ceiling on the GPU box: how many reads/s can the stages around the device sustain?
+  parse : tools/host_ceiling (C++: the product's ReadSplitter + parseSpan) on 262 144 x 1 kbp reads, 1..32 parser threads
+  format: real device results of one 65 536-read batch (ygpu_run on the bench genome), then the product's OQC/FBS filter + SAM text (yaha_session_emit)
+          over them with 1..128 threads -- the recorded results are replayed, nothing of the product path is stubbed.
+Run after bench.py has built the cache:  python tools/host_ceiling.py > gpurun_out/host_ceiling.jsonl"""
+import json, os, subprocess, sys, time
+root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root)
+import yaha_amd as ya
+cache = os.environ.get("YAHA_BENCH_CACHE", "/tmp/yaha_bench_cache")
+X = os.path.join(cache, "g100m_s42.X15_01_65525S"); G = os.path.join(cache, "g100m_s42.fa")
+R = os.path.join(cache, "ceiling_262144.fa")
+if not os.path.exists(R):
+    subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome", G, "--out", R, "--seed", "99", "--n", "262144", "--len", "1000", "--div", "0.017"])
+exe = os.path.join(root, "tools", "host_ceiling")
+if not os.path.exists(exe):
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tools", "host_ceiling.cpp"), "-L" + os.path.join(root, "yaha_amd", "csrc"), "-lyaha_hip",
+                           "-Wl,-rpath," + os.path.join(root, "yaha_amd", "csrc"), "-pthread"])
+sys.stdout.write(subprocess.run([exe, R, "4096", "1", "2", "4", "8", "16", "32"], stdout=subprocess.PIPE, check=True).stdout.decode()); sys.stdout.flush()
+N = 65536
+for T in (1, 8, 16, 32, 64, 128):
+    with ya.Session(["-x", X, "-q", R, "-t", str(T)]) as s:
+        b = s.next_batch(N)
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.upload(b); ctx.run(); r = ctx.collect()
+            best = 1e9
+            for _ in range(2):
+                t = time.time(); text = s.emit(r); best = min(best, time.time() - t)
+            print(json.dumps({"stage": "format (OQC + SAM text)", "threads": T, "reads": b.n_reads, "clumps_in": int(r.n_clumps), "sam_bytes": len(text), "seconds": best, "reads_per_s": b.n_reads / best})); sys.stdout.flush()

@@ -42,10 +42,37 @@ if emit and kernel:
         return max((d.get(counter, 0.0) for d in ds.values()), default=0.0)
     fetch = biggest("fetch", "FETCH_SIZE") * 1024.0 * 2.0; write = biggest("write", "WRITE_SIZE") * 1024.0
     valu = biggest("sq", "SQ_INSTS_VALU"); dur_ns = out[k].get("max_ns") or out[k].get("avg_ns", 0.0)
+    ldsc, ldsa, gui = biggest("lds", "SQ_LDS_BANK_CONFLICT"), biggest("lds", "SQ_LDS_IDX_ACTIVE"), biggest("grbm", "GRBM_GUI_ACTIVE")
     js = {"kernel": kernel, "reads_per_gpu": reads, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
           "valu_insts_per_launch": valu, "kernel_ns_largest_launch": dur_ns,
+          "lds_bank_conflict_cycles": ldsc, "lds_idx_active_cycles": ldsa, "lds_bank_conflict_frac": (ldsc / ldsa) if ldsa else None,
+          "gpu_busy_cycles": gui, "effective_clock_ghz": (gui / dur_ns) if (gui and dur_ns) else None,
+          "lds": {c: biggest("lds", c) for c in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM")},
           "valu_cycles_per_inst": (1024 * 2.4 * dur_ns / valu) if valu else None,
           "valu_issue_frac": (valu * 4.0 / (1024 * 2.4 * dur_ns)) if dur_ns else None,
           "sq": {c: biggest("sq", c) for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU")},
-          "source": "rocprofv3 --pmc, separate passes (tools/pmc_pass.sh); FETCH_SIZE x2 per the gfx950 note; valu_cycles_per_inst = SIMD cycles (1024 SIMDs, 2.4 GHz) per wave64 VALU instruction over the launch; valu_issue_frac prices every instruction at 4 cycles (tools/micro/pk_rate.hip measures 2.5-2.9 for plain two-operand 32-bit ops and 4.3-4.7 for compares, selects, max and three-operand ops)"}
+          "source": "rocprofv3 --pmc, separate passes with --kernel-trace only (tools/pmc_pass.sh); FETCH_SIZE x2 per the gfx950 note (see the calibration of byte-wide loads in profiles/); valu_cycles_per_inst = SIMD cycles (1024 SIMDs, 2.4 GHz) per wave64 VALU instruction over the launch; valu_issue_frac prices every instruction at 4 cycles (tools/micro/pk_rate.hip measures 2.5-2.9 for plain two-operand 32-bit ops and 4.3-4.7 for compares, selects, max and three-operand ops)"}
     json.dump(js, open(emit, "w"), indent=1); print("wrote", emit, js)
+
+# FETCH_SIZE calibration (tools/micro/fetch_calib.hip): counter per kernel against the bytes each kernel reads exactly once
+cal = os.path.join(root, "calib.json")
+if os.path.exists(cal):
+    want = {}
+    for line in open(cal):
+        try:
+            j = json.loads(line); want[j["kernel"].split()[0].split("<")[0]] = j
+        except Exception:
+            pass
+    for f in glob.glob(os.path.join(root, "calib", "**", "*counter_collection.csv"), recursive=True):
+        print("FETCH_SIZE calibration:")
+        seen = collections.OrderedDict()
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == "FETCH_SIZE":
+                seen.setdefault((row.get("Dispatch_Id"), short(row.get("Kernel_Name", "?"))), 0.0); seen[(row.get("Dispatch_Id"), short(row.get("Kernel_Name", "?")))] += float(row.get("Counter_Value", 0) or 0)
+        names = ["k_wide", "k_byte<false> sparse", "k_byte<true> dense"]
+        lines = [json.loads(l) for l in open(cal) if l.startswith("{")]
+        for (d, kn), v in seen.items():
+            exp = next((l for l in lines if l["kernel"].split()[0].split("<")[0] in kn), None)
+            idx = list(seen.keys()).index((d, kn))
+            exp = lines[idx] if idx < len(lines) else exp
+            if exp: print("   %-28s FETCH_SIZE %.0f KiB = %.3f GB; bytes read exactly once %.3f GB; bytes / (FETCH_SIZE*1024) = %.3f" % (exp["kernel"], v, v * 1024 / 1e9, exp["bytes_read_once"] / 1e9, exp["bytes_read_once"] / (v * 1024) if v else 0))
