@@ -228,3 +228,39 @@ def test_async_tickets_one_host_thread_two_contexts(work, index11):
             t = a.submit(b2)
             assert ya.result_records(a.wait(t)) == exp2             # wait without polling
             b.close()
+
+
+def _sha(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def test_index_built_on_the_device_is_byte_identical(work, meta, tmp_path):
+    # count -> scan -> fill -> order -> sample on the GPU (device/index_build.hip) against the reference's own files (SHA-256 goldens)
+    # and against this repo's host builder (the reference's three passes restated), incl. the Floyd sampling of over-represented k-mers.
+    import shutil
+    d = str(tmp_path)
+    shutil.copy(os.path.join(work, "genome_small.nib2"), os.path.join(d, "genome_small.nib2"))
+    g = os.path.join(d, "genome_small.nib2")
+    for args, name in ((["-L", "11"], "genome_small.X11_01_65525S"), (["-L", "8", "-H", "20"], "genome_small.X08_01_00020S")):
+        r = subprocess.run([ya.CLI_PATH, "-g", g] + args, stderr=subprocess.PIPE, check=True)
+        assert b"Building the index on GPU" in r.stderr
+        assert os.path.getsize(os.path.join(d, name)) == meta["index"][name]["size"] if "size" in meta["index"][name] else True
+        assert _sha(os.path.join(d, name)) == meta["index"][name]["sha256"], name
+    # a repeat-rich 6 Mbp genome: -L 15 (the default; 4.3 GB table), and -L 10 -H 40 where thousands of k-mers are sampled and the long lists take
+    # the workgroup and device sorts
+    big = os.path.join(d, "big.fa")
+    subprocess.check_call([os.path.join(ROOT, "tools", "yaha_sim"), "genome", "--seed", "5", "--out", big, "--seqs", "5", "--len", "6000000", "--repeat-frac", "0.5", "--nrun", "3", "--lowcomplex", "6"])
+    for args, name in ((["-L", "15"], "big.X15_01_65525S"), (["-L", "10", "-H", "40"], "big.X10_01_00040S"), (["-L", "12", "-H", "3000"], "big.X12_01_03000S")):
+        subprocess.run([ya.CLI_PATH, "-g", big] + args, stderr=subprocess.DEVNULL, check=True)
+        dev = os.path.join(d, name + ".device")
+        os.rename(os.path.join(d, name), dev)
+        r = subprocess.run([ya.CLI_PATH, "-g", big, "-cpuindex"] + args, stderr=subprocess.PIPE, check=True)
+        assert b"Building the index on GPU" not in r.stderr
+        assert subprocess.run(["cmp", "-s", dev, os.path.join(d, name)]).returncode == 0, "device-built index differs from the host-built one: " + name
+        os.remove(dev)
+        os.remove(os.path.join(d, name))

@@ -1,0 +1,225 @@
+// index_build.hip -- the hash index (reference Index.c:49-335) built on the MI355X: count -> scan -> fill -> order -> sample.
+//
+// The reference's builder is three single-threaded passes over the genome (count the k-mers, fill the reference-offset array ROA in ascending
+// offset order per k-mer, Floyd-sample k-mers with more than maxHits occurrences).  For an hg18-scale genome (3.1 Gbp, 4^15 = 1 G k-mers, 16.7 GB
+// file) that is minutes of pointer-chasing; here every base offset is one unit of work:
+//   k_ix_count   thread per 16 consecutive offsets: rolling 2-bit hash of the 4-bit reference (Index.c:32-43), one atomicAdd per valid k-mer
+//   [exclusive scan of the 4^k counters -> startingOffs]
+//   k_ix_fill    the same walk; slot = startingOffs[h] + atomicAdd(cursor[h]) -- the order inside a k-mer's list is whatever the atomics gave
+//   k_ix_order*  every list is put into ascending offset order, which is the ONLY order the reference can produce (its fill pass scans the genome
+//                left to right, Index.c:201-229), so the result is independent of the atomics: lists of <= 32 entries are insertion-sorted by one
+//                thread (they arrive almost sorted), up to 8 192 entries by one workgroup in LDS (bitonic), longer ones by a device radix sort each
+//   sampling     k-mers with more than maxHits occurrences keep a Floyd sample drawn with the default-seeded Marsaglia generator, consumed in
+//                k-mer order (Index.c:271-315, Math.c:304-343): inherently sequential, but it concerns a handful of k-mers -- their lists go to
+//                the host, the samples come back, and one gather pass compacts ROA (k_ix_compact).
+// k-mers never span sequences and skip any window holding a code > 3 (Index.c:98-127).  Skip distance 1 only (the default); the host builder
+// (host/formats.cpp) keeps -S > 1 and machines without a GPU.  Output: the complete file image, byte-identical to the reference's.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../host/yaha_host.h"
+
+namespace {
+#define IXCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return false; } } while (0)
+#define IX_PER_THREAD 16
+#define IX_SMALL 32u
+#define IX_BLOCK 8192u
+
+struct SeqTab { const uint32_t *start, *len; uint32_t n; };
+
+__device__ __forceinline__ uint32_t nibAt(const uint8_t *b, uint64_t off) { const uint8_t v = b[off >> 1]; return (off & 1) ? (uint32_t)(v & 15u) : (uint32_t)(v >> 4); }
+
+// Calls visit(hash, offset) for every valid k-mer start in [p0, p0 + IX_PER_THREAD) (skip distance 1).
+template <class Visit> __device__ __forceinline__ void walkKmers(const uint8_t *bases, SeqTab T, int k, uint64_t p0, uint64_t nOffsets, Visit visit)
+{
+    if (p0 >= nOffsets) return;
+    // the sequence that holds p0 (sequences are ascending; a thread's span may cross into the next one)
+    uint32_t lo = 0, hi = T.n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)T.start[mid] + T.len[mid] <= p0) lo = mid + 1; else hi = mid; }
+    uint32_t si = lo;
+    const uint32_t mask = 0xFFFFFFFFu >> (32 - 2 * k);
+    uint32_t h = 0; int good = 0;                       // good = valid codes accumulated in h, inside the current sequence
+    uint64_t p = p0;                                    // next offset whose code is to be shifted in
+    uint64_t segEnd = 0, segStart = 0; bool inSeq = false;
+    const uint64_t pEnd = p0 + IX_PER_THREAD + (uint64_t)k - 1;      // the last k-mer start of this thread needs codes up to here
+    for (; p < pEnd && p < nOffsets; p++) {
+        while (si < T.n && p >= (uint64_t)T.start[si] + T.len[si]) { si++; inSeq = false; }
+        if (si >= T.n) break;
+        if (!inSeq) { segStart = T.start[si]; segEnd = segStart + T.len[si]; inSeq = true; good = 0; }
+        if (p < segStart) { good = 0; continue; }       // padding between sequences
+        const uint32_t c = nibAt(bases, p);
+        if (c > 3u) { good = 0; continue; }
+        h = ((h << 2) | c) & mask; good++;
+        if (good >= k) { const uint64_t s = p + 1 - (uint64_t)k; if (s >= p0 && s < p0 + IX_PER_THREAD) visit(h, (uint32_t)s); }
+    }
+    (void)segEnd;
+}
+
+__global__ void k_ix_count(const uint8_t *bases, SeqTab T, int k, uint64_t nOffsets, uint32_t *counts)
+{
+    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * IX_PER_THREAD;
+    walkKmers(bases, T, k, p0, nOffsets, [&](uint32_t h, uint32_t) { atomicAdd(&counts[h], 1u); });
+}
+__global__ void k_ix_fill(const uint8_t *bases, SeqTab T, int k, uint64_t nOffsets, const uint32_t *so, uint32_t *cursor, uint32_t *roa)
+{
+    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * IX_PER_THREAD;
+    walkKmers(bases, T, k, p0, nOffsets, [&](uint32_t h, uint32_t off) { roa[so[h] + atomicAdd(&cursor[h], 1u)] = off; });
+}
+// lists of 2 .. IX_SMALL entries: in-place insertion sort by one thread; longer ones are listed for the workgroup / device sorts
+__global__ void k_ix_order_small(const uint32_t *so, uint64_t nKmers, uint32_t *roa, uint32_t *bigList, unsigned int *nBig, uint32_t bigCap, uint32_t *overList, unsigned int *nOver, uint32_t overCap, uint32_t maxHits)
+{
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nKmers) return;
+    const uint32_t b = so[h], n = so[h + 1] - b;
+    if (n > maxHits) { const unsigned s = atomicAdd(nOver, 1u); if (s < overCap) overList[s] = (uint32_t)h; }
+    if (n < 2u) return;
+    if (n > IX_SMALL) { const unsigned s = atomicAdd(nBig, 1u); if (s < bigCap) bigList[s] = (uint32_t)h; return; }
+    uint32_t *a = roa + b;
+    for (uint32_t i = 1; i < n; i++) { const uint32_t v = a[i]; uint32_t j = i; while (j > 0 && a[j - 1] > v) { a[j] = a[j - 1]; j--; } a[j] = v; }
+}
+// lists of IX_SMALL+1 .. IX_BLOCK entries: bitonic sort in LDS, one workgroup per list
+__global__ void __launch_bounds__(256) k_ix_order_block(const uint32_t *so, const uint32_t *bigList, uint32_t nBig, uint32_t *roa)
+{
+    __shared__ uint32_t s[IX_BLOCK];
+    for (uint32_t li = blockIdx.x; li < nBig; li += gridDim.x) {
+        const uint32_t h = bigList[li], b = so[h], n = so[h + 1] - b;
+        if (n > IX_BLOCK) continue;                                           // left to the device radix sort
+        uint32_t m = 64; while (m < n) m <<= 1;
+        for (uint32_t i = threadIdx.x; i < m; i += 256) s[i] = i < n ? roa[b + i] : 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t size = 2; size <= m; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = threadIdx.x; t < m / 2; t += 256) {
+                    const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
+                    const bool up = (i & size) == 0; const uint32_t x = s[i], y = s[j];
+                    if ((x > y) == up) { s[i] = y; s[j] = x; }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = threadIdx.x; i < n; i += 256) roa[b + i] = s[i];
+        __syncthreads();
+    }
+}
+__global__ void k_ix_clamp(const uint32_t *so, uint64_t nKmers, uint32_t maxHits, uint32_t *cnt2)
+{
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < nKmers) { const uint32_t n = so[h + 1] - so[h]; cnt2[h] = n > maxHits ? maxHits : n; }
+    if (h == nKmers) cnt2[h] = 0;
+}
+// ROA' = the lists of all k-mers that were not sampled, at their new places (a wave per 64 consecutive k-mers: their lists are adjacent in both arrays)
+__global__ void k_ix_compact(const uint32_t *so, const uint32_t *so2, uint64_t nKmers, uint32_t maxHits, const uint32_t *roa, uint32_t *roa2)
+{
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nKmers) return;
+    const uint32_t b = so[h], n = so[h + 1] - b;
+    if (n > maxHits) return;                                                  // sampled lists are written from the host's samples
+    const uint32_t d = so2[h];
+    for (uint32_t i = 0; i < n; i++) roa2[d + i] = roa[b + i];
+}
+
+struct Buf { void *p = nullptr; ~Buf() { if (p) hipFree(p); } template <class T> T *as() { return (T *)p; } };
+}  // namespace
+
+namespace yaha {
+int visibleDevices() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+
+// Builds the complete index file image {-1, wordLen, maxHits, total} + startingOffs[4^k + 1] + ROA[total] on HIP device `device`.
+bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, IndexImage &image, FILE *log, std::string &err)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { err = "no such HIP device"; return false; }
+    IXCHK(hipSetDevice(device));
+    const uint64_t HT = 1ull << (2 * wordLen), nOffsets = g.nBaseBytes * 2;
+    std::vector<uint32_t> st, ln; for (auto &s : g.seqs) if ((int64_t)s.length >= wordLen) { st.push_back(s.start); ln.push_back(s.length); }
+    // a sequence shorter than a k-mer holds none; the table keeps only the others (ascending starts)
+    const uint32_t nSeq = (uint32_t)st.size();
+    Buf dBases, dStart, dLen, dCnt, dSO, dCur, dROA, dTemp, dBig, dOver, dN, dSO2, dROA2;
+    IXCHK(hipMalloc(&dBases.p, g.nBaseBytes + 64)); IXCHK(hipMemcpy(dBases.p, g.bases, g.nBaseBytes, hipMemcpyHostToDevice));
+    IXCHK(hipMalloc(&dStart.p, 4ull * (nSeq + 1))); IXCHK(hipMalloc(&dLen.p, 4ull * (nSeq + 1)));
+    if (nSeq) { IXCHK(hipMemcpy(dStart.p, st.data(), 4ull * nSeq, hipMemcpyHostToDevice)); IXCHK(hipMemcpy(dLen.p, ln.data(), 4ull * nSeq, hipMemcpyHostToDevice)); }
+    SeqTab T; T.start = dStart.as<uint32_t>(); T.len = dLen.as<uint32_t>(); T.n = nSeq;
+    IXCHK(hipMalloc(&dCnt.p, 4ull * (HT + 1))); IXCHK(hipMemset(dCnt.p, 0, 4ull * (HT + 1)));
+    const uint64_t nThreads = (nOffsets + IX_PER_THREAD - 1) / IX_PER_THREAD; const unsigned grid = (unsigned)((nThreads + 255) / 256);
+    if (grid) hipLaunchKernelGGL(k_ix_count, dim3(grid), dim3(256), 0, 0, dBases.as<uint8_t>(), T, wordLen, nOffsets, dCnt.as<uint32_t>());
+    IXCHK(hipGetLastError());
+    // startingOffs = exclusive prefix sums (4^k + 1 entries, the last one = total)
+    IXCHK(hipMalloc(&dSO.p, 4ull * (HT + 1)));
+    size_t tb = 0; IXCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (int)(HT + 1)));
+    IXCHK(hipMalloc(&dTemp.p, tb)); IXCHK(hipcub::DeviceScan::ExclusiveSum(dTemp.p, tb, dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (int)(HT + 1)));
+    uint32_t total = 0; IXCHK(hipMemcpy(&total, dSO.as<uint32_t>() + HT, 4, hipMemcpyDeviceToHost));
+    // fill (the counters become the cursors)
+    IXCHK(hipMemset(dCnt.p, 0, 4ull * (HT + 1)));
+    IXCHK(hipMalloc(&dROA.p, 4ull * ((uint64_t)total + 16)));
+    if (grid) hipLaunchKernelGGL(k_ix_fill, dim3(grid), dim3(256), 0, 0, dBases.as<uint8_t>(), T, wordLen, nOffsets, dSO.as<uint32_t>(), dCnt.as<uint32_t>(), dROA.as<uint32_t>());
+    IXCHK(hipGetLastError());
+    // order every list
+    uint32_t bigCap = 1u << 22, overCap = 1u << 20; unsigned int two[2] = {0, 0};
+    IXCHK(hipMalloc(&dBig.p, 4ull * bigCap)); IXCHK(hipMalloc(&dOver.p, 4ull * overCap)); IXCHK(hipMalloc(&dN.p, 8));
+    for (int attempt = 0;; attempt++) {
+        IXCHK(hipMemset(dN.p, 0, 8));
+        hipLaunchKernelGGL(k_ix_order_small, dim3((unsigned)((HT + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), HT, dROA.as<uint32_t>(), dBig.as<uint32_t>(), dN.as<unsigned int>(), bigCap,
+                           dOver.as<uint32_t>(), dN.as<unsigned int>() + 1, overCap, (uint32_t)maxHits);
+        IXCHK(hipGetLastError()); IXCHK(hipMemcpy(two, dN.p, 8, hipMemcpyDeviceToHost));
+        if (two[0] <= bigCap && two[1] <= overCap) break;
+        if (attempt) { err = "index build: list of long k-mer lists overflows"; return false; }
+        // (the small lists are sorted already; a second pass over them is harmless) regrow the lists and redo
+        if (two[0] > bigCap) { bigCap = two[0] + 1024; hipFree(dBig.p); dBig.p = nullptr; IXCHK(hipMalloc(&dBig.p, 4ull * bigCap)); }
+        if (two[1] > overCap) { overCap = two[1] + 1024; hipFree(dOver.p); dOver.p = nullptr; IXCHK(hipMalloc(&dOver.p, 4ull * overCap)); }
+    }
+    const uint32_t nBig = two[0], nOver = two[1];
+    std::vector<uint32_t> hSOpair;                       // startingOffs of the long lists
+    if (nBig) {
+        hipLaunchKernelGGL(k_ix_order_block, dim3(std::min<uint32_t>(nBig, 4096u)), dim3(256), 0, 0, dSO.as<uint32_t>(), dBig.as<uint32_t>(), nBig, dROA.as<uint32_t>());
+        IXCHK(hipGetLastError());
+        std::vector<uint32_t> big(nBig); IXCHK(hipMemcpy(big.data(), dBig.p, 4ull * nBig, hipMemcpyDeviceToHost));
+        // the few lists beyond a workgroup's LDS: one device radix sort each
+        Buf dAlt; size_t altCap = 0; size_t tb2 = 0; Buf dTemp2; size_t temp2Cap = 0;
+        for (uint32_t h : big) {
+            uint32_t be[2]; IXCHK(hipMemcpy(be, dSO.as<uint32_t>() + h, 8, hipMemcpyDeviceToHost));
+            const uint32_t n = be[1] - be[0]; if (n <= IX_BLOCK) continue;
+            if (n > altCap) { if (dAlt.p) hipFree(dAlt.p); dAlt.p = nullptr; altCap = (size_t)n + n / 4; IXCHK(hipMalloc(&dAlt.p, 4ull * altCap)); }
+            uint32_t *seg = dROA.as<uint32_t>() + be[0];
+            IXCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb2, seg, dAlt.as<uint32_t>(), (int)n));
+            if (tb2 > temp2Cap) { if (dTemp2.p) hipFree(dTemp2.p); dTemp2.p = nullptr; temp2Cap = tb2 * 2; IXCHK(hipMalloc(&dTemp2.p, temp2Cap)); }
+            IXCHK(hipcub::DeviceRadixSort::SortKeys(dTemp2.p, tb2, seg, dAlt.as<uint32_t>(), (int)n));
+            IXCHK(hipMemcpy(seg, dAlt.p, 4ull * n, hipMemcpyDeviceToDevice));
+        }
+    }
+    IXCHK(hipDeviceSynchronize());
+    if (log) fprintf(log, "Randomly Sampling hits for %d-mers that occur more than %d times in the reference.\n", wordLen, maxHits);
+    uint32_t newTotal = total; const uint32_t *finalSO = dSO.as<uint32_t>(); const uint32_t *finalROA = dROA.as<uint32_t>();
+    if (nOver) {
+        // sampling pass (Index.c:271-315): the over-represented k-mers in ascending order, one generator for all of them
+        std::vector<uint32_t> over(nOver); IXCHK(hipMemcpy(over.data(), dOver.p, 4ull * nOver, hipMemcpyDeviceToHost));
+        std::sort(over.begin(), over.end());
+        IXCHK(hipMalloc(&dSO2.p, 4ull * (HT + 1)));
+        hipLaunchKernelGGL(k_ix_clamp, dim3((unsigned)((HT + 1 + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), HT, (uint32_t)maxHits, dCnt.as<uint32_t>());
+        IXCHK(hipGetLastError());
+        IXCHK(hipcub::DeviceScan::ExclusiveSum(dTemp.p, tb, dCnt.as<uint32_t>(), dSO2.as<uint32_t>(), (int)(HT + 1)));
+        IXCHK(hipMemcpy(&newTotal, dSO2.as<uint32_t>() + HT, 4, hipMemcpyDeviceToHost));
+        IXCHK(hipMalloc(&dROA2.p, 4ull * ((uint64_t)newTotal + 16)));
+        hipLaunchKernelGGL(k_ix_compact, dim3((unsigned)((HT + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), HT, (uint32_t)maxHits, dROA.as<uint32_t>(), dROA2.as<uint32_t>());
+        IXCHK(hipGetLastError());
+        RandState rs; randInitDefault(rs);
+        std::vector<uint32_t> list, sample((size_t)std::max(maxHits, 1));
+        for (uint32_t h : over) {
+            uint32_t be[2], d; IXCHK(hipMemcpy(be, dSO.as<uint32_t>() + h, 8, hipMemcpyDeviceToHost)); IXCHK(hipMemcpy(&d, dSO2.as<uint32_t>() + h, 4, hipMemcpyDeviceToHost));
+            const uint32_t n = be[1] - be[0]; list.resize(n);
+            IXCHK(hipMemcpy(list.data(), dROA.as<uint32_t>() + be[0], 4ull * n, hipMemcpyDeviceToHost));
+            randSample(rs, list.data(), (int)n, sample.data(), maxHits);
+            IXCHK(hipMemcpy(dROA2.as<uint32_t>() + d, sample.data(), 4ull * (size_t)maxHits, hipMemcpyHostToDevice));
+        }
+        finalSO = dSO2.as<uint32_t>(); finalROA = dROA2.as<uint32_t>();
+    }
+    if (log) fprintf(log, "%u %d-mers had more than %d hits.\n", nOver, wordLen, maxHits);
+    if (!image.alloc(4 + HT + 1 + (uint64_t)newTotal)) { err = "Insufficient memory to build the index."; return false; }
+    image[0] = 0xFFFFFFFFu; image[1] = (uint32_t)wordLen; image[2] = (uint32_t)maxHits; image[3] = newTotal;
+    IXCHK(hipMemcpy(image.p + 4, finalSO, 4ull * (HT + 1), hipMemcpyDeviceToHost));
+    if (newTotal) IXCHK(hipMemcpy(image.p + 4 + HT + 1, finalROA, 4ull * newTotal, hipMemcpyDeviceToHost));
+    return true;
+}
+}  // namespace yaha

@@ -13,7 +13,8 @@ static void usage(FILE *o)
 {
     fputs("Usage (defaults in parentheses):\n\n"
           "Index creation:\n"
-          "  yaha -g genome.{fa|fna|fasta|nib2} [-H maxHits (65525)] [-L wordLen (15)] [-S skipDist (1)]\n\n"
+          "  yaha -g genome.{fa|fna|fasta|nib2} [-H maxHits (65525)] [-L wordLen (15)] [-S skipDist (1)] [-device D (0)] [-cpuindex]\n"
+          "       (built on the GPU when one is visible and -S is 1; -cpuindex forces the host builder; the files are identical)\n\n"
           "Query alignment (hot path on MI355X):\n"
           "  yaha -x indexFile [-q queryFile|(stdin)] [-o8|(-osh)|-oss outFile|(stdout)] [-t hostThreads (1)]\n"
           "       [-gpus N (1)] [-ctx contextsPerGpu (2)] [-device D (0)] [-batch readsPerBatch (4096)]\n"
@@ -83,6 +84,7 @@ int parseArgs(int argc, char **argv, Args &a)
         else if (is("-gpus")) { if (!parseInt(val(), "-gpus", a.gpus)) return 2; if (a.gpus < 1) { fprintf(stderr, "-gpus must be at least 1.\n\n"); usage(stderr); return 2; } }
         else if (is("-ctx")) { if (!parseInt(val(), "-ctx", a.ctxPerGpu)) return 2; if (a.ctxPerGpu < 1 || a.ctxPerGpu > 8) { fprintf(stderr, "-ctx must be between 1 and 8.\n\n"); usage(stderr); return 2; } }
         else if (is("-device")) { if (!parseInt(val(), "-device", a.device)) return 2; }
+        else if (is("-cpuindex")) a.cpuIndex = true;
         else if (is("-batch")) { if (!parseInt(val(), "-batch", a.batchReads)) return 2;
                                  if (a.batchReads < 1 || a.batchReads > 65536) { fprintf(stderr, "-batch must be between 1 and 65536 (reads per device batch).\n\n"); usage(stderr); return 2; } }
         else { fprintf(stderr, "%s is not a valid option.\n\n", k); usage(stderr); return 2; }

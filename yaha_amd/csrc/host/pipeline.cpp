@@ -54,7 +54,13 @@ int runIndex(Args &a, FILE *log)                                              //
     fprintf(log, "Creating index file %s.\n", xfile.c_str());
     Genome g; if (!loadNib2(nib2.c_str(), g, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
     IndexImage image;
-    if (!buildIndex(g, a.wordLen, a.skipDist, a.maxHits, image, log)) { fprintf(log, "Insufficient memory to build the index.\n"); return 1; }
+    // count -> scan -> fill -> order -> sample on the GPU (device/index_build.hip) when there is one and the skip distance is the default 1; the host
+    // builder (the reference's three passes, formats.cpp) otherwise.  Both produce the reference's file byte for byte.
+    const bool onDevice = !a.cpuIndex && a.skipDist == 1 && getenv("YAHA_CPU_INDEX") == nullptr && visibleDevices() > a.device;
+    if (onDevice) {
+        fprintf(log, "Building the index on GPU %d.\n", a.device);
+        if (!buildIndexDevice(a.device, g, a.wordLen, a.maxHits, image, log, err)) { fprintf(log, "Index build on the GPU failed: %s\n", err.c_str()); return 1; }
+    } else if (!buildIndex(g, a.wordLen, a.skipDist, a.maxHits, image, log)) { fprintf(log, "Insufficient memory to build the index.\n"); return 1; }
     if (!writeFile(xfile.c_str(), image.p, image.words * 4, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
     fprintf(log, "Index %s created.\n", xfile.c_str());
     return 0;

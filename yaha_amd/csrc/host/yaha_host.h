@@ -50,6 +50,9 @@ struct IndexFile {
 // builds the complete file image {-1, wordLen, maxHits, total} + SO[4^L+1] + ROA[total] (huge-page backed: 4.3 GB at L=15)
 struct IndexImage { uint32_t *p = nullptr; size_t words = 0, bytes = 0; bool alloc(size_t n); void release(); uint32_t &operator[](size_t i) { return p[i]; } ~IndexImage() { release(); } };
 bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, IndexImage &image, FILE *log);
+// the same image built on HIP device `device` (device/index_build.hip; skip distance 1)
+bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, IndexImage &image, FILE *log, std::string &err);
+int  visibleDevices();                                  // HIP devices this process can use (0 on a machine without a GPU)
 bool parseIndex(const uint32_t *img, size_t bytes, IndexFile &ix, std::string &err);
 bool loadIndex(const char *path, IndexFile &ix, std::string &err);
 
@@ -63,7 +66,7 @@ struct Args {
     bool OQC = true; int OQCMinNonOverlap = -1, BPCost = 5, maxBPLog = 5; bool FBS = false; float FBS_PSLength = 0.90f, FBS_PSScore = 0.90f;
     int maxQueryLength = 32000; bool verbose = false, outputBlast8 = false, outputSAM = true, hardClip = true;
     // extensions of this implementation (not in the reference CLI)
-    int batchReads = 4096; int device = 0; int gpus = 1; int ctxPerGpu = 2;
+    int batchReads = 4096; int device = 0; int gpus = 1; int ctxPerGpu = 2; bool cpuIndex = false;
     bool query = false, index = true;
 };
 void postProcessArgs(Args &a, bool query);                                  // AlignArgs.c:108-169
