@@ -36,6 +36,8 @@ static bool fileNewerThan(const std::string &f1, const std::string &f2)      // 
 
 int runIndex(Args &a, FILE *log)                                              // Main.c:587-628
 {
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool timing = getenv("YAHA_TIMING") != nullptr; double t0 = now();
     if (a.wordLen > 15) { fprintf(log, "Word Length (-L) for index creation is currently restricted to < 16.\n"); return 1; }
     if (a.skipDist < 1 || a.skipDist > a.wordLen) { fprintf(log, "Skip Distance (-S) for index creation must be between 1 and WordLength (inclusive).\n"); return 1; }
     size_t dot = a.gfileName.rfind('.'); std::string ext = dot == std::string::npos ? "" : a.gfileName.substr(dot);
@@ -49,6 +51,7 @@ int runIndex(Args &a, FILE *log)                                              //
             std::vector<uint8_t> img;
             if (!compressFasta(a.gfileName.c_str(), img, err) || !writeFile(nib2.c_str(), img.data(), img.size(), err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
             fprintf(log, "Finished compressing %s, now forming index.\n", nib2.c_str());
+            if (timing) { fprintf(log, "[yaha] compress %.1f s\n", now() - t0); t0 = now(); }
         } else fprintf(log, "%s already exists.  Creating the index file.\n", nib2.c_str());
     }
     fprintf(log, "Creating index file %s.\n", xfile.c_str());
@@ -61,7 +64,9 @@ int runIndex(Args &a, FILE *log)                                              //
         fprintf(log, "Building the index on GPU %d.\n", a.device);
         if (!buildIndexDevice(a.device, g, a.wordLen, a.maxHits, image, log, err)) { fprintf(log, "Index build on the GPU failed: %s\n", err.c_str()); return 1; }
     } else if (!buildIndex(g, a.wordLen, a.skipDist, a.maxHits, image, log)) { fprintf(log, "Insufficient memory to build the index.\n"); return 1; }
+    if (timing) { fprintf(log, "[yaha] index image (%.2f GB) built in %.1f s %s\n", image.words * 4 / 1e9, now() - t0, onDevice ? "on the GPU" : "on the host"); t0 = now(); }
     if (!writeFile(xfile.c_str(), image.p, image.words * 4, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
+    if (timing) fprintf(log, "[yaha] index file written in %.1f s\n", now() - t0);
     fprintf(log, "Index %s created.\n", xfile.c_str());
     return 0;
 }
