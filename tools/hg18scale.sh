@@ -3,7 +3,7 @@
 # (-L 15: 4.3 GB table + ~12 GB ROA) on the GPU, then the bench step on it: does reads/s depend on the size of the index?  Run on the GPU box.
 R=$GRAFT_REPO_ROOT; export YAHA_TIMING=1
 cd $R
-/usr/bin/time -v python3 bench.py --genome-mbp 3100 --steps 4 --warmup 1 --no-extras --cpu-seconds 24 > gpurun_out/hg18scale_bench.json 2> gpurun_out/hg18scale_bench.err
+python3 bench.py --genome-mbp 3100 --steps 4 --warmup 1 --no-extras --cpu-seconds 24 > gpurun_out/hg18scale_bench.json 2> gpurun_out/hg18scale_bench.err
 grep -E "\[yaha\]|\[bench\]|Maximum resident|Elapsed|hits|error|Error" gpurun_out/hg18scale_bench.err | head -40
 ls -la /tmp/yaha_bench_cache/ | head
 python3 - <<PY
