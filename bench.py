@@ -169,6 +169,7 @@ def side_workload(ya, idx, reads_path, n_reads, device, contexts, steps, label):
         for c in ctxs:
             c.upload(b)
             c.run()
+            c.run()                                     # two warm-up passes: the first one sizes the arenas, the second one runs with them
         dt, st = run_contexts(ctxs, steps)
         cnt = ctxs[0].collect().counters.as_dict()
         for c in reversed(ctxs):

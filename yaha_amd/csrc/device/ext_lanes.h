@@ -13,8 +13,17 @@
 //                Trace rows are staged in LDS and leave as whole 128-byte blocks of 10 rows; all global stores of an
 //                iteration are issued at its top.  It also stamps its own start / end time (wall_clock64) for bench.py.
 //   k_ext_trace  lane per problem: walks the 4-bit cells back to the origin (run lengths are recovered from the continue
-//                bits; the next 8 rows of a straight run are fetched together) and writes the ops INTO THE STRIP, over
-//                rows the walk has already consumed.
+//                bits; the next 8 rows of a straight run are fetched together), stages the ops in rows the walk has already
+//                consumed, then copies them to an exactly-sized slot of the ops arena.
+//
+// TRACE MEMORY GROWS WITH THE ROWS THAT ARE COMPUTED, not with the rows an extension may reach (an X-drop run stops after a median of 60
+// rows of a bound of ~500): a wave hands its 64 lanes' blocks over together, once every ten rows ("flush"), into one 8 KB slot of the
+// wave's current arena chunk -- lane l's block of the chunk's k-th flush at chunk + l * 2 KB + k * 128 B.  A chunk is YD_CHUNK_FLUSHES consecutive
+// flushes of one wave (128 KB); waves take chunks from a common counter as they go and note them in a per-wave table.  Row i of a problem that started
+// in flush f0 at row slot `phase` of lane l is row (i - 1 + phase) % 10 of the lane-l block of flush f0 + (i - 1 + phase) / 10, whatever
+// the other lanes did meanwhile: (wave, lane, f0, phase) is all the traceback needs (carried in ExtRes).  Consecutive problems of a lane
+// share a block (the earlier one's last rows, the later one's first); a lane starts its next problem no sooner than two row slots after
+// the previous one's last row, because the traceback uses the row after a problem's best row as spare space.
 //
 // The kernel is specialised for the default band (-BW 5: bandwidth 10, W = 21, origin column 10) and needs maxGap >= 10.
 // The reference's boundary insertions V(i, left - i) = -(GO + i*GE) are not special-cased: with PF(0, left) = -GO the
@@ -28,31 +37,42 @@
 #define YD_REFILL_MIN 4                        // idle lanes of a wave before it runs a refill pass
 #define YD_LW 21                               // register columns of the lane kernel = strip width for -BW 5
 #define YD_LWORST (-(1 << 28))                 // sentinel: far below any reachable score (|score| < 2^23), no overflow when it decays
+#define YD_CHUNK_FLUSHES 16                    // flushes of one wave per arena chunk
+#define YD_LANE_DWORDS (YD_CHUNK_FLUSHES * 32)  // inside a chunk a lane's blocks are consecutive (2 KB = 160 rows): a traceback reads neighbouring lines
+#define YD_CHUNK_DWORDS (64 * YD_LANE_DWORDS)  // 128 KB: 64 lanes x 16 flushes x 128 B
+#define YD_LDS_STRIDE 33                       // dwords per lane in the LDS staging block: odd, so that the row code (a lane per bank) and the hand-over
+                                               // (eight lanes read one lane's block) are both free of bank conflicts
 
 typedef uint32_t yd_u32x4 __attribute__((ext_vector_type(4)));
 struct ExtProb { uint32_t qBase, rOff; uint16_t qOff, qLen; uint32_t flags; };           // 16 B; qBase = offset of the read in fwd/rev
 enum { XP_STRAND = 1, XP_REV = 2, XP_VALID = 4 };
-struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, rLen, rows, cells; };       // 32 B; maxj in register columns; rows/cells = work of this call
+// 32 B.  maxj in register columns; rows/cells = work of this call.  where = phase | lane << 4 | wave << 10 (the problem's place in the arena);
+// opsOff = the flush index of its first block as k_ext_rows leaves it, the offset of its op list in the ops arena after k_ext_trace.
+struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, where, rows, cells; };
 
 struct ExtArgs {
     DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
-    const ExtProb *probs; uint32_t nProb; const unsigned long long *stripOff; unsigned long long stripBase;
+    const ExtProb *probs; uint32_t nProb;
     const uint32_t *order;                      // problem indices in processing order (longest bound first), or nullptr
     unsigned long long *clock;                  // optional: [0] = earliest start, [1] = latest end of the launch in wall_clock64() ticks (100 MHz)
-    uint32_t *trace;                            // 128-byte blocks of 10 rows (3 dwords each, 2 dwords of padding); stripOff counts blocks
+    uint32_t *trace; uint32_t nChunks;          // the arena: nChunks chunks of YD_CHUNK_DWORDS
+    unsigned int *chunkCount;                   // chunks handed out so far
+    uint32_t *waveChunks; uint32_t maxCh;       // [wave][maxCh]: the chunk of the wave's flushes [16 k, 16 k + 16)
+    uint32_t *ops; unsigned int *opsCount; uint32_t opsCap;     // k_ext_trace: the op lists, exactly sized, in list order (forward) / reversed (backward)
     ExtRes *res; unsigned int *queue; DevCounters *ctr;      // ctr == nullptr: the consumer of the results accounts for the work (careful extensions)
-    int *errFlag;
+    int *errFlag; int dbgMode;                  // dbgMode: experiments only (YGPU_TRACE_MODE)
 };
+enum { YERR_TRACEMEM = 9 };                     // the trace arena (or a wave's chunk table) is full: the host grows it / cuts the batch and redoes the stage
 
 // CAPS = false when neither run cap can bind inside a 21-column strip (maxGap >= 21 and maxIntron >= 21: a run spans at most 20
 // columns): the run-length state (PI, PD) is then dead and is compiled out.
 // SECOND = the careful-extension round of splitClump (split_lanes.h): same code, its own kernel name in profiles, work counted by
 // the consumer of the results.
+// three waves per SIMD: the register allocation is held at 168 (a fourth wave would cost more in spills than it hides, a third one is needed to cover the row's loads)
 template <bool CAPS, bool SECOND>
-__global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ext_rows(ExtArgs A)
 {
-    __shared__ uint32_t sBlk[32][256];          // per lane: the current 10-row trace block, [dword][thread] (conflict-free for any row slot)
-    __shared__ uint32_t sList[4][3][64];        // per wave: the blocks to write out (owner thread, destination)
+    __shared__ uint32_t sBlk[256 * YD_LDS_STRIDE];   // per lane: the current 10-row trace block (30 dwords), lane stride 33
     if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());
     const int lane = laneId();
     const int GO = A.P.GO, GE = A.P.GE, GOE = A.P.GO + A.P.GE, RC = A.P.RC, MS = A.P.MS, XC = A.P.X, maxIntron = A.P.maxIntron, maxGap = A.P.maxGap;
@@ -60,6 +80,8 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     const uint32_t maxROff = A.P.maxROff;
     YD_GLOBAL const uint8_t *gBases = toGlobal(A.bases);
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t *const myBlk = &sBlk[threadIdx.x * YD_LDS_STRIDE];
 
     // The strip state lives in registers and is written by the row code only (a fresh problem selects its row-0 values at
     // the top of its first row): one definition per loop iteration keeps the register allocator from duplicating it.
@@ -67,65 +89,67 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     uint32_t w0 = 0, w1 = 0, w2 = 0;
     int p = -1, i = 0, qLen = 0, rLen = 0, maxScore = YD_LWORST, maxi = 0, maxj = 0, qStep = 0, qcNext = 0;
     uint32_t rOff = 0; bool rev = false, done = false;
-    YD_GLOBAL const uint8_t *q = toGlobal(A.fwd); YD_GLOBAL uint32_t *strip = toGlobal(A.trace);
+    YD_GLOBAL const uint8_t *q = toGlobal(A.fwd);
     unsigned calls = 0, rows = 0, cells = 0;
 #pragma unroll
     for (int j = 0; j < YD_LW; j++) { PV[j] = YD_LWORST; PF[j] = YD_LWORST; PI[j] = 0; }
 
     // Pool of claimed problems: lane l holds entry l, completely set up (clamped lengths, first reference window, first
-    // query base), so that handing an entry to an idle lane is eight cross-lane moves and no memory latency.  One atomic
+    // query base), so that handing an entry to an idle lane is a few cross-lane moves and no memory latency.  One atomic
     // and one round of dependent loads per 64 problems.
-    unsigned poolBase = 0; int poolCount = 0, poolNext = 0; bool exhausted = false;
-    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, eSLo = 0, eSHi = 0, ePidx = 0;
+    int poolCount = 0, poolNext = 0; bool exhausted = false;
+    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0;
     // deferred stores (see the row code)
-    bool pendFlush = false; YD_GLOBAL uint32_t *pendBlk = toGlobal(A.trace); int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pCells = 0;
-    // The 10-row trace blocks of all lanes of a wave are in phase: row i of a problem that started when the wave was at row slot `phase` sits in
-    // strip row i - 1 + phase, and every lane writes LDS row slot `wslot` in the same iteration.  All blocks of the wave are then complete in the
-    // same iteration (wslot == 9) and leave together, once every ten rows; a problem that ends in between leaves its partial block behind
-    // (`dirty`), which goes out with the next refill pass or the next common hand-over, whichever comes first.
-    int wslot = 0, phase = 0; bool dirty = false; YD_GLOBAL uint32_t *curBlk = toGlobal(A.trace);
-
-    // Finished blocks leave the wave together: the lanes that have one list it in LDS, then eight lanes write each block, 16 bytes apiece, so
-    // that a store instruction carries whole 128-byte lines (a lane writing its own block alone sends eight 16-byte pieces in eight instructions).
+    bool pendFlush = false; int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pCells = 0, pendF0 = 0, pF0 = 0;
+    // Trace memory: the wave's 64 blocks of ten rows leave together (a "flush"), into slot (flush & 15) of the wave's current arena chunk.  wslot = the row
+    // slot all lanes write in this iteration, flush = flushes done so far; a problem notes (flush, wslot) when it starts.  A lane whose problem ended inside
+    // the block keeps the block `dirty` until the next hand-over; a lane that starts a problem inside a block shares it with its previous problem.
+    int wslot = 0, phase = 0; unsigned flush = 0; bool dirty = false, justDone = false;
+    YD_GLOBAL uint32_t *chunkPtr = toGlobal(A.trace); bool noMem = false;
+    auto takeChunk = [&]() {                                                 // wave-uniform: the chunk of flushes [flush, flush + 16)
+        unsigned c = 0;
+        if (lane == 0) c = atomicAdd(A.chunkCount, 1u);
+        c = uniU(c);
+        const unsigned ci = flush / YD_CHUNK_FLUSHES;
+        if (c >= A.nChunks || ci >= A.maxCh) { noMem = true; c = 0; if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_TRACEMEM); }
+        if (lane == 0 && ci < A.maxCh) A.waveChunks[(size_t)wave * A.maxCh + ci] = c;       // (a valid entry also when the arena is full: nothing may follow a stale one)
+        chunkPtr = toGlobal(A.trace) + (size_t)c * YD_CHUNK_DWORDS;
+    };
+    takeChunk();
+    // Hand-over: eight lanes write each block, 16 bytes apiece, so that one store instruction carries eight whole 128-byte lines.
     auto flushBlocks = [&]() {
         const unsigned long long f = __ballot(pendFlush);
-        const int n = __builtin_popcountll(f);
-        if (n == 0) return;
-        const int tid = (int)threadIdx.x, wv = tid >> 6;
-        if (pendFlush) {
-            const int r = __builtin_popcountll(f & lanesBelow); const unsigned long long a = (unsigned long long)pendBlk;
-            sList[wv][0][r] = (uint32_t)tid; sList[wv][1][r] = (uint32_t)a; sList[wv][2][r] = (uint32_t)(a >> 32);
-            pendFlush = false;
+        pendFlush = false;
+        if (f != 0ull && !noMem) {
+            YD_GLOBAL uint32_t *slot = chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u;
+            const int piece = lane & 7, wv = (int)(threadIdx.x >> 6);
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                if (((f >> (g * 8)) & 0xFFull) == 0ull) continue;            // wave-uniform
+                const int o = g * 8 + (lane >> 3);
+                const uint32_t *src = &sBlk[(wv * 64 + o) * YD_LDS_STRIDE + piece * 4];
+                yd_u32x4 v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                if ((f >> o) & 1ull) *(YD_GLOBAL yd_u32x4 *)(slot + o * YD_LANE_DWORDS + piece * 4) = v;
+            }
         }
-        __builtin_amdgcn_wave_barrier();                                     // LDS operations of a wave execute in order; keep the compiler from moving them
-        const uint32_t *flat = &sBlk[0][0];
-        const int piece = lane & 7;
-        for (int g0 = 0; g0 * 8 < n; g0 += 2) {                              // two groups of eight blocks per pass: their LDS reads overlap
-            uint32_t b[2]; unsigned long long a[2]; yd_u32x4 v[2]; bool on[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) { const int e = (g0 + t) * 8 + (lane >> 3); on[t] = e < n; const int ee = on[t] ? e : 0; b[t] = sList[wv][0][ee]; a[t] = (unsigned long long)sList[wv][1][ee] | ((unsigned long long)sList[wv][2][ee] << 32); }
-#pragma unroll
-            for (int t = 0; t < 2; t++) { v[t].x = flat[b[t] + (piece * 4 + 0) * 256]; v[t].y = flat[b[t] + (piece * 4 + 1) * 256]; v[t].z = flat[b[t] + (piece * 4 + 2) * 256]; v[t].w = flat[b[t] + (piece * 4 + 3) * 256]; }
-#pragma unroll
-            for (int t = 0; t < 2; t++) if (on[t]) *(YD_GLOBAL yd_u32x4 *)((YD_GLOBAL uint32_t *)a[t] + piece * 4) = v[t];
-        }
-        __builtin_amdgcn_wave_barrier();
     };
+    auto nextFlush = [&]() { flush++; if (flush % YD_CHUNK_FLUSHES == 0u) takeChunk(); };     // wave-uniform
     bool firstFill = true;
     for (;;) {
+        if (noMem) break;                                                    // wave-uniform: the arena is full, the host redoes the stage with more memory or fewer roots
+        // the blocks the previous iteration completed leave first: a problem that starts now notes the flush its own first block will go out with
+        if (wslot == 0 && __ballot(pendFlush) != 0ull) { flushBlocks(); nextFlush(); }
         // ---- refill: until every lane is busy or nothing is left ----
         for (;;) {
-            const unsigned long long need = __ballot(p < 0 && !done);
+            const unsigned long long need = __ballot(p < 0 && !done && !justDone);
             if (!need) break;
             // a refill pass costs ~100 wave instructions whatever the number of lanes it serves: wait until a few are idle
             if (__builtin_popcountll(need) < YD_REFILL_MIN && __ballot(p >= 0) != 0ull && !firstFill) break;
-            if (p < 0 && dirty) { pendFlush = true; dirty = false; }         // the lanes about to start a problem still hold the last rows of their previous one
-            flushBlocks();
             if (poolNext >= poolCount) {                                     // wave-uniform: claim and set up the next 64 problems
                 unsigned base = 0;
                 if (!exhausted) { if (lane == 0) base = atomicAdd(A.queue, 64u); base = uniU(base); if (base >= A.nProb) exhausted = true; }
                 if (exhausted) { if (p < 0) done = true; break; }
-                poolBase = base; poolCount = (int)min(64u, A.nProb - base); poolNext = 0;
+                poolCount = (int)min(64u, A.nProb - base); poolNext = 0;
                 eLens = 0;
                 if (lane < poolCount) {
                     const unsigned np = A.order ? A.order[base + (unsigned)lane] : base + (unsigned)lane;
@@ -140,12 +164,11 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                         if (!rv_ && (pr.rOff + rl) > maxROff) { rl = maxROff - pr.rOff; ql = (int)rl - bandwidth; }
                         if (ql > 0) { ql &= 0xFFFF; rl &= 0xFFFF; }
                     }
-                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.rLen = 0; r.rows = r.cells = 0; A.res[np] = r; }
+                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.where = 0; r.rows = r.cells = 0; A.res[np] = r; }
                     else {
                         eLens = (uint32_t)ql | (rl << 16); eROff = pr.rOff; eQ = pr.qBase + pr.qOff;
                         YD_GLOBAL const uint8_t *qp = toGlobal((pr.flags & XP_STRAND) ? A.rev : A.fwd) + eQ;
                         eMisc = (pr.flags & 3u) | ((uint32_t)qp[0] << 8);
-                        const unsigned long long so = A.stripOff[np] - A.stripBase; eSLo = (uint32_t)so; eSHi = (uint32_t)(so >> 32);
                         // reference window of row 1: register column c holds reference index c - leftR
                         eW1 = 0; eW2 = 0;
                         for (int c = leftR; c < YD_LW; c++) {
@@ -160,10 +183,10 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             // the k-th idle lane takes entry poolNext + k
             const int nNeed = __builtin_popcountll(need), avail = poolCount - poolNext;
             const int e = poolNext + __builtin_popcountll(need & lanesBelow);
-            const bool take = (p < 0 && !done) && e < poolCount;
+            const bool take = (p < 0 && !done && !justDone) && e < poolCount;
             const int src = take ? e : lane;
             const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
-            const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64), gSLo = (uint32_t)__shfl((int)eSLo, src, 64), gSHi = (uint32_t)__shfl((int)eSHi, src, 64);
+            const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64);
             const uint32_t gPidx = (uint32_t)__shfl((int)ePidx, src, 64);
             const bool init = take && gLens != 0u;
             // row 0 of the strip (SW.cpp:905-935; PF(0, left) = -GO, see the header) for the lanes that start a problem: plain selects,
@@ -177,21 +200,21 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
                 p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
                 rev = (gMisc & XP_REV) != 0; rOff = gROff; pCells = 0;
                 q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu);
-                strip = toGlobal(A.trace) + (((unsigned long long)gSHi << 32) | gSLo) * 32ull; curBlk = strip; phase = wslot;
+                phase = wslot; pF0 = flush;
                 w0 = 0; w1 = gW1; w2 = gW2;
             }
             poolNext += nNeed < avail ? nNeed : avail;
         }
         firstFill = false;
-        if (__ballot(p >= 0) == 0ull) break;
+        if (__ballot(p >= 0) == 0ull && __ballot(justDone) == 0ull) break;   // nothing runs, nothing left (a lane waiting out its gap row keeps the wave alive)
 
         // ---- one DP row in every lane (lanes without a problem run on idle state; their stores are masked) ----
-        // All memory operations of an iteration are issued here at the top: the previous row's trace cells and a finished
+        // All memory operations of an iteration are issued at its top: the previous ten rows' trace cells (above) and a finished
         // problem's result (both deferred), and the loads the row needs at its END (next query base, next reference base).
         // The wait the compiler puts at the loop header then finds them ~1000 instructions old.
-        flushBlocks();                                                       // deferred from the previous row
         if (pendRes >= 0) {
-            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = pendRows >> 20; r.rows = pendRows & 0xFFFFFu; r.cells = pendCells;      // rLen: the strip row of row 1
+            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendF0; r.nOps = 0;
+            r.where = (pendRows >> 20) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows & 0xFFFFFu; r.cells = pendCells;
             A.res[pendRes] = r; pendRes = -1;
         }
         const bool busy = p >= 0;
@@ -236,8 +259,8 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
             dV = upV;                                                        // the next column's diagonal predecessor
             __builtin_amdgcn_sched_barrier(0);                               // keep the cells in program order: their many condition masks stay short-lived
         }
-        { const int slot = wslot * 3, tid = (int)threadIdx.x;               // this row's cells go to the lane's LDS block (the same row slot in every lane)
-          sBlk[slot][tid] = t0; sBlk[slot + 1][tid] = t1; sBlk[slot + 2][tid] = t2; }
+        { const int slot = wslot * 3;                                        // this row's cells go to the lane's LDS block (the same row slot in every lane)
+          myBlk[slot] = t0; myBlk[slot + 1] = t1; myBlk[slot + 2] = t2; }
         int rv = YD_LWORST, rj = 0;
         if (rowKey) { rv = (int)(rowKey >> 5) - YD_BIAS; rj = 31 - (int)(rowKey & 31u); }
         if (rv > maxScore) { maxScore = rv; maxi = i; maxj = rj; }
@@ -245,18 +268,20 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
         const uint32_t nb = nbOdd == 2u ? 15u : (nbOdd ? (nbByte & 15u) : (nbByte >> 4));
         w0 = (w0 >> 4) | (w1 << 28); w1 = (w1 >> 4) | (w2 << 28); w2 = (w2 >> 4) | (nb << 16);
         const bool fin = busy && (rv < maxScore - XC || i >= qLen);
-        if (busy) { dirty = true; pendBlk = curBlk; }
-        if (wslot == 9) { pendFlush = dirty; dirty = false; if (busy) curBlk += 32; wslot = 0; } else wslot++;      // wave-uniform
+        if (busy) dirty = true;
+        if (wslot == 9) { pendFlush = dirty; dirty = false; wslot = 0; } else wslot++;      // wave-uniform
+        justDone = fin;                                                      // the next row slot stays empty behind a finished problem (its traceback's spare row)
         if (fin) {
-            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i | ((unsigned)phase << 20); pendCells = pCells;
+            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i | ((unsigned)phase << 20); pendCells = pCells; pendF0 = pF0;
             p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
         }
     }
-    // the last deferred stores
-    if (dirty) pendFlush = true;
-    flushBlocks();
+    // the last deferred stores; one more flush slot stays reserved behind the last block (the spare row of a problem that ended in row slot 9)
+    if (wslot != 0 && dirty) pendFlush = true;
+    if (!noMem && __ballot(pendFlush) != 0ull) { flushBlocks(); nextFlush(); }
     if (pendRes >= 0) {
-        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = 0; r.nOps = 0; r.rLen = pendRows >> 20; r.rows = pendRows & 0xFFFFFu; r.cells = pendCells;
+        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendF0; r.nOps = 0;
+        r.where = (pendRows >> 20) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows & 0xFFFFFu; r.cells = pendCells;
         A.res[pendRes] = r;
     }
     if (!SECOND && A.clock && lane == 0) atomicMax(&A.clock[1], (unsigned long long)wall_clock64());
@@ -272,73 +297,128 @@ __global__ void __launch_bounds__(256) k_ext_rows(ExtArgs A)
     }
 }
 
-// ---- traceback, lane per problem (SW.cpp:1138-1195) -----------------------------------------------------------------
 struct ExtRowBits { uint32_t a, b, c; };
-__device__ __forceinline__ ExtRowBits extLoadRow(YD_GLOBAL const uint32_t *strip, int y)
-{ ExtRowBits r; YD_GLOBAL const uint32_t *t = strip + (size_t)((y - 1) / 10) * 32u + (size_t)((y - 1) % 10) * 3u; r.a = t[0]; r.b = t[1]; r.c = t[2]; return r; }
 __device__ __forceinline__ uint32_t extNib(const ExtRowBits &r, int x) { const uint32_t w = x < 8 ? r.a : (x < 16 ? r.b : r.c); return (w >> ((x & 7) * 4)) & 15u; }
 
-// Walks from (y, x) back to the origin (0, leftR).  The ops are written INTO THE STRIP, over rows the walk has already
-// consumed: emission k (far end first) goes to dword E-1-k, E = end of row maxi+1 (the strip has one spare row).  After
+// ---- traceback, lane per problem (SW.cpp:1138-1195) -----------------------------------------------------------------
+// Logical strip of a problem: blocks of 32 dwords (10 rows of 3 dwords + 2 spare), block b = the lane's block of the wave's flush f0 + b.
+// Logical dword d lives at chunk(f0 + d / 32) + lane * 512 + ((f0 + d / 32) % 16) * 32 + d % 32.
+__device__ unsigned int gTraceDbg[8];             // diagnostics of the first out-of-strip access (YGPU_TRACE)
+struct ExtStrip {
+    YD_GLOBAL uint32_t *arena; YD_GLOBAL const uint32_t *tab; unsigned f0, laneOff; int cIdx; YD_GLOBAL uint32_t *cBase; int limit; bool wild;
+    __device__ __forceinline__ YD_GLOBAL uint32_t *at(int d)
+    {
+        if ((unsigned)d >= (unsigned)limit) { wild = true; d = 0; }         // outside the problem's strip: a corrupted trace; never follow it into the table
+        const unsigned f = f0 + (unsigned)(d >> 5); const int ci = (int)(f / YD_CHUNK_FLUSHES);
+        if (ci != cIdx) { cIdx = ci; cBase = arena + (size_t)tab[ci] * YD_CHUNK_DWORDS + laneOff; }
+        return cBase + (f % YD_CHUNK_FLUSHES) * 32u + (unsigned)(d & 31);
+    }
+};
+
+// Walks from (y, x) back to the origin (0, leftR).  The ops are staged INSIDE THE STRIP, over rows the walk has already
+// consumed: emission k (far end first) goes to logical dword E-1-k, E = end of row maxi+1 (the strip has one spare row).  After
 // k rows are consumed at most 2k+1 ops exist (every op but a D needs a row of its own, and two D ops never touch) and
-// 3k+3 dwords are free, so the walk never overwrites a row it still has to read.  The result is the ascending array
-// strip[opsOff .. opsOff+nOps): the forward extension's list in order (ops are added to the front, SW.cpp:1186), the
-// backward extension's list reversed (added to the back, SW.cpp:1190).
+// 3k+3 dwords are free, so the walk never overwrites a row it still has to read.  The finished list -- ascending dwords: the forward
+// extension's list in order (ops are added to the front, SW.cpp:1186), the backward extension's list reversed (added to the back,
+// SW.cpp:1190) -- is then copied to a slot of the ops arena that is exactly its size (one reservation per wave).
 __device__ __forceinline__ int extRowWord(int y) { return ((y - 1) / 10) * 32 + ((y - 1) % 10) * 3; }
 #define YD_TRACE_DEPTH 8
 __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.nProb) return;
-    ExtRes r = A.res[p];
-    if (r.score <= 0) return;
-    YD_GLOBAL uint32_t *strip = toGlobal(A.trace) + (A.stripOff[p] - A.stripBase) * 32ull;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId();
+    if (*toGlobal(A.errFlag) != 0) return;                                   // k_ext_rows ran out of arena (or an earlier kernel failed): the stage is redone, its strips are incomplete
+    // problems in the order k_ext_rows took them: the 64 problems of a pool ran in one wave at the same time, so the lanes of a wave here walk neighbouring blocks
+    const bool live = t < A.nProb;
+    const uint32_t p = live ? ((A.order && !(A.dbgMode & 2)) ? A.order[t] : t) : 0u;
+    ExtRes r; r.score = 0; r.nOps = 0;
+    if (live) r = A.res[p];
+    const bool walk = live && r.score > 0;
     constexpr int leftR = YD_LBAND;
-    const int ph = (int)r.rLen;                                              // row i of the problem is strip row i - 1 + ph (k_ext_rows keeps the blocks of a wave in phase)
-    const int E = extRowWord(r.maxi + 1 + ph) + 3;
-    int y = r.maxi, x = r.maxj, prev = -1, acc = 0, n = 0; bool bad = false;
-    // w = word offset of row y inside the strip, rr = its row inside the 10-row block (kept incrementally: no divisions in the loops)
-    int rr = (y - 1 + ph) % 10, w = ((y - 1 + ph) / 10) * 32 + rr * 3;
-    auto flush = [&]() { const int wp = E - 1 - n; if (wp < w + 3) bad = true; else strip[wp] = opMake(prev, acc); n++; };   // rows above row y are consumed
-    auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
-    auto stepUp = [&](int &ww, int &r2) { if (r2 == 0) { r2 = 9; ww -= 5; } else { r2--; ww -= 3; } };                        // one row towards the origin
-    // The kernel is bound by the latency of dependent loads (one per path cell).  Most of a path is straight runs of M / R cells
-    // in one column, so the cells of the next YD_TRACE_DEPTH rows in column x are fetched together (one dword each) and consumed in turn.
-    for (int guard = 0; guard < 70000 && y > 0 && x >= 0 && x < YD_LW; guard++) {
-        const int ws = x >> 3, sh = (x & 7) * 4;
-        uint32_t d[YD_TRACE_DEPTH];
-        { int wk = w, rk = rr;
+    int n = 0; bool bad = false; int E = 0;
+    ExtStrip S; S.arena = toGlobal(A.trace); S.cIdx = -1; S.cBase = S.arena; S.f0 = 0; S.laneOff = 0; S.tab = toGlobal(A.waveChunks); S.limit = 0; S.wild = false;
+    if (walk) {
+        const int ph = (int)(r.where & 15u);                                 // row i of the problem is strip row i - 1 + ph (k_ext_rows keeps the blocks of a wave in phase)
+        S.f0 = r.opsOff; S.laneOff = ((r.where >> 4) & 63u) * YD_LANE_DWORDS; S.tab = toGlobal(A.waveChunks) + (size_t)(r.where >> 10) * A.maxCh;
+        E = extRowWord(r.maxi + 1 + ph) + 3; S.limit = E;
+        int y = r.maxi, x = r.maxj, prev = -1, acc = 0;
+        // The walk keeps a PHYSICAL cursor on row y: cp = its first dword, rr = its row inside the 10-row block, w = its logical word offset (for the
+        // staging bound), fb = its block's flush index.  One row up is cp - 3; across a block boundary cp - 5 (the lane's previous block is the line below),
+        // across a chunk boundary one table look-up.
+        struct Cur { YD_GLOBAL uint32_t *cp; int rr, w; unsigned fb; };
+        Cur c; c.rr = (y - 1 + ph) % 10; c.w = ((y - 1 + ph) / 10) * 32 + c.rr * 3; c.fb = S.f0 + (unsigned)((y - 1 + ph) / 10); c.cp = S.at(c.w);
+        auto stepUp = [&](Cur &u) {                                          // one row towards the origin
+            if (u.rr != 0) { u.rr--; u.w -= 3; u.cp -= 3; return; }
+            u.rr = 9; u.w -= 5; u.fb--;
+            if (u.fb % YD_CHUNK_FLUSHES == YD_CHUNK_FLUSHES - 1u) u.cp = S.arena + (size_t)S.tab[u.fb / YD_CHUNK_FLUSHES] * YD_CHUNK_DWORDS + S.laneOff + (YD_CHUNK_FLUSHES - 1u) * 32u + 27u;
+            else u.cp -= 5;
+        };
+        const int row0w = extRowWord(1 + ph) - 3;                               // the logical position of row 0 (not in the strip): with the cursor there every row is consumed
+        auto flush = [&]() { const int wp = E - 1 - n; if (wp < c.w + 3) bad = true; else *S.at(wp) = opMake(prev, acc); n++; };   // rows above row y are consumed
+        auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
+        // The kernel is bound by the latency of dependent loads (one per path cell).  Most of a path is straight runs of M / R cells
+        // in one column, so the cells of the next YD_TRACE_DEPTH rows in column x are fetched together (one dword each) and consumed in turn.
+        for (int guard = 0; guard < 70000 && y > 0 && x >= 0 && x < YD_LW; guard++) {
+            const int ws = x >> 3, sh = (x & 7) * 4;
+            uint32_t d[YD_TRACE_DEPTH];
+            // rows fetched together: as many as the walk has left, and none beyond the chunk (the cursor steps without branches or table look-ups inside it,
+            // so that the loads are issued back to back)
+            int lim = (int)(c.fb % YD_CHUNK_FLUSHES) * 10 + c.rr + 1; lim = lim < y ? lim : y; lim = lim < YD_TRACE_DEPTH ? lim : YD_TRACE_DEPTH;
+            { YD_GLOBAL uint32_t *up = c.cp; int ur = c.rr;
 #pragma unroll
-          for (int k = 0; k < YD_TRACE_DEPTH; k++) { d[k] = strip[wk + ws]; if (y > k + 1) stepUp(wk, rk); } }
-        uint32_t nib = (d[0] >> sh) & 15u; int took = 0;
+              for (int k = 0; k < YD_TRACE_DEPTH; k++) { d[k] = up[ws]; const bool go = k + 1 < lim; const int dec = ur == 0 ? 5 : 3; up -= go ? dec : 0; ur = go ? (ur == 0 ? 9 : ur - 1) : ur; } }
+            uint32_t nib = (d[0] >> sh) & 15u; int took = 0;
 #pragma unroll
-        for (int k = 0; k < YD_TRACE_DEPTH; k++) {
-            nib = (d[k] >> sh) & 15u;
-            const int op = (int)(nib & 3u);
-            if (op >= OP_D || y <= 0) break;
-            if (prev != op) { if (prev >= 0) flush(); prev = op; acc = 1; } else acc++;
-            y--; stepUp(w, rr); took++;
-        }
-        if (took == YD_TRACE_DEPTH || y <= 0) continue;                                   // still in a straight run (or at the origin row)
-        if ((nib & 3u) == (uint32_t)OP_D) {                                  // deletion run: walk the continue bits along the row
-            ExtRowBits rb; rb.a = strip[w]; rb.b = strip[w + 1]; rb.c = strip[w + 2];
-            int run = 1, xx = x;
-            while (extNib(rb, xx) & 4u) { xx--; if (xx < 0) break; run++; }
-            put(OP_D, run); x -= run;
-        } else {                                                            // insertion run: walk the continue bits up and to the right
-            int run = 1, yy = y, xx = x, ww = w, q2 = rr; uint32_t nb2 = nib;
-            while (nb2 & 8u) {
-                yy--; xx++; if (yy <= 0 || xx >= YD_LW) break;
-                run++; stepUp(ww, q2);
-                nb2 = (strip[ww + (xx >> 3)] >> ((xx & 7) * 4)) & 15u;
+            for (int k = 0; k < YD_TRACE_DEPTH; k++) {
+                if (k >= lim) break;
+                nib = (d[k] >> sh) & 15u;
+                const int op = (int)(nib & 3u);
+                if (op >= OP_D || y <= 0) break;
+                if (prev != op) { if (prev >= 0) flush(); prev = op; acc = 1; } else acc++;
+                y--; took++;
+                if (took < lim) { const int dec = c.rr == 0 ? 5 : 3; c.cp -= dec; c.w -= dec; c.fb -= c.rr == 0 ? 1u : 0u; c.rr = c.rr == 0 ? 9 : c.rr - 1; }   // inside the chunk: no look-up
             }
-            put(OP_I, run); for (int t = 0; t < run; t++) stepUp(w, rr); y -= run; x += run;
+            if (took == lim) { if (y > 0) stepUp(c); else c.w = row0w; continue; }          // the whole batch was a straight run: one full step (it may leave the chunk), next batch
+            if ((nib & 3u) == (uint32_t)OP_D) {                                  // deletion run: walk the continue bits along the row
+                ExtRowBits rb; rb.a = c.cp[0]; rb.b = c.cp[1]; rb.c = c.cp[2];
+                int run = 1, xx = x;
+                while (extNib(rb, xx) & 4u) { xx--; if (xx < 0) break; run++; }
+                put(OP_D, run); x -= run;
+            } else {                                                            // insertion run: walk the continue bits up and to the right
+                int run = 1, yy = y, xx = x; Cur u = c; uint32_t nb2 = nib;
+                while (nb2 & 8u) {
+                    yy--; xx++; if (yy <= 0 || xx >= YD_LW) break;
+                    run++; stepUp(u);
+                    nb2 = (u.cp[xx >> 3] >> ((xx & 7) * 4)) & 15u;
+                }
+                put(OP_I, run); y -= run; x += run;
+                if (y > 0) { for (int k = 0; k < run; k++) stepUp(c); } else c.w = row0w;
+            }
         }
+        if (y <= 0 && x > leftR) put(OP_D, x - leftR);                           // row 0: deletions back to the origin (SW.cpp:905-935)
+        if (prev >= 0) { const int wp = E - 1 - n; if (wp < 0) bad = true; else *S.at(wp) = opMake(prev, acc); n++; }
+        if (bad || S.wild) { bad = true; atomicCAS(A.errFlag, 0, (int)YERR_TRACE); n = 0; if (S.wild && atomicCAS(&gTraceDbg[5], 0u, 1u) == 0u) { gTraceDbg[6] = p; gTraceDbg[7] = r.where; } }
     }
-    if (y <= 0 && x > leftR) put(OP_D, x - leftR);                           // row 0: deletions back to the origin (SW.cpp:905-935)
-    if (prev >= 0) { const int wp = E - 1 - n; if (wp < 0) bad = true; else strip[wp] = opMake(prev, acc); n++; }
-    if (bad) { atomicCAS(A.errFlag, 0, (int)YERR_TRACE); return; }
-    r.opsOff = (uint32_t)(E - n); r.nOps = (uint32_t)n; A.res[p] = r;
+    // exactly-sized slots in the ops arena: one reservation per wave
+    if (A.dbgMode & 1) n = 0;
+    int incl = n;
+#pragma unroll
+    for (int d2 = 1; d2 < 64; d2 <<= 1) { const int v = __shfl_up(incl, d2, 64); if (lane >= d2) incl += v; }
+    const int total = __shfl(incl, 63, 64); unsigned ob = 0;
+    if (lane == 63 && total) ob = atomicAdd(A.opsCount, (unsigned)total);
+    ob = (unsigned)__shfl((int)ob, 63, 64);
+    if (walk && !bad) {
+        const unsigned off = ob + (unsigned)(incl - n);
+        if ((unsigned long long)off + (unsigned)n > (unsigned long long)A.opsCap) { atomicCAS(A.errFlag, 0, (int)YERR_OUT); return; }
+        YD_GLOBAL uint32_t *dst = toGlobal(A.ops) + off;
+        for (int k0 = 0; k0 < n; k0 += 8) {                                  // eight loads in flight, then eight stores (the staged list is a few lines in L2)
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (k0 + j < n) ? *S.at(E - n + k0 + j) : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (k0 + j < n) dst[k0 + j] = v[j];
+        }
+        r.opsOff = off; r.nOps = (uint32_t)n; A.res[p] = r;
+    }
 }
 
 // order values are global problem indices; a chunk's kernels index from the chunk's first problem

@@ -76,7 +76,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.35, opsRatio = 0.03; DevBuf waveChunks, extOps, traceCnt;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -298,7 +298,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->rowsBound.p + nProb, 0, 8, ctx->stream));
     PhaseArgs X; X.state = ctx->rootState.as<RootState>(); X.stateOps = ctx->stateOps.as<uint32_t>(); X.stateOpsCount = cnt + CNT_STATEOPS; X.stateOpsCap = stateOpsCap;
-    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.trace = nullptr; X.stripOff = nullptr; X.stripBase = 0; X.rootBegin = 0;
+    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = nullptr; X.rootBegin = 0;
     TRACE("lanes: ensure");
     X.slowList = ctx->slowList.as<uint32_t>(); X.slowCount = cnt + CNT_SLOW; X.useList = 1;
     EV0(T_P1);
@@ -334,71 +334,80 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     EV1(T_P1);
     TRACE("lanes: p1+scan");
     if (kTrace) { uint32_t v[3] = {0, 0, 0}; fetchU32(ctx, cnt + CNT_SLOW, &v[0]); uint32_t w[3] = {0, 0, 0}; fetchU32(ctx, cnt + CNT_NDP, w, 3); v[1] = w[0]; v[2] = w[2]; fprintf(stderr, "[ygpu] roots %u, joints %u, DP joints %u (W<=16: %u, wave fallback %u), gap ops %u\n", NC, J, v[1], w[1], v[0], v[2]); }
-    unsigned long long totalRows = 0;
-    HIPCHK(hipMemcpyAsync(&totalRows, ctx->stripOff.as<unsigned long long>() + nProb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long boundBlocks = 0;                                      // sum over the problems of the 10-row blocks each may reach (its row BOUND)
+    HIPCHK(hipMemcpyAsync(&boundBlocks, ctx->stripOff.as<unsigned long long>() + nProb, 8, hipMemcpyDeviceToHost, ctx->stream));
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
     if (ef == YERR_OUT) return -2;
     if (ef) return 0;                                                         // reported by the caller
-    // Trace memory: 128-byte blocks of 10 rows.  The roots are processed in chunks: k_ext_rows of chunk c+1 (VALU-bound, main
-    // stream) overlaps the latency-bound tail of chunk c (traceback, scoreClump/emit, splitClump waves; second stream).  When
-    // the strips do not fit in memory the chunks reuse one buffer and run back to back instead.
-    // The budget is this context's share of the free memory (the contexts of one device run concurrently and each sees the same free figure); when the
-    // allocation still fails (another process, fragmentation) the budget is halved and the roots take the chunked path instead of failing the batch.
-    size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
-    const int nShare = std::max(1, gCtxPerDevice[ctx->device & 63].load());
-    unsigned long long budget = std::max<unsigned long long>(1ull << 16, (unsigned long long)((freeB / nShare + ctx->extTrace.cap) * 7 / 10) / 128ull);
-    budget = std::min<unsigned long long>(budget, (96ull << 30) / 128ull);    // at most 96 GB of strips per context: bounds the first-use allocation
-    if (ctx->traceBudgetBlocks > 0) budget = (unsigned long long)ctx->traceBudgetBlocks;     // test hook: force the chunked path
-    std::vector<uint32_t> cuts; bool fits = false, haveStrip = false; size_t nChunks = 0; unsigned long long chunkMax = 0;
-    for (int tries = 0;; tries++) {
-        cuts.assign(1, 0u);                                                   // root indices
-        fits = totalRows <= budget;
-        if (fits) {
-            const uint32_t K = (ctx->laneChunks > 0) ? (uint32_t)ctx->laneChunks : 1u;      // measured: every k_ext_rows launch ends in a drain of long problems, so more chunks lose more than the overlap gains
-            for (uint32_t c = 1; c <= K; c++) { uint32_t r1 = (uint32_t)((uint64_t)NC * c / K); if (r1 > cuts.back()) cuts.push_back(r1); }
-        } else {
-            if (!haveStrip) {
-                ctx->hStripOff.resize(nProb + 1); haveStrip = true;
-                HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
-            }
-            uint32_t r0 = 0;
-            while (r0 < NC) {
-                uint32_t lo = r0 + 1, hi = NC;                                // largest r1 with strips(r0 .. r1) <= budget
-                if (ctx->hStripOff[2 * (size_t)lo] - ctx->hStripOff[2 * (size_t)r0] > budget) { ctx->err = "not enough device memory for one root's extension trace strips"; return YGPU_ENOMEM; }
-                while (lo < hi) { uint32_t mid = lo + (hi - lo + 1) / 2; if (ctx->hStripOff[2 * (size_t)mid] - ctx->hStripOff[2 * (size_t)r0] <= budget) lo = mid; else hi = mid - 1; }
-                cuts.push_back(lo); r0 = lo;
-            }
-        }
-        nChunks = cuts.size() - 1; chunkMax = 0;
-        if (fits) chunkMax = totalRows; else for (size_t c = 0; c < nChunks; c++) chunkMax = std::max(chunkMax, ctx->hStripOff[2 * (size_t)cuts[c + 1]] - ctx->hStripOff[2 * (size_t)cuts[c]]);
-        if (ctx->extTrace.ensure(128ull * chunkMax + 256) == 0) break;
-        (void)hipGetLastError();                                              // the failed hipMalloc is handled here
-        if (tries >= 5 || ctx->traceBudgetBlocks > 0) { ctx->err = "hipMalloc failed for the extension trace strips"; return YGPU_ENOMEM; }
-        budget = std::max<unsigned long long>(1ull << 16, std::min(budget, chunkMax) / 2);
-    }
-    TRACE("lanes: cuts + trace memory");
-    ENSURE(ctx->chunkCnt, 32ull * (nChunks + 1));                            // 8 words per chunk: queues and counts of its kernels
-    HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 32ull * (nChunks + 1), ctx->stream));
-    if (kTrace) fprintf(stderr, "[ygpu] trace blocks %llu budget %llu chunks %zu %s\n", totalRows, budget, nChunks, fits ? "(pipelined)" : "(sequential, one buffer)");
+    // ---- trace memory (ext_lanes.h): an arena of 128 KB chunks that the waves of k_ext_rows take as their rows are computed -------------------------
+    // What a launch will need is not known before it ran (an X-drop run stops where it stops); the arena is sized from the bound scaled by the ratio
+    // the last batches showed (ctx->traceRatio, a quarter of the bound to begin with) and the stage is redone with a larger one when it overflows.
+    // When even the budget (this context's share of the free memory) is not enough, the roots are cut into ranges that use the arena one after the other.
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
-    ENSURE(ctx->rowsClock, 16); { const unsigned long long init[2] = {~0ull, 0ull}; HIPCHK(hipMemcpyAsync(ctx->rowsClock.p, init, 16, hipMemcpyHostToDevice, ctx->stream)); }
-    E.clock = ctx->rowsClock.as<unsigned long long>();
-    E.trace = ctx->extTrace.as<uint32_t>(); E.ctr = ctx->ctr.as<DevCounters>(); E.errFlag = ctx->errFlag.as<int>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
     auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
     auto rowsKernel2 = caps ? k_ext_rows<true, true> : k_ext_rows<false, true>;
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
-    const bool overlap = fits && nChunks > 1;
-    hipStream_t sTail = overlap ? ctx->stream2 : ctx->stream;
-    X.trace = ctx->extTrace.as<uint32_t>(); X.stripOff = ctx->stripOff.as<unsigned long long>();
+    const unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU), maxWavesK = maxBlocksK * 4u;
+    const double chunkBlocks = (double)YD_CHUNK_FLUSHES * 64.0;             // lane blocks (128 B) per chunk
+    size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
+    const int nShare = std::max(1, gCtxPerDevice[ctx->device & 63].load());
+    unsigned long long budgetChunks = std::max<unsigned long long>(maxWavesK + 64ull, (unsigned long long)((freeB / nShare + ctx->extTrace.cap) * 7 / 10) / (YD_CHUNK_DWORDS * 4ull));
+    budgetChunks = std::min<unsigned long long>(budgetChunks, (96ull << 30) / (YD_CHUNK_DWORDS * 4ull));
+    const double slackChunks = (double)maxWavesK + 64.0;                    // every wave's open chunk
+    const double wantChunks = (double)boundBlocks * ctx->traceRatio / chunkBlocks + slackChunks;
+    std::vector<uint32_t> cuts; cuts.push_back(0);                            // root indices
+    unsigned long long nChunksArena = 0;
+    if (wantChunks <= (double)budgetChunks && ctx->traceBudgetBlocks <= 0) { cuts.push_back(NC); nChunksArena = (unsigned long long)wantChunks; }
+    else {
+        // ranges of roots whose estimated need fits the budget (the estimate follows the problems' bounds); YGPU_TRACE_BUDGET_BLOCKS (test hook) sets the
+        // bound blocks per range directly, so that small inputs take this path
+        double perRange = std::max(1.0, ((double)budgetChunks - slackChunks) * chunkBlocks / ctx->traceRatio);                                  // bound blocks per range
+        if (ctx->traceBudgetBlocks > 0) perRange = std::min(perRange, (double)ctx->traceBudgetBlocks);
+        nChunksArena = (unsigned long long)std::min((double)budgetChunks, perRange * ctx->traceRatio / chunkBlocks + slackChunks);
+        ctx->hStripOff.resize(nProb + 1);
+        HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        uint32_t r0 = 0;
+        while (r0 < NC) {
+            uint32_t lo = r0 + 1, hi = NC;                                    // largest r1 with bound(r0 .. r1) <= perRange (at least one root)
+            while (lo < hi) { uint32_t mid = lo + (hi - lo + 1) / 2; if ((double)(ctx->hStripOff[2 * (size_t)mid] - ctx->hStripOff[2 * (size_t)r0]) <= perRange) lo = mid; else hi = mid - 1; }
+            cuts.push_back(lo); r0 = lo;
+        }
+    }
+    const size_t nRanges = cuts.size() - 1;
+    nChunksArena = std::min<unsigned long long>(std::max<unsigned long long>(nChunksArena, maxWavesK + 64ull), 0xFFFFFFF0ull);
+    if (ctx->extTrace.ensure((size_t)nChunksArena * YD_CHUNK_DWORDS * 4ull + 256) != 0) {
+        (void)hipGetLastError();
+        // the allocation failed although the budget allowed it (another process, fragmentation): take what is there and let the ranges do the rest
+        ctx->traceRatio = std::max(ctx->traceRatio, 0.05); ctx->err = "hipMalloc failed for the extension trace arena"; return YGPU_ENOMEM;
+    }
+    nChunksArena = std::min<unsigned long long>(0xFFFFFFF0ull, (unsigned long long)((ctx->extTrace.cap - 256) / (YD_CHUNK_DWORDS * 4ull)));
+    const uint32_t maxCh = (uint32_t)std::min<unsigned long long>(nChunksArena, std::max<unsigned long long>(64ull, 4ull * nChunksArena / std::max(1u, maxWavesK) + 64ull));
+    ENSURE(ctx->waveChunks, 4ull * (size_t)maxWavesK * maxCh + 64);
+    // the op lists of the extensions (exactly sized slots, k_ext_trace): sized like the arena, from the ratio of the last batches
+    const uint32_t extOpsCap = (uint32_t)std::min<double>(2.0e9, (double)boundBlocks * 10.0 * ctx->opsRatio + 4.0e6);
+    ENSURE(ctx->extOps, 4ull * extOpsCap + 64);
+    ENSURE(ctx->chunkCnt, 32ull * (nRanges + 2));                            // 8 words per range: queues and counts of its kernels
+    HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 32ull * (nRanges + 2), ctx->stream));
+    ENSURE(ctx->traceCnt, 64); HIPCHK(hipMemsetAsync(ctx->traceCnt.p, 0, 64, ctx->stream));       // [0] chunks handed out, [1] ops handed out, [2] the high-water mark of [0] over the ranges
+    TRACE("lanes: trace arena");
+    if (kTrace) fprintf(stderr, "[ygpu] trace bound %.2f GB, arena %.2f GB (%llu chunks, ratio %.3f), %zu range(s); ext ops cap %u\n", boundBlocks * 128.0 / 1e9, nChunksArena * (YD_CHUNK_DWORDS * 4.0) / 1e9, nChunksArena, ctx->traceRatio, nRanges, extOpsCap);
+    ENSURE(ctx->rowsClock, 16); { const unsigned long long init[2] = {~0ull, 0ull}; HIPCHK(hipMemcpyAsync(ctx->rowsClock.p, init, 16, hipMemcpyHostToDevice, ctx->stream)); }
+    E.clock = ctx->rowsClock.as<unsigned long long>();
+    E.trace = ctx->extTrace.as<uint32_t>(); E.nChunks = (uint32_t)nChunksArena; E.chunkCount = ctx->traceCnt.as<unsigned int>(); E.waveChunks = ctx->waveChunks.as<uint32_t>(); E.maxCh = maxCh;
+    E.ops = ctx->extOps.as<uint32_t>(); E.opsCount = ctx->traceCnt.as<unsigned int>() + 1; E.opsCap = extOpsCap;
+    E.ctr = ctx->ctr.as<DevCounters>(); E.errFlag = ctx->errFlag.as<int>(); E.dbgMode = getenv("YGPU_TRACE_MODE") ? atoi(getenv("YGPU_TRACE_MODE")) : 0;
+    X.extOps = ctx->extOps.as<uint32_t>();
     uint32_t *cc = ctx->chunkCnt.as<uint32_t>();
+    unsigned long long usedChunksMax = 0;
     EV0(T_XROWS);
-    for (size_t c = 0; c < nChunks; c++) {
+    for (size_t c = 0; c < nRanges; c++) {
         const uint32_t r0 = cuts[c], r1 = cuts[c + 1], p0 = 2 * r0, np = 2 * (r1 - r0);
-        const unsigned long long sb = fits ? 0ull : ctx->hStripOff[p0];
-        E.probs = ctx->extProbs.as<ExtProb>() + p0; E.nProb = np; E.stripOff = ctx->stripOff.as<unsigned long long>() + p0; E.stripBase = sb; E.res = ctx->extRes.as<ExtRes>() + p0;
+        E.probs = ctx->extProbs.as<ExtProb>() + p0; E.nProb = np; E.res = ctx->extRes.as<ExtRes>() + p0;
         E.queue = cc + 8 * c;
+        HIPCHK(hipMemsetAsync(ctx->traceCnt.p, 0, 4, ctx->stream));          // the arena starts empty for every range (the previous one's lists are in the ops arena)
+        HIPCHK(hipMemsetAsync(E.res, 0, sizeof(ExtRes) * (uint64_t)np, ctx->stream));   // a launch that runs out of arena leaves problems unfinished: they must read as "no extension", not as the last batch's results
         {   // longest bound first: the launch's drain phase is then left with short problems only
             size_t bytes = 0; uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 17, ctx->stream));
@@ -407,73 +416,91 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             KL(k_rebase_u32, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, v1, np, p0);
             E.order = v1;
         }
-        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + 255) / 256, (uint64_t)ctx->nCU * perCU);
+        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + 255) / 256, (uint64_t)maxBlocksK);
         KL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, E);
-        if (c + 1 == nChunks) EV1(T_XROWS);
-        if (overlap) { HIPCHK(hipEventRecord(ctx->evChunk[c % YD_MAX_CHUNK_EV], ctx->stream)); HIPCHK(hipStreamWaitEvent(sTail, ctx->evChunk[c % YD_MAX_CHUNK_EV], 0)); }
-        else TRACE("lanes: ext_rows");
-        // the chunk's tail
-        if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], sTail); }
-        KL(k_ext_trace, dim3(gridFor(np, 256)), dim3(256), 0, sTail, E);
-        if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_XTRACE][1], sTail);
-        if (!overlap) TRACE("lanes: ext_trace");
+        if (c + 1 == nRanges) EV1(T_XROWS);
+        TRACE("lanes: ext_rows");
+        if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], ctx->stream); }
+        KL(k_ext_trace, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E);
+        if (c + 1 == nRanges) hipEventRecord(ctx->ev[T_XTRACE][1], ctx->stream);
+        TRACE("lanes: ext_trace");
+        if (kTrace) { unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gTraceDbg), sizeof w8); if (w8[0]) { ExtRes rr; hipMemcpy(&rr, E.res + w8[6], sizeof rr, hipMemcpyDeviceToHost); ExtProb pp; hipMemcpy(&pp, E.probs + w8[6], sizeof pp, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[ygpu] k_ext_trace left its strip: dword %d of %u, f0 %u, laneOff %u; problem %u where %08x (wave %u lane %u phase %u) score %d maxi %d maxj %d rows %u qLen %u flags %u\n", (int)w8[1], w8[2], w8[3], w8[4], w8[6], w8[7], w8[7] >> 10, (w8[7] >> 4) & 63, w8[7] & 15, rr.score, rr.maxi, rr.maxj, rr.rows, pp.qLen, pp.flags);
+            memset(w8, 0, sizeof w8); hipMemcpyToSymbol(HIP_SYMBOL(gTraceDbg), w8, sizeof w8); } }
         AlignArgs Ac = A; Ac.nRoots = r1; Ac.queueHead = cc + 8 * c + 1;
-        PhaseArgs Xc = X; Xc.stripBase = sb; Xc.rootBegin = r0; Xc.slowList = ctx->slowList.as<uint32_t>() + r0; Xc.slowCount = cc + 8 * c + 2; Xc.useList = 1;
-        if (c == 0) { ctx->evUsed[T_P3] = true; hipEventRecord(ctx->ev[T_P3][0], sTail); }
+        PhaseArgs Xc = X; Xc.rootBegin = r0; Xc.slowList = ctx->slowList.as<uint32_t>() + r0; Xc.slowCount = cc + 8 * c + 2; Xc.useList = 1;
+        if (c == 0) { ctx->evUsed[T_P3] = true; hipEventRecord(ctx->ev[T_P3][0], ctx->stream); }
         const uint32_t nr = r1 - r0, cap2 = nr / 4 + 1024;
         if (ctx->splitLanes) {
             ENSURE(ctx->memoKeys, 12ull * YD_MEMO * (nr + 1)); ENSURE(ctx->memoCount, 4ull * (nr + 1)); ENSURE(ctx->probs2, sizeof(ExtProb) * (uint64_t)cap2);
-            ENSURE(ctx->rowsBound2, 8ull * (cap2 + 1)); ENSURE(ctx->stripOff2, 8ull * (cap2 + 1)); ENSURE(ctx->extRes2, sizeof(ExtRes) * (uint64_t)cap2); ENSURE(ctx->fallList, 4ull * (nr + 1));
-            HIPCHK(hipMemsetAsync(ctx->memoCount.p, 0, 4ull * (nr + 1), sTail)); HIPCHK(hipMemsetAsync(ctx->rowsBound2.p, 0, 8ull * (cap2 + 1), sTail));
+            ENSURE(ctx->rowsBound2, 8ull * (cap2 + 1)); ENSURE(ctx->extRes2, sizeof(ExtRes) * (uint64_t)cap2); ENSURE(ctx->fallList, 4ull * (nr + 1));
+            HIPCHK(hipMemsetAsync(ctx->memoCount.p, 0, 4ull * (nr + 1), ctx->stream)); HIPCHK(hipMemsetAsync(ctx->rowsBound2.p, 0, 8ull * (cap2 + 1), ctx->stream));
             Xc.memoKeys = ctx->memoKeys.as<uint32_t>(); Xc.memoCount = ctx->memoCount.as<unsigned int>(); Xc.probs2 = ctx->probs2.as<ExtProb>(); Xc.rowsBound2 = ctx->rowsBound2.as<unsigned long long>();
             Xc.nProb2 = cc + 8 * c + 3; Xc.probs2Cap = cap2;
         } else { Xc.memoKeys = nullptr; Xc.memoCount = nullptr; Xc.probs2 = nullptr; Xc.rowsBound2 = nullptr; Xc.nProb2 = nullptr; Xc.probs2Cap = 0; }
-        KL(k_p3_lanes, dim3(gridFor(nr, 256)), dim3(256), 0, sTail, Ac, Xc);
+        KL(k_p3_lanes, dim3(gridFor(nr, 256)), dim3(256), 0, ctx->stream, Ac, Xc);
         PhaseArgs Xw = Xc;                                                    // what k_align_p3 gets: all split roots, or only those k_split_lanes gives back
+        // the range's use of the arena (for the next batch's estimate), then the careful-extension round starts it afresh
+        unsigned int used[2] = {0, 0}; uint32_t three[3] = {0, 0, 0};       // slow roots, predicted problems
+        HIPCHK(hipMemcpyAsync(used, ctx->traceCnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->splitLanes) HIPCHK(hipMemcpyAsync(three, cc + 8 * c + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        usedChunksMax = std::max<unsigned long long>(usedChunksMax, used[0]);
         if (ctx->splitLanes) {
             // splitClump in lanes: the careful extensions the split roots will ask for go through a second k_ext_rows / k_ext_trace round
-            rc = cubScan64(ctx, ctx->rowsBound2.as<unsigned long long>(), ctx->stripOff2.as<unsigned long long>(), cap2 + 1, sTail); if (rc) return rc;
-            uint32_t three[3] = {0, 0, 0}; unsigned long long blocks2 = 0;       // slow roots, predicted problems
-            HIPCHK(hipMemcpyAsync(three, cc + 8 * c + 2, 8, hipMemcpyDeviceToHost, sTail));
-            HIPCHK(hipMemcpyAsync(&blocks2, ctx->stripOff2.as<unsigned long long>() + cap2, 8, hipMemcpyDeviceToHost, sTail)); HIPCHK(hipStreamSynchronize(sTail));
             const uint32_t nSlow = three[0], n2 = std::min(three[1], cap2);
-            if (kTrace) fprintf(stderr, "[ygpu] split roots %u, careful extensions listed %u (trace blocks %llu)\n", nSlow, n2, blocks2);
+            if (kTrace) fprintf(stderr, "[ygpu] range %zu: chunks used %u, ext ops %u; split roots %u, careful extensions listed %u\n", c, used[0], used[1], nSlow, n2);
             if (nSlow) {
                 ExtArgs E2 = E;
                 if (n2) {
-                    ENSURE(ctx->extTrace2, 128ull * blocks2 + 256);
-                    E2.probs = ctx->probs2.as<ExtProb>(); E2.nProb = n2; E2.stripOff = ctx->stripOff2.as<unsigned long long>(); E2.stripBase = 0;
+                    E2.probs = ctx->probs2.as<ExtProb>(); E2.nProb = n2;
+                    HIPCHK(hipMemsetAsync(ctx->traceCnt.p, 0, 4, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->extRes2.p, 0, sizeof(ExtRes) * (uint64_t)n2, ctx->stream));
                     {   // longest bound first here too: this launch is small and ends when its longest problem ends
                         ENSURE(ctx->keys2a, 4ull * (cap2 + 1)); ENSURE(ctx->keys2b, 4ull * (cap2 + 1)); ENSURE(ctx->vals2a, 4ull * (cap2 + 1)); ENSURE(ctx->vals2b, 4ull * (cap2 + 1));
-                        KL(k_prob_keys, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, ctx->probs2.as<ExtProb>(), n2, ctx->keys2a.as<uint32_t>(), ctx->vals2a.as<uint32_t>());
+                        KL(k_prob_keys, dim3(gridFor(n2, 256)), dim3(256), 0, ctx->stream, ctx->probs2.as<ExtProb>(), n2, ctx->keys2a.as<uint32_t>(), ctx->vals2a.as<uint32_t>());
                         size_t bytes = 0;
-                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, sTail));
+                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, ctx->stream));
                         if (ctx->cubTemp2.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp2.p, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, sTail));
+                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp2.p, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, ctx->stream));
                     }
-                    E2.order = ctx->vals2b.as<uint32_t>(); E2.trace = ctx->extTrace2.as<uint32_t>(); E2.res = ctx->extRes2.as<ExtRes>(); E2.queue = cc + 8 * c + 4; E2.ctr = nullptr;   // counted by k_split_lanes
+                    E2.order = ctx->vals2b.as<uint32_t>(); E2.res = ctx->extRes2.as<ExtRes>(); E2.queue = cc + 8 * c + 4; E2.ctr = nullptr;   // counted by k_split_lanes
                     {   // a small launch: a few problems per lane, so its length is set by the lanes' chains of problems, not by the chip's throughput.  One wave
                         // per SIMD runs a row 2.4x faster than three sharing it (a lone wave issues every ~5 cycles) and gives every lane more problems to balance.
                         const uint64_t blocks2 = ctx->rows2PerCU > 0 ? (uint64_t)ctx->rows2PerCU : (uint64_t)ctx->nCU;
-                        KL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(((uint64_t)n2 + 255) / 256, blocks2)), dim3(256), 0, sTail, E2); }
-                    KL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, sTail, E2);
+                        KL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(std::min<uint64_t>(((uint64_t)n2 + 255) / 256, blocks2), (uint64_t)maxBlocksK)), dim3(256), 0, ctx->stream, E2); }
+                    KL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, ctx->stream, E2);
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
                 SplitArgs Sx; Sx.scratch = ctx->splitScratch.as<uint8_t>(); Sx.memoKeys = ctx->memoKeys.as<uint32_t>(); Sx.memoCount = ctx->memoCount.as<unsigned int>();
-                Sx.res2 = ctx->extRes2.as<ExtRes>(); Sx.trace2 = ctx->extTrace2.as<uint32_t>(); Sx.stripOff2 = ctx->stripOff2.as<unsigned long long>(); Sx.nProb2 = n2;
+                Sx.res2 = ctx->extRes2.as<ExtRes>(); Sx.ops2 = ctx->extOps.as<uint32_t>(); Sx.nProb2 = n2;
                 Sx.fallList = ctx->fallList.as<uint32_t>(); Sx.fallCount = cc + 8 * c + 5; Sx.nSlots = nSlow;
-                KL(k_split_lanes, dim3(gridFor(nSlow, 64)), dim3(64), 0, sTail, Ac, Xc, Sx);
+                KL(k_split_lanes, dim3(gridFor(nSlow, 64)), dim3(64), 0, ctx->stream, Ac, Xc, Sx);
                 Xw.slowList = ctx->fallList.as<uint32_t>(); Xw.slowCount = cc + 8 * c + 5;
-                if (kTrace) { uint32_t fc = 0; HIPCHK(hipMemcpyAsync(&fc, cc + 8 * c + 5, 4, hipMemcpyDeviceToHost, sTail)); HIPCHK(hipStreamSynchronize(sTail)); unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gFallWhy), sizeof w8); fprintf(stderr, "[ygpu] roots left to the wave kernel %u (other %u, DP not listed %u, second split %u, depth/list %u)\n", fc, w8[0], w8[1], w8[2], w8[3]); memset(w8, 0, sizeof w8); hipMemcpyToSymbol(HIP_SYMBOL(gFallWhy), w8, sizeof w8); }
+                if (kTrace) { uint32_t fc = 0; HIPCHK(hipMemcpyAsync(&fc, cc + 8 * c + 5, 4, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gFallWhy), sizeof w8); fprintf(stderr, "[ygpu] roots left to the wave kernel %u (other %u, DP not listed %u, second split %u, depth/list %u)\n", fc, w8[0], w8[1], w8[2], w8[3]); memset(w8, 0, sizeof w8); hipMemcpyToSymbol(HIP_SYMBOL(gFallWhy), w8, sizeof w8); }
             }
         }
-        KL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, sTail, Ac, Xw);
-        if (c + 1 == nChunks) hipEventRecord(ctx->ev[T_P3][1], sTail);
-        if (!overlap) TRACE("lanes: p3");
+        KL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, ctx->stream, Ac, Xw);
+        if (c + 1 == nRanges) hipEventRecord(ctx->ev[T_P3][1], ctx->stream);
+        TRACE("lanes: p3");
     }
-    if (overlap) { HIPCHK(hipEventRecord(ctx->evTail, sTail)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0)); }
     HIPCHK(hipMemcpyAsync(ctx->hRowsClock, ctx->rowsClock.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    TRACE("lanes: chunks done");
+    // errors of the trace memory: grow what overflowed and have the caller redo the stage
+    unsigned int usedOps = 0; HIPCHK(hipMemcpyAsync(&usedOps, ctx->traceCnt.as<unsigned int>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+    if (ef == YERR_TRACEMEM) {
+        if (ctx->traceRatio >= 64.0) { ctx->err = "the extension trace arena overflows even at 64 times the problems' bound"; return YGPU_ENOMEM; }
+        ctx->traceRatio = std::min(64.0, ctx->traceRatio * 2.0); return -3;
+    }
+    if (ef == YERR_OUT && usedOps > extOpsCap) { ctx->opsRatio = std::min(4.0, std::max(ctx->opsRatio * 2.0, 1.3 * (double)usedOps / std::max(1.0, (double)boundBlocks * 10.0))); return -3; }
+    if (ef == 0 && boundBlocks) {
+        // next batch's estimate: what this one used, with a margin
+        const double usedRatio = ((double)usedChunksMax - (double)std::min<unsigned long long>(usedChunksMax, maxWavesK)) * chunkBlocks * (double)nRanges / (double)boundBlocks;
+        // (followed at once: an estimate that turns out too small costs one redo of the stage, one that stays too large costs memory and, for long reads whose
+        // bound is a hundred times their use, forces the ranges)
+        ctx->traceRatio = std::max(0.01, usedRatio * 1.3);
+        ctx->opsRatio = std::max(0.002, std::max(1.3 * (double)usedOps / ((double)boundBlocks * 10.0), ctx->opsRatio * 0.7));
+    }
+    TRACE("lanes: ranges done");
     return 0;
 }
 
@@ -518,21 +545,23 @@ static int stageAlign(ygpu_ctx *ctx)
 #ifdef YD_PROF
             { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); }
 #endif
-            bool laneOverflow = false;
+            bool laneOverflow = false, traceOverflow = false;
             if (!useLanes) KL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
-            else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, gapOpsPerJoint); if (rc == -2) laneOverflow = true; else if (rc) return rc; }
+            else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, gapOpsPerJoint); if (rc == -2) laneOverflow = true; else if (rc == -3) traceOverflow = true; else if (rc) return rc; }
 #ifdef YD_PROF
             { hipStreamSynchronize(ctx->stream); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
               const char *nm[10] = {"root_total", "dp_rows", "traceback", "perfect_ext", "score", "emit", "split", "merge", "dp_calls", "roots"};
               fprintf(stderr, "[YD_PROF] waves %u:", waves); for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", nm[i], z[i]); fprintf(stderr, "\n"); }
 #endif
             uint32_t got[2] = {0, 0}, ef = 0;
-            if (laneOverflow) ef = YERR_OUT;
+            if (laneOverflow || traceOverflow) ef = YERR_OUT;
             else { rc = fetchU32(ctx, cnt + CNT_OUTCLUMPS, got, 2); if (rc) return rc; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc; }
             if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
-            if (ef != YERR_OUT || attempt >= 6) { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
-            outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
-            gapOpsPerJoint *= 2; stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap);
+            if (ef != YERR_OUT || attempt >= 12) { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
+            if (!traceOverflow) {                                            // (a full trace arena has grown its own estimate)
+                outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
+                gapOpsPerJoint *= 2; stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap);
+            }
             HIPCHK(hipMemcpyAsync(ctx->clumpFrags.p, ctx->clumpFrags0.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_SCORED, 0, 8 * (16 - C_SCORED), ctx->stream));
         }
@@ -641,7 +670,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps};
+                         &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         for (int i = 0; i < YD_MAX_CHUNK_EV; i++) hipEventDestroy(ctx->evChunk[i]);
@@ -838,25 +867,33 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
     HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
     std::vector<ExtRes> hres(nX); std::vector<JointRec> hj(nJ); std::vector<uint32_t> xOff(nX + 1, 0), jOff(nJ + 1, 0);
     if (nX) {
-        xrows.push_back(0ull);
-        ENSURE(ctx->extProbs, sizeof(ExtProb) * (uint64_t)nX); ENSURE(ctx->rowsBound, 8ull * (nX + 1)); ENSURE(ctx->stripOff, 8ull * (nX + 1)); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nX); ENSURE(ctx->chunkCnt, 64);
+        ENSURE(ctx->extProbs, sizeof(ExtProb) * (uint64_t)nX); ENSURE(ctx->extRes, sizeof(ExtRes) * (uint64_t)nX); ENSURE(ctx->chunkCnt, 64);
         HIPCHK(hipMemcpyAsync(ctx->extProbs.p, xp.data(), sizeof(ExtProb) * (uint64_t)nX, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->rowsBound.p, xrows.data(), 8ull * (nX + 1), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 64, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->extRes.p, 0, sizeof(ExtRes) * (uint64_t)nX, ctx->stream));
-        rc = cubScan64(ctx, ctx->rowsBound.as<unsigned long long>(), ctx->stripOff.as<unsigned long long>(), nX + 1); if (rc) return rc;
-        unsigned long long blocks = 0; HIPCHK(hipMemcpyAsync(&blocks, ctx->stripOff.as<unsigned long long>() + nX, 8, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (blocks > (32ull << 30) / 128ull) { ctx->err = "too many extension rows in one ygpu_dp_batch call"; return YGPU_EINVAL; }
-        ENSURE(ctx->extTrace, 128ull * blocks + 256);
-        ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>(); E.probs = ctx->extProbs.as<ExtProb>(); E.nProb = nX;
-        E.stripOff = ctx->stripOff.as<unsigned long long>(); E.stripBase = 0; E.order = nullptr; E.clock = nullptr; E.trace = ctx->extTrace.as<uint32_t>(); E.res = ctx->extRes.as<ExtRes>();
-        E.queue = ctx->chunkCnt.as<unsigned int>(); E.ctr = nullptr; E.errFlag = ctx->errFlag.as<int>();
+        unsigned long long blocks = 0, opsBound = 64; for (uint32_t k = 0; k < nX; k++) { blocks += xrows[k]; opsBound += 2ull * xp[k].qLen + 4; }
         const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
         auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
         auto rowsKernel2 = caps ? k_ext_rows<true, true> : k_ext_rows<false, true>;
         int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
-        const unsigned blocksK = (unsigned)std::min<uint64_t>(((uint64_t)nX + 255) / 256, (uint64_t)ctx->nCU * (second ? 1 : perCU));
+        const unsigned blocksK = (unsigned)std::min<uint64_t>(((uint64_t)nX + 255) / 256, (uint64_t)ctx->nCU * (second ? 1 : perCU)), wavesK = blocksK * 4u;
+        // the arena at the problems' full bound (every lane slot of a flush counts, so twice that) plus a chunk of slack per wave: test-sized batches
+        for (unsigned long long mult = 2;; mult *= 8) {
+        const unsigned long long nCh = mult * blocks / (YD_CHUNK_FLUSHES * 64ull) + 2ull * wavesK + 64ull;
+        if (nCh * (YD_CHUNK_DWORDS * 4ull) > (64ull << 30) || opsBound > 0x7FFFFFF0ull) { ctx->err = "too many extension rows in one ygpu_dp_batch call"; return YGPU_EINVAL; }
+        const uint32_t maxCh = (uint32_t)nCh;
+        ENSURE(ctx->extTrace, nCh * (YD_CHUNK_DWORDS * 4ull) + 256); ENSURE(ctx->waveChunks, 4ull * (size_t)wavesK * maxCh + 64); ENSURE(ctx->extOps, 4ull * opsBound + 64); ENSURE(ctx->traceCnt, 64);
+        HIPCHK(hipMemsetAsync(ctx->traceCnt.p, 0, 64, ctx->stream));
+        ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>(); E.probs = ctx->extProbs.as<ExtProb>(); E.nProb = nX;
+        E.order = nullptr; E.clock = nullptr; E.trace = ctx->extTrace.as<uint32_t>(); E.nChunks = (uint32_t)nCh; E.chunkCount = ctx->traceCnt.as<unsigned int>(); E.waveChunks = ctx->waveChunks.as<uint32_t>(); E.maxCh = maxCh;
+        E.ops = ctx->extOps.as<uint32_t>(); E.opsCount = ctx->traceCnt.as<unsigned int>() + 1; E.opsCap = (uint32_t)opsBound; E.res = ctx->extRes.as<ExtRes>();
+        E.queue = ctx->chunkCnt.as<unsigned int>(); E.ctr = nullptr; E.errFlag = ctx->errFlag.as<int>(); E.dbgMode = 0;
         if (second) KL(rowsKernel2, dim3(blocksK), dim3(256), 0, ctx->stream, E); else KL(rowsKernel, dim3(blocksK), dim3(256), 0, ctx->stream, E);
         KL(k_ext_trace, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, E);
+        uint32_t ef2 = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef2); if (rc) return rc;
+        if (ef2 != YERR_TRACEMEM) break;                                    // (other errors are reported below)
+        if (mult >= 1024) { ctx->err = "extension trace arena overflows"; return YGPU_ENOMEM; }
+        HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 64, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->extRes.p, 0, sizeof(ExtRes) * (uint64_t)nX, ctx->stream));
+        }
         HIPCHK(hipMemcpyAsync(hres.data(), ctx->extRes.p, sizeof(ExtRes) * (uint64_t)nX, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
         for (uint32_t k = 0; k < nX; k++) xOff[k + 1] = xOff[k] + (hres[k].score > 0 ? hres[k].nOps : 0u);
     }
@@ -897,7 +934,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
     uint32_t *dOff = ctx->dpProbs.as<uint32_t>(), *dDst = dOff + (n + 2);       // per-list offsets and destinations (the lists are done one after the other)
     if (nX) {
         HIPCHK(hipMemcpyAsync(dOff, xOff.data(), 4ull * nX, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipMemcpyAsync(dDst, xdst.data(), 4ull * nX, hipMemcpyHostToDevice, ctx->stream));
-        KL(k_dp_gather_ext, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, ctx->extProbs.as<ExtProb>(), ctx->extRes.as<ExtRes>(), ctx->stripOff.as<unsigned long long>(), ctx->extTrace.as<uint32_t>(), dOff, dDst, nX,
+        KL(k_dp_gather_ext, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, ctx->extProbs.as<ExtProb>(), ctx->extRes.as<ExtRes>(), ctx->extOps.as<uint32_t>(), dOff, dDst, nX,
            ctx->dpRes.as<ygpu_dp_result>(), ctx->dpOps.as<uint32_t>());
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
