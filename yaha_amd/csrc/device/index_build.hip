@@ -21,6 +21,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <ctime>
+#include <cstdlib>
 #include "../host/yaha_host.h"
 
 namespace {
@@ -121,10 +123,22 @@ __global__ void k_ix_compact(const uint32_t *so, const uint32_t *so2, uint64_t n
     for (uint32_t i = 0; i < n; i++) roa2[d + i] = roa[b + i];
 }
 
+// (begin, end, new begin) of the listed k-mers in one array: the host loops over a handful of long lists without a copy per list
+__global__ void k_ix_gather(const uint32_t *so, const uint32_t *so2, const uint32_t *list, uint32_t n, uint32_t minLen, uint32_t *out, unsigned int *nOut)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = list[i], b = so[h], e = so[h + 1];
+    if (e - b <= minLen) return;
+    const unsigned s = atomicAdd(nOut, 1u);
+    out[4 * (size_t)s] = h; out[4 * (size_t)s + 1] = b; out[4 * (size_t)s + 2] = e; out[4 * (size_t)s + 3] = so2 ? so2[h] : 0u;
+}
+
 struct Buf { void *p = nullptr; ~Buf() { if (p) hipFree(p); } template <class T> T *as() { return (T *)p; } };
 }  // namespace
 
 namespace yaha {
+static double wallNow() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 int visibleDevices() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 
 // Builds the complete index file image {-1, wordLen, maxHits, total} + startingOffs[4^k + 1] + ROA[total] on HIP device `device`.
@@ -132,6 +146,8 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, Ind
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { err = "no such HIP device"; return false; }
+    const bool timing = getenv("YAHA_TIMING") != nullptr; double tLast = wallNow();
+    auto lap = [&](const char *what) { if (timing && log) { hipDeviceSynchronize(); const double t = wallNow(); fprintf(log, "[yaha]   index on GPU: %-28s %7.2f s\n", what, t - tLast); tLast = t; } };
     IXCHK(hipSetDevice(device));
     const uint64_t HT = 1ull << (2 * wordLen), nOffsets = g.nBaseBytes * 2;
     std::vector<uint32_t> st, ln; for (auto &s : g.seqs) if ((int64_t)s.length >= wordLen) { st.push_back(s.start); ln.push_back(s.length); }
@@ -142,6 +158,7 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, Ind
     IXCHK(hipMalloc(&dStart.p, 4ull * (nSeq + 1))); IXCHK(hipMalloc(&dLen.p, 4ull * (nSeq + 1)));
     if (nSeq) { IXCHK(hipMemcpy(dStart.p, st.data(), 4ull * nSeq, hipMemcpyHostToDevice)); IXCHK(hipMemcpy(dLen.p, ln.data(), 4ull * nSeq, hipMemcpyHostToDevice)); }
     SeqTab T; T.start = dStart.as<uint32_t>(); T.len = dLen.as<uint32_t>(); T.n = nSeq;
+    lap("reference to HBM");
     IXCHK(hipMalloc(&dCnt.p, 4ull * (HT + 1))); IXCHK(hipMemset(dCnt.p, 0, 4ull * (HT + 1)));
     const uint64_t nThreads = (nOffsets + IX_PER_THREAD - 1) / IX_PER_THREAD; const unsigned grid = (unsigned)((nThreads + 255) / 256);
     if (grid) hipLaunchKernelGGL(k_ix_count, dim3(grid), dim3(256), 0, 0, dBases.as<uint8_t>(), T, wordLen, nOffsets, dCnt.as<uint32_t>());
@@ -151,11 +168,13 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, Ind
     size_t tb = 0; IXCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (int)(HT + 1)));
     IXCHK(hipMalloc(&dTemp.p, tb)); IXCHK(hipcub::DeviceScan::ExclusiveSum(dTemp.p, tb, dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (int)(HT + 1)));
     uint32_t total = 0; IXCHK(hipMemcpy(&total, dSO.as<uint32_t>() + HT, 4, hipMemcpyDeviceToHost));
+    lap("count + scan");
     // fill (the counters become the cursors)
     IXCHK(hipMemset(dCnt.p, 0, 4ull * (HT + 1)));
     IXCHK(hipMalloc(&dROA.p, 4ull * ((uint64_t)total + 16)));
     if (grid) hipLaunchKernelGGL(k_ix_fill, dim3(grid), dim3(256), 0, 0, dBases.as<uint8_t>(), T, wordLen, nOffsets, dSO.as<uint32_t>(), dCnt.as<uint32_t>(), dROA.as<uint32_t>());
     IXCHK(hipGetLastError());
+    lap("fill");
     // order every list
     uint32_t bigCap = 1u << 22, overCap = 1u << 20; unsigned int two[2] = {0, 0};
     IXCHK(hipMalloc(&dBig.p, 4ull * bigCap)); IXCHK(hipMalloc(&dOver.p, 4ull * overCap)); IXCHK(hipMalloc(&dN.p, 8));
@@ -175,21 +194,25 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, Ind
     if (nBig) {
         hipLaunchKernelGGL(k_ix_order_block, dim3(std::min<uint32_t>(nBig, 4096u)), dim3(256), 0, 0, dSO.as<uint32_t>(), dBig.as<uint32_t>(), nBig, dROA.as<uint32_t>());
         IXCHK(hipGetLastError());
-        std::vector<uint32_t> big(nBig); IXCHK(hipMemcpy(big.data(), dBig.p, 4ull * nBig, hipMemcpyDeviceToHost));
         // the few lists beyond a workgroup's LDS: one device radix sort each
+        Buf dHuge; IXCHK(hipMalloc(&dHuge.p, 16ull * nBig + 16)); IXCHK(hipMemset(dN.p, 0, 4));
+        hipLaunchKernelGGL(k_ix_gather, dim3((nBig + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), (const uint32_t *)nullptr, dBig.as<uint32_t>(), nBig, IX_BLOCK, dHuge.as<uint32_t>(), dN.as<unsigned int>());
+        IXCHK(hipGetLastError());
+        unsigned int nHuge = 0; IXCHK(hipMemcpy(&nHuge, dN.p, 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> huge(4ull * nHuge); if (nHuge) IXCHK(hipMemcpy(huge.data(), dHuge.p, 16ull * nHuge, hipMemcpyDeviceToHost));
         Buf dAlt; size_t altCap = 0; size_t tb2 = 0; Buf dTemp2; size_t temp2Cap = 0;
-        for (uint32_t h : big) {
-            uint32_t be[2]; IXCHK(hipMemcpy(be, dSO.as<uint32_t>() + h, 8, hipMemcpyDeviceToHost));
-            const uint32_t n = be[1] - be[0]; if (n <= IX_BLOCK) continue;
+        for (unsigned int k = 0; k < nHuge; k++) {
+            const uint32_t b0 = huge[4ull * k + 1], n = huge[4ull * k + 2] - b0;
             if (n > altCap) { if (dAlt.p) hipFree(dAlt.p); dAlt.p = nullptr; altCap = (size_t)n + n / 4; IXCHK(hipMalloc(&dAlt.p, 4ull * altCap)); }
-            uint32_t *seg = dROA.as<uint32_t>() + be[0];
+            uint32_t *seg = dROA.as<uint32_t>() + b0;
             IXCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb2, seg, dAlt.as<uint32_t>(), (int)n));
             if (tb2 > temp2Cap) { if (dTemp2.p) hipFree(dTemp2.p); dTemp2.p = nullptr; temp2Cap = tb2 * 2; IXCHK(hipMalloc(&dTemp2.p, temp2Cap)); }
             IXCHK(hipcub::DeviceRadixSort::SortKeys(dTemp2.p, tb2, seg, dAlt.as<uint32_t>(), (int)n));
-            IXCHK(hipMemcpy(seg, dAlt.p, 4ull * n, hipMemcpyDeviceToDevice));
+            IXCHK(hipMemcpyAsync(seg, dAlt.p, 4ull * n, hipMemcpyDeviceToDevice, 0));
         }
     }
     IXCHK(hipDeviceSynchronize());
+    lap("order the lists");
     if (log) fprintf(log, "Randomly Sampling hits for %d-mers that occur more than %d times in the reference.\n", wordLen, maxHits);
     uint32_t newTotal = total; const uint32_t *finalSO = dSO.as<uint32_t>(); const uint32_t *finalROA = dROA.as<uint32_t>();
     if (nOver) {
@@ -206,20 +229,31 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, Ind
         IXCHK(hipGetLastError());
         RandState rs; randInitDefault(rs);
         std::vector<uint32_t> list, sample((size_t)std::max(maxHits, 1));
-        for (uint32_t h : over) {
-            uint32_t be[2], d; IXCHK(hipMemcpy(be, dSO.as<uint32_t>() + h, 8, hipMemcpyDeviceToHost)); IXCHK(hipMemcpy(&d, dSO2.as<uint32_t>() + h, 4, hipMemcpyDeviceToHost));
-            const uint32_t n = be[1] - be[0]; list.resize(n);
-            IXCHK(hipMemcpy(list.data(), dROA.as<uint32_t>() + be[0], 4ull * n, hipMemcpyDeviceToHost));
+        Buf dOv; IXCHK(hipMalloc(&dOv.p, 16ull * nOver + 16)); IXCHK(hipMemset(dN.p, 0, 4));
+        IXCHK(hipMemcpy(dOver.p, over.data(), 4ull * nOver, hipMemcpyHostToDevice));        // ascending now
+        hipLaunchKernelGGL(k_ix_gather, dim3((nOver + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), dOver.as<uint32_t>(), nOver, 0u, dOv.as<uint32_t>(), dN.as<unsigned int>());
+        IXCHK(hipGetLastError());
+        std::vector<uint32_t> ov(4ull * nOver); IXCHK(hipMemcpy(ov.data(), dOv.p, 16ull * nOver, hipMemcpyDeviceToHost));
+        std::vector<size_t> idx(nOver); for (size_t k = 0; k < nOver; k++) idx[k] = k;
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ov[4 * a] < ov[4 * b]; });   // the gather's atomics shuffled them: back to k-mer order (the generator's order)
+        for (size_t k : idx) {
+            const uint32_t b0 = ov[4 * k + 1], n = ov[4 * k + 2] - b0, d = ov[4 * k + 3]; list.resize(n);
+            IXCHK(hipMemcpy(list.data(), dROA.as<uint32_t>() + b0, 4ull * n, hipMemcpyDeviceToHost));
             randSample(rs, list.data(), (int)n, sample.data(), maxHits);
             IXCHK(hipMemcpy(dROA2.as<uint32_t>() + d, sample.data(), 4ull * (size_t)maxHits, hipMemcpyHostToDevice));
         }
         finalSO = dSO2.as<uint32_t>(); finalROA = dROA2.as<uint32_t>();
     }
     if (log) fprintf(log, "%u %d-mers had more than %d hits.\n", nOver, wordLen, maxHits);
+    lap("sampling + compaction");
     if (!image.alloc(4 + HT + 1 + (uint64_t)newTotal)) { err = "Insufficient memory to build the index."; return false; }
     image[0] = 0xFFFFFFFFu; image[1] = (uint32_t)wordLen; image[2] = (uint32_t)maxHits; image[3] = newTotal;
+    const bool pinned = hipHostRegister(image.p, image.bytes, hipHostRegisterDefault) == hipSuccess;      // DMA straight into the image instead of staging through a bounce buffer
+    if (!pinned) (void)hipGetLastError();
     IXCHK(hipMemcpy(image.p + 4, finalSO, 4ull * (HT + 1), hipMemcpyDeviceToHost));
     if (newTotal) IXCHK(hipMemcpy(image.p + 4 + HT + 1, finalROA, 4ull * newTotal, hipMemcpyDeviceToHost));
+    if (pinned) hipHostUnregister(image.p);
+    lap("image to host memory");
     return true;
 }
 }  // namespace yaha
