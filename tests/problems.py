@@ -93,3 +93,36 @@ def write_long_indel_reads(genome_fa, out, n, seed, max_del=1250, junk=0, flank=
             if rnd.random() < 0.5:
                 s = "".join(comp[c] for c in reversed(s))
             f.write(">indel_%s_%d_%d_%d\n%s\n" % (names[si], a, d, i, s))
+
+
+def load_stage_golden(name, read_ids):
+    """tests/golden/stage_<name>.json.gz (made by tests/golden/make_stage_golden.py from an instrumented build of the REAL reference):
+    returns (fragments {read*2+strand: [(sro, sqo, eqo, refLen), ...]}, DP problems, expected DP results)."""
+    import gzip
+    import json
+    import os
+    d = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stage_%s.json.gz" % name), "rt"))
+    idx = {rid: i for i, rid in enumerate(read_ids)}
+    frags = {}
+    for rid, strand, fl in d["fragments"]:
+        frags[idx[rid] * 2 + strand] = [tuple(f) for f in fl]
+    mode = {"full": ya.DP_FULL, "banded": ya.DP_BANDED, "ext_fwd": ya.DP_EXT_FWD, "ext_rev": ya.DP_EXT_REV}
+    probs, exp = [], []
+    for kind, rid, strand, rOff, rLen, qOff, qLen, score, aQ, aR, ops in d["dp"]:
+        m = mode[kind]
+        if m < ya.DP_EXT_FWD and score == 0:
+            continue                                    # (the dump prints no list for a zero score; cannot be compared)
+        probs.append(ya.DPProblem(idx[rid], strand, m, qOff, qLen, rLen, rOff))
+        ol = tuple((int(o[:-1]), o[-1]) for o in ops.split()) if ops else ()
+        exp.append((score, aQ, aR, ol))
+    return d, frags, probs, exp
+
+
+def fasta_ids(path, n):
+    out = []
+    for line in open(path):
+        if line.startswith(">"):
+            out.append(line[1:].strip().replace(" ", "_"))
+            if len(out) == n:
+                break
+    return out

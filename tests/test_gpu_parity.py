@@ -264,3 +264,25 @@ def test_index_built_on_the_device_is_byte_identical(work, meta, tmp_path):
         assert subprocess.run(["cmp", "-s", dev, os.path.join(d, name)]).returncode == 0, "device-built index differs from the host-built one: " + name
         os.remove(dev)
         os.remove(os.path.join(d, name))
+
+
+@pytest.mark.parametrize("name", ["r1k", "rchim"])
+def test_device_stages_match_the_instrumented_reference(work, index11, name):
+    # ygpu_seed_join and ygpu_dp_batch (every kernel family) replayed against dumps of the REAL reference -- the fragment arrays after
+    # findFragmentsSort and each DP call's arguments and results, printed by an instrumented build (tests/golden/make_stage_golden.py, fixtures
+    # tests/golden/stage_*.json.gz) -- not against this repo's own restatement.
+    from problems import load_stage_golden, fasta_ids
+    reads = os.path.join(work, name + ".fa")
+    ids = fasta_ids(reads, 24)
+    d, frags, probs, exp = load_stage_golden(name, ids)
+    with ya.Session(["-x", index11, "-q", reads]) as s:
+        b = s.next_batch(24)
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.upload(b)
+            f, n = ctx.seed_join()
+            got = {}
+            for sro, sqo, eqo, rl, rs in frag_tuples(f, n):
+                got.setdefault(rs, []).append((sro, sqo, eqo, rl))
+            assert got == frags
+            for kernels in (ya.DP_KERNELS_AUTO, ya.DP_KERNELS_WAVE, ya.DP_KERNELS_LANES, ya.DP_KERNELS_LANES_CAREFUL):
+                _dp_check(ctx, probs, exp, kernels)

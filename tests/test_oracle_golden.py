@@ -171,3 +171,22 @@ def test_large_gap_parameters_match_the_live_reference(work, index11, tmp_path, 
         r, _own = oracle.run(s.index, s.params, b, threads=4)
         assert r.counters.dp_gap_cells > 40 * 4000                  # the wide gap fills really ran (strip width ~ the indel's length)
     assert run_oracle_pipeline(index11, reads, "-osh", extra) == want
+
+
+@pytest.mark.parametrize("name", ["r1k", "rchim"])
+def test_oracle_stages_match_the_instrumented_reference(work, index11, name):
+    # fragment arrays after findFragmentsSort and every DP call of the REAL reference (an instrumented build, tests/golden/make_stage_golden.py)
+    from problems import load_stage_golden, fasta_ids
+    reads = os.path.join(work, name + ".fa")
+    ids = fasta_ids(reads, 24)
+    d, frags, probs, exp = load_stage_golden(name, ids)
+    assert len(probs) > 400 and len(frags) >= 40
+    with ya.Session(["-x", index11, "-q", reads]) as s:
+        b = s.next_batch(24)
+        got = {}
+        for sro, sqo, eqo, rl, rs in oracle.seed_join(s.index, s.params, b):
+            got.setdefault(rs, []).append((sro, sqo, eqo, rl))
+        assert got == frags
+        res = oracle.dp_batch(s.index, s.params, b, probs)
+        bad = [k for k in range(len(probs)) if res[k] != exp[k]]
+        assert not bad, "%d of %d DP calls differ from the reference, first: %r got %r exp %r" % (len(bad), len(probs), (probs[bad[0]].mode, probs[bad[0]].rOff, probs[bad[0]].qOff, probs[bad[0]].qLen), res[bad[0]], exp[bad[0]])
