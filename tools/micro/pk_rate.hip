@@ -36,6 +36,10 @@ template <int OP> __global__ void __launch_bounds__(256) k(uint32_t *out, int it
                 if (OP == 20) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(a[i]));                            // VOP2 with a 32-bit literal (8-byte encoding)
                 if (OP == 21) asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(c));                    // the same operation in the VOP3 encoding
                 if (OP == 22) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "s"(c));                        // SGPR operand
+                if (OP == 23) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, s[20:21]" : "+v"(a[i]) : : "vcc");        // shift a lane-mask bit in: carry-in from an SGPR pair
+                if (OP == 24) asm volatile("v_cmp_ge_i32 s[20:21], %0, %1\n v_max_i32 %0, %0, %1\n s_nop 1\n v_addc_co_u32 %2, vcc, %2, %2, s[20:21]" : "+v"(a[i]), "+v"(a[(i + 1) & 7]) : "v"(c) : "vcc", "s20", "s21");
+                if (OP == 25) asm volatile("v_cmp_ge_i32 s[20:21], %0, %1\n v_max_i32 %0, %0, %1\n v_cndmask_b32 %2, 0, 4, s[20:21]\n v_or_b32 %0, %0, %2" : "+v"(a[i]), "+v"(a[(i + 1) & 7]) : "v"(c) : "s20", "s21");
+                if (OP == 26) asm volatile("v_addc_co_u32 %0, s[22:23], %0, %0, s[20:21]" : "+v"(a[i]) : : "s22", "s23");
             }
         }
     }
@@ -51,7 +55,7 @@ template <int OP> void run(const char *name, uint32_t *d)
         hipLaunchKernelGGL(k<OP>, dim3(256 * w), dim3(256), 0, 0, d, 4, 12345u); (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0); hipLaunchKernelGGL(k<OP>, dim3(256 * w), dim3(256), 0, 0, d, iters, 12345u); (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-        const int perAsm = (OP == 12 || OP == 13 || OP == 19) ? 2 : 1;
+        const int perAsm = (OP == 12 || OP == 13 || OP == 19) ? 2 : (OP == 24 ? 3 : (OP == 25 ? 4 : 1));
         const double instr = (double)iters * REP * 8 * perAsm * w;       // per SIMD
         printf("  %dw: %5.2f", w, ms * 1e-3 * 2.4e9 / instr);
     }
@@ -67,6 +71,7 @@ int main()
     run<12>("v_cmp vcc + dependent v_cndmask", d); run<13>("v_cmp sgpr pair + dependent v_cndmask", d);
     run<8>("v_add3_u32 (VOP3)", d); run<9>("v_lshl_or_b32 (VOP3)", d); run<10>("v_bfi_b32 (VOP3)", d); run<11>("v_and_or_b32 (VOP3)", d);
     run<2>("v_pk_sub_i16 clamp (VOP3P)", d); run<3>("v_pk_max_i16 (VOP3P)", d); run<19>("v_sub_u32 / v_pk_max_i16 alternating", d);
+    run<23>("v_addc_co_u32 vcc out, sgpr-pair carry in", d); run<26>("v_addc_co_u32 sgpr out, sgpr-pair carry in", d); run<24>("v_cmp sgpr + v_max + s_nop 1 + v_addc (per VALU)", d); run<25>("v_cmp sgpr + v_max + v_cndmask + v_or (per VALU)", d);
     run<14>("v_sub_u32, one dependent chain", d); run<15>("v_pk_sub_i16 clamp, one dependent chain", d);
     return 0;
 }
