@@ -32,7 +32,7 @@ __global__ void k_dp_gather_ext(const ExtProb *probs, const ExtRes *res, const u
     if (p >= n) return;
     const ExtRes r = res[p]; ygpu_dp_result o; o.score = 0; o.addedQLen = o.addedRLen = 0; o.op_start = outOff[p]; o.n_ops = 0;
     if (r.score > 0) {
-        const bool rv = (probs[p].flags & XP_REV) != 0; const uint32_t *src = extOps + r.opsOff; const char codes[4] = {'M', 'R', 'D', 'I'};
+        const bool rv = (probs[p].flags & XP_REV) != 0; const uint32_t *src = extOpsPtr(extOps, r); const char codes[4] = {'M', 'R', 'D', 'I'};
         o.score = r.score; o.addedQLen = (uint16_t)r.maxi; o.addedRLen = (uint16_t)(r.maxi + (r.maxj - YD_LBAND)); o.n_ops = r.nOps;
         for (uint32_t k = 0; k < r.nOps; k++) { const uint32_t op = src[rv ? r.nOps - 1u - k : k]; outOps[o.op_start + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
     }

@@ -47,8 +47,10 @@ typedef uint32_t yd_u32x4 __attribute__((ext_vector_type(4)));
 struct ExtProb { uint32_t qBase, rOff; uint16_t qOff, qLen; uint32_t flags; };           // 16 B; qBase = offset of the read in fwd/rev
 enum { XP_STRAND = 1, XP_REV = 2, XP_VALID = 4 };
 // 32 B.  maxj in register columns; rows/cells = work of this call.  where = phase | lane << 4 | wave << 10 (the problem's place in the arena);
-// opsOff = the flush index of its first block as k_ext_rows leaves it, the offset of its op list in the ops arena after k_ext_trace.
+// opsOff = the flush index of its first block as k_ext_rows leaves it.  After k_ext_trace (where, opsOff) = high and low word of the op list's place:
+// a signed dword offset from the trace arena's base (the list stays where the walk staged it unless it straddles two chunks; then it is in the ops arena).
 struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, where, rows, cells; };
+__device__ __forceinline__ const uint32_t *extOpsPtr(const uint32_t *traceBase, const ExtRes &r) { return traceBase + (long long)(((unsigned long long)r.where << 32) | (unsigned long long)r.opsOff); }
 
 struct ExtArgs {
     DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
@@ -398,26 +400,34 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
         if (prev >= 0) { const int wp = E - 1 - n; if (wp < 0) bad = true; else *S.at(wp) = opMake(prev, acc); n++; }
         if (bad || S.wild) { bad = true; atomicCAS(A.errFlag, 0, (int)YERR_TRACE); n = 0; if (S.wild && atomicCAS(&gTraceDbg[5], 0u, 1u) == 0u) { gTraceDbg[6] = p; gTraceDbg[7] = r.where; } }
     }
-    // exactly-sized slots in the ops arena: one reservation per wave
+    // The finished list is contiguous where it was staged unless it straddles two chunks; only then it is copied, to an exactly-sized slot of the ops arena
+    // (one reservation per wave).  Either way the result carries its address as an offset from the trace arena's base.
     if (A.dbgMode & 1) n = 0;
-    int incl = n;
+    const bool inPlace = walk && !bad && n > 0 && (S.f0 + (unsigned)((E - n) >> 5)) / YD_CHUNK_FLUSHES == (S.f0 + (unsigned)((E - 1) >> 5)) / YD_CHUNK_FLUSHES;
+    const int nCopy = (walk && !bad && !inPlace) ? n : 0;
+    int incl = nCopy;
 #pragma unroll
     for (int d2 = 1; d2 < 64; d2 <<= 1) { const int v = __shfl_up(incl, d2, 64); if (lane >= d2) incl += v; }
     const int total = __shfl(incl, 63, 64); unsigned ob = 0;
     if (lane == 63 && total) ob = atomicAdd(A.opsCount, (unsigned)total);
     ob = (unsigned)__shfl((int)ob, 63, 64);
     if (walk && !bad) {
-        const unsigned off = ob + (unsigned)(incl - n);
-        if ((unsigned long long)off + (unsigned)n > (unsigned long long)A.opsCap) { atomicCAS(A.errFlag, 0, (int)YERR_OUT); return; }
-        YD_GLOBAL uint32_t *dst = toGlobal(A.ops) + off;
-        for (int k0 = 0; k0 < n; k0 += 8) {                                  // eight loads in flight, then eight stores (the staged list is a few lines in L2)
-            uint32_t v[8];
+        long long place;
+        if (inPlace) place = (long long)(S.at(E - n) - S.arena);
+        else {
+            const unsigned off = ob + (unsigned)(incl - nCopy);
+            if ((unsigned long long)off + (unsigned)n > (unsigned long long)A.opsCap) { atomicCAS(A.errFlag, 0, (int)YERR_OUT); return; }
+            YD_GLOBAL uint32_t *dst = toGlobal(A.ops) + off;
+            for (int k0 = 0; k0 < n; k0 += 8) {                              // eight loads in flight, then eight stores (the staged list is a few lines in L2)
+                uint32_t v[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = (k0 + j < n) ? *S.at(E - n + k0 + j) : 0u;
+                for (int j = 0; j < 8; j++) v[j] = (k0 + j < n) ? *S.at(E - n + k0 + j) : 0u;
 #pragma unroll
-            for (int j = 0; j < 8; j++) if (k0 + j < n) dst[k0 + j] = v[j];
+                for (int j = 0; j < 8; j++) if (k0 + j < n) dst[k0 + j] = v[j];
+            }
+            place = (long long)(dst - S.arena);
         }
-        r.opsOff = off; r.nOps = (uint32_t)n; A.res[p] = r;
+        r.opsOff = (uint32_t)(unsigned long long)place; r.where = (uint32_t)((unsigned long long)place >> 32); r.nOps = (uint32_t)n; A.res[p] = r;
     }
 }
 

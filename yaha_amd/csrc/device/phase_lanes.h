@@ -34,7 +34,7 @@ struct JointRec {                                           // 32 B
 struct PhaseArgs {
     RootState *state; uint32_t *stateOps; unsigned int *stateOpsCount; uint32_t stateOpsCap;
     ExtProb *probs; unsigned long long *rowsBound;      // 2 per root
-    const ExtRes *res; const uint32_t *extOps;          // extension results; their op lists live in the ops arena (k_ext_trace)
+    const ExtRes *res; const uint32_t *extOps;          // extension results; extOps = the trace arena's base, which their op lists' offsets refer to (extOpsPtr)
     uint32_t *slowList; unsigned int *slowCount;        // roots (k_p3_lanes) or joints (k_gap_lanes) handed to the wave kernels
     int useList;                                        // k_align_p3: take roots from slowList[0 .. *slowCount)
     uint32_t rootBegin;                                 // k_p3_lanes: first root of the chunk (A.nRoots = its end)
@@ -530,12 +530,12 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
         const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
         if (rb.score > 0) {                                                  // AlignExtFrag.cpp:112-125
             const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-            L.a = X.extOps + rb.opsOff; L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
+            L.a = extOpsPtr(X.extOps, rb); L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
             score += rb.score; sqo = (sqo - aQ) & 0xFFFF; sro -= (uint32_t)aR; refLen = (refLen + aR) & 0xFFFF;
         }
         if (rf.score > 0) {                                                  // AlignExtFrag.cpp:128-141
             const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-            L.c = X.extOps + rf.opsOff; L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
+            L.c = extOpsPtr(X.extOps, rf); L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
             score += rf.score; eqo = (eqo + aQ) & 0xFFFF; refLen = (refLen + aR) & 0xFFFF;
         }
         status |= stAligned;
@@ -647,12 +647,12 @@ __global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
             int score = f.score;
             if (UNI_B(rb.score > 0)) {                                      // AlignExtFrag.cpp:112-125
                 const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-                al.mergeFrontSrc(b, f.start, f.len, X.extOps + rb.opsOff, (int)rb.nOps, true);
+                al.mergeFrontSrc(b, f.start, f.len, extOpsPtr(X.extOps, rb), (int)rb.nOps, true);
                 score += rb.score; f.sqo = (f.sqo - aQ) & 0xFFFF; f.sro -= (uint32_t)aR; f.refLen = (f.refLen + aR) & 0xFFFF;
             }
             if (UNI_B(rf.score > 0)) {                                      // AlignExtFrag.cpp:128-141
                 const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-                al.mergeBackSrc(b, f.start, f.len, X.extOps + rf.opsOff, (int)rf.nOps);
+                al.mergeBackSrc(b, f.start, f.len, extOpsPtr(X.extOps, rf), (int)rf.nOps);
                 score += rf.score; f.eqo = (f.eqo + aQ) & 0xFFFF; f.refLen = (f.refLen + aR) & 0xFFFF;
             }
             f.score = uni(score); f.sqo = uni(f.sqo); f.eqo = uni(f.eqo); f.refLen = uni(f.refLen); f.sro = uniU(f.sro);

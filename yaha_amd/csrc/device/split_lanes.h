@@ -45,12 +45,12 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
         if (rb.score > 0) {
             const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-            L.a = X.extOps + rb.opsOff; L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
+            L.a = extOpsPtr(X.extOps, rb); L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
             f.score += rb.score; f.sqo = (f.sqo - aQ) & 0xFFFF; f.sro -= (uint32_t)aR; f.refLen = (f.refLen + aR) & 0xFFFF;
         }
         if (rf.score > 0) {
             const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-            L.c = X.extOps + rf.opsOff; L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
+            L.c = extOpsPtr(X.extOps, rf); L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
             f.score += rf.score; f.eqo = (f.eqo + aQ) & 0xFFFF; f.refLen = (f.refLen + aR) & 0xFFFF;
         }
         f.status |= stAligned;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
                     const ExtRes e = Sx.res2[idx];
                     extCalls++; extRows += e.rows; extCells += e.cells; touched += e.rows + 4 * (unsigned)P.bandWidth + 1u;
                     o.score = e.score > 0 ? e.score : 0; o.addedQ = o.addedR = o.nOps = 0; o.arr = nullptr; o.rev = rev;
-                    if (o.score > 0) { o.addedQ = e.maxi; o.addedR = e.maxi + (e.maxj - YD_LBAND); o.nOps = (int)e.nOps; o.arr = Sx.ops2 + e.opsOff; }
+                    if (o.score > 0) { o.addedQ = e.maxi; o.addedR = e.maxi + (e.maxj - YD_LBAND); o.nOps = (int)e.nOps; o.arr = extOpsPtr(Sx.ops2, e); }
                     return true;
                 }
             }

@@ -355,7 +355,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     const int nShare = std::max(1, gCtxPerDevice[ctx->device & 63].load());
     unsigned long long budgetChunks = std::max<unsigned long long>(maxWavesK + 64ull, (unsigned long long)((freeB / nShare + ctx->extTrace.cap) * 7 / 10) / (YD_CHUNK_DWORDS * 4ull));
     budgetChunks = std::min<unsigned long long>(budgetChunks, (96ull << 30) / (YD_CHUNK_DWORDS * 4ull));
-    const double slackChunks = (double)maxWavesK + 64.0;                    // every wave's open chunk
+    const double slackChunks = (double)maxWavesK + (double)ctx->nCU * 8.0 + 64.0;   // every wave's open chunk, and the careful-extension round's
     const double wantChunks = (double)boundBlocks * ctx->traceRatio / chunkBlocks + slackChunks;
     std::vector<uint32_t> cuts; cuts.push_back(0);                            // root indices
     unsigned long long nChunksArena = 0;
@@ -398,7 +398,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     E.trace = ctx->extTrace.as<uint32_t>(); E.nChunks = (uint32_t)nChunksArena; E.chunkCount = ctx->traceCnt.as<unsigned int>(); E.waveChunks = ctx->waveChunks.as<uint32_t>(); E.maxCh = maxCh;
     E.ops = ctx->extOps.as<uint32_t>(); E.opsCount = ctx->traceCnt.as<unsigned int>() + 1; E.opsCap = extOpsCap;
     E.ctr = ctx->ctr.as<DevCounters>(); E.errFlag = ctx->errFlag.as<int>(); E.dbgMode = getenv("YGPU_TRACE_MODE") ? atoi(getenv("YGPU_TRACE_MODE")) : 0;
-    X.extOps = ctx->extOps.as<uint32_t>();
+    X.extOps = ctx->extTrace.as<uint32_t>();                                 // the base the op lists' offsets refer to
     uint32_t *cc = ctx->chunkCnt.as<uint32_t>();
     unsigned long long usedChunksMax = 0;
     EV0(T_XROWS);
@@ -454,7 +454,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                 ExtArgs E2 = E;
                 if (n2) {
                     E2.probs = ctx->probs2.as<ExtProb>(); E2.nProb = n2;
-                    HIPCHK(hipMemsetAsync(ctx->traceCnt.p, 0, 4, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->extRes2.p, 0, sizeof(ExtRes) * (uint64_t)n2, ctx->stream));
+                    HIPCHK(hipMemsetAsync(ctx->extRes2.p, 0, sizeof(ExtRes) * (uint64_t)n2, ctx->stream));        // (the arena goes on: the first round's lists stay in it)
                     {   // longest bound first here too: this launch is small and ends when its longest problem ends
                         ENSURE(ctx->keys2a, 4ull * (cap2 + 1)); ENSURE(ctx->keys2b, 4ull * (cap2 + 1)); ENSURE(ctx->vals2a, 4ull * (cap2 + 1)); ENSURE(ctx->vals2b, 4ull * (cap2 + 1));
                         KL(k_prob_keys, dim3(gridFor(n2, 256)), dim3(256), 0, ctx->stream, ctx->probs2.as<ExtProb>(), n2, ctx->keys2a.as<uint32_t>(), ctx->vals2a.as<uint32_t>());
@@ -472,7 +472,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
                 SplitArgs Sx; Sx.scratch = ctx->splitScratch.as<uint8_t>(); Sx.memoKeys = ctx->memoKeys.as<uint32_t>(); Sx.memoCount = ctx->memoCount.as<unsigned int>();
-                Sx.res2 = ctx->extRes2.as<ExtRes>(); Sx.ops2 = ctx->extOps.as<uint32_t>(); Sx.nProb2 = n2;
+                Sx.res2 = ctx->extRes2.as<ExtRes>(); Sx.ops2 = ctx->extTrace.as<uint32_t>(); Sx.nProb2 = n2;
                 Sx.fallList = ctx->fallList.as<uint32_t>(); Sx.fallCount = cc + 8 * c + 5; Sx.nSlots = nSlow;
                 KL(k_split_lanes, dim3(gridFor(nSlow, 64)), dim3(64), 0, ctx->stream, Ac, Xc, Sx);
                 Xw.slowList = ctx->fallList.as<uint32_t>(); Xw.slowCount = cc + 8 * c + 5;
@@ -934,7 +934,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
     uint32_t *dOff = ctx->dpProbs.as<uint32_t>(), *dDst = dOff + (n + 2);       // per-list offsets and destinations (the lists are done one after the other)
     if (nX) {
         HIPCHK(hipMemcpyAsync(dOff, xOff.data(), 4ull * nX, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipMemcpyAsync(dDst, xdst.data(), 4ull * nX, hipMemcpyHostToDevice, ctx->stream));
-        KL(k_dp_gather_ext, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, ctx->extProbs.as<ExtProb>(), ctx->extRes.as<ExtRes>(), ctx->extOps.as<uint32_t>(), dOff, dDst, nX,
+        KL(k_dp_gather_ext, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, ctx->extProbs.as<ExtProb>(), ctx->extRes.as<ExtRes>(), ctx->extTrace.as<uint32_t>(), dOff, dDst, nX,
            ctx->dpRes.as<ygpu_dp_result>(), ctx->dpOps.as<uint32_t>());
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
