@@ -1,0 +1,26 @@
+// nodevice_stubs.cpp -- DIAGNOSTIC BUILD ONLY (make -C yaha_amd/csrc asan): the device entry points of include/yaha_hip.h answered with YGPU_ENODEV, so that
+// the HOST stages (reader, .nib2 / index formats, argument handling, OQC/FBS, SAM text, pipeline) can be linked without HIP and run under
+// AddressSanitizer / UndefinedBehaviorSanitizer on the CPU (GPU sanitizers are not available on the pool).  Never part of the
+// product: libyaha_hip.so is built from device/ygpu.hip and has no such stubs.
+#include "../../yaha_amd/csrc/host/yaha_host.h"
+extern "C" {
+int  ygpu_init(int, const ygpu_index_view *, const ygpu_params *, ygpu_ctx **out) { if (out) *out = nullptr; return YGPU_ENODEV; }
+int  ygpu_clone(const ygpu_ctx *, ygpu_ctx **out) { if (out) *out = nullptr; return YGPU_ENODEV; }
+void ygpu_destroy(ygpu_ctx *) {}
+const char *ygpu_last_error(const ygpu_ctx *) { return "sanitizer build of the host stages: no device code linked"; }
+int  ygpu_upload(ygpu_ctx *, const ygpu_read_batch *) { return YGPU_ENODEV; }
+int  ygpu_run(ygpu_ctx *) { return YGPU_ENODEV; }
+int  ygpu_collect(ygpu_ctx *, ygpu_result_batch *) { return YGPU_ENODEV; }
+int  ygpu_submit(ygpu_ctx *, const ygpu_read_batch *, ygpu_ticket *) { return YGPU_ENODEV; }
+int  ygpu_poll(ygpu_ctx *, ygpu_ticket) { return YGPU_ENODEV; }
+int  ygpu_wait(ygpu_ctx *, ygpu_ticket, ygpu_result_batch *) { return YGPU_ENODEV; }
+int  ygpu_last_timing(ygpu_ctx *, float *, int *, const char *const **, const float **) { return YGPU_ENODEV; }
+int  ygpu_seed_join(ygpu_ctx *, const ygpu_fragment **, uint64_t *) { return YGPU_ENODEV; }
+int  ygpu_chain(ygpu_ctx *, const ygpu_fragment **, const uint32_t **, const uint32_t **, uint64_t *) { return YGPU_ENODEV; }
+int  ygpu_dp_batch(ygpu_ctx *, const ygpu_dp_problem *, uint32_t, const ygpu_dp_result **, const uint32_t **, uint64_t *) { return YGPU_ENODEV; }
+int  ygpu_dp_batch_ex(ygpu_ctx *, const ygpu_dp_problem *, uint32_t, int, const ygpu_dp_result **, const uint32_t **, uint64_t *) { return YGPU_ENODEV; }
+}
+namespace yaha {
+int  visibleDevices() { return 0; }
+bool buildIndexDevice(int, const Genome &, int, int, IndexImage &, FILE *, std::string &err) { err = "sanitizer build: no device code"; return false; }
+}

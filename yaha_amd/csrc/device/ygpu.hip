@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <thread>
 #include <mutex>
@@ -392,6 +393,14 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 32ull * (nRanges + 2), ctx->stream));
     ENSURE(ctx->traceCnt, 64); HIPCHK(hipMemsetAsync(ctx->traceCnt.p, 0, 64, ctx->stream));       // [0] chunks handed out, [1] ops handed out, [2] the high-water mark of [0] over the ranges
     TRACE("lanes: trace arena");
+    if (kTrace && getenv("YGPU_COUNT_DUPS")) {                                // diagnostics: how many extension problems of the batch are exact duplicates (direction, strand, read, rOff, qOff, qLen)?
+        std::vector<ExtProb> hp(nProb); hipMemcpy(hp.data(), ctx->extProbs.p, sizeof(ExtProb) * (size_t)nProb, hipMemcpyDeviceToHost);
+        std::vector<std::array<uint32_t, 4>> keys; keys.reserve(nProb);
+        for (auto &e : hp) if (e.flags & XP_VALID) keys.push_back({e.qBase, e.rOff, (uint32_t)e.qOff | ((uint32_t)e.qLen << 16), e.flags & 3u});
+        std::sort(keys.begin(), keys.end()); size_t dup = 0, sameStart = 0;
+        for (size_t k = 1; k < keys.size(); k++) { dup += keys[k] == keys[k - 1]; sameStart += keys[k][0] == keys[k - 1][0] && keys[k][1] == keys[k - 1][1] && (keys[k][2] & 0xFFFF) == (keys[k - 1][2] & 0xFFFF) && keys[k][3] == keys[k - 1][3]; }
+        fprintf(stderr, "[ygpu] extension problems: %zu valid, %zu exact duplicates (%.2f%%), %zu share (read, strand, direction, rOff, qOff) with their predecessor (%.2f%%)\n", keys.size(), dup, 100.0 * dup / std::max<size_t>(1, keys.size()), sameStart, 100.0 * sameStart / std::max<size_t>(1, keys.size()));
+    }
     if (kTrace) fprintf(stderr, "[ygpu] trace bound %.2f GB, arena %.2f GB (%llu chunks, ratio %.3f), %zu range(s); ext ops cap %u\n", boundBlocks * 128.0 / 1e9, nChunksArena * (YD_CHUNK_DWORDS * 4.0) / 1e9, nChunksArena, ctx->traceRatio, nRanges, extOpsCap);
     ENSURE(ctx->rowsClock, 16); { const unsigned long long init[2] = {~0ull, 0ull}; HIPCHK(hipMemcpyAsync(ctx->rowsClock.p, init, 16, hipMemcpyHostToDevice, ctx->stream)); }
     E.clock = ctx->rowsClock.as<unsigned long long>();
