@@ -30,9 +30,11 @@ with ya.Session(["-x", X, "-q", R]) as s0:
         for s in sessions:
             assert s.next_batch(N).n_reads == N
         reps = 3 if T > 1 else 2
-        def work(s):
+        import ctypes as C
+        def work(s):                                   # the C call only (ctypes drops the GIL for it); the text stays in the session's buffer
+            t_, n_ = C.c_char_p(), C.c_size_t()
             for _ in range(reps):
-                s.emit(r)
+                assert ya.lib().yaha_session_emit(s._h, C.byref(r), C.byref(t_), C.byref(n_)) == 0
         th = [threading.Thread(target=work, args=(s,)) for s in sessions]
         t = time.time()
         for x in th: x.start()

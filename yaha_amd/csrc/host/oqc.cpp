@@ -125,7 +125,9 @@ void postFilter(const Args &a, const Genome &g, const Read &r, const ygpu_clump 
     if (n < 1) return;
     if (n == 1) { OutClump o = mk(0); o.status |= stPrimary; o.mapQuality = 250; o.numSecondaries = 0; o.matchedPrimary = 1; primaryCount = 1; out.push_back(o); return; }   // :907-916
 
-    Ctx X{a, cl, ops, {}};
+    static thread_local std::vector<CNode> tlNodes, tlPrim; static thread_local std::vector<PAttr> tlPA; static thread_local std::vector<OutClump> tlPush;   // scratch reused from read to read
+    Ctx X{a, cl, ops, std::move(tlNodes)};
+    struct GiveBack { Ctx &x; ~GiveBack() { tlNodes = std::move(x.nodes); } } giveBack{X};
     X.nodes.resize(n);
     for (uint32_t i = 0; i < n; i++) {                                  // initcGraphNode :342-363, list walked head->tail :929-934
         CNode &nd = X.nodes[i]; const ygpu_clump &c = cl[i]; bool rev = (c.status & stReversed) != 0;
@@ -198,8 +200,8 @@ void postFilter(const Args &a, const Genome &g, const Read &r, const ygpu_clump 
     // filterBySimilarity :571-692
     std::vector<CNode> &gn = X.nodes;
     const int primeCount = gn[bestNode].pathLength;
-    std::vector<CNode> primaries(primeCount); std::vector<PAttr> PA(primeCount);
-    std::vector<OutClump> pushOrder;                                    // push-to-head order; reversed at the end
+    std::vector<CNode> &primaries = tlPrim; std::vector<PAttr> &PA = tlPA; primaries.assign(primeCount, CNode()); PA.assign(primeCount, PAttr());
+    std::vector<OutClump> &pushOrder = tlPush; pushOrder.clear();      // push-to-head order; reversed at the end
     {
         int pi = primeCount - 1;
         for (int p = bestNode; p >= 0; p = gn[p].bestPrev) {

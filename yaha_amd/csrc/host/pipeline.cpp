@@ -93,6 +93,16 @@ static bool sessionLoad(yaha_session *s)
 static void formatBatch(yaha_session *s, const ygpu_result_batch *r, std::string &text, int nt)
 {
     const Args &a = s->args; const uint32_t n = r->n_reads;
+    if (nt <= 1) {                                                       // one thread, one batch: straight into the batch's text (its buffer is reused from batch to batch)
+        text.clear(); if (text.capacity() < (size_t)n * 1024) text.reserve((size_t)n * 1536);
+        std::vector<OutClump> oc;
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t c0 = r->clump_start[i], c1 = r->clump_start[i + 1]; int primaryCount = 0;
+            postFilter(a, s->genome, s->reads[i], r->clumps + c0, c1 - c0, r->ops, oc, primaryCount);
+            for (auto &o : oc) printClump(a, s->genome, s->reads[i], o, primaryCount, text);
+        }
+        return;
+    }
     std::vector<std::string> parts(n);
     std::atomic<uint32_t> next(0);
     auto work = [&]() {
