@@ -142,7 +142,7 @@ int runQueries(Args &a, FILE *log)
     if (fputs(S->header.c_str(), out) < 0) { fprintf(log, "Failure writing the output file.\n"); return 1; }
     ygpu_params P; paramsFromArgs(A, P);
     ygpu_index_view V; yaha_session_index_view(S.get(), &V);
-    // -gpus N devices x -ctx M contexts per device (default 2: while one context's batch is in a latency-bound device stage the other
+    // -gpus N devices x -ctx M contexts per device (default 3: while one context's batch is in a latency-bound device stage the other
     // one's batch computes).  Contexts of one device share its index image.
     const int perDev = std::max(1, A.ctxPerGpu), ngpu = std::max(1, A.gpus) * perDev;
     std::vector<ygpu_ctx *> ctx(ngpu, nullptr);
