@@ -77,7 +77,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.35, opsRatio = 0.03; DevBuf waveChunks, extOps, traceCnt;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.35, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -113,6 +113,7 @@ static int cubScan64(ygpu_ctx *ctx, const unsigned long long *in, unsigned long 
 #include <chrono>
 static double nowMs() { using namespace std::chrono; return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count(); }
 static const bool kTrace = getenv("YGPU_TRACE") != nullptr;
+static const bool kStats = getenv("YGPU_STATS") != nullptr;      // one line per ygpu_run: attempts of the align stage, ranges, arena size
 #define TRACE(what) do { if (kTrace) { hipStreamSynchronize(ctx->stream); double t_ = nowMs(); fprintf(stderr, "[ygpu] %-28s %9.3f ms\n", what, t_ - ctx->traceT); ctx->traceT = t_; } } while (0)
 #define ENSURE(buf, bytes) do { if ((buf).ensure(bytes)) { ctx->err = "hipMalloc failed for " #buf; return YGPU_ENOMEM; } } while (0)
 #define EV0(t) (ctx->evUsed[t] = true, hipEventRecord(ctx->ev[t][0], ctx->stream))
@@ -376,7 +377,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             cuts.push_back(lo); r0 = lo;
         }
     }
-    const size_t nRanges = cuts.size() - 1;
+    const size_t nRanges = cuts.size() - 1; ctx->statRanges = (int)nRanges;
     nChunksArena = std::min<unsigned long long>(std::max<unsigned long long>(nChunksArena, maxWavesK + 64ull), 0xFFFFFFF0ull);
     if (ctx->extTrace.ensure((size_t)nChunksArena * YD_CHUNK_DWORDS * 4ull + 256) != 0) {
         (void)hipGetLastError();
@@ -540,6 +541,7 @@ static int stageAlign(ygpu_ctx *ctx)
         uint32_t gapOpsPerJoint = 16;
         uint32_t outClumpCap = NC + NC / 2 + 1024; uint32_t outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + ctx->totalBases / 2 + 65536);
         for (int attempt = 0;; attempt++) {
+            ctx->statAttempts = attempt + 1;
             ENSURE(ctx->outClumps, sizeof(ygpu_clump) * (uint64_t)outClumpCap); ENSURE(ctx->outClumps2, sizeof(ygpu_clump) * (uint64_t)outClumpCap);
             ENSURE(ctx->outOps, 4ull * outOpsCap); ENSURE(ctx->outRoot, 4ull * outClumpCap); ENSURE(ctx->outPush, 4ull * outClumpCap); ENSURE(ctx->dstIdx, 4ull * outClumpCap);
             HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 12, ctx->stream));      // qalign, outclumps, outops
@@ -723,8 +725,10 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
 int ygpu_run(ygpu_ctx *ctx)
 {
     if (!ctx || !ctx->stream) return YGPU_EINVAL;
-    ctx->stageDone = 0;
-    int rc = runTo(ctx, 3); if (rc) return rc;
+    ctx->stageDone = 0; const double t0 = nowMs(); ctx->statAttempts = 0; ctx->statRanges = 0;
+    int rc = runTo(ctx, 3);
+    if (kStats) { size_t fb = 0, tb = 0; hipMemGetInfo(&fb, &tb); fprintf(stderr, "[ygpu] ctx %p run: %u reads, rc %d, %.1f ms; align attempts %d, ranges %d, trace arena %.2f GB (ratio %.3f), free %.1f GB\n", (void *)ctx, ctx->nReads, rc, nowMs() - t0, ctx->statAttempts, ctx->statRanges, ctx->extTrace.cap / 1e9, ctx->traceRatio, fb / 1e9); }
+    if (rc) return rc;
     ctx->totalMs = 0;
     for (int t = 0; t < T_N; t++) {
         float m = 0; ctx->ms[t] = (ctx->evUsed[t] && hipEventElapsedTime(&m, ctx->ev[t][0], ctx->ev[t][1]) == hipSuccess) ? m : 0;

@@ -66,7 +66,7 @@ struct Args {
     bool OQC = true; int OQCMinNonOverlap = -1, BPCost = 5, maxBPLog = 5; bool FBS = false; float FBS_PSLength = 0.90f, FBS_PSScore = 0.90f;
     int maxQueryLength = 32000; bool verbose = false, outputBlast8 = false, outputSAM = true, hardClip = true;
     // extensions of this implementation (not in the reference CLI)
-    int batchReads = 4096; int device = 0; int gpus = 1; int ctxPerGpu = 3; bool cpuIndex = false;
+    int batchReads = 4096; int device = 0; int gpus = 1; int ctxPerGpu = 2; bool cpuIndex = false;
     bool query = false, index = true;
 };
 void postProcessArgs(Args &a, bool query);                                  // AlignArgs.c:108-169
