@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; C=/tmp/yaha_bench_cache; X=$C/g100m_s42.X15_01_65525S
 READS=$C/e2e_n262144_l1000_s3000.fa
 [ -f $READS ] || $R/tools/yaha_sim reads --genome $C/g100m_s42.fa --out $READS --seed 3000 --n 262144 --len 1000 --div 0.017
 head -32 $READS > $C/tiny.fa
-for opts in "-ctx 3 -batch 8192" "-ctx 2 -batch 8192" "-ctx 3 -batch 4096" "-ctx 2 -batch 4096" "-ctx 1 -batch 4096"; do
+for opts in "-ctx 2 -batch 16384" "-ctx 2 -batch 8192" "-ctx 2 -batch 16384 -t 12" "-ctx 3 -batch 16384" "-ctx 2 -batch 4096"; do
   $R/yaha_amd/csrc/yaha -x $X -q $C/tiny.fa -osh /dev/shm/tiny.sam 2> /dev/null
   s=$(date +%s%N)
   YAHA_TIMING=1 $R/yaha_amd/csrc/yaha -x $X -q $READS -osh /dev/shm/o.sam $opts 2> /dev/shm/timing.txt

@@ -102,11 +102,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     int poolCount = 0, poolNext = 0; bool exhausted = false;
     uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0;
     // deferred stores (see the row code)
-    bool pendFlush = false; int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pCells = 0, pendF0 = 0, pF0 = 0;
+    bool pendFlush = false; int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pendStart = 0, pStart = 0;   // pStart = the flush and the row slot a problem started in: flush << 4 | slot
     // Trace memory: the wave's 64 blocks of ten rows leave together (a "flush"), into slot (flush & 15) of the wave's current arena chunk.  wslot = the row
     // slot all lanes write in this iteration, flush = flushes done so far; a problem notes (flush, wslot) when it starts.  A lane whose problem ended inside
     // the block keeps the block `dirty` until the next hand-over; a lane that starts a problem inside a block shares it with its previous problem.
-    int wslot = 0, phase = 0; unsigned flush = 0; bool dirty = false, justDone = false;
+    int wslot = 0; unsigned flush = 0; bool dirty = false, justDone = false;
     YD_GLOBAL uint32_t *chunkPtr = toGlobal(A.trace); bool noMem = false;
     auto takeChunk = [&]() {                                                 // wave-uniform: the chunk of flushes [flush, flush + 16)
         unsigned c = 0;
@@ -200,9 +200,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             }
             if (init) {
                 p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0;
-                rev = (gMisc & XP_REV) != 0; rOff = gROff; pCells = 0;
+                rev = (gMisc & XP_REV) != 0; rOff = gROff;
                 q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu);
-                phase = wslot; pF0 = flush;
+                pStart = (flush << 4) | (unsigned)wslot;
                 w0 = 0; w1 = gW1; w2 = gW2;
             }
             poolNext += nNeed < avail ? nNeed : avail;
@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         // problem's result (both deferred), and the loads the row needs at its END (next query base, next reference base).
         // The wait the compiler puts at the loop header then finds them ~1000 instructions old.
         if (pendRes >= 0) {
-            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendF0; r.nOps = 0;
-            r.where = (pendRows >> 20) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows & 0xFFFFFu; r.cells = pendCells;
+            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendStart >> 4; r.nOps = 0;
+            r.where = (pendStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows; r.cells = pendCells;
             A.res[pendRes] = r; pendRes = -1;
         }
         const bool busy = p >= 0;
@@ -230,7 +230,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         // (both clamps keep that relation, SW.cpp:499-516), so endCol = min(left + rLen - i, W - 1) = W - 1 on every row i <= qLen:
         // only the first `left` rows have cells to keep out of the row maximum, and only in the columns left of the origin.
         int sc = leftR + 1 - i; if (sc < 0) sc = 0;
-        if (busy) { const unsigned nc = (unsigned)(YD_LW - sc); rows++; cells += nc; pCells += nc; }
         int PVCol = YD_LWORST, PE = YD_LWORST, PD = 0;
         uint32_t t0 = 0, t1 = 0, t2 = 0, rowKey = 0;
         int dV = PV[0];
@@ -274,7 +273,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (wslot == 9) { pendFlush = dirty; dirty = false; wslot = 0; } else wslot++;      // wave-uniform
         justDone = fin;                                                      // the next row slot stays empty behind a finished problem (its traceback's spare row)
         if (fin) {
-            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i | ((unsigned)phase << 20); pendCells = pCells; pendF0 = pF0;
+            // work of this call: i rows; row r has 21 - max(11 - r, 0) real cells (the columns left of the origin come into the band one row at a time)
+            const unsigned m = i < leftR ? (unsigned)i : (unsigned)leftR, nCells = (unsigned)YD_LW * (unsigned)i - ((unsigned)(leftR + 1) * m - m * (m + 1u) / 2u);
+            rows += (unsigned)i; cells += nCells;
+            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i; pendCells = nCells; pendStart = pStart;
             p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
         }
     }
@@ -282,8 +284,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     if (wslot != 0 && dirty) pendFlush = true;
     if (!noMem && __ballot(pendFlush) != 0ull) { flushBlocks(); nextFlush(); }
     if (pendRes >= 0) {
-        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendF0; r.nOps = 0;
-        r.where = (pendRows >> 20) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows & 0xFFFFFu; r.cells = pendCells;
+        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendStart >> 4; r.nOps = 0;
+        r.where = (pendStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows; r.cells = pendCells;
         A.res[pendRes] = r;
     }
     if (!SECOND && A.clock && lane == 0) atomicMax(&A.clock[1], (unsigned long long)wall_clock64());
