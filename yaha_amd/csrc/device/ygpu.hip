@@ -168,6 +168,9 @@ static int stageSeed(ygpu_ctx *ctx)
                 if (mx > 1024u) KL((k_seg_sort<256, 16>), dim3(2 * n), dim3(256), 0, ctx->stream, in, out, so, 1024u, std::min(mx, 4096u));
                 KL((k_seg_sort<128, 8>), dim3(2 * n), dim3(128), 0, ctx->stream, in, out, so, 0u, std::min(mx, 1024u));
                 uint32_t nBig = 0; rc = fetchU32(ctx, cntBig, &nBig); if (rc) return rc;
+                if (kTrace) { std::vector<uint32_t> so2(2 * (size_t)n + 1); hipMemcpy(so2.data(), so, 4ull * (2 * n + 1), hipMemcpyDeviceToHost); unsigned long long hb = 0, mxl = 0, c8 = 0, c4 = 0, c1 = 0, c0 = 0;
+                    for (uint32_t k = 0; k < 2 * n; k++) { const unsigned long long l = so2[k + 1] - so2[k]; if (l > mx) { hb += l; mxl = std::max(mxl, l); } else if (l > 8192) c8 += l; else if (l > 4096) c4 += l; else if (l > 1024) c1 += l; else c0 += l; }
+                    fprintf(stderr, "[ygpu] hit sort: %u hits; segments above %u hits: %u holding %llu hits (%.1f%%, longest %llu); classes 8k-16k %.1f%%, 4k-8k %.1f%%, 1k-4k %.1f%%, <=1k %.1f%%\n", H, mx, nBig, hb, 100.0 * hb / H, mxl, 100.0 * c8 / H, 100.0 * c4 / H, 100.0 * c1 / H, 100.0 * c0 / H); }
                 if (nBig) {
                     size_t bytes = 0;
                     HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, in, out, (int)H, (int)(2 * n), ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), 15, 47, ctx->stream));
