@@ -4,7 +4,7 @@
 #pragma once
 #include "split_lanes.h"
 
-// classify a gap problem as k_p1_joints does (phase_lanes.h): pure diagonal or DP; sort key = (strip width, rows)
+// classify a gap problem as k_p1_joints does (phase_lanes.h): pure diagonal or DP; sort key = (class, strip width, rows)
 __global__ void k_dp_classify(DevParams P, const uint8_t *bases, const uint8_t *fwd, const uint8_t *rev, JointRec *joints, uint32_t n, uint32_t *keys, uint32_t *diagOps)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,7 +20,7 @@ __global__ void k_dp_classify(DevParams P, const uint8_t *bases, const uint8_t *
         for (int k = 0; k < qGap; k++) { const int c = (uint32_t)q[(int)j.nsqo + k] != refAt(j.nsro + (uint32_t)k); mm += c; runs += c != pc; pc = c; }
         if (mm * (P.MS + P.RC) <= P.MS + 2 * (P.GO + P.GE)) { j.kind = JK_DIAG; j.score = P.MS * (qGap - mm) - P.RC * mm; j.nOps = (uint16_t)runs; }
     }
-    if (j.kind == JK_DP) { const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1; key = ((uint32_t)min(W, 0xFFFF) << 16) | (uint32_t)qGap; }
+    if (j.kind == JK_DP) key = gapJointKey(P, banded, qGap, rGap);
     joints[t] = j; keys[t] = key; diagOps[t] = j.kind == JK_DIAG ? (uint32_t)j.nOps : 0u;
 }
 

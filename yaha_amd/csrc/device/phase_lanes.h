@@ -43,7 +43,7 @@ struct PhaseArgs {
     uint32_t *memoKeys; unsigned int *memoCount; ExtProb *probs2; unsigned long long *rowsBound2; unsigned int *nProb2; uint32_t probs2Cap;
     // joints
     uint32_t *jointCount; const uint32_t *jointBase; JointRec *joints; uint32_t nJoints;
-    uint32_t *sortKeys, *sortVals; const uint32_t *sortedVals; unsigned int *nDP;
+    uint32_t *sortKeys, *sortVals; const uint32_t *sortedVals; unsigned int *nDP, *nDPb;
     uint32_t *gapOps; unsigned int *gapOpsCount; uint32_t gapOpsCap;
     uint32_t *extKeys, *extVals;                        // k_ext_rows takes the problems longest-bound first (keys = 0xFFFF - qLen)
     uint8_t *gapScratch;                                // YD_GAP_SCRATCH bytes per k_gap_lanes thread (trace strip + op list of gapDPLane)
@@ -72,6 +72,16 @@ template <int N> __device__ __forceinline__ void blockCounters(unsigned long lon
     if (laneId() == 0) { for (int k = 0; k < N; k++) if (val[k]) atomicAdd(&sAcc[k], val[k]); }
     __syncthreads();
     if (threadIdx.x < (unsigned)N && sAcc[threadIdx.x]) atomicAdd(dst[threadIdx.x], (unsigned long long)sAcc[threadIdx.x]);
+}
+
+template <int N> __device__ __forceinline__ void blockCountersU32(unsigned int *const (&dst)[N], const unsigned (&val)[N])
+{
+    __shared__ unsigned sAcc32[N];
+    if (threadIdx.x < (unsigned)N) sAcc32[threadIdx.x] = 0;
+    __syncthreads();
+    if (laneId() == 0) { for (int k = 0; k < N; k++) if (val[k]) atomicAdd(&sAcc32[k], val[k]); }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)N && sAcc32[threadIdx.x]) atomicAdd(dst[threadIdx.x], sAcc32[threadIdx.x]);
 }
 
 // Arena space for a 256-thread block: the waves' totals meet in LDS, one atomic per block; returns this wave's base.
@@ -203,12 +213,22 @@ __global__ void k_joint_counts(AlignArgs A, PhaseArgs X)
     if (r == A.nRoots) X.jointCount[r] = 0u;
 }
 
+// sort key of a DP joint: class << 28 | strip width << 16 | rows.  Class 0 / 1: banded, within k_gap_band's limits, W <= 12 / 16; 2: other W <= 16; 3: the rest.
+__device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, bool banded, int qGap, int rGap)
+{
+    const int lenDiff = qGap > rGap ? qGap - rGap : rGap - qGap;
+    const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1;
+    uint32_t cls = W <= 16 ? 2u : 3u;
+    if (banded && W <= 16 && P.bandWidth >= 5 && P.maxGap >= 16 && qGap <= YD_GROWS && rGap <= YD_GREF) cls = W <= 12 ? 0u : 1u;
+    return (cls << 28) | ((uint32_t)min(W, 0xFFF) << 16) | (uint32_t)qGap;
+}
+
 // lane per root: exact-match extensions of every joint (AlignHelpers.c:216-232), then the gap's kind (AlignExtFrag.cpp:190-231)
 __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
 {
     const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
-    unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0;
+    unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0, nB12 = 0, nB16 = 0;
     if (live) {
         const ChainClumpRec rec = A.clumps[A.order[r]]; const int n = (int)rec.nFrags;
         if (n > 1) {
@@ -245,7 +265,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
                         for (int t = 0; t < qGap; t++) mm += (uint32_t)q[(int)cur.eqo + 1 + t] != refAt(eRO + 1u + (uint32_t)t);
                         if (mm * (P.MS + P.RC) <= P.MS + 2 * (P.GO + P.GE)) { j.kind = JK_DIAG; j.score = P.MS * (qGap - mm) - P.RC * mm; }
                     }
-                    if (j.kind == JK_DP) { const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1; key = ((uint32_t)min(W, 0xFFFF) << 16) | (uint32_t)qGap; nDP++; nDP16 += W <= 16; }
+                    if (j.kind == JK_DP) { key = gapJointKey(P, banded, qGap, rGap); const uint32_t cls = key >> 28; nDP++; nDP16 += cls <= 2u; nB12 += cls == 0u; nB16 += cls <= 1u; }
                 }
                 X.joints[jb + (uint32_t)(k - 1)] = j; X.sortKeys[jb + (uint32_t)(k - 1)] = key; X.sortVals[jb + (uint32_t)(k - 1)] = jb + (uint32_t)(k - 1);
                 cur = nxt;
@@ -253,13 +273,14 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
             F[n - 1] = cur;
         }
     }
-    perfect = waveSumU(perfect); touched = waveSumU(touched); nDP = waveSumU(nDP); nDP16 = waveSumU(nDP16);
+    perfect = waveSumU(perfect); touched = waveSumU(touched); nDP = waveSumU(nDP); nDP16 = waveSumU(nDP16); nB12 = waveSumU(nB12); nB16 = waveSumU(nB16);
     { unsigned long long *const dst[2] = {&A.ctr->v[C_PERFECT], &A.ctr->v[C_TOUCHED]}; const unsigned val[2] = {perfect, touched}; blockCounters<2>(dst, val); }
-    if (lane == 0 && nDP) { atomicAdd(X.nDP, nDP); atomicAdd(X.nDP + 1, nDP16); }
+    { unsigned int *const dst[4] = {X.nDP, X.nDP + 1, X.nDPb, X.nDPb + 1}; const unsigned val[4] = {nDP, nDP16, nB12, nB16}; blockCountersU32<4>(dst, val); }
 }
 
-// lane per DP joint, in size order (key = strip width, rows).  Persistent 64-thread blocks.  The GW = 16 instance takes the
-// sorted joints [0, n16), the GW = 32 instance [n16, nDP)  (X.nDP[0] = nDP, X.nDP[1] = n16, counted by k_p1_joints).
+// lane per DP joint, in size order (key = class, strip width, rows).  Persistent 64-thread blocks.  The sorted joints are [0, nB12) banded with W <= 12 and
+// [nB12, nB16) banded with W <= 16: k_gap_band<12|16> (gap_band_lanes.h);  [nB16, n16) the other W <= 16: the GW = 16 instance of this kernel;  [n16, nDP): GW = 32
+// (X.nDP[0] = nDP, X.nDP[1] = n16, X.nDPb[0] = nB12, X.nDPb[1] = nB16, counted by k_p1_joints).
 template <int GW>
 __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
 {
@@ -270,7 +291,7 @@ __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
     { uint32_t *sp = (uint32_t *)(X.gapScratch + (size_t)blockIdx.x * 64u * YD_GAP_SCRATCH) + lane; GM.T = (uint8_t *)sp; GM.tmp = sp + (size_t)((YD_GROWS + 1) * 32 / 4) * 64; }
     YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
     const uint32_t nAll = X.nDP[0], n16 = X.nDP[1];
-    const uint32_t tBegin = GW == 16 ? 0u : n16, tEnd = GW == 16 ? n16 : nAll;
+    const uint32_t tBegin = GW == 16 ? X.nDPb[1] : n16, tEnd = GW == 16 ? n16 : nAll;
     for (uint32_t base = tBegin + blockIdx.x * 64u; base < tEnd; base += gridDim.x * 64u) {
         const uint32_t t = base + (uint32_t)lane; const bool live = t < tEnd;
         int nT = 0, score = 0; unsigned cells = 0; bool tooBig = false; uint32_t ji = 0;

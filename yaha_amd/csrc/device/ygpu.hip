@@ -31,6 +31,7 @@
 #include "seed.h"
 #include "segsort.h"
 #include "phase_lanes.h"
+#include "gap_band_lanes.h"
 #include "split_lanes.h"
 #include "dp_stage.h"
 
@@ -57,7 +58,7 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_SEGBIG, CNT_N = 24 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_SEGBIG, CNT_NB12, CNT_NB16, CNT_N = 24 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_N };
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
@@ -318,8 +319,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     ENSURE(ctx->gapOps, 4ull * gapOpsCap); ENSURE(ctx->slowList, 4ull * (std::max(NC, J) + 1));
     X.slowList = ctx->slowList.as<uint32_t>();
     X.joints = ctx->joints.as<JointRec>(); X.nJoints = J; X.sortKeys = ctx->sortKeys.as<uint32_t>(); X.sortVals = ctx->sortVals.as<uint32_t>(); X.sortedVals = ctx->sortVals2.as<uint32_t>();
-    X.nDP = cnt + CNT_NDP; X.gapOps = ctx->gapOps.as<uint32_t>(); X.gapOpsCount = cnt + CNT_GAPOPS; X.gapOpsCap = gapOpsCap;
-    HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 12, ctx->stream));                 // ndp, ndp16, gapops
+    X.nDP = cnt + CNT_NDP; X.nDPb = cnt + CNT_NB12; X.gapOps = ctx->gapOps.as<uint32_t>(); X.gapOpsCount = cnt + CNT_GAPOPS; X.gapOpsCap = gapOpsCap;
+    HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 12, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NB12, 0, 8, ctx->stream));      // ndp, ndp16, gapops; nb12, nb16
     if (J) {
         KL(k_p1_joints, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
         size_t bytes = 0;
@@ -328,6 +329,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 6);   // 17 / 26 KB of LDS per 64-thread block
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
+        KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        KL(k_gap_band<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_wave, dim3(std::min(waves, 512u)), dim3(64), 0, ctx->stream, A, X);
@@ -923,7 +926,8 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         rc = fetchU32(ctx, ctx->sortKeys.p, keys.data(), nJ); if (rc) return rc;
         for (uint32_t k = 0; k < nJ; k++) idx[k] = k;
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });           // the production path sorts the DP joints by (strip width, rows) as well
-        uint32_t nd[3] = {0, 0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != 0xFFFFFFFFu) { nd[0]++; nd[1] += (keys[k] >> 16) <= 16u; }
+        uint32_t nd[3] = {0, 0, 0}, nb[2] = {0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != 0xFFFFFFFFu) { const uint32_t cls = keys[k] >> 28; nd[0]++; nd[1] += cls <= 2u; nb[0] += cls == 0u; nb[1] += cls <= 1u; }
+        HIPCHK(hipMemcpyAsync(cnt + CNT_NB12, nb, 8, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->sortVals2.p, idx.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(cnt + CNT_NDP, nd, 12, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemsetAsync(cnt + CNT_SLOW, 0, 4, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
@@ -932,10 +936,12 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         ENSURE(ctx->scratchAlign, per * waves);
         AlignArgs A; memset(&A, 0, sizeof A); A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = B; A.queueHead = cnt + CNT_QALIGN; A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per;
         A.maxQ = ctx->maxQ; A.listCap = listCap; A.front = front; A.genCap = genCap; A.traceRows = traceRows; A.ctr = ctx->ctr.as<DevCounters>(); A.errFlag = ctx->errFlag.as<int>();
-        PhaseArgs X; memset(&X, 0, sizeof X); X.joints = ctx->joints.as<JointRec>(); X.nJoints = nJ; X.sortedVals = ctx->sortVals2.as<uint32_t>(); X.nDP = cnt + CNT_NDP;
+        PhaseArgs X; memset(&X, 0, sizeof X); X.joints = ctx->joints.as<JointRec>(); X.nJoints = nJ; X.sortedVals = ctx->sortVals2.as<uint32_t>(); X.nDP = cnt + CNT_NDP; X.nDPb = cnt + CNT_NB12;
         X.gapOps = ctx->gapOps.as<uint32_t>(); X.gapOpsCount = cnt + CNT_GAPOPS; X.gapOpsCap = gapOpsCap; X.slowList = ctx->slowList.as<uint32_t>(); X.slowCount = cnt + CNT_SLOW;
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(nJ, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(nJ, 64), (uint64_t)ctx->nCU * 6);
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
+        KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        KL(k_gap_band<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_wave, dim3(waves), dim3(64), 0, ctx->stream, A, X);
