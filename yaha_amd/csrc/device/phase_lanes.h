@@ -536,6 +536,28 @@ __device__ inline int predictCarefulDPs(const DevParams &P, const MergedOps &L, 
     return nOut;
 }
 
+// a root after phase 2: its frame and the merged edit list [backward extension][phase-1 list][forward extension] (AlignExtFrag.cpp:112-141)
+struct P3Root { MergedOps L; uint32_t sro; int sqo, eqo, refLen, status, score; };
+__device__ __forceinline__ P3Root p3Merged(const PhaseArgs &X, uint32_t r)
+{
+    P3Root o; MergedOps &L = o.L; L.a = L.b = L.c = nullptr; L.na = L.nb = L.nc = L.jab = L.jbc = 0;
+    const RootState *S = X.state + r;
+    o.sro = S->f.sro; o.sqo = S->f.sqo; o.eqo = S->f.eqo; o.refLen = S->f.refLen; o.status = S->f.status; o.score = S->f.score;
+    L.b = X.stateOps + S->listOff; L.nb = S->f.len;
+    const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
+    if (rb.score > 0) {                                                  // AlignExtFrag.cpp:112-125
+        const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
+        L.a = extOpsPtr(X.extOps, rb); L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
+        o.score += rb.score; o.sqo = (o.sqo - aQ) & 0xFFFF; o.sro -= (uint32_t)aR; o.refLen = (o.refLen + aR) & 0xFFFF;
+    }
+    if (rf.score > 0) {                                                  // AlignExtFrag.cpp:128-141
+        const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
+        L.c = extOpsPtr(X.extOps, rf); L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
+        o.score += rf.score; o.eqo = (o.eqo + aQ) & 0xFFFF; o.refLen = (o.refLen + aR) & 0xFFFF;
+    }
+    return o;
+}
+
 __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
 {
     const int lane = laneId(); const uint32_t r = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -545,20 +567,8 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
     uint32_t sro = 0; int sqo = 0, eqo = 0, refLen = 0, status = 0, n = 0;
     int matches = 0, mism = 0, ins = 0, del = 0, AGS = 0;
     if (live) {
-        const RootState *S = X.state + r;
-        sro = S->f.sro; sqo = S->f.sqo; eqo = S->f.eqo; refLen = S->f.refLen; status = S->f.status; int score = S->f.score;
-        L.b = X.stateOps + S->listOff; L.nb = S->f.len;
-        const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
-        if (rb.score > 0) {                                                  // AlignExtFrag.cpp:112-125
-            const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-            L.a = extOpsPtr(X.extOps, rb); L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
-            score += rb.score; sqo = (sqo - aQ) & 0xFFFF; sro -= (uint32_t)aR; refLen = (refLen + aR) & 0xFFFF;
-        }
-        if (rf.score > 0) {                                                  // AlignExtFrag.cpp:128-141
-            const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-            L.c = extOpsPtr(X.extOps, rf); L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
-            score += rf.score; eqo = (eqo + aQ) & 0xFFFF; refLen = (refLen + aR) & 0xFFFF;
-        }
+        const P3Root R0 = p3Merged(X, r);
+        L = R0.L; sro = R0.sro; sqo = R0.sqo; eqo = R0.eqo; refLen = R0.refLen; status = R0.status; const int score = R0.score;
         status |= stAligned;
         // scoreClump
         n = L.count(); const int aligned = score; int maxAGS = 0; verdict = 0;
@@ -578,36 +588,8 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
             }
         }
     }
-    {
-        const unsigned long long sm = __ballot(verdict == 1); const unsigned slot = waveReserve(sm, X.slowCount, lane);
-        ExtProb pp[YD_MEMO]; int np = 0;
-        if (verdict == 1) {
-            X.slowList[slot] = r;
-            if (X.probs2) {
-                const ChainClumpRec rec = A.clumps[A.order[r]]; const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
-                np = predictCarefulDPs(P, L, n, sqo, eqo, sro, refLen, toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0, qlen, toGlobal(A.bases), pp, r0, (rec.rs & 1u) ? XP_STRAND : 0u);
-            }
-        }
-        if (X.probs2) {
-            int incl = np;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-            const int total = __shfl(incl, 63, 64); unsigned pb = 0;
-            if (lane == 63 && total) pb = atomicAdd(X.nProb2, (unsigned)total);
-            pb = (unsigned)__shfl((int)pb, 63, 64);
-            if (verdict == 1) {
-                const unsigned first = pb + (unsigned)(incl - np); int kept = 0;
-                for (int k = 0; k < np; k++) {
-                    const unsigned idx = first + (unsigned)k; if (idx >= X.probs2Cap) break;
-                    X.probs2[idx] = pp[k]; X.rowsBound2[idx] = (unsigned long long)((pp[k].qLen + 19u) / 10u);
-                    uint32_t *key = X.memoKeys + ((size_t)slot * YD_MEMO + (size_t)k) * 3;
-                    key[0] = pp[k].rOff; key[1] = (uint32_t)pp[k].qOff | ((uint32_t)pp[k].qLen << 16); key[2] = ((pp[k].flags & XP_REV) ? 1u : 0u) | (idx << 1);
-                    kept++;
-                }
-                X.memoCount[slot] = (unsigned)kept;
-            }
-        }
-    }
+    // a root that needs splitClump goes to the split list; k_p3_predict lists its careful extensions
+    { const unsigned long long sm = __ballot(verdict == 1); const unsigned slot = waveReserve(sm, X.slowCount, lane); if (verdict == 1) X.slowList[slot] = r; }
     // emit the accepted clumps (emit() in align.h)
     const bool acc = verdict == 2;
     const unsigned long long am = __ballot(acc);
@@ -638,6 +620,39 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
     if (lane == 0 && nAcc) { atomicAdd(&A.ctr->v[C_SCORED], (unsigned long long)nAcc); atomicAdd(&A.ctr->v[C_OPS], (unsigned long long)nOpsTot); }
 }
 
+
+// lane per split root (compacted: in k_p3_lanes the 4 % of lanes that need this kept nearly every wave waiting for it): the careful extensions splitClump will
+// ask for -> probs2 (the second k_ext_rows / k_ext_trace round) and the root's memo keys.  Persistent 64-thread blocks over the split list.
+__global__ void __launch_bounds__(64) k_p3_predict(AlignArgs A, PhaseArgs X)
+{
+    const int lane = laneId(); const DevParams &P = A.P; const uint32_t nSlow = *X.slowCount;
+    for (uint32_t base = blockIdx.x * 64u; base < nSlow; base += gridDim.x * 64u) {
+        const uint32_t slot = base + (uint32_t)lane; const bool live = slot < nSlow;
+        ExtProb pp[YD_MEMO]; int np = 0;
+        if (live) {
+            const uint32_t r = X.slowList[slot]; const P3Root R0 = p3Merged(X, r);
+            const ChainClumpRec rec = A.clumps[A.order[r]]; const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
+            np = predictCarefulDPs(P, R0.L, R0.L.count(), R0.sqo, R0.eqo, R0.sro, R0.refLen, toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0, qlen, toGlobal(A.bases), pp, r0, (rec.rs & 1u) ? XP_STRAND : 0u);
+        }
+        int incl = np;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int total = __shfl(incl, 63, 64); unsigned pb = 0;
+        if (lane == 63 && total) pb = atomicAdd(X.nProb2, (unsigned)total);
+        pb = (unsigned)__shfl((int)pb, 63, 64);
+        if (live) {
+            const unsigned first = pb + (unsigned)(incl - np); int kept = 0;
+            for (int k = 0; k < np; k++) {
+                const unsigned idx = first + (unsigned)k; if (idx >= X.probs2Cap) break;
+                X.probs2[idx] = pp[k]; X.rowsBound2[idx] = (unsigned long long)((pp[k].qLen + 19u) / 10u);
+                uint32_t *key = X.memoKeys + ((size_t)slot * YD_MEMO + (size_t)k) * 3;
+                key[0] = pp[k].rOff; key[1] = (uint32_t)pp[k].qOff | ((uint32_t)pp[k].qLen << 16); key[2] = ((pp[k].flags & XP_REV) ? 1u : 0u) | (idx << 1);
+                kept++;
+            }
+            X.memoCount[slot] = (unsigned)kept;
+        }
+    }
+}
 
 // merge the extension results, then scoreClump / splitClump as in k_align
 __global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)

@@ -455,6 +455,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             Xc.nProb2 = cc + 8 * c + 3; Xc.probs2Cap = cap2;
         } else { Xc.memoKeys = nullptr; Xc.memoCount = nullptr; Xc.probs2 = nullptr; Xc.rowsBound2 = nullptr; Xc.nProb2 = nullptr; Xc.probs2Cap = 0; }
         KL(k_p3_lanes, dim3(gridFor(nr, 256)), dim3(256), 0, ctx->stream, Ac, Xc);
+        if (ctx->splitLanes) KL(k_p3_predict, dim3((unsigned)std::min<uint64_t>(gridFor(nr, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, Ac, Xc);
         PhaseArgs Xw = Xc;                                                    // what k_align_p3 gets: all split roots, or only those k_split_lanes gives back
         // the range's use of the arena (for the next batch's estimate), then the careful-extension round starts it afresh
         unsigned int used[2] = {0, 0}; uint32_t three[3] = {0, 0, 0};       // slow roots, predicted problems
