@@ -12,7 +12,7 @@ __global__ void k_dp_classify(DevParams P, const uint8_t *bases, const uint8_t *
     JointRec j = joints[t];
     YD_GLOBAL const uint8_t *q = toGlobal((j.flags & 1u) ? rev : fwd) + j.qBase; YD_GLOBAL const uint8_t *gB = toGlobal(bases);
     auto refAt = [&](uint32_t off) -> uint32_t { const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
-    const int qGap = j.qGap, rGap = j.rGap, lenDiff = qGap > rGap ? qGap - rGap : rGap - qGap;
+    const int qGap = j.qGap, rGap = j.rGap;
     const bool banded = (j.flags & 2u) != 0;
     j.kind = JK_DP; uint32_t key = 0xFFFFFFFFu;
     if (qGap == rGap && qGap > 0) {

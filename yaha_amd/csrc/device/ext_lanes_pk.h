@@ -1,0 +1,407 @@
+// ext_lanes_pk.h -- k_ext_rows in PACKED 16-BIT arithmetic, one problem per lane, the strip SKEWED over the two halves of each register.
+//
+// k_ext_rows (ext_lanes.h) is bound by vector-instruction issue: ~30 instructions per cell at ~4 cycles each.  v_pk_*_i16 instructions run at the same
+// rate and serve two cells.  The serial E chain of a row (column c needs column c-1) rules out packing two columns of the SAME row, so the 22 register
+// columns are split in two halves that run one row apart:
+//
+//     register pair k (k = 0..10):   low half  = column k      of row t       high half = column k + 11 of row t - 1        (iteration t of the problem)
+//
+// Inside an iteration the pairs are computed left to right, as the columns are in k_ext_rows.  For both halves the diagonal neighbour is the pair's own old
+// value and the upper neighbour the next pair's old value, exactly as in the 32-bit kernel; the two places where the halves meet:
+//   * the left neighbour of column 11 (pair 0, high) is column 10 of the same row t-1 = pair 10's low half as the PREVIOUS iteration left it (V, and the E
+//     value carried in a register of its own);
+//   * the upper neighbour of column 10 (pair 10, low) is column 11 of row t-1 = pair 0's high half as THIS iteration has just computed it.
+// Column 21 (pair 10, high) does not exist: it is held at the sentinel and stands for "no cell above to the right" of column 20.
+// Row 0 of the high half is not special either: started from the sentinel, the E chain that enters from the origin (0, 10) produces exactly
+// V(0, j) = -(GO + (j - 10) GE) in the problem's first iteration.  A problem of i rows takes i + 1 iterations; row t's maximum is known after iteration t + 1.
+//
+// Decisions are the sign bits of saturating differences (no compares, no SGPR pairs): bit 15 / 31 of  dT = E - G (set: E does NOT win), dU = F - max(G, E),
+// dE = (PE - GE) - (PV - GOE) (set: the E run does NOT continue), dF likewise.  v_perm_b32 gathers the sign BYTES of two registers (both halves), v_bfi shifts
+// them into bit planes: one trace record (16 bytes) per iteration and lane,
+//     dword 0 (AB2): pairs 8..10: bits 5..7 of the A bytes, bits 2..4 of the B bytes
+//     dword 1 (M):   mismatch bits, pair k at bit 10 - k (low half) and 26 - k (high half)
+//     dword 2 (A):   byte 0 = notT low half, byte 1 = notT high half, byte 2 = notU low, byte 3 = notU high;  bit k of a byte = pair k (k = 0..7)
+//     dword 3 (B):   as A for notContE / notContF
+// (the traceback of a straight run needs notT, notU and the mismatch bit of one pair per record: dwords 0,1 or 1,2 -- one 8-byte load)
+// eight records to the 128-byte block; everything else -- the pool of pre-loaded problems, the wave-wide hand-over of blocks into arena chunks, ExtRes --
+// is k_ext_rows'.  Record t holds row t's columns 0..10 and row t-1's columns 11..20; the traceback (k_ext_trace_pk) reads cell (y, x) in record y + (x >= 11).
+//
+// Used when the scores fit 16 bits with room for the sentinel (-16000; all arithmetic saturates, so a difference with a sentinel operand keeps its sign):
+// MS * (longest read) <= 15000, RC + X + GO + 21 * GE <= 4000, and neither run cap can bind (maxGap, maxIntron >= 21); otherwise k_ext_rows.
+#pragma once
+#include "ext_lanes.h"
+
+typedef short yd_s16x2 __attribute__((ext_vector_type(2)));
+#define YD_LW16 (-16000)
+#define YD_NP 11                               // register pairs
+#define YD_RCREAL 0x7FF0u                      // reference code of a matrix cell: 0x7FF0 | nibble (as a score bound: never below a real V); not a cell: 0x800F
+
+__device__ __forceinline__ yd_s16x2 pkS(uint32_t v) { return __builtin_bit_cast(yd_s16x2, v); }
+__device__ __forceinline__ uint32_t pkU(yd_s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pkAdd(uint32_t a, uint32_t b) { return pkU(__builtin_elementwise_add_sat(pkS(a), pkS(b))); }
+__device__ __forceinline__ uint32_t pkSub(uint32_t a, uint32_t b) { return pkU(__builtin_elementwise_sub_sat(pkS(a), pkS(b))); }
+__device__ __forceinline__ uint32_t pkMax(uint32_t a, uint32_t b) { return pkU(__builtin_elementwise_max(pkS(a), pkS(b))); }
+// (inline assembly with register operands: written as vector expressions these two are scalarised into compares and selects)
+__device__ __forceinline__ uint32_t pkMin(uint32_t a, uint32_t b) { return pkU(__builtin_elementwise_min(pkS(a), pkS(b))); }
+__device__ __forceinline__ uint32_t pkMinU(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pkMad(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// 0xFFFF in every negative half.  (Not inline assembly with the literal 15: in a packed instruction an inline constant feeds the low half only.)
+__device__ __forceinline__ uint32_t pkSignMask(uint32_t a) { return pkU(pkS(a) >> (yd_s16x2)(15)); }
+// the same as one opaque instruction (c15 = 0x000F000F in a register): written as an expression the compiler turns sub + shift + select into two
+// 16-bit compares and two selects, which cost twice as much here (v_cmp writes an SGPR pair)
+__device__ __forceinline__ uint32_t pkSignMaskAsm(uint32_t a, uint32_t c15) { uint32_t d; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(d) : "v"(c15), "v"(a)); return d; }
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }                      // v_bfi_b32
+__device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) * 0x10001u; }
+
+template <bool SECOND>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ext_rows_pk(ExtArgs A)
+{
+    __shared__ uint32_t sBlk[256 * YD_LDS_STRIDE];   // per lane: the current block of eight 16-byte records, lane stride 33
+    if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());
+    const int lane = laneId();
+    const int GO = A.P.GO, GE = A.P.GE, XC = A.P.X;
+    constexpr int bandwidth = YD_LBAND, leftR = YD_LBAND;
+    const uint32_t maxROff = A.P.maxROff;
+    YD_GLOBAL const uint8_t *gBases = toGlobal(A.bases);
+    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t *const myBlk = &sBlk[threadIdx.x * YD_LDS_STRIDE];
+    const uint32_t GEp = pk2(GE), GOEp = pk2(GO + GE), MSp = pk2(A.P.MS), NEGK = pk2(-(A.P.MS + A.P.RC)), LWp = pk2(YD_LW16), ONEp = 0x00010001u, LWlo = (uint32_t)YD_LW16 & 0xFFFFu;
+
+    uint32_t NEGKv = NEGK, MSv = MSp, ONEv = ONEp, C15v = 0x000F000Fu;      // operands of the inline-assembly instructions: kept in VGPRs (copied from SGPRs at every use otherwise)
+    asm volatile("" : "+v"(NEGKv), "+v"(MSv), "+v"(ONEv), "+v"(C15v));
+    uint32_t PV[YD_NP], PF[YD_NP], rc[YD_NP], carryE = LWp, nbByte = 0, nbOdd = 2u;
+    int p = -1, i = 0, qLen = 0, rLen = 0, maxScore = YD_LWORST, maxi = 0, maxj = 0, qStep = 0, qcNext = 0, qcPrev = 0, rvLo = YD_LWORST, rjLo = 0;
+    uint32_t rOff = 0; bool rev = false, done = false;
+    YD_GLOBAL const uint8_t *q = toGlobal(A.fwd);
+    unsigned calls = 0, rows = 0, cells = 0;
+#pragma unroll
+    for (int k = 0; k < YD_NP; k++) { PV[k] = LWp; PF[k] = LWp; rc[k] = 0x7FFF7FFFu; }
+
+    int poolCount = 0, poolNext = 0; bool exhausted = false;
+    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0;
+    bool pendFlush = false; int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pendStart = 0, pStart = 0;
+    int wslot = 0; unsigned flush = 0; bool dirty = false, justDone = false;
+    YD_GLOBAL uint32_t *chunkPtr = toGlobal(A.trace); bool noMem = false;
+    auto takeChunk = [&]() {                                                 // wave-uniform: the chunk of flushes [flush, flush + 16)
+        unsigned c = 0;
+        if (lane == 0) c = atomicAdd(A.chunkCount, 1u);
+        c = uniU(c);
+        const unsigned ci = flush / YD_CHUNK_FLUSHES;
+        if (c >= A.nChunks || ci >= A.maxCh) { noMem = true; c = 0; if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_TRACEMEM); }
+        if (lane == 0 && ci < A.maxCh) A.waveChunks[(size_t)wave * A.maxCh + ci] = c;
+        chunkPtr = toGlobal(A.trace) + (size_t)c * YD_CHUNK_DWORDS;
+    };
+    takeChunk();
+    // Hand-over: eight lanes write each block, 16 bytes apiece (see k_ext_rows).  f = the lanes whose block leaves, slot = where the wave's blocks of this flush go.
+    auto flushBlocks = [&](unsigned long long f, YD_GLOBAL uint32_t *slot) {
+        if (f != 0ull && !noMem) {
+            int ln = lane; asm volatile("" : "+v"(ln));                      // (opaque: the eight address pairs are computed here, not kept in registers across the row code)
+            const int piece = ln & 7, wv = (int)(threadIdx.x >> 6);
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                if (((f >> (g * 8)) & 0xFFull) == 0ull) continue;            // wave-uniform
+                const int o = g * 8 + (ln >> 3);
+                const uint32_t *src = &sBlk[(wv * 64 + o) * YD_LDS_STRIDE + piece * 4];
+                yd_u32x4 v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                if ((f >> o) & 1ull) *(YD_GLOBAL yd_u32x4 *)(slot + o * YD_LANE_DWORDS + piece * 4) = v;
+            }
+        }
+    };
+    auto nextFlush = [&]() { flush++; if (flush % YD_CHUNK_FLUSHES == 0u) takeChunk(); };     // wave-uniform
+    bool firstFill = true;
+    for (;;) {
+        if (noMem) break;
+        // What the previous iteration loaded is consumed HERE, before this iteration issues any store (the memory counter is in-order: a wait for these loads
+        // further down would also wait for the stores issued in between).  Slide the reference window: pair k takes pair k+1; pair 10's low half takes what
+        // was pair 1's high half, its high half the new base.  (A lane that starts a problem below overwrites the window.)
+        {
+            const uint32_t nb = nbOdd == 2u ? 15u : (nbOdd ? (nbByte & 15u) : (nbByte >> 4));
+#pragma unroll
+            for (int k = 0; k + 1 < YD_NP; k++) rc[k] = rc[k + 1];
+            rc[YD_NP - 1] = (rc[0] >> 16) | ((nb | YD_RCREAL) << 16);
+            asm volatile("" : "+v"(qcNext));
+        }
+        // the blocks the previous iteration completed: their place is fixed now (a problem that starts below notes the flush ITS first block will go out
+        // with), the stores themselves are issued after this iteration's loads (program order = the order the memory counter retires in)
+        unsigned long long flushNow = 0ull; YD_GLOBAL uint32_t *flushSlot = chunkPtr;
+        if (wslot == 0) { flushNow = __ballot(pendFlush); pendFlush = false; if (flushNow != 0ull) { flushSlot = chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u; nextFlush(); } }
+        // ---- refill (k_ext_rows') ----
+        for (;;) {
+            const unsigned long long need = __ballot(p < 0 && !done && !justDone);
+            if (!need) break;
+            if (__builtin_popcountll(need) < YD_REFILL_MIN && __ballot(p >= 0) != 0ull && !firstFill) break;
+            if (poolNext >= poolCount) {
+                unsigned base = 0;
+                if (!exhausted) { if (lane == 0) base = atomicAdd(A.queue, 64u); base = uniU(base); if (base >= A.nProb) exhausted = true; }
+                if (exhausted) { if (p < 0) done = true; break; }
+                poolCount = (int)min(64u, A.nProb - base); poolNext = 0;
+                eLens = 0;
+                if (lane < poolCount) {
+                    const unsigned np = A.order ? A.order[base + (unsigned)lane] : base + (unsigned)lane;
+                    ePidx = np;
+                    const ExtProb pr = A.probs[np];
+                    int ql = 0; uint32_t rl = 0; const bool rv_ = (pr.flags & XP_REV) != 0;
+                    if (pr.flags & XP_VALID) {                              // findAGSExtension, SW.cpp:479-516
+                        calls++;
+                        ql = pr.qLen;
+                        rl = (uint32_t)(ql + bandwidth);
+                        if (rv_ && rl > pr.rOff) { rl = pr.rOff + 1; ql = (int)rl - bandwidth; }
+                        if (!rv_ && (pr.rOff + rl) > maxROff) { rl = maxROff - pr.rOff; ql = (int)rl - bandwidth; }
+                        if (ql > 0) { ql &= 0xFFFF; rl &= 0xFFFF; }
+                    }
+                    if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.where = 0; r.rows = r.cells = 0; A.res[np] = r; }
+                    else {
+                        eLens = (uint32_t)ql | (rl << 16); eROff = pr.rOff; eQ = pr.qBase + pr.qOff;
+                        YD_GLOBAL const uint8_t *qp = toGlobal((pr.flags & XP_STRAND) ? A.rev : A.fwd) + eQ;
+                        eMisc = (pr.flags & 3u) | ((uint32_t)qp[0] << 8);
+                        eW1 = 0; eW2 = 0;                                     // reference indices 0..10 (nibble c - leftR of the window, as in k_ext_rows)
+                        for (int c = leftR; c < YD_LW; c++) {
+                            const int idx = c - leftR; uint32_t nib = 15u;
+                            if (idx < (int)rl) { const uint32_t off = rv_ ? pr.rOff - (uint32_t)idx : pr.rOff + (uint32_t)idx; const uint32_t b = gBases[off >> 1]; nib = (off & 1u) ? (b & 15u) : (b >> 4); }
+                            const uint32_t sh = (uint32_t)(c & 7) * 4u;
+                            if (c < 16) eW1 |= nib << sh; else eW2 |= nib << sh;
+                        }
+                    }
+                }
+            }
+            const int nNeed = __builtin_popcountll(need), avail = poolCount - poolNext;
+            const int e = poolNext + __builtin_popcountll(need & lanesBelow);
+            const bool take = (p < 0 && !done && !justDone) && e < poolCount;
+            const int src = take ? e : lane;
+            const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
+            const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64);
+            const uint32_t gPidx = (uint32_t)__shfl((int)ePidx, src, 64);
+            const bool init = take && gLens != 0u;
+            // A fresh problem: low halves = row 0 of columns 0..10 (the origin (0, 10): V = 0, F = -GO; sentinel left of it), high halves = the sentinel
+            // ("row -1"; the first iteration turns it into row 0 of columns 11..20).  Reference codes: low halves of pairs 0..9 lie left of the matrix in
+            // row 1 (bit 15: not a cell; it slides out with the window), pair 10 low = index 0, pair k high = index k.
+#pragma unroll
+            for (int k = 0; k < YD_NP; k++) {
+                const uint32_t iV = k == leftR ? (LWp & 0xFFFF0000u) : LWp, iF = k == leftR ? ((LWp & 0xFFFF0000u) | ((uint32_t)(-GO) & 0xFFFFu)) : LWp;
+                const int c = leftR + k;                                      // window nibble of reference index k
+                const uint32_t nibHi = (((c < 16 ? gW1 : gW2) >> ((c & 7) * 4)) & 15u) | YD_RCREAL, nibLo = k == leftR ? (((gW1 >> ((leftR & 7) * 4)) & 15u) | YD_RCREAL) : 0x800Fu;
+                PV[k] = init ? iV : PV[k]; PF[k] = init ? iF : PF[k]; rc[k] = init ? (nibLo | (nibHi << 16)) : rc[k];
+            }
+            if (init) {
+                p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0; carryE = LWp; rvLo = YD_LWORST; rjLo = 0;
+                rev = (gMisc & XP_REV) != 0; rOff = gROff;
+                q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu); qcPrev = 0;
+                pStart = (flush << 4) | (unsigned)wslot;
+            }
+            poolNext += nNeed < avail ? nNeed : avail;
+        }
+        firstFill = false;
+        const bool last = __ballot(p >= 0) == 0ull && __ballot(justDone) == 0ull;      // wave-uniform: nothing runs, nothing left; leave once this pass' stores are out
+
+        // ---- one iteration in every lane: row i in the low halves, row i - 1 in the high halves ----
+        const bool busy = p >= 0;
+        ++i;
+        const int qc = qcNext;
+        { const int ni = i < qLen ? i : (qLen > 0 ? qLen - 1 : 0); qcNext = (int)q[ni * qStep]; }   // next iteration's query base
+        { const int idx = i + bandwidth; const bool in = busy && idx < rLen; const uint32_t off = in ? (rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx) : 0u;
+          nbByte = gBases[off >> 1]; nbOdd = in ? (off & 1u) : 2u; }
+        // the iteration's stores, behind its loads: a finished problem's result and the blocks that leave
+        if (pendRes >= 0) {
+            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendStart >> 4; r.nOps = 0;
+            r.where = (pendStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows; r.cells = pendCells;
+            A.res[pendRes] = r; pendRes = -1;
+        }
+        flushBlocks(flushNow, flushSlot);
+        if (last) break;
+        const uint32_t qcP = ((uint32_t)qc | ((uint32_t)qcPrev << 16)) ^ (YD_RCREAL * 0x10001u);      // code ^ qcP = nibble ^ query code
+        qcPrev = qc;
+        uint32_t qcPv = qcP; asm volatile("" : "+v"(qcPv));                   // (opaque: else the constant is re-applied in every pair)
+        uint32_t PVCol = (PV[YD_NP - 1] << 16) | LWlo;                       // low: nothing left of column 0; high: V(i-1, 10)
+        uint32_t PE = (carryE << 16) | LWlo;                                 //                                       E(i-1, 10)
+        uint32_t rowMax = LWp, jbest = 0, dV = PV[0];
+        uint32_t accA = 0, accB = 0, accA2 = 0, accB2 = 0, accM = 0;
+#pragma unroll
+        for (int k = 0; k < YD_NP; k++) {
+            const uint32_t mm = pkMinU(rc[k] ^ qcPv, ONEv);                   // 0 = match, 1 = mismatch, per half
+            uint32_t V = pkAdd(dV, pkMad(mm, NEGKv, MSv));                     // G = diagonal + (MS | -RC)
+            const uint32_t CE = pkSub(PE, GEp), NE = pkSub(PVCol, GOEp);
+            PE = pkMax(CE, NE);
+            const uint32_t dE = pkSub(CE, NE);                               // >= 0: the E run continues (ties continue, SW.cpp:1029-1033)
+            const uint32_t dT = pkSub(PE, V);                                // >= 0: E wins over G ('>=' in extension mode, SW.cpp:1036)
+            V = pkMax(V, PE);
+            uint32_t upV, upF;
+            if (k + 1 < YD_NP) { upV = PV[k + 1]; upF = PF[k + 1]; } else { upV = PV[0] >> 16; upF = PF[0] >> 16; }      // column 10's upper neighbour = column 11 of row i-1, just computed
+            const uint32_t CF = pkSub(upF, GEp), NF = pkSub(upV, GOEp);
+            const uint32_t F = pkMax(CF, NF);
+            const uint32_t dF = pkSub(CF, NF);
+            const uint32_t dU = pkSub(F, V);
+            V = pkMax(V, F);
+            // sign bytes of both halves -> bit planes
+            const uint32_t S1 = __builtin_amdgcn_perm(dU, dT, 0x07050301u), S2 = __builtin_amdgcn_perm(dF, dE, 0x07050301u);
+            if (k < 8) { accA = bfi(0x80808080u, S1, accA >> 1); accB = bfi(0x80808080u, S2, accB >> 1); asm volatile("" : "+v"(accA), "+v"(accB)); }
+            else { accA2 = bfi(0x80808080u, S1, accA2 >> 1); accB2 = bfi(0x80808080u, S2, accB2 >> 1); asm volatile("" : "+v"(accA2), "+v"(accB2)); }
+            accM = (accM << 1) | mm;
+            // row-major first maximum over the real cells, per half.  Low half: the columns left of the matrix (one of them is the boundary column, with a
+            // real-sized value) have a reference code that is negative as a score (0x800F), the cells of the matrix one that is above every score (0x7FF0 | nibble):
+            // one minimum.  High half of pair 10: the column that does not exist.
+            uint32_t Vm = V;
+            if (k < leftR) Vm = pkMin(V, rc[k]);
+            if (k == YD_NP - 1) { V = bfi(0x0000FFFFu, V, LWp); Vm = V; }
+            const uint32_t gt = pkSignMaskAsm(pkSub(rowMax, Vm), C15v);      // 0xFFFF where this cell beats the maximum so far
+            jbest = bfi(gt, (uint32_t)k * 0x10001u, jbest);
+            rowMax = pkMax(rowMax, Vm);
+            PV[k] = V; PF[k] = k == YD_NP - 1 ? bfi(0x0000FFFFu, F, LWp) : F; PVCol = V; dV = upV;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        carryE = PE;
+        { const int slot = wslot * 4;                                        // this iteration's record goes to the lane's LDS block (the same slot in every lane)
+          myBlk[slot] = accA2 | (accB2 >> 3); myBlk[slot + 1] = accM; myBlk[slot + 2] = accA; myBlk[slot + 3] = accB; }
+        // row i - 1 is complete now: its maximum (columns 0..10 from the previous iteration, 11..20 from this one; the first one in column order), X-drop test
+        const int rvHi = (int)(short)(rowMax >> 16), rjHi = (int)(jbest >> 16) + YD_NP;
+        int rv = rvLo, rj = rjLo;
+        if (rvHi > rv) { rv = rvHi; rj = rjHi; }
+        rvLo = (int)(short)(rowMax & 0xFFFFu); rjLo = (int)(jbest & 0xFFFFu);
+        const int row = i - 1;
+        if (row >= 1 && rv > maxScore) { maxScore = rv; maxi = row; maxj = rj; }
+        const bool fin = busy && row >= 1 && (rv < maxScore - XC || row >= qLen);
+        if (busy) dirty = true;
+        if (wslot == 7) { pendFlush = dirty; dirty = false; wslot = 0; } else wslot++;      // wave-uniform
+        justDone = fin;                                                      // the next record slot stays empty behind a finished problem (its traceback's spare record)
+        if (fin) {
+            const unsigned m = row < leftR ? (unsigned)row : (unsigned)leftR, nCells = (unsigned)YD_LW * (unsigned)row - ((unsigned)(leftR + 1) * m - m * (m + 1u) / 2u);
+            rows += (unsigned)row; cells += nCells;
+            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)row; pendCells = nCells; pendStart = pStart;
+            p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
+        }
+    }
+    if (wslot != 0 && dirty) pendFlush = true;
+    { const unsigned long long f = __ballot(pendFlush); if (!noMem && f != 0ull) { flushBlocks(f, chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u); nextFlush(); } }
+    if (pendRes >= 0) {
+        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendStart >> 4; r.nOps = 0;
+        r.where = (pendStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows; r.cells = pendCells;
+        A.res[pendRes] = r;
+    }
+    if (!SECOND && A.clock && lane == 0) atomicMax(&A.clock[1], (unsigned long long)wall_clock64());
+    unsigned c0 = (unsigned)waveSumI((int)calls), c1 = (unsigned)waveSumI((int)rows);
+    unsigned long long cc = cells;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { cc += (unsigned long long)__shfl_xor((long long)cc, d, 64); }
+    if (lane == 0 && !SECOND && A.ctr) {
+        unsigned long long *c = A.ctr->v;
+        atomicAdd(&c[C_EXT_CALLS], (unsigned long long)c0); atomicAdd(&c[C_EXT_ROWS], (unsigned long long)c1); atomicAdd(&c[C_EXT_CELLS], cc);
+        atomicAdd(&c[C_TOUCHED], (unsigned long long)c1 + (unsigned long long)c0 * (unsigned long long)(4 * A.P.bandWidth + 1));
+    }
+}
+
+// ---- traceback over the packed records, lane per problem (SW.cpp:1138-1195; see k_ext_trace for the staging of the ops inside the strip) ---------------
+// Logical strip: record n (1-based, + phase) = dwords [(n-1)/8 * 32 + (n-1)%8 * 4, +4).  Cell (y, x) is pair k = x % 11 (x < 22), half h = x / 11, of record y + h.
+struct PkRec { uint32_t a, m, ab2, b; };
+__device__ __forceinline__ PkRec pkLoadRec(YD_GLOBAL const uint32_t *cp) { const yd_u32x4 v = *(YD_GLOBAL const yd_u32x4 *)cp; PkRec r; r.ab2 = v.x; r.m = v.y; r.a = v.z; r.b = v.w; return r; }
+__device__ __forceinline__ int pkRecWord(int n) { return ((n - 1) >> 3) * 32 + ((n - 1) & 7) * 4; }
+__device__ __forceinline__ bool pkContE(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6; return ((d >> (8 * h + bit)) & 1u) == 0u; }
+__device__ __forceinline__ bool pkContF(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6; return ((d >> (16 + 8 * h + bit)) & 1u) == 0u; }
+__global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId();
+    if (*toGlobal(A.errFlag) != 0) return;
+    const bool live = t < A.nProb;
+    const uint32_t p = live ? ((A.order && !(A.dbgMode & 2)) ? A.order[t] : t) : 0u;
+    ExtRes r; r.score = 0; r.nOps = 0;
+    if (live) r = A.res[p];
+    const bool walk = live && r.score > 0;
+    constexpr int leftR = YD_LBAND;
+    int n = 0; bool bad = false; int E = 0;
+    ExtStrip S; S.arena = toGlobal(A.trace); S.cIdx = -1; S.cBase = S.arena; S.f0 = 0; S.laneOff = 0; S.tab = toGlobal(A.waveChunks); S.limit = 0; S.wild = false;
+    if (walk) {
+        const int ph = (int)(r.where & 15u);
+        S.f0 = r.opsOff; S.laneOff = ((r.where >> 4) & 63u) * YD_LANE_DWORDS; S.tab = toGlobal(A.waveChunks) + (size_t)(r.where >> 10) * A.maxCh;
+        E = pkRecWord(r.maxi + 2 + ph) + 4; S.limit = E;                         // record maxi + 2 is the spare one (computed, or the idle slot behind the problem)
+        int y = r.maxi, x = r.maxj, prev = -1, acc = 0;
+        // physical cursor on the record of the current cell (record y + h): cp = its first dword, rr = its slot in the block, w = its logical offset, fb = its flush
+        struct Cur { YD_GLOBAL uint32_t *cp; int rr, w; unsigned fb; };
+        Cur u; { const int idx = y + (x >= YD_NP ? 1 : 0) - 1 + ph; u.rr = idx & 7; u.w = (idx >> 3) * 32 + u.rr * 4; u.fb = S.f0 + (unsigned)(idx >> 3); u.cp = S.at(u.w); }
+        auto stepUp = [&](Cur &c) {                                          // one record towards the origin (a lane's blocks are consecutive inside a chunk)
+            c.w -= 4;
+            if (c.rr != 0) { c.rr--; c.cp -= 4; return; }
+            c.rr = 7; c.fb--;
+            if (c.fb % YD_CHUNK_FLUSHES == YD_CHUNK_FLUSHES - 1u) c.cp = S.arena + (size_t)S.tab[c.fb / YD_CHUNK_FLUSHES] * YD_CHUNK_DWORDS + S.laneOff + (YD_CHUNK_FLUSHES - 1u) * 32u + 28u;
+            else c.cp -= 4;
+        };
+        const int row0w = pkRecWord(1 + ph) - 4;                                // with the cursor there every record is consumed
+        // free for staging: the records above record (cursor + 1) -- the record after the cursor's may still hold the high half of the cursor's row
+        auto flush = [&]() { const int wp = E - 1 - n; if (wp < u.w + 8) bad = true; else *S.at(wp) = opMake(prev, acc); n++; };
+        auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
+        for (int guard = 0; guard < 70000 && y > 0 && x >= 0 && x < YD_LW; guard++) {
+            const int h = x >= YD_NP ? 1 : 0, k = x - YD_NP * h;
+            const int second = k < 8 ? 0 : 1, bt = k < 8 ? k : k - 3, sT = 8 * h + bt, sU = 16 + sT, sM = 16 * h + 10 - k;
+            uint32_t dTU[YD_TRACE_DEPTH], dM[YD_TRACE_DEPTH];
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+            int lim = (int)(u.fb % YD_CHUNK_FLUSHES) * 8 + u.rr + 1; lim = lim < y ? lim : y; lim = lim < YD_TRACE_DEPTH ? lim : YD_TRACE_DEPTH;
+            { YD_GLOBAL uint32_t *up = u.cp;
+#pragma unroll
+              for (int d = 0; d < YD_TRACE_DEPTH; d++) { const u32x2 v = *(YD_GLOBAL const u32x2 *)(up + (second ? 0 : 1)); dTU[d] = second ? v.x : v.y; dM[d] = second ? v.y : v.x; up -= (d + 1 < lim) ? 4 : 0; } }
+            int took = 0, op = 0;
+#pragma unroll
+            for (int d = 0; d < YD_TRACE_DEPTH; d++) {
+                if (d >= lim) break;
+                const uint32_t notT = (dTU[d] >> sT) & 1u, notU = (dTU[d] >> sU) & 1u, mmb = (dM[d] >> sM) & 1u;
+                op = notU == 0u ? OP_I : (notT == 0u ? OP_D : (mmb ? OP_R : OP_M));
+                if (op >= OP_D || y <= 0) break;
+                if (prev != op) { if (prev >= 0) flush(); prev = op; acc = 1; } else acc++;
+                y--; took++;
+                if (took < lim) { u.cp -= 4; u.w -= 4; u.fb -= u.rr == 0 ? 1u : 0u; u.rr = u.rr == 0 ? 7 : u.rr - 1; }   // inside the chunk: no look-up
+            }
+            if (took == lim) { if (y > 0) stepUp(u); else u.w = row0w; continue; }
+            if (op == OP_D) {                                                    // deletion run: the continue bits along the row, leftwards (the row's low half is one record up)
+                PkRec rb = pkLoadRec(u.cp);
+                int run = 1, xx = x, hh = h; Cur v = u;
+                for (;;) {
+                    if (!pkContE(rb, xx - YD_NP * hh, hh)) break;
+                    xx--; if (xx < 0) break;
+                    run++;
+                    if (hh && xx < YD_NP) { hh = 0; stepUp(v); rb = pkLoadRec(v.cp); }
+                }
+                put(OP_D, run); x -= run;
+                if (h && x < YD_NP) stepUp(u);
+            } else {                                                            // insertion run: the continue bits up and to the right
+                int run = 1, yy = y, xx = x, hh = h; Cur v = u;
+                PkRec rb = pkLoadRec(v.cp);
+                while (pkContF(rb, xx - YD_NP * hh, hh)) {
+                    yy--; xx++; if (yy <= 0 || xx >= YD_LW) break;
+                    run++;
+                    if (!hh && xx >= YD_NP) hh = 1;                              // (y-1, 11) is in the record of (y, 10)
+                    else { stepUp(v); rb = pkLoadRec(v.cp); }
+                }
+                put(OP_I, run); y -= run; x += run;
+                const int h2 = x >= YD_NP ? 1 : 0, steps = run - (h2 - h);
+                if (y > 0) { for (int s = 0; s < steps; s++) stepUp(u); } else u.w = row0w;
+            }
+        }
+        if (y <= 0 && x > leftR) put(OP_D, x - leftR);                           // row 0: deletions back to the origin (SW.cpp:905-935)
+        if (prev >= 0) { const int wp = E - 1 - n; if (wp < 0) bad = true; else *S.at(wp) = opMake(prev, acc); n++; }
+        if (bad || S.wild) { bad = true; atomicCAS(A.errFlag, 0, (int)YERR_TRACE); n = 0; }
+    }
+    if (A.dbgMode & 1) n = 0;
+    const bool inPlace = walk && !bad && n > 0 && (S.f0 + (unsigned)((E - n) >> 5)) / YD_CHUNK_FLUSHES == (S.f0 + (unsigned)((E - 1) >> 5)) / YD_CHUNK_FLUSHES;
+    const int nCopy = (walk && !bad && !inPlace) ? n : 0;
+    int incl = nCopy;
+#pragma unroll
+    for (int d2 = 1; d2 < 64; d2 <<= 1) { const int v = __shfl_up(incl, d2, 64); if (lane >= d2) incl += v; }
+    const int total = __shfl(incl, 63, 64); unsigned ob = 0;
+    if (lane == 63 && total) ob = atomicAdd(A.opsCount, (unsigned)total);
+    ob = (unsigned)__shfl((int)ob, 63, 64);
+    if (walk && !bad) {
+        long long place;
+        if (inPlace) place = (long long)(S.at(E - n) - S.arena);
+        else {
+            const unsigned off = ob + (unsigned)(incl - nCopy);
+            if ((unsigned long long)off + (unsigned)n > (unsigned long long)A.opsCap) { atomicCAS(A.errFlag, 0, (int)YERR_OUT); return; }
+            YD_GLOBAL uint32_t *dst = toGlobal(A.ops) + off;
+            for (int k0 = 0; k0 < n; k0 += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = (k0 + j < n) ? *S.at(E - n + k0 + j) : 0u;
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (k0 + j < n) dst[k0 + j] = v[j];
+            }
+            place = (long long)(dst - S.arena);
+        }
+        r.opsOff = (uint32_t)(unsigned long long)place; r.where = (uint32_t)((unsigned long long)place >> 32); r.nOps = (uint32_t)n; A.res[p] = r;
+    }
+}

@@ -226,7 +226,7 @@ __device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, bool banded,
 // lane per root: exact-match extensions of every joint (AlignHelpers.c:216-232), then the gap's kind (AlignExtFrag.cpp:190-231)
 __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
 {
-    const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
     unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0, nB12 = 0, nB16 = 0;
     if (live) {

@@ -32,6 +32,7 @@
 #include "segsort.h"
 #include "phase_lanes.h"
 #include "gap_band_lanes.h"
+#include "ext_lanes_pk.h"
 #include "split_lanes.h"
 #include "dp_stage.h"
 
@@ -280,6 +281,14 @@ static int stageChain(ygpu_ctx *ctx)
 // Per-wave scratch of the wave kernels, sized from the parameters.  A gap fill between two chained fragments has min(qGap, rGap) <= maxDesert
 // and |qGap - rGap| <= maxGap (GraphPath.cpp:211-230), so its strip is at most MD + G + 2*BW + 3 columns wide (banded: 2*BW + 1 + |qGap - rGap|,
 // full: rGap + 1) and rows x width <= (MD + 2) * (MD + G + 2*BW + 3) cells; the extensions need (maxQ + 2) rows of 64 cells.
+// X-drop extensions in packed 16-bit arithmetic (ext_lanes_pk.h) when every score fits with room for the sentinel
+static bool extRowsPacked(const ygpu_ctx *ctx, bool caps)
+{
+    static const bool force32 = getenv("YGPU_EXT32") != nullptr;
+    const DevParams &P = ctx->P;
+    return !force32 && !caps && P.MS >= 0 && (long long)P.MS * std::max(1, ctx->maxQ) <= 15000 && P.RC >= 0 && P.GO >= 0 && P.GE >= 0 && P.X >= 0 && (long long)P.RC + P.X + P.GO + 21ll * P.GE <= 4000;
+}
+
 static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap, int &traceRows)
 {
     front = 2 * ctx->maxQ + 8 * ctx->P.bandWidth + 64; listCap = 2 * front + 3 * ctx->maxQ + 1024;
@@ -347,14 +356,17 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
     if (ef == YERR_OUT) return -2;
     if (ef) return 0;                                                         // reported by the caller
+    // (the kernels of the X-drop extensions: packed 16-bit rows when the scores fit, see ext_lanes_pk.h; YGPU_EXT32=1 forces the 32-bit kernels)
     // ---- trace memory (ext_lanes.h): an arena of 128 KB chunks that the waves of k_ext_rows take as their rows are computed -------------------------
     // What a launch will need is not known before it ran (an X-drop run stops where it stops); the arena is sized from the bound scaled by the ratio
     // the last batches showed (ctx->traceRatio, a quarter of the bound to begin with) and the stage is redone with a larger one when it overflows.
     // When even the budget (this context's share of the free memory) is not enough, the roots are cut into ranges that use the arena one after the other.
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
-    auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
-    auto rowsKernel2 = caps ? k_ext_rows<true, true> : k_ext_rows<false, true>;
+    const bool pk = extRowsPacked(ctx, caps);
+    auto rowsKernel = pk ? k_ext_rows_pk<false> : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
+    auto rowsKernel2 = pk ? k_ext_rows_pk<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
+    auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace;
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     const unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU), maxWavesK = maxBlocksK * 4u;
@@ -437,7 +449,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         if (c + 1 == nRanges) EV1(T_XROWS);
         TRACE("lanes: ext_rows");
         if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], ctx->stream); }
-        KL(k_ext_trace, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E);
+        KL(traceKernel, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E);
         if (c + 1 == nRanges) hipEventRecord(ctx->ev[T_XTRACE][1], ctx->stream);
         TRACE("lanes: ext_trace");
         if (kTrace) { unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gTraceDbg), sizeof w8); if (w8[0]) { ExtRes rr; hipMemcpy(&rr, E.res + w8[6], sizeof rr, hipMemcpyDeviceToHost); ExtProb pp; hipMemcpy(&pp, E.probs + w8[6], sizeof pp, hipMemcpyDeviceToHost);
@@ -485,7 +497,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                         // per SIMD runs a row 2.4x faster than three sharing it (a lone wave issues every ~5 cycles) and gives every lane more problems to balance.
                         const uint64_t blocks2 = ctx->rows2PerCU > 0 ? (uint64_t)ctx->rows2PerCU : (uint64_t)ctx->nCU;
                         KL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(std::min<uint64_t>(((uint64_t)n2 + 255) / 256, blocks2), (uint64_t)maxBlocksK)), dim3(256), 0, ctx->stream, E2); }
-                    KL(k_ext_trace, dim3(gridFor(n2, 256)), dim3(256), 0, ctx->stream, E2);
+                    KL(traceKernel, dim3(gridFor(n2, 256)), dim3(256), 0, ctx->stream, E2);
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
                 SplitArgs Sx; Sx.scratch = ctx->splitScratch.as<uint8_t>(); Sx.memoKeys = ctx->memoKeys.as<uint32_t>(); Sx.memoCount = ctx->memoCount.as<unsigned int>();
@@ -892,8 +904,10 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 64, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->extRes.p, 0, sizeof(ExtRes) * (uint64_t)nX, ctx->stream));
         unsigned long long blocks = 0, opsBound = 64; for (uint32_t k = 0; k < nX; k++) { blocks += xrows[k]; opsBound += 2ull * xp[k].qLen + 4; }
         const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
-        auto rowsKernel = caps ? k_ext_rows<true, false> : k_ext_rows<false, false>;
-        auto rowsKernel2 = caps ? k_ext_rows<true, true> : k_ext_rows<false, true>;
+        const bool pk = extRowsPacked(ctx, caps);
+        auto rowsKernel = pk ? k_ext_rows_pk<false> : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
+        auto rowsKernel2 = pk ? k_ext_rows_pk<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
+        auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace;
         int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
         const unsigned blocksK = (unsigned)std::min<uint64_t>(((uint64_t)nX + 255) / 256, (uint64_t)ctx->nCU * (second ? 1 : perCU)), wavesK = blocksK * 4u;
         // the arena at the problems' full bound (every lane slot of a flush counts, so twice that) plus a chunk of slack per wave: test-sized batches
@@ -908,7 +922,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         E.ops = ctx->extOps.as<uint32_t>(); E.opsCount = ctx->traceCnt.as<unsigned int>() + 1; E.opsCap = (uint32_t)opsBound; E.res = ctx->extRes.as<ExtRes>();
         E.queue = ctx->chunkCnt.as<unsigned int>(); E.ctr = nullptr; E.errFlag = ctx->errFlag.as<int>(); E.dbgMode = 0;
         if (second) KL(rowsKernel2, dim3(blocksK), dim3(256), 0, ctx->stream, E); else KL(rowsKernel, dim3(blocksK), dim3(256), 0, ctx->stream, E);
-        KL(k_ext_trace, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, E);
+        KL(traceKernel, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, E);
         uint32_t ef2 = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef2); if (rc) return rc;
         if (ef2 != YERR_TRACEMEM) break;                                    // (other errors are reported below)
         if (mult >= 1024) { ctx->err = "extension trace arena overflows"; return YGPU_ENOMEM; }
