@@ -79,7 +79,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.35, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -117,7 +117,7 @@ static double nowMs() { using namespace std::chrono; return duration<double, std
 static const bool kTrace = getenv("YGPU_TRACE") != nullptr;
 static const bool kStats = getenv("YGPU_STATS") != nullptr;      // one line per ygpu_run: attempts of the align stage, ranges, arena size
 #define TRACE(what) do { if (kTrace) { hipStreamSynchronize(ctx->stream); double t_ = nowMs(); fprintf(stderr, "[ygpu] %-28s %9.3f ms\n", what, t_ - ctx->traceT); ctx->traceT = t_; } } while (0)
-#define ENSURE(buf, bytes) do { if ((buf).ensure(bytes)) { ctx->err = "hipMalloc failed for " #buf; return YGPU_ENOMEM; } } while (0)
+#define ENSURE(buf, bytes) do { const size_t was_ = (buf).cap; if ((buf).ensure(bytes)) { ctx->err = "hipMalloc failed for " #buf; return YGPU_ENOMEM; } if (kStats && (buf).cap != was_ && (buf).cap >= (1ull << 30)) fprintf(stderr, "[ygpu] ctx %p: " #buf " grows %.2f -> %.2f GB\n", (void *)ctx, was_ / 1e9, (buf).cap / 1e9); } while (0)
 #define EV0(t) (ctx->evUsed[t] = true, hipEventRecord(ctx->ev[t][0], ctx->stream))
 #define EV1(t) hipEventRecord(ctx->ev[t][1], ctx->stream)
 
@@ -359,7 +359,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     // (the kernels of the X-drop extensions: packed 16-bit rows when the scores fit, see ext_lanes_pk.h; YGPU_EXT32=1 forces the 32-bit kernels)
     // ---- trace memory (ext_lanes.h): an arena of 128 KB chunks that the waves of k_ext_rows take as their rows are computed -------------------------
     // What a launch will need is not known before it ran (an X-drop run stops where it stops); the arena is sized from the bound scaled by the ratio
-    // the last batches showed (ctx->traceRatio, a quarter of the bound to begin with) and the stage is redone with a larger one when it overflows.
+    // the last batches showed (ctx->traceRatio; the first batch guesses from the mean bound) and the stage is redone with a larger one when it overflows.
     // When even the budget (this context's share of the free memory) is not enough, the roots are cut into ranges that use the arena one after the other.
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
@@ -367,14 +367,24 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     auto rowsKernel = pk ? k_ext_rows_pk<false> : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
     auto rowsKernel2 = pk ? k_ext_rows_pk<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
     auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace;
+    static const int traceSort = getenv("YGPU_TRACE_SORT") ? atoi(getenv("YGPU_TRACE_SORT")) : 0;    // the traceback's order: 0 k_ext_rows' order (default: the sort costs what it saves), n > 0: by arena region of 2^n chunks, then by walk length
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     const unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU), maxWavesK = maxBlocksK * 4u;
     const double chunkBlocks = (double)YD_CHUNK_FLUSHES * 64.0;             // lane blocks (128 B) per chunk
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
     const int nShare = std::max(1, gCtxPerDevice[ctx->device & 63].load());
-    unsigned long long budgetChunks = std::max<unsigned long long>(maxWavesK + 64ull, (unsigned long long)((freeB / nShare + ctx->extTrace.cap) * 7 / 10) / (YD_CHUNK_DWORDS * 4ull));
+    // this context's budget: an equal share of 60 % of the device's memory whatever the order the contexts get here in (the first one used to take most of what
+    // was free and left the others to cut their batches into ranges), and no more than what is free now
+    const size_t fairB = (size_t)((double)totB * 0.6 / nShare), availB = (size_t)((double)(freeB + ctx->extTrace.cap) * 0.8);
+    unsigned long long budgetChunks = std::max<unsigned long long>(maxWavesK + 64ull, (unsigned long long)std::min(fairB, availB) / (YD_CHUNK_DWORDS * 4ull));
     budgetChunks = std::min<unsigned long long>(budgetChunks, (96ull << 30) / (YD_CHUNK_DWORDS * 4ull));
+    if (ctx->traceRatio <= 0.0) {
+        // first batch: an X-drop run stops after ~100-200 rows whatever its bound (most roots are chance hits), so the share of the bound that gets used
+        // follows the mean bound; too small an estimate costs a redo of this stage (the arena doubles), too large a one memory the other contexts need
+        const double meanBoundRows = 10.0 * (double)boundBlocks / std::max(1u, nProb);
+        ctx->traceRatio = std::min(0.6, std::max(0.02, 170.0 / std::max(1.0, meanBoundRows)));
+    }
     const double slackChunks = (double)maxWavesK + (double)ctx->nCU * 8.0 + 64.0;   // every wave's open chunk, and the careful-extension round's
     const double wantChunks = (double)boundBlocks * ctx->traceRatio / chunkBlocks + slackChunks;
     std::vector<uint32_t> cuts; cuts.push_back(0);                            // root indices
@@ -397,6 +407,11 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     }
     const size_t nRanges = cuts.size() - 1; ctx->statRanges = (int)nRanges;
     nChunksArena = std::min<unsigned long long>(std::max<unsigned long long>(nChunksArena, maxWavesK + 64ull), 0xFFFFFFF0ull);
+    {   // an arena that is there and within the estimate's safety margin is not re-allocated for the margin's sake (freeing and allocating tens of GB stalls
+        // every context of the device; should it overflow, the stage is redone with twice as much)
+        const unsigned long long capChunks = ctx->extTrace.cap > 256 ? (unsigned long long)((ctx->extTrace.cap - 256) / (YD_CHUNK_DWORDS * 4ull)) : 0ull;
+        if (nRanges == 1 && capChunks > maxWavesK + 64ull && nChunksArena > capChunks && (double)nChunksArena <= 1.3 * (double)capChunks) nChunksArena = capChunks;
+    }
     if (ctx->extTrace.ensure((size_t)nChunksArena * YD_CHUNK_DWORDS * 4ull + 256) != 0) {
         (void)hipGetLastError();
         // the allocation failed although the budget allowed it (another process, fragmentation): take what is there and let the ranges do the rest
@@ -449,6 +464,26 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         if (c + 1 == nRanges) EV1(T_XROWS);
         TRACE("lanes: ext_rows");
         if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], ctx->stream); }
+        if (kTrace && getenv("YGPU_TRACE_LENS")) {                            // diagnostics: the walks of the traceback, per problem and per wave of 64 in k_ext_rows' order
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            std::vector<ExtRes> hr(np); std::vector<uint32_t> ho(np);
+            hipMemcpy(hr.data(), E.res, sizeof(ExtRes) * (size_t)np, hipMemcpyDeviceToHost); hipMemcpy(ho.data(), E.order, 4ull * np, hipMemcpyDeviceToHost);
+            unsigned long long walkers = 0, sumLen = 0, sumWaveMax = 0, sumRows = 0, hist[8] = {0}; std::vector<uint32_t> lens; lens.reserve(np);
+            for (uint32_t w = 0; w < np; w += 64) { uint32_t mx = 0; for (uint32_t k = w; k < std::min(np, w + 64); k++) { const ExtRes &r = hr[ho[k]]; const uint32_t len = r.score > 0 ? (uint32_t)r.maxi : 0u; walkers += r.score > 0; sumLen += len; sumRows += r.rows; mx = std::max(mx, len); int b = 0; while (b < 7 && (len >> (b + 3))) b++; hist[len ? b : 0] += 1; } sumWaveMax += mx; }
+            fprintf(stderr, "[ygpu] traceback: %u problems, %llu walk (%.1f%%), mean walk %.1f rows (all) / %.1f (walkers), rows computed mean %.1f; sum over waves of the longest walk %llu = %.1f x the lanes' mean\n",
+                    np, walkers, 100.0 * walkers / np, (double)sumLen / np, (double)sumLen / std::max(1ull, walkers), (double)sumRows / np, sumWaveMax, (double)sumWaveMax * 64.0 / std::max(1ull, sumLen));
+            fprintf(stderr, "[ygpu] walk length histogram (0..7, 8.., 16.., 32.., 64.., 128.., 256.., 512..):"); for (int b = 0; b < 8; b++) fprintf(stderr, " %llu", hist[b]); fprintf(stderr, "\n");
+        }
+        if (traceSort > 0 && np > 4096u) {                                    // traceback order: by arena chunk, then by walk length (k_trace_keys)
+            uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
+            int lenShift = 0; while ((ctx->maxQ >> lenShift) > 1023) lenShift++;
+            KL(k_trace_keys, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E.res, E.order, np, E.waveChunks, E.maxCh, traceSort, lenShift, k0, v0);
+            size_t bytes = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 32, ctx->stream));
+            if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, 32, ctx->stream));
+            E.order = v1;
+        }
         KL(traceKernel, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E);
         if (c + 1 == nRanges) hipEventRecord(ctx->ev[T_XTRACE][1], ctx->stream);
         TRACE("lanes: ext_trace");
@@ -548,14 +583,16 @@ static int stageAlign(ygpu_ctx *ctx)
         const size_t per = alignScratchBytes(ctx->maxQ, traceRows, listCap, genCap);
         size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
         uint64_t maxWaves = std::max<uint64_t>(64, (uint64_t)((freeB / std::max(1, gCtxPerDevice[ctx->device & 63].load()) + ctx->scratchAlign.cap) * 6 / 10) / per);
-        const unsigned wavesPerCU = ctx->alignWavesPerCU > 0 ? (unsigned)ctx->alignWavesPerCU : 12u;
+        // the default band runs its X-drop extensions one problem per lane (ext_lanes.h); other bands stay on the wave kernel
+        const bool useLanes = ctx->laneExt && ctx->P.bandWidth == 5 && ctx->P.maxGap >= YD_LBAND;
+        // waves of the wave-per-root kernels (and their scratch, ~1 KB per query base each): the whole stage without the lane kernels, only the roots those
+        // hand back with them
+        const unsigned wavesPerCU = ctx->alignWavesPerCU > 0 ? (unsigned)ctx->alignWavesPerCU : (useLanes ? 4u : 12u);
         const unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * wavesPerCU), maxWaves);      // 3 waves per SIMD (137 VGPRs)
         ENSURE(ctx->scratchAlign, per * waves);
         ENSURE(ctx->clumpFrags0, 16ull * (ctx->nClumpFrags + 1));
         HIPCHK(hipMemcpyAsync(ctx->clumpFrags0.p, ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
         ENSURE(ctx->rootPush, 4ull * (NC + 1)); ENSURE(ctx->rootBase, 4ull * (NC + 1));
-        // the default band runs its X-drop extensions one problem per lane (ext_lanes.h); other bands stay on the wave kernel
-        const bool useLanes = ctx->laneExt && ctx->P.bandWidth == 5 && ctx->P.maxGap >= YD_LBAND;
         uint32_t stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + 8ull * ctx->nClumpFrags + 65536);
         uint32_t gapOpsPerJoint = 16;
         uint32_t outClumpCap = NC + NC / 2 + 1024; uint32_t outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 32ull * NC + ctx->totalBases / 2 + 65536);
