@@ -213,6 +213,35 @@ __global__ void k_joint_counts(AlignArgs A, PhaseArgs X)
     if (r == A.nRoots) X.jointCount[r] = 0u;
 }
 
+// Exact-match run: the number of leading positions t in [0, maxLen) with q[qi + DIR*t] == reference base at ro + DIR*t (the reference's byte-by-byte loops of
+// AlignHelpers.c:216-232 and AlignExtFrag.cpp:88-104).  Eight positions per step: 8 query codes (one per byte, < 16: include/yaha_hip.h) folded into a nibble
+// stream, 8 reference nibbles (two per byte, high nibble first) swapped into the same order, one XOR, count of matching nibbles from the near end.  The
+// byte loop had two dependent loads per base.  A window is only read when all eight positions are inside [0, maxLen): no access the byte loop would not make,
+// except the bytes that complete the reference window's 8-byte load (inside the image's slack).
+typedef unsigned long long yd_u64u __attribute__((aligned(1)));
+template <int DIR>
+__device__ __forceinline__ int matchRun(YD_GLOBAL const uint8_t *q, int qi, YD_GLOBAL const uint8_t *gB, uint32_t ro, int maxLen)
+{
+    int m = 0;
+    while (maxLen - m >= 8) {
+        const int qa = DIR > 0 ? qi + m : qi - m - 7; const uint32_t ra = DIR > 0 ? ro + (uint32_t)m : ro - (uint32_t)m - 7u;
+        unsigned long long qx = *(YD_GLOBAL const yd_u64u *)(q + qa);
+        qx = (qx | (qx >> 4)) & 0x00FF00FF00FF00FFull; qx = (qx | (qx >> 8)) & 0x0000FFFF0000FFFFull;
+        const uint32_t qs = (uint32_t)(qx | (qx >> 16));
+        unsigned long long rx = *(YD_GLOBAL const yd_u64u *)(gB + (ra >> 1));
+        rx = ((rx & 0x0F0F0F0F0F0F0F0Full) << 4) | ((rx >> 4) & 0x0F0F0F0F0F0F0F0Full);
+        const uint32_t rs = (uint32_t)(rx >> (4u * (ra & 1u)));
+        const uint32_t diff = qs ^ rs;
+        if (diff) return m + (DIR > 0 ? (__builtin_ctz(diff) >> 2) : (__builtin_clz(diff) >> 2));
+        m += 8;
+    }
+    for (; m < maxLen; m++) {
+        const uint32_t off = DIR > 0 ? ro + (uint32_t)m : ro - (uint32_t)m; const uint32_t b = gB[off >> 1];
+        if ((uint32_t)q[DIR > 0 ? qi + m : qi - m] != ((off & 1u) ? (b & 15u) : (b >> 4))) break;
+    }
+    return m;
+}
+
 // sort key of a DP joint: class << 28 | strip width << 16 | rows.  Class 0 / 1: banded, within k_gap_band's limits, W <= 12 / 16; 2: other W <= 16; 3: the rest.
 __device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, bool banded, int qGap, int rGap)
 {
@@ -240,10 +269,10 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
             for (int k = 1; k < n; k++) {
                 DevFrag nxt = F[k];
                 int gap = (int)min(gapI(cur.eqo, nxt.sqo), gapU(cur.sro + (uint32_t)cur.refLen - 1u, nxt.sro));
-                { int c = 0; while (c < gap && (uint32_t)q[(int)nxt.sqo - 1 - c] == refAt(nxt.sro - 1u - (uint32_t)c)) c++;
+                { const int c = matchRun<-1>(q, (int)nxt.sqo - 1, gB, nxt.sro - 1u, gap);
                   perfect += c; touched += c + (c < gap);
                   if (c > 0) { nxt.sqo = (uint16_t)(nxt.sqo - c); nxt.sro -= (uint32_t)c; nxt.refLen = (uint16_t)(nxt.refLen + c); } gap -= c; }
-                { const uint32_t eRO = cur.sro + (uint32_t)cur.refLen - 1u; int c = 0; while (c < gap && (uint32_t)q[(int)cur.eqo + 1 + c] == refAt(eRO + 1u + (uint32_t)c)) c++;
+                { const uint32_t eRO = cur.sro + (uint32_t)cur.refLen - 1u; const int c = matchRun<1>(q, (int)cur.eqo + 1, gB, eRO + 1u, gap);
                   perfect += c; touched += c + (c < gap);
                   if (c > 0) { cur.eqo = (uint16_t)(cur.eqo + c); cur.refLen = (uint16_t)(cur.refLen + c); } }
                 F[k - 1] = cur;
@@ -402,7 +431,7 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
             int firstAdd = 0;
             int backLen = (int)((uint32_t)sqo < sro ? (uint32_t)sqo : sro), forwLen;
             if (backLen > 0) {
-                int m = 0; while (m < backLen && (uint32_t)q[sqo - 1 - m] == refAt(sro - 1u - (uint32_t)m)) m++;
+                const int m = matchRun<-1>(q, sqo - 1, gB, sro - 1u, backLen);
                 perfect += m; touched += m + (m < backLen);
                 if (m > 0) { firstAdd = m; score += m * P.MS; backLen -= m; sqo -= m; sro -= (uint32_t)m; refLen = (refLen + m) & 0xFFFF; }
             }
@@ -411,7 +440,7 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
                 const uint32_t qrem = (uint32_t)(((qlen - 1) - eqo) & 0xFFFF), rrem = P.maxROff - eRO;
                 forwLen = (int)(qrem < rrem ? qrem : rrem);
                 if (forwLen > 0) {
-                    int m = 0; while (m < forwLen && (uint32_t)q[eqo + 1 + m] == refAt(eRO + 1u + (uint32_t)m)) m++;
+                    const int m = matchRun<1>(q, eqo + 1, gB, eRO + 1u, forwLen);
                     perfect += m; touched += m + (m < forwLen);
                     if (m > 0) { pl = (pl + m) & 0xFFFF; score += m * P.MS; forwLen -= m; eqo += m; refLen = (refLen + m) & 0xFFFF; }
                 }
@@ -440,22 +469,34 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
 // Phase 3 for roots that scoreClump accepts or rejects without a split (AlignHelpers.c:302-366): the merged edit list
 // [backward extension ops][phase-1 ops][forward extension ops] is scanned in place; accepted clumps are written out by
 // their lane.  A root that needs splitClump goes to slowList for k_align_p3.
+typedef uint32_t yd_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 struct MergedOps {
     const uint32_t *a, *b, *c; int na, nb, nc; int jab, jbc;      // junction merges (mergeEOLToFront / mergeEOLToBack, SW.cpp:151-261)
     // a = the backward extension's ops as k_ext_trace leaves them (list order reversed): list element k = a[na-1-k]
+    // The lists are read through a window of four ops (one 16-byte load, aligned to the segment's start): a lane's list shares its lines with nobody, the
+    // lanes of 20 waves per CU evict each other's lines between two of their dependent one-op reads, and every such read was a fetch from beyond L2.
+    // (Reads up to 12 bytes past a segment's end: inside the arenas' slack.)
+    mutable const uint32_t *wp = nullptr; mutable uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    __device__ __forceinline__ uint32_t fetch(const uint32_t *seg, int idx) const
+    {
+        const uint32_t *base = seg + (idx & ~3);
+        if (base != wp) { const yd_u32x4u v = *(YD_GLOBAL const yd_u32x4u *)toGlobal(base); w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w; wp = base; }
+        const int sl = idx & 3;
+        return sl == 0 ? w0 : (sl == 1 ? w1 : (sl == 2 ? w2 : w3));
+    }
     __device__ int count() const { return (na - jab) + nb + (nc - jbc); }
     __device__ uint32_t at(int k) const
     {
         const int ka = na - jab;
-        if (k < ka) return a[na - 1 - k];
+        if (k < ka) return fetch(a, na - 1 - k);
         k -= ka;
         if (k < nb) {
-            uint32_t op = b[k]; int len = opLen(op);
+            uint32_t op = fetch(b, k); int len = opLen(op);
             if (k == 0 && jab) len += opLen(a[0]);
             if (k == nb - 1 && jbc) len += opLen(c[0]);
             return opMake(opCode(op), len & 0xFFFF);
         }
-        return c[k - nb + jbc];
+        return fetch(c, k - nb + jbc);
     }
 };
 // Which careful extensions will splitClump ask for?  The frames it visits (the root, then recursively the head and tail
@@ -467,7 +508,6 @@ struct PredFrame { int start, len, sqo, eqo, refLen; uint32_t sro; int phase, mi
 __device__ inline int predictCarefulDPs(const DevParams &P, const MergedOps &L, int n0, int sqo0, int eqo0, uint32_t sro0, int refLen0,
                                         YD_GLOBAL const uint8_t *q, int qlen, YD_GLOBAL const uint8_t *gB, ExtProb *out, uint32_t qBase, uint32_t strand)
 {
-    auto refAt = [&](uint32_t off) -> uint32_t { const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
     PredFrame st[5]; int depth = 0, nOut = 0; const int wS = sqo0, wE = eqo0;
     PredFrame f; f.start = 0; f.len = n0; f.sqo = sqo0; f.eqo = eqo0; f.sro = sro0; f.refLen = refLen0; f.phase = 0;
     for (int guard = 0; guard < 64; guard++) {
@@ -518,14 +558,14 @@ __device__ inline int predictCarefulDPs(const DevParams &P, const MergedOps &L, 
             const bool goBack = cutB, goForw = cutF || !cutB;                // sic: forward also when neither end was cut
             if (goBack) {
                 int backLen = (int)((uint32_t)sqo < sro ? (uint32_t)sqo : sro);
-                if (backLen > 0) { int m = 0; while (m < backLen && (uint32_t)q[sqo - 1 - m] == refAt(sro - 1u - (uint32_t)m)) m++; backLen -= m; sqo -= m; sro -= (uint32_t)m; refLen = (refLen + m) & 0xFFFF; }
+                if (backLen > 0) { const int m = matchRun<-1>(q, sqo - 1, gB, sro - 1u, backLen); backLen -= m; sqo -= m; sro -= (uint32_t)m; refLen = (refLen + m) & 0xFFFF; }
                 if (backLen >= P.minExtLength && nOut < YD_MEMO) { ExtProb p; p.qBase = qBase; p.rOff = sro - 1u; p.qOff = (uint16_t)((sqo - 1) & 0xFFFF); p.qLen = (uint16_t)(backLen & 0xFFFF); p.flags = strand | XP_REV | XP_VALID; out[nOut++] = p; }
             }
             if (goForw) {
                 const uint32_t eRO = sro + (uint32_t)refLen - 1u;
                 const uint32_t qrem = (uint32_t)(((qlen - 1) - eqo) & 0xFFFF), rrem = P.maxROff - eRO;
                 int forwLen = (int)(qrem < rrem ? qrem : rrem);
-                if (forwLen > 0) { int m = 0; while (m < forwLen && (uint32_t)q[eqo + 1 + m] == refAt(eRO + 1u + (uint32_t)m)) m++; forwLen -= m; eqo += m; refLen = (refLen + m) & 0xFFFF; }
+                if (forwLen > 0) { const int m = matchRun<1>(q, eqo + 1, gB, eRO + 1u, forwLen); forwLen -= m; eqo += m; refLen = (refLen + m) & 0xFFFF; }
                 if (forwLen >= P.minExtLength && nOut < YD_MEMO) { ExtProb p; p.qBase = qBase; p.rOff = sro + (uint32_t)refLen; p.qOff = (uint16_t)((eqo + 1) & 0xFFFF); p.qLen = (uint16_t)(forwLen & 0xFFFF); p.flags = strand | XP_VALID; out[nOut++] = p; }
             }
             f.phase = 4; continue;

@@ -38,7 +38,6 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         const ChainClumpRec rec = A.clumps[A.order[r]];
         const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
         YD_GLOBAL const uint8_t *q = toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0; YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
-        auto refAt = [&](uint32_t off) -> uint32_t { const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
         // ---- the root as k_p3_lanes saw it: phase-1 list + the two extension results --------------------------------------------
         SFrame f; { const RootState *S = X.state + r; f.sro = S->f.sro; f.sqo = S->f.sqo; f.eqo = S->f.eqo; f.refLen = S->f.refLen; f.status = S->f.status; f.score = S->f.score; f.len = S->f.len; f.start = 0; f.phase = 0; }
         MergedOps L; L.a = L.c = nullptr; L.na = L.nc = L.jab = L.jbc = 0; L.b = X.stateOps + X.state[r].listOff; L.nb = f.len;
@@ -133,7 +132,7 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
             if (goBack) {
                 backLen = (int)((uint32_t)fr.sqo < fr.sro ? (uint32_t)fr.sqo : fr.sro);
                 if (backLen > 0) {
-                    int m = 0; while (m < backLen && (uint32_t)q[fr.sqo - 1 - m] == refAt(fr.sro - 1u - (uint32_t)m)) m++;
+                    const int m = matchRun<-1>(q, fr.sqo - 1, gB, fr.sro - 1u, backLen);
                     perfect += m; touched += m + (m < backLen);
                     if (m > 0) { b[fr.start] = opMake(opCode(b[fr.start]), (opLen(b[fr.start]) + m) & 0xFFFF); score += m * P.MS; backLen -= m; fr.sqo -= m; fr.sro -= (uint32_t)m; fr.refLen = (fr.refLen + m) & 0xFFFF; }
                 }
@@ -143,7 +142,7 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
                 const uint32_t qrem = (uint32_t)(((qlen - 1) - fr.eqo) & 0xFFFF), rrem = P.maxROff - eRO;
                 forwLen = (int)(qrem < rrem ? qrem : rrem);
                 if (forwLen > 0) {
-                    int m = 0; while (m < forwLen && (uint32_t)q[fr.eqo + 1 + m] == refAt(eRO + 1u + (uint32_t)m)) m++;
+                    const int m = matchRun<1>(q, fr.eqo + 1, gB, eRO + 1u, forwLen);
                     perfect += m; touched += m + (m < forwLen);
                     if (m > 0) { const int li = fr.start + fr.len - 1; b[li] = opMake(opCode(b[li]), (opLen(b[li]) + m) & 0xFFFF); score += m * P.MS; forwLen -= m; fr.eqo += m; fr.refLen = (fr.refLen + m) & 0xFFFF; }
                 }
