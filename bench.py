@@ -297,9 +297,11 @@ def main():
     rows_ms = stage_ms.get("ext_rows", 0.0) / steps
     rows_dev_ms = stage_ms.get("ext_rows_device_clock", 0.0) / steps
     if rows_ms > 0:
+        packed = stage_ms.get("ext_rows_packed16", 0.0) > 0       # a flag among the timings: the packed 16-bit kernel ran (16-byte trace records instead of 12-byte rows)
         kname, kernel_ms = "k_ext_rows", (rows_dev_ms if rows_dev_ms > 0 else rows_ms)
-        stream_bytes = 13.5 * counters["dp_ext_rows"] + 48.0 * counters["dp_ext_calls"]     # what the kernel itself streams: per row 1 query code + 1/2 B reference + 12 B of trace cells; 48 B per problem
+        stream_bytes = (17.5 if packed else 13.5) * counters["dp_ext_rows"] + 48.0 * counters["dp_ext_calls"]     # what the kernel itself streams: per row 1 query code + 1/2 B reference + 16 (12) B of trace cells; 48 B per problem
     else:                                                    # other band widths run the wave-per-root kernel
+        packed = False
         kname, kernel_ms, stream_bytes = "k_align", align_ms, None
     kbytes = B * n_reads
     achieved = (kbytes / (kernel_ms * 1e-3)) / 1e9 if kernel_ms > 0 else 0.0
@@ -326,14 +328,14 @@ def main():
         "config": {"workload": "BASELINE config 2 shape: synthetic hg18-like genome %d Mbp (24 seqs, 45%% repeats), index -L 15 -S 1 -H 65525, %d x %d bp reads per GPU at %.1f%% divergence, defaults -BW 5 -G 50 -H 650 -M 25 -X 25, hot path A1..A10 with inputs resident in HBM"
                    % (args.genome_mbp, n_reads, args.read_len, 100 * args.div),
                    "reads_per_gpu": n_reads, "read_len": args.read_len, "parallelism": "reads sharded x%d, index replicated, no collective; %d contexts (batches in flight) per GPU" % (world, max(1, args.contexts))},
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+        "roofline": {"bound": "hbm", "kernel": kname, "kernel_variant": ("k_ext_rows_pk (packed 16-bit, two cells per instruction)" if (rows_ms > 0 and packed) else ("k_ext_rows (32-bit)" if rows_ms > 0 else kname)), "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_read": B, "reads_per_launch": n_reads, "kernel_ms_per_launch": kernel_ms,
                      "kernel_ms_hip_events": rows_ms, "kernel_ms_device_clock": rows_dev_ms,
                      "kernel_stream_bytes_per_launch": stream_bytes, "kernel_stream_frac": (stream_bytes / (kernel_ms * 1e-3) / 8.0e12) if (stream_bytes and kernel_ms > 0) else None,
                      "cell_updates_per_s": counters["dp_ext_cells"] / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
                      "valu_frac_nominal": (valu * 2.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
                      "valu_frac_measured_mix": (valu * 4.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
-                     "note": "integer DP: `frac` follows SURVEY 8(d) (algorithmic bytes of the reads of one launch / kernel time / 8 TB/s) and is ~1% by construction; the kernel is bound by vector-ALU issue: valu_frac_nominal prices each wave64 VALU instruction at the nominal 2 SIMD cycles, valu_frac_measured_mix at the 4 cycles its compare/select/max-heavy mix measures (DESIGN.md section 6); kernel_stream_frac counts the trace cells the kernel writes (an implementation choice, not algorithmic traffic)",
+                     "note": "integer DP: `frac` follows SURVEY 8(d) (algorithmic bytes of the reads of one launch / kernel time / 8 TB/s) and is ~1% by construction; the kernel is bound by vector-ALU issue: valu_frac_nominal prices each wave64 VALU instruction at the nominal 2 SIMD cycles, valu_frac_measured_mix at what its mix measures: 4.4 cycles for the packed 16-bit kernel, 4.0 for the 32-bit one (DESIGN.md section 7); kernel_stream_frac counts the trace cells the kernel writes (an implementation choice, not algorithmic traffic)",
                      "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch", "lds_bank_conflict_frac", "gpu_busy_cycles", "source") if k2 in pmc} if pmc else None)},
         "path": {"algorithmic_bytes_per_read": B, "hbm_frac_whole_path": value * B / (8.0e12 * world),
                  "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) * steps * world / dt},

@@ -393,10 +393,10 @@ __global__ void __launch_bounds__(64) k_chain_big(ChainArgs A, const uint32_t *b
 }
 
 // single-fragment regions: a clump iff refLen >= minMatch (QueryMatch.c:281-290); one allocation per wavefront
-// One atomic pair per 256-thread block (a single L2 word takes only ~88 atomics/us; there are ~10^5 waves here).
-__global__ void __launch_bounds__(256) k_regions_single(ChainArgs A)
+// Two atomics per 1024-thread block (a single L2 word takes only ~88 atomics/us; there are ~10^5 waves here).
+__global__ void __launch_bounds__(1024) k_regions_single(ChainArgs A)
 {
-    __shared__ unsigned sCnt[4], sBase[2];
+    __shared__ unsigned sCnt[16], sBase[2];
     const uint32_t reg = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId(), wv = (int)(threadIdx.x >> 6);
     bool make = false; DevFrag f; f.refLen = 0; f.rs = 0;
     if (reg < A.nRegions) {
@@ -407,8 +407,9 @@ __global__ void __launch_bounds__(256) k_regions_single(ChainArgs A)
     if (lane == 0) sCnt[wv] = (unsigned)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned n = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
-        if (n) { sBase[0] = atomicAdd(&A.counts[0], n); sBase[1] = atomicAdd(&A.counts[1], n); atomicAdd(&A.ctr->v[C_FORMED], (unsigned long long)n); }
+        unsigned n = 0; for (unsigned k = 0; k < blockDim.x / 64u; k++) n += sCnt[k];
+        // clump slots and fragment slots advance together: one 64-bit add on the pair of counters (counts is 8-byte aligned)
+        if (n) { const unsigned long long old = atomicAdd((unsigned long long *)&A.counts[0], (unsigned long long)n | ((unsigned long long)n << 32)); sBase[0] = (unsigned)old; sBase[1] = (unsigned)(old >> 32); atomicAdd(&A.ctr->v[C_FORMED], (unsigned long long)n); }
     }
     __syncthreads();
     if (make) {

@@ -141,9 +141,9 @@ __global__ void k_region_starts(const uint32_t *isHead, const uint32_t *regIdx, 
 }
 // multi-fragment region list + largest region
 // smallList: regions with 2..8 fragments (k_chain_lanes); multiList: 9..64 (k_chain); bigList: more than 64 (k_chain_big)
-__global__ void __launch_bounds__(256) k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned int *nSmall)
+__global__ void __launch_bounds__(1024) k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned int *nSmall)
 {
-    __shared__ unsigned sM[4], sS[4], sBase[2];                              // one atomic per list and 256-thread block
+    __shared__ unsigned sM[16], sS[16], sBase[2];                            // one atomic per list and 1024-thread block (a single L2 word takes ~88 atomics per microsecond)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
     const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
     const bool big = n > 64, small = n >= 2 && n <= 8, multi = n > 8 && !big;
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_region_classify(const uint32_t *regStar
     if (lane == 0) { sM[wv] = (unsigned)__builtin_popcountll(mm); sS[wv] = (unsigned)__builtin_popcountll(ms); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned tm = sM[0] + sM[1] + sM[2] + sM[3], ts = sS[0] + sS[1] + sS[2] + sS[3];
+        unsigned tm = 0, ts = 0; for (unsigned k = 0; k < blockDim.x / 64u; k++) { tm += sM[k]; ts += sS[k]; }
         sBase[0] = tm ? atomicAdd(nMulti, tm) : 0u; sBase[1] = ts ? atomicAdd(nSmall, ts) : 0u;
     }
     __syncthreads();
