@@ -266,6 +266,26 @@ def test_index_built_on_the_device_is_byte_identical(work, meta, tmp_path):
         os.remove(os.path.join(d, name))
 
 
+@pytest.mark.parametrize("reads,extra", [("r1k.fa", []), ("rchim.fa", []), ("r10k.fa", [])])
+def test_both_extension_kernel_families(work, index11, reads, extra, monkeypatch):
+    # The X-drop extensions run in packed 16-bit arithmetic (k_ext_rows_pk / k_ext_trace_pk, ext_lanes_pk.h) whenever the scores fit, which is every default
+    # run up to 15 kbp reads; YGPU_EXT32 forces the 32-bit kernels (k_ext_rows / k_ext_trace) on the same input.  Whole pipeline (records and work counters
+    # against the oracle in device_pipeline) and the stage entry for the lane kernels, both ways; the two SAM texts must be the same text.
+    path = os.path.join(work, reads)
+    packed = device_pipeline(index11, path, "-osh", extra, batch=150)
+    with ya.Session(["-x", index11, "-q", path] + extra) as s:
+        b = s.next_batch(200)
+        probs = dp_problems_from_chain(s, b, limit=4000, seed=11)
+        exp = oracle.dp_batch(s.index, s.params, b, probs)
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.upload(b)
+            _dp_check(ctx, probs, exp, ya.DP_KERNELS_LANES)
+            monkeypatch.setenv("YGPU_EXT32", "1")
+            _dp_check(ctx, probs, exp, ya.DP_KERNELS_LANES)
+            _dp_check(ctx, probs, exp, ya.DP_KERNELS_LANES_CAREFUL)
+    assert device_pipeline(index11, path, "-osh", extra, batch=150) == packed
+
+
 @pytest.mark.parametrize("name", ["r1k", "rchim"])
 def test_device_stages_match_the_instrumented_reference(work, index11, name):
     # ygpu_seed_join and ygpu_dp_batch (every kernel family) replayed against dumps of the REAL reference -- the fragment arrays after

@@ -284,7 +284,7 @@ static int stageChain(ygpu_ctx *ctx)
 // X-drop extensions in packed 16-bit arithmetic (ext_lanes_pk.h) when every score fits with room for the sentinel
 static bool extRowsPacked(const ygpu_ctx *ctx, bool caps)
 {
-    static const bool force32 = getenv("YGPU_EXT32") != nullptr;
+    const bool force32 = getenv("YGPU_EXT32") != nullptr;            // (read at every call: the tests run both kernel families in one process)
     const DevParams &P = ctx->P;
     return !force32 && !caps && P.MS >= 0 && (long long)P.MS * std::max(1, ctx->maxQ) <= 15000 && P.RC >= 0 && P.GO >= 0 && P.GE >= 0 && P.X >= 0 && (long long)P.RC + P.X + P.GO + 21ll * P.GE <= 4000;
 }
