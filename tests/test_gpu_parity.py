@@ -286,6 +286,42 @@ def test_both_extension_kernel_families(work, index11, reads, extra, monkeypatch
     assert device_pipeline(index11, path, "-osh", extra, batch=150) == packed
 
 
+@pytest.mark.parametrize("xdrop", ["25", "3900", "4100"])
+def test_packed_rows_at_the_ends_of_their_score_range(work, index11, tmp_path, xdrop):
+    # k_ext_rows_pk computes in saturating 16-bit arithmetic with a sentinel of -16000 and is used while MS * (longest read) <= 15000 and
+    # RC + X + GO + 21 GE <= 4000 (ext_lanes_pk.h).  Reads of 15000 bases (the last length it takes), 15001 (the first the 32-bit kernel gets) and 9000, each an
+    # exact copy of the genome behind 1200 random bases: forward extensions that climb to a score of ~13800, backward extensions that stay below
+    # zero for as long as the X-drop allows (-X 3900: the largest the packed kernel takes; 4100: the 32-bit kernel), every result against the oracle.
+    import random
+    from problems import read_fasta
+    _, seqs = read_fasta(os.path.join(work, "genome_small.fa"))
+    rnd = random.Random(7)
+    for k, (total, start) in enumerate([(15000, 2000), (15001, 40000), (9000, 70000)]):
+        junk = "".join(rnd.choice("ACGT") for _ in range(1200))
+        reads = str(tmp_path / ("long%d.fa" % k))
+        with open(reads, "w") as f:
+            body = list(seqs[0][start:start + total - 1200])
+            for pos in range(900, len(body), 2500):                              # a substitution every 2 500 bases: the seed fragments end there, the extensions run on
+                body[pos] = "ACGT"[("ACGT".index(body[pos]) + 1) % 4]
+            f.write(">long%d\n%s%s\n" % (k, junk, "".join(body)))
+        with ya.Session(["-x", index11, "-q", reads, "-X", xdrop]) as s:
+            b = s.next_batch(4)
+            assert b.n_reads == 1
+            probs = []
+            for rs, frags in oracle.chain(s.index, s.params, b):
+                f0 = frags[0]
+                probs.append(ya.DPProblem(0, rs & 1, ya.DP_EXT_REV, f0[1] - 1, min(f0[1], f0[0]), 0, f0[0] - 1))
+                probs.append(ya.DPProblem(0, rs & 1, ya.DP_EXT_FWD, f0[2] + 1, total - 1 - f0[2], 0, f0[0] + f0[3]))
+            assert probs
+            exp = oracle.dp_batch(s.index, s.params, b, probs)
+            assert max(e[0] for e in exp) > total - 1200 - 1000 - 40                # the long climb is among them (5 substitutions, first fragment of 900 bases)
+            with ya.Context(s.index, s.params) as ctx:
+                ctx.upload(b)
+                _dp_check(ctx, probs, exp, ya.DP_KERNELS_LANES)
+                _dp_check(ctx, probs, exp, ya.DP_KERNELS_LANES_CAREFUL)
+        assert device_pipeline(index11, reads, "-osh", ["-X", xdrop], batch=4)
+
+
 @pytest.mark.parametrize("name", ["r1k", "rchim"])
 def test_device_stages_match_the_instrumented_reference(work, index11, name):
     # ygpu_seed_join and ygpu_dp_batch (every kernel family) replayed against dumps of the REAL reference -- the fragment arrays after
