@@ -367,7 +367,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     auto rowsKernel = pk ? k_ext_rows_pk<false> : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
     auto rowsKernel2 = pk ? k_ext_rows_pk<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
     auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace;
-    static const int traceSort = getenv("YGPU_TRACE_SORT") ? atoi(getenv("YGPU_TRACE_SORT")) : 0;    // the traceback's order: 0 k_ext_rows' order (default: the sort costs what it saves), n > 0: by arena region of 2^n chunks, then by walk length
+    static const int traceSort = getenv("YGPU_TRACE_SORT") ? atoi(getenv("YGPU_TRACE_SORT")) : 7;    // the traceback's order: 0 k_ext_rows' order, n > 0: by arena region of 2^n chunks, then by walk length
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     const unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU), maxWavesK = maxBlocksK * 4u;
@@ -474,14 +474,15 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                     np, walkers, 100.0 * walkers / np, (double)sumLen / np, (double)sumLen / std::max(1ull, walkers), (double)sumRows / np, sumWaveMax, (double)sumWaveMax * 64.0 / std::max(1ull, sumLen));
             fprintf(stderr, "[ygpu] walk length histogram (0..7, 8.., 16.., 32.., 64.., 128.., 256.., 512..):"); for (int b = 0; b < 8; b++) fprintf(stderr, " %llu", hist[b]); fprintf(stderr, "\n");
         }
-        if (traceSort > 0 && np > 4096u) {                                    // traceback order: by arena chunk, then by walk length (k_trace_keys)
+        if (traceSort > 0 && np > 4096u) {                                    // traceback order: by arena region, then by walk length (k_trace_keys)
             uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
-            int lenShift = 0; while ((ctx->maxQ >> lenShift) > 1023) lenShift++;
+            int lenShift = 0; while ((ctx->maxQ >> lenShift) > 31) lenShift++;
+            int keyBits = 5; while (keyBits < 32 && ((unsigned long long)E.nChunks >> traceSort) >> (keyBits - 5)) keyBits++;        // region bits above the five length bits
             KL(k_trace_keys, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E.res, E.order, np, E.waveChunks, E.maxCh, traceSort, lenShift, k0, v0);
             size_t bytes = 0;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 32, ctx->stream));
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, keyBits, ctx->stream));
             if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, 32, ctx->stream));
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, keyBits, ctx->stream));
             E.order = v1;
         }
         KL(traceKernel, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E);
