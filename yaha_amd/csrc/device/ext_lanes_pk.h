@@ -71,8 +71,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     uint32_t NEGKv = NEGK, MSv = MSp, ONEv = ONEp, C15v = 0x000F000Fu;      // operands of the inline-assembly instructions: kept in VGPRs (copied from SGPRs at every use otherwise)
     asm volatile("" : "+v"(NEGKv), "+v"(MSv), "+v"(ONEv), "+v"(C15v));
     uint32_t PV[YD_NP], PF[YD_NP], rc[YD_NP], carryE = LWp, nbByte = 0, nbOdd = 2u;
-    int p = -1, i = 0, qLen = 0, rLen = 0, maxScore = YD_LWORST, maxi = 0, maxj = 0, qStep = 0, qcNext = 0, qcPrev = 0, rvLo = YD_LWORST, rjLo = 0;
-    uint32_t rOff = 0; bool rev = false, done = false;
+    int p = -1, i = 0, qLen = 0, maxScore = YD_LWORST, maxi = 0, maxj = 0, qcNext = 0, qcPrev = 0, rvLo = YD_LWORST, rjLo = 0;
+    // running addresses of the two byte streams: query index qi (stepped by qStep inside [qLo, qHi]) and reference offset rCur (stepped by rStep while rLeft > 0)
+    int qi = 0, qStep = 0, qLo = 0, qHi = 0, rStep = 0, rLeft = 0; uint32_t rCur = 0; bool done = false;
     YD_GLOBAL const uint8_t *q = toGlobal(A.fwd);
     unsigned calls = 0, rows = 0, cells = 0;
 #pragma unroll
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 
     int poolCount = 0, poolNext = 0; bool exhausted = false;
     uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0;
-    bool pendFlush = false; int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pendStart = 0, pStart = 0;
+    bool pendFlush = false; int pendRes = -1; unsigned pStart = 0;      // pendRes: the problem whose result this lane stores in its next pass (its state stays untouched until then)
     int wslot = 0; unsigned flush = 0; bool dirty = false, justDone = false;
     YD_GLOBAL uint32_t *chunkPtr = toGlobal(A.trace); bool noMem = false;
     auto takeChunk = [&]() {                                                 // wave-uniform: the chunk of flushes [flush, flush + 16)
@@ -184,9 +185,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 PV[k] = init ? iV : PV[k]; PF[k] = init ? iF : PF[k]; rc[k] = init ? (nibLo | (nibHi << 16)) : rc[k];
             }
             if (init) {
-                p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); rLen = (int)(gLens >> 16); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0; carryE = LWp; rvLo = YD_LWORST; rjLo = 0;
-                rev = (gMisc & XP_REV) != 0; rOff = gROff;
-                q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qcNext = (int)((gMisc >> 8) & 0xFFu); qcPrev = 0;
+                p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0; carryE = LWp; rvLo = YD_LWORST; rjLo = 0;
+                const bool rev = (gMisc & XP_REV) != 0;
+                q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qi = 0; qLo = rev ? 1 - qLen : 0; qHi = rev ? 0 : qLen - 1;
+                qcNext = (int)((gMisc >> 8) & 0xFFu); qcPrev = 0;
+                // iteration i loads reference index i + 10 (valid while below rLen): rCur starts at index 10
+                rStep = qStep; rCur = rev ? gROff - (uint32_t)bandwidth : gROff + (uint32_t)bandwidth; rLeft = (int)(gLens >> 16) - bandwidth;
                 pStart = (flush << 4) | (unsigned)wslot;
             }
             poolNext += nNeed < avail ? nNeed : avail;
@@ -198,13 +202,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         const bool busy = p >= 0;
         ++i;
         const int qc = qcNext;
-        { const int ni = i < qLen ? i : (qLen > 0 ? qLen - 1 : 0); qcNext = (int)q[ni * qStep]; }   // next iteration's query base
-        { const int idx = i + bandwidth; const bool in = busy && idx < rLen; const uint32_t off = in ? (rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx) : 0u;
+        { int t = qi + qStep; t = t < qLo ? qLo : t; qi = t > qHi ? qHi : t; qcNext = (int)q[qi]; }   // next iteration's query base (index i * qStep, held inside the extension)
+        { rCur += (uint32_t)rStep; rLeft--; const bool in = rLeft > 0; const uint32_t off = in ? rCur : 0u;   // the reference base that enters the window (index i + 10)
           nbByte = gBases[off >> 1]; nbOdd = in ? (off & 1u) : 2u; }
         // the iteration's stores, behind its loads: a finished problem's result and the blocks that leave
         if (pendRes >= 0) {
-            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendStart >> 4; r.nOps = 0;
-            r.where = (pendStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows; r.cells = pendCells;
+            // the problem ended in the previous pass at row i - 2 (i has been stepped since; the lane sat out the refill above, so maxScore / maxi / maxj / pStart
+            // are still its own).  Work of the call: row r has 21 - max(11 - r, 0) real cells.
+            const unsigned rowF = (unsigned)(i - 2), m = rowF < (unsigned)leftR ? rowF : (unsigned)leftR, nCells = __umul24((unsigned)YD_LW, rowF) - (__umul24((unsigned)(leftR + 1), m) - __umul24(m, m + 1u) / 2u);
+            rows += rowF; cells += nCells;
+            ExtRes r; r.score = maxScore > 0 ? maxScore : 0; r.maxi = maxi; r.maxj = maxj; r.opsOff = pStart >> 4; r.nOps = 0;
+            r.where = (pStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = rowF; r.cells = nCells;
             A.res[pendRes] = r; pendRes = -1;
         }
         flushBlocks(flushNow, flushSlot);
@@ -258,25 +266,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (rvHi > rv) { rv = rvHi; rj = rjHi; }
         rvLo = (int)(short)(rowMax & 0xFFFFu); rjLo = (int)(jbest & 0xFFFFu);
         const int row = i - 1;
-        if (row >= 1 && rv > maxScore) { maxScore = rv; maxi = row; maxj = rj; }
+        if (busy && row >= 1 && rv > maxScore) { maxScore = rv; maxi = row; maxj = rj; }
         const bool fin = busy && row >= 1 && (rv < maxScore - XC || row >= qLen);
         if (busy) dirty = true;
         if (wslot == 7) { pendFlush = dirty; dirty = false; wslot = 0; } else wslot++;      // wave-uniform
         justDone = fin;                                                      // the next record slot stays empty behind a finished problem (its traceback's spare record)
-        if (fin) {
-            const unsigned m = row < leftR ? (unsigned)row : (unsigned)leftR, nCells = (unsigned)YD_LW * (unsigned)row - ((unsigned)(leftR + 1) * m - m * (m + 1u) / 2u);
-            rows += (unsigned)row; cells += nCells;
-            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)row; pendCells = nCells; pendStart = pStart;
-            p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
-        }
+        // A finished lane keeps its state: the result is stored from it in the next pass; its byte streams stay inside the finished extension (clamped index,
+        // rLeft <= 0), so an idle lane's loads are harmless.
+        if (fin) { pendRes = p; p = -1; }
     }
     if (wslot != 0 && dirty) pendFlush = true;
     { const unsigned long long f = __ballot(pendFlush); if (!noMem && f != 0ull) { flushBlocks(f, chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u); nextFlush(); } }
-    if (pendRes >= 0) {
-        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendStart >> 4; r.nOps = 0;
-        r.where = (pendStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows; r.cells = pendCells;
-        A.res[pendRes] = r;
-    }
+    // (a result still pending here belongs to a launch that ran out of arena: the host zeroes the results and redoes the stage)
     if (!SECOND && A.clock && lane == 0) atomicMax(&A.clock[1], (unsigned long long)wall_clock64());
     unsigned c0 = (unsigned)waveSumI((int)calls), c1 = (unsigned)waveSumI((int)rows);
     unsigned long long cc = cells;
