@@ -14,7 +14,7 @@ __global__ void k_dp_classify(DevParams P, const uint8_t *bases, const uint8_t *
     auto refAt = [&](uint32_t off) -> uint32_t { const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
     const int qGap = j.qGap, rGap = j.rGap;
     const bool banded = (j.flags & 2u) != 0;
-    j.kind = JK_DP; uint32_t key = 0xFFFFFFFFu;
+    j.kind = JK_DP; uint32_t key = YD_JKEY_NONE;
     if (qGap == rGap && qGap > 0) {
         int mm = 0, runs = 0, pc = -1;
         for (int k = 0; k < qGap; k++) { const int c = (uint32_t)q[(int)j.nsqo + k] != refAt(j.nsro + (uint32_t)k); mm += c; runs += c != pc; pc = c; }

@@ -462,5 +462,5 @@ __global__ void k_rebase_u32(uint32_t *v, uint32_t n, uint32_t sub)
 __global__ void k_prob_keys(const ExtProb *probs, uint32_t n, uint32_t *keys, uint32_t *vals)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) { keys[p] = (probs[p].flags & XP_VALID) ? 0xFFFFu - probs[p].qLen : 0x10000u; vals[p] = p; }
+    if (p < n) { keys[p] = (probs[p].flags & XP_VALID) ? 0xFFFFu - probs[p].qLen : 0xFFFFu; vals[p] = p; }
 }

@@ -242,14 +242,18 @@ __device__ __forceinline__ int matchRun(YD_GLOBAL const uint8_t *q, int qi, YD_G
     return m;
 }
 
-// sort key of a DP joint: class << 28 | strip width << 16 | rows.  Class 0 / 1: banded, within k_gap_band's limits, W <= 12 / 16; 2: other W <= 16; 3: the rest.
+// sort key of a DP joint, 16 bits (two radix passes): class : 2 | strip width : 7 | rows : 7, both clamped (the order only groups similar shapes; the class
+// boundaries are exact).  Class 0 / 1: banded, within k_gap_band's limits, W <= 12 / 16; 2: other W <= 16; 3: the rest.  Joints without a DP: YD_JKEY_NONE, last.
+#define YD_JKEY_NONE 0xFFFFu
+#define YD_JKEY_BITS 16
+__device__ __forceinline__ uint32_t gapJointClass(uint32_t key) { return key >> 14; }
 __device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, bool banded, int qGap, int rGap)
 {
     const int lenDiff = qGap > rGap ? qGap - rGap : rGap - qGap;
     const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1;
     uint32_t cls = W <= 16 ? 2u : 3u;
     if (banded && W <= 16 && P.bandWidth >= 5 && P.maxGap >= 16 && qGap <= YD_GROWS && rGap <= YD_GREF) cls = W <= 12 ? 0u : 1u;
-    return (cls << 28) | ((uint32_t)min(W, 0xFFF) << 16) | (uint32_t)qGap;
+    return (cls << 14) | ((uint32_t)min(W, 127) << 7) | (uint32_t)min(qGap, 126);
 }
 
 // lane per root: exact-match extensions of every joint (AlignHelpers.c:216-232), then the gap's kind (AlignExtFrag.cpp:190-231)
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
                 const int qGap = (int)(gapI(cur.eqo, nxt.sqo) & 0xFFFF), rGap = (int)(gapU(eRO, nxt.sro) & 0xFFFF);
                 JointRec j; j.nsro = eRO + 1u; j.qBase = r0; j.nsqo = (uint16_t)((cur.eqo + 1) & 0xFFFF); j.qGap = (uint16_t)qGap; j.rGap = (uint16_t)rGap;
                 j.flags = (uint8_t)(rec.rs & 1u); j.opsOff = 0; j.nOps = 0; j.pad = 0; j.score = 0; j.cells = 0; j.kind = JK_NONE;
-                uint32_t key = 0xFFFFFFFFu;
+                uint32_t key = YD_JKEY_NONE;
                 if (qGap == 0 && rGap == 0) { }
                 else if (qGap == 0) j.kind = JK_D;
                 else if (rGap == 0) j.kind = JK_I;
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
                         for (int t = 0; t < qGap; t++) mm += (uint32_t)q[(int)cur.eqo + 1 + t] != refAt(eRO + 1u + (uint32_t)t);
                         if (mm * (P.MS + P.RC) <= P.MS + 2 * (P.GO + P.GE)) { j.kind = JK_DIAG; j.score = P.MS * (qGap - mm) - P.RC * mm; }
                     }
-                    if (j.kind == JK_DP) { key = gapJointKey(P, banded, qGap, rGap); const uint32_t cls = key >> 28; nDP++; nDP16 += cls <= 2u; nB12 += cls == 0u; nB16 += cls <= 1u; }
+                    if (j.kind == JK_DP) { key = gapJointKey(P, banded, qGap, rGap); const uint32_t cls = gapJointClass(key); nDP++; nDP16 += cls <= 2u; nB12 += cls == 0u; nB16 += cls <= 1u; }
                 }
                 X.joints[jb + (uint32_t)(k - 1)] = j; X.sortKeys[jb + (uint32_t)(k - 1)] = key; X.sortVals[jb + (uint32_t)(k - 1)] = jb + (uint32_t)(k - 1);
                 cur = nxt;
@@ -456,7 +460,7 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
             ExtProb pb; pb.qBase = r0; pb.rOff = sro - 1u; pb.qOff = (uint16_t)((sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF); pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
             ExtProb pf; pf.qBase = r0; pf.rOff = sro + (uint32_t)refLen; pf.qOff = (uint16_t)((eqo + 1) & 0xFFFF); pf.qLen = (uint16_t)(forwLen & 0xFFFF); pf.flags = strand | (vf ? XP_VALID : 0u);
             X.probs[2 * (size_t)r] = pb; X.probs[2 * (size_t)r + 1] = pf;
-            X.extKeys[2 * (size_t)r] = vb ? 0xFFFFu - pb.qLen : 0x10000u; X.extKeys[2 * (size_t)r + 1] = vf ? 0xFFFFu - pf.qLen : 0x10000u;
+            X.extKeys[2 * (size_t)r] = vb ? 0xFFFFu - pb.qLen : 0xFFFFu; X.extKeys[2 * (size_t)r + 1] = vf ? 0xFFFFu - pf.qLen : 0xFFFFu;      // 16 bits: two radix passes (a valid problem has qLen >= 1)
             X.extVals[2 * (size_t)r] = 2u * r; X.extVals[2 * (size_t)r + 1] = 2u * r + 1u;
             X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)((pb.qLen + 19u) / 10u) : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)((pf.qLen + 19u) / 10u) : 0ull;   // trace blocks of 10 rows: up to 9 rows of phase in front, one spare row behind
         }

@@ -333,9 +333,9 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     if (J) {
         KL(k_p1_joints, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
         size_t bytes = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, YD_JKEY_BITS, ctx->stream));
         if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, 32, ctx->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, YD_JKEY_BITS, ctx->stream));
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 6);   // 17 / 26 KB of LDS per 64-thread block
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
         KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
@@ -453,9 +453,9 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         HIPCHK(hipMemsetAsync(E.res, 0, sizeof(ExtRes) * (uint64_t)np, ctx->stream));   // a launch that runs out of arena leaves problems unfinished: they must read as "no extension", not as the last batch's results
         {   // longest bound first: the launch's drain phase is then left with short problems only
             size_t bytes = 0; uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 17, ctx->stream));
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 16, ctx->stream));
             if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, 17, ctx->stream));
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, 16, ctx->stream));
             KL(k_rebase_u32, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, v1, np, p0);
             E.order = v1;
         }
@@ -524,9 +524,9 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                         ENSURE(ctx->keys2a, 4ull * (cap2 + 1)); ENSURE(ctx->keys2b, 4ull * (cap2 + 1)); ENSURE(ctx->vals2a, 4ull * (cap2 + 1)); ENSURE(ctx->vals2b, 4ull * (cap2 + 1));
                         KL(k_prob_keys, dim3(gridFor(n2, 256)), dim3(256), 0, ctx->stream, ctx->probs2.as<ExtProb>(), n2, ctx->keys2a.as<uint32_t>(), ctx->vals2a.as<uint32_t>());
                         size_t bytes = 0;
-                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, ctx->stream));
+                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 16, ctx->stream));
                         if (ctx->cubTemp2.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp2.p, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 17, ctx->stream));
+                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp2.p, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 16, ctx->stream));
                     }
                     E2.order = ctx->vals2b.as<uint32_t>(); E2.res = ctx->extRes2.as<ExtRes>(); E2.queue = cc + 8 * c + 4; E2.ctr = nullptr;   // counted by k_split_lanes
                     {   // a small launch: a few problems per lane, so its length is set by the lanes' chains of problems, not by the chip's throughput.  One wave
@@ -980,7 +980,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         rc = fetchU32(ctx, ctx->sortKeys.p, keys.data(), nJ); if (rc) return rc;
         for (uint32_t k = 0; k < nJ; k++) idx[k] = k;
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });           // the production path sorts the DP joints by (strip width, rows) as well
-        uint32_t nd[3] = {0, 0, 0}, nb[2] = {0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != 0xFFFFFFFFu) { const uint32_t cls = keys[k] >> 28; nd[0]++; nd[1] += cls <= 2u; nb[0] += cls == 0u; nb[1] += cls <= 1u; }
+        uint32_t nd[3] = {0, 0, 0}, nb[2] = {0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != YD_JKEY_NONE) { const uint32_t cls = keys[k] >> 14; nd[0]++; nd[1] += cls <= 2u; nb[0] += cls == 0u; nb[1] += cls <= 1u; }
         HIPCHK(hipMemcpyAsync(cnt + CNT_NB12, nb, 8, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->sortVals2.p, idx.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(cnt + CNT_NDP, nd, 12, hipMemcpyHostToDevice, ctx->stream));
