@@ -89,7 +89,7 @@ struct ygpu_ctx {
     // asynchronous tickets (ygpu_submit / ygpu_wait): one worker thread per context, started on first use
     std::thread worker; std::mutex aMu; std::condition_variable aCv; const ygpu_read_batch *aBatch = nullptr; uint64_t aTicket = 0; int aRc = 0; bool aOpen = false, aDone = false, aQuit = false; ygpu_result_batch aOut{};
     // timing
-    hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N]; bool rowsPacked = false;
+    hipEvent_t evSync = nullptr; hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N]; bool rowsPacked = false;
 };
 
 static DevBatch devBatch(ygpu_ctx *c) { DevBatch b; b.fwd = c->dFwd.as<uint8_t>(); b.rev = c->dRev.as<uint8_t>(); b.readOff = c->dReadOff.as<uint32_t>(); b.nReads = c->nReads; return b; }
@@ -116,13 +116,23 @@ static int cubScan64(ygpu_ctx *ctx, const unsigned long long *in, unsigned long 
 static double nowMs() { using namespace std::chrono; return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count(); }
 static const bool kTrace = getenv("YGPU_TRACE") != nullptr;
 static const bool kStats = getenv("YGPU_STATS") != nullptr;      // one line per ygpu_run: attempts of the align stage, ranges, arena size
-#define TRACE(what) do { if (kTrace) { hipStreamSynchronize(ctx->stream); double t_ = nowMs(); fprintf(stderr, "[ygpu] %-28s %9.3f ms\n", what, t_ - ctx->traceT); ctx->traceT = t_; } } while (0)
+#define TRACE(what) do { if (kTrace) { streamSync(ctx); double t_ = nowMs(); fprintf(stderr, "[ygpu] %-28s %9.3f ms\n", what, t_ - ctx->traceT); ctx->traceT = t_; } } while (0)
 #define ENSURE(buf, bytes) do { const size_t was_ = (buf).cap; if ((buf).ensure(bytes)) { ctx->err = "hipMalloc failed for " #buf; return YGPU_ENOMEM; } if (kStats && (buf).cap != was_ && (buf).cap >= (1ull << 30)) fprintf(stderr, "[ygpu] ctx %p: " #buf " grows %.2f -> %.2f GB\n", (void *)ctx, was_ / 1e9, (buf).cap / 1e9); } while (0)
 #define EV0(t) (ctx->evUsed[t] = true, hipEventRecord(ctx->ev[t][0], ctx->stream))
 #define EV1(t) hipEventRecord(ctx->ev[t][1], ctx->stream)
 
+// Waits of the host for its stream: on an event created with hipEventBlockingSync, so that the thread sleeps instead of spinning -- a context has ~15 such
+// waits per batch, each tens of milliseconds long, and a node runs (GPUs x contexts) of these threads (YGPU_SPIN_SYNC=1: plain hipStreamSynchronize).
+static hipError_t streamSync(ygpu_ctx *ctx)
+{
+    static const bool spin = getenv("YGPU_SPIN_SYNC") != nullptr;
+    if (spin || !ctx->evSync) return hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipEventRecord(ctx->evSync, ctx->stream);
+    return e != hipSuccess ? e : hipEventSynchronize(ctx->evSync);
+}
+
 static int fetchU32(ygpu_ctx *ctx, const void *dptr, uint32_t *out, size_t n = 1)
-{ HIPCHK(hipMemcpyAsync(out, dptr, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
+{ HIPCHK(hipMemcpyAsync(out, dptr, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx)); return 0; }
 
 // ---- A1 + A2 (+ fragment array) --------------------------------------------------------------------------------
 static int stageSeed(ygpu_ctx *ctx)
@@ -397,7 +407,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         if (ctx->traceBudgetBlocks > 0) perRange = std::min(perRange, (double)ctx->traceBudgetBlocks);
         nChunksArena = (unsigned long long)std::min((double)budgetChunks, perRange * ctx->traceRatio / chunkBlocks + slackChunks);
         ctx->hStripOff.resize(nProb + 1);
-        HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
         uint32_t r0 = 0;
         while (r0 < NC) {
             uint32_t lo = r0 + 1, hi = NC;                                    // largest r1 with bound(r0 .. r1) <= perRange (at least one root)
@@ -465,7 +475,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         TRACE("lanes: ext_rows");
         if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], ctx->stream); }
         if (kTrace && getenv("YGPU_TRACE_LENS")) {                            // diagnostics: the walks of the traceback, per problem and per wave of 64 in k_ext_rows' order
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(streamSync(ctx));
             std::vector<ExtRes> hr(np); std::vector<uint32_t> ho(np);
             hipMemcpy(hr.data(), E.res, sizeof(ExtRes) * (size_t)np, hipMemcpyDeviceToHost); hipMemcpy(ho.data(), E.order, 4ull * np, hipMemcpyDeviceToHost);
             unsigned long long walkers = 0, sumLen = 0, sumWaveMax = 0, sumRows = 0, hist[8] = {0}; std::vector<uint32_t> lens; lens.reserve(np);
@@ -509,7 +519,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         unsigned int used[2] = {0, 0}; uint32_t three[3] = {0, 0, 0};       // slow roots, predicted problems
         HIPCHK(hipMemcpyAsync(used, ctx->traceCnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         if (ctx->splitLanes) HIPCHK(hipMemcpyAsync(three, cc + 8 * c + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(streamSync(ctx));
         usedChunksMax = std::max<unsigned long long>(usedChunksMax, used[0]);
         if (ctx->splitLanes) {
             // splitClump in lanes: the careful extensions the split roots will ask for go through a second k_ext_rows / k_ext_trace round
@@ -541,7 +551,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                 Sx.fallList = ctx->fallList.as<uint32_t>(); Sx.fallCount = cc + 8 * c + 5; Sx.nSlots = nSlow;
                 KL(k_split_lanes, dim3(gridFor(nSlow, 64)), dim3(64), 0, ctx->stream, Ac, Xc, Sx);
                 Xw.slowList = ctx->fallList.as<uint32_t>(); Xw.slowCount = cc + 8 * c + 5;
-                if (kTrace) { uint32_t fc = 0; HIPCHK(hipMemcpyAsync(&fc, cc + 8 * c + 5, 4, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gFallWhy), sizeof w8); fprintf(stderr, "[ygpu] roots left to the wave kernel %u (other %u, DP not listed %u, second split %u, depth/list %u)\n", fc, w8[0], w8[1], w8[2], w8[3]); memset(w8, 0, sizeof w8); hipMemcpyToSymbol(HIP_SYMBOL(gFallWhy), w8, sizeof w8); }
+                if (kTrace) { uint32_t fc = 0; HIPCHK(hipMemcpyAsync(&fc, cc + 8 * c + 5, 4, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx)); unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gFallWhy), sizeof w8); fprintf(stderr, "[ygpu] roots left to the wave kernel %u (other %u, DP not listed %u, second split %u, depth/list %u)\n", fc, w8[0], w8[1], w8[2], w8[3]); memset(w8, 0, sizeof w8); hipMemcpyToSymbol(HIP_SYMBOL(gFallWhy), w8, sizeof w8); }
             }
         }
         KL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, ctx->stream, Ac, Xw);
@@ -617,7 +627,7 @@ static int stageAlign(ygpu_ctx *ctx)
             if (!useLanes) KL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
             else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, gapOpsPerJoint); if (rc == -2) laneOverflow = true; else if (rc == -3) traceOverflow = true; else if (rc) return rc; }
 #ifdef YD_PROF
-            { hipStreamSynchronize(ctx->stream); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
+            { streamSync(ctx); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
               const char *nm[10] = {"root_total", "dp_rows", "traceback", "perfect_ext", "score", "emit", "split", "merge", "dp_calls", "roots"};
               fprintf(stderr, "[YD_PROF] waves %u:", waves); for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", nm[i], z[i]); fprintf(stderr, "\n"); }
 #endif
@@ -655,7 +665,7 @@ static int runTo(ygpu_ctx *ctx, int stage)
     if (ctx->stageDone < 1) { rc = stageSeed(ctx); if (rc) return rc; EV0(T_FRAGS); rc = buildFrags(ctx); if (rc) return rc; if (!ctx->nFrags) EV1(T_FRAGS); ctx->stageDone = 1; }
     if (stage >= 2 && ctx->stageDone < 2) { if (ctx->nFrags) { rc = stageChain(ctx); if (rc) return rc; } ctx->stageDone = 2; }
     if (stage >= 3 && ctx->stageDone < 3) { rc = stageAlign(ctx); if (rc) return rc; ctx->stageDone = 3; }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(streamSync(ctx));
     return 0;
 }
 
@@ -675,6 +685,7 @@ static int initCommon(ygpu_ctx *ctx, int device)
     gCtxPerDevice[device & 63]++; ctx->counted = true;
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
+    if (hipEventCreateWithFlags(&ctx->evSync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { ctx->evSync = nullptr; (void)hipGetLastError(); }
     return 0;
 }
 
@@ -706,7 +717,7 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     HIPCHK(hipMemcpyAsync(ctx->dSO.p, ix->startingOffs, 4 * (HT + 1), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->dROA.p, ix->ROA, 4ull * ix->totalMatches, hipMemcpyHostToDevice, ctx->stream));
     ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(streamSync(ctx));
     return 0;
 }
 
@@ -723,7 +734,7 @@ int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
     ctx->dBases.p = parent->dBases.p; ctx->dBases.cap = parent->dBases.cap; ctx->dSO.p = parent->dSO.p; ctx->dSO.cap = parent->dSO.cap; ctx->dROA.p = parent->dROA.p; ctx->dROA.cap = parent->dROA.cap;
     ctx->sharedIndex = true;
     ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(streamSync(ctx));
     return 0;
 }
 
@@ -741,6 +752,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
                          &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
+        if (ctx->evSync) hipEventDestroy(ctx->evSync);
         for (int i = 0; i < YD_MAX_CHUNK_EV; i++) hipEventDestroy(ctx->evChunk[i]);
         hipEventDestroy(ctx->evTail); hipStreamDestroy(ctx->stream2);
         hipStreamDestroy(ctx->stream);
@@ -775,7 +787,7 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
         HIPCHK(hipMemcpyAsync(ctx->dKmerOff.p, ctx->hKmerOff.data(), 4ull * (2 * n + 1), hipMemcpyHostToDevice, ctx->stream));
         KL(k_revcomp, dim3(n), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->dReadOff.as<uint32_t>(), n);
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(streamSync(ctx));
     return 0;
 }
 
@@ -806,7 +818,7 @@ int ygpu_collect(ygpu_ctx *ctx, ygpu_result_batch *out)
     if (ctx->nOut) HIPCHK(hipMemcpyAsync(ctx->hClumps.data(), ctx->outClumps2.p, sizeof(ygpu_clump) * (uint64_t)ctx->nOut, hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->nOutOps) HIPCHK(hipMemcpyAsync(ctx->hOps.data(), ctx->outOps.p, 4ull * ctx->nOutOps, hipMemcpyDeviceToHost, ctx->stream));
     DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(streamSync(ctx));
     dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags; dc.v[C_REGIONS] = ctx->nRegions;
     memcpy(&ctx->hCounters, dc.v, sizeof(ygpu_counters));
     out->n_reads = n; out->clump_start = ctx->hClumpStart.data(); out->clumps = ctx->hClumps.data(); out->ops = ctx->hOps.data();
@@ -967,7 +979,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         if (mult >= 1024) { ctx->err = "extension trace arena overflows"; return YGPU_ENOMEM; }
         HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->chunkCnt.p, 0, 64, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->extRes.p, 0, sizeof(ExtRes) * (uint64_t)nX, ctx->stream));
         }
-        HIPCHK(hipMemcpyAsync(hres.data(), ctx->extRes.p, sizeof(ExtRes) * (uint64_t)nX, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpyAsync(hres.data(), ctx->extRes.p, sizeof(ExtRes) * (uint64_t)nX, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
         for (uint32_t k = 0; k < nX; k++) xOff[k + 1] = xOff[k] + (hres[k].score > 0 ? hres[k].nOps : 0u);
     }
     if (nJ) {
@@ -999,7 +1011,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_wave, dim3(waves), dim3(64), 0, ctx->stream, A, X);
-        HIPCHK(hipMemcpyAsync(hj.data(), ctx->joints.p, sizeof(JointRec) * (uint64_t)nJ, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpyAsync(hj.data(), ctx->joints.p, sizeof(JointRec) * (uint64_t)nJ, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
         for (uint32_t k = 0; k < nJ; k++) jOff[k + 1] = jOff[k] + hj[k].nOps;
     }
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
@@ -1012,13 +1024,13 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         HIPCHK(hipMemcpyAsync(dOff, xOff.data(), 4ull * nX, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipMemcpyAsync(dDst, xdst.data(), 4ull * nX, hipMemcpyHostToDevice, ctx->stream));
         KL(k_dp_gather_ext, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, ctx->extProbs.as<ExtProb>(), ctx->extRes.as<ExtRes>(), ctx->extTrace.as<uint32_t>(), dOff, dDst, nX,
            ctx->dpRes.as<ygpu_dp_result>(), ctx->dpOps.as<uint32_t>());
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(streamSync(ctx));
     }
     if (nJ) {
         HIPCHK(hipMemcpyAsync(dOff, jOff.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipMemcpyAsync(dDst, jdst.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream));
         KL(k_dp_gather_gap, dim3(gridFor(nJ, 256)), dim3(256), 0, ctx->stream, ctx->P, ctx->dBases.as<uint8_t>(), ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->joints.as<JointRec>(), ctx->gapOps.as<uint32_t>(), dOff, dDst, nJ,
            ctx->dpRes.as<ygpu_dp_result>(), ctx->dpOps.as<uint32_t>());
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(streamSync(ctx));
     }
     ctx->hDpRes.resize(n); ctx->hDpOps.resize(tot);
     if (n) HIPCHK(hipMemcpy(ctx->hDpRes.data(), ctx->dpRes.p, sizeof(ygpu_dp_result) * (uint64_t)n, hipMemcpyDeviceToHost));
