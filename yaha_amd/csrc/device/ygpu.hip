@@ -89,7 +89,7 @@ struct ygpu_ctx {
     // asynchronous tickets (ygpu_submit / ygpu_wait): one worker thread per context, started on first use
     std::thread worker; std::mutex aMu; std::condition_variable aCv; const ygpu_read_batch *aBatch = nullptr; uint64_t aTicket = 0; int aRc = 0; bool aOpen = false, aDone = false, aQuit = false; ygpu_result_batch aOut{};
     // timing
-    hipEvent_t evSync = nullptr; hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N]; bool rowsPacked = false;
+    long long lastFall = -1; unsigned int hFall = 0; hipEvent_t evSync = nullptr; hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N]; bool rowsPacked = false;
 };
 
 static DevBatch devBatch(ygpu_ctx *c) { DevBatch b; b.fwd = c->dFwd.as<uint8_t>(); b.rev = c->dRev.as<uint8_t>(); b.readOff = c->dReadOff.as<uint32_t>(); b.nReads = c->nReads; return b; }
@@ -554,7 +554,13 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                 if (kTrace) { uint32_t fc = 0; HIPCHK(hipMemcpyAsync(&fc, cc + 8 * c + 5, 4, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx)); unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gFallWhy), sizeof w8); fprintf(stderr, "[ygpu] roots left to the wave kernel %u (other %u, DP not listed %u, second split %u, depth/list %u)\n", fc, w8[0], w8[1], w8[2], w8[3]); memset(w8, 0, sizeof w8); hipMemcpyToSymbol(HIP_SYMBOL(gFallWhy), w8, sizeof w8); }
             }
         }
-        KL(k_align_p3, dim3(std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u))), dim3(64), 0, ctx->stream, Ac, Xw);
+        {   // the wave-per-root kernel takes what the lane kernels hand back: nothing at all on ordinary batches, and 1 024 waves that only find an empty list cost
+            // 0.3 ms -- so its grid follows what the last batch handed back (all split roots when k_split_lanes is off)
+            unsigned p3Waves = std::min<unsigned>(waves, std::max<unsigned>(64u, (r1 - r0) / 8u));
+            if (ctx->splitLanes && ctx->lastFall >= 0) p3Waves = std::min<unsigned>(p3Waves, std::max<unsigned>(64u, (unsigned)std::min<long long>(1ll << 20, 2ll * ctx->lastFall)));
+            KL(k_align_p3, dim3(p3Waves), dim3(64), 0, ctx->stream, Ac, Xw);
+            if (ctx->splitLanes && c + 1 == nRanges) HIPCHK(hipMemcpyAsync(&ctx->hFall, Xw.slowCount, 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         if (c + 1 == nRanges) hipEventRecord(ctx->ev[T_P3][1], ctx->stream);
         TRACE("lanes: p3");
     }
@@ -562,6 +568,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     // errors of the trace memory: grow what overflowed and have the caller redo the stage
     unsigned int usedOps = 0; HIPCHK(hipMemcpyAsync(&usedOps, ctx->traceCnt.as<unsigned int>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
     rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+    if (ctx->splitLanes) ctx->lastFall = (long long)ctx->hFall;              // (the fetch above synchronised the stream)
     if (ef == YERR_TRACEMEM) {
         if (ctx->traceRatio >= 64.0) { ctx->err = "the extension trace arena overflows even at 64 times the problems' bound"; return YGPU_ENOMEM; }
         ctx->traceRatio = std::min(64.0, ctx->traceRatio * 2.0); return -3;
