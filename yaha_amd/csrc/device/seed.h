@@ -19,12 +19,12 @@ __global__ void k_revcomp(const uint8_t *fwd, uint8_t *rev, const uint32_t *read
 
 // A1: one workgroup per (read, strand); thread per k-mer start.  posS/posC are indexed by kmerOff[rs] + i.
 __global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const uint32_t *ROA, const uint32_t *kmerOff,
-                              uint32_t *posS, uint32_t *posC, uint32_t *posRsI, DevCounters *ctr)
+                              uint32_t *posS, uint32_t *posC, uint32_t *posRsI, unsigned int *parts)
 {
     const uint32_t rs = blockIdx.x; const uint32_t read = rs >> 1;
     const uint32_t o = B.readOff[read]; const int qlen = (int)(B.readOff[read + 1] - o);
     const int L = P.wordLen, nPos = qlen - L + 1;
-    if (nPos <= 0) return;
+    if (nPos <= 0) return;                                                        // (block-uniform)
     const uint8_t *codes = ((rs & 1u) ? B.rev : B.fwd) + o;
     const uint32_t base = kmerOff[rs];
     unsigned lookups = 0;
@@ -45,7 +45,26 @@ __global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const
         }
         posS[base + i] = s; posC[base + i] = cnt; posRsI[base + i] = (rs << 15) | (uint32_t)i;
     }
-    if (lookups) atomicAdd(&ctr->v[C_KMER], (unsigned long long)lookups);
+    // the work counter: one atomic per workgroup, spread over 1 024 words that k_sum_parts adds up (a single L2 word takes ~88 atomics per microsecond; one
+    // per wave on the counter itself was most of this kernel's time on short reads: 262 k waves for 65 536 x 100 bp)
+    __shared__ unsigned sLook;
+    if (threadIdx.x == 0) sLook = 0;
+    __syncthreads();
+    lookups = (unsigned)waveSumI((int)lookups);
+    if ((threadIdx.x & 63u) == 0 && lookups) atomicAdd(&sLook, lookups);
+    __syncthreads();
+    if (threadIdx.x == 0 && sLook) atomicAdd(&parts[blockIdx.x & 1023u], sLook);
+}
+// counter += sum of its 1 024 partial sums (one workgroup of 1 024 threads)
+__global__ void __launch_bounds__(1024) k_sum_parts(const unsigned int *parts, unsigned long long *counter)
+{
+    __shared__ unsigned long long sSum;
+    if (threadIdx.x == 0) sSum = 0;
+    __syncthreads();
+    unsigned v = (unsigned)waveSumI((int)parts[threadIdx.x]);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&sSum, (unsigned long long)v);
+    __syncthreads();
+    if (threadIdx.x == 0 && sSum) atomicAdd(counter, sSum);
 }
 
 // A2a: thread per hit -> 64-bit key  rs(17) | diag(32) | qo(15).  A block owns 1024 consecutive hits; they belong to at most
