@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) * 0x10001u; }
 
 template <bool SECOND>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ext_rows_pk(ExtArgs A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ext_rows_pk(ExtArgs A)
 {
     __shared__ uint32_t sBlk[256 * YD_LDS_STRIDE];   // per lane: the current block of eight 16-byte records, lane stride 33
     if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());
@@ -70,17 +70,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 
     uint32_t NEGKv = NEGK, MSv = MSp, ONEv = ONEp, C15v = 0x000F000Fu;      // operands of the inline-assembly instructions: kept in VGPRs (copied from SGPRs at every use otherwise)
     asm volatile("" : "+v"(NEGKv), "+v"(MSv), "+v"(ONEv), "+v"(C15v));
-    uint32_t PV[YD_NP], PF[YD_NP], rc[YD_NP], carryE = LWp, nbByte = 0, nbOdd = 2u;
+    uint32_t PV[YD_NP], PF[YD_NP], rc[YD_NP], carryE = LWp, nbNext = 15u;
     int p = -1, i = 0, qLen = 0, maxScore = YD_LWORST, maxi = 0, maxj = 0, qcNext = 0, qcPrev = 0, rvLo = YD_LWORST, rjLo = 0;
-    // running addresses of the two byte streams: query index qi (stepped by qStep inside [qLo, qHi]) and reference offset rCur (stepped by rStep while rLeft > 0)
-    int qi = 0, qStep = 0, qLo = 0, qHi = 0, rStep = 0, rLeft = 0; uint32_t rCur = 0; bool done = false;
+    // The two input streams -- a query code and a reference nibble per iteration -- come through per-lane WINDOWS: 64-bit shift registers of the next codes /
+    // nibbles in the order the lane consumes them (low end first), refilled with whole aligned dwords: 4 codes every 4th iteration, 8 nibbles every 8th (the
+    // iterations are the wave's: (wslot & 3) == 0 and wslot == 0).  A byte load per lane and iteration made every lane's stream a line of its own in L1 and
+    // L2, 196-262 k lines that evict each other: 61 GB of fetches per launch for 2 GB of input.  qHave / rHave = buffered entries, qNext / rNext = index
+    // (inside the extension) of the first one not buffered; after the pool's first fill (a partial dword + a full one) the buffered end is dword-aligned, so
+    // every refill is one full dword.  Nothing outside the extension's own range is ever addressed (a dword is loaded only if it holds an entry of the range).
+    uint32_t qwLo = 0, qwHi = 0, rwLo = 0, rwHi = 0, qLd = 0, rLd = 0, rOffP = 0, qSel = 0x03020100u;
+    int qHave = 0, rHave = 0, qNext = 0, rNext = 0, rLenP = 0, qStep = 0, rLeft = 0; bool pendQ = false, pendR = false, done = false;
+    bool insQ = false, insR = false;                                         // wave-uniform: the previous pass ran the query / reference refill
     YD_GLOBAL const uint8_t *q = toGlobal(A.fwd);
     unsigned calls = 0, rows = 0, cells = 0;
 #pragma unroll
     for (int k = 0; k < YD_NP; k++) { PV[k] = LWp; PF[k] = LWp; rc[k] = 0x7FFF7FFFu; }
 
     int poolCount = 0, poolNext = 0; bool exhausted = false;
-    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0;
+    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0, eQwLo = 0, eQwHi = 0, eRwLo = 0, eRwHi = 0, eHave = 0;
     bool pendFlush = false; int pendRes = -1; unsigned pStart = 0;      // pendRes: the problem whose result this lane stores in its next pass (its state stays untouched until then)
     int wslot = 0; unsigned flush = 0; bool dirty = false, justDone = false;
     YD_GLOBAL uint32_t *chunkPtr = toGlobal(A.trace); bool noMem = false;
@@ -117,11 +124,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         // further down would also wait for the stores issued in between).  Slide the reference window: pair k takes pair k+1; pair 10's low half takes what
         // was pair 1's high half, its high half the new base.  (A lane that starts a problem below overwrites the window.)
         {
-            const uint32_t nb = nbOdd == 2u ? 15u : (nbOdd ? (nbByte & 15u) : (nbByte >> 4));
 #pragma unroll
             for (int k = 0; k + 1 < YD_NP; k++) rc[k] = rc[k + 1];
-            rc[YD_NP - 1] = (rc[0] >> 16) | ((nb | YD_RCREAL) << 16);
-            asm volatile("" : "+v"(qcNext));
+            rc[YD_NP - 1] = (rc[0] >> 16) | ((nbNext | YD_RCREAL) << 16);
+        }
+        // the dwords the previous pass loaded go to the ends of the windows (entries in consumption order: a reverse extension's bytes, and its nibbles, swapped)
+        if (insQ) {
+            if (pendQ) {
+                const uint32_t v = __builtin_amdgcn_perm(0u, qLd, qSel);
+                const unsigned long long t = (unsigned long long)v << (8 * (qHave & 7));
+                qwLo |= (uint32_t)t; qwHi |= (uint32_t)(t >> 32); qHave += 4; qNext += 4;
+            }
+            insQ = false;
+        }
+        if (insR) {
+            if (pendR) {
+                const uint32_t sw = ((rLd & 0x0F0F0F0Fu) << 4) | ((rLd >> 4) & 0x0F0F0F0Fu);      // forward: the even offset (high nibble) first
+                const uint32_t v = qStep < 0 ? __builtin_amdgcn_perm(0u, rLd, 0x00010203u) : sw;   // reverse: bytes swapped, each byte's low nibble (the higher offset) first
+                const unsigned long long t = (unsigned long long)v << (4 * (rHave & 15));
+                rwLo |= (uint32_t)t; rwHi |= (uint32_t)(t >> 32); rHave += 8; rNext += 8;
+            }
+            insR = false;
         }
         // the blocks the previous iteration completed: their place is fixed now (a problem that starts below notes the flush ITS first block will go out
         // with), the stores themselves are issued after this iteration's loads (program order = the order the memory counter retires in)
@@ -163,6 +186,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                             const uint32_t sh = (uint32_t)(c & 7) * 4u;
                             if (c < 16) eW1 |= nib << sh; else eW2 |= nib << sh;
                         }
+                        // first fill of the stream windows: query codes from index 1 (index 0 is in eMisc), reference nibbles from index 11 (0..10 are in eW1/eW2);
+                        // a partial aligned dword, then a full one -- each only if it holds an entry of the extension
+                        uint32_t qh = 0, rh = 0; eQwLo = eQwHi = eRwLo = eRwHi = 0;
+                        {
+                            const size_t a1 = (size_t)(qp + (rv_ ? -1 : 1)); const uint32_t lo2 = (uint32_t)(a1 & 3u), c1 = rv_ ? lo2 + 1u : 4u - lo2;
+                            YD_GLOBAL const uint32_t *d1 = (YD_GLOBAL const uint32_t *)(a1 - lo2);
+                            uint32_t v1 = 0, v2 = 0;
+                            if (ql >= 2) { const uint32_t w = *d1; v1 = rv_ ? __builtin_amdgcn_perm(0u, w, 0x00010203u) >> (8u * (3u - lo2)) : w >> (8u * lo2); qh = c1; }
+                            if (ql > (int)(1u + c1)) { const uint32_t w = rv_ ? d1[-1] : d1[1]; v2 = rv_ ? __builtin_amdgcn_perm(0u, w, 0x00010203u) : w; qh = c1 + 4u; }
+                            const unsigned long long t = (unsigned long long)v1 | ((unsigned long long)v2 << (8u * c1));
+                            eQwLo = (uint32_t)t; eQwHi = (uint32_t)(t >> 32);
+                        }
+                        {
+                            const uint32_t n11 = rv_ ? pr.rOff - 11u : pr.rOff + 11u, lo3 = n11 & 7u, c1 = rv_ ? lo3 + 1u : 8u - lo3;
+                            uint32_t v1 = 0, v2 = 0;
+                            if (rl > 11u) {
+                                YD_GLOBAL const uint32_t *d1 = (YD_GLOBAL const uint32_t *)(gBases + ((n11 >> 1) & ~3u));
+                                const uint32_t w = *d1;
+                                v1 = rv_ ? __builtin_amdgcn_perm(0u, w, 0x00010203u) >> (4u * (7u - lo3)) : (((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu)) >> (4u * lo3);
+                                rh = c1;
+                                if (rl > 11u + c1) { const uint32_t w2 = rv_ ? d1[-1] : d1[1]; v2 = rv_ ? __builtin_amdgcn_perm(0u, w2, 0x00010203u) : (((w2 & 0x0F0F0F0Fu) << 4) | ((w2 >> 4) & 0x0F0F0F0Fu)); rh = c1 + 8u; }
+                            }
+                            const unsigned long long t = (unsigned long long)v1 | (c1 < 16u ? ((unsigned long long)v2 << (4u * c1)) : 0ull);
+                            eRwLo = (uint32_t)t; eRwHi = (uint32_t)(t >> 32);
+                        }
+                        eHave = qh | (rh << 8);
                     }
                 }
             }
@@ -173,6 +222,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
             const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64);
             const uint32_t gPidx = (uint32_t)__shfl((int)ePidx, src, 64);
+            const uint32_t gQwLo = (uint32_t)__shfl((int)eQwLo, src, 64), gQwHi = (uint32_t)__shfl((int)eQwHi, src, 64), gRwLo = (uint32_t)__shfl((int)eRwLo, src, 64), gRwHi = (uint32_t)__shfl((int)eRwHi, src, 64);
+            const uint32_t gHave = (uint32_t)__shfl((int)eHave, src, 64);
             const bool init = take && gLens != 0u;
             // A fresh problem: low halves = row 0 of columns 0..10 (the origin (0, 10): V = 0, F = -GO; sentinel left of it), high halves = the sentinel
             // ("row -1"; the first iteration turns it into row 0 of columns 11..20).  Reference codes: low halves of pairs 0..9 lie left of the matrix in
@@ -187,10 +238,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (init) {
                 p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0; carryE = LWp; rvLo = YD_LWORST; rjLo = 0;
                 const bool rev = (gMisc & XP_REV) != 0;
-                q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qi = 0; qLo = rev ? 1 - qLen : 0; qHi = rev ? 0 : qLen - 1;
+                q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qSel = rev ? 0x00010203u : 0x03020100u;
                 qcNext = (int)((gMisc >> 8) & 0xFFu); qcPrev = 0;
-                // iteration i loads reference index i + 10 (valid while below rLen): rCur starts at index 10
-                rStep = qStep; rCur = rev ? gROff - (uint32_t)bandwidth : gROff + (uint32_t)bandwidth; rLeft = (int)(gLens >> 16) - bandwidth;
+                qwLo = gQwLo; qwHi = gQwHi; qHave = (int)(gHave & 0xFFu); qNext = 1 + qHave; pendQ = false;
+                // iteration i takes reference index i + 10 from the window (valid while below rLen)
+                rOffP = gROff; rLenP = (int)(gLens >> 16); rLeft = rLenP - bandwidth;
+                rwLo = gRwLo; rwHi = gRwHi; rHave = (int)(gHave >> 8); rNext = 11 + rHave; pendR = false;
                 pStart = (flush << 4) | (unsigned)wslot;
             }
             poolNext += nNeed < avail ? nNeed : avail;
@@ -202,9 +255,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         const bool busy = p >= 0;
         ++i;
         const int qc = qcNext;
-        { int t = qi + qStep; t = t < qLo ? qLo : t; qi = t > qHi ? qHi : t; qcNext = (int)q[qi]; }   // next iteration's query base (index i * qStep, held inside the extension)
-        { rCur += (uint32_t)rStep; rLeft--; const bool in = rLeft > 0; const uint32_t off = in ? rCur : 0u;   // the reference base that enters the window (index i + 10)
-          nbByte = gBases[off >> 1]; nbOdd = in ? (off & 1u) : 2u; }
+        // next iteration's query code (index i) and the reference nibble that enters the window (index i + 10; 15 beyond the reference): off the windows' low ends
+        qcNext = (int)(qwLo & 0xFFu); qwLo = __builtin_amdgcn_alignbit(qwHi, qwLo, 8); qwHi >>= 8; qHave--;
+        { rLeft--; nbNext = rLeft > 0 ? (rwLo & 15u) : 15u; rwLo = __builtin_amdgcn_alignbit(rwHi, rwLo, 4); rwHi >>= 4; rHave--; }
+        // refills (wave-uniform schedule): the loads are consumed at the top of the next pass
+        if ((wslot & 3) == 0) {
+            pendQ = qHave <= 4 && qNext < qLen;
+            if (pendQ) { const int k = qStep < 0 ? -qNext - 3 : qNext; qLd = *(YD_GLOBAL const uint32_t *)(q + k); }      // (q + qNext * qStep is dword-aligned going up, the last byte of a dword going down)
+            insQ = true;
+        }
+        if (wslot == 0) {
+            pendR = rHave <= 8 && rNext < rLenP;
+            if (pendR) { const uint32_t n = qStep < 0 ? rOffP - (uint32_t)rNext - 7u : rOffP + (uint32_t)rNext; rLd = *(YD_GLOBAL const uint32_t *)(gBases + (n >> 1)); }
+            insR = true;
+        }
         // the iteration's stores, behind its loads: a finished problem's result and the blocks that leave
         if (pendRes >= 0) {
             // the problem ended in the previous pass at row i - 2 (i has been stepped since; the lane sat out the refill above, so maxScore / maxi / maxj / pStart
