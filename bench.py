@@ -327,7 +327,7 @@ def main():
     out = {
         "metric": "aligned reads/s (whole node), 1 000 bp reads, OQC mode hot path", "value": value, "unit": "reads/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("int16" if packed else "int32"), "dtype_note": "integer dynamic programming, bit-exact: the X-drop extension rows (93 % of the DP cells) in saturating packed int16 when the scores fit (else int32), everything else int32", "data": "synthetic",
         "bases_per_s": value * Lq,
         "config": {"workload": "BASELINE config 2 shape: synthetic hg18-like genome %d Mbp (24 seqs, 45%% repeats), index -L 15 -S 1 -H 65525, %d x %d bp reads per GPU at %.1f%% divergence, defaults -BW 5 -G 50 -H 650 -M 25 -X 25, hot path A1..A10 with inputs resident in HBM"
                    % (args.genome_mbp, n_reads, args.read_len, 100 * args.div),
