@@ -25,7 +25,8 @@
 #pragma once
 #include "ext_lanes.h"
 
-struct RootState { Frame f; uint32_t listOff; int backLen, forwLen; };
+// a root after phase 1, 32 bytes (two to the 64-byte sector; it used to be a whole 100-byte Frame, of which the phase-3 kernels read these fields)
+struct RootState { uint32_t sro, listOff; int32_t score; uint16_t sqo, eqo, refLen, len; uint8_t status, pad[3]; uint32_t pad2[2]; };
 enum { JK_NONE = 0, JK_D, JK_I, JK_R, JK_DIAG, JK_DP };
 struct JointRec {                                           // 32 B
     uint32_t nsro, qBase; uint16_t nsqo, qGap, rGap; uint8_t kind, flags;   // flags: bit0 strand, bit1 banded
@@ -453,8 +454,8 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
             ops[nOut] = opMake(pc, pl); nOut++;
             if (nOut > 1 && firstAdd) ops[0] = opMake(opCode(ops[0]), (opLen(ops[0]) + firstAdd) & 0xFFFF);
             RootState s; memset(&s, 0, sizeof s);
-            s.f.sro = sro; s.f.sqo = sqo; s.f.eqo = eqo; s.f.refLen = refLen; s.f.score = score; s.f.status = (rec.rs & 1u) ? stReversed : 0; s.f.phase = PH_NONE; s.f.start = A.front; s.f.len = nOut;
-            s.listOff = slot; s.backLen = backLen; s.forwLen = forwLen;
+            s.sro = sro; s.sqo = (uint16_t)sqo; s.eqo = (uint16_t)eqo; s.refLen = (uint16_t)refLen; s.score = score; s.status = (rec.rs & 1u) ? stReversed : 0; s.len = (uint16_t)nOut;
+            s.listOff = slot;
             X.state[r] = s;
             const uint32_t strand = (rec.rs & 1u) ? XP_STRAND : 0u; const bool vb = backLen >= P.minExtLength, vf = forwLen >= P.minExtLength;
             ExtProb pb; pb.qBase = r0; pb.rOff = sro - 1u; pb.qOff = (uint16_t)((sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF); pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
@@ -585,9 +586,9 @@ struct P3Root { MergedOps L; uint32_t sro; int sqo, eqo, refLen, status, score; 
 __device__ __forceinline__ P3Root p3Merged(const PhaseArgs &X, uint32_t r)
 {
     P3Root o; MergedOps &L = o.L; L.a = L.b = L.c = nullptr; L.na = L.nb = L.nc = L.jab = L.jbc = 0;
-    const RootState *S = X.state + r;
-    o.sro = S->f.sro; o.sqo = S->f.sqo; o.eqo = S->f.eqo; o.refLen = S->f.refLen; o.status = S->f.status; o.score = S->f.score;
-    L.b = X.stateOps + S->listOff; L.nb = S->f.len;
+    const RootState S = X.state[r];
+    o.sro = S.sro; o.sqo = S.sqo; o.eqo = S.eqo; o.refLen = S.refLen; o.status = S.status; o.score = S.score;
+    L.b = X.stateOps + S.listOff; L.nb = S.len;
     const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
     if (rb.score > 0) {                                                  // AlignExtFrag.cpp:112-125
         const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
@@ -718,8 +719,9 @@ __global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
             const unsigned r = X.useList ? uniU(X.slowList[ri]) : ri;
             const ChainClumpRec rec = A.clumps[A.order[r]];
             al.setRead(rec); al.rootRank = r; al.pushes = 0;
-            Frame f = X.state[r].f; const uint32_t listOff = uniU(X.state[r].listOff);
-            f.start = uni(f.start); f.len = uni(f.len);
+            const RootState S0 = X.state[r]; const uint32_t listOff = uniU(S0.listOff);
+            Frame f; memset(&f, 0, sizeof f); f.sro = S0.sro; f.sqo = S0.sqo; f.eqo = S0.eqo; f.refLen = S0.refLen; f.score = S0.score; f.status = S0.status; f.phase = PH_NONE;
+            f.start = A.front; f.len = uni((int)S0.len);
             uint32_t *b = al.buf(0);
             for (int k = lane; k < f.len; k += 64) b[f.start + k] = X.stateOps[listOff + k];
             __threadfence_block();

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
         YD_GLOBAL const uint8_t *q = toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0; YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
         // ---- the root as k_p3_lanes saw it: phase-1 list + the two extension results --------------------------------------------
-        SFrame f; { const RootState *S = X.state + r; f.sro = S->f.sro; f.sqo = S->f.sqo; f.eqo = S->f.eqo; f.refLen = S->f.refLen; f.status = S->f.status; f.score = S->f.score; f.len = S->f.len; f.start = 0; f.phase = 0; }
+        SFrame f; { const RootState S = X.state[r]; f.sro = S.sro; f.sqo = S.sqo; f.eqo = S.eqo; f.refLen = S.refLen; f.status = S.status; f.score = S.score; f.len = S.len; f.start = 0; f.phase = 0; }
         MergedOps L; L.a = L.c = nullptr; L.na = L.nc = L.jab = L.jbc = 0; L.b = X.stateOps + X.state[r].listOff; L.nb = f.len;
         const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
         if (rb.score > 0) {
