@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, u
 {
     using Load = rocprim::block_load<unsigned long long, BS, IPT, rocprim::block_load_method::block_load_transpose>;
     using Store = rocprim::block_store<unsigned long long, BS, IPT, rocprim::block_store_method::block_store_transpose>;
-    using Sort = rocprim::block_radix_sort<unsigned long long, BS, IPT>;
+    using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t>;
     __shared__ union { typename Load::storage_type load; typename Store::storage_type store; typename Sort::storage_type sort; } st;
     const uint32_t b = segOff[blockIdx.x], len = segOff[blockIdx.x + 1] - b;
     if (len <= lo || len > hi) return;                                       // another launch's size class (or nothing to do)
@@ -27,8 +27,16 @@ __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, u
     // blocked arrangement = the order the hits were written in; the padding keys sort last and, the sort being stable, stay behind real keys with the same bits
     Load().load(in + b, keys, len, ~0ull, st.load);
     __syncthreads();
-    Sort().sort(keys, st.sort, 15, 47);
+    // what moves through the sort's LDS passes is the 32-bit diagonal with the 15-bit query offset as payload (6 bytes a hit instead of 8); the 17 (read, strand)
+    // bits are the segment's number
+    uint32_t dg[IPT]; uint16_t qo[IPT];
+#pragma unroll
+    for (unsigned k = 0; k < IPT; k++) { dg[k] = (uint32_t)(keys[k] >> 15); qo[k] = (uint16_t)(keys[k] & 0x7FFFull); }
+    Sort().sort(dg, qo, st.sort, 0, 32);
     __syncthreads();
+    const unsigned long long rs = (unsigned long long)blockIdx.x << 47;
+#pragma unroll
+    for (unsigned k = 0; k < IPT; k++) keys[k] = rs | ((unsigned long long)dg[k] << 15) | (unsigned long long)qo[k];
     Store().store(out + b, keys, len, st.store);
 }
 
