@@ -59,7 +59,7 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_SEGBIG, CNT_NB12, CNT_NB16, CNT_N = 24 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* five: the segments of the four workgroup-sort classes, the long ones */, CNT_N = CNT_SEGC + 5 + 3 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_XROWS_PK, T_N };
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
@@ -78,7 +78,7 @@ struct ygpu_ctx {
     DevBuf posS, posC, posRsI, hitOff, keysA, keysB, segOff, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
-    DevBuf kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
+    DevBuf segLists, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
     bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
@@ -169,19 +169,21 @@ static int stageSeed(ygpu_ctx *ctx)
             ENSURE(ctx->segOff, 4ull * (2 * n + 2));
             KL(k_seg_offsets, dim3(gridFor(2 * n + 1, 256)), dim3(256), 0, ctx->stream, ctx->dKmerOff.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), 2 * n, ctx->segOff.as<uint32_t>());
             if (ctx->segSort >= 2) {
-                // segments of up to 16 384 hits: one workgroup each (segsort.h), in four size classes; every launch covers all segments and a
-                // workgroup whose segment belongs to another class leaves at once
+                // segments of up to 16 384 hits: one workgroup each (segsort.h), in four size classes, one launch per class over exactly its segments
                 const unsigned long long *in = ctx->keysA.as<unsigned long long>(); unsigned long long *out = ctx->keysB.as<unsigned long long>(); const uint32_t *so = ctx->segOff.as<uint32_t>();
-                ENSURE(ctx->bigB, 4ull * (2 * n + 1)); ENSURE(ctx->bigE, 4ull * (2 * n + 1));
-                uint32_t *cntBig = ctx->counters.as<uint32_t>() + CNT_SEGBIG;
-                HIPCHK(hipMemsetAsync(cntBig, 0, 4, ctx->stream));
+                ENSURE(ctx->bigB, 4ull * (2 * n + 1)); ENSURE(ctx->bigE, 4ull * (2 * n + 1)); ENSURE(ctx->segLists, 16ull * (2 * n + 1));
+                uint32_t *segCnt = ctx->counters.as<uint32_t>() + CNT_SEGC;
+                HIPCHK(hipMemsetAsync(segCnt, 0, 20, ctx->stream));
                 const uint32_t mx = ctx->segSortMax;                                  // YD_SEGSORT_MAX; lower only to drive the long-segment path in tests
-                KL(k_seg_big, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, 2 * n, mx, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), cntBig);
-                if (mx > 8192u) KL((k_seg_sort<1024, 16>), dim3(2 * n), dim3(1024), 0, ctx->stream, in, out, so, 8192u, std::min(mx, 16384u));
-                if (mx > 4096u) KL((k_seg_sort<512, 16>), dim3(2 * n), dim3(512), 0, ctx->stream, in, out, so, 4096u, std::min(mx, 8192u));
-                if (mx > 1024u) KL((k_seg_sort<256, 16>), dim3(2 * n), dim3(256), 0, ctx->stream, in, out, so, 1024u, std::min(mx, 4096u));
-                KL((k_seg_sort<128, 8>), dim3(2 * n), dim3(128), 0, ctx->stream, in, out, so, 0u, std::min(mx, 1024u));
-                uint32_t nBig = 0; rc = fetchU32(ctx, cntBig, &nBig); if (rc) return rc;
+                uint32_t *lists = ctx->segLists.as<uint32_t>();
+                KL(k_seg_classify, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, 2 * n, std::min(mx, 1024u), std::min(mx, 4096u), std::min(mx, 8192u), std::min(mx, 16384u),
+                   lists, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), segCnt);
+                uint32_t nc[5] = {0, 0, 0, 0, 0}; rc = fetchU32(ctx, segCnt, nc, 5); if (rc) return rc;
+                if (nc[3]) KL((k_seg_sort<1024, 16>), dim3(nc[3]), dim3(1024), 0, ctx->stream, in, out, so, lists + 3ull * (2 * n));
+                if (nc[2]) KL((k_seg_sort<512, 16>), dim3(nc[2]), dim3(512), 0, ctx->stream, in, out, so, lists + 2ull * (2 * n));
+                if (nc[1]) KL((k_seg_sort<256, 16>), dim3(nc[1]), dim3(256), 0, ctx->stream, in, out, so, lists + 1ull * (2 * n));
+                if (nc[0]) KL((k_seg_sort<128, 8>), dim3(nc[0]), dim3(128), 0, ctx->stream, in, out, so, lists);
+                const uint32_t nBig = nc[4];
                 if (kTrace) { std::vector<uint32_t> so2(2 * (size_t)n + 1); hipMemcpy(so2.data(), so, 4ull * (2 * n + 1), hipMemcpyDeviceToHost); unsigned long long hb = 0, mxl = 0, c8 = 0, c4 = 0, c1 = 0, c0 = 0;
                     for (uint32_t k = 0; k < 2 * n; k++) { const unsigned long long l = so2[k + 1] - so2[k]; if (l > mx) { hb += l; mxl = std::max(mxl, l); } else if (l > 8192) c8 += l; else if (l > 4096) c4 += l; else if (l > 1024) c1 += l; else c0 += l; }
                     fprintf(stderr, "[ygpu] hit sort: %u hits; segments above %u hits: %u holding %llu hits (%.1f%%, longest %llu); classes 8k-16k %.1f%%, 4k-8k %.1f%%, 1k-4k %.1f%%, <=1k %.1f%%\n", H, mx, nBig, hb, 100.0 * hb / H, mxl, 100.0 * c8 / H, 100.0 * c4 / H, 100.0 * c1 / H, 100.0 * c0 / H); }
@@ -758,7 +760,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt};
+                         &ctx->segLists, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
