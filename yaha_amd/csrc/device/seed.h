@@ -108,28 +108,39 @@ __global__ void k_seg_offsets(const uint32_t *kmerOff, const uint32_t *hitOff, u
 
 // A2b: fragment heads.  A hit starts a new fragment when (read,strand) or diagonal changes or the k-mer neither overlaps
 // nor abuts the previous one (QueryMatch.c:99).
-__global__ void k_frag_heads(const unsigned long long *keys, uint32_t nHits, int wordLen, uint32_t *isHead)
+// head flag of hit t in the sorted key array: a new (read, strand, diagonal), or a query offset more than one word beyond the previous hit's
+// (QueryMatch.c:84-121).  t == nHits (the scan's extra element): 0.
+__device__ __forceinline__ uint32_t hitIsHead(const unsigned long long *keys, uint32_t t, uint32_t nHits, int wordLen)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nHits) return;
-    uint32_t head = 1;
-    if (t > 0) {
-        const unsigned long long a = keys[t - 1], b = keys[t];
-        if ((a >> 15) == (b >> 15)) { const uint32_t qa = (uint32_t)(a & 0x7FFFu), qb = (uint32_t)(b & 0x7FFFu); head = qb > qa + (uint32_t)wordLen; }
-    }
-    isHead[t] = head;
+    if (t >= nHits) return 0u;
+    if (t == 0) return 1u;
+    const unsigned long long a = keys[t - 1], b = keys[t];
+    if ((a >> 15) != (b >> 15)) return 1u;
+    return (uint32_t)(b & 0x7FFFu) > (uint32_t)(a & 0x7FFFu) + (uint32_t)wordLen ? 1u : 0u;
 }
-// A2c: one thread per hit; run starts write the fragment start, run ends write its end (QueryMatch.c:101-118)
-__global__ void k_frag_build(const unsigned long long *keys, const uint32_t *isHead, const uint32_t *fragIdx /* exclusive scan of isHead */,
+// the scan's input: the head flags computed from the keys on the fly (no flag array: 0.8 GB written and read twice for 200 M hits)
+struct HitHeadFlag {
+    const unsigned long long *keys; uint32_t nHits; int wordLen;
+    __host__ __device__ __forceinline__ uint32_t operator()(uint32_t t) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return hitIsHead(keys, t, nHits, wordLen);
+#else
+        (void)t; return 0u;
+#endif
+    }
+};
+__global__ void k_frag_build(const unsigned long long *keys, const uint32_t *fragIdx /* exclusive scan of the head flags */,
                              uint32_t nHits, int wordLen, DevFrag *frags)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nHits) return;
     const unsigned long long k = keys[t];
     const uint32_t qo = (uint32_t)(k & 0x7FFFu), diag = (uint32_t)(k >> 15), rs = (uint32_t)(k >> 47);
-    const uint32_t f = fragIdx[t] + isHead[t] - 1u;                               // index of the fragment this hit belongs to
-    if (isHead[t]) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
-    const bool last = (t + 1 == nHits) || isHead[t + 1];
+    const uint32_t head = hitIsHead(keys, t, nHits, wordLen);
+    const uint32_t f = fragIdx[t] + head - 1u;                                    // index of the fragment this hit belongs to
+    if (head) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
+    const bool last = (t + 1 == nHits) || hitIsHead(keys, t + 1, nHits, wordLen);
     if (last) frags[f].eqo = (uint16_t)(qo + (uint32_t)wordLen - 1u);
 }
 __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)

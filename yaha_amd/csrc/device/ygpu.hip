@@ -209,10 +209,14 @@ static int stageSeed(ygpu_ctx *ctx)
     }
     EV1(T_SORT);
     EV0(T_FRAGS);
-    ENSURE(ctx->isHead, 4ull * (H + 1)); ENSURE(ctx->scanOut, 4ull * (H + 1));
-    HIPCHK(hipMemsetAsync((uint32_t *)ctx->isHead.p + H, 0, 4, ctx->stream));
-    KL(k_frag_heads, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, ctx->isHead.as<uint32_t>());
-    rc = cubScan(ctx, ctx->isHead.as<uint32_t>(), ctx->scanOut.as<uint32_t>(), H + 1); if (rc) return rc;
+    ENSURE(ctx->scanOut, 4ull * (H + 1));
+    {   // fragment index of every hit = exclusive scan of the head flags, which the scan computes from the sorted keys as it reads them
+        hipcub::TransformInputIterator<uint32_t, HitHeadFlag, hipcub::CountingInputIterator<uint32_t>> flags(hipcub::CountingInputIterator<uint32_t>(0u), HitHeadFlag{ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen});
+        size_t bytes = 0;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags, ctx->scanOut.as<uint32_t>(), (int)(H + 1), ctx->stream));
+        if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp.p, bytes, flags, ctx->scanOut.as<uint32_t>(), (int)(H + 1), ctx->stream));
+    }
     uint32_t F = 0; rc = fetchU32(ctx, ctx->scanOut.as<uint32_t>() + H, &F); if (rc) return rc;
     ctx->nFrags = F;
     ENSURE(ctx->frags, 16ull * (F + 1));
@@ -222,7 +226,7 @@ static int buildFrags(ygpu_ctx *ctx)       // (re)creates the fragment array fro
 {
     const uint32_t H = ctx->nHits, F = ctx->nFrags;
     if (!H) return 0;
-    KL(k_frag_build, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), ctx->isHead.as<uint32_t>(), ctx->scanOut.as<uint32_t>(), H, ctx->P.wordLen, ctx->frags.as<DevFrag>());
+    KL(k_frag_build, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), ctx->scanOut.as<uint32_t>(), H, ctx->P.wordLen, ctx->frags.as<DevFrag>());
     KL(k_frag_finish, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F);
     return 0;
 }
