@@ -89,7 +89,7 @@ struct ygpu_ctx {
     // asynchronous tickets (ygpu_submit / ygpu_wait): one worker thread per context, started on first use
     std::thread worker; std::mutex aMu; std::condition_variable aCv; const ygpu_read_batch *aBatch = nullptr; uint64_t aTicket = 0; int aRc = 0; bool aOpen = false, aDone = false, aQuit = false; ygpu_result_batch aOut{};
     // timing
-    long long lastFall = -1; unsigned int hFall = 0; hipEvent_t evSync = nullptr; hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N]; bool rowsPacked = false;
+    long long lastFall = -1; unsigned int hFall = 0; uint32_t *pinned = nullptr; hipEvent_t evSync = nullptr; hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N]; bool rowsPacked = false;
 };
 
 static DevBatch devBatch(ygpu_ctx *c) { DevBatch b; b.fwd = c->dFwd.as<uint8_t>(); b.rev = c->dRev.as<uint8_t>(); b.readOff = c->dReadOff.as<uint32_t>(); b.nReads = c->nReads; return b; }
@@ -131,8 +131,15 @@ static hipError_t streamSync(ygpu_ctx *ctx)
     return e != hipSuccess ? e : hipEventSynchronize(ctx->evSync);
 }
 
+// the next stage's sizes cross PCIe as a few words, through a pinned slot (a pageable destination goes through a staging kernel and a second copy)
 static int fetchU32(ygpu_ctx *ctx, const void *dptr, uint32_t *out, size_t n = 1)
-{ HIPCHK(hipMemcpyAsync(out, dptr, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx)); return 0; }
+{
+    if (ctx->pinned && n <= 64) {
+        HIPCHK(hipMemcpyAsync(ctx->pinned, dptr, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+        memcpy(out, ctx->pinned, 4 * n); return 0;
+    }
+    HIPCHK(hipMemcpyAsync(out, dptr, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx)); return 0;
+}
 
 // ---- A1 + A2 (+ fragment array) --------------------------------------------------------------------------------
 static int stageSeed(ygpu_ctx *ctx)
@@ -701,6 +708,7 @@ static int initCommon(ygpu_ctx *ctx, int device)
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
     if (hipEventCreateWithFlags(&ctx->evSync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { ctx->evSync = nullptr; (void)hipGetLastError(); }
+    if (hipHostMalloc((void **)&ctx->pinned, 256, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; (void)hipGetLastError(); }
     return 0;
 }
 
@@ -768,6 +776,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
+        if (ctx->pinned) hipHostFree(ctx->pinned);
         for (int i = 0; i < YD_MAX_CHUNK_EV; i++) hipEventDestroy(ctx->evChunk[i]);
         hipEventDestroy(ctx->evTail); hipStreamDestroy(ctx->stream2);
         hipStreamDestroy(ctx->stream);
