@@ -286,6 +286,17 @@ def test_both_extension_kernel_families(work, index11, reads, extra, monkeypatch
     assert device_pipeline(index11, path, "-osh", extra, batch=150) == packed
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_packed_rows_random_scoring(work, index11, seed):
+    # scoring parameters drawn at random inside the packed 16-bit kernel's limits (and the reference's own: GEC >= 1): the whole pipeline, records and work
+    # counters, against the oracle; chimeric and plain reads, both extension directions, splits
+    import random
+    rnd = random.Random(1000 + seed)
+    extra = ["-MS", str(rnd.randint(1, 4)), "-RC", str(rnd.randint(1, 9)), "-GOC", str(rnd.randint(1, 14)), "-GEC", str(rnd.randint(1, 6)), "-X", str(rnd.choice([8, 25, 60, 150, 400]))]
+    for reads in ("r1k.fa", "rchim.fa"):
+        assert device_pipeline(index11, os.path.join(work, reads), "-osh", extra, batch=200)
+
+
 @pytest.mark.parametrize("xdrop", ["25", "3900", "4100"])
 def test_packed_rows_at_the_ends_of_their_score_range(work, index11, tmp_path, xdrop):
     # k_ext_rows_pk computes in saturating 16-bit arithmetic with a sentinel of -16000 and is used while MS * (longest read) <= 15000 and
