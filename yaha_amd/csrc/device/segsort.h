@@ -4,7 +4,8 @@
 // (diagonal, query offset) order.  k_expand_hits (seed.h) writes the hits of one (read, strand) -- one segment, a few thousand 64-bit keys --
 // in ascending query offset, so a STABLE sort on the 32 diagonal bits [15, 47) of the key finishes the job.  A segment of up to 16 384 keys
 // fits in a workgroup's registers and LDS: one read and one write of HBM per key instead of the library's digit passes over global memory.
-// Longer segments (repeat-rich reads) are left to hipcub::DeviceSegmentedRadixSort through begin/end arrays that are empty for all others.
+// Longer segments (repeat-rich reads) are first cut by diagonal into buckets that fit (k_seg_split); what still does not fit is left to
+// hipcub::DeviceSegmentedRadixSort through begin/end arrays that are empty for all others.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rocprim/block/block_load.hpp>
@@ -15,40 +16,40 @@
 #define YD_SEGSORT_MAX 16384u
 
 template <unsigned BS, unsigned IPT>
-__global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segOff, const uint32_t *list)
+__global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
 {
     using Load = rocprim::block_load<unsigned long long, BS, IPT, rocprim::block_load_method::block_load_transpose>;
     using Store = rocprim::block_store<unsigned long long, BS, IPT, rocprim::block_store_method::block_store_transpose>;
     using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t>;
     __shared__ union { typename Load::storage_type load; typename Store::storage_type store; typename Sort::storage_type sort; } st;
     const uint32_t seg = list[blockIdx.x];                                   // the segments of this launch's size class (k_seg_classify)
-    const uint32_t b = segOff[seg], len = segOff[seg + 1] - b;
+    const uint32_t b = segB[seg], len = segE[seg] - b;
+    const unsigned long long rs = in[b] & ~((1ull << 47) - 1ull);            // the (read, strand) bits: the same in every key of a segment
     unsigned long long keys[IPT];
     // blocked arrangement = the order the hits were written in; the padding keys sort last and, the sort being stable, stay behind real keys with the same bits
+    // (in == out is fine: the workgroup has read its whole segment before it stores)
     Load().load(in + b, keys, len, ~0ull, st.load);
     __syncthreads();
-    // what moves through the sort's LDS passes is the 32-bit diagonal with the 15-bit query offset as payload (6 bytes a hit instead of 8); the 17 (read, strand)
-    // bits are the segment's number
+    // what moves through the sort's LDS passes is the 32-bit diagonal with the 15-bit query offset as payload (6 bytes a hit instead of 8)
     uint32_t dg[IPT]; uint16_t qo[IPT];
 #pragma unroll
     for (unsigned k = 0; k < IPT; k++) { dg[k] = (uint32_t)(keys[k] >> 15); qo[k] = (uint16_t)(keys[k] & 0x7FFFull); }
     Sort().sort(dg, qo, st.sort, 0, 32);
     __syncthreads();
-    const unsigned long long rs = (unsigned long long)seg << 47;
 #pragma unroll
     for (unsigned k = 0; k < IPT; k++) keys[k] = rs | ((unsigned long long)dg[k] << 15) | (unsigned long long)qo[k];
     Store().store(out + b, keys, len, st.store);
 }
 
-// Size classes of the segments: class c (0..3) = at most hi[c] hits -> lists[c] (the workgroup sorts above: one launch per class over exactly its segments;
-// launching every class over all segments and letting the wrong ones leave cost 0.1 ms per 10 000 workgroups of 128 KB of LDS); longer ones = class 4: begin/end
-// offsets for the library's segmented sort, every other segment empty there.  counts[0..4]; one atomic per wave and class.
-__global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segOff, uint32_t nSeg, uint32_t hi0, uint32_t hi1, uint32_t hi2, uint32_t hi3,
+// Size classes of the segments [segB[s], segE[s]): class c (0..3) = at most hi[c] hits -> lists[c] (the workgroup sorts above: one launch per class over exactly
+// its segments; launching every class over all segments and letting the wrong ones leave cost 0.1 ms per 10 000 workgroups of 128 KB of LDS); longer ones =
+// class 4 -> lists[4], and begin/end offsets for the library's segmented sort (every other segment empty there).  counts[0..4]; one atomic per wave and class.
+__global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segB, const uint32_t *segE, uint32_t nSeg, uint32_t hi0, uint32_t hi1, uint32_t hi2, uint32_t hi3,
                                                       uint32_t *lists, uint32_t *bigB, uint32_t *bigE, unsigned int *counts)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63u);
     uint32_t b = 0, e = 0; int cls = -1;
-    if (s < nSeg) { b = segOff[s]; e = segOff[s + 1]; const uint32_t len = e - b; cls = len == 0 ? -1 : (len <= hi0 ? 0 : (len <= hi1 ? 1 : (len <= hi2 ? 2 : (len <= hi3 ? 3 : 4)))); }
+    if (s < nSeg) { b = segB[s]; e = segE[s]; const uint32_t len = e - b; cls = len == 0 ? -1 : (len <= hi0 ? 0 : (len <= hi1 ? 1 : (len <= hi2 ? 2 : (len <= hi3 ? 3 : 4)))); }
     if (s < nSeg) { bigB[s] = cls == 4 ? b : 0u; bigE[s] = cls == 4 ? e : 0u; }
 #pragma unroll
     for (int c = 0; c < 5; c++) {
@@ -57,6 +58,69 @@ __global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segOff, ui
         unsigned base = 0; const int first = __builtin_ctzll(m);
         if (lane == first) base = atomicAdd(&counts[c], (unsigned)__builtin_popcountll(m));
         base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
-        if (c < 4 && cls == c) lists[(size_t)c * nSeg + base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = s;
+        if (cls == c) lists[(size_t)c * nSeg + base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = s;
     }
+}
+
+// A long segment (more than 16 384 hits: 44 % of the hits of a repeat-rich batch) is cut by DIAGONAL into up to 16 buckets that fit the workgroup sort: one
+// stable counting pass by a workgroup per segment -- thread t owns a contiguous run of the segment's hits (count per bucket, exclusive scan over (bucket,
+// thread), scatter in order) -- instead of the library's four digit passes.  Bucket = the diagonal's top bits (monotone, so sorting the buckets one by one
+// sorts the segment); sub-segment sb * 16 + k = bucket k of the sb-th long segment.  A bucket that still exceeds the workgroup sort goes to the library.
+#define YD_SPLIT_NB 16
+__global__ void __launch_bounds__(1024) k_seg_split(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *bigList,
+                                                    int diagBits, uint32_t *subB, uint32_t *subE)
+{
+    // Wave w owns the w-th sixteenth of the segment and walks it 64 hits at a time (coalesced); the stable order is (wave, group, lane).
+    __shared__ uint32_t sCnt[YD_SPLIT_NB][16];                                // [bucket][wave]: counts, then running write positions
+    const uint32_t seg = bigList[blockIdx.x], b = segB[seg], len = segE[seg] - b, t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    int lg = 0; while (lg < 4 && ((len + 6143u) / 6144u) > (1u << lg)) lg++;                     // ~6 k hits a bucket on average, 16 buckets at most
+    const uint32_t nb = 1u << lg; const int sh = diagBits > lg ? diagBits - lg : 0;
+    const uint32_t per = ((len + 15u) / 16u + 63u) & ~63u, k0 = min(len, w * per), k1 = min(len, k0 + per);   // the wave's range, whole groups of 64
+    if (t < YD_SPLIT_NB * 16u) sCnt[t >> 4][t & 15u] = 0u;
+    __syncthreads();
+    // pass 1: hits per (bucket, wave)
+    for (uint32_t k = k0 + lane; k < k1; k += 64u) { const uint32_t d = (uint32_t)(in[b + k] >> 15); atomicAdd(&sCnt[min(d >> sh, nb - 1u)][w], 1u); }
+    __syncthreads();
+    // exclusive scan in (bucket, wave) order: 256 entries, one wave does it (4 per lane)
+    if (w == 0) {
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = sum; sum += (&sCnt[0][0])[4u * lane + (uint32_t)k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
+        const uint32_t excl = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) (&sCnt[0][0])[4u * lane + (uint32_t)k] = excl + v[k];
+    }
+    __syncthreads();
+    if (t < YD_SPLIT_NB) { subB[blockIdx.x * YD_SPLIT_NB + t] = b + sCnt[t][0]; subE[blockIdx.x * YD_SPLIT_NB + t] = t + 1u < YD_SPLIT_NB ? b + sCnt[t + 1u][0] : b + len; }
+    __syncthreads();
+    // pass 2: every group of 64 is split by bucket with four ballots (the lanes of one bucket keep their order), written behind what the wave has already
+    // written into that bucket
+    for (uint32_t g = k0; g < k1; g += 64u) {
+        const uint32_t k = g + lane; const bool live = k < k1;
+        const unsigned long long key = live ? in[b + k] : 0ull;
+        const uint32_t bk = live ? min((uint32_t)(key >> 15) >> sh, nb - 1u) : 0u;
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int bit = 0; bit < 4; bit++) { const unsigned long long m = __ballot((bk >> bit) & 1u); peers &= ((bk >> bit) & 1u) ? m : ~m; }
+        const uint32_t rank = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
+        if (live) out[b + sCnt[bk][w] + rank] = key;
+        __builtin_amdgcn_wave_barrier();
+        if (live && rank == 0u) sCnt[bk][w] += (uint32_t)__builtin_popcountll(peers);          // the bucket's first lane moves the wave's position on
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// begin/end of the listed sub-segments only (the library's segmented sort costs 0.3 ms over 56 k mostly empty segments, nothing over the nine that need it)
+__global__ void k_seg_gather_bounds(const uint32_t *segB, const uint32_t *segE, const uint32_t *list, uint32_t n, uint32_t *outB, uint32_t *outE)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { outB[i] = segB[list[i]]; outE[i] = segE[list[i]]; }
+}
+// sorted long sub-segments of the library path back to where the others are: dst[range] = src[range] for the listed sub-segments
+__global__ void k_seg_copy_back(const unsigned long long *src, unsigned long long *dst, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
+{
+    const uint32_t seg = list[blockIdx.x], b = segB[seg], e = segE[seg];
+    for (uint32_t k = b + threadIdx.x; k < e; k += blockDim.x) dst[k] = src[k];
 }

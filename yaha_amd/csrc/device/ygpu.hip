@@ -78,7 +78,7 @@ struct ygpu_ctx {
     DevBuf posS, posC, posRsI, hitOff, keysA, keysB, segOff, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
-    DevBuf segLists, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
+    DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
     bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
@@ -178,27 +178,48 @@ static int stageSeed(ygpu_ctx *ctx)
             if (ctx->segSort >= 2) {
                 // segments of up to 16 384 hits: one workgroup each (segsort.h), in four size classes, one launch per class over exactly its segments
                 const unsigned long long *in = ctx->keysA.as<unsigned long long>(); unsigned long long *out = ctx->keysB.as<unsigned long long>(); const uint32_t *so = ctx->segOff.as<uint32_t>();
-                ENSURE(ctx->bigB, 4ull * (2 * n + 1)); ENSURE(ctx->bigE, 4ull * (2 * n + 1)); ENSURE(ctx->segLists, 16ull * (2 * n + 1));
+                ENSURE(ctx->bigB, 4ull * (2 * n + 1)); ENSURE(ctx->bigE, 4ull * (2 * n + 1)); ENSURE(ctx->segLists, 20ull * (2 * n + 1));
                 uint32_t *segCnt = ctx->counters.as<uint32_t>() + CNT_SEGC;
                 HIPCHK(hipMemsetAsync(segCnt, 0, 20, ctx->stream));
                 const uint32_t mx = ctx->segSortMax;                                  // YD_SEGSORT_MAX; lower only to drive the long-segment path in tests
+                const uint32_t hi0 = std::min(mx, 1024u), hi1 = std::min(mx, 4096u), hi2 = std::min(mx, 8192u), hi3 = std::min(mx, 16384u);
                 uint32_t *lists = ctx->segLists.as<uint32_t>();
-                KL(k_seg_classify, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, 2 * n, std::min(mx, 1024u), std::min(mx, 4096u), std::min(mx, 8192u), std::min(mx, 16384u),
-                   lists, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), segCnt);
+                KL(k_seg_classify, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, so + 1, 2 * n, hi0, hi1, hi2, hi3, lists, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), segCnt);
                 uint32_t nc[5] = {0, 0, 0, 0, 0}; rc = fetchU32(ctx, segCnt, nc, 5); if (rc) return rc;
-                if (nc[3]) KL((k_seg_sort<1024, 16>), dim3(nc[3]), dim3(1024), 0, ctx->stream, in, out, so, lists + 3ull * (2 * n));
-                if (nc[2]) KL((k_seg_sort<512, 16>), dim3(nc[2]), dim3(512), 0, ctx->stream, in, out, so, lists + 2ull * (2 * n));
-                if (nc[1]) KL((k_seg_sort<256, 16>), dim3(nc[1]), dim3(256), 0, ctx->stream, in, out, so, lists + 1ull * (2 * n));
-                if (nc[0]) KL((k_seg_sort<128, 8>), dim3(nc[0]), dim3(128), 0, ctx->stream, in, out, so, lists);
+                if (nc[3]) KL((k_seg_sort<1024, 16>), dim3(nc[3]), dim3(1024), 0, ctx->stream, in, out, so, so + 1, lists + 3ull * (2 * n));
+                if (nc[2]) KL((k_seg_sort<512, 16>), dim3(nc[2]), dim3(512), 0, ctx->stream, in, out, so, so + 1, lists + 2ull * (2 * n));
+                if (nc[1]) KL((k_seg_sort<256, 16>), dim3(nc[1]), dim3(256), 0, ctx->stream, in, out, so, so + 1, lists + 1ull * (2 * n));
+                if (nc[0]) KL((k_seg_sort<128, 8>), dim3(nc[0]), dim3(128), 0, ctx->stream, in, out, so, so + 1, lists);
                 const uint32_t nBig = nc[4];
                 if (kTrace) { std::vector<uint32_t> so2(2 * (size_t)n + 1); hipMemcpy(so2.data(), so, 4ull * (2 * n + 1), hipMemcpyDeviceToHost); unsigned long long hb = 0, mxl = 0, c8 = 0, c4 = 0, c1 = 0, c0 = 0;
                     for (uint32_t k = 0; k < 2 * n; k++) { const unsigned long long l = so2[k + 1] - so2[k]; if (l > mx) { hb += l; mxl = std::max(mxl, l); } else if (l > 8192) c8 += l; else if (l > 4096) c4 += l; else if (l > 1024) c1 += l; else c0 += l; }
                     fprintf(stderr, "[ygpu] hit sort: %u hits; segments above %u hits: %u holding %llu hits (%.1f%%, longest %llu); classes 8k-16k %.1f%%, 4k-8k %.1f%%, 1k-4k %.1f%%, <=1k %.1f%%\n", H, mx, nBig, hb, 100.0 * hb / H, mxl, 100.0 * c8 / H, 100.0 * c4 / H, 100.0 * c1 / H, 100.0 * c0 / H); }
                 if (nBig) {
-                    size_t bytes = 0;
-                    HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, in, out, (int)H, (int)(2 * n), ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), 15, 47, ctx->stream));
-                    if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-                    HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, in, out, (int)H, (int)(2 * n), ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), 15, 47, ctx->stream));
+                    // long segments: cut by diagonal into buckets that fit the workgroup sort (k_seg_split: keysA -> keysB), the buckets sorted in place; what still
+                    // does not fit (a bucket above the limit) goes through the library's segmented sort (keysB -> keysA) and is copied back
+                    const uint32_t nSub = nBig * YD_SPLIT_NB;
+                    ENSURE(ctx->subB, 4ull * nSub + 64); ENSURE(ctx->subE, 4ull * nSub + 64); ENSURE(ctx->subLists, 20ull * nSub + 64); ENSURE(ctx->subBigB, 4ull * nSub + 64); ENSURE(ctx->subBigE, 4ull * nSub + 64);
+                    int diagBits = 1; while (diagBits < 32 && (ctx->P.maxROff >> diagBits)) diagBits++;
+                    uint32_t *sB = ctx->subB.as<uint32_t>(), *sE = ctx->subE.as<uint32_t>(), *l2 = ctx->subLists.as<uint32_t>();
+                    KL(k_seg_split, dim3(nBig), dim3(1024), 0, ctx->stream, in, out, so, so + 1, lists + 4ull * (2 * n), diagBits, sB, sE);
+                    HIPCHK(hipMemsetAsync(segCnt, 0, 20, ctx->stream));
+                    KL(k_seg_classify, dim3(gridFor(nSub, 256)), dim3(256), 0, ctx->stream, sB, sE, nSub, hi0, hi1, hi2, hi3, l2, ctx->subBigB.as<uint32_t>(), ctx->subBigE.as<uint32_t>(), segCnt);
+                    uint32_t ns[5] = {0, 0, 0, 0, 0}; rc = fetchU32(ctx, segCnt, ns, 5); if (rc) return rc;
+                    if (ns[3]) KL((k_seg_sort<1024, 16>), dim3(ns[3]), dim3(1024), 0, ctx->stream, out, out, sB, sE, l2 + 3ull * nSub);
+                    if (ns[2]) KL((k_seg_sort<512, 16>), dim3(ns[2]), dim3(512), 0, ctx->stream, out, out, sB, sE, l2 + 2ull * nSub);
+                    if (ns[1]) KL((k_seg_sort<256, 16>), dim3(ns[1]), dim3(256), 0, ctx->stream, out, out, sB, sE, l2 + 1ull * nSub);
+                    if (ns[0]) KL((k_seg_sort<128, 8>), dim3(ns[0]), dim3(128), 0, ctx->stream, out, out, sB, sE, l2);
+                    if (kTrace) fprintf(stderr, "[ygpu] hit sort: %u long segments cut into buckets: %u / %u / %u / %u in the workgroup classes, %u left to the library\n", nBig, ns[0], ns[1], ns[2], ns[3], ns[4]);
+                    if (ns[4]) {
+                        unsigned long long *tmp = ctx->keysA.as<unsigned long long>();
+                        uint32_t *cB = ctx->subBigB.as<uint32_t>(), *cE = ctx->subBigE.as<uint32_t>();           // compact bounds of the ns[4] buckets that did not fit
+                        KL(k_seg_gather_bounds, dim3(gridFor(ns[4], 256)), dim3(256), 0, ctx->stream, sB, sE, l2 + 4ull * nSub, ns[4], cB, cE);
+                        size_t bytes = 0;
+                        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, (const unsigned long long *)out, tmp, (int)H, (int)ns[4], cB, cE, 15, 47, ctx->stream));
+                        if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
+                        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, (const unsigned long long *)out, tmp, (int)H, (int)ns[4], cB, cE, 15, 47, ctx->stream));
+                        KL(k_seg_copy_back, dim3(ns[4]), dim3(256), 0, ctx->stream, tmp, out, sB, sE, l2 + 4ull * nSub);
+                    }
                 }
             } else {
             size_t bytes = 0;
@@ -772,7 +793,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->segLists, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt};
+                         &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
