@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
             const int second = k < 8 ? 0 : 1, bt = k < 8 ? k : k - 3, sT = 8 * h + bt, sU = 16 + sT, sM = 16 * h + 10 - k;
             uint32_t dTU[YD_TRACE_DEPTH], dM[YD_TRACE_DEPTH];
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-            int lim = (int)(u.fb % YD_CHUNK_FLUSHES) * 8 + u.rr + 1; lim = lim < y ? lim : y; lim = lim < YD_TRACE_DEPTH ? lim : YD_TRACE_DEPTH;
+            int lim = u.rr + 1; lim = lim < y ? lim : y;                      // to the start of the 128-byte block: a line is fetched once, by one batch
             { YD_GLOBAL uint32_t *up = u.cp;
 #pragma unroll
               for (int d = 0; d < YD_TRACE_DEPTH; d++) { const u32x2 v = *(YD_GLOBAL const u32x2 *)(up + (second ? 0 : 1)); dTU[d] = second ? v.x : v.y; dM[d] = second ? v.y : v.x; up -= (d + 1 < lim) ? 4 : 0; } }
@@ -470,3 +470,4 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
         r.opsOff = (uint32_t)(unsigned long long)place; r.where = (uint32_t)((unsigned long long)place >> 32); r.nOps = (uint32_t)n; A.res[p] = r;
     }
 }
+
