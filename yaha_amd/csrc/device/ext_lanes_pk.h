@@ -71,7 +71,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     uint32_t NEGKv = NEGK, MSv = MSp, ONEv = ONEp, C15v = 0x000F000Fu;      // operands of the inline-assembly instructions: kept in VGPRs (copied from SGPRs at every use otherwise)
     asm volatile("" : "+v"(NEGKv), "+v"(MSv), "+v"(ONEv), "+v"(C15v));
     uint32_t PV[YD_NP], PF[YD_NP], rc[YD_NP], carryE = LWp, nbNext = 15u;
-    int p = -1, i = 0, qLen = 0, maxScore = YD_LWORST, maxi = 0, maxj = 0, qcNext = 0, qcPrev = 0, rvLo = YD_LWORST, rjLo = 0;
+    int p = -1, i = 0, qLen = 0, maxScore = YD_LWORST, maxi = 0, qcNext = 0, qcPrev = 0, rvLo = YD_LWORST;
+    uint32_t SV[YD_NP]; int maxSide = 0;                                    // the strip of the iteration that set the maximum (the column is found when the problem ends)
+#pragma unroll
+    for (int k = 0; k < YD_NP; k++) SV[k] = 0;
     // The two input streams -- a query code and a reference nibble per iteration -- come through per-lane WINDOWS: 64-bit shift registers of the next codes /
     // nibbles in the order the lane consumes them (low end first), refilled with whole aligned dwords: 4 codes every 4th iteration, 8 nibbles every 8th (the
     // iterations are the wave's: (wslot & 3) == 0 and wslot == 0).  A byte load per lane and iteration made every lane's stream a line of its own in L1 and
@@ -236,7 +239,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 PV[k] = init ? iV : PV[k]; PF[k] = init ? iF : PF[k]; rc[k] = init ? (nibLo | (nibHi << 16)) : rc[k];
             }
             if (init) {
-                p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); i = 0; maxScore = YD_LWORST; maxi = 0; maxj = 0; carryE = LWp; rvLo = YD_LWORST; rjLo = 0;
+                p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); i = 0; maxScore = YD_LWORST; maxi = 0; carryE = LWp; rvLo = YD_LWORST;
                 const bool rev = (gMisc & XP_REV) != 0;
                 q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qSel = rev ? 0x00010203u : 0x03020100u;
                 qcNext = (int)((gMisc >> 8) & 0xFFu); qcPrev = 0;
@@ -275,6 +278,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             // are still its own).  Work of the call: row r has 21 - max(11 - r, 0) real cells.
             const unsigned rowF = (unsigned)(i - 2), m = rowF < (unsigned)leftR ? rowF : (unsigned)leftR, nCells = __umul24((unsigned)YD_LW, rowF) - (__umul24((unsigned)(leftR + 1), m) - __umul24(m, m + 1u) / 2u);
             rows += rowF; cells += nCells;
+            int maxj = 0;                                                     // the first column of the kept strip's half that holds the maximum
+#pragma unroll
+            for (int k = YD_NP - 1; k >= 0; k--) { const int v = maxSide ? (int)(short)(SV[k] >> 16) : (int)(short)(SV[k] & 0xFFFFu); if (v == maxScore) maxj = k + (maxSide ? YD_NP : 0); }
             ExtRes r; r.score = maxScore > 0 ? maxScore : 0; r.maxi = maxi; r.maxj = maxj; r.opsOff = pStart >> 4; r.nOps = 0;
             r.where = (pStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = rowF; r.cells = nCells;
             A.res[pendRes] = r; pendRes = -1;
@@ -286,7 +292,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         uint32_t qcPv = qcP; asm volatile("" : "+v"(qcPv));                   // (opaque: else the constant is re-applied in every pair)
         uint32_t PVCol = (PV[YD_NP - 1] << 16) | LWlo;                       // low: nothing left of column 0; high: V(i-1, 10)
         uint32_t PE = (carryE << 16) | LWlo;                                 //                                       E(i-1, 10)
-        uint32_t rowMax = LWp, jbest = 0, dV = PV[0];
+        uint32_t rowMax = LWp, dV = PV[0];
         uint32_t accA = 0, accB = 0, accA2 = 0, accB2 = 0, accM = 0;
 #pragma unroll
         for (int k = 0; k < YD_NP; k++) {
@@ -315,8 +321,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             uint32_t Vm = V;
             if (k < leftR) Vm = pkMin(V, rc[k]);
             if (k == YD_NP - 1) { V = bfi(0x0000FFFFu, V, LWp); Vm = V; }
-            const uint32_t gt = pkSignMaskAsm(pkSub(rowMax, Vm), C15v);      // 0xFFFF where this cell beats the maximum so far
-            jbest = bfi(gt, (uint32_t)k * 0x10001u, jbest);
             rowMax = pkMax(rowMax, Vm);
             PV[k] = V; PF[k] = k == YD_NP - 1 ? bfi(0x0000FFFFu, F, LWp) : F; PVCol = V; dV = upV;
             __builtin_amdgcn_sched_barrier(0);
@@ -325,13 +329,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         { const int slot = wslot * 4;                                        // this iteration's record goes to the lane's LDS block (the same slot in every lane)
           myBlk[slot] = accA2 | (accB2 >> 3); myBlk[slot + 1] = accM; myBlk[slot + 2] = accA; myBlk[slot + 3] = accB; }
         // row i - 1 is complete now: its maximum (columns 0..10 from the previous iteration, 11..20 from this one; the first one in column order), X-drop test
-        const int rvHi = (int)(short)(rowMax >> 16), rjHi = (int)(jbest >> 16) + YD_NP;
-        int rv = rvLo, rj = rjLo;
-        if (rvHi > rv) { rv = rvHi; rj = rjHi; }
-        rvLo = (int)(short)(rowMax & 0xFFFFu); rjLo = (int)(jbest & 0xFFFFu);
+        // The scan is row-major with a strict '>': row i-1's columns 11..20 (this iteration's high halves) come after its columns 0..10 (seen one iteration ago),
+        // and before row i's columns 0..10 (this iteration's low halves, counted unless row i-1 ends the problem).  The strip of the iteration that set the
+        // maximum is kept; the column is looked up in it when the problem ends.
+        const int rvHi = (int)(short)(rowMax >> 16);
+        const int rv = rvHi > rvLo ? rvHi : rvLo;
+        rvLo = (int)(short)(rowMax & 0xFFFFu);
         const int row = i - 1;
-        if (busy && row >= 1 && rv > maxScore) { maxScore = rv; maxi = row; maxj = rj; }
+        bool snap = false;
+        if (busy && row >= 1 && rvHi > maxScore) { maxScore = rvHi; maxi = row; maxSide = 1; snap = true; }
         const bool fin = busy && row >= 1 && (rv < maxScore - XC || row >= qLen);
+        if (busy && !fin && i >= 1 && rvLo > maxScore) { maxScore = rvLo; maxi = i; maxSide = 0; snap = true; }
+        if (snap) {
+#pragma unroll
+            for (int k = 0; k < YD_NP; k++) SV[k] = PV[k];
+        }
         if (busy) dirty = true;
         if (wslot == 7) { pendFlush = dirty; dirty = false; wslot = 0; } else wslot++;      // wave-uniform
         justDone = fin;                                                      // the next record slot stays empty behind a finished problem (its traceback's spare record)
