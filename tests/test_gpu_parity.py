@@ -159,6 +159,24 @@ def test_two_contexts_in_flight_match_one(work, index11):
         assert got[1] == exp1 and got[2] == exp2
 
 
+def test_small_batch_then_large_batch_on_one_context(work, index11, monkeypatch):
+    # after its first batch a context bounds the clump slots by what the last batch used (the slots are pre-set, a store each); a batch that overflows the
+    # bound is redone at the full one and must give the records a fresh context gives.  YGPU_CLUMP_BOUND sets a first bound that the batch overflows.
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s, ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s0:
+        small = s0.next_batch(3)                                         # (a session's batches share its buffers: one session per batch kept)
+        large = s.next_batch(600)
+        with ya.Context(s.index, s.params) as fresh:
+            fresh.upload(large); fresh.run(); exp = ya.result_records(fresh.collect())
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.upload(small); ctx.run(); ya.result_records(ctx.collect())
+            ctx.upload(large); ctx.run(); got = ya.result_records(ctx.collect())
+            monkeypatch.setenv("YGPU_CLUMP_BOUND", "64")
+            ctx.upload(large); ctx.run(); redone = ya.result_records(ctx.collect())
+            monkeypatch.delenv("YGPU_CLUMP_BOUND")
+            ctx.upload(small); ctx.run(); ctx.upload(large); ctx.run(); again = ya.result_records(ctx.collect())
+        assert len(exp) > 100 and got == exp and redone == exp and again == exp
+
+
 def test_cli_drop_in(work, index11, tmp_path):
     out = str(tmp_path / "o.sam")
     subprocess.check_call([ya.CLI_PATH, "-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", out, "-FBS", "Y", "-t", "4", "-batch", "64"], stderr=subprocess.DEVNULL)

@@ -139,8 +139,14 @@ __global__ void k_frag_build(const unsigned long long *keys, const uint32_t *fra
     const uint32_t qo = (uint32_t)(k & 0x7FFFu), diag = (uint32_t)(k >> 15), rs = (uint32_t)(k >> 47);
     const uint32_t head = hitIsHead(keys, t, nHits, wordLen);
     const uint32_t f = fragIdx[t] + head - 1u;                                    // index of the fragment this hit belongs to
-    if (head) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
     const bool last = (t + 1 == nHits) || hitIsHead(keys, t + 1, nHits, wordLen);
+    if (head && last) {                                                          // a fragment of one hit (most of them on a large genome): the whole record in one 16-byte store
+        const uint32_t eqo = qo + (uint32_t)wordLen - 1u;
+        uint4 v; v.x = diag + qo; v.y = qo | (eqo << 16); v.z = (uint32_t)wordLen /* refLen, used = 0 */; v.w = rs;
+        *(uint4 *)&frags[f] = v;
+        return;
+    }
+    if (head) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
     if (last) frags[f].eqo = (uint16_t)(qo + (uint32_t)wordLen - 1u);
 }
 __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)

@@ -79,7 +79,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -286,7 +286,11 @@ static int stageChain(ygpu_ctx *ctx)
     EV1(T_FRAGS);
 
     EV0(T_CHAIN);
-    uint32_t clumpCap = F + R / 2 + 1024 + 32 * (ctx->nCU * 27 + 64) + 512 * (ctx->nCU * 8), fragCap = 2 * F + 1024 + 256 * (ctx->nCU * 27 + 64) + 2048 * (ctx->nCU * 8);   // + one open chunk per wave (k_chain: 32/256, k_chain_lanes: 512/2048)
+    // (clump slots are pre-set to "invalid", so their number is a 16-byte store each: after the first batch the bound is twice what the last batch used -- most
+    // fragments of a large genome are single hits that form no clump: 128 M fragments, 5.4 M clumps a batch at 3.1 Gbp -- and a batch that overflows it is redone at the full bound)
+    const uint32_t clumpSlack = 1024 + 32 * (ctx->nCU * 27 + 64) + 512 * (ctx->nCU * 8), clumpCapFull = F + R / 2 + clumpSlack;
+    uint32_t clumpCap = ctx->lastClumpSlots ? (uint32_t)std::min<uint64_t>(clumpCapFull, 2ull * ctx->lastClumpSlots + clumpSlack) : clumpCapFull, fragCap = 2 * F + 1024 + 256 * (ctx->nCU * 27 + 64) + 2048 * (ctx->nCU * 8);   // + one open chunk per wave (k_chain: 32/256, k_chain_lanes: 512/2048)
+    if (const char *e = getenv("YGPU_CLUMP_BOUND")) { const long v = atol(e); if (v > 0 && (uint64_t)v < clumpCapFull) clumpCap = (uint32_t)v; }      // tests: a first bound that overflows
     const unsigned waves = (unsigned)std::min<uint64_t>(std::max<uint32_t>(ctx->nMulti, 1u), (uint64_t)ctx->nCU * 24);     // latency-bound serial work: 6 waves per SIMD
     const unsigned wavesBig = (unsigned)std::min<uint64_t>(std::max<uint32_t>(ctx->nBig, 1u), (uint64_t)ctx->nCU * 3);        // 40 KB of LDS each
     for (int attempt = 0;; attempt++) {
@@ -310,9 +314,9 @@ static int stageChain(ygpu_ctx *ctx)
         if (ctx->nBig) KL(k_chain_big, dim3(wavesBig), dim3(64), 0, ctx->stream, A, ctx->bigList.as<uint32_t>(), ctx->nBig, cnt + CNT_QBIG);
         uint32_t got[2]; rc = fetchU32(ctx, cnt + CNT_CLUMPS, got, 2); if (rc) return rc;
         uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
-        if (ef == 0 && got[0] <= clumpCap && got[1] <= fragCap) { ctx->nClumpSlots = got[0]; ctx->nClumpFrags = got[1]; break; }
+        if (ef == 0 && got[0] <= clumpCap && got[1] <= fragCap) { ctx->nClumpSlots = got[0]; ctx->nClumpFrags = got[1]; ctx->lastClumpSlots = got[0]; break; }
         if (attempt >= 6) { ctx->err = "chain stage: arena overflow persists"; return YGPU_EOVERFLOW; }
-        clumpCap *= 2; fragCap *= 2;                                           // grow and redo: the fragment array was modified in place
+        if (clumpCap < clumpCapFull) clumpCap = clumpCapFull; else { clumpCap *= 2; fragCap *= 2; }      // grow and redo: the fragment array was modified in place
         rc = buildFrags(ctx); if (rc) return rc;
     }
     // creation-order rank of every root clump
