@@ -118,36 +118,68 @@ __device__ __forceinline__ uint32_t hitIsHead(const unsigned long long *keys, ui
     if ((a >> 15) != (b >> 15)) return 1u;
     return (uint32_t)(b & 0x7FFFu) > (uint32_t)(a & 0x7FFFu) + (uint32_t)wordLen ? 1u : 0u;
 }
+// A fragment of ONE hit that is alone in its region (QueryMatch.c:146-158: the fragments before and after it are of another (read, strand) or more than maxGap
+// diagonals away) can only become a clump if one word is a whole match (refLen = wordLen >= minMatch, QueryMatch.c:281-290).  With the defaults (15 < 25) it
+// is dead on arrival, and on a large genome these chance hits are most fragments (3.1 Gbp: 128 M fragments a batch, ~100 M of them dead): they are counted
+// and not written.  Dropping them changes nothing for the others: the diagonals are sorted, so the fragments on either side of a dropped run are further
+// apart than the dropped fragment was from them -- every region boundary stays where it was.  maxGapDrop < 0: keep every fragment (ygpu_seed_join).
+// head / last / dead of hit t from its two neighbours, loaded once, without branches (bit 0 head, bit 1 last hit of its fragment, bit 2 dead single)
+__device__ __forceinline__ uint32_t hitClass(const unsigned long long *keys, uint32_t t, uint32_t nHits, int wordLen, int maxGapDrop)
+{
+    const bool first = t == 0, end = t + 1 >= nHits;
+    const unsigned long long b = keys[t], a = keys[first ? t : t - 1], c = keys[end ? t : t + 1];
+    const uint32_t qa = (uint32_t)(a & 0x7FFFu), qb = (uint32_t)(b & 0x7FFFu), qc = (uint32_t)(c & 0x7FFFu);
+    const uint32_t da = (uint32_t)(a >> 15), db = (uint32_t)(b >> 15), dc = (uint32_t)(c >> 15);
+    const bool sameA = (uint32_t)(a >> 47) == (uint32_t)(b >> 47), sameC = (uint32_t)(c >> 47) == (uint32_t)(b >> 47);
+    const bool head = first | !sameA | (da != db) | (qb > qa + (uint32_t)wordLen);
+    const bool last = end | !sameC | (dc != db) | (qc > qb + (uint32_t)wordLen);
+    const bool nearA = !first & sameA & (absDiffU(da, db) <= (uint32_t)maxGapDrop), nearC = !end & sameC & (absDiffU(dc, db) <= (uint32_t)maxGapDrop);
+    const bool dead = (maxGapDrop >= 0) & head & last & !nearA & !nearC;
+    return (head ? 1u : 0u) | (last ? 2u : 0u) | (dead ? 4u : 0u);
+}
 // the scan's input: the head flags computed from the keys on the fly (no flag array: 0.8 GB written and read twice for 200 M hits)
 struct HitHeadFlag {
-    const unsigned long long *keys; uint32_t nHits; int wordLen;
+    const unsigned long long *keys; uint32_t nHits; int wordLen, maxGapDrop;
     __host__ __device__ __forceinline__ uint32_t operator()(uint32_t t) const
     {
 #if defined(__HIP_DEVICE_COMPILE__)
-        return hitIsHead(keys, t, nHits, wordLen);
+        if (t >= nHits) return 0u;
+        const uint32_t c = hitClass(keys, t, nHits, wordLen, maxGapDrop);
+        return c & ~(c >> 2) & 1u;                                               // a head that is not dropped
 #else
         (void)t; return 0u;
 #endif
     }
 };
-__global__ void k_frag_build(const unsigned long long *keys, const uint32_t *fragIdx /* exclusive scan of the head flags */,
-                             uint32_t nHits, int wordLen, DevFrag *frags)
+__global__ void __launch_bounds__(256) k_frag_build(const unsigned long long *keys, const uint32_t *fragIdx /* exclusive scan of the head flags */,
+                             uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
 {
+    __shared__ unsigned sDead;
+    if (threadIdx.x == 0) sDead = 0;
+    __syncthreads();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nHits) return;
-    const unsigned long long k = keys[t];
-    const uint32_t qo = (uint32_t)(k & 0x7FFFu), diag = (uint32_t)(k >> 15), rs = (uint32_t)(k >> 47);
-    const uint32_t head = hitIsHead(keys, t, nHits, wordLen);
-    const uint32_t f = fragIdx[t] + head - 1u;                                    // index of the fragment this hit belongs to
-    const bool last = (t + 1 == nHits) || hitIsHead(keys, t + 1, nHits, wordLen);
-    if (head && last) {                                                          // a fragment of one hit (most of them on a large genome): the whole record in one 16-byte store
-        const uint32_t eqo = qo + (uint32_t)wordLen - 1u;
-        uint4 v; v.x = diag + qo; v.y = qo | (eqo << 16); v.z = (uint32_t)wordLen /* refLen, used = 0 */; v.w = rs;
-        *(uint4 *)&frags[f] = v;
-        return;
+    bool dead = false;
+    if (t < nHits) {
+        const uint32_t cls = hitClass(keys, t, nHits, wordLen, maxGapDrop);
+        const bool head = (cls & 1u) != 0u, last = (cls & 2u) != 0u; dead = (cls & 4u) != 0u;
+        if (!dead) {
+            const unsigned long long k = keys[t];
+            const uint32_t qo = (uint32_t)(k & 0x7FFFu), diag = (uint32_t)(k >> 15), rs = (uint32_t)(k >> 47);
+            const uint32_t f = fragIdx[t] + (head ? 1u : 0u) - 1u;                // index of the fragment this hit belongs to
+            if (head && last) {                                                  // a fragment of one hit: the whole record in one 16-byte store
+                const uint32_t eqo = qo + (uint32_t)wordLen - 1u;
+                uint4 v; v.x = diag + qo; v.y = qo | (eqo << 16); v.z = (uint32_t)wordLen /* refLen, used = 0 */; v.w = rs;
+                *(uint4 *)&frags[f] = v;
+            } else {
+                if (head) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
+                if (last) frags[f].eqo = (uint16_t)(qo + (uint32_t)wordLen - 1u);
+            }
+        }
     }
-    if (head) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
-    if (last) frags[f].eqo = (uint16_t)(qo + (uint32_t)wordLen - 1u);
+    const unsigned long long dm = __ballot(dead);
+    if ((threadIdx.x & 63u) == 0 && dm) atomicAdd(&sDead, (unsigned)__builtin_popcountll(dm));
+    __syncthreads();
+    if (threadIdx.x == 0 && sDead) atomicAdd(&deadParts[blockIdx.x & 1023u], sDead);
 }
 __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
 {

@@ -79,7 +79,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -142,6 +142,8 @@ static int fetchU32(ygpu_ctx *ctx, const void *dptr, uint32_t *out, size_t n = 1
 }
 
 // ---- A1 + A2 (+ fragment array) --------------------------------------------------------------------------------
+// maxGap for the dead-single test of seed.h, or -1: every fragment is kept (the fragments themselves are asked for, or one word can be a whole match)
+static int fragDropGap(const ygpu_ctx *ctx) { return (ctx->keepAllFrags || ctx->P.wordLen >= ctx->P.minMatch) ? -1 : ctx->P.maxGap; }
 static int stageSeed(ygpu_ctx *ctx)
 {
     const uint32_t n = ctx->nReads, K = ctx->nKmers; DevBatch B = devBatch(ctx);
@@ -239,7 +241,7 @@ static int stageSeed(ygpu_ctx *ctx)
     EV0(T_FRAGS);
     ENSURE(ctx->scanOut, 4ull * (H + 1));
     {   // fragment index of every hit = exclusive scan of the head flags, which the scan computes from the sorted keys as it reads them
-        hipcub::TransformInputIterator<uint32_t, HitHeadFlag, hipcub::CountingInputIterator<uint32_t>> flags(hipcub::CountingInputIterator<uint32_t>(0u), HitHeadFlag{ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen});
+        hipcub::TransformInputIterator<uint32_t, HitHeadFlag, hipcub::CountingInputIterator<uint32_t>> flags(hipcub::CountingInputIterator<uint32_t>(0u), HitHeadFlag{ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, fragDropGap(ctx)});
         size_t bytes = 0;
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags, ctx->scanOut.as<uint32_t>(), (int)(H + 1), ctx->stream));
         if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
@@ -254,7 +256,10 @@ static int buildFrags(ygpu_ctx *ctx)       // (re)creates the fragment array fro
 {
     const uint32_t H = ctx->nHits, F = ctx->nFrags;
     if (!H) return 0;
-    KL(k_frag_build, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), ctx->scanOut.as<uint32_t>(), H, ctx->P.wordLen, ctx->frags.as<DevFrag>());
+    // the fragments that are dropped (seed.h: hitIsDeadSingle) are counted: the counters report every fragment and region of the reference
+    ENSURE(ctx->kmerParts, 4096); HIPCHK(hipMemsetAsync(ctx->kmerParts.p, 0, 4096, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_FRAGS, 0, 8, ctx->stream));
+    KL(k_frag_build, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), ctx->scanOut.as<uint32_t>(), H, ctx->P.wordLen, fragDropGap(ctx), ctx->frags.as<DevFrag>(), ctx->kmerParts.as<unsigned int>());
+    KL(k_sum_parts, dim3(1), dim3(1024), 0, ctx->stream, ctx->kmerParts.as<unsigned int>(), ctx->ctr.as<DevCounters>()->v + C_FRAGS);
     KL(k_frag_finish, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F);
     return 0;
 }
@@ -868,7 +873,8 @@ int ygpu_collect(ygpu_ctx *ctx, ygpu_result_batch *out)
     if (ctx->nOutOps) HIPCHK(hipMemcpyAsync(ctx->hOps.data(), ctx->outOps.p, 4ull * ctx->nOutOps, hipMemcpyDeviceToHost, ctx->stream));
     DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(streamSync(ctx));
-    dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags; dc.v[C_REGIONS] = ctx->nRegions;
+    { const unsigned long long dropped = dc.v[C_FRAGS];                      // dead single-hit fragments (each one a region of its own) that were counted, not written
+      dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags + dropped; dc.v[C_REGIONS] = ctx->nRegions + dropped; }
     memcpy(&ctx->hCounters, dc.v, sizeof(ygpu_counters));
     out->n_reads = n; out->clump_start = ctx->hClumpStart.data(); out->clumps = ctx->hClumps.data(); out->ops = ctx->hOps.data();
     out->n_clumps = ctx->nOut; out->n_ops = ctx->nOutOps; out->counters = ctx->hCounters;
@@ -925,7 +931,7 @@ int ygpu_last_timing(ygpu_ctx *ctx, float *total_ms, int *n_stages, const char *
 int ygpu_seed_join(ygpu_ctx *ctx, const ygpu_fragment **frags, uint64_t *n_frags)
 {
     if (!ctx || !ctx->stream) return YGPU_EINVAL;
-    ctx->stageDone = 0; int rc = runTo(ctx, 1); if (rc) return rc;
+    ctx->stageDone = 0; ctx->keepAllFrags = true; int rc = runTo(ctx, 1); ctx->keepAllFrags = false; if (rc) return rc;
     ctx->hFrags.resize(ctx->nFrags);
     if (ctx->nFrags) HIPCHK(hipMemcpy(ctx->hFrags.data(), ctx->frags.p, 16ull * ctx->nFrags, hipMemcpyDeviceToHost));
     for (auto &f : ctx->hFrags) f.reserved = 0;
