@@ -1,8 +1,9 @@
 """One-off validation at the bench workload's scale: the whole `yaha` command line of this repo against the real reference binary
-(oracle/_ref/yaha) on the bench genome (100 Mbp, -L 15) -- SAM identical minus @PG.  Run on the GPU box after bench.py built the cache."""
+(oracle/_ref/yaha) on the bench genome (100 Mbp or, with YAHA_PARITY_GENOME=g3100m_s42, 3.1 Gbp; -L 15) -- SAM identical minus @PG.  Run on the GPU box after bench.py built the cache."""
 import os, subprocess, sys, time
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
-X = "/tmp/yaha_bench_cache/g100m_s42.X15_01_65525S"; G = "/tmp/yaha_bench_cache/g100m_s42.fa"
+GENOME = os.environ.get("YAHA_PARITY_GENOME", "g100m_s42")            # g3100m_s42 = G-hg18scale (bench.py's default cache)
+X = "/tmp/yaha_bench_cache/%s.X15_01_65525S" % GENOME; G = "/tmp/yaha_bench_cache/%s.fa" % GENOME
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 SETS = (("1kbp", ["--len", "1000", "--div", "0.017", "--chimeric", "0.05"], 1.0), ("10kbp", ["--len", "10000", "--div", "0.034"], 1 / 16), ("150bp", ["--len", "150", "--div", "0.01"], 2.0),
         ("fastq_N_edges_jitter", ["--len", "800", "--div", "0.05", "--fastq", "--withN", "0.3", "--edges", "--len-jitter", "700", "--chimeric", "0.1"], 0.25),
