@@ -13,7 +13,7 @@ for f in glob.glob(os.path.join(root, "stats1", "*kernel_stats.csv")):
     for row in csv.DictReader(open(f)):
         k = short(row["Name"]); o = dur.get(k, (0.0, 0, 0.0)); dur[k] = (0.0, o[1] + int(row["Calls"]), o[2] + float(row["TotalDurationNs"]))
 steps = 8.0
-print("per-kernel counters, one context, 16 384 x 1 kbp reads (rocprofv3 --pmc in separate passes with --kernel-trace only; tools/pmc_pass.sh, tools/pmc_table.py)")
+print("per-kernel counters, one context, bench.py defaults (3.1 Gbp genome, 16 384 x 1 kbp reads) (rocprofv3 --pmc in separate passes with --kernel-trace only; tools/pmc_pass.sh, tools/pmc_table.py)")
 print("counters = sums over the dispatches of one step; percentages of SQ_WAVE_CYCLES; VALU ms = instructions x 4.4 cycles / (1024 SIMDs x 2.4 GHz); fetch = FETCH_SIZE x 2 KiB, write = WRITE_SIZE KiB;")
 print("LDS conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; ms/step = total duration of the kernel's launches over the %d steps of the --stats run / %d" % (steps, steps))
 print("%-44s %8s %6s %9s %8s %8s %8s %9s %9s %9s %8s" % ("kernel", "ms/step", "calls", "VALU(M)", "VALU ms", "active%", "memwait%", "iss.wait%", "fetch GB", "write GB", "ldsconf%"))
