@@ -134,8 +134,12 @@ template <class T> struct StageQueue {
 
 int runQueries(Args &a, FILE *log)
 {
+    const bool timing0 = getenv("YAHA_TIMING") != nullptr;
+    auto now0 = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tStep = now0();
     std::unique_ptr<yaha_session> S(new yaha_session); S->args = a;
     if (!sessionLoad(S.get())) { fprintf(log, "%s\n", S->err.c_str()); return 1; }
+    if (timing0) { fprintf(stderr, "[yaha] index and input opened in %.1f ms\n", now0() - tStep); tStep = now0(); }
     Args &A = S->args;
     FILE *out = (A.ofileName == "stdout") ? stdout : fopen(A.ofileName.c_str(), "w");
     if (!out) { fprintf(log, "Failure to open output file: %s.\n", A.ofileName.c_str()); return 1; }
@@ -151,6 +155,7 @@ int runQueries(Args &a, FILE *log)
         int rc = (d % perDev == 0) ? ygpu_init(dev, &V, &P, &ctx[d]) : ygpu_clone(ctx[d - d % perDev], &ctx[d]);
         if (rc != 0) { fprintf(log, "ygpu_init(device %d) failed: %d %s\n", dev, rc, ctx[d] ? ygpu_last_error(ctx[d]) : ""); return 1; }
     }
+    if (timing0) { fprintf(stderr, "[yaha] device contexts created (index image uploaded) in %.1f ms\n", now0() - tStep); tStep = now0(); }
     // Five stages, batches handed over through bounded queues, a ticket ordering the output (= the reference's -t 1 order):
     //   splitter   (1 thread)          record boundaries of the memory-mapped / block-read input (memchr; reader.cpp) -- the only serial part;
     //   parsers    (a few threads)     id, sequence, quality, codes, reverse complement and the skip rules of one batch of records;
