@@ -1,8 +1,8 @@
 #!/bin/bash
 # end-to-end probe of the yaha command line on the bench genome (run on the GPU box after bench.py built its cache): tools/cli_probe.sh ["opts" ...]
-R=$GRAFT_REPO_ROOT; C=/tmp/yaha_bench_cache; X=$C/g100m_s42.X15_01_65525S
-READS=$C/e2e_n262144_l1000_s3000.fa
-[ -f $READS ] || $R/tools/yaha_sim reads --genome $C/g100m_s42.fa --out $READS --seed 3000 --n 262144 --len 1000 --div 0.017
+R=$GRAFT_REPO_ROOT; C=/tmp/yaha_bench_cache; X=$C/${YAHA_PARITY_GENOME:-g100m_s42}.X15_01_65525S
+READS=$C/e2e_${YAHA_PARITY_GENOME:-g100m_s42}_n262144.fa
+[ -f $READS ] || $R/tools/yaha_sim reads --genome $C/${YAHA_PARITY_GENOME:-g100m_s42}.fa --out $READS --seed 3000 --n 262144 --len 1000 --div 0.017
 head -32 $READS > $C/tiny.fa
 if [ $# -eq 0 ]; then set -- "-ctx 2 -batch 8192" "-ctx 3 -batch 8192" "-ctx 2 -batch 4096" "-ctx 4 -batch 4096" "-ctx 3 -batch 16384"; fi
 for opts in "$@"; do
