@@ -373,9 +373,16 @@ __device__ __forceinline__ PkRec pkLoadRec(YD_GLOBAL const uint32_t *cp) { const
 __device__ __forceinline__ int pkRecWord(int n) { return ((n - 1) >> 3) * 32 + ((n - 1) & 7) * 4; }
 __device__ __forceinline__ bool pkContE(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6; return ((d >> (8 * h + bit)) & 1u) == 0u; }
 __device__ __forceinline__ bool pkContF(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6; return ((d >> (16 + 8 * h + bit)) & 1u) == 0u; }
+#define YD_TSTRIDE 36          // dwords per problem in the traceback's block cache (32 + padding; 16-byte aligned).  (32 with an XOR swizzle -- a fifth workgroup per CU -- was no faster.)
 __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
 {
+    // The 64 lanes of a wave read 64 different 128-byte blocks per pass.  Read by their own lanes -- eight 8-byte pieces each -- that is 512 line requests a
+    // pass, and the kernel's time followed the number of such requests, not the bytes.  Here the wave fetches the blocks TOGETHER: eight loads of 16 bytes per
+    // lane, each covering eight whole blocks (eight lanes per block), through LDS ([problem][36 dwords], 36 KB a workgroup); a lane then reads its own records there, and a gap
+    // run that stays inside the block needs no further load.
+    __shared__ uint32_t sBlkT[4][64 * YD_TSTRIDE];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId();
+    uint32_t *const wBlk = sBlkT[threadIdx.x >> 6]; const uint32_t *const myRec = wBlk + lane * YD_TSTRIDE;
     if (*toGlobal(A.errFlag) != 0) return;
     const bool live = t < A.nProb;
     const uint32_t p = live ? ((A.order && !(A.dbgMode & 2)) ? A.order[t] : t) : 0u;
@@ -385,14 +392,19 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
     constexpr int leftR = YD_LBAND;
     int n = 0; bool bad = false; int E = 0;
     ExtStrip S; S.arena = toGlobal(A.trace); S.cIdx = -1; S.cBase = S.arena; S.f0 = 0; S.laneOff = 0; S.tab = toGlobal(A.waveChunks); S.limit = 0; S.wild = false;
+    struct Cur { YD_GLOBAL uint32_t *cp; int rr, w; unsigned fb; };
+    int y = 0, x = 0, prev = -1, acc = 0, row0w = 0;
+    Cur u; u.cp = S.arena; u.rr = 0; u.w = 0; u.fb = 0;
     if (walk) {
         const int ph = (int)(r.where & 15u);
         S.f0 = r.opsOff; S.laneOff = ((r.where >> 4) & 63u) * YD_LANE_DWORDS; S.tab = toGlobal(A.waveChunks) + (size_t)(r.where >> 10) * A.maxCh;
         E = pkRecWord(r.maxi + 2 + ph) + 4; S.limit = E;                         // record maxi + 2 is the spare one (computed, or the idle slot behind the problem)
-        int y = r.maxi, x = r.maxj, prev = -1, acc = 0;
+        y = r.maxi; x = r.maxj;
         // physical cursor on the record of the current cell (record y + h): cp = its first dword, rr = its slot in the block, w = its logical offset, fb = its flush
-        struct Cur { YD_GLOBAL uint32_t *cp; int rr, w; unsigned fb; };
-        Cur u; { const int idx = y + (x >= YD_NP ? 1 : 0) - 1 + ph; u.rr = idx & 7; u.w = (idx >> 3) * 32 + u.rr * 4; u.fb = S.f0 + (unsigned)(idx >> 3); u.cp = S.at(u.w); }
+        { const int idx = y + (x >= YD_NP ? 1 : 0) - 1 + ph; u.rr = idx & 7; u.w = (idx >> 3) * 32 + u.rr * 4; u.fb = S.f0 + (unsigned)(idx >> 3); u.cp = S.at(u.w); }
+        row0w = pkRecWord(1 + ph) - 4;                                      // with the cursor there every record is consumed
+    }
+    {
         auto stepUp = [&](Cur &c) {                                          // one record towards the origin (a lane's blocks are consecutive inside a chunk)
             c.w -= 4;
             if (c.rr != 0) { c.rr--; c.cp -= 4; return; }
@@ -400,19 +412,35 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
             if (c.fb % YD_CHUNK_FLUSHES == YD_CHUNK_FLUSHES - 1u) c.cp = S.arena + (size_t)S.tab[c.fb / YD_CHUNK_FLUSHES] * YD_CHUNK_DWORDS + S.laneOff + (YD_CHUNK_FLUSHES - 1u) * 32u + 28u;
             else c.cp -= 4;
         };
-        const int row0w = pkRecWord(1 + ph) - 4;                                // with the cursor there every record is consumed
         // free for staging: the records above record (cursor + 1) -- the record after the cursor's may still hold the high half of the cursor's row
         auto flush = [&]() { const int wp = E - 1 - n; if (wp < u.w + 8) bad = true; else *S.at(wp) = opMake(prev, acc); n++; };
         auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
-        for (int guard = 0; guard < 70000 && y > 0 && x >= 0 && x < YD_LW; guard++) {
+        for (int guard = 0;; guard++) {
+            const bool act = walk && guard < 70000 && y > 0 && x >= 0 && x < YD_LW;
+            if (__ballot(act) == 0ull) break;                                  // wave-uniform
+            {   // the wave's 64 current blocks -> LDS
+                const unsigned long long myBase = (unsigned long long)(act ? u.cp - u.rr * 4 : S.arena);
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    const int src = g * 8 + (lane >> 3);
+                    const unsigned long long b = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(myBase >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myBase, src, 64);
+                    const yd_u32x4 v = *(YD_GLOBAL const yd_u32x4 *)((YD_GLOBAL const uint32_t *)b + (lane & 7) * 4);
+                    *(yd_u32x4 *)(wBlk + src * YD_TSTRIDE + (lane & 7) * 4) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!act) continue;
+            const int rr0 = u.rr;                                            // the cursor's slot when the block was fetched
+            auto blkRec = [&](int slot, YD_GLOBAL const uint32_t *cp) -> PkRec {  // the record in `slot` of the fetched block, or (slot < 0: a block further up) the one at cp
+                if (slot >= 0) { const uint32_t *q = myRec + slot * 4; PkRec r2; r2.ab2 = q[0]; r2.m = q[1]; r2.a = q[2]; r2.b = q[3]; return r2; }
+                return pkLoadRec(cp);
+            };
             const int h = x >= YD_NP ? 1 : 0, k = x - YD_NP * h;
             const int second = k < 8 ? 0 : 1, bt = k < 8 ? k : k - 3, sT = 8 * h + bt, sU = 16 + sT, sM = 16 * h + 10 - k;
             uint32_t dTU[YD_TRACE_DEPTH], dM[YD_TRACE_DEPTH];
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
             int lim = u.rr + 1; lim = lim < y ? lim : y;                      // to the start of the 128-byte block: a line is fetched once, by one batch
-            { YD_GLOBAL uint32_t *up = u.cp;
 #pragma unroll
-              for (int d = 0; d < YD_TRACE_DEPTH; d++) { const u32x2 v = *(YD_GLOBAL const u32x2 *)(up + (second ? 0 : 1)); dTU[d] = second ? v.x : v.y; dM[d] = second ? v.y : v.x; up -= (d + 1 < lim) ? 4 : 0; } }
+            for (int d = 0; d < YD_TRACE_DEPTH; d++) { const int sl = rr0 - d < 0 ? 0 : rr0 - d; dTU[d] = myRec[sl * 4 + (second ? 0 : 2)]; dM[d] = myRec[sl * 4 + 1]; }
             int took = 0, op = 0;
 #pragma unroll
             for (int d = 0; d < YD_TRACE_DEPTH; d++) {
@@ -426,33 +454,37 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
             }
             if (took == lim) { if (y > 0) stepUp(u); else u.w = row0w; continue; }
             if (op == OP_D) {                                                    // deletion run: the continue bits along the row, leftwards (the row's low half is one record up)
-                PkRec rb = pkLoadRec(u.cp);
+                int sl = rr0 - took;                                             // the cursor's slot in the fetched block
+                PkRec rb = blkRec(sl, u.cp);
                 int run = 1, xx = x, hh = h; Cur v = u;
                 for (;;) {
                     if (!pkContE(rb, xx - YD_NP * hh, hh)) break;
                     xx--; if (xx < 0) break;
                     run++;
-                    if (hh && xx < YD_NP) { hh = 0; stepUp(v); rb = pkLoadRec(v.cp); }
+                    if (hh && xx < YD_NP) { hh = 0; stepUp(v); rb = blkRec(--sl, v.cp); }
                 }
                 put(OP_D, run); x -= run;
                 if (h && x < YD_NP) stepUp(u);
             } else {                                                            // insertion run: the continue bits up and to the right
                 int run = 1, yy = y, xx = x, hh = h; Cur v = u;
-                PkRec rb = pkLoadRec(v.cp);
+                int sl = rr0 - took;
+                PkRec rb = blkRec(sl, v.cp);
                 while (pkContF(rb, xx - YD_NP * hh, hh)) {
                     yy--; xx++; if (yy <= 0 || xx >= YD_LW) break;
                     run++;
                     if (!hh && xx >= YD_NP) hh = 1;                              // (y-1, 11) is in the record of (y, 10)
-                    else { stepUp(v); rb = pkLoadRec(v.cp); }
+                    else { stepUp(v); rb = blkRec(--sl, v.cp); }
                 }
                 put(OP_I, run); y -= run; x += run;
                 const int h2 = x >= YD_NP ? 1 : 0, steps = run - (h2 - h);
                 if (y > 0) { for (int s = 0; s < steps; s++) stepUp(u); } else u.w = row0w;
             }
         }
+        if (walk) {
         if (y <= 0 && x > leftR) put(OP_D, x - leftR);                           // row 0: deletions back to the origin (SW.cpp:905-935)
         if (prev >= 0) { const int wp = E - 1 - n; if (wp < 0) bad = true; else *S.at(wp) = opMake(prev, acc); n++; }
         if (bad || S.wild) { bad = true; atomicCAS(A.errFlag, 0, (int)YERR_TRACE); n = 0; }
+        }
     }
     if (A.dbgMode & 1) n = 0;
     const bool inPlace = walk && !bad && n > 0 && (S.f0 + (unsigned)((E - n) >> 5)) / YD_CHUNK_FLUSHES == (S.f0 + (unsigned)((E - 1) >> 5)) / YD_CHUNK_FLUSHES;
