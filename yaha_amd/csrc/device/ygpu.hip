@@ -50,9 +50,7 @@ struct DevBuf {
     int ensure(size_t bytes, bool keep = false, hipStream_t st = 0)
     {
         if (bytes <= cap) return 0;
-        // head room: a regrowth is a hipMalloc + hipFree -- a device-wide synchronisation that stalls the sibling contexts too; buffers below 256 MB get twice
-        // their need (batches differ by +-10 %: with 25 % the first dozen batches of a run kept regrowing one buffer or another), large ones 25 %
-        size_t ncap = (bytes < (256ull << 20) ? 2 * bytes : bytes + bytes / 4) + 256; void *np = nullptr;
+        size_t ncap = bytes + bytes / 4 + 256; void *np = nullptr;
         if (hipMalloc(&np, ncap) != hipSuccess) return -1;
         if (keep && p && cap) { hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st); hipStreamSynchronize(st); }
         if (p) hipFree(p);
