@@ -64,3 +64,18 @@ def test_cli_index_then_usage(work, tmp_path):
     assert r.returncode == 0 and b"Usage" in r.stderr
     r = subprocess.run([ya.CLI_PATH, "-x", "nonexistent.X11_01_65525S", "-q", "none.fa"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0
+
+
+def test_bench_picks_the_genome_the_box_can_hold(tmp_path, monkeypatch):
+    # bench.py's default workload is G-hg18scale (3.1 Gbp) when the box has the disk and memory for it, else the 100 Mbp genome; a cache that already holds
+    # the 3.1 Gbp index is always used
+    import importlib, sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    import shutil as _sh
+    usage = type("U", (), {})
+    small = usage(); small.free = 10 << 30
+    monkeypatch.setattr(_sh, "disk_usage", lambda p: small)
+    assert bench.pick_genome_mbp(str(tmp_path), 42) == 100
+    (tmp_path / "g3100m_s42.X15_01_65525S.done").write_text("ok")
+    assert bench.pick_genome_mbp(str(tmp_path), 42) == 3100
