@@ -438,16 +438,17 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 // read 64 different chunks); so the problems are grouped by the ARENA CHUNK their strip starts in (the wave of k_ext_rows that ran them and the chunk it was
 // writing) and sorted by walk length, descending, inside the group: lanes of a wave read one chunk and walk paths of similar length.
 // key = arena region (physical chunk >> regionLog) | length bucket : 5 (32 buckets of the longest read's length: two radix passes for the bench batch)
-__global__ void k_trace_keys(const ExtRes *res, const uint32_t *order, uint32_t n, const uint32_t *waveChunks, uint32_t maxCh, int regionLog, int lenShift, uint32_t *keys, uint32_t *vals)
+__global__ void k_trace_keys(const ExtRes *res, const uint32_t *order, uint32_t n, const uint32_t *waveChunks, uint32_t maxCh, int regionLog, int lenShift, int lenBits, uint32_t *keys, uint32_t *vals)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t p = order ? order[t] : t;
     const ExtRes r = res[p];
-    const uint32_t len = r.score > 0 ? min((uint32_t)r.maxi >> lenShift, 31u) : 0u;
+    const uint32_t top = (1u << lenBits) - 1u;
+    const uint32_t len = r.score > 0 ? min((uint32_t)r.maxi >> lenShift, top) : 0u;
     const uint32_t ci = r.opsOff / YD_CHUNK_FLUSHES;
-    const uint32_t phys = (r.score > 0 && ci < maxCh) ? waveChunks[(size_t)(r.where >> 10) * maxCh + ci] : 0u;
-    keys[t] = (min(phys >> regionLog, 0x7FFFFFFu) << 5) | (31u - len);
+    const uint32_t phys = (regionLog < 20 && r.score > 0 && ci < maxCh) ? waveChunks[(size_t)(r.where >> 10) * maxCh + ci] : 0u;     // (regionLog >= 20: one region)
+    keys[t] = (min(phys >> regionLog, 0xFFFFFFu) << lenBits) | (top - len);
     vals[t] = p;
 }
 

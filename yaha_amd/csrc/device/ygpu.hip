@@ -422,7 +422,10 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     auto rowsKernel = pk ? k_ext_rows_pk<false> : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
     auto rowsKernel2 = pk ? k_ext_rows_pk<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
     auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace;
-    static const int traceSort = getenv("YGPU_TRACE_SORT") ? atoi(getenv("YGPU_TRACE_SORT")) : 7;    // the traceback's order: 0 k_ext_rows' order, n > 0: by arena region of 2^n chunks, then by walk length
+    // the traceback's order: 0 = k_ext_rows' order; n > 0: by arena region of 2^n chunks, then by walk length (YGPU_TRACE_LENBITS bits).  With the wave-wide block
+    // fetch of k_ext_trace_pk a wave walks in lock step, so what counts is that its lanes' walks are equally long: the default is the length alone (n = 20: one region),
+    // in 128 classes -- one radix pass (3.1 Gbp, three contexts: 52.0 ms a step with regions of 128 chunks and 32 classes, 57.3 in the rows kernel's order, 51.2 so)
+    static const int traceSort = getenv("YGPU_TRACE_SORT") ? atoi(getenv("YGPU_TRACE_SORT")) : 20;
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     const unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU), maxWavesK = maxBlocksK * 4u;
@@ -531,9 +534,10 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         }
         if (traceSort > 0 && np > 4096u) {                                    // traceback order: by arena region, then by walk length (k_trace_keys)
             uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
-            int lenShift = 0; while ((ctx->maxQ >> lenShift) > 31) lenShift++;
-            int keyBits = 5; while (keyBits < 32 && ((unsigned long long)E.nChunks >> traceSort) >> (keyBits - 5)) keyBits++;        // region bits above the five length bits
-            KL(k_trace_keys, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E.res, E.order, np, E.waveChunks, E.maxCh, traceSort, lenShift, k0, v0);
+            static const int lenBits = getenv("YGPU_TRACE_LENBITS") ? std::min(8, std::max(1, atoi(getenv("YGPU_TRACE_LENBITS")))) : 7;
+            int lenShift = 0; while ((ctx->maxQ >> lenShift) > (1 << lenBits) - 1) lenShift++;
+            int keyBits = lenBits; while (keyBits < 32 && ((unsigned long long)E.nChunks >> std::min(traceSort, 31)) >> (keyBits - lenBits)) keyBits++;        // region bits above the length bits
+            KL(k_trace_keys, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E.res, E.order, np, E.waveChunks, E.maxCh, std::min(traceSort, 31), lenShift, lenBits, k0, v0);
             size_t bytes = 0;
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, keyBits, ctx->stream));
             if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
