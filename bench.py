@@ -219,6 +219,53 @@ def end_to_end(ya, idx, fa, cache, n_reads, seed):
     return {"reads": n_reads, "seconds": dt, "e2e_reads_per_s": n_reads / dt, "seconds_each_run": runs, "sam_records": nrec, "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam (defaults: -ctx 2 -batch 4096)" % n_reads}
 
 
+def stub_rank(args, rank, world):
+    """YAHA_BENCH_STUB=1 (tests only, CPU tier): the launch / rendezvous / barrier / max-over-ranks / one-JSON-line plumbing of the N > 1 path with a
+    sleep in place of the device step -- no GPU, gloo instead of RCCL.  Never a measurement: the line says so."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    d = dist if world > 1 else None
+    if d: d.barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+    if d: d.barrier()
+    dt = max_over_ranks(time.time() - t0, d, device="cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (no device): launch-path test only", "value": world * args.reads_per_gpu * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "stub"}, "ranks_seen": world}), flush=True)
+    if d:
+        d.barrier(); d.destroy_process_group()
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes (torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1) before this process has touched a GPU -- it never does -- and relay rank 0's JSON line.  A process that has initialised the
+    GPU is never replaced by another program (the pool forbids that exec); the parent stays a plain supervisor and exits with the children's code."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    log("starting %d ranks: %s" % (n, " ".join(cmd)))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in p.stdout:                                   # rank 0 prints exactly one JSON line; anything else on stdout is passed on to stderr
+        t = out.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0 or line is None:
+        raise SystemExit(rc if rc != 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,7 +283,13 @@ def main():
     ap.add_argument("--contexts", type=int, default=3, help="device contexts (batches in flight) per GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])       # nothing above has imported torch or touched a GPU
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        log("--gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs" % (args.gpus, world))
+    if os.environ.get("YAHA_BENCH_STUB"):
+        return stub_rank(args, rank, world)
     import torch
     dist = None
     if world > 1:

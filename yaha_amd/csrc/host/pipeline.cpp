@@ -19,7 +19,7 @@
 using namespace yaha;
 
 struct yaha_session {
-    Args args; Genome genome; IndexFile index; ReadReader reader; std::string err, header, text;
+    Args args; Genome genome; IndexFile index; ReadReader reader; std::string err, header; Text text;
     std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
     bool readerOpen = false;
 };
@@ -88,37 +88,29 @@ static bool sessionLoad(yaha_session *s)
     return true;
 }
 
-// OQC/FBS filter + SAM text of one batch.  nt > 1: the reads of the batch are shared out to nt threads (the ctypes/Session path, one
+// OQC/FBS filter + SAM text of one batch.  nt > 1: the reads of the batch are cut into nt contiguous ranges, one thread each (the ctypes/Session path, one
 // batch at a time); the command line formats whole batches on a pool of threads instead (runQueries) and passes nt = 1.
-static void formatBatch(yaha_session *s, const ygpu_result_batch *r, std::string &text, int nt)
+static void formatRange(const yaha_session *s, const ygpu_result_batch *r, uint32_t i0, uint32_t i1, Text &text, std::vector<OutClump> &oc)
 {
-    const Args &a = s->args; const uint32_t n = r->n_reads;
-    if (nt <= 1) {                                                       // one thread, one batch: straight into the batch's text (its buffer is reused from batch to batch)
-        text.clear(); if (text.capacity() < (size_t)n * 1024) text.reserve((size_t)n * 1536);
-        std::vector<OutClump> oc;
-        for (uint32_t i = 0; i < n; i++) {
-            uint32_t c0 = r->clump_start[i], c1 = r->clump_start[i + 1]; int primaryCount = 0;
-            postFilter(a, s->genome, s->reads[i], r->clumps + c0, c1 - c0, r->ops, oc, primaryCount);
-            for (auto &o : oc) printClump(a, s->genome, s->reads[i], o, primaryCount, text);
-        }
-        return;
+    const Args &a = s->args;
+    for (uint32_t i = i0; i < i1; i++) {
+        uint32_t c0 = r->clump_start[i], c1 = r->clump_start[i + 1]; int primaryCount = 0;
+        postFilter(a, s->genome, s->reads[i], r->clumps + c0, c1 - c0, r->ops, oc, primaryCount);
+        for (auto &o : oc) printClump(a, s->genome, s->reads[i], o, primaryCount, text);
     }
-    std::vector<std::string> parts(n);
-    std::atomic<uint32_t> next(0);
-    auto work = [&]() {
-        std::vector<OutClump> oc;
-        for (;;) {
-            uint32_t i = next.fetch_add(1); if (i >= n) break;
-            uint32_t c0 = r->clump_start[i], c1 = r->clump_start[i + 1]; int primaryCount = 0;
-            postFilter(a, s->genome, s->reads[i], r->clumps + c0, c1 - c0, r->ops, oc, primaryCount);
-            for (auto &o : oc) printClump(a, s->genome, s->reads[i], o, primaryCount, parts[i]);
-        }
-    };
+}
+static void formatBatch(yaha_session *s, const ygpu_result_batch *r, Text &text, int nt)
+{
+    const uint32_t n = r->n_reads;
+    text.clear();
+    if (nt <= 1 || n < 2 * (uint32_t)nt) { std::vector<OutClump> oc; formatRange(s, r, 0, n, text, oc); return; }   // straight into the batch's text (its buffer is reused from batch to batch)
+    std::vector<Text> parts(nt);
+    auto work = [&](int t) { std::vector<OutClump> oc; formatRange(s, r, (uint32_t)((uint64_t)n * t / nt), (uint32_t)((uint64_t)n * (t + 1) / nt), parts[t], oc); };
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work(); for (auto &x : th) x.join();
-    size_t tot = 0; for (auto &p : parts) tot += p.size();
-    text.clear(); text.reserve(tot); for (auto &p : parts) text += p;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0); for (auto &x : th) x.join();
+    size_t tot = 0; for (auto &p : parts) tot += p.len;
+    text.room(tot); for (auto &p : parts) text.append(p.p, p.len);
 }
 
 namespace {
@@ -172,7 +164,7 @@ int runQueries(Args &a, FILE *log)
     const int nParse = std::max(1, std::min(std::min(8, 2 * nDev), hw / 2)), nFmt = std::max(std::max(1, A.numThreads), std::min(std::max(1, hw / 2), 8 * nDev));
     StageQueue<BatchP> parseQ((size_t)nParse + 2, 1), inQ((size_t)ngpu + 2, nParse), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu + nParse);
     std::mutex outMu; uint64_t nextOut = 0; std::atomic<bool> stop(false); std::atomic<int> rcAll(0);
-    std::map<uint64_t, std::string> done;
+    std::map<uint64_t, Text> done;
     const bool timing = getenv("YAHA_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto fail = [&](const char *what) { if (!stop.exchange(true)) fprintf(log, "%s -- stopping; the output ends with the last batch completed before this one.\n", what); rcAll = 1; };
@@ -237,7 +229,7 @@ int runQueries(Args &a, FILE *log)
         BatchP b;
         while (fmtQ.pop(b)) {
             if (stop) continue;
-            const double t0 = now(); std::string text;
+            const double t0 = now(); Text text;
             if (!b->reads.empty()) {
                 ygpu_result_batch res; memset(&res, 0, sizeof res);
                 res.n_reads = (uint32_t)b->reads.size(); res.clump_start = b->clumpStart.data(); res.clumps = b->clumps.data(); res.ops = b->ops.data(); res.n_clumps = b->nClumps; res.n_ops = b->nOps;
@@ -247,8 +239,8 @@ int runQueries(Args &a, FILE *log)
             std::unique_lock<std::mutex> lk(outMu);
             done[b->ticket] = std::move(text);
             while (!stop && !done.empty() && done.begin()->first == nextOut) {
-                const std::string &t = done.begin()->second;
-                if (!t.empty() && fwrite(t.data(), 1, t.size(), out) != t.size()) { fail("Failure writing the output file"); break; }
+                const Text &t = done.begin()->second;
+                if (t.len && fwrite(t.p, 1, t.len, out) != t.len) { fail("Failure writing the output file"); break; }
                 done.erase(done.begin()); nextOut++;
             }
         }
@@ -301,7 +293,7 @@ int yaha_session_next_batch(yaha_session *s, uint32_t max_reads, ygpu_read_batch
 int yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **text, size_t *len)
 {
     if (r->n_reads != s->reads.size()) { s->err = "result batch does not match the current read batch"; return YGPU_EINVAL; }
-    formatBatch(s, r, s->text, std::max(1, s->args.numThreads)); *text = s->text.c_str(); *len = s->text.size(); return 0;
+    formatBatch(s, r, s->text, std::max(1, s->args.numThreads)); *s->text.room(1) = 0; *text = s->text.p; *len = s->text.len; return 0;
 }
 int yaha_build_index(int argc, const char *const *argv)
 {

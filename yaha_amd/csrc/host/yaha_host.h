@@ -9,6 +9,9 @@
 #include <string>
 #include <vector>
 #include <memory>
+#include <cstdlib>
+#include <cstring>
+#include <new>
 #include "../../../include/yaha_hip.h"
 
 namespace yaha {
@@ -114,7 +117,21 @@ struct OutClump {                                        // one clump as it reac
 // clumps: QS->clumps head->tail after postProcessClumps.  Result: print order.  primaryCount = QS->primaryCount.
 void postFilter(const Args &a, const Genome &g, const Read &r, const ygpu_clump *clumps, uint32_t n, const uint32_t *ops,
                 std::vector<OutClump> &out, int &primaryCount);
-void printClump(const Args &a, const Genome &g, const Read &r, const OutClump &oc, int primaryCount, std::string &out);
+// Output text of a batch: a plain growable byte buffer that is reused from batch to batch (no zero-fill on growth, no per-record allocation; a formatter
+// thread keeps its buffers, so that the steady state touches no allocator and maps no new pages).
+struct Text {
+    char *p = nullptr; size_t len = 0, cap = 0;
+    Text() {} Text(const Text &) = delete; Text &operator=(const Text &) = delete;
+    Text(Text &&o) noexcept : p(o.p), len(o.len), cap(o.cap) { o.p = nullptr; o.len = o.cap = 0; }
+    Text &operator=(Text &&o) noexcept { if (this != &o) { free(p); p = o.p; len = o.len; cap = o.cap; o.p = nullptr; o.len = o.cap = 0; } return *this; }
+    ~Text() { free(p); }
+    void clear() { len = 0; }
+    char *room(size_t n) { if (len + n > cap) grow(len + n); return p + len; }      // at least n writable bytes at the end
+    void append(const char *s, size_t n) { memcpy(room(n), s, n); len += n; }
+  private:
+    void grow(size_t need) { size_t c = cap ? cap : (1u << 16); while (c < need) c += c / 2; char *q = (char *)realloc(p, c); if (!q) throw std::bad_alloc(); p = q; cap = c; }
+};
+void printClump(const Args &a, const Genome &g, const Read &r, const OutClump &oc, int primaryCount, Text &out);
 
 // ---- whole-run driver (replacement of processQueryFile, Query.c:551-709) --------------------------------
 int runQueries(Args &a, FILE *log);
