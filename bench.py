@@ -118,31 +118,51 @@ def head_reads(src, dst, n):
             o.write(line)
 
 
-def cpu_baseline(idx, reads_path, n_reads, cache, target_s):
-    """reference yaha on a bounded sample of the same reads: best of -t {32, 64, 128, all cores} (the reference serialises its readers on a file
-    lock, so more threads than it can feed are slower); wall time minus a zero-work run (index mmap pre-touch)."""
+def usable_cpus():
+    """CPUs this process may really use: affinity mask and the control group's CPU quota (a 256-thread box with cpu.max = 16 CPUs runs 16 threads' worth)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(idx, fa, reads_path, n_reads, cache, target_s, read_len, div):
+    """reference yaha on a bounded sample of the same workload (same simulator, genome, read length and divergence; its own seed so that it can be longer than one
+    batch): best of -t {q, 2q, 4q}, q = the CPUs this box lets the process use (the reference serialises its readers on a file lock, and threads beyond the
+    control group's quota only get throttled); at least target_s / 3 seconds of reference run time per thread count; wall time minus a one-read run (index
+    mmap pre-touch)."""
     import oracle
     cores = os.cpu_count() or 1
+    q = usable_cpus()
     if oracle.have_reference():
         one = os.path.join(cache, "one_read.fa")
         head_reads(reads_path, one, 1)
-        t = time.time(); oracle.run_reference(["-x", idx, "-q", one, "-osh", "/dev/null", "-t", str(cores)]); t_zero = time.time() - t
+        t = time.time(); oracle.run_reference(["-x", idx, "-q", one, "-osh", "/dev/null", "-t", str(q)]); t_zero = time.time() - t
         probe = os.path.join(cache, "probe.fa")
-        n_probe = min(n_reads, 4 * cores)
+        n_probe = min(n_reads, 64 * q)
         head_reads(reads_path, probe, n_probe)
-        t = time.time(); oracle.run_reference(["-x", idx, "-q", probe, "-osh", "/dev/null", "-t", str(cores)]); t_probe = max(time.time() - t - t_zero, 1e-3)
-        threads = sorted(set(t for t in (32, 64, 128, cores) if t <= cores)) or [cores]
-        n = int(min(n_reads, max(n_probe, (target_s / len(threads)) * n_probe / t_probe)))
-        sample = os.path.join(cache, "sample.fa")
-        head_reads(reads_path, sample, n)
+        t = time.time(); oracle.run_reference(["-x", idx, "-q", probe, "-osh", "/dev/null", "-t", str(2 * q)]); t_probe = max(time.time() - t - t_zero, 1e-3)
+        threads = sorted(set(min(t, cores) for t in (q, 2 * q, 4 * q)))
+        n = int(min(262144, max(n_probe, (target_s / len(threads)) * n_probe / t_probe)))
+        n = (n + 1023) // 1024 * 1024
+        sample = make_reads(cache, fa, "cpu", n, read_len, div, 4000)
         by_t = {}
         for nt in threads:
             t = time.time(); oracle.run_reference(["-x", idx, "-q", sample, "-osh", "/dev/null", "-t", str(nt)]); dt = max(time.time() - t - t_zero, 1e-3)
             by_t[nt] = n / dt
         best = max(by_t, key=lambda k: by_t[k])
-        return {"value": by_t[best], "unit": "reads/s", "cores": best, "kind": "reference", "host_cores": cores, "reads_per_s_by_threads": {str(k): v for k, v in by_t.items()},
-                "sample": "%d of the same 1 kbp reads, oracle/_ref/yaha (whole program: reader, hot path, OQC, SAM to /dev/null) at -t %s, best = -t %d; wall minus a %.1fs zero-read run"
-                          % (n, "/".join(str(t) for t in threads), best, t_zero)}
+        return {"value": by_t[best], "unit": "reads/s", "cores": best, "kind": "reference", "host_cores": cores, "usable_cpus": q, "reads_per_s_by_threads": {str(k): v for k, v in by_t.items()},
+                "sample": "%d reads of the same workload (%d bp, same simulator and genome, seed 4000), oracle/_ref/yaha (whole program: reader, hot path, OQC, SAM to /dev/null) at -t %s, best = -t %d; "
+                          "wall minus a %.1fs one-read run; the box shows %d hardware threads and lets the process use %d CPUs (control-group quota)"
+                          % (n, read_len, "/".join(str(t) for t in threads), best, t_zero, cores, q)}
     import yaha_amd as ya
     with ya.Session(["-x", idx, "-q", reads_path]) as s:
         b = s.next_batch(min(n_reads, 64 * cores))
@@ -198,25 +218,32 @@ def side_workload(ya, idx, reads_path, n_reads, device, contexts, steps, label):
             "k_ext_rows_ms_per_step": st.get("ext_rows_device_clock", 0.0) / steps, "dp_cells_per_read": (cnt["dp_ext_cells"] + cnt["dp_gap_cells"]) / max(n, 1), "hits_per_read": cnt["hits"] / max(n, 1)}
 
 
-def end_to_end(ya, idx, fa, cache, n_reads, seed):
-    """The whole `yaha` command line (process start, index mmap + upload, input parsing, device, OQC, SAM text to a file in /dev/shm)."""
+def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1):
+    """The whole `yaha` command line with its defaults (process start, index mmap + upload to every device, input parsing, device, OQC, SAM text to a file in
+    /dev/shm) on n_reads x 1 kbp reads -- BASELINE config 4's size by default -- over `gpus` devices.  `steady_reads_per_s` is the command line's own figure
+    (YAHA_STATS=1): reads written after the first batch / time between the first and the last batch's write, i.e. without start-up."""
     reads = make_reads(cache, fa, "e2e", n_reads, 1000, 0.017, seed)
     out = "/dev/shm/yaha_bench_e2e_%d.sam" % os.getpid()
     tiny = os.path.join(cache, "tiny.fa")
     head_reads(reads, tiny, 16)
+    more = ["-gpus", str(gpus)] if gpus > 1 else []
+    env = dict(os.environ, YAHA_STATS="1")
     try:
-        subprocess.run([ya.CLI_PATH, "-x", idx, "-q", tiny, "-osh", out], stderr=subprocess.DEVNULL, check=True)      # absorbs part of the driver's scrubbing of the memory the bench contexts freed
-        runs = []
+        subprocess.run([ya.CLI_PATH, "-x", idx, "-q", tiny, "-osh", out] + more, stderr=subprocess.DEVNULL, check=True)      # absorbs part of the driver's scrubbing of the memory the bench contexts freed
+        runs, stats = [], []
         for _ in range(2):                               # the first run still pays for that scrubbing (a property of what ran before, not of the command line): best of two, both reported
             t = time.time()
-            subprocess.run([ya.CLI_PATH, "-x", idx, "-q", reads, "-osh", out], stderr=subprocess.DEVNULL, check=True)
+            p = subprocess.run([ya.CLI_PATH, "-x", idx, "-q", reads, "-osh", out] + more, stderr=subprocess.PIPE, check=True, env=env)
             runs.append(time.time() - t)
-        dt = min(runs)
+            st = [l for l in p.stderr.decode().split("\n") if l.startswith("[yaha] stats ")]
+            stats.append(json.loads(st[0][len("[yaha] stats "):]) if st else {})
+        best = min(range(len(runs)), key=lambda i: runs[i]); dt = runs[best]
         nrec = sum(1 for l in open(out) if not l.startswith("@"))
     finally:
         if os.path.exists(out):
             os.remove(out)
-    return {"reads": n_reads, "seconds": dt, "e2e_reads_per_s": n_reads / dt, "seconds_each_run": runs, "sam_records": nrec, "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam (defaults: -ctx 2 -batch 4096)" % n_reads}
+    return {"reads": n_reads, "gpus": gpus, "seconds": dt, "e2e_reads_per_s": n_reads / dt, "steady_reads_per_s": stats[best].get("steady_reads_per_s"), "seconds_each_run": runs, "sam_records": nrec, "cli_stats": stats[best],
+            "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam%s (defaults: -ctx 3, batches of ~16 M bases, host threads from the usable CPUs)" % (n_reads, " -gpus %d" % gpus if gpus > 1 else "")}
 
 
 def stub_rank(args, rank, world):
@@ -276,10 +303,10 @@ def main():
     ap.add_argument("--genome-mbp", type=int, default=0, help="synthetic genome size; 0 = G-hg18scale (3 100 Mbp: the index the metric is quoted on) when the box has the disk and memory for it, else 100")
     ap.add_argument("--div", type=float, default=0.017)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="CPU-baseline budget (wall seconds of the reference over all its thread counts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs measured after the timed region (other read lengths, D2H-inclusive rate, command line)")
-    ap.add_argument("--e2e-reads", type=int, default=262144)
+    ap.add_argument("--e2e-reads", type=int, default=1048576, help="reads of the end-to-end command-line leg (BASELINE config 4: 1 M x 1 kbp)")
     ap.add_argument("--contexts", type=int, default=3, help="device contexts (batches in flight) per GPU")
     args = ap.parse_args()
 
@@ -357,6 +384,8 @@ def main():
         for c in reversed(ctxs):
             c.close()
     dt = max_over_ranks(dt, dist)
+    if dist is not None:
+        dist.barrier()                                   # every rank has closed its contexts: the devices are free for the command-line leg below
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -440,12 +469,19 @@ def main():
         out["workloads"] = wl
         try:
             out["end_to_end"] = end_to_end(ya, idx, fa, cache, args.e2e_reads, 3000)
-            out["e2e_reads_per_s"] = out["end_to_end"]["e2e_reads_per_s"]
+            out["e2e_reads_per_s"] = out["end_to_end"]["e2e_reads_per_s"]; out["steady_reads_per_s"] = out["end_to_end"]["steady_reads_per_s"]
         except Exception as e:
             out["end_to_end"] = {"error": str(e)[:200]}
+    if world > 1 and not args.no_extras:
+        # N > 1: the whole command line over the N devices (`yaha -gpus N`, one process, N x 3 contexts, index image uploaded to every device), the other ranks idle
+        try:
+            out["end_to_end"] = end_to_end(ya, idx, fa, cache, args.e2e_reads, 3000, gpus=world)
+            out["e2e_reads_per_s"] = out["end_to_end"]["e2e_reads_per_s"]; out["steady_reads_per_s"] = out["end_to_end"]["steady_reads_per_s"]
+        except Exception as e:
+            out["end_to_end"] = {"error": str(e)[:300]}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(idx, reads_path, n_reads, cache, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(idx, fa, reads_path, n_reads, cache, args.cpu_seconds, args.read_len, args.div)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the measurement
             out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": os.cpu_count(), "kind": "error", "sample": str(e)[:200]}
     print(json.dumps(out), flush=True)

@@ -56,3 +56,25 @@ def test_two_ranks_shard_and_merge(work, index11, tmp_path):
     merged = strip_pg(open(tmp_path / "merged.sam").read())
     assert merged == golden_lines("rchim_default")
     assert float(open(tmp_path / "tmax.txt").read()) == 2.0
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's form) must start two ranks itself -- as child processes, the parent never touches a
+    GPU -- and relay rank 0's single JSON line with n_gpus == 2.  YAHA_BENCH_STUB=1 swaps the device step for a sleep and RCCL for gloo: launch path only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["YAHA_BENCH_STUB"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["steps"] == 3 and j["warmup"] == 1
+    assert j["ms_per_step"] >= 4.0                      # the max over ranks (rank 1 sleeps 4 ms a step), not rank 0's 2 ms
+    # under an external launcher (WORLD_SIZE set) the same file is a rank, not a launcher: one rank, no spawn
+    env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2"], env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p1.returncode == 0 and json.loads(p1.stdout.decode().strip())["n_gpus"] == 1

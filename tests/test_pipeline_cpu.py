@@ -1,0 +1,82 @@
+"""CPU tier: the command line's host pipeline as a whole (host/pipeline.cpp: splitter -> parsers -> context threads -> formatter pool -> ordered writer, recycled
+batch objects, -gpus N x -ctx M, failure handling), with the device entry points answered by a TEST DOUBLE backed by the oracle (tests/fixtures/oracle_device.cpp).
+The program is built here into a scratch directory -- once under ThreadSanitizer, once under AddressSanitizer + UBSan -- and its SAM is compared with the
+reference's golden output.  The HIP path itself is proven by the -m gpu tests; this file proves the host threads around it on a box without a GPU."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, golden_lines, strip_pg
+
+HOST = os.path.join(ROOT, "yaha_amd", "csrc", "host")
+SRCS = sorted(glob.glob(os.path.join(HOST, "*.cpp"))) + [os.path.join(ROOT, "yaha_amd", "csrc", "main.cpp"), os.path.join(ROOT, "tests", "fixtures", "oracle_device.cpp"),
+                                                          os.path.join(ROOT, "oracle", "hotpath.cpp")]
+
+
+def _build(tmp, san):
+    exe = os.path.join(tmp, "yaha_" + san.replace(",", "_"))
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-pthread", "-o", exe] + SRCS)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def exes(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("pipe"))
+    return {"tsan": _build(d, "thread"), "asan": _build(d, "address,undefined")}
+
+
+def _run(exe, args, env=None, stdin=None):
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1", **(env or {}))
+    return subprocess.run([exe] + args, env=e, stdin=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def _clean(p):
+    err = p.stderr.decode()
+    assert "ThreadSanitizer" not in err and "AddressSanitizer" not in err and "runtime error:" not in err, err[-4000:]
+
+
+@pytest.mark.parametrize("san", ["tsan", "asan"])
+@pytest.mark.parametrize("name,reads,extra", [
+    ("rchim_default", "rchim.fa", ["-batch", "37", "-gpus", "2", "-ctx", "2"]),            # many small batches over 4 contexts on 2 devices: ordering, pool recycling
+    ("r1k_default", "r1k.fa", []),                                                           # defaults: one batch of ~16 M bases, -ctx 3
+    ("rq_default", "rq.fq", ["-batch", "5", "-t", "3"]),                                     # FASTQ, explicit formatter count
+    ("r10k_default", "r10k.fa", ["-batch", "3", "-ctx", "1"]),
+])
+def test_command_line_pipeline_matches_the_reference(exes, work, index11, san, name, reads, extra):
+    p = _run(exes[san], ["-x", index11, "-q", os.path.join(work, reads), "-osh", "stdout"] + extra, env={"YTEST_DEVICES": "2", "YAHA_CPUS": "6"})
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    _clean(p)
+    assert strip_pg(p.stdout.decode()) == golden_lines(name)
+
+
+def test_stats_line_and_stdin(exes, work, index11):
+    with open(os.path.join(work, "rchim.fa"), "rb") as f:
+        p = _run(exes["tsan"], ["-x", index11, "-q", "stdin", "-osh", "stdout", "-batch", "50"], env={"YAHA_STATS": "1", "YAHA_READ_BLOCK": "997"}, stdin=f)
+    assert p.returncode == 0
+    _clean(p)
+    assert strip_pg(p.stdout.decode()) == golden_lines("rchim_default")
+    import json
+    line = [l for l in p.stderr.decode().split("\n") if l.startswith("[yaha] stats ")]
+    assert len(line) == 1
+    st = json.loads(line[0][len("[yaha] stats "):])
+    assert st["reads"] > 0 and st["last_batch_written_ms"] >= st["first_batch_written_ms"] > 0 and st["ctx_per_gpu"] == 3
+
+
+def test_a_device_failure_stops_the_run_cleanly(exes, work, index11):
+    # the third hot-path call fails: exit code 1, a message, and the output is a prefix of the good output that ends at a batch boundary
+    good = _run(exes["tsan"], ["-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", "stdout", "-batch", "20", "-ctx", "2"])
+    bad = _run(exes["tsan"], ["-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", "stdout", "-batch", "20", "-ctx", "2"], env={"YTEST_FAIL_RUN": "3"})
+    _clean(bad)
+    assert good.returncode == 0 and bad.returncode == 1
+    assert "hot path failed" in bad.stderr.decode() and "stopping" in bad.stderr.decode()
+    g, b = good.stdout.decode(), bad.stdout.decode()
+    assert len(b) < len(g) and g.startswith(b) and (b.endswith("\n") or b == "")
+
+
+def test_no_such_device(exes, work, index11):
+    p = _run(exes["asan"], ["-x", index11, "-q", os.path.join(work, "r1k.fa"), "-osh", "stdout", "-gpus", "2"], env={"YTEST_DEVICES": "1"})
+    _clean(p)
+    assert p.returncode == 1 and "ygpu_init(device 1) failed" in p.stderr.decode()

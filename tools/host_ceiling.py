@@ -8,8 +8,9 @@ root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, root)
 import yaha_amd as ya
 cache = os.environ.get("YAHA_BENCH_CACHE", "/tmp/yaha_bench_cache")
-X = os.path.join(cache, "g100m_s42.X15_01_65525S"); G = os.path.join(cache, "g100m_s42.fa")
-R = os.path.join(cache, "ceiling_262144.fa")
+tag = "g3100m_s42" if os.path.exists(os.path.join(cache, "g3100m_s42.X15_01_65525S.done")) else "g100m_s42"
+X = os.path.join(cache, tag + ".X15_01_65525S"); G = os.path.join(cache, tag + ".fa")
+R = os.path.join(cache, "ceiling_%s_262144.fa" % tag)
 if not os.path.exists(R):
     subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome", G, "--out", R, "--seed", "99", "--n", "262144", "--len", "1000", "--div", "0.017"])
 exe = os.path.join(root, "tools", "host_ceiling")
@@ -25,11 +26,13 @@ with ya.Session(["-x", X, "-q", R]) as s0:
     b0 = s0.next_batch(N)
     ctx = ya.Context(s0.index, s0.params)
     ctx.upload(b0); ctx.run(); r = ctx.collect()
-    for T in (1, 8, 16, 32, 64, 128):
+    import bench
+    print(json.dumps({"box": {"hardware_threads": os.cpu_count(), "usable_cpus": bench.usable_cpus(), "cpu.max": (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None)}, "index": tag})); sys.stdout.flush()
+    for T in (1, 2, 4, 8, 12, 16, 24, 32, 64):
         sessions = [ya.Session(["-x", X, "-q", R, "-t", "1"]) for _ in range(T)]
         for s in sessions:
             assert s.next_batch(N).n_reads == N
-        reps = 3 if T > 1 else 2
+        reps = 4
         import ctypes as C
         def work(s):                                   # the C call only (ctypes drops the GIL for it); the text stays in the session's buffer
             t_, n_ = C.c_char_p(), C.c_size_t()

@@ -17,7 +17,7 @@ static void usage(FILE *o)
           "       (built on the GPU when one is visible and -S is 1; -cpuindex forces the host builder; the files are identical)\n\n"
           "Query alignment (hot path on MI355X):\n"
           "  yaha -x indexFile [-q queryFile|(stdin)] [-o8|(-osh)|-oss outFile|(stdout)] [-t hostThreads (1)]\n"
-          "       [-gpus N (1)] [-ctx contextsPerGpu (2)] [-device D (0)] [-batch readsPerBatch (4096)]\n"
+          "       [-gpus N (1)] [-ctx contextsPerGpu (3)] [-device D (0)] [-batch readsPerBatch (about 16 M bases)]\n"
           "  general : [-BW 5] [-G 50] [-H 650] [-M 25] [-MD 50] [-P 0.9] [-X 25]\n"
           "  scoring : [-AGS Y|N] [-GEC 2] [-GOC 5] [-MS 1] [-RC 3]\n"
           "  OQC     : [-OQC Y|N] [-BP 5] [-MGDP 5] [-MNO minMatch]   FBS: [-FBS Y|N] [-PRL 0.9] [-PSS 0.9]\n"

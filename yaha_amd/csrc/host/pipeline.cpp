@@ -15,6 +15,7 @@
 #include <deque>
 #include <memory>
 #include <sys/stat.h>
+#include <sched.h>
 
 using namespace yaha;
 
@@ -124,55 +125,71 @@ template <class T> struct StageQueue {
 };
 }  // namespace
 
+// CPUs this process may really use: the smaller of the affinity mask and the control group's CPU quota (cpu.max; v1: cfs_quota/cfs_period).  A container that
+// shows 256 hardware threads and has a quota of 16 CPUs is throttled -- every thread of it, the ones that feed the GPUs included, stopped for the rest of each
+// 100 ms period -- as soon as more than 16 threads are busy: the pools below are sized from this number, not from hardware_concurrency().
+int effectiveCpus()
+{
+    int n = (int)std::thread::hardware_concurrency(); if (n < 1) n = 1;
+    cpu_set_t set; if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1 && c < n) n = c; }
+    long long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[64] = ""; if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q); fclose(f); }
+    else {
+        if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f1, "%lld", &quota) != 1) quota = -1; fclose(f1); }
+        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &period) != 1) period = -1; fclose(f2); }
+    }
+    if (quota > 0 && period > 0) { const int c = (int)((quota + period - 1) / period); if (c >= 1 && c < n) n = c; }
+    if (const char *e = getenv("YAHA_CPUS")) { const int c = atoi(e); if (c >= 1) n = c; }
+    return n;
+}
+
 int runQueries(Args &a, FILE *log)
 {
-    const bool timing0 = getenv("YAHA_TIMING") != nullptr;
-    auto now0 = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double tStep = now0();
+    const bool timing = getenv("YAHA_TIMING") != nullptr, stats = timing || getenv("YAHA_STATS") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tEnter = now(); double tStep = tEnter;
     std::unique_ptr<yaha_session> S(new yaha_session); S->args = a;
     if (!sessionLoad(S.get())) { fprintf(log, "%s\n", S->err.c_str()); return 1; }
-    if (timing0) { fprintf(stderr, "[yaha] index and input opened in %.1f ms\n", now0() - tStep); tStep = now0(); }
+    if (timing) { fprintf(stderr, "[yaha] index and input opened in %.1f ms\n", now() - tStep); tStep = now(); }
     Args &A = S->args;
     FILE *out = (A.ofileName == "stdout") ? stdout : fopen(A.ofileName.c_str(), "w");
     if (!out) { fprintf(log, "Failure to open output file: %s.\n", A.ofileName.c_str()); return 1; }
+    setvbuf(out, nullptr, _IONBF, 0);                                       // whole batches are written with one call each
     if (fputs(S->header.c_str(), out) < 0) { fprintf(log, "Failure writing the output file.\n"); return 1; }
     ygpu_params P; paramsFromArgs(A, P);
     ygpu_index_view V; yaha_session_index_view(S.get(), &V);
-    // -gpus N devices x -ctx M contexts per device (default 2: while one context's batch is in a latency-bound device stage the other
-    // one's batch computes).  Contexts of one device share its index image.
-    const int perDev = std::max(1, A.ctxPerGpu), ngpu = std::max(1, A.gpus) * perDev;
+    // -gpus N devices x -ctx M contexts per device (default 3: while one context's batch is in a latency-bound device stage the others'
+    // batches compute).  Contexts of one device share its index image.
+    const int perDev = std::max(1, A.ctxPerGpu), nDev = std::max(1, A.gpus), ngpu = nDev * perDev;
     std::vector<ygpu_ctx *> ctx(ngpu, nullptr);
-    for (int d = 0; d < ngpu; d++) {
-        const int dev = A.device + d / perDev;
-        int rc = (d % perDev == 0) ? ygpu_init(dev, &V, &P, &ctx[d]) : ygpu_clone(ctx[d - d % perDev], &ctx[d]);
-        if (rc != 0) { fprintf(log, "ygpu_init(device %d) failed: %d %s\n", dev, rc, ctx[d] ? ygpu_last_error(ctx[d]) : ""); return 1; }
-    }
-    if (timing0) { fprintf(stderr, "[yaha] device contexts created (index image uploaded) in %.1f ms\n", now0() - tStep); tStep = now0(); }
-    // Five stages, batches handed over through bounded queues, a ticket ordering the output (= the reference's -t 1 order):
+    // Six stages, batches handed over through bounded queues, a ticket ordering the output (= the reference's -t 1 order):
     //   splitter   (1 thread)          record boundaries of the memory-mapped / block-read input (memchr; reader.cpp) -- the only serial part;
-    //   parsers    (a few threads)     id, sequence, quality, codes, reverse complement and the skip rules of one batch of records;
-    //   contexts   (1 thread each)     upload, run the hot path, collect, copy the results out of the context's buffers;
-    //   formatters (-t threads)        OQC/FBS filter and SAM text of one whole batch each; whoever completes the next ticket writes.
-    // So the device never waits for parsing or formatting unless those stages as a whole are slower than it.  The first failure (a device
-    // error, a write error) stops the run: nothing after the last complete batch before it is written, and the exit code is 1.
-    struct Batch { uint64_t ticket = 0; std::vector<Span> spans; std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
-                   std::vector<uint32_t> clumpStart, ops; std::vector<ygpu_clump> clumps; uint64_t nClumps = 0, nOps = 0; double tRead = 0, tDev = 0; };
+    //   parsers    (a few threads)     id, sequence, quality, codes and the skip rules of one batch of records;
+    //   contexts   (1 thread each)     upload, run the hot path, collect, copy the results out of the context's buffers (asleep while the device works);
+    //   formatters                     OQC/FBS filter and SAM text of one whole batch each, into the batch's own text buffer;
+    //   writer     (1 thread)          batches in ticket order, one write each; the batch object -- reads, codes, results, text, all with their capacity --
+    //                                  then goes back to the pool the splitter takes from, so that the steady state allocates nothing and maps no new pages.
+    // The device never waits for parsing or formatting unless those stages as a whole are slower than it.  The first failure (a device error, a write
+    // error) stops the run: nothing after the last complete batch before it is written, and the exit code is 1.
+    struct Batch { uint64_t ticket = 0; std::vector<Span> spans; std::vector<Read> reads; size_t nReads = 0; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
+                   std::vector<uint32_t> clumpStart, ops; std::vector<ygpu_clump> clumps; uint64_t nClumps = 0, nOps = 0; Text text; double tRead = 0, tDev = 0, tFmt = 0; };
     typedef std::unique_ptr<Batch> BatchP;
-    // -t is the reference's thread count and is echoed in @PG; the formatter pool takes that many threads, and at least enough for the devices in use
-    // (OQC + SAM text cost ~15-20 us of CPU a read; one MI355X delivers ~0.2 M reads/s)
-    const int hw = std::max(1, (int)std::thread::hardware_concurrency()), nDev = std::max(1, A.gpus);
-    const int nParse = std::max(1, std::min(std::min(8, 2 * nDev), hw / 2)), nFmt = std::max(std::max(1, A.numThreads), std::min(std::max(1, hw / 2), 8 * nDev));
-    StageQueue<BatchP> parseQ((size_t)nParse + 2, 1), inQ((size_t)ngpu + 2, nParse), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu + nParse);
-    std::mutex outMu; uint64_t nextOut = 0; std::atomic<bool> stop(false); std::atomic<int> rcAll(0);
-    std::map<uint64_t, Text> done;
-    const bool timing = getenv("YAHA_TIMING") != nullptr;
-    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    struct Pool { std::mutex mu; std::vector<BatchP> free; BatchP get() { { std::lock_guard<std::mutex> lk(mu); if (!free.empty()) { BatchP b = std::move(free.back()); free.pop_back(); return b; } } return BatchP(new Batch); }
+                  void put(BatchP &&b) { std::lock_guard<std::mutex> lk(mu); free.push_back(std::move(b)); } } pool;
+    // Thread counts follow the CPUs the process may use (effectiveCpus: affinity and the control group's quota).  -t is the reference's thread count and is
+    // echoed in @PG; given explicitly (> 1) it is the number of formatter threads, otherwise every CPU that is not a parser, the splitter or the writer is one.
+    const int cpus = effectiveCpus();
+    const int nParse = std::max(1, std::min(8, (cpus + 7) / 10)), nFmt = A.numThreads > 1 ? A.numThreads : std::max(1, cpus - nParse - 2);
+    StageQueue<BatchP> parseQ((size_t)nParse + 2, 1), inQ((size_t)ngpu + 2, nParse), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu + nParse), outQ((size_t)nFmt + 4, nFmt);
+    std::atomic<bool> stop(false); std::atomic<int> rcAll(0);
     auto fail = [&](const char *what) { if (!stop.exchange(true)) fprintf(log, "%s -- stopping; the output ends with the last batch completed before this one.\n", what); rcAll = 1; };
+    // batches follow the read length: about 16 M bases each (16 384 reads of 1 kbp, 1 600 of 10 kbp, 65 536 of 100 bp), unless -batch gives a read count
+    const size_t maxReads = A.batchReads > 0 ? (size_t)A.batchReads : 65536, maxBases = A.batchReads > 0 ? ~(size_t)0 : ((size_t)16 << 20);
     auto splitter = [&]() {
         uint64_t ticket = 0;
         while (!stop) {
-            BatchP b(new Batch);
-            if (S->reader.split.nextSpans((size_t)A.batchReads, b->spans) == 0) break;
+            BatchP b = pool.get();
+            if (S->reader.split.nextSpans(maxReads, maxBases, b->spans) == 0) break;
             b->ticket = ticket++;
             parseQ.push(std::move(b));
         }
@@ -181,29 +198,44 @@ int runQueries(Args &a, FILE *log)
     auto parser = [&]() {
         BatchP b;
         while (parseQ.pop(b)) {
+            b->nReads = 0;
             if (!stop) {
                 const double t0 = now();
-                b->reads.reserve(b->spans.size()); b->offsets.assign(1, 0); Read r; size_t bases = 0;
-                for (auto &sp : b->spans) if (parseSpan(sp, S->reader.fastq, S->reader.maxQueryLength, S->reader.wordLen, r)) { bases += r.fwdCodes.size(); b->reads.push_back(std::move(r)); }
-                b->codes.resize(bases); size_t o = 0;
-                for (auto &rd : b->reads) { memcpy(b->codes.data() + o, rd.fwdCodes.data(), rd.fwdCodes.size()); o += rd.fwdCodes.size(); b->offsets.push_back(o); }
-                std::vector<Span>().swap(b->spans);
+                if (b->reads.size() < b->spans.size()) b->reads.resize(b->spans.size());      // Read objects keep their strings' capacity from batch to batch
+                b->offsets.assign(1, 0); size_t bases = 0, k = 0;
+                for (auto &sp : b->spans) if (parseSpan(sp, S->reader.fastq, S->reader.maxQueryLength, S->reader.wordLen, b->reads[k])) { bases += b->reads[k].fwdCodes.size(); k++; }
+                b->nReads = k; b->codes.resize(bases); size_t o = 0;
+                for (size_t i = 0; i < k; i++) { const Read &rd = b->reads[i]; memcpy(b->codes.data() + o, rd.fwdCodes.data(), rd.fwdCodes.size()); o += rd.fwdCodes.size(); b->offsets.push_back(o); }
                 b->tRead = now() - t0;
             }
-            if (b->reads.empty()) fmtQ.push(std::move(b)); else inQ.push(std::move(b));      // a batch whose records were all skipped still takes its place in the output order
+            b->spans.clear();                                                  // lets go of the input chunk
+            if (b->nReads == 0) { b->nClumps = b->nOps = 0; fmtQ.push(std::move(b)); } else inQ.push(std::move(b));      // a batch whose records were all skipped still takes its place in the output order
         }
         inQ.producerDone(); fmtQ.producerDone();
     };
+    // Contexts are made by the threads that use them, all devices at once (an index image of 16.7 GB takes 0.65 s to reach a device; eight in a row would be
+    // five seconds), while the splitter and the parsers already work on the first batches.  The first context of a device uploads the image, the others share it.
     // A context's first batch allocates its device buffers (a hundred hipMalloc calls, each of which waits for the device to go idle): first batches run one at
     // a time and hold back the other contexts' new batches meanwhile, instead of fighting their kernels for every allocation (0.6 s per context otherwise, measured).
-    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; };
-    std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < std::max(1, A.gpus); k++) warm.emplace_back(new Warm);
+    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
+    std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < nDev; k++) warm.emplace_back(new Warm);
+    std::atomic<int> ctxUp(0); double tCtxUp = 0;
     auto device = [&](int d) {
-        BatchP b; bool first = true; Warm &W = *warm[d / perDev];
+        BatchP b; bool first = true; Warm &W = *warm[d / perDev]; const int dev = A.device + d / perDev, lead = d - d % perDev;
+        int rc0;
+        if (d == lead) {
+            rc0 = ygpu_init(dev, &V, &P, &ctx[d]);
+            { std::lock_guard<std::mutex> lk(W.mu); W.ready = rc0 == 0 ? 1 : -1; } W.cv.notify_all();
+        } else {
+            { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : YGPU_EINVAL; }
+            if (rc0 == 0) { std::lock_guard<std::mutex> one(W.first); rc0 = ygpu_clone(ctx[lead], &ctx[d]); }
+        }
+        if (rc0 != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", dev, rc0, ctx[d] ? ygpu_last_error(ctx[d]) : (d == lead ? "" : "(the device's first context failed)")); fail(m); }
+        if (++ctxUp == ngpu) { tCtxUp = now(); if (timing) fprintf(stderr, "[yaha] %d device contexts up (index image on %d device%s) %.1f ms after start\n", ngpu, nDev, nDev > 1 ? "s" : "", tCtxUp - tEnter); }
         while (inQ.pop(b)) {
-            if (stop) continue;
+            if (stop) { b->nReads = 0; fmtQ.push(std::move(b)); continue; }
             const double t0 = now();
-            ygpu_read_batch rb{(uint32_t)b->reads.size(), b->codes.data(), b->offsets.data()}; ygpu_result_batch res;
+            ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res;
             int rc;
             if (first) {
                 std::lock_guard<std::mutex> one(W.first);
@@ -214,11 +246,10 @@ int runQueries(Args &a, FILE *log)
                 { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.firstRunning == 0; }); }
                 rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc == 0) rc = ygpu_collect(ctx[d], &res);
             }
-            if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, ygpu_last_error(ctx[d])); fail(m); continue; }
+            if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, ygpu_last_error(ctx[d])); fail(m); b->nReads = 0; fmtQ.push(std::move(b)); continue; }
             // the context's result buffers are reused by its next batch
             b->clumpStart.assign(res.clump_start, res.clump_start + res.n_reads + 1); b->clumps.assign(res.clumps, res.clumps + res.n_clumps); b->ops.assign(res.ops, res.ops + res.n_ops);
             b->nClumps = res.n_clumps; b->nOps = res.n_ops;
-            std::vector<uint8_t>().swap(b->codes);
             b->tDev = now() - t0;
             fmtQ.push(std::move(b));
         }
@@ -228,36 +259,51 @@ int runQueries(Args &a, FILE *log)
         yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs; local.genome.maxROff = S->genome.maxROff;
         BatchP b;
         while (fmtQ.pop(b)) {
-            if (stop) continue;
-            const double t0 = now(); Text text;
-            if (!b->reads.empty()) {
+            const double t0 = now(); b->text.clear();
+            if (!stop && b->nReads) {
                 ygpu_result_batch res; memset(&res, 0, sizeof res);
-                res.n_reads = (uint32_t)b->reads.size(); res.clump_start = b->clumpStart.data(); res.clumps = b->clumps.data(); res.ops = b->ops.data(); res.n_clumps = b->nClumps; res.n_ops = b->nOps;
-                local.reads.swap(b->reads); formatBatch(&local, &res, text, 1); local.reads.swap(b->reads);
+                res.n_reads = (uint32_t)b->nReads; res.clump_start = b->clumpStart.data(); res.clumps = b->clumps.data(); res.ops = b->ops.data(); res.n_clumps = b->nClumps; res.n_ops = b->nOps;
+                local.reads.swap(b->reads); formatBatch(&local, &res, b->text, 1); local.reads.swap(b->reads);
             }
-            if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  parse %.1f  device (upload, run, collect, copy) %.1f  format %.1f ms\n", (unsigned long long)b->ticket, b->reads.size(), b->tRead, b->tDev, now() - t0);
-            std::unique_lock<std::mutex> lk(outMu);
-            done[b->ticket] = std::move(text);
-            while (!stop && !done.empty() && done.begin()->first == nextOut) {
-                const Text &t = done.begin()->second;
-                if (t.len && fwrite(t.p, 1, t.len, out) != t.len) { fail("Failure writing the output file"); break; }
-                done.erase(done.begin()); nextOut++;
+            b->tFmt = now() - t0;
+            outQ.push(std::move(b));
+        }
+        outQ.producerDone();
+    };
+    uint64_t nWritten = 0, nFirst = 0; double tFirstOut = 0, tLastOut = 0;
+    auto writer = [&]() {
+        std::map<uint64_t, BatchP> done; uint64_t nextOut = 0; BatchP b;
+        while (outQ.pop(b)) {
+            done[b->ticket] = std::move(b);
+            while (!done.empty() && done.begin()->first == nextOut) {
+                BatchP w = std::move(done.begin()->second); done.erase(done.begin()); nextOut++;
+                if (!stop) {
+                    if (w->text.len && fwrite(w->text.p, 1, w->text.len, out) != w->text.len) fail("Failure writing the output file");
+                    else { const double t = now(); if (nWritten == 0) { tFirstOut = t; nFirst = w->nReads; } tLastOut = t; nWritten += w->nReads; }
+                    if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  parse %.1f  device (upload, run, collect, copy) %.1f  format %.1f ms  written at %.1f\n", (unsigned long long)w->ticket, w->nReads, w->tRead, w->tDev, w->tFmt, now() - tEnter);
+                }
+                pool.put(std::move(w));
             }
         }
     };
-    const double tStart = now();
-    if (timing) fprintf(stderr, "[yaha] contexts ready: %d parser, %d formatter threads\n", nParse, nFmt);
+    if (timing) fprintf(stderr, "[yaha] %d usable CPUs: %d parser, %d formatter threads, %d contexts\n", cpus, nParse, nFmt, ngpu);
     std::vector<std::thread> th;
+    for (int d = 0; d < ngpu; d++) th.emplace_back(device, d);                 // the index image starts towards the devices first
     th.emplace_back(splitter);
     for (int i = 0; i < nParse; i++) th.emplace_back(parser);
-    for (int d = 0; d < ngpu; d++) th.emplace_back(device, d);
     for (int i = 0; i < nFmt; i++) th.emplace_back(formatter);
+    th.emplace_back(writer);
     for (auto &x : th) x.join();
     const double tDone = now();
-    for (int d = ngpu - 1; d >= 0; d--) ygpu_destroy(ctx[d]);                 // clones before their parents
+    for (int d = ngpu - 1; d >= 0; d--) if (ctx[d]) ygpu_destroy(ctx[d]);     // clones before their parents
     if (fflush(out) != 0 || ferror(out)) { if (!stop) fprintf(log, "Failure writing the output file.\n"); rcAll = 1; }
     if (out != stdout && fclose(out) != 0) { fprintf(log, "Failure closing the output file.\n"); rcAll = 1; }
-    if (timing) fprintf(stderr, "[yaha] batches %.1f ms, teardown %.1f ms\n", tDone - tStart, now() - tDone);
+    if (timing) fprintf(stderr, "[yaha] batches done %.1f ms after start, teardown %.1f ms\n", tDone - tEnter, now() - tDone);
+    if (stats) {    // one line for scripts (bench.py): steady = reads written after the first batch / time from the first batch's write to the last one's
+        const double steady = (nWritten > nFirst && tLastOut > tFirstOut) ? (nWritten - nFirst) / ((tLastOut - tFirstOut) * 1e-3) : 0.0;
+        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, \"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d}\n",
+                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev);
+    }
     return rcAll;
 }
 }  // namespace yaha

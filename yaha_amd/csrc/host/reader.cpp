@@ -22,6 +22,7 @@
 #include <cerrno>
 #include <algorithm>
 #include <fcntl.h>
+#include <poll.h>
 #include <unistd.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -70,7 +71,15 @@ void ReadSplitter::fill()
     } else if (cur != chunk->data()) { memmove(chunk->data(), cur, tail); chunk->resize(tail); }
     const size_t have = chunk->size(); chunk->resize(have + blockBytes);
     size_t got = 0;
-    while (got < blockBytes) { ssize_t r = ::read(fd, chunk->data() + have + got, blockBytes - got); if (r < 0 && errno == EINTR) continue; if (r <= 0) { atEof = true; break; } got += (size_t)r; }
+    // blocks until some input has arrived, then takes what is there without waiting again (up to the block size): a fast producer is read in large blocks,
+    // a slow one -- a pipe from a sequencer, an interactive test -- sees its records processed as they come instead of after 32 MB have accumulated
+    while (got < blockBytes) {
+        if (got > 0) { struct pollfd pf = {fd, POLLIN, 0}; if (poll(&pf, 1, 0) <= 0) break; }
+        ssize_t r = ::read(fd, chunk->data() + have + got, blockBytes - got);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) { atEof = true; break; }
+        got += (size_t)r;
+    }
     chunk->resize(have + got);
     cur = chunk->data(); end = cur + chunk->size();
 }
@@ -130,11 +139,15 @@ bool ReadSplitter::nextSpan(Span &s)
     if (cur >= end && atEof) done = true;                    // the next call would see an empty id and an empty sequence
     return true;
 }
-size_t ReadSplitter::nextSpans(size_t maxSpans, std::vector<Span> &out)
+size_t ReadSplitter::nextSpans(size_t maxSpans, size_t maxBases, std::vector<Span> &out)
 {
     out.clear();
-    Span s;
-    while (out.size() < maxSpans && nextSpan(s)) out.push_back(s);
+    Span s; size_t bases = 0;
+    while (out.size() < maxSpans && bases < maxBases) {
+        s.hold.reset();                                      // a reference kept from the last record would make every refill start a new chunk
+        if (!nextSpan(s)) break;
+        bases += s.seqEnd - s.seq0; out.push_back(s);
+    }
     return out.size();
 }
 

@@ -69,7 +69,7 @@ struct Args {
     bool OQC = true; int OQCMinNonOverlap = -1, BPCost = 5, maxBPLog = 5; bool FBS = false; float FBS_PSLength = 0.90f, FBS_PSScore = 0.90f;
     int maxQueryLength = 32000; bool verbose = false, outputBlast8 = false, outputSAM = true, hardClip = true;
     // extensions of this implementation (not in the reference CLI)
-    int batchReads = 4096; int device = 0; int gpus = 1; int ctxPerGpu = 2; bool cpuIndex = false;
+    int batchReads = 0; int device = 0; int gpus = 1; int ctxPerGpu = 3; bool cpuIndex = false;      // batchReads 0: batches of ~16 M bases
     bool query = false, index = true;
 };
 void postProcessArgs(Args &a, bool query);                                  // AlignArgs.c:108-169
@@ -93,7 +93,8 @@ struct ReadSplitter {
     bool open(const char *path, std::string &err);       // peeks '>' / '@' (Query.c:63-74)
     void close();
     bool nextSpan(Span &s);                              // false at the end of input (an empty sequence ends it, Query.c:216-217)
-    size_t nextSpans(size_t maxSpans, std::vector<Span> &out);
+    size_t nextSpans(size_t maxSpans, std::vector<Span> &out) { return nextSpans(maxSpans, ~(size_t)0, out); }
+    size_t nextSpans(size_t maxSpans, size_t maxBases, std::vector<Span> &out);   // up to maxSpans records, stopping once their sequences reach maxBases bytes
     ~ReadSplitter() { close(); }
   private:
     void fill(); bool seek(char c, size_t *pos); bool seekNlAt(size_t *pos);
@@ -134,6 +135,7 @@ struct Text {
 void printClump(const Args &a, const Genome &g, const Read &r, const OutClump &oc, int primaryCount, Text &out);
 
 // ---- whole-run driver (replacement of processQueryFile, Query.c:551-709) --------------------------------
+int effectiveCpus();                                    // affinity mask and control-group CPU quota
 int runQueries(Args &a, FILE *log);
 int runIndex(Args &a, FILE *log);
 }  // namespace yaha
