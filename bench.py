@@ -422,7 +422,11 @@ def main():
     if os.path.exists(pj):
         try:
             pmc = json.load(open(pj))
-            if pmc.get("reads_per_gpu") == n_reads and pmc.get("kernel") == kname:
+            import hashlib
+            dev = os.path.join(ROOT, "yaha_amd", "csrc", "device")
+            ksrc = hashlib.sha256(b"".join(open(os.path.join(dev, f), "rb").read() for f in ("ext_lanes.h", "ext_lanes_pk.h"))).hexdigest()[:16]
+            # counters of another kernel are worse than none: the file names the sources of the extension kernels it was measured on (tools/pmc_summary.py)
+            if pmc.get("reads_per_gpu") == n_reads and pmc.get("kernel") == kname and pmc.get("kernel_source_sha16") == ksrc:
                 traffic = pmc.get("hbm_bytes_per_launch")
             else:
                 pmc = None
@@ -447,7 +451,7 @@ def main():
                      "valu_frac_nominal": (valu * 2.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
                      "valu_frac_measured_mix": (valu * 4.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
                      "note": "integer DP: `frac` follows SURVEY 8(d) (algorithmic bytes of the reads of one launch / kernel time / 8 TB/s) and is ~1% by construction; the kernel is bound by vector-ALU issue: valu_frac_nominal prices each wave64 VALU instruction at the nominal 2 SIMD cycles, valu_frac_measured_mix at what its mix measures: 4.4 cycles for the packed 16-bit kernel, 4.0 for the 32-bit one (DESIGN.md section 7); kernel_stream_frac counts the trace cells the kernel writes (an implementation choice, not algorithmic traffic)",
-                     "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch", "lds_bank_conflict_frac", "gpu_busy_cycles", "source") if k2 in pmc} if pmc else None)},
+                     "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch", "lds_bank_conflict_frac", "gpu_busy_cycles", "git_head", "kernel_source_sha16", "source") if k2 in pmc} if pmc else None)},
         "path": {"algorithmic_bytes_per_read": B, "hbm_frac_whole_path": value * B / (8.0e12 * world),
                  "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) * steps * world / dt},
         "stage_ms_per_step": {k2: v / steps for k2, v in stage_ms.items()},
@@ -464,6 +468,16 @@ def main():
                 wl.append(side_workload(ya, idx, make_reads(cache, fa, "side", n, length, div, 2000), n, local, args.contexts, nsteps, label))
             except Exception as e:
                 wl.append({"workload": label, "error": str(e)[:200]})
+        # the headline's int32 twin: the same batch with the X-drop extension rows in the 32-bit kernels (the reference computes in int; the packed 16-bit kernel is a
+        # lossless narrowing of the same recurrence, bit-identical results -- tests/test_gpu_parity.py::test_both_extension_kernel_families)
+        os.environ["YGPU_EXT32"] = "1"
+        try:
+            w32 = side_workload(ya, idx, reads_path, n_reads, local, args.contexts, max(3, steps // 2), "c2 with the 32-bit extension kernels (YGPU_EXT32=1), dtype int32")
+            w32["dtype"] = "int32"; wl.append(w32); out["value_int32"] = w32["reads_per_s"]
+        except Exception as e:
+            wl.append({"workload": "c2 int32", "error": str(e)[:200]})
+        finally:
+            del os.environ["YGPU_EXT32"]
         wl.insert(1, {"workload": "c2: 1 kbp reads, r=0.05 (realised 1.7%) = the headline", "reads_per_step": n_reads, "steps": steps, "reads_per_s": value, "bases_per_s": value * Lq, "ms_per_step": 1e3 * dt / steps,
                       "k_ext_rows_ms_per_step": rows_dev_ms})
         out["workloads"] = wl

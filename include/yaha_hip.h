@@ -127,11 +127,22 @@ int  ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *batch);
 int  ygpu_run(ygpu_ctx *ctx);
 /* Copy results of the last ygpu_run to host memory owned by the context. */
 int  ygpu_collect(ygpu_ctx *ctx, ygpu_result_batch *out);
+/* The same into memory of the caller's: ygpu_result_size gives the element counts of the last ygpu_run; ygpu_collect_into copies clump_start[n_reads + 1],
+ * clumps[n_clumps] and ops[n_ops] there and points `out` at them.  With buffers from ygpu_host_alloc (page-locked host memory) the copy is a DMA straight
+ * into them -- no staging copy by the calling thread, none afterwards to get the results out of the context: a batching host keeps a result buffer per batch
+ * in flight and hands it to its formatter threads while the context already runs the next batch (the reference's QueryState owns its clump list the same
+ * way, QueryState.c:156-161).  Any memory works; pageable memory is staged by the runtime. */
+int  ygpu_result_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops);
+int  ygpu_collect_into(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_clump *clumps, uint32_t *ops, ygpu_result_batch *out);
+void *ygpu_host_alloc(size_t bytes);           /* NULL when no device runtime is there or the memory cannot be locked */
+void  ygpu_host_free(void *p);
 /* Asynchronous form: ygpu_submit hands the batch to the context and returns at once; the context's own worker thread does
  * upload + run + collect; ygpu_wait blocks until the ticket is complete and returns the results (ygpu_poll: 1 = complete, 0 = still running).
  * One host thread can so keep several contexts (devices) busy -- the reference needs one thread per QueryState for that (Query.c:642-684).
  * One open ticket per context: the caller keeps the batch alive until ygpu_wait returns, results stay valid until the next ygpu_submit /
- * ygpu_run on the context; a second ygpu_submit before ygpu_wait returns YGPU_EBUSY. */
+ * ygpu_run on the context; a second ygpu_submit before ygpu_wait returns YGPU_EBUSY, a ygpu_wait for a ticket that is not open (or that another
+ * thread is already waiting for) YGPU_EINVAL.  ygpu_last_error describes the ticket's failure once ygpu_wait has returned it; while a ticket is open
+ * the text belongs to the worker and must not be read. */
 typedef uint64_t ygpu_ticket;
 int  ygpu_submit(ygpu_ctx *ctx, const ygpu_read_batch *batch, ygpu_ticket *ticket);
 int  ygpu_poll(ygpu_ctx *ctx, ygpu_ticket ticket);

@@ -47,6 +47,17 @@ int ygpu_collect(ygpu_ctx *c, ygpu_result_batch *r)
     memset(r, 0, sizeof *r); r->n_reads = c->res.n_reads; r->clump_start = c->res.clump_start; r->clumps = c->res.clumps; r->ops = c->res.ops; r->n_clumps = c->res.n_clumps; r->n_ops = c->res.n_ops; r->counters = c->res.counters;
     return 0;
 }
+int ygpu_result_size(ygpu_ctx *c, uint64_t *nc, uint64_t *no) { if (!c->have) return YGPU_EINVAL; *nc = c->res.n_clumps; *no = c->res.n_ops; return 0; }
+int ygpu_collect_into(ygpu_ctx *c, uint32_t *cs, ygpu_clump *cl, uint32_t *ops, ygpu_result_batch *r)
+{
+    if (!c->have) return YGPU_EINVAL;
+    memcpy(cs, c->res.clump_start, 4ull * (c->res.n_reads + 1)); if (c->res.n_clumps) memcpy(cl, c->res.clumps, sizeof(ygpu_clump) * c->res.n_clumps); if (c->res.n_ops) memcpy(ops, c->res.ops, 4ull * c->res.n_ops);
+    memset(r, 0, sizeof *r); r->n_reads = c->res.n_reads; r->clump_start = cs; r->clumps = cl; r->ops = ops; r->n_clumps = c->res.n_clumps; r->n_ops = c->res.n_ops; r->counters = c->res.counters;
+    return 0;
+}
+static std::atomic<long> gHostAllocs(0);
+void *ygpu_host_alloc(size_t n) { gHostAllocs++; return getenv("YTEST_NO_PINNED") ? nullptr : malloc(n ? n : 1); }      // (the double's "pinned" memory is plain memory; YTEST_NO_PINNED exercises the pipeline's fall-back to it)
+void ygpu_host_free(void *p) { free(p); }
 int  ygpu_submit(ygpu_ctx *, const ygpu_read_batch *, ygpu_ticket *) { return YGPU_ENODEV; }
 int  ygpu_poll(ygpu_ctx *, ygpu_ticket) { return YGPU_ENODEV; }
 int  ygpu_wait(ygpu_ctx *, ygpu_ticket, ygpu_result_batch *) { return YGPU_ENODEV; }

@@ -111,6 +111,17 @@ def test_lane_pipeline_parameter_corners(work, index11, reads, extra, tmp_path):
         assert mine == strip_pg(open(ref_out).read())
 
 
+# Bands wider than a wave has lanes for (4 * BW + 1 > 64 columns in the X-drop extension: -BW 16 and up) run through the sequential recurrence of dp_wave.h;
+# the reference accepts any band (Main.c:324-327).  device == oracle per batch, and the reference binary's SAM when it is there.
+@pytest.mark.parametrize("reads,extra", [("r1k.fa", ["-BW", "16"]), ("rchim.fa", ["-BW", "20", "-G", "80"]), ("r10k.fa", ["-BW", "40"]), ("rq.fq", ["-BW", "33", "-X", "40"])])
+def test_bands_wider_than_a_wave(work, index11, reads, extra, tmp_path):
+    mine = device_pipeline(index11, os.path.join(work, reads), "-osh", extra, batch=300)
+    if oracle.have_reference():
+        ref_out = str(tmp_path / "ref.sam")
+        oracle.run_reference(["-x", index11, "-q", os.path.join(work, reads), "-osh", ref_out] + list(extra))
+        assert mine == strip_pg(open(ref_out).read())
+
+
 @pytest.mark.parametrize("budget", ["3000", "40000"])
 def test_trace_memory_chunks(work, index11, meta, budget, monkeypatch):
     # When the extension trace strips of a batch do not fit in device memory the roots are processed in chunks that reuse one

@@ -29,7 +29,8 @@ def exes(tmp_path_factory):
 
 
 def _run(exe, args, env=None, stdin=None):
-    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1", **(env or {}))
+    e = dict(os.environ, YAHA_KEEP_TEARDOWN="1", TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    e.update(env or {})
     return subprocess.run([exe] + args, env=e, stdin=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 
 
@@ -74,6 +75,13 @@ def test_a_device_failure_stops_the_run_cleanly(exes, work, index11):
     assert "hot path failed" in bad.stderr.decode() and "stopping" in bad.stderr.decode()
     g, b = good.stdout.decode(), bad.stdout.decode()
     assert len(b) < len(g) and g.startswith(b) and (b.endswith("\n") or b == "")
+
+
+def test_results_in_plain_memory_when_nothing_can_be_page_locked_and_the_fast_exit(exes, work, index11):
+    p = _run(exes["asan"], ["-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", "stdout", "-batch", "41"], env={"YTEST_NO_PINNED": "1", "YAHA_KEEP_TEARDOWN": ""})
+    assert p.returncode == 0
+    _clean(p)
+    assert strip_pg(p.stdout.decode()) == golden_lines("rchim_default")
 
 
 def test_no_such_device(exes, work, index11):

@@ -11,6 +11,10 @@ const char *ygpu_last_error(const ygpu_ctx *) { return "sanitizer build of the h
 int  ygpu_upload(ygpu_ctx *, const ygpu_read_batch *) { return YGPU_ENODEV; }
 int  ygpu_run(ygpu_ctx *) { return YGPU_ENODEV; }
 int  ygpu_collect(ygpu_ctx *, ygpu_result_batch *) { return YGPU_ENODEV; }
+int  ygpu_result_size(ygpu_ctx *, uint64_t *, uint64_t *) { return YGPU_ENODEV; }
+int  ygpu_collect_into(ygpu_ctx *, uint32_t *, ygpu_clump *, uint32_t *, ygpu_result_batch *) { return YGPU_ENODEV; }
+void *ygpu_host_alloc(size_t) { return nullptr; }
+void ygpu_host_free(void *) {}
 int  ygpu_submit(ygpu_ctx *, const ygpu_read_batch *, ygpu_ticket *) { return YGPU_ENODEV; }
 int  ygpu_poll(ygpu_ctx *, ygpu_ticket) { return YGPU_ENODEV; }
 int  ygpu_wait(ygpu_ctx *, ygpu_ticket, ygpu_result_batch *) { return YGPU_ENODEV; }

@@ -9,10 +9,11 @@ subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome"
 sets = [[], ["-OQC", "N"], ["-FBS", "Y"], ["-AGS", "N"], ["-X", "10", "-MD", "20"], ["-BW", "8", "-G", "80"], ["-BW", "3", "-G", "20"], ["-M", "15", "-P", "0.8"], ["-H", "200"],
         ["-G", "15"], ["-M", "15"], ["-M", "16", "-G", "3"], ["-M", "30", "-G", "120"], ["-GOC", "9", "-GEC", "3", "-RC", "1"], ["-MS", "2", "-X", "40"], ["-oss"]]
 ok = True
+print("commit %s, index %s" % (os.environ.get("GIT_HEAD", "?"), GENOME))
 for extra in sets:
     oflag = "-oss" if extra == ["-oss"] else "-osh"; ex = [] if extra == ["-oss"] else extra
-    subprocess.run([os.path.join(root, "oracle/_ref/yaha"), "-x", X, "-q", R, oflag, "/tmp/ref.sam", "-t", "256"] + ex, stderr=subprocess.DEVNULL, check=True)
-    t = time.time(); subprocess.run([os.path.join(root, "yaha_amd/csrc/yaha"), "-x", X, "-q", R, oflag, "/tmp/mine.sam", "-t", "32"] + ex, stderr=subprocess.DEVNULL, check=True); tm = time.time() - t
+    subprocess.run([os.path.join(root, "oracle/_ref/yaha"), "-x", X, "-q", R, oflag, "/tmp/ref.sam", "-t", os.environ.get("REF_THREADS", "32")] + ex, stderr=subprocess.DEVNULL, check=True)
+    t = time.time(); subprocess.run([os.path.join(root, "yaha_amd/csrc/yaha"), "-x", X, "-q", R, oflag, "/tmp/mine.sam"] + ex, stderr=subprocess.DEVNULL, check=True); tm = time.time() - t
     a = sorted(l for l in open("/tmp/ref.sam") if not l.startswith("@PG")); b = sorted(l for l in open("/tmp/mine.sam") if not l.startswith("@PG"))
     print("%-28s records %6d identical=%s  (%.1f s)" % (" ".join(extra) or "(defaults)", len(a), a == b, tm)); ok &= a == b
 print("ALL IDENTICAL" if ok else "DIFFERENCES FOUND")

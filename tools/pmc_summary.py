@@ -43,7 +43,10 @@ if emit and kernel:
     fetch = biggest("fetch", "FETCH_SIZE") * 1024.0 * 2.0; write = biggest("write", "WRITE_SIZE") * 1024.0
     valu = biggest("sq", "SQ_INSTS_VALU"); dur_ns = out[k].get("max_ns") or out[k].get("avg_ns", 0.0)
     ldsc, ldsa, gui = biggest("lds", "SQ_LDS_BANK_CONFLICT"), biggest("lds", "SQ_LDS_IDX_ACTIVE"), biggest("grbm", "GRBM_GUI_ACTIVE")
-    js = {"kernel": kernel, "reads_per_gpu": reads, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+    import hashlib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ksrc = hashlib.sha256(b"".join(open(os.path.join(here, "yaha_amd", "csrc", "device", f), "rb").read() for f in ("ext_lanes.h", "ext_lanes_pk.h"))).hexdigest()[:16]
+    js = {"kernel": kernel, "reads_per_gpu": reads, "git_head": os.environ.get("GIT_HEAD"), "kernel_source_sha16": ksrc, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
           "valu_insts_per_launch": valu, "kernel_ns_largest_launch": dur_ns,
           "lds_bank_conflict_cycles": ldsc, "lds_idx_active_cycles": ldsa, "lds_bank_conflict_frac": (ldsc / ldsa) if ldsa else None,
           "gpu_busy_cycles": gui, "effective_clock_ghz": (gui / dur_ns) if (gui and dur_ns) else None,
@@ -69,10 +72,12 @@ if os.path.exists(cal):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") == "FETCH_SIZE":
                 seen.setdefault((row.get("Dispatch_Id"), short(row.get("Kernel_Name", "?"))), 0.0); seen[(row.get("Dispatch_Id"), short(row.get("Kernel_Name", "?")))] += float(row.get("Counter_Value", 0) or 0)
-        names = ["k_wide", "k_byte<false> sparse", "k_byte<true> dense"]
         lines = [json.loads(l) for l in open(cal) if l.startswith("{")]
+        # dispatches are matched to the program's own lines BY KERNEL NAME (the program also launches an initialisation kernel first: matching by position
+        # shifted every label by one dispatch in round 2's summary)
         for (d, kn), v in seen.items():
-            exp = next((l for l in lines if l["kernel"].split()[0].split("<")[0] in kn), None)
-            idx = list(seen.keys()).index((d, kn))
-            exp = lines[idx] if idx < len(lines) else exp
-            if exp: print("   %-28s FETCH_SIZE %.0f KiB = %.3f GB; bytes read exactly once %.3f GB; bytes / (FETCH_SIZE*1024) = %.3f" % (exp["kernel"], v, v * 1024 / 1e9, exp["bytes_read_once"] / 1e9, exp["bytes_read_once"] / (v * 1024) if v else 0))
+            base = kn.split("(")[0].strip()
+            exp = next((l for l in lines if l["kernel"].split()[0] == base), None)
+            if exp is None:
+                print("   %-28s FETCH_SIZE %.0f KiB (not a calibration kernel)" % (base, v)); continue
+            print("   %-28s FETCH_SIZE %.0f KiB = %.3f GB; bytes read exactly once %.3f GB; bytes / (FETCH_SIZE*1024) = %.3f" % (exp["kernel"], v, v * 1024 / 1e9, exp["bytes_read_once"] / 1e9, exp["bytes_read_once"] / (v * 1024) if v else 0))

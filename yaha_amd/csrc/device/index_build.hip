@@ -112,15 +112,37 @@ __global__ void k_ix_clamp(const uint32_t *so, uint64_t nKmers, uint32_t maxHits
     if (h < nKmers) { const uint32_t n = so[h + 1] - so[h]; cnt2[h] = n > maxHits ? maxHits : n; }
     if (h == nKmers) cnt2[h] = 0;
 }
-// ROA' = the lists of all k-mers that were not sampled, at their new places (a wave per 64 consecutive k-mers: their lists are adjacent in both arrays)
+// ROA' = the lists of all k-mers that were not sampled, at their new places.  A thread per k-mer: at -L 15 nearly every list has 0..3 entries and neighbouring
+// threads write neighbouring words; a list of more than 32 entries is copied by the whole wave instead (the lanes that own such lists take turns).
 __global__ void k_ix_compact(const uint32_t *so, const uint32_t *so2, uint64_t nKmers, uint32_t maxHits, const uint32_t *roa, uint32_t *roa2)
 {
     const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= nKmers) return;
-    const uint32_t b = so[h], n = so[h + 1] - b;
-    if (n > maxHits) return;                                                  // sampled lists are written from the host's samples
-    const uint32_t d = so2[h];
-    for (uint32_t i = 0; i < n; i++) roa2[d + i] = roa[b + i];
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t b = 0, n = 0, d = 0;
+    if (h < nKmers) { b = so[h]; n = so[h + 1] - b; d = so2[h]; if (n > maxHits) n = 0; }      // sampled lists are written from the host's samples
+    if (n <= 32u) for (uint32_t i = 0; i < n; i++) roa2[d + i] = roa[b + i];
+    unsigned long long longLists = __ballot(n > 32u);
+    while (longLists) {
+        const int src = __builtin_ctzll(longLists); longLists &= longLists - 1ull;
+        const uint32_t bb = (uint32_t)__shfl((int)b, src, 64), nn = (uint32_t)__shfl((int)n, src, 64), dd = (uint32_t)__shfl((int)d, src, 64);
+        for (uint32_t i = (uint32_t)lane; i < nn; i += 64u) roa2[dd + i] = roa[bb + i];
+    }
+}
+// The lists of the over-represented k-mers, packed one after the other (a wave per list), and the way back for their samples: one transfer each way per
+// group of lists instead of two blocking copies per k-mer (a small -H on a large genome has millions of such lists).
+__global__ void k_ix_pack(const uint32_t *roa, const uint32_t *desc /* per list: begin, length, packed offset (64-bit as two words) */, uint32_t nLists, uint32_t *packed)
+{
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; const int lane = (int)(threadIdx.x & 63);
+    if (w >= nLists) return;
+    const uint32_t b = desc[4 * w], n = desc[4 * w + 1]; const uint64_t o = (uint64_t)desc[4 * w + 2] | ((uint64_t)desc[4 * w + 3] << 32);
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) packed[o + i] = roa[b + i];
+}
+__global__ void k_ix_unpack(const uint32_t *samples, const uint32_t *dst /* per list: its place in ROA' */, uint32_t nLists, uint32_t maxHits, uint32_t *roa2)
+{
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; const int lane = (int)(threadIdx.x & 63);
+    if (w >= nLists) return;
+    const uint32_t d = dst[w]; const uint64_t o = (uint64_t)w * maxHits;
+    for (uint32_t i = (uint32_t)lane; i < maxHits; i += 64u) roa2[d + i] = samples[o + i];
 }
 
 // (begin, end, new begin) of the listed k-mers in one array: the host loops over a handful of long lists without a copy per list
@@ -134,7 +156,7 @@ __global__ void k_ix_gather(const uint32_t *so, const uint32_t *so2, const uint3
     out[4 * (size_t)s] = h; out[4 * (size_t)s + 1] = b; out[4 * (size_t)s + 2] = e; out[4 * (size_t)s + 3] = so2 ? so2[h] : 0u;
 }
 
-struct Buf { void *p = nullptr; ~Buf() { if (p) hipFree(p); } template <class T> T *as() { return (T *)p; } };
+struct Buf { void *p = nullptr; ~Buf() { if (p) hipFree(p); } void release() { if (p) hipFree(p); p = nullptr; } template <class T> T *as() { return (T *)p; } };
 }  // namespace
 
 namespace yaha {
@@ -228,7 +250,6 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, Ind
         hipLaunchKernelGGL(k_ix_compact, dim3((unsigned)((HT + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), HT, (uint32_t)maxHits, dROA.as<uint32_t>(), dROA2.as<uint32_t>());
         IXCHK(hipGetLastError());
         RandState rs; randInitDefault(rs);
-        std::vector<uint32_t> list, sample((size_t)std::max(maxHits, 1));
         Buf dOv; IXCHK(hipMalloc(&dOv.p, 16ull * nOver + 16)); IXCHK(hipMemset(dN.p, 0, 4));
         IXCHK(hipMemcpy(dOver.p, over.data(), 4ull * nOver, hipMemcpyHostToDevice));        // ascending now
         hipLaunchKernelGGL(k_ix_gather, dim3((nOver + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), dOver.as<uint32_t>(), nOver, 0u, dOv.as<uint32_t>(), dN.as<unsigned int>());
@@ -236,12 +257,36 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, Ind
         std::vector<uint32_t> ov(4ull * nOver); IXCHK(hipMemcpy(ov.data(), dOv.p, 16ull * nOver, hipMemcpyDeviceToHost));
         std::vector<size_t> idx(nOver); for (size_t k = 0; k < nOver; k++) idx[k] = k;
         std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ov[4 * a] < ov[4 * b]; });   // the gather's atomics shuffled them: back to k-mer order (the generator's order)
-        for (size_t k : idx) {
-            const uint32_t b0 = ov[4 * k + 1], n = ov[4 * k + 2] - b0, d = ov[4 * k + 3]; list.resize(n);
-            IXCHK(hipMemcpy(list.data(), dROA.as<uint32_t>() + b0, 4ull * n, hipMemcpyDeviceToHost));
-            randSample(rs, list.data(), (int)n, sample.data(), maxHits);
-            IXCHK(hipMemcpy(dROA2.as<uint32_t>() + d, sample.data(), 4ull * (size_t)maxHits, hipMemcpyHostToDevice));
+        // groups of lists of at most 64 M entries: pack on the device, one copy down, sample on the host in k-mer order (the generator is sequential by
+        // definition), one copy of the samples up, scatter on the device
+        const uint64_t groupCap = 64ull << 20;
+        std::vector<uint32_t> desc, dst, packed, samples; Buf dDesc, dDst, dPacked, dSamples;
+        size_t g0 = 0;
+        while (g0 < idx.size()) {
+            size_t g1 = g0; uint64_t tot = 0; desc.clear(); dst.clear();
+            while (g1 < idx.size()) {
+                const size_t k = idx[g1]; const uint32_t b0 = ov[4 * k + 1], n = ov[4 * k + 2] - b0;
+                if (g1 > g0 && (tot + n > groupCap || (uint64_t)(g1 - g0 + 1) * (uint64_t)maxHits > groupCap)) break;
+                desc.push_back(b0); desc.push_back(n); desc.push_back((uint32_t)tot); desc.push_back((uint32_t)(tot >> 32)); dst.push_back(ov[4 * k + 3]); tot += n; g1++;
+            }
+            const uint32_t nl = (uint32_t)(g1 - g0);
+            dDesc.release(); dDst.release(); dPacked.release(); dSamples.release();
+            IXCHK(hipMalloc(&dDesc.p, 16ull * nl)); IXCHK(hipMalloc(&dDst.p, 4ull * nl)); IXCHK(hipMalloc(&dPacked.p, 4ull * tot + 16)); IXCHK(hipMalloc(&dSamples.p, 4ull * (uint64_t)nl * (uint64_t)maxHits + 16));
+            IXCHK(hipMemcpy(dDesc.p, desc.data(), 16ull * nl, hipMemcpyHostToDevice)); IXCHK(hipMemcpy(dDst.p, dst.data(), 4ull * nl, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_ix_pack, dim3((unsigned)(((uint64_t)nl * 64 + 255) / 256)), dim3(256), 0, 0, dROA.as<uint32_t>(), dDesc.as<uint32_t>(), nl, dPacked.as<uint32_t>());
+            IXCHK(hipGetLastError());
+            packed.resize(tot); IXCHK(hipMemcpy(packed.data(), dPacked.p, 4ull * tot, hipMemcpyDeviceToHost));
+            samples.resize((size_t)nl * (size_t)maxHits);
+            for (uint32_t l = 0; l < nl; l++) {
+                const uint64_t o = (uint64_t)desc[4 * l + 2] | ((uint64_t)desc[4 * l + 3] << 32);
+                randSample(rs, packed.data() + o, (int)desc[4 * l + 1], samples.data() + (size_t)l * (size_t)maxHits, maxHits);
+            }
+            IXCHK(hipMemcpy(dSamples.p, samples.data(), 4ull * samples.size(), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_ix_unpack, dim3((unsigned)(((uint64_t)nl * 64 + 255) / 256)), dim3(256), 0, 0, dSamples.as<uint32_t>(), dDst.as<uint32_t>(), nl, (uint32_t)maxHits, dROA2.as<uint32_t>());
+            IXCHK(hipGetLastError());
+            g0 = g1;
         }
+        IXCHK(hipDeviceSynchronize());
         finalSO = dSO2.as<uint32_t>(); finalROA = dROA2.as<uint32_t>();
     }
     if (log) fprintf(log, "%u %d-mers had more than %d hits.\n", nOver, wordLen, maxHits);

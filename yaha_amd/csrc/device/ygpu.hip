@@ -57,6 +57,9 @@ struct DevBuf {
         p = np; cap = ncap; return 0;
     }
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    // exactly `bytes` (no growth margin), the old buffer freed FIRST: for buffers sized against what is free on the device -- the request may then reuse the
+    // buffer's own memory.  The contents are lost; on failure the buffer is empty.
+    int ensureExact(size_t bytes) { if (bytes <= cap) return 0; release(); void *np = nullptr; if (hipMalloc(&np, bytes) != hipSuccess) return -1; p = np; cap = bytes; return 0; }
     template <class T> T *as() const { return (T *)p; }
 };
 enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* five: the segments of the four workgroup-sort classes, the long ones */, CNT_N = CNT_SEGC + 5 + 3 };
@@ -87,7 +90,7 @@ struct ygpu_ctx {
     std::vector<uint32_t> hClumpStart, hOps, hClumpFragStart, hClumpRS, hDpOps; std::vector<ygpu_clump> hClumps; std::vector<ygpu_fragment> hFrags, hClumpFrags;
     std::vector<ygpu_dp_result> hDpRes; ygpu_counters hCounters{};
     // asynchronous tickets (ygpu_submit / ygpu_wait): one worker thread per context, started on first use
-    std::thread worker; std::mutex aMu; std::condition_variable aCv; const ygpu_read_batch *aBatch = nullptr; uint64_t aTicket = 0; int aRc = 0; bool aOpen = false, aDone = false, aQuit = false; ygpu_result_batch aOut{};
+    std::thread worker; std::mutex aMu; std::condition_variable aCv; const ygpu_read_batch *aBatch = nullptr; uint64_t aTicket = 0; int aRc = 0; bool aOpen = false, aDone = false, aQuit = false, aWaiting = false; ygpu_result_batch aOut{};
     // timing
     long long lastFall = -1; unsigned int hFall = 0; uint32_t *pinned = nullptr; hipEvent_t evSync = nullptr; hipEvent_t ev[T_N][2]; float ms[T_N] = {0}; float totalMs = 0; const char *names[T_N]; bool rowsPacked = false;
 };
@@ -349,7 +352,9 @@ static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap, int 
     front = 2 * ctx->maxQ + 8 * ctx->P.bandWidth + 64; listCap = 2 * front + 3 * ctx->maxQ + 1024;
     const long long md = std::min<long long>(ctx->P.maxDesert, 32000), g = std::min<long long>(ctx->P.maxGap, 32000), wMax = md + g + 2 * ctx->P.bandWidth + 3;
     genCap = (int)std::max<long long>(1024, wMax + 1);
-    traceRows = (int)std::max<long long>(ctx->maxQ + 2, ((md + 2) * wMax + 63) / 64 + 1);
+    // rows of 64 cells: an X-drop extension of a whole read, 4 * BW + 1 columns wide (more than one 64-cell row per DP row when BW > 15), or the widest gap fill
+    const long long wExt = 4ll * ctx->P.bandWidth + 1;
+    traceRows = (int)std::max<long long>((ctx->maxQ + 2) * ((wExt + 63) / 64), ((md + 2) * wMax + 63) / 64 + 1);
 }
 
 
@@ -445,36 +450,47 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     }
     const double slackChunks = (double)maxWavesK + (double)ctx->nCU * 8.0 + 64.0;   // every wave's open chunk, and the careful-extension round's
     const double wantChunks = (double)boundBlocks * ctx->traceRatio / chunkBlocks + slackChunks;
-    std::vector<uint32_t> cuts; cuts.push_back(0);                            // root indices
-    unsigned long long nChunksArena = 0;
-    if (wantChunks <= (double)budgetChunks && ctx->traceBudgetBlocks <= 0) { cuts.push_back(NC); nChunksArena = (unsigned long long)wantChunks; }
-    else {
-        // ranges of roots whose estimated need fits the budget (the estimate follows the problems' bounds); YGPU_TRACE_BUDGET_BLOCKS (test hook) sets the
-        // bound blocks per range directly, so that small inputs take this path
-        double perRange = std::max(1.0, ((double)budgetChunks - slackChunks) * chunkBlocks / ctx->traceRatio);                                  // bound blocks per range
-        if (ctx->traceBudgetBlocks > 0) perRange = std::min(perRange, (double)ctx->traceBudgetBlocks);
-        nChunksArena = (unsigned long long)std::min((double)budgetChunks, perRange * ctx->traceRatio / chunkBlocks + slackChunks);
-        ctx->hStripOff.resize(nProb + 1);
-        HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
-        uint32_t r0 = 0;
-        while (r0 < NC) {
-            uint32_t lo = r0 + 1, hi = NC;                                    // largest r1 with bound(r0 .. r1) <= perRange (at least one root)
-            while (lo < hi) { uint32_t mid = lo + (hi - lo + 1) / 2; if ((double)(ctx->hStripOff[2 * (size_t)mid] - ctx->hStripOff[2 * (size_t)r0]) <= perRange) lo = mid; else hi = mid - 1; }
-            cuts.push_back(lo); r0 = lo;
+    std::vector<uint32_t> cuts;                                               // root indices
+    unsigned long long nChunksArena = 0; size_t nRanges = 1; bool haveBounds = false;
+    for (;;) {
+        cuts.assign(1, 0);
+        if (wantChunks <= (double)budgetChunks && ctx->traceBudgetBlocks <= 0) { cuts.push_back(NC); nChunksArena = (unsigned long long)wantChunks; }
+        else {
+            // ranges of roots whose estimated need fits the budget (the estimate follows the problems' bounds); YGPU_TRACE_BUDGET_BLOCKS (test hook) sets the
+            // bound blocks per range directly, so that small inputs take this path
+            double perRange = std::max(1.0, ((double)budgetChunks - slackChunks) * chunkBlocks / ctx->traceRatio);                                  // bound blocks per range
+            if (ctx->traceBudgetBlocks > 0) perRange = std::min(perRange, (double)ctx->traceBudgetBlocks);
+            nChunksArena = (unsigned long long)std::min((double)budgetChunks, perRange * ctx->traceRatio / chunkBlocks + slackChunks);
+            if (!haveBounds) {
+                ctx->hStripOff.resize(nProb + 1);
+                HIPCHK(hipMemcpyAsync(ctx->hStripOff.data(), ctx->stripOff.p, 8ull * (nProb + 1), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx)); haveBounds = true;
+            }
+            uint32_t r0 = 0;
+            while (r0 < NC) {
+                uint32_t lo = r0 + 1, hi = NC;                                    // largest r1 with bound(r0 .. r1) <= perRange (at least one root)
+                while (lo < hi) { uint32_t mid = lo + (hi - lo + 1) / 2; if ((double)(ctx->hStripOff[2 * (size_t)mid] - ctx->hStripOff[2 * (size_t)r0]) <= perRange) lo = mid; else hi = mid - 1; }
+                cuts.push_back(lo); r0 = lo;
+            }
         }
-    }
-    const size_t nRanges = cuts.size() - 1; ctx->statRanges = (int)nRanges;
-    nChunksArena = std::min<unsigned long long>(std::max<unsigned long long>(nChunksArena, maxWavesK + 64ull), 0xFFFFFFF0ull);
-    {   // an arena that is there and within the estimate's safety margin is not re-allocated for the margin's sake (freeing and allocating tens of GB stalls
-        // every context of the device; should it overflow, the stage is redone with twice as much)
-        const unsigned long long capChunks = ctx->extTrace.cap > 256 ? (unsigned long long)((ctx->extTrace.cap - 256) / (YD_CHUNK_DWORDS * 4ull)) : 0ull;
-        if (nRanges == 1 && capChunks > maxWavesK + 64ull && nChunksArena > capChunks && (double)nChunksArena <= 1.3 * (double)capChunks) nChunksArena = capChunks;
-    }
-    if (ctx->extTrace.ensure((size_t)nChunksArena * YD_CHUNK_DWORDS * 4ull + 256) != 0) {
+        nRanges = cuts.size() - 1;
+        const unsigned long long minChunks = maxWavesK + 64ull;
+        nChunksArena = std::min<unsigned long long>(std::max<unsigned long long>(nChunksArena, minChunks), 0xFFFFFFF0ull);
+        {   // an arena that is there and within the estimate's safety margin is not re-allocated for the margin's sake (freeing and allocating tens of GB stalls
+            // every context of the device; should it overflow, the stage is redone with twice as much)
+            const unsigned long long capChunks = ctx->extTrace.cap > 256 ? (unsigned long long)((ctx->extTrace.cap - 256) / (YD_CHUNK_DWORDS * 4ull)) : 0ull;
+            if (nRanges == 1 && capChunks > minChunks && nChunksArena > capChunks && (double)nChunksArena <= 1.3 * (double)capChunks) nChunksArena = capChunks;
+        }
+        // The arena is idle here (the stage has not started): the old one is freed before the new one is asked for, and the request is exact, so that a
+        // budget that counts the old arena as reusable can be met.  A request the device refuses although the budget allowed it (another process took the
+        // memory meanwhile, fragmentation) is halved and the roots are cut into ranges for what there is; only an arena that cannot even hold every wave's
+        // open chunk is an error.
+        if (ctx->extTrace.ensureExact((size_t)nChunksArena * YD_CHUNK_DWORDS * 4ull + 256) == 0) break;
         (void)hipGetLastError();
-        // the allocation failed although the budget allowed it (another process, fragmentation): take what is there and let the ranges do the rest
-        ctx->traceRatio = std::max(ctx->traceRatio, 0.05); ctx->err = "hipMalloc failed for the extension trace arena"; return YGPU_ENOMEM;
+        if (nChunksArena <= minChunks) { ctx->err = "hipMalloc failed for the extension trace arena (not even one chunk per wave fits)"; return YGPU_ENOMEM; }
+        budgetChunks = std::max<unsigned long long>(minChunks, nChunksArena / 2);
+        if (kTrace) fprintf(stderr, "[ygpu] trace arena of %llu chunks refused by the device: retrying with %llu and ranges\n", nChunksArena, budgetChunks);
     }
+    ctx->statRanges = (int)nRanges;
     nChunksArena = std::min<unsigned long long>(0xFFFFFFF0ull, (unsigned long long)((ctx->extTrace.cap - 256) / (YD_CHUNK_DWORDS * 4ull)));
     const uint32_t maxCh = (uint32_t)std::min<unsigned long long>(nChunksArena, std::max<unsigned long long>(64ull, 4ull * nChunksArena / std::max(1u, maxWavesK) + 64ull));
     ENSURE(ctx->waveChunks, 4ull * (size_t)maxWavesK * maxCh + 64);
@@ -759,7 +775,9 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     // supported parameter ranges of the wave-parallel DP (dp_wave.h)
     long big = 32000L * std::max(std::max(p->MScore, p->RCost), p->GECost) + p->GOCost + 128L * p->GECost;
     if (p->wordLen < 1 || p->wordLen > 15 || ix->wordLen != p->wordLen) { ctx->err = "wordLen must be 1..15 and match the index"; return YGPU_EINVAL; }
-    if (p->bandWidth < 0 || 4 * p->bandWidth + 1 > 64) { ctx->err = "bandWidth > 15 is not supported by the wave-parallel extension kernel"; return YGPU_EINVAL; }
+    // (any band the reference accepts, Main.c:324-327: an extension strip of 4 * BW + 1 <= 64 columns runs with a column per lane, a wider one goes through the
+    // sequential recurrence of dp_wave.h with its scratch sized by alignDims below; the bound here only keeps that scratch within a few MB per wave)
+    if (p->bandWidth < 0 || p->bandWidth > 255) { ctx->err = "bandWidth must be between 0 and 255"; return YGPU_EINVAL; }
     if (p->maxGap < 0 || p->maxGap > 16383 || p->maxIntron < 0 || p->maxHits < 0 || p->maxHits > 65525) { ctx->err = "maxGap/maxIntron/maxHits out of range"; return YGPU_EINVAL; }
     if (p->MScore < 0 || p->RCost < 0 || p->GECost < 0 || p->GOCost < 0 || big >= (1L << 23)) { ctx->err = "scoring parameters out of the supported range"; return YGPU_EINVAL; }
     { int rc0 = initCommon(ctx, device); if (rc0) return rc0; }
@@ -885,6 +903,32 @@ int ygpu_collect(ygpu_ctx *ctx, ygpu_result_batch *out)
     return 0;
 }
 
+int ygpu_result_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops)
+{
+    if (!ctx || ctx->stageDone < 3) return YGPU_EINVAL;
+    if (n_clumps) *n_clumps = ctx->nOut; if (n_ops) *n_ops = ctx->nOutOps;
+    return 0;
+}
+int ygpu_collect_into(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_clump *clumps, uint32_t *ops, ygpu_result_batch *out)
+{
+    if (!ctx || !out || !clump_start || ctx->stageDone < 3 || (ctx->nOut && !clumps) || (ctx->nOutOps && !ops)) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->nReads;
+    HIPCHK(hipMemcpyAsync(clump_start, ctx->readStart.p, 4ull * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nOut) HIPCHK(hipMemcpyAsync(clumps, ctx->outClumps2.p, sizeof(ygpu_clump) * (uint64_t)ctx->nOut, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nOutOps) HIPCHK(hipMemcpyAsync(ops, ctx->outOps.p, 4ull * ctx->nOutOps, hipMemcpyDeviceToHost, ctx->stream));
+    DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(streamSync(ctx));
+    { const unsigned long long dropped = dc.v[C_FRAGS];
+      dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags + dropped; dc.v[C_REGIONS] = ctx->nRegions + dropped; }
+    memcpy(&ctx->hCounters, dc.v, sizeof(ygpu_counters));
+    out->n_reads = n; out->clump_start = clump_start; out->clumps = clumps; out->ops = ops;
+    out->n_clumps = ctx->nOut; out->n_ops = ctx->nOutOps; out->counters = ctx->hCounters;
+    return 0;
+}
+void *ygpu_host_alloc(size_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+void ygpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 static void asyncWorker(ygpu_ctx *ctx)
 {
     std::unique_lock<std::mutex> lk(ctx->aMu);
@@ -902,7 +946,7 @@ int ygpu_submit(ygpu_ctx *ctx, const ygpu_read_batch *batch, ygpu_ticket *ticket
 {
     if (!ctx || !ctx->stream || !batch || !ticket) return YGPU_EINVAL;
     std::unique_lock<std::mutex> lk(ctx->aMu);
-    if (ctx->aOpen) { ctx->err = "ygpu_submit: the previous ticket has not been waited for"; return YGPU_EBUSY; }
+    if (ctx->aOpen) return YGPU_EBUSY;                                       // (the context's error text is the worker's while a ticket is open: the code says it all)
     if (!ctx->worker.joinable()) ctx->worker = std::thread(asyncWorker, ctx);
     ctx->aBatch = batch; ctx->aOpen = true; ctx->aDone = false; ctx->aRc = 0; *ticket = ++ctx->aTicket;
     ctx->aCv.notify_all();
@@ -919,9 +963,10 @@ int ygpu_wait(ygpu_ctx *ctx, ygpu_ticket ticket, ygpu_result_batch *out)
 {
     if (!ctx || !out) return YGPU_EINVAL;
     std::unique_lock<std::mutex> lk(ctx->aMu);
-    if (!ctx->aOpen || ticket != ctx->aTicket) { ctx->err = "ygpu_wait: no such open ticket"; return YGPU_EINVAL; }
+    if (!ctx->aOpen || ctx->aWaiting || ticket != ctx->aTicket) return YGPU_EINVAL;      // no such open ticket, or another thread is already waiting for it
+    ctx->aWaiting = true;
     ctx->aCv.wait(lk, [&] { return ctx->aDone; });
-    ctx->aOpen = false; *out = ctx->aOut;
+    ctx->aOpen = false; ctx->aWaiting = false; *out = ctx->aOut;
     return ctx->aRc;
 }
 

@@ -60,11 +60,16 @@ int runIndex(Args &a, FILE *log)                                              //
     IndexImage image;
     // count -> scan -> fill -> order -> sample on the GPU (device/index_build.hip) when there is one and the skip distance is the default 1; the host
     // builder (the reference's three passes, formats.cpp) otherwise.  Both produce the reference's file byte for byte.
-    const bool onDevice = !a.cpuIndex && a.skipDist == 1 && getenv("YAHA_CPU_INDEX") == nullptr && visibleDevices() > a.device;
+    bool onDevice = !a.cpuIndex && a.skipDist == 1 && a.device >= 0 && getenv("YAHA_CPU_INDEX") == nullptr && visibleDevices() > a.device;
     if (onDevice) {
         fprintf(log, "Building the index on GPU %d.\n", a.device);
-        if (!buildIndexDevice(a.device, g, a.wordLen, a.maxHits, image, log, err)) { fprintf(log, "Index build on the GPU failed: %s\n", err.c_str()); return 1; }
-    } else if (!buildIndex(g, a.wordLen, a.skipDist, a.maxHits, image, log)) { fprintf(log, "Insufficient memory to build the index.\n"); return 1; }
+        if (!buildIndexDevice(a.device, g, a.wordLen, a.maxHits, image, log, err)) {
+            // (a shared or smaller device may lack the ~40 GB an hg18-scale build keeps resident: the host builder writes the same file, slower)
+            fprintf(log, "Index build on the GPU failed (%s): building on the host instead.\n", err.c_str());
+            image.release(); onDevice = false;
+        }
+    }
+    if (!onDevice && !buildIndex(g, a.wordLen, a.skipDist, a.maxHits, image, log)) { fprintf(log, "Insufficient memory to build the index.\n"); return 1; }
     if (timing) { fprintf(log, "[yaha] index image (%.2f GB) built in %.1f s %s\n", image.words * 4 / 1e9, now() - t0, onDevice ? "on the GPU" : "on the host"); t0 = now(); }
     if (!writeFile(xfile.c_str(), image.p, image.words * 4, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
     if (timing) fprintf(log, "[yaha] index file written in %.1f s\n", now() - t0);
@@ -165,14 +170,19 @@ int runQueries(Args &a, FILE *log)
     // Six stages, batches handed over through bounded queues, a ticket ordering the output (= the reference's -t 1 order):
     //   splitter   (1 thread)          record boundaries of the memory-mapped / block-read input (memchr; reader.cpp) -- the only serial part;
     //   parsers    (a few threads)     id, sequence, quality, codes and the skip rules of one batch of records;
-    //   contexts   (1 thread each)     upload, run the hot path, collect, copy the results out of the context's buffers (asleep while the device works);
+    //   contexts   (1 thread each)     upload, run the hot path, results by DMA into the batch's page-locked buffers (asleep while the device works);
     //   formatters                     OQC/FBS filter and SAM text of one whole batch each, into the batch's own text buffer;
     //   writer     (1 thread)          batches in ticket order, one write each; the batch object -- reads, codes, results, text, all with their capacity --
     //                                  then goes back to the pool the splitter takes from, so that the steady state allocates nothing and maps no new pages.
     // The device never waits for parsing or formatting unless those stages as a whole are slower than it.  The first failure (a device error, a write
     // error) stops the run: nothing after the last complete batch before it is written, and the exit code is 1.
+    // Result storage of a batch: page-locked host memory (ygpu_host_alloc) the device copies into directly (ygpu_collect_into) -- no staging copy by the context
+    // thread, no copy out of the context afterwards (two passes over ~9 KB a read otherwise); plain memory when it cannot be locked.  Grows, never shrinks.
+    struct ResBuf { void *p = nullptr; size_t cap = 0; bool pinned = false;
+                    ~ResBuf() { drop(); } void drop() { if (p) { if (pinned) ygpu_host_free(p); else free(p); } p = nullptr; cap = 0; }
+                    bool ensure(size_t bytes) { if (bytes <= cap) return true; drop(); const size_t c = bytes + bytes / 4 + 4096; p = ygpu_host_alloc(c); pinned = p != nullptr; if (!p) p = malloc(c); cap = p ? c : 0; return p != nullptr; } };
     struct Batch { uint64_t ticket = 0; std::vector<Span> spans; std::vector<Read> reads; size_t nReads = 0; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
-                   std::vector<uint32_t> clumpStart, ops; std::vector<ygpu_clump> clumps; uint64_t nClumps = 0, nOps = 0; Text text; double tRead = 0, tDev = 0, tFmt = 0; };
+                   ResBuf clumpStart, ops, clumps; uint64_t nClumps = 0, nOps = 0; Text text; double tRead = 0, tDev = 0, tFmt = 0; };
     typedef std::unique_ptr<Batch> BatchP;
     struct Pool { std::mutex mu; std::vector<BatchP> free; BatchP get() { { std::lock_guard<std::mutex> lk(mu); if (!free.empty()) { BatchP b = std::move(free.back()); free.pop_back(); return b; } } return BatchP(new Batch); }
                   void put(BatchP &&b) { std::lock_guard<std::mutex> lk(mu); free.push_back(std::move(b)); } } pool;
@@ -236,19 +246,23 @@ int runQueries(Args &a, FILE *log)
             if (stop) { b->nReads = 0; fmtQ.push(std::move(b)); continue; }
             const double t0 = now();
             ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res;
+            auto hotPath = [&]() -> int {                                      // upload, run, results straight into the batch's own buffers
+                int rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;
+                uint64_t nc = 0, no = 0; rc = ygpu_result_size(ctx[d], &nc, &no); if (rc != 0) return rc;
+                if (!b->clumpStart.ensure(4 * (b->nReads + 1)) || !b->clumps.ensure(sizeof(ygpu_clump) * nc) || !b->ops.ensure(4 * no)) return YGPU_ENOMEM;
+                return ygpu_collect_into(ctx[d], (uint32_t *)b->clumpStart.p, (ygpu_clump *)b->clumps.p, (uint32_t *)b->ops.p, &res);
+            };
             int rc;
             if (first) {
                 std::lock_guard<std::mutex> one(W.first);
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning++; }
-                rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc == 0) rc = ygpu_collect(ctx[d], &res); first = false;
+                rc = hotPath(); first = false;
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning--; } W.cv.notify_all();
             } else {
                 { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.firstRunning == 0; }); }
-                rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc == 0) rc = ygpu_collect(ctx[d], &res);
+                rc = hotPath();
             }
-            if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, ygpu_last_error(ctx[d])); fail(m); b->nReads = 0; fmtQ.push(std::move(b)); continue; }
-            // the context's result buffers are reused by its next batch
-            b->clumpStart.assign(res.clump_start, res.clump_start + res.n_reads + 1); b->clumps.assign(res.clumps, res.clumps + res.n_clumps); b->ops.assign(res.ops, res.ops + res.n_ops);
+            if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, rc == YGPU_ENOMEM && !b->ops.p ? "host memory for the results" : ygpu_last_error(ctx[d])); fail(m); b->nReads = 0; fmtQ.push(std::move(b)); continue; }
             b->nClumps = res.n_clumps; b->nOps = res.n_ops;
             b->tDev = now() - t0;
             fmtQ.push(std::move(b));
@@ -262,7 +276,7 @@ int runQueries(Args &a, FILE *log)
             const double t0 = now(); b->text.clear();
             if (!stop && b->nReads) {
                 ygpu_result_batch res; memset(&res, 0, sizeof res);
-                res.n_reads = (uint32_t)b->nReads; res.clump_start = b->clumpStart.data(); res.clumps = b->clumps.data(); res.ops = b->ops.data(); res.n_clumps = b->nClumps; res.n_ops = b->nOps;
+                res.n_reads = (uint32_t)b->nReads; res.clump_start = (const uint32_t *)b->clumpStart.p; res.clumps = (const ygpu_clump *)b->clumps.p; res.ops = (const uint32_t *)b->ops.p; res.n_clumps = b->nClumps; res.n_ops = b->nOps;
                 local.reads.swap(b->reads); formatBatch(&local, &res, b->text, 1); local.reads.swap(b->reads);
             }
             b->tFmt = now() - t0;
@@ -280,7 +294,7 @@ int runQueries(Args &a, FILE *log)
                 if (!stop) {
                     if (w->text.len && fwrite(w->text.p, 1, w->text.len, out) != w->text.len) fail("Failure writing the output file");
                     else { const double t = now(); if (nWritten == 0) { tFirstOut = t; nFirst = w->nReads; } tLastOut = t; nWritten += w->nReads; }
-                    if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  parse %.1f  device (upload, run, collect, copy) %.1f  format %.1f ms  written at %.1f\n", (unsigned long long)w->ticket, w->nReads, w->tRead, w->tDev, w->tFmt, now() - tEnter);
+                    if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  parse %.1f  device (upload, run, collect) %.1f  format %.1f ms  written at %.1f\n", (unsigned long long)w->ticket, w->nReads, w->tRead, w->tDev, w->tFmt, now() - tEnter);
                 }
                 pool.put(std::move(w));
             }
@@ -295,7 +309,11 @@ int runQueries(Args &a, FILE *log)
     th.emplace_back(writer);
     for (auto &x : th) x.join();
     const double tDone = now();
-    for (int d = ngpu - 1; d >= 0; d--) if (ctx[d]) ygpu_destroy(ctx[d]);     // clones before their parents
+    // The command line (csrc/main.cpp) leaves right after this function: it sets YAHA_FAST_EXIT and lets the process exit release the device memory and the
+    // page-locked buffers in one go, instead of a hipFree per buffer (a second of waiting at the end of every run, measured).  Library users get the orderly path.
+    const bool fastExit = getenv("YAHA_FAST_EXIT") != nullptr;
+    if (!fastExit) for (int d = ngpu - 1; d >= 0; d--) if (ctx[d]) ygpu_destroy(ctx[d]);     // clones before their parents
+    if (fastExit) { BatchP b; while (!pool.free.empty()) { b = std::move(pool.free.back()); pool.free.pop_back(); b->clumpStart.p = b->clumps.p = b->ops.p = nullptr; } }   // (their page-locked memory goes with the process as well)
     if (fflush(out) != 0 || ferror(out)) { if (!stop) fprintf(log, "Failure writing the output file.\n"); rcAll = 1; }
     if (out != stdout && fclose(out) != 0) { fprintf(log, "Failure closing the output file.\n"); rcAll = 1; }
     if (timing) fprintf(stderr, "[yaha] batches done %.1f ms after start, teardown %.1f ms\n", tDone - tEnter, now() - tDone);
