@@ -284,7 +284,8 @@ def test_index_built_on_the_device_is_byte_identical(work, meta, tmp_path):
     # the workgroup and device sorts
     big = os.path.join(d, "big.fa")
     subprocess.check_call([os.path.join(ROOT, "tools", "yaha_sim"), "genome", "--seed", "5", "--out", big, "--seqs", "5", "--len", "6000000", "--repeat-frac", "0.5", "--nrun", "3", "--lowcomplex", "6"])
-    for args, name in ((["-L", "15"], "big.X15_01_65525S"), (["-L", "10", "-H", "40"], "big.X10_01_00040S"), (["-L", "12", "-H", "3000"], "big.X12_01_03000S")):
+    for args, name in ((["-L", "15"], "big.X15_01_65525S"), (["-L", "10", "-H", "40"], "big.X10_01_00040S"), (["-L", "12", "-H", "3000"], "big.X12_01_03000S"),
+                       (["-L", "13", "-S", "2"], "big.X13_02_65525S"), (["-L", "11", "-S", "7", "-H", "100"], "big.X11_07_00100S"), (["-L", "12", "-S", "12"], "big.X12_12_65525S")):      # -S > 1: starts follow the reference's scan (N runs re-phase it)
         subprocess.run([ya.CLI_PATH, "-g", big] + args, stderr=subprocess.DEVNULL, check=True)
         dev = os.path.join(d, name + ".device")
         os.rename(os.path.join(d, name), dev)

@@ -53,7 +53,7 @@ def test_context_creation_fails_loudly_without_a_gpu_or_with_bad_params(work, in
             with pytest.raises(RuntimeError):
                 ya.Context(s.index, s.params)
         p = ya.Params.from_buffer_copy(s.params)
-        p.bandWidth = 40
+        p.bandWidth = 300
         with pytest.raises(RuntimeError):
             ya.Context(s.index, p)
 
@@ -64,6 +64,27 @@ def test_cli_index_then_usage(work, tmp_path):
     assert r.returncode == 0 and b"Usage" in r.stderr
     r = subprocess.run([ya.CLI_PATH, "-x", "nonexistent.X11_01_65525S", "-q", "none.fa"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0
+
+
+def test_cli_compress_and_uncompress_only(work, meta, tmp_path):
+    """-c / -u (Main.c:284-293: builds of the reference without COMPILE_USER_MODE): genome.fa -> genome.nib2 only, genome.nib2 -> genome.fasta (50 bases a line,
+    Compress.c:337-397).  The .nib2 is the golden one; the FASTA compresses back to the same bytes."""
+    import hashlib, shutil, subprocess
+    g = str(tmp_path / "g.fa"); shutil.copy(os.path.join(work, "genome_small.fa"), g)
+    assert subprocess.run([ya.CLI_PATH, "-g", g, "-c"], stderr=subprocess.PIPE).returncode == 0
+    nib = str(tmp_path / "g.nib2")
+    assert hashlib.sha256(open(nib, "rb").read()).hexdigest() == meta["index"]["genome_small.nib2"]["sha256"]
+    assert not [f for f in os.listdir(tmp_path) if ".X" in f]                      # no index was made
+    assert subprocess.run([ya.CLI_PATH, "-g", nib, "-u"], stderr=subprocess.PIPE).returncode == 0
+    fasta = open(tmp_path / "g.fasta").read().split("\n")
+    assert fasta[0].startswith(">") and all(len(l) <= 50 for l in fasta if not l.startswith(">")) and len(fasta[1]) == 50
+    orig = "".join(l for l in open(g).read().split("\n") if not l.startswith(">")).upper()
+    assert "".join(l for l in fasta if not l.startswith(">")) == orig
+    os.rename(nib, str(tmp_path / "first.nib2"))
+    assert subprocess.run([ya.CLI_PATH, "-g", str(tmp_path / "g.fasta"), "-c"], stderr=subprocess.PIPE).returncode == 0
+    assert open(nib, "rb").read() == open(tmp_path / "first.nib2", "rb").read()
+    assert subprocess.run([ya.CLI_PATH, "-g", nib, "-c"], stderr=subprocess.PIPE).returncode != 0      # -c wants a FASTA file
+    assert subprocess.run([ya.CLI_PATH, "-g", g, "-u"], stderr=subprocess.PIPE).returncode != 0        # -u a .nib2
 
 
 def test_bench_picks_the_genome_the_box_can_hold(tmp_path, monkeypatch):

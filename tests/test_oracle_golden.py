@@ -31,6 +31,22 @@ def test_index_sampling_of_overrepresented_kmers_is_byte_identical(work, meta):
     assert sha(os.path.join(work, name)) == meta["index"][name]["sha256"]
 
 
+@pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref/yaha not built")
+@pytest.mark.parametrize("args", [["-L", "11", "-S", "3"], ["-L", "9", "-S", "9", "-H", "50"], ["-L", "12", "-S", "2"]])
+def test_skip_distance_index_matches_the_live_reference(work, tmp_path, args):
+    # -S > 1 (Index.c:98-127: steps of S from the sequence start, restart at an absolute multiple of S behind a run of N): the reference binary builds the
+    # same genome here and the files must be identical -- the host builder in this tier, the device builder in the GPU tier (test_gpu_parity.py)
+    import shutil, subprocess
+    a, b = tmp_path / "mine", tmp_path / "ref"; a.mkdir(); b.mkdir()
+    for d in (a, b):
+        shutil.copy(os.path.join(work, "genome_small.nib2"), str(d / "g.nib2"))
+    subprocess.run([ya.CLI_PATH, "-g", str(a / "g.nib2"), "-cpuindex"] + args, stderr=subprocess.DEVNULL, check=True)
+    oracle.run_reference(["-g", str(b / "g.nib2")] + args)
+    name = [f for f in os.listdir(a) if ".X" in f]
+    assert len(name) == 1 and os.path.exists(b / name[0])
+    assert sha(str(a / name[0])) == sha(str(b / name[0]))
+
+
 def run_oracle_pipeline(index, reads, oflag, extra, batch=97, threads=4):
     out = []
     with ya.Session(["-x", index, "-q", reads] + oflag_args(oflag) + list(extra)) as s:

@@ -26,5 +26,5 @@ int  ygpu_dp_batch_ex(ygpu_ctx *, const ygpu_dp_problem *, uint32_t, int, const 
 }
 namespace yaha {
 int  visibleDevices() { return 0; }
-bool buildIndexDevice(int, const Genome &, int, int, IndexImage &, FILE *, std::string &err) { err = "sanitizer build: no device code"; return false; }
+bool buildIndexDevice(int, const Genome &, int, int, int, IndexImage &, FILE *, std::string &err) { err = "sanitizer build: no device code"; return false; }
 }

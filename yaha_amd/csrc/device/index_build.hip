@@ -12,8 +12,8 @@
 //   sampling     k-mers with more than maxHits occurrences keep a Floyd sample drawn with the default-seeded Marsaglia generator, consumed in
 //                k-mer order (Index.c:271-315, Math.c:304-343): inherently sequential, but it concerns a handful of k-mers -- their lists go to
 //                the host, the samples come back, and one gather pass compacts ROA (k_ix_compact).
-// k-mers never span sequences and skip any window holding a code > 3 (Index.c:98-127).  Skip distance 1 only (the default); the host builder
-// (host/formats.cpp) keeps -S > 1 and machines without a GPU.  Output: the complete file image, byte-identical to the reference's.
+// k-mers never span sequences and skip any window holding a code > 3 (Index.c:98-127); any skip distance (walkKmers states which starts the reference's scan
+// visits when -S > 1).  The host builder (host/formats.cpp) remains for machines without a GPU.  Output: the complete file image, byte-identical to the reference's.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
@@ -31,11 +31,14 @@ namespace {
 #define IX_SMALL 32u
 #define IX_BLOCK 8192u
 
-struct SeqTab { const uint32_t *start, *len; uint32_t n; };
+struct SeqTab { const uint32_t *start, *len; uint32_t n; int skip; const uint32_t *firstBad; };     // skip > 1: firstBad[s] = offset of the first code > 3 of sequence s (0xFFFFFFFF: none)
 
 __device__ __forceinline__ uint32_t nibAt(const uint8_t *b, uint64_t off) { const uint8_t v = b[off >> 1]; return (off & 1) ? (uint32_t)(v & 15u) : (uint32_t)(v >> 4); }
 
-// Calls visit(hash, offset) for every valid k-mer start in [p0, p0 + IX_PER_THREAD) (skip distance 1).
+// Calls visit(hash, offset) for every k-mer start in [p0, p0 + IX_PER_THREAD) that the reference's scan visits (Index.c:98-127).  Skip distance 1: every start
+// whose window is clean.  Skip distance S > 1: the scan steps S from the sequence's start until a window holds a code > 3, and restarts behind that run of codes
+// at the next ABSOLUTE multiple of S (`((bad + S-1) / S) * S`) -- so a start is visited iff its window is clean and it is (start of sequence) + jS before the
+// sequence's first bad code, or a multiple of S after it.
 template <class Visit> __device__ __forceinline__ void walkKmers(const uint8_t *bases, SeqTab T, int k, uint64_t p0, uint64_t nOffsets, Visit visit)
 {
     if (p0 >= nOffsets) return;
@@ -56,11 +59,34 @@ template <class Visit> __device__ __forceinline__ void walkKmers(const uint8_t *
         const uint32_t c = nibAt(bases, p);
         if (c > 3u) { good = 0; continue; }
         h = ((h << 2) | c) & mask; good++;
-        if (good >= k) { const uint64_t s = p + 1 - (uint64_t)k; if (s >= p0 && s < p0 + IX_PER_THREAD) visit(h, (uint32_t)s); }
+        if (good >= k) {
+            const uint64_t s = p + 1 - (uint64_t)k;
+            if (s >= p0 && s < p0 + IX_PER_THREAD) {
+                bool ok = true;
+                if (T.skip > 1) { const uint64_t fb = T.firstBad[si]; ok = (s + (uint64_t)k <= fb) ? ((s - segStart) % (uint64_t)T.skip == 0) : (s % (uint64_t)T.skip == 0); }
+                if (ok) visit(h, (uint32_t)s);
+            }
+        }
     }
     (void)segEnd;
 }
 
+// skip distance > 1: the first code > 3 of every sequence (one atomicMin per thread and sequence that has one in the thread's span)
+__global__ void k_ix_first_bad(const uint8_t *bases, SeqTab T, uint64_t nOffsets, uint32_t *firstBad)
+{
+    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * IX_PER_THREAD;
+    if (p0 >= nOffsets) return;
+    uint32_t lo = 0, hi = T.n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)T.start[mid] + T.len[mid] <= p0) lo = mid + 1; else hi = mid; }
+    uint32_t si = lo; uint32_t best = 0xFFFFFFFFu;
+    for (uint64_t p = p0; p < p0 + IX_PER_THREAD && p < nOffsets; p++) {
+        while (si < T.n && p >= (uint64_t)T.start[si] + T.len[si]) { if (best != 0xFFFFFFFFu) { atomicMin(&firstBad[si], best); best = 0xFFFFFFFFu; } si++; }
+        if (si >= T.n) break;
+        if (p < T.start[si]) continue;
+        if (best == 0xFFFFFFFFu && nibAt(bases, p) > 3u) best = (uint32_t)p;
+    }
+    if (best != 0xFFFFFFFFu && si < T.n) atomicMin(&firstBad[si], best);
+}
 __global__ void k_ix_count(const uint8_t *bases, SeqTab T, int k, uint64_t nOffsets, uint32_t *counts)
 {
     const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * IX_PER_THREAD;
@@ -164,7 +190,7 @@ static double wallNow() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts
 int visibleDevices() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 
 // Builds the complete index file image {-1, wordLen, maxHits, total} + startingOffs[4^k + 1] + ROA[total] on HIP device `device`.
-bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, IndexImage &image, FILE *log, std::string &err)
+bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, int maxHits, IndexImage &image, FILE *log, std::string &err)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { err = "no such HIP device"; return false; }
@@ -175,12 +201,19 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, Ind
     std::vector<uint32_t> st, ln; for (auto &s : g.seqs) if ((int64_t)s.length >= wordLen) { st.push_back(s.start); ln.push_back(s.length); }
     // a sequence shorter than a k-mer holds none; the table keeps only the others (ascending starts)
     const uint32_t nSeq = (uint32_t)st.size();
-    Buf dBases, dStart, dLen, dCnt, dSO, dCur, dROA, dTemp, dBig, dOver, dN, dSO2, dROA2;
+    Buf dFirstBad, dBases, dStart, dLen, dCnt, dSO, dCur, dROA, dTemp, dBig, dOver, dN, dSO2, dROA2;
     IXCHK(hipMalloc(&dBases.p, g.nBaseBytes + 64)); IXCHK(hipMemcpy(dBases.p, g.bases, g.nBaseBytes, hipMemcpyHostToDevice));
     IXCHK(hipMalloc(&dStart.p, 4ull * (nSeq + 1))); IXCHK(hipMalloc(&dLen.p, 4ull * (nSeq + 1)));
     if (nSeq) { IXCHK(hipMemcpy(dStart.p, st.data(), 4ull * nSeq, hipMemcpyHostToDevice)); IXCHK(hipMemcpy(dLen.p, ln.data(), 4ull * nSeq, hipMemcpyHostToDevice)); }
-    SeqTab T; T.start = dStart.as<uint32_t>(); T.len = dLen.as<uint32_t>(); T.n = nSeq;
+    SeqTab T; T.start = dStart.as<uint32_t>(); T.len = dLen.as<uint32_t>(); T.n = nSeq; T.skip = skipDist; T.firstBad = nullptr;
     lap("reference to HBM");
+    const uint64_t nThreads0 = (nOffsets + IX_PER_THREAD - 1) / IX_PER_THREAD; const unsigned grid0 = (unsigned)((nThreads0 + 255) / 256);
+    if (skipDist > 1) {
+        IXCHK(hipMalloc(&dFirstBad.p, 4ull * (nSeq + 1))); IXCHK(hipMemset(dFirstBad.p, 0xFF, 4ull * (nSeq + 1)));
+        if (grid0) hipLaunchKernelGGL(k_ix_first_bad, dim3(grid0), dim3(256), 0, 0, dBases.as<uint8_t>(), T, nOffsets, dFirstBad.as<uint32_t>());
+        IXCHK(hipGetLastError());
+        T.firstBad = dFirstBad.as<uint32_t>();
+    }
     IXCHK(hipMalloc(&dCnt.p, 4ull * (HT + 1))); IXCHK(hipMemset(dCnt.p, 0, 4ull * (HT + 1)));
     const uint64_t nThreads = (nOffsets + IX_PER_THREAD - 1) / IX_PER_THREAD; const unsigned grid = (unsigned)((nThreads + 255) / 256);
     if (grid) hipLaunchKernelGGL(k_ix_count, dim3(grid), dim3(256), 0, 0, dBases.as<uint8_t>(), T, wordLen, nOffsets, dCnt.as<uint32_t>());

@@ -14,6 +14,7 @@ static void usage(FILE *o)
     fputs("Usage (defaults in parentheses):\n\n"
           "Index creation:\n"
           "  yaha -g genome.{fa|fna|fasta|nib2} [-H maxHits (65525)] [-L wordLen (15)] [-S skipDist (1)] [-device D (0)] [-cpuindex]\n"
+          "  yaha -g genome.{fa|fna|fasta} -c   (compress to genome.nib2 only)      yaha -g genome.nib2 -u   (back to genome.fasta)\n"
           "       (built on the GPU when one is visible and -S is 1; -cpuindex forces the host builder; the files are identical)\n\n"
           "Query alignment (hot path on MI355X):\n"
           "  yaha -x indexFile [-q queryFile|(stdin)] [-o8|(-osh)|-oss outFile|(stdout)] [-t hostThreads (1)]\n"
@@ -81,6 +82,8 @@ int parseArgs(int argc, char **argv, Args &a)
         else if (is("-PSS")) { if (!parseFloat(val(), "-PSS", a.FBS_PSScore)) return 2; }
         else if (is("-I")) { if (!parseInt(val(), "-I", a.maxIntron)) return 2; }          // experimental builds of the reference, Main.c:418-435
         else if (is("-R")) { if (!parseInt(val(), "-R", a.minRawScore)) return 2; }
+        else if (is("-c")) { a.compress = true; index = false; }                                // the two below: Main.c:284-293 (builds of the reference without COMPILE_USER_MODE)
+        else if (is("-u")) { a.uncompress = true; index = false; }
         else if (is("-gpus")) { if (!parseInt(val(), "-gpus", a.gpus)) return 2; if (a.gpus < 1) { fprintf(stderr, "-gpus must be at least 1.\n\n"); usage(stderr); return 2; } }
         else if (is("-ctx")) { if (!parseInt(val(), "-ctx", a.ctxPerGpu)) return 2; if (a.ctxPerGpu < 1 || a.ctxPerGpu > 8) { fprintf(stderr, "-ctx must be between 1 and 8.\n\n"); usage(stderr); return 2; } }
         else if (is("-device")) { if (!parseInt(val(), "-device", a.device)) return 2; }
@@ -90,6 +93,17 @@ int parseArgs(int argc, char **argv, Args &a)
         else { fprintf(stderr, "%s is not a valid option.\n\n", k); usage(stderr); return 2; }
     }
     a.query = query; a.index = index && !query;
+    if ((a.compress || a.uncompress) && !query) {                                                  // Main.c:472-533: -c wants a FASTA genome, -u a .nib2
+        if (!a.haveG) { fprintf(stderr, "Genome file specification (-g) is required for index creation.\n\n"); usage(stderr); return 2; }
+        size_t dot = a.gfileName.rfind('.'); const std::string ext = dot == std::string::npos ? "" : a.gfileName.substr(dot);
+        const bool fasta = ext == ".fna" || ext == ".fa" || ext == ".fasta";
+        if (!fasta && ext != ".nib2") { fprintf(stderr, "Expecting a \".fa\", \".fna\", \".fasta\", or \".nib2\" genome file.\n"); return 2; }
+        if (a.compress && !fasta) { fprintf(stderr, "Expecting a \".fa\", \".fna\", or \".fasta\" genome file.\n"); return 2; }
+        if (a.uncompress && !a.compress && fasta) { fprintf(stderr, "Expecting a \".nib2\" genome file.\n"); return 2; }
+        a.ofileName = a.gfileName.substr(0, dot) + (a.compress ? ".nib2" : ".fasta");
+        postProcessArgs(a, false);
+        return 0;
+    }
     if (a.index) {
         if (!a.haveG) { fprintf(stderr, "Genome file specification (-g) is required for index creation.\n\n"); usage(stderr); return 2; }
         if (a.haveO) { fprintf(stderr, "Output file specification is not allowed during index creation.\n\n"); usage(stderr); return 2; }

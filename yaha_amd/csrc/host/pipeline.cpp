@@ -58,12 +58,12 @@ int runIndex(Args &a, FILE *log)                                              //
     fprintf(log, "Creating index file %s.\n", xfile.c_str());
     Genome g; if (!loadNib2(nib2.c_str(), g, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
     IndexImage image;
-    // count -> scan -> fill -> order -> sample on the GPU (device/index_build.hip) when there is one and the skip distance is the default 1; the host
+    // count -> scan -> fill -> order -> sample on the GPU (device/index_build.hip) when there is one; the host
     // builder (the reference's three passes, formats.cpp) otherwise.  Both produce the reference's file byte for byte.
-    bool onDevice = !a.cpuIndex && a.skipDist == 1 && a.device >= 0 && getenv("YAHA_CPU_INDEX") == nullptr && visibleDevices() > a.device;
+    bool onDevice = !a.cpuIndex && a.device >= 0 && getenv("YAHA_CPU_INDEX") == nullptr && visibleDevices() > a.device;
     if (onDevice) {
         fprintf(log, "Building the index on GPU %d.\n", a.device);
-        if (!buildIndexDevice(a.device, g, a.wordLen, a.maxHits, image, log, err)) {
+        if (!buildIndexDevice(a.device, g, a.wordLen, a.skipDist, a.maxHits, image, log, err)) {
             // (a shared or smaller device may lack the ~40 GB an hg18-scale build keeps resident: the host builder writes the same file, slower)
             fprintf(log, "Index build on the GPU failed (%s): building on the host instead.\n", err.c_str());
             image.release(); onDevice = false;
@@ -74,6 +74,28 @@ int runIndex(Args &a, FILE *log)                                              //
     if (!writeFile(xfile.c_str(), image.p, image.words * 4, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
     if (timing) fprintf(log, "[yaha] index file written in %.1f s\n", now() - t0);
     fprintf(log, "Index %s created.\n", xfile.c_str());
+    return 0;
+}
+
+int runCompress(Args &a, FILE *log)                                           // Main.c:572-577 -> compressFile
+{
+    std::string err; std::vector<uint8_t> img;
+    if (!compressFasta(a.gfileName.c_str(), img, err) || !writeFile(a.ofileName.c_str(), img.data(), img.size(), err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
+    return 0;
+}
+int runUncompress(Args &a, FILE *log)                                         // uncompressFile, Compress.c:337-397
+{
+    std::string err; Genome g;
+    if (!loadNib2(a.gfileName.c_str(), g, err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
+    if (a.verbose) fprintf(log, "Read in %zu reference sequences from %s.\n", g.seqs.size(), a.gfileName.c_str());
+    std::string out; size_t tot = 0; for (auto &s : g.seqs) tot += s.name.size() + 2 + s.length + s.length / 50 + 1; out.reserve(tot + 16);
+    for (auto &s : g.seqs) {
+        out += '>'; out += s.name; out += '\n';
+        int col = 0;
+        for (uint32_t j = 0; j < s.length; j++) { if (col == 50) { out += '\n'; col = 0; } out += kFourBitChars[get4(g.bases, s.start + j)]; col++; }
+        if (col != 0) out += '\n';
+    }
+    if (!writeFile(a.ofileName.c_str(), out.data(), out.size(), err)) { fprintf(log, "%s\n", err.c_str()); return 1; }
     return 0;
 }
 
@@ -371,6 +393,8 @@ int yaha_main(int argc, char **argv)
     Args a; int rc = parseArgs(argc, argv, a);
     if (rc != 0) return rc - 1;
     if (a.query) return runQueries(a, stderr);
+    if (a.compress) return runCompress(a, stderr);
+    if (a.uncompress) return runUncompress(a, stderr);
     return runIndex(a, stderr);
 }
 }

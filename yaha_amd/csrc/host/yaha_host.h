@@ -53,8 +53,8 @@ struct IndexFile {
 // builds the complete file image {-1, wordLen, maxHits, total} + SO[4^L+1] + ROA[total] (huge-page backed: 4.3 GB at L=15)
 struct IndexImage { uint32_t *p = nullptr; size_t words = 0, bytes = 0; bool alloc(size_t n); void release(); uint32_t &operator[](size_t i) { return p[i]; } ~IndexImage() { release(); } };
 bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, IndexImage &image, FILE *log);
-// the same image built on HIP device `device` (device/index_build.hip; skip distance 1)
-bool buildIndexDevice(int device, const Genome &g, int wordLen, int maxHits, IndexImage &image, FILE *log, std::string &err);
+// the same image built on HIP device `device` (device/index_build.hip)
+bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, int maxHits, IndexImage &image, FILE *log, std::string &err);
 int  visibleDevices();                                  // HIP devices this process can use (0 on a machine without a GPU)
 bool parseIndex(const uint32_t *img, size_t bytes, IndexFile &ix, std::string &err);
 bool loadIndex(const char *path, IndexFile &ix, std::string &err);
@@ -70,7 +70,7 @@ struct Args {
     int maxQueryLength = 32000; bool verbose = false, outputBlast8 = false, outputSAM = true, hardClip = true;
     // extensions of this implementation (not in the reference CLI)
     int batchReads = 0; int device = 0; int gpus = 1; int ctxPerGpu = 3; bool cpuIndex = false;      // batchReads 0: batches of ~16 M bases
-    bool query = false, index = true;
+    bool query = false, index = true, compress = false, uncompress = false;   // -c / -u: .fa -> .nib2 / .nib2 -> .fasta only (Main.c:284-293, non-user builds of the reference)
 };
 void postProcessArgs(Args &a, bool query);                                  // AlignArgs.c:108-169
 // returns 0 to continue, >0 exit code+1 to stop (usage / error)
@@ -138,4 +138,6 @@ void printClump(const Args &a, const Genome &g, const Read &r, const OutClump &o
 int effectiveCpus();                                    // affinity mask and control-group CPU quota
 int runQueries(Args &a, FILE *log);
 int runIndex(Args &a, FILE *log);
+int runCompress(Args &a, FILE *log);                     // -c: compressFile only (Main.c:572-577)
+int runUncompress(Args &a, FILE *log);                   // -u: uncompressFile, Compress.c:337-397 (50 bases a line)
 }  // namespace yaha
