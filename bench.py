@@ -170,7 +170,7 @@ def cpu_baseline(idx, fa, reads_path, n_reads, cache, target_s, read_len, div):
         return {"value": b.n_reads / dt, "unit": "reads/s", "cores": cores, "kind": "port", "sample": "%d reads, oracle/hotpath.cpp on %d threads (hot path only)" % (b.n_reads, cores)}
 
 
-def run_contexts(ctxs, steps, collect=False):
+def run_contexts(ctxs, steps, collect=False, postfilter=False):
     """`steps` passes of the hot path shared out to the contexts (one host thread each, a common counter); returns (seconds, summed stage ms)."""
     import threading
     stage_ms, lock, todo = {}, threading.Lock(), [steps]
@@ -182,7 +182,9 @@ def run_contexts(ctxs, steps, collect=False):
                     return
                 todo[0] -= 1
             c.run()                                     # synchronous: returns when the results are complete in HBM
-            if collect:
+            if postfilter:
+                c.postfilter()                          # OQC / FBS / MAPQ on the device (oqc_stage.h) and D2H of the clumps that are printed
+            elif collect:
                 c.collect()                             # D2H of the clump records and edit ops into the context's host buffers
             tm = c.timing()[1]
             with lock:
@@ -380,6 +382,15 @@ def main():
             unshared_rows_ms = st1.get("ext_rows_device_clock", 0.0) / 2 or None
             dt2, _st = run_contexts(ctxs, args.steps, collect=True)     # every step also copies its results to host memory (the other context computes meanwhile)
             d2h = {"value_with_d2h": n_reads * args.steps / dt2, "ms_per_step": 1e3 * dt2 / args.steps, "result_bytes_per_step": 32 * n_clumps + 4 * n_ops + 4 * (n_reads + 1)}
+            # ... and with the post-filter on the device instead (what the command line does): every step = hot path + OQC/FBS/MAPQ of all reads + D2H of the printed clumps only
+            try:
+                for c in ctxs:
+                    c.set_postfilter(s)
+                f = ctxs[0].postfilter(); fb = 40 * int(f.n_clumps) + 4 * int(f.n_ops) + 4 * (n_reads + 1)
+                dt3, _st3 = run_contexts(ctxs, args.steps, postfilter=True)
+                d2h.update({"value_with_postfilter": n_reads * args.steps / dt3, "ms_per_step_with_postfilter": 1e3 * dt3 / args.steps, "filtered_result_bytes_per_step": fb, "printed_clumps_per_read": int(f.n_clumps) / n_reads})
+            except Exception as e:
+                d2h["postfilter_error"] = str(e)[:200]
         k = s.params.wordLen
         for c in reversed(ctxs):
             c.close()
@@ -460,6 +471,8 @@ def main():
     }
     if d2h:
         out["value_with_d2h"] = d2h["value_with_d2h"]; out["d2h"] = d2h
+        if "value_with_postfilter" in d2h:
+            out["value_with_postfilter"] = d2h["value_with_postfilter"]
     if world == 1 and not args.no_extras:
         # the same step on BASELINE's other read lengths (configs 1 and 3), and the whole command line (config 2 end to end)
         wl = []

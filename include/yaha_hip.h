@@ -136,6 +136,36 @@ int  ygpu_result_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops);
 int  ygpu_collect_into(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_clump *clumps, uint32_t *ops, ygpu_result_batch *out);
 void *ygpu_host_alloc(size_t bytes);           /* NULL when no device runtime is there or the memory cannot be locked */
 void  ygpu_host_free(void *p);
+/* ---- post-filter on the device (optional stage behind ygpu_run) ------------------------------------------------------------------------------------------
+ * The reference's loop goes on, after the hot path, with postFilterBySimilarity (Query.c:450, GraphPath.cpp:897-1086: Optimal Query Coverage, filter by
+ * similarity, mapping quality) and prints what is left -- for a 1 kbp read one or two of the ~75 clumps the hot path returns.  ygpu_postfilter runs that step
+ * for the whole batch on the device (same routine as the host's, yaha_amd/csrc/oqc_core.h) and ygpu_collect_filtered returns, per read and in PRINT order,
+ * only the clumps printClumps would see (QS->clumps after the filter) with the fields the filter sets (Math.h Clump_t: status, mapQuality, numSecondaries,
+ * matchedPrimary; QS->primaryCount), and only their edit ops.  Bit-identical to filtering ygpu_collect's output on the host; -OQC N runs keep the host filter. */
+typedef struct ygpu_postfilter_params {
+    int32_t  minNonOverlap, BPCost, maxBPLog, FBS;     /* AlignArgs: OQCMinNonOverlap, BPCost, maxBPLog, FBS (0/1) */
+    float    FBS_PSLength, FBS_PSScore;
+    int32_t  bppVmin, bppN;                            /* break point penalty (int)(min(log10(d), maxBPLog) * BPCost + 0.5) as a step function of the distance d > 10: */
+    const uint32_t *bppThr;                            /*   bppVmin + number of thresholds <= d; bppN thresholds, ascending (host memory; copied) */
+    uint32_t n_seqs; const uint32_t *seq_start, *seq_length;   /* reference sequences in bases, ascending (findBaseSequenceNum, BaseSeq.c:81-90; host memory; copied) */
+} ygpu_postfilter_params;
+typedef struct ygpu_out_clump {                        /* 40 bytes */
+    ygpu_clump c;                                      /* op_start indexes the filtered batch's ops */
+    uint8_t  status, mapQuality; uint16_t numSecondaries, matchedPrimary, primaryCount;
+} ygpu_out_clump;
+typedef struct ygpu_filtered_batch {
+    uint32_t              n_reads;
+    const uint32_t       *clump_start;   /* n_reads + 1 */
+    const ygpu_out_clump *clumps;
+    const uint32_t       *ops;
+    uint64_t              n_clumps, n_ops;
+    ygpu_counters         counters;
+} ygpu_filtered_batch;
+int  ygpu_set_postfilter(ygpu_ctx *ctx, const ygpu_postfilter_params *p);     /* once per context */
+int  ygpu_postfilter(ygpu_ctx *ctx);                                           /* after ygpu_run */
+int  ygpu_filtered_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops);
+int  ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump *clumps, uint32_t *ops, ygpu_filtered_batch *out);
+
 /* Asynchronous form: ygpu_submit hands the batch to the context and returns at once; the context's own worker thread does
  * upload + run + collect; ygpu_wait blocks until the ticket is complete and returns the results (ygpu_poll: 1 = complete, 0 = still running).
  * One host thread can so keep several contexts (devices) busy -- the reference needs one thread per QueryState for that (Query.c:642-684).
@@ -214,6 +244,11 @@ int  yaha_session_next_batch(yaha_session *s, uint32_t max_reads, ygpu_read_batc
 /* Post-filter (OQC/FBS/dedup/MAPQ, GraphPath.cpp:897-1174) and format (printClump, AlignOutput.c:115-321)
  * the hot-path results of the current batch; text owned by the session until the next call. */
 int  yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **text, size_t *len);
+/* The same for a batch whose post-filter ran on the device: set a context up with the session's filter parameters (pointers into the session, valid until it is
+ * closed; returns YGPU_EINVAL for runs the device stage does not take: -OQC N, break point costs that are no step function), then format what
+ * ygpu_collect_filtered returned.  yaha_session_emit(ygpu_collect(...)) and yaha_session_emit_filtered(ygpu_collect_filtered(...)) give the same text. */
+int  yaha_session_postfilter_params(yaha_session *s, ygpu_postfilter_params *p);
+int  yaha_session_emit_filtered(yaha_session *s, const ygpu_filtered_batch *r, const char **text, size_t *len);
 /* `yaha -g genome.fa [-L k] [-S s] [-H h]`: writes genome.nib2 and genome.X<LL>_<SS>_<HHHHH>S (Main.c:554-628). */
 int  yaha_build_index(int argc, const char *const *argv);
 /* The complete command-line program (index creation or query alignment on the GPU). */

@@ -5,6 +5,7 @@
 // What it proves is the HOST pipeline; the HIP path is proven by the -m gpu tests.
 #include "../../yaha_amd/csrc/host/yaha_host.h"
 #include "../../oracle/hotpath.h"
+#include "../../yaha_amd/csrc/oqc_core.h"
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -12,7 +13,7 @@
 #include <thread>
 #include <chrono>
 
-struct ygpu_ctx { ygpu_index_view V; ygpu_params P; std::vector<uint8_t> codes; std::vector<uint64_t> offs; uint32_t n = 0; yoracle_result res; bool have = false; int device = 0; std::string err; };
+struct ygpu_ctx { bool pfSet = false, pfDone = false; yoqc::Params pf; std::vector<uint32_t> thr, ss, sl; std::vector<uint32_t> fcs, fops; std::vector<ygpu_out_clump> fcl; ygpu_index_view V; ygpu_params P; std::vector<uint8_t> codes; std::vector<uint64_t> offs; uint32_t n = 0; yoracle_result res; bool have = false; int device = 0; std::string err; };
 static std::atomic<int> gInits(0), gRuns(0);
 extern "C" {
 int ygpu_init(int device, const ygpu_index_view *v, const ygpu_params *p, ygpu_ctx **out)
@@ -37,6 +38,7 @@ int ygpu_run(ygpu_ctx *c)
     const int k = ++gRuns;
     if (const char *f = getenv("YTEST_FAIL_RUN")) if (k == atoi(f)) { c->err = "test double: injected device failure"; return YGPU_EINTERNAL; }
     if (c->have) { yoracle_free_result(&c->res); c->have = false; }
+    c->pfDone = false;
     ygpu_read_batch b{c->n, c->codes.data(), c->offs.data()};
     if (yoracle_run(&c->V, &c->P, &b, 1, &c->res) != 0) { c->err = "oracle failed"; return YGPU_EINTERNAL; }
     c->have = true; return 0;
@@ -53,6 +55,43 @@ int ygpu_collect_into(ygpu_ctx *c, uint32_t *cs, ygpu_clump *cl, uint32_t *ops, 
     if (!c->have) return YGPU_EINVAL;
     memcpy(cs, c->res.clump_start, 4ull * (c->res.n_reads + 1)); if (c->res.n_clumps) memcpy(cl, c->res.clumps, sizeof(ygpu_clump) * c->res.n_clumps); if (c->res.n_ops) memcpy(ops, c->res.ops, 4ull * c->res.n_ops);
     memset(r, 0, sizeof *r); r->n_reads = c->res.n_reads; r->clump_start = cs; r->clumps = cl; r->ops = ops; r->n_clumps = c->res.n_clumps; r->n_ops = c->res.n_ops; r->counters = c->res.counters;
+    return 0;
+}
+// the post-filter stage: the same routine the device runs (oqc_core.h), here on the double's copy of the results
+int ygpu_set_postfilter(ygpu_ctx *c, const ygpu_postfilter_params *p)
+{
+    c->thr.assign(p->bppThr, p->bppThr + p->bppN); c->ss.assign(p->seq_start, p->seq_start + p->n_seqs); c->sl.assign(p->seq_length, p->seq_length + p->n_seqs);
+    yoqc::Params &P = c->pf; P.GOCost = c->P.GOCost; P.GECost = c->P.GECost; P.RCost = c->P.RCost; P.MScore = c->P.MScore; P.minNonOverlap = p->minNonOverlap; P.BPCost = p->BPCost; P.maxBPLog = p->maxBPLog; P.FBS = p->FBS;
+    P.FBS_PSLength = p->FBS_PSLength; P.FBS_PSScore = p->FBS_PSScore; P.bppVmin = p->bppVmin; P.bppN = p->bppN; P.bppThr = c->thr.data(); c->pfSet = true; return 0;
+}
+int ygpu_postfilter(ygpu_ctx *c)
+{
+    if (!c->have || !c->pfSet) return YGPU_EINVAL;
+    const yoracle_result &R = c->res; c->fcs.assign(1, 0); c->fcl.clear(); c->fops.clear();
+    yoqc::Seqs G{c->ss.data(), c->sl.data(), (uint32_t)c->ss.size()};
+    for (uint32_t r = 0; r < R.n_reads; r++) {
+        const uint32_t b = R.clump_start[r], n = R.clump_start[r + 1] - b;
+        if (n) {
+            size_t pool = 0; for (uint32_t i = 0; i < n; i++) pool += 2 * ((size_t)R.clumps[b + i].n_ops + 1);
+            std::vector<yoqc::SortKey> keys(n); std::vector<int> stack(4 * (size_t)n + 8), pfx(n), path(n), pl(pool + 1); std::vector<yoqc::CNode> nodes(n), prim(n); std::vector<yoqc::PAttr> pa(n); std::vector<yoqc::OutRec> push(n), out(n);
+            yoqc::Scratch S{keys.data(), stack.data(), nodes.data(), prim.data(), pa.data(), pfx.data(), path.data(), pl.data(), push.data()};
+            int pc = 0; const int qlen = (int)(c->offs[r + 1] - c->offs[r]);
+            const int m = yoqc::run(c->pf, G, R.clumps + b, (int)n, R.ops, qlen, c->codes.data() + c->offs[r], S, out.data(), &pc);
+            for (int k = 0; k < m; k++) {
+                ygpu_out_clump f; f.c = R.clumps[b + out[k].clump]; const uint32_t *src = R.ops + f.c.op_start; f.c.op_start = (uint32_t)c->fops.size(); c->fops.insert(c->fops.end(), src, src + f.c.n_ops);
+                f.status = out[k].status; f.mapQuality = out[k].mapQuality; f.numSecondaries = out[k].numSecondaries; f.matchedPrimary = out[k].matchedPrimary; f.primaryCount = (uint16_t)pc; c->fcl.push_back(f);
+            }
+        }
+        c->fcs.push_back((uint32_t)c->fcl.size());
+    }
+    c->pfDone = true; return 0;
+}
+int ygpu_filtered_size(ygpu_ctx *c, uint64_t *nc, uint64_t *no) { if (!c->pfDone) return YGPU_EINVAL; *nc = c->fcl.size(); *no = c->fops.size(); return 0; }
+int ygpu_collect_filtered(ygpu_ctx *c, uint32_t *cs, ygpu_out_clump *cl, uint32_t *ops, ygpu_filtered_batch *r)
+{
+    if (!c->pfDone) return YGPU_EINVAL;
+    memcpy(cs, c->fcs.data(), 4 * c->fcs.size()); if (!c->fcl.empty()) memcpy(cl, c->fcl.data(), sizeof(ygpu_out_clump) * c->fcl.size()); if (!c->fops.empty()) memcpy(ops, c->fops.data(), 4 * c->fops.size());
+    memset(r, 0, sizeof *r); r->n_reads = c->res.n_reads; r->clump_start = cs; r->clumps = cl; r->ops = ops; r->n_clumps = c->fcl.size(); r->n_ops = c->fops.size(); r->counters = c->res.counters;
     return 0;
 }
 static std::atomic<long> gHostAllocs(0);

@@ -111,6 +111,33 @@ def test_lane_pipeline_parameter_corners(work, index11, reads, extra, tmp_path):
         assert mine == strip_pg(open(ref_out).read())
 
 
+# The post-filter on the device (ygpu_postfilter: OQC, filter by similarity, mapping quality -- oqc_core.h, one read per lane) against the host's filter over the
+# same hot-path results: the SAM text of what the device returns (only the clumps that are printed) must equal the text the host makes from everything.
+# The parameter sets move every knob of the filter: -FBS with loose and tight similarity, break point cost and its log cap (the step-function table), the
+# minimum non-overlap, soft clipping, scoring that changes the overlap scores, and chimeric / long / FASTQ reads for paths of several primaries.
+@pytest.mark.parametrize("reads,extra", [
+    ("r1k.fa", []), ("rchim.fa", []), ("rchim.fa", ["-FBS", "Y"]), ("rchim.fa", ["-FBS", "Y", "-PRL", "0.5", "-PSS", "0.5"]), ("rchim.fa", ["-BP", "0"]), ("rchim.fa", ["-BP", "17", "-MGDP", "9"]),
+    ("rchim.fa", ["-MGDP", "1", "-MNO", "3"]), ("rchim.fa", ["-MNO", "200", "-FBS", "Y", "-PSS", "0.2", "-PRL", "0.1"]), ("r10k.fa", ["-FBS", "Y"]), ("rq.fq", ["-M", "15", "-P", "0.8", "-FBS", "Y", "-PSS", "0.3"]),
+    ("rchim.fa", ["-GOC", "9", "-GEC", "3", "-RC", "1", "-FBS", "Y"]), ("r100.fa", ["-M", "15", "-FBS", "Y", "-PRL", "0.3", "-PSS", "0.3"])])
+def test_postfilter_on_the_device_equals_the_host_filter(work, index11, reads, extra):
+    with ya.Session(["-x", index11, "-q", os.path.join(work, reads), "-osh", "stdout"] + list(extra)) as s:
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.set_postfilter(s)
+            total = 0
+            while True:
+                b = s.next_batch(173)
+                if b.n_reads == 0:
+                    break
+                ctx.upload(b); ctx.run()
+                host = s.emit(ctx.collect())
+                f = ctx.postfilter()
+                assert f.n_reads == b.n_reads
+                dev = s.emit_filtered(f)
+                assert dev == host
+                total += len(host)
+            assert total > 0
+
+
 # Bands wider than a wave has lanes for (4 * BW + 1 > 64 columns in the X-drop extension: -BW 16 and up) run through the sequential recurrence of dp_wave.h;
 # the reference accepts any band (Main.c:324-327).  device == oracle per batch, and the reference binary's SAM when it is there.
 @pytest.mark.parametrize("reads,extra", [("r1k.fa", ["-BW", "16"]), ("rchim.fa", ["-BW", "20", "-G", "80"]), ("r10k.fa", ["-BW", "40"]), ("rq.fq", ["-BW", "33", "-X", "40"])])

@@ -23,6 +23,7 @@ def test_library_exports_every_symbol_the_header_declares():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(ya.Clump) == 32 and C.sizeof(ya.Fragment) == 16 and C.sizeof(ya.DPProblem) == 16 and C.sizeof(ya.DPResult) == 16
     assert C.sizeof(ya.Params) == 64 and C.sizeof(ya.Counters) == 128
+    assert C.sizeof(ya.OutClump) == 40 and C.sizeof(ya.PostfilterParams) == 64 and ya.OutClump.status.offset == 32 and ya.OutClump.primaryCount.offset == 38
 
 
 def test_derived_parameters_follow_the_reference_defaults(work, index11):

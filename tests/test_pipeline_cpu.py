@@ -53,6 +53,19 @@ def test_command_line_pipeline_matches_the_reference(exes, work, index11, san, n
     assert strip_pg(p.stdout.decode()) == golden_lines(name)
 
 
+def test_every_golden_run_through_the_command_line(exes, work, index11, meta):
+    """All of the reference's golden outputs (defaults, -FBS Y, -OQC N, -o8, soft clipping, custom scoring, FASTQ ...) through the whole pipeline; with OQC on the
+    post-filter stage (ygpu_postfilter: oqc_core.h behind the hot path) delivers what is printed, with -OQC N the host's duplicate removal does; and once more
+    with the host filter forced (YAHA_HOST_OQC=1): the same text."""
+    for name, r in sorted(meta["runs"].items()):
+        args = ["-x", index11, "-q", os.path.join(work, r["reads"]), r["oflag"], "stdout", "-batch", "61"] + list(r["extra"])
+        for env in ({}, {"YAHA_HOST_OQC": "1"}):
+            p = _run(exes["asan"], args, env=env)
+            assert p.returncode == 0, (name, p.stderr.decode()[-1500:])
+            _clean(p)
+            assert strip_pg(p.stdout.decode()) == golden_lines(name), (name, env)
+
+
 def test_stats_line_and_stdin(exes, work, index11):
     with open(os.path.join(work, "rchim.fa"), "rb") as f:
         p = _run(exes["tsan"], ["-x", index11, "-q", "stdin", "-osh", "stdout", "-batch", "50"], env={"YAHA_STATS": "1", "YAHA_READ_BLOCK": "997"}, stdin=f)

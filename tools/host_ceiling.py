@@ -45,4 +45,22 @@ with ya.Session(["-x", X, "-q", R]) as s0:
         dt = time.time() - t
         print(json.dumps({"stage": "format (OQC + SAM text), one whole batch per thread", "threads": T, "reads": N * T * reps, "clumps_in_per_batch": int(r.n_clumps), "seconds": dt, "reads_per_s": N * T * reps / dt})); sys.stdout.flush()
         for s in sessions: s.close()
+    # the same with the post-filter done on the device (ygpu_postfilter, what the command line does): the host's share of a read is printing what is left
+    ctx.set_postfilter(s0); f = ctx.postfilter()
+    for T in (1, 2, 4, 8, 12, 16):
+        sessions = [ya.Session(["-x", X, "-q", R, "-t", "1"]) for _ in range(T)]
+        for s in sessions:
+            assert s.next_batch(N).n_reads == N
+        reps = 20
+        def work2(s):
+            t_, n_ = C.c_char_p(), C.c_size_t()
+            for _ in range(reps):
+                assert ya.lib().yaha_session_emit_filtered(s._h, C.byref(f), C.byref(t_), C.byref(n_)) == 0
+        th = [threading.Thread(target=work2, args=(s,)) for s in sessions]
+        t = time.time()
+        for x in th: x.start()
+        for x in th: x.join()
+        dt = time.time() - t
+        print(json.dumps({"stage": "format (SAM text of the device-filtered clumps), one whole batch per thread", "threads": T, "reads": N * T * reps, "clumps_in_per_batch": int(f.n_clumps), "seconds": dt, "reads_per_s": N * T * reps / dt})); sys.stdout.flush()
+        for s in sessions: s.close()
     ctx.close()

@@ -67,14 +67,28 @@ class DPResult(C.Structure):
                 ("op_start", C.c_uint32), ("n_ops", C.c_uint32)]
 
 
+class PostfilterParams(C.Structure):
+    _fields_ = [("minNonOverlap", C.c_int32), ("BPCost", C.c_int32), ("maxBPLog", C.c_int32), ("FBS", C.c_int32), ("FBS_PSLength", C.c_float), ("FBS_PSScore", C.c_float),
+                ("bppVmin", C.c_int32), ("bppN", C.c_int32), ("bppThr", C.c_void_p), ("n_seqs", C.c_uint32), ("seq_start", C.c_void_p), ("seq_length", C.c_void_p)]
+
+
+class OutClump(C.Structure):
+    _fields_ = [("c", Clump), ("status", C.c_uint8), ("mapQuality", C.c_uint8), ("numSecondaries", C.c_uint16), ("matchedPrimary", C.c_uint16), ("primaryCount", C.c_uint16)]
+
+
+class FilteredBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("clump_start", C.POINTER(C.c_uint32)), ("clumps", C.POINTER(OutClump)), ("ops", C.POINTER(C.c_uint32)),
+                ("n_clumps", C.c_uint64), ("n_ops", C.c_uint64), ("counters", Counters)]
+
+
 DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
 DP_KERNELS_AUTO, DP_KERNELS_WAVE, DP_KERNELS_LANES, DP_KERNELS_LANES_CAREFUL = 0, 1, 2, 3
 
 EXPORTS = (
-    "ygpu_init", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_last_timing",
+    "ygpu_init", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
     "ygpu_submit", "ygpu_poll", "ygpu_wait", "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch", "ygpu_dp_batch_ex",
     "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
-    "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit",
+    "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit", "yaha_session_postfilter_params", "yaha_session_emit_filtered",
     "yaha_build_index", "yaha_main")
 
 _lib = None
@@ -141,6 +155,13 @@ class Session:
             raise RuntimeError("yaha_session_emit failed: %d" % rc)
         return C.string_at(t, n.value).decode()
 
+    def emit_filtered(self, filtered):
+        t, n = C.c_char_p(), C.c_size_t()
+        rc = lib().yaha_session_emit_filtered(self._h, C.byref(filtered), C.byref(t), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("yaha_session_emit_filtered failed: %d" % rc)
+        return C.string_at(t, n.value).decode()
+
     def close(self):
         if self._h:
             lib().yaha_session_close(self._h)
@@ -171,6 +192,7 @@ class Context:
             raise RuntimeError("%s failed: %d %s" % (what, rc, lib().ygpu_last_error(self._h).decode()))
 
     def upload(self, batch):
+        self._n_reads = int(batch.n_reads)
         self._check(lib().ygpu_upload(self._h, C.byref(batch)), "ygpu_upload")
 
     def run(self):
@@ -179,6 +201,23 @@ class Context:
     def collect(self):
         r = ResultBatch()
         self._check(lib().ygpu_collect(self._h, C.byref(r)), "ygpu_collect")
+        return r
+
+    def set_postfilter(self, session):
+        """The session's OQC / FBS parameters for ygpu_postfilter on this context (raises for runs the device stage does not take)."""
+        p = PostfilterParams()
+        if lib().yaha_session_postfilter_params(session._h, C.byref(p)) != 0:
+            raise RuntimeError("yaha_session_postfilter_params: " + lib().yaha_session_error(session._h).decode())
+        self._check(lib().ygpu_set_postfilter(self._h, C.byref(p)), "ygpu_set_postfilter")
+
+    def postfilter(self):
+        """OQC, filter by similarity and mapping quality on the device; returns the clumps that are printed (FilteredBatch; arrays owned by this object)."""
+        self._check(lib().ygpu_postfilter(self._h), "ygpu_postfilter")
+        nc, no = C.c_uint64(), C.c_uint64()
+        self._check(lib().ygpu_filtered_size(self._h, C.byref(nc), C.byref(no)), "ygpu_filtered_size")
+        self._f_cs = (C.c_uint32 * (self._n_reads + 1))(); self._f_cl = (OutClump * max(1, nc.value))(); self._f_ops = (C.c_uint32 * max(1, no.value))()
+        r = FilteredBatch()
+        self._check(lib().ygpu_collect_filtered(self._h, self._f_cs, self._f_cl, self._f_ops, C.byref(r)), "ygpu_collect_filtered")
         return r
 
     def timing(self):

@@ -35,6 +35,7 @@
 #include "ext_lanes_pk.h"
 #include "split_lanes.h"
 #include "dp_stage.h"
+#include "oqc_stage.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return YGPU_ENODEV; } } while (0)
 
@@ -83,6 +84,9 @@ struct ygpu_ctx {
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
     bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
+    // post-filter stage (oqc_stage.h)
+    DevBuf oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
+    bool oqSet = false, oqDone = false; yoqc::Params oqP{}; yoqc::Seqs oqG{}; uint32_t nFOut = 0, nFOps = 0;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
@@ -824,7 +828,8 @@ void ygpu_destroy(ygpu_ctx *ctx)
         DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt};
+                         &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
+                         &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
@@ -870,7 +875,7 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
 int ygpu_run(ygpu_ctx *ctx)
 {
     if (!ctx || !ctx->stream) return YGPU_EINVAL;
-    ctx->stageDone = 0; const double t0 = nowMs(); ctx->statAttempts = 0; ctx->statRanges = 0;
+    ctx->stageDone = 0; ctx->oqDone = false; const double t0 = nowMs(); ctx->statAttempts = 0; ctx->statRanges = 0;
     int rc = runTo(ctx, 3);
     if (kStats) { size_t fb = 0, tb = 0; hipMemGetInfo(&fb, &tb); fprintf(stderr, "[ygpu] ctx %p run: %u reads, rc %d, %.1f ms; align attempts %d, ranges %d, trace arena %.2f GB (ratio %.3f), free %.1f GB\n", (void *)ctx, ctx->nReads, rc, nowMs() - t0, ctx->statAttempts, ctx->statRanges, ctx->extTrace.cap / 1e9, ctx->traceRatio, fb / 1e9); }
     if (rc) return rc;
@@ -928,6 +933,79 @@ int ygpu_collect_into(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_clump *clumps, 
 }
 void *ygpu_host_alloc(size_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
 void ygpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// ---- post-filter on the device (oqc_stage.h; reference GraphPath.cpp:897-1086) ----------------------------------------------------------------------
+int ygpu_set_postfilter(ygpu_ctx *ctx, const ygpu_postfilter_params *p)
+{
+    if (!ctx || !ctx->stream || !p) return YGPU_EINVAL;
+    if (p->bppN < 0 || p->bppN > 65536 || (p->bppN && !p->bppThr) || (p->n_seqs && (!p->seq_start || !p->seq_length))) { ctx->err = "ygpu_set_postfilter: bad break point table or sequence table"; return YGPU_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    ENSURE(ctx->oqThr, 4ull * (p->bppN + 1)); ENSURE(ctx->oqSeqStart, 4ull * (p->n_seqs + 1)); ENSURE(ctx->oqSeqLen, 4ull * (p->n_seqs + 1));
+    if (p->bppN) HIPCHK(hipMemcpyAsync(ctx->oqThr.p, p->bppThr, 4ull * p->bppN, hipMemcpyHostToDevice, ctx->stream));
+    if (p->n_seqs) { HIPCHK(hipMemcpyAsync(ctx->oqSeqStart.p, p->seq_start, 4ull * p->n_seqs, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipMemcpyAsync(ctx->oqSeqLen.p, p->seq_length, 4ull * p->n_seqs, hipMemcpyHostToDevice, ctx->stream)); }
+    HIPCHK(streamSync(ctx));
+    yoqc::Params &P = ctx->oqP;
+    P.GOCost = ctx->P.GO; P.GECost = ctx->P.GE; P.RCost = ctx->P.RC; P.MScore = ctx->P.MS;
+    P.minNonOverlap = p->minNonOverlap; P.BPCost = p->BPCost; P.maxBPLog = p->maxBPLog; P.FBS = p->FBS; P.FBS_PSLength = p->FBS_PSLength; P.FBS_PSScore = p->FBS_PSScore;
+    P.bppVmin = p->bppVmin; P.bppN = p->bppN; P.bppThr = ctx->oqThr.as<uint32_t>();
+    ctx->oqG.start = ctx->oqSeqStart.as<uint32_t>(); ctx->oqG.length = ctx->oqSeqLen.as<uint32_t>(); ctx->oqG.n = p->n_seqs;
+    ctx->oqSet = true; return 0;
+}
+int ygpu_postfilter(ygpu_ctx *ctx)
+{
+    if (!ctx || !ctx->stream || ctx->stageDone < 3) return YGPU_EINVAL;
+    if (!ctx->oqSet) { ctx->err = "ygpu_postfilter: ygpu_set_postfilter has not been called on this context"; return YGPU_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->nReads, C = ctx->nOut; ctx->nFOut = ctx->nFOps = 0; ctx->oqDone = false;
+    ENSURE(ctx->oqOutStart, 4ull * (n + 2)); ENSURE(ctx->oqOpsStart, 4ull * (n + 2));
+    if (n == 0 || C == 0) { HIPCHK(hipMemsetAsync(ctx->oqOutStart.p, 0, 4ull * (n + 2), ctx->stream)); HIPCHK(streamSync(ctx)); ctx->oqDone = true; return 0; }
+    ENSURE(ctx->oqNeed, 8ull * (n + 2)); ENSURE(ctx->oqPoolOff, 8ull * (n + 2));
+    KL(k_oqc_sizes, dim3(gridFor(n + 1, 256)), dim3(256), 0, ctx->stream, ctx->readStart.as<uint32_t>(), ctx->outClumps2.as<ygpu_clump>(), n, ctx->oqNeed.as<unsigned long long>());
+    int rc = cubScan64(ctx, ctx->oqNeed.as<unsigned long long>(), ctx->oqPoolOff.as<unsigned long long>(), n + 1); if (rc) return rc;
+    unsigned long long poolInts = 0;
+    HIPCHK(hipMemcpyAsync(&poolInts, ctx->oqPoolOff.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+    ENSURE(ctx->oqKeys, sizeof(yoqc::SortKey) * (uint64_t)C); ENSURE(ctx->oqStack, 4ull * (4ull * C + 8ull * n + 16)); ENSURE(ctx->oqNodes, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(ctx->oqPrim, sizeof(yoqc::CNode) * (uint64_t)C);
+    ENSURE(ctx->oqPA, sizeof(yoqc::PAttr) * (uint64_t)C); ENSURE(ctx->oqPfx, 4ull * C); ENSURE(ctx->oqPath, 4ull * C); ENSURE(ctx->oqPool, 4ull * (poolInts + 16)); ENSURE(ctx->oqPush, sizeof(yoqc::OutRec) * (uint64_t)C); ENSURE(ctx->oqOut, sizeof(yoqc::OutRec) * (uint64_t)C);
+    ENSURE(ctx->oqOutCnt, 4ull * (n + 2)); ENSURE(ctx->oqOutOps, 4ull * (n + 2)); ENSURE(ctx->oqPrimCnt, 4ull * (n + 2));
+    HIPCHK(hipMemsetAsync((uint32_t *)ctx->oqOutCnt.p + n, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync((uint32_t *)ctx->oqOutOps.p + n, 0, 8, ctx->stream));
+    OqcArgs A; A.P = ctx->oqP; A.G = ctx->oqG; A.cs = ctx->readStart.as<uint32_t>(); A.cl = ctx->outClumps2.as<ygpu_clump>(); A.ops = ctx->outOps.as<uint32_t>(); A.fwd = ctx->dFwd.as<uint8_t>(); A.readOff = ctx->dReadOff.as<uint32_t>(); A.nReads = n;
+    A.poolOff = ctx->oqPoolOff.as<unsigned long long>(); A.keys = ctx->oqKeys.as<yoqc::SortKey>(); A.stack = ctx->oqStack.as<int>(); A.nodes = ctx->oqNodes.as<yoqc::CNode>(); A.prim = ctx->oqPrim.as<yoqc::CNode>(); A.pa = ctx->oqPA.as<yoqc::PAttr>();
+    A.pfxOff = ctx->oqPfx.as<int>(); A.path = ctx->oqPath.as<int>(); A.pool = ctx->oqPool.as<int>(); A.push = ctx->oqPush.as<yoqc::OutRec>(); A.out = ctx->oqOut.as<yoqc::OutRec>();
+    A.outCnt = ctx->oqOutCnt.as<uint32_t>(); A.outOpsCnt = ctx->oqOutOps.as<uint32_t>(); A.primCnt = ctx->oqPrimCnt.as<uint32_t>();
+    KL(k_oqc_run, dim3(gridFor(n, 64)), dim3(64), 0, ctx->stream, A);
+    rc = cubScan(ctx, ctx->oqOutCnt.as<uint32_t>(), ctx->oqOutStart.as<uint32_t>(), n + 1); if (rc) return rc;
+    rc = cubScan(ctx, ctx->oqOutOps.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), n + 1); if (rc) return rc;
+    uint32_t tot[2] = {0, 0};
+    rc = fetchU32(ctx, ctx->oqOutStart.as<uint32_t>() + n, &tot[0]); if (rc) return rc;
+    rc = fetchU32(ctx, ctx->oqOpsStart.as<uint32_t>() + n, &tot[1]); if (rc) return rc;
+    ctx->nFOut = tot[0]; ctx->nFOps = tot[1];
+    ENSURE(ctx->oqFClumps, sizeof(ygpu_out_clump) * ((uint64_t)tot[0] + 1)); ENSURE(ctx->oqFOps, 4ull * ((uint64_t)tot[1] + 1));
+    KL(k_oqc_gather, dim3(gridFor(n, 64)), dim3(64), 0, ctx->stream, A, ctx->oqOutStart.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), ctx->oqFClumps.as<ygpu_out_clump>(), ctx->oqFOps.as<uint32_t>());
+    ctx->oqDone = true;
+    return 0;
+}
+int ygpu_filtered_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops)
+{
+    if (!ctx || ctx->stageDone < 3 || !ctx->oqDone) return YGPU_EINVAL;
+    if (n_clumps) *n_clumps = ctx->nFOut; if (n_ops) *n_ops = ctx->nFOps;
+    return 0;
+}
+int ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump *clumps, uint32_t *ops, ygpu_filtered_batch *out)
+{
+    if (!ctx || !out || !clump_start || ctx->stageDone < 3 || !ctx->oqDone || (ctx->nFOut && !clumps) || (ctx->nFOps && !ops)) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->nReads;
+    HIPCHK(hipMemcpyAsync(clump_start, ctx->oqOutStart.p, 4ull * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nFOut) HIPCHK(hipMemcpyAsync(clumps, ctx->oqFClumps.p, sizeof(ygpu_out_clump) * (uint64_t)ctx->nFOut, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nFOps) HIPCHK(hipMemcpyAsync(ops, ctx->oqFOps.p, 4ull * ctx->nFOps, hipMemcpyDeviceToHost, ctx->stream));
+    DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(streamSync(ctx));
+    { const unsigned long long dropped = dc.v[C_FRAGS];
+      dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags + dropped; dc.v[C_REGIONS] = ctx->nRegions + dropped; }
+    memcpy(&ctx->hCounters, dc.v, sizeof(ygpu_counters));
+    out->n_reads = n; out->clump_start = clump_start; out->clumps = clumps; out->ops = ops; out->n_clumps = ctx->nFOut; out->n_ops = ctx->nFOps; out->counters = ctx->hCounters;
+    return 0;
+}
 
 static void asyncWorker(ygpu_ctx *ctx)
 {

@@ -4,6 +4,7 @@
 // With -gpus N one context per device is driven by its own host thread; batches are dealt round-robin and the
 // output is re-ordered by batch ticket, so the text equals a `-t 1` run of the reference.
 #include "yaha_host.h"
+#include "../oqc_core.h"
 #include <cstring>
 #include <cstdlib>
 #include <thread>
@@ -21,6 +22,7 @@ using namespace yaha;
 
 struct yaha_session {
     Args args; Genome genome; IndexFile index; ReadReader reader; std::string err, header; Text text;
+    std::vector<uint32_t> pfThr, pfSeqStart, pfSeqLen;               // what yaha_session_postfilter_params points into
     std::vector<Read> reads; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
     bool readerOpen = false;
 };
@@ -127,6 +129,17 @@ static void formatRange(const yaha_session *s, const ygpu_result_batch *r, uint3
         for (auto &o : oc) printClump(a, s->genome, s->reads[i], o, primaryCount, text);
     }
 }
+// SAM text of a batch whose post-filter ran on the device (ygpu_postfilter): the clumps arrive in print order with the filter's fields set
+static void formatFiltered(const yaha_session *s, const ygpu_filtered_batch *r, Text &text)
+{
+    const Args &a = s->args; text.clear();
+    for (uint32_t i = 0; i < r->n_reads; i++)
+        for (uint32_t k = r->clump_start[i]; k < r->clump_start[i + 1]; k++) {
+            const ygpu_out_clump &f = r->clumps[k];
+            OutClump oc; oc.c = f.c; oc.ops = r->ops + f.c.op_start; oc.status = f.status; oc.mapQuality = f.mapQuality; oc.numSecondaries = f.numSecondaries; oc.matchedPrimary = f.matchedPrimary;
+            printClump(a, s->genome, s->reads[i], oc, (int)f.primaryCount, text);
+        }
+}
 static void formatBatch(yaha_session *s, const ygpu_result_batch *r, Text &text, int nt)
 {
     const uint32_t n = r->n_reads;
@@ -204,7 +217,7 @@ int runQueries(Args &a, FILE *log)
                     ~ResBuf() { drop(); } void drop() { if (p) { if (pinned) ygpu_host_free(p); else free(p); } p = nullptr; cap = 0; }
                     bool ensure(size_t bytes) { if (bytes <= cap) return true; drop(); const size_t c = bytes + bytes / 4 + 4096; p = ygpu_host_alloc(c); pinned = p != nullptr; if (!p) p = malloc(c); cap = p ? c : 0; return p != nullptr; } };
     struct Batch { uint64_t ticket = 0; std::vector<Span> spans; std::vector<Read> reads; size_t nReads = 0; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
-                   ResBuf clumpStart, ops, clumps; uint64_t nClumps = 0, nOps = 0; Text text; double tRead = 0, tDev = 0, tFmt = 0; };
+                   ResBuf clumpStart, ops, clumps; uint64_t nClumps = 0, nOps = 0; bool filtered = false; Text text; double tRead = 0, tDev = 0, tFmt = 0; };
     typedef std::unique_ptr<Batch> BatchP;
     struct Pool { std::mutex mu; std::vector<BatchP> free; BatchP get() { { std::lock_guard<std::mutex> lk(mu); if (!free.empty()) { BatchP b = std::move(free.back()); free.pop_back(); return b; } } return BatchP(new Batch); }
                   void put(BatchP &&b) { std::lock_guard<std::mutex> lk(mu); free.push_back(std::move(b)); } } pool;
@@ -249,6 +262,15 @@ int runQueries(Args &a, FILE *log)
     // five seconds), while the splitter and the parsers already work on the first batches.  The first context of a device uploads the image, the others share it.
     // A context's first batch allocates its device buffers (a hundred hipMalloc calls, each of which waits for the device to go idle): first batches run one at
     // a time and hold back the other contexts' new batches meanwhile, instead of fighting their kernels for every allocation (0.6 s per context otherwise, measured).
+    // The post-filter (OQC, filter by similarity, mapping quality) runs on the device behind the hot path (ygpu_postfilter; the same routine as the host's,
+    // oqc_core.h): the results that cross PCIe and reach the formatters are the clumps that get printed.  The host filter remains for -OQC N (duplicate
+    // removal only), for break point costs that are no step function, and on request (YAHA_HOST_OQC=1).
+    yoqc::Params oqP; std::vector<uint32_t> oqThr, oqSeqStart, oqSeqLen; oqcParamsFromArgs(A, oqP, oqThr);
+    for (auto &sq : S->genome.seqs) { oqSeqStart.push_back(sq.start); oqSeqLen.push_back(sq.length); }
+    const bool deviceFilter = A.OQC && oqP.bppN >= 0 && getenv("YAHA_HOST_OQC") == nullptr;
+    ygpu_postfilter_params PF; memset(&PF, 0, sizeof PF);
+    PF.minNonOverlap = oqP.minNonOverlap; PF.BPCost = oqP.BPCost; PF.maxBPLog = oqP.maxBPLog; PF.FBS = oqP.FBS; PF.FBS_PSLength = oqP.FBS_PSLength; PF.FBS_PSScore = oqP.FBS_PSScore;
+    PF.bppVmin = oqP.bppVmin; PF.bppN = std::max(0, oqP.bppN); PF.bppThr = oqThr.data(); PF.n_seqs = (uint32_t)oqSeqStart.size(); PF.seq_start = oqSeqStart.data(); PF.seq_length = oqSeqLen.data();
     struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
     std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < nDev; k++) warm.emplace_back(new Warm);
     std::atomic<int> ctxUp(0); double tCtxUp = 0;
@@ -262,15 +284,23 @@ int runQueries(Args &a, FILE *log)
             { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : YGPU_EINVAL; }
             if (rc0 == 0) { std::lock_guard<std::mutex> one(W.first); rc0 = ygpu_clone(ctx[lead], &ctx[d]); }
         }
+        if (rc0 == 0 && deviceFilter) rc0 = ygpu_set_postfilter(ctx[d], &PF);
         if (rc0 != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", dev, rc0, ctx[d] ? ygpu_last_error(ctx[d]) : (d == lead ? "" : "(the device's first context failed)")); fail(m); }
         if (++ctxUp == ngpu) { tCtxUp = now(); if (timing) fprintf(stderr, "[yaha] %d device contexts up (index image on %d device%s) %.1f ms after start\n", ngpu, nDev, nDev > 1 ? "s" : "", tCtxUp - tEnter); }
         while (inQ.pop(b)) {
             if (stop) { b->nReads = 0; fmtQ.push(std::move(b)); continue; }
             const double t0 = now();
-            ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res;
-            auto hotPath = [&]() -> int {                                      // upload, run, results straight into the batch's own buffers
+            ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res; memset(&res, 0, sizeof res);
+            auto hotPath = [&]() -> int {                                      // upload, run (+ post-filter), results straight into the batch's own buffers
                 int rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;
-                uint64_t nc = 0, no = 0; rc = ygpu_result_size(ctx[d], &nc, &no); if (rc != 0) return rc;
+                uint64_t nc = 0, no = 0; b->filtered = deviceFilter;
+                if (deviceFilter) {
+                    rc = ygpu_postfilter(ctx[d]); if (rc == 0) rc = ygpu_filtered_size(ctx[d], &nc, &no); if (rc != 0) return rc;
+                    if (!b->clumpStart.ensure(4 * (b->nReads + 1)) || !b->clumps.ensure(sizeof(ygpu_out_clump) * nc) || !b->ops.ensure(4 * no)) return YGPU_ENOMEM;
+                    ygpu_filtered_batch fr; rc = ygpu_collect_filtered(ctx[d], (uint32_t *)b->clumpStart.p, (ygpu_out_clump *)b->clumps.p, (uint32_t *)b->ops.p, &fr);
+                    res.n_clumps = fr.n_clumps; res.n_ops = fr.n_ops; return rc;
+                }
+                rc = ygpu_result_size(ctx[d], &nc, &no); if (rc != 0) return rc;
                 if (!b->clumpStart.ensure(4 * (b->nReads + 1)) || !b->clumps.ensure(sizeof(ygpu_clump) * nc) || !b->ops.ensure(4 * no)) return YGPU_ENOMEM;
                 return ygpu_collect_into(ctx[d], (uint32_t *)b->clumpStart.p, (ygpu_clump *)b->clumps.p, (uint32_t *)b->ops.p, &res);
             };
@@ -296,7 +326,11 @@ int runQueries(Args &a, FILE *log)
         BatchP b;
         while (fmtQ.pop(b)) {
             const double t0 = now(); b->text.clear();
-            if (!stop && b->nReads) {
+            if (!stop && b->nReads && b->filtered) {
+                ygpu_filtered_batch fr; memset(&fr, 0, sizeof fr);
+                fr.n_reads = (uint32_t)b->nReads; fr.clump_start = (const uint32_t *)b->clumpStart.p; fr.clumps = (const ygpu_out_clump *)b->clumps.p; fr.ops = (const uint32_t *)b->ops.p; fr.n_clumps = b->nClumps; fr.n_ops = b->nOps;
+                local.reads.swap(b->reads); formatFiltered(&local, &fr, b->text); local.reads.swap(b->reads);
+            } else if (!stop && b->nReads) {
                 ygpu_result_batch res; memset(&res, 0, sizeof res);
                 res.n_reads = (uint32_t)b->nReads; res.clump_start = (const uint32_t *)b->clumpStart.p; res.clumps = (const ygpu_clump *)b->clumps.p; res.ops = (const uint32_t *)b->ops.p; res.n_clumps = b->nClumps; res.n_ops = b->nOps;
                 local.reads.swap(b->reads); formatBatch(&local, &res, b->text, 1); local.reads.swap(b->reads);
@@ -380,6 +414,21 @@ int yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **
 {
     if (r->n_reads != s->reads.size()) { s->err = "result batch does not match the current read batch"; return YGPU_EINVAL; }
     formatBatch(s, r, s->text, std::max(1, s->args.numThreads)); *s->text.room(1) = 0; *text = s->text.p; *len = s->text.len; return 0;
+}
+int yaha_session_postfilter_params(yaha_session *s, ygpu_postfilter_params *p)
+{
+    yoqc::Params P; oqcParamsFromArgs(s->args, P, s->pfThr);
+    if (!s->args.OQC || P.bppN < 0) { s->err = "the device post-filter takes OQC runs with non-negative break point costs only"; return YGPU_EINVAL; }
+    s->pfSeqStart.clear(); s->pfSeqLen.clear(); for (auto &sq : s->genome.seqs) { s->pfSeqStart.push_back(sq.start); s->pfSeqLen.push_back(sq.length); }
+    memset(p, 0, sizeof *p);
+    p->minNonOverlap = P.minNonOverlap; p->BPCost = P.BPCost; p->maxBPLog = P.maxBPLog; p->FBS = P.FBS; p->FBS_PSLength = P.FBS_PSLength; p->FBS_PSScore = P.FBS_PSScore;
+    p->bppVmin = P.bppVmin; p->bppN = P.bppN; p->bppThr = s->pfThr.data(); p->n_seqs = (uint32_t)s->pfSeqStart.size(); p->seq_start = s->pfSeqStart.data(); p->seq_length = s->pfSeqLen.data();
+    return 0;
+}
+int yaha_session_emit_filtered(yaha_session *s, const ygpu_filtered_batch *r, const char **text, size_t *len)
+{
+    if (r->n_reads != s->reads.size()) { s->err = "result batch does not match the current read batch"; return YGPU_EINVAL; }
+    formatFiltered(s, r, s->text); *s->text.room(1) = 0; *text = s->text.p; *len = s->text.len; return 0;
 }
 int yaha_build_index(int argc, const char *const *argv)
 {

@@ -133,6 +133,11 @@ struct Text {
     void grow(size_t need) { size_t c = cap ? cap : (1u << 16); while (c < need) c += c / 2; char *q = (char *)realloc(p, c); if (!q) throw std::bad_alloc(); p = q; cap = c; }
 };
 void printClump(const Args &a, const Genome &g, const Read &r, const OutClump &oc, int primaryCount, Text &out);
+}  // namespace yaha
+namespace yoqc { struct Params; }
+namespace yaha {
+// the post-filter's parameters in the form oqc_core.h takes them (host and device stage); thr receives the break point table P points into
+void oqcParamsFromArgs(const Args &a, yoqc::Params &P, std::vector<uint32_t> &thr);
 
 // ---- whole-run driver (replacement of processQueryFile, Query.c:551-709) --------------------------------
 int effectiveCpus();                                    // affinity mask and control-group CPU quota
