@@ -74,7 +74,7 @@ int ygpu_postfilter(ygpu_ctx *c)
         if (n) {
             size_t pool = 0; for (uint32_t i = 0; i < n; i++) pool += 2 * ((size_t)R.clumps[b + i].n_ops + 1);
             std::vector<yoqc::SortKey> keys(n); std::vector<int> stack(4 * (size_t)n + 8), pfx(n), path(n), pl(pool + 1); std::vector<yoqc::CNode> nodes(n), prim(n); std::vector<yoqc::PAttr> pa(n); std::vector<yoqc::OutRec> push(n), out(n);
-            yoqc::Scratch S{keys.data(), stack.data(), nodes.data(), prim.data(), pa.data(), pfx.data(), path.data(), pl.data(), push.data()};
+            yoqc::Scratch S{keys.data(), stack.data(), 0x7fffffff, nullptr, nodes.data(), pfx.data(), path.data(), pl.data(), 0x7fffffff, nullptr, prim.data(), pa.data(), push.data()};
             int pc = 0; const int qlen = (int)(c->offs[r + 1] - c->offs[r]);
             const int m = yoqc::run(c->pf, G, R.clumps + b, (int)n, R.ops, qlen, c->codes.data() + c->offs[r], S, out.data(), &pc);
             for (int k = 0; k < m; k++) {

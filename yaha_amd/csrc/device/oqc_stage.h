@@ -2,8 +2,7 @@
 // (reference GraphPath.cpp:897-1086) for every read of the batch, right where the hot path left its clumps, so that only the clumps that are PRINTED -- one or
 // two of the ~75 a 1 kbp read produces -- and their edit ops travel to the host (9 KB a read -> ~0.2 KB) and the host's share of a read is parsing and
 // printing.  The routine itself is ../oqc_core.h, the very source the host compiles (host/oqc.cpp): one read per lane, sequential, all of its work space in
-// per-read slices of batch-wide arrays.  It is serial, branchy, latency-bound code -- a few hundred dependent steps a read -- that occupies one wave per CU
-// and next to no issue slots: it runs underneath the other contexts' kernels.
+// per-read slices of batch-wide arrays (the hot ones staged in LDS, see k_oqc_lds).
 #pragma once
 #include "common.h"
 #include "../oqc_core.h"
@@ -15,30 +14,125 @@ struct OqcArgs {
     yoqc::SortKey *keys; int *stack; yoqc::CNode *nodes, *prim; yoqc::PAttr *pa; int *pfxOff, *path, *pool; yoqc::OutRec *push, *out;
     uint32_t *outCnt, *outOpsCnt; uint32_t *primCnt;
 };
-// ints of running-sum tables a read may need: two per op and clump of the read (every clump's table built), none for reads of fewer than two clumps
-__global__ void k_oqc_sizes(const uint32_t *cs, const ygpu_clump *cl, uint32_t nReads, unsigned long long *need)
+// What the routine costs on a GPU, measured: one read per lane with its work space in HBM took 75 ms a batch (a few thousand DEPENDENT accesses a read, microseconds
+// each); one read per wave with the work space in LDS still 39 ms for the reads of 320..640 clumps -- the graph loop is quadratic in the nodes that survive the
+// duplicate scan, and reads in repeats have hundreds.  So a read gets a WAVE, the work space in LDS, and the steps oqc_core.h marks as independent run on its
+// 64 lanes: the scan behind a node in the duplicate removal (64 candidates at a time, the ballot finds where the scan ends), the nodes and their running-sum
+// tables, and the successors of a node in the graph loop (each lane relaxes a different successor: it reads the node and its path and writes its own successor
+// only).  What must stay in the reference's order stays on the first lane: the sort (it consumes the read's random bits in comparison order), the walk along
+// the best path before each node's successors, the choice of the best node, the similarity filter.
+// Reads come in classes by their number of clumps (the LDS a workgroup gets is fixed at launch): keys + sort stack, then nodes + table index + path share it.
+#define YQ_NCLASS 4
+#define YQ_STACK_LDS 256              // ints of the sort's stack kept in LDS (depth ~2 log2 n ranges); deeper recursion continues in HBM
+#define YQ_LDS_MAX 65536u
+__device__ __constant__ const int kOqcCapN[YQ_NCLASS] = {112, 448, 1000, 0x7fffffff};      // clumps a read of the class may have (the last class: keys in LDS while 16 n fits, the rest in HBM)
+__host__ __device__ inline unsigned oqcLdsBytes(int capN, int poolInts) { return 64u * (unsigned)capN + 4u * YQ_STACK_LDS + 4u * (unsigned)poolInts + 64u; }
+// classes of the reads with two or more clumps (lists[c * nReads ...], cnt[c]); reads with one clump are settled here (GraphPath.cpp:907-916); ints of running-sum
+// tables a read may need in HBM: two per op and clump of the read (every clump's table built)
+__global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *lists, unsigned int *cnt)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > nReads) return;
-    unsigned long long v = 0;
-    if (r < nReads) { const uint32_t b = cs[r], e = cs[r + 1]; if (e - b >= 2) for (uint32_t c = b; c < e; c++) v += 2ull * ((unsigned long long)cl[c].n_ops + 1ull); }
-    need[r] = v;
-}
-__global__ void __launch_bounds__(64) k_oqc_run(OqcArgs A)
-{
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= A.nReads) return;
-    const uint32_t b = A.cs[r], n = A.cs[r + 1] - b;
-    uint32_t m = 0, nops = 0; int primary = 0;
-    if (n) {
-        yoqc::Scratch S;
-        S.keys = A.keys + b; S.stack = A.stack + 4ull * b + 8ull * r; S.nodes = A.nodes + b; S.prim = A.prim + b; S.pa = A.pa + b; S.pfxOff = A.pfxOff + b; S.path = A.path + b;
-        S.pool = A.pool + A.poolOff[r]; S.push = A.push + b;
-        const uint32_t o = A.readOff[r]; const int qlen = (int)(A.readOff[r + 1] - o);
-        m = (uint32_t)yoqc::run(A.P, A.G, A.cl + b, (int)n, A.ops, qlen, A.fwd + o, S, A.out + b, &primary);
-        for (uint32_t k = 0; k < m; k++) nops += A.cl[b + (uint32_t)A.out[b + k].clump].n_ops;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63);
+    unsigned long long v = 0; int cls = -1;
+    if (r < A.nReads) {
+        const uint32_t b = A.cs[r], n = A.cs[r + 1] - b;
+        if (n >= 2) { for (uint32_t c = b; c < b + n; c++) v += 2ull * ((unsigned long long)A.cl[c].n_ops + 1ull); cls = 0; while (n > (uint32_t)kOqcCapN[cls]) cls++; }
+        else {
+            uint32_t m = 0, nops = 0; int pc = 0;
+            if (n == 1) { m = (uint32_t)yoqc::single(A.cl + b, A.out + b, &pc); nops = A.cl[b].n_ops; }
+            A.outCnt[r] = m; A.outOpsCnt[r] = nops; A.primCnt[r] = (uint32_t)pc;
+        }
     }
-    A.outCnt[r] = m; A.outOpsCnt[r] = nops; A.primCnt[r] = (uint32_t)primary;
+    if (r <= A.nReads) need[r] = v;
+#pragma unroll
+    for (int c = 0; c < YQ_NCLASS; c++) {
+        const unsigned long long mk = __ballot(cls == c);
+        if (!mk) continue;
+        unsigned base = 0; const int leader = __builtin_ctzll(mk);
+        if (lane == leader) base = atomicAdd(&cnt[c], (unsigned)__builtin_popcountll(mk));
+        base = (unsigned)__shfl((int)base, leader, 64);
+        if (cls == c) lists[(size_t)c * A.nReads + base + (unsigned)__builtin_popcountll(mk & ((1ull << lane) - 1ull))] = r;
+    }
+}
+// One read per workgroup of one wave.  LDS (dynamic, `ldsBytes`): [sort stack | pool | keys ... ] during the sort and the duplicate scan, then [sort stack | pool |
+// nodes, tbl, path] over the keys' place (the surviving keys are parked in HBM for the moment the nodes are made).  What does not fit LDS lives in the read's
+// slices of the batch-wide HBM arrays (inLds* say which).
+__global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list, uint32_t count, unsigned ldsBytes, int poolInts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sOqc[];
+    if (blockIdx.x >= count) return;
+    const int lane = (int)threadIdx.x;
+    const uint32_t r = list[blockIdx.x], b = A.cs[r]; const int n = (int)(A.cs[r + 1] - b);
+    const uint32_t o = A.readOff[r]; const int qlen = (int)(A.readOff[r + 1] - o);
+    int *const sStack = (int *)sOqc, *const sPool = sStack + YQ_STACK_LDS; unsigned char *const sMain = (unsigned char *)(sPool + poolInts);
+    const unsigned mainBytes = ldsBytes - (unsigned)(sMain - sOqc);
+    yoqc::Scratch S;
+    S.stack = sStack; S.stackCap = YQ_STACK_LDS; S.stack2 = A.stack + 4ull * b + 8ull * r;
+    S.pool = sPool; S.poolCap = poolInts; S.pool2 = A.pool + A.poolOff[r];
+    S.prim = A.prim + b; S.pa = A.pa + b; S.push = A.push + b;
+    const bool keysInLds = 16u * (unsigned)n <= mainBytes;
+    S.keys = keysInLds ? (yoqc::SortKey *)sMain : A.keys + b;
+    S.nodes = A.nodes + b; S.tbl = A.pfxOff + b; S.path = A.path + b;             // set for good once the number of survivors is known
+    yoqc::Run X{A.P, A.cl + b, A.ops, S, 0, 0};
+    for (int i = lane; i < n; i += 64) X.makeKey(i, qlen);
+    __syncthreads();
+    if (lane == 0) X.sortKeys(n, A.fwd + o, qlen);
+    __syncthreads();
+    // deleteSubsumedDups: the scan behind node i, 64 candidates at a time; it ends at the first live candidate whose EQO exceeds the node's
+    int cnt = 0;
+    for (int i = 0; i < n; i++) {
+        const yoqc::SortKey ki = X.S.keys[i];                              // (uniform)
+        if (ki.clump < 0) continue;
+        const int curEQO = yoqc::keyEQO(ki.key);
+        if (lane == 0) X.S.keys[cnt] = ki;                                 // survivors compacted in place (cnt <= i)
+        cnt++;
+        for (int base = i + 1; base < n; base += 64) {
+            const int j = base + lane; bool live = false, ends = false;
+            if (j < n) { const yoqc::SortKey kj = X.S.keys[j]; live = kj.clump >= 0; ends = live && yoqc::keyEQO(kj.key) > curEQO; }
+            const unsigned long long em = __ballot(ends);
+            const int stop = em ? __builtin_ctzll(em) : 64;
+            if (live && lane < stop && X.dupKill(ki.key, ki.clump, j)) X.S.keys[j].clump = ~X.S.keys[j].clump;
+            if (em) break;
+        }
+        __syncthreads();
+    }
+    // nodes, table index and path take the keys' place when they fit (48 bytes a survivor); the surviving keys wait in HBM (the read's slice of the key array)
+    const bool nodesInLds = 48u * (unsigned)cnt <= mainBytes;
+    if (nodesInLds && keysInLds) {
+        for (int p = lane; p < cnt; p += 64) A.keys[b + p] = X.S.keys[p];
+        __syncthreads();
+        X.S.keys = A.keys + b;
+    }
+    if (nodesInLds) { X.S.nodes = (yoqc::CNode *)sMain; X.S.tbl = (int *)(sMain + 40u * (unsigned)cnt); X.S.path = X.S.tbl + cnt; }
+    for (int p = lane; p < cnt; p += 64) X.makeNode(p, A.G, qlen, -1);
+    __syncthreads();
+    if (lane == 0) for (int p = 0; p < cnt; p++) X.assignTable(p);          // bump allocation: sequential, a few instructions a node
+    X.poolUsed = __shfl(X.poolUsed, 0, 64); X.pool2Used = __shfl(X.pool2Used, 0, 64);
+    __syncthreads();
+    for (int p = lane; p < cnt; p += 64) X.fillTable(p);
+    __syncthreads();
+    int bestScore = YQ_WORST, bestNode = -1, startj = 1;
+    for (int i = 0; i < cnt; i++) {                                         // :973-1063
+        if (lane == 0) X.cachePath(i);
+        __syncthreads();
+        const int leftSQO = X.S.nodes[i].SQO; int first = -1;
+        for (int base = startj; base < cnt; base += 64) {
+            const int j = base + lane;
+            const bool far = j < cnt && ((int)X.S.nodes[j].SQO - leftSQO) >= A.P.minNonOverlap;
+            if (far) X.relax(i, j);
+            const unsigned long long fm = __ballot(far);
+            if (first < 0 && fm) first = base + __builtin_ctzll(fm);
+        }
+        if (startj < cnt) startj = first >= 0 ? first : cnt;                // (the reference moves startj only inside the loop over j)
+        __syncthreads();
+        X.considerBest(i, bestScore, bestNode);                              // (uniform: every lane reads the same node)
+    }
+    if (lane == 0) {
+        int primary = 0;
+        const uint32_t m = (uint32_t)X.finish(cnt, bestNode, A.out + b, &primary);
+        uint32_t nops = 0;
+        for (uint32_t k = 0; k < m; k++) nops += A.cl[b + (uint32_t)A.out[b + k].clump].n_ops;
+        A.outCnt[r] = m; A.outOpsCnt[r] = nops; A.primCnt[r] = (uint32_t)primary;
+    }
 }
 // the printed clumps of read r, in print order, with their ops copied behind one another: out clump k of the read = fClumps[outStart[r] + k]
 __global__ void k_oqc_gather(OqcArgs A, const uint32_t *outStart, const uint32_t *opsStart, ygpu_out_clump *fClumps, uint32_t *fOps)

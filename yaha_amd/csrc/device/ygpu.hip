@@ -85,7 +85,7 @@ struct ygpu_ctx {
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
     bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // post-filter stage (oqc_stage.h)
-    DevBuf oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
+    DevBuf oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
     bool oqSet = false, oqDone = false; yoqc::Params oqP{}; yoqc::Seqs oqG{}; uint32_t nFOut = 0, nFOps = 0;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
@@ -829,7 +829,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
                          &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
-                         &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
+                         &ctx->oqLists, &ctx->oqClsCnt, &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
@@ -959,20 +959,31 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     const uint32_t n = ctx->nReads, C = ctx->nOut; ctx->nFOut = ctx->nFOps = 0; ctx->oqDone = false;
     ENSURE(ctx->oqOutStart, 4ull * (n + 2)); ENSURE(ctx->oqOpsStart, 4ull * (n + 2));
     if (n == 0 || C == 0) { HIPCHK(hipMemsetAsync(ctx->oqOutStart.p, 0, 4ull * (n + 2), ctx->stream)); HIPCHK(streamSync(ctx)); ctx->oqDone = true; return 0; }
-    ENSURE(ctx->oqNeed, 8ull * (n + 2)); ENSURE(ctx->oqPoolOff, 8ull * (n + 2));
-    KL(k_oqc_sizes, dim3(gridFor(n + 1, 256)), dim3(256), 0, ctx->stream, ctx->readStart.as<uint32_t>(), ctx->outClumps2.as<ygpu_clump>(), n, ctx->oqNeed.as<unsigned long long>());
-    int rc = cubScan64(ctx, ctx->oqNeed.as<unsigned long long>(), ctx->oqPoolOff.as<unsigned long long>(), n + 1); if (rc) return rc;
-    unsigned long long poolInts = 0;
-    HIPCHK(hipMemcpyAsync(&poolInts, ctx->oqPoolOff.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
-    ENSURE(ctx->oqKeys, sizeof(yoqc::SortKey) * (uint64_t)C); ENSURE(ctx->oqStack, 4ull * (4ull * C + 8ull * n + 16)); ENSURE(ctx->oqNodes, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(ctx->oqPrim, sizeof(yoqc::CNode) * (uint64_t)C);
-    ENSURE(ctx->oqPA, sizeof(yoqc::PAttr) * (uint64_t)C); ENSURE(ctx->oqPfx, 4ull * C); ENSURE(ctx->oqPath, 4ull * C); ENSURE(ctx->oqPool, 4ull * (poolInts + 16)); ENSURE(ctx->oqPush, sizeof(yoqc::OutRec) * (uint64_t)C); ENSURE(ctx->oqOut, sizeof(yoqc::OutRec) * (uint64_t)C);
+    ENSURE(ctx->oqNeed, 8ull * (n + 2)); ENSURE(ctx->oqPoolOff, 8ull * (n + 2)); ENSURE(ctx->oqLists, 4ull * YQ_NCLASS * (uint64_t)n + 64); ENSURE(ctx->oqClsCnt, 64);
+    ENSURE(ctx->oqPrim, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(ctx->oqPA, sizeof(yoqc::PAttr) * (uint64_t)C); ENSURE(ctx->oqPush, sizeof(yoqc::OutRec) * (uint64_t)C); ENSURE(ctx->oqOut, sizeof(yoqc::OutRec) * (uint64_t)C);
     ENSURE(ctx->oqOutCnt, 4ull * (n + 2)); ENSURE(ctx->oqOutOps, 4ull * (n + 2)); ENSURE(ctx->oqPrimCnt, 4ull * (n + 2));
-    HIPCHK(hipMemsetAsync((uint32_t *)ctx->oqOutCnt.p + n, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync((uint32_t *)ctx->oqOutOps.p + n, 0, 8, ctx->stream));
+    HIPCHK(hipMemsetAsync((uint32_t *)ctx->oqOutCnt.p + n, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync((uint32_t *)ctx->oqOutOps.p + n, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->oqClsCnt.p, 0, 64, ctx->stream));
     OqcArgs A; A.P = ctx->oqP; A.G = ctx->oqG; A.cs = ctx->readStart.as<uint32_t>(); A.cl = ctx->outClumps2.as<ygpu_clump>(); A.ops = ctx->outOps.as<uint32_t>(); A.fwd = ctx->dFwd.as<uint8_t>(); A.readOff = ctx->dReadOff.as<uint32_t>(); A.nReads = n;
-    A.poolOff = ctx->oqPoolOff.as<unsigned long long>(); A.keys = ctx->oqKeys.as<yoqc::SortKey>(); A.stack = ctx->oqStack.as<int>(); A.nodes = ctx->oqNodes.as<yoqc::CNode>(); A.prim = ctx->oqPrim.as<yoqc::CNode>(); A.pa = ctx->oqPA.as<yoqc::PAttr>();
-    A.pfxOff = ctx->oqPfx.as<int>(); A.path = ctx->oqPath.as<int>(); A.pool = ctx->oqPool.as<int>(); A.push = ctx->oqPush.as<yoqc::OutRec>(); A.out = ctx->oqOut.as<yoqc::OutRec>();
+    A.poolOff = ctx->oqPoolOff.as<unsigned long long>(); A.prim = ctx->oqPrim.as<yoqc::CNode>(); A.pa = ctx->oqPA.as<yoqc::PAttr>(); A.push = ctx->oqPush.as<yoqc::OutRec>(); A.out = ctx->oqOut.as<yoqc::OutRec>();
     A.outCnt = ctx->oqOutCnt.as<uint32_t>(); A.outOpsCnt = ctx->oqOutOps.as<uint32_t>(); A.primCnt = ctx->oqPrimCnt.as<uint32_t>();
-    KL(k_oqc_run, dim3(gridFor(n, 64)), dim3(64), 0, ctx->stream, A);
+    A.keys = nullptr; A.stack = nullptr; A.nodes = nullptr; A.pfxOff = nullptr; A.path = nullptr; A.pool = nullptr;
+    uint32_t *lists = ctx->oqLists.as<uint32_t>();
+    KL(k_oqc_classify, dim3(gridFor(n + 1, 256)), dim3(256), 0, ctx->stream, A, ctx->oqNeed.as<unsigned long long>(), lists, ctx->oqClsCnt.as<unsigned int>());
+    int rc = cubScan64(ctx, ctx->oqNeed.as<unsigned long long>(), ctx->oqPoolOff.as<unsigned long long>(), n + 1); if (rc) return rc;
+    unsigned long long poolInts = 0; uint32_t nCls[YQ_NCLASS] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(&poolInts, ctx->oqPoolOff.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    rc = fetchU32(ctx, ctx->oqClsCnt.p, nCls, YQ_NCLASS); if (rc) return rc;
+    ENSURE(ctx->oqPool, 4ull * (poolInts + 16)); A.pool = ctx->oqPool.as<int>();
+    // work space of the reads in HBM: what a wave's LDS does not hold (the survivors' keys while the nodes are made; everything for the reads of the last class)
+    ENSURE(ctx->oqKeys, sizeof(yoqc::SortKey) * (uint64_t)C); ENSURE(ctx->oqStack, 4ull * (4ull * C + 8ull * n + 16)); ENSURE(ctx->oqNodes, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(ctx->oqPfx, 4ull * C); ENSURE(ctx->oqPath, 4ull * C);
+    A.keys = ctx->oqKeys.as<yoqc::SortKey>(); A.stack = ctx->oqStack.as<int>(); A.nodes = ctx->oqNodes.as<yoqc::CNode>(); A.pfxOff = ctx->oqPfx.as<int>(); A.path = ctx->oqPath.as<int>();
+    // the classes: clumps a read may have -> LDS of its workgroup; ints of LDS pool (the first tables; later ones go to the read's slice of the HBM pool)
+    static const int capN[YQ_NCLASS] = {112, 448, 1000, 0}, poolLds[YQ_NCLASS] = {768, 1536, 0, 0};
+    for (int c = 0; c < YQ_NCLASS; c++) if (nCls[c]) {
+        const unsigned lds = c == YQ_NCLASS - 1 ? YQ_LDS_MAX : std::min(YQ_LDS_MAX, oqcLdsBytes(capN[c], poolLds[c]));
+        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, ctx->stream, A, lists + (size_t)c * n, nCls[c], lds, poolLds[c]);
+    }
+    if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 448 / 1000 clumps: %u / %u / %u, more %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3], nCls[0], nCls[1], nCls[2], nCls[3], poolInts * 4.0 / 1e6);
     rc = cubScan(ctx, ctx->oqOutCnt.as<uint32_t>(), ctx->oqOutStart.as<uint32_t>(), n + 1); if (rc) return rc;
     rc = cubScan(ctx, ctx->oqOutOps.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), n + 1); if (rc) return rc;
     uint32_t tot[2] = {0, 0};

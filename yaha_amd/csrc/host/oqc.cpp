@@ -80,7 +80,7 @@ void postFilter(const Args &a, const Genome &g, const Read &r, const ygpu_clump 
     size_t poolInts = 0; for (uint32_t i = 0; i < n; i++) poolInts += 2 * ((size_t)cl[i].n_ops + 1);
     if (tlKeys.size() < n) { tlKeys.resize(n); tlStack.resize(4 * (size_t)n + 8); tlPfx.resize(n); tlPath.resize(n); tlNodes.resize(n); tlPrim.resize(n); tlPA.resize(n); tlPush.resize(n); tlOut.resize(n); }
     if (tlPool.size() < poolInts) tlPool.resize(poolInts);
-    yoqc::Scratch S{tlKeys.data(), tlStack.data(), tlNodes.data(), tlPrim.data(), tlPA.data(), tlPfx.data(), tlPath.data(), tlPool.data(), tlPush.data()};
+    yoqc::Scratch S{tlKeys.data(), tlStack.data(), 0x7fffffff, nullptr, tlNodes.data(), tlPfx.data(), tlPath.data(), tlPool.data(), 0x7fffffff, nullptr, tlPrim.data(), tlPA.data(), tlPush.data()};
     const int m = yoqc::run(P, Sq, cl, (int)n, ops, qlen, r.fwdCodes.data(), S, tlOut.data(), &primaryCount);
     for (int k = 0; k < m; k++) {
         const yoqc::OutRec &o = tlOut[k]; OutClump oc; oc.c = cl[o.clump]; oc.ops = ops + cl[o.clump].op_start; oc.status = o.status; oc.mapQuality = o.mapQuality; oc.numSecondaries = o.numSecondaries; oc.matchedPrimary = o.matchedPrimary;

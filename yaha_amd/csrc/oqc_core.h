@@ -39,8 +39,12 @@ struct CNode {                                                         // cGraph
 };
 struct PAttr { int alignedQueryLength, numOutputSecondaries; int16_t secondScore, thirdScore; };   // :526-533
 struct OutRec { int clump; uint8_t status, mapQuality; uint16_t numSecondaries, matchedPrimary, pad; };   // one clump as it reaches printClump, in print order
-// per-read work space: keys n, stack 2n ints, nodes n, prim n, pa n, pfxOff n, path n, pool 2 * (sum over the read's clumps of n_ops + 1) ints, push n
-struct Scratch { SortKey *keys; int *stack; CNode *nodes; CNode *prim; PAttr *pa; int *pfxOff; int *path; int *pool; OutRec *push; };
+// Per-read work space (n = clumps of the read, cnt <= n = nodes that survive the duplicate removal):
+//   keys n; the sort's stack: stackCap ints in `stack`, what goes beyond in `stack2` (4n + 8 ints hold any recursion); nodes, tbl, path: cnt each;
+//   running-sum tables: `pool` while they fit its poolCap ints, `pool2` after that (2 * (sum over the read's clumps of n_ops + 1) ints hold every table);
+//   prim, pa, push: n each (touched once at the end).
+// The device keeps keys, stack, nodes, tbl, path and a small pool in LDS (device/oqc_stage.h); the host has one of everything.
+struct Scratch { SortKey *keys; int *stack; int stackCap; int *stack2; CNode *nodes; int *tbl; int *path; int *pool; int poolCap; int *pool2; CNode *prim; PAttr *pa; OutRec *push; };
 
 struct Rand { uint32_t s[5]; };                                        // Marsaglia xorshift, Math.c:257-290
 YQ_FN uint32_t randBits(Rand &r)
@@ -61,41 +65,136 @@ YQ_FN void seedFromCodes(const uint8_t *codes, int n, Rand &rs)        // genera
 }
 YQ_FN uint64_t compareKey(int SQO, int EQO, int score)                // getCompareKey :377-380
 { return ((((uint64_t)(uint16_t)SQO << 16) + (uint16_t)(-(int)(int16_t)(uint16_t)EQO)) << 16) + (uint16_t)(-(int)(int16_t)score); }
+YQ_FN int keyEQO(uint64_t k) { return (int)(uint16_t)(0u - (uint32_t)((k >> 16) & 0xffff)); }
+YQ_FN int keyScore(uint64_t k) { return (int)(int16_t)(uint16_t)(0u - (uint32_t)(k & 0xffff)); }
 YQ_FN int findSeq(const Seqs &g, uint32_t off)                        // findBaseSequenceNum, BaseSeq.c:81-90
 { for (uint32_t i = 0; i < g.n; i++) if (off >= g.start[i] && off < g.start[i] + g.length[i]) return (int)i; return -1; }
 
-// The state of one read's run.  Edit lists are scored through running sums built once per clump that is asked about (see scoreForLength).
+// double-precision pieces of the filter, defined at the end of this file under "no contraction" (a fused multiply-add would round once where the reference rounds twice)
+YQ_FN uint8_t mapQuality(int totScore, int secondScore, int thirdScore);
+YQ_FN bool similarEnough(int nodeScore, int primaryScore, float PSScore);
+YQ_FN bool overlapsEnough(int overlap, int len, double target);
+
+// bppN < 0 (negative costs: not a non-decreasing step function): the expression itself, on the host only -- the device stage is not used for such runs
+#if defined(__HIP_DEVICE_COMPILE__)
+YQ_FN int exactBPP(uint32_t, int, int) { return 0; }
+#else
+inline int exactBPP(uint32_t distance, int BPCost, int MBPL) { double lg = log10((double)distance); if (lg > MBPL) lg = (double)MBPL; return (int)(lg * BPCost + 0.5); }
+#endif
+
+// The state of one read's run, in the steps the reference takes (postFilterBySimilarity :897-1086).  run() below strings them together for one thread; the device
+// stage calls the same steps, the independent ones -- the duplicate scan behind a node, the candidate successors of a node -- from the lanes of a wave.
 struct Run {
-    const Params &P; const ygpu_clump *cl; const uint32_t *ops; Scratch S; int poolUsed;
-    YQ_FN const uint32_t *opsOf(int c) const { return ops + cl[c].op_start; }
-    YQ_FN int nOps(int c) const { return (int)cl[c].n_ops; }
+    const Params &P; const ygpu_clump *cl; const uint32_t *ops; Scratch S; int poolUsed, pool2Used;
     YQ_FN int opScore(char op, int len) const
     { return op == 'M' ? P.MScore * len : op == 'R' ? -(P.RCost * len) : op == 'I' ? -(P.GOCost + P.GECost * len) : 0; }
-    // calcScoreForLength (:705-732) walks a clump's edit list from one end until `length` query bases are covered; the graph loop asks it ~120 times a read
-    // for the same few clumps.  Every clump that is asked about gets (once) the running sums Q[m], S[m] = query bases and score after its first m ops,
-    // untruncated; a call is then a binary search for the op the walk stops in plus that op's truncated share.  The walk from the other end reads the same
-    // table backwards (Qb[m] = Q[n] - Q[n-m]).  Same arithmetic, same results: only the order of the integer additions differs.
-    YQ_FN const int *table(int c)
+
+    // ---- keys, sort ------------------------------------------------------------------------------------------------------------------------------------------
+    YQ_FN void makeKey(int i, int qlen)                                 // keys in list order head->tail (:929-934)
     {
-        int off = S.pfxOff[c];
-        if (off < 0) {
-            const uint32_t *o = opsOf(c); const int n = nOps(c);
-            off = poolUsed; S.pfxOff[c] = off; poolUsed += 2 * (n + 1);
-            int *Q = S.pool + off, *Sc = Q + n + 1; int q = 0, sc = 0; Q[0] = 0; Sc[0] = 0;
-            for (int k = 0; k < n; k++) {
-                const char op = YGPU_OP_CODE(o[k]); const int len = (int)YGPU_OP_LEN(o[k]);
-                if (op == 'D') sc -= (P.GOCost + P.GECost * len); else { q += len; sc += opScore(op, len); }
-                Q[k + 1] = q; Sc[k + 1] = sc;
+        const ygpu_clump &c = cl[i]; const bool rev = (c.status & stReversed) != 0;
+        SortKey k; k.key = compareKey(rev ? (qlen - 1) - c.eqo : c.sqo, rev ? (qlen - 1) - c.sqo : c.eqo, (int)c.totScore); k.clump = i; k.pad = 0; S.keys[i] = k;
+    }
+    YQ_FN int &stackAt(int k) { return k < S.stackCap ? S.stack[k] : S.stack2[k - S.stackCap]; }
+    // The sort (myQuickSortHelper :427-453 on getCompareKey, ties broken by the per-read generator) decides which of two equal-keyed clumps comes first -- which
+    // duplicate survives, which copy of a repeat becomes the primary -- so its comparisons must happen in the reference's order.  They depend on keys and positions
+    // only: the routine runs on (key, clump) pairs with the keys computed once; the reference's recursion (left part first) is an explicit stack of ranges.
+    YQ_FN void sortKeys(int n, const uint8_t *fwdCodes, int qlen)
+    {
+        Rand rs; seedFromCodes(fwdCodes, qlen, rs);
+        SortKey *arr = S.keys;
+        int sp = 0; stackAt(sp++) = 0; stackAt(sp++) = n - 1;
+        while (sp > 0) {
+            const int right = stackAt(--sp), left = stackAt(--sp);
+            if (left >= right) continue;
+            const int pivot = (left + right) / 2;
+            { const SortKey t = arr[pivot]; arr[pivot] = arr[right]; arr[right] = t; }
+            int store = left;
+            const uint64_t pk = arr[right].key;
+            for (int i = left; i < right; i++) {                        // "if less: swap(arr[i], arr[store]), store++" written with masks (host: the outcome of a
+                const uint64_t xk = arr[i].key, yk = arr[store].key; const uint32_t xc = (uint32_t)arr[i].clump, yc = (uint32_t)arr[store].clump;   // comparison is a coin toss to the branch predictor)
+                bool less = xk < pk;
+                if (xk == pk) less = (randBits(rs) & 1) != 0;
+                const uint64_t m = (uint64_t)0 - (uint64_t)less; const uint64_t dk = (xk ^ yk) & m; const uint32_t dc = (xc ^ yc) & (uint32_t)m;
+                arr[i].key = xk ^ dk; arr[i].clump = (int)(xc ^ dc); arr[store].key = yk ^ dk; arr[store].clump = (int)(yc ^ dc); store += (int)less;
+            }
+            { const SortKey t = arr[store]; arr[store] = arr[right]; arr[right] = t; }
+            // the reference sorts [left, store-1] completely before it touches [store+1, right]: the right part goes on the stack first
+            stackAt(sp++) = store + 1; stackAt(sp++) = right;
+            stackAt(sp++) = left; stackAt(sp++) = store - 1;
+        }
+    }
+
+    // ---- deleteSubsumedDups :488-517, on the sorted keys --------------------------------------------------------------------------------------------------------
+    // All the scan reads of a node -- SQO, EQO, score -- is in the key (SQO<<32 | (-EQO & 0xffff)<<16 | -score & 0xffff); only two nodes of equal SQO and EQO are
+    // ever compared by reference position.  A dead node is marked in its clump field (~clump).  dupKill(ck, ci, j): must the live node at j die behind the live
+    // node (ck, ci)?  (The caller has checked that j's EQO does not exceed the node's: there the scan ends.)
+    YQ_FN bool dupKill(uint64_t ck, int ci, int j) const
+    {
+        const uint64_t k = S.keys[j].key;
+        if (keyEQO(ck) > keyEQO(k) && keyScore(k) < keyScore(ck) / 8) return true;
+        if ((k >> 16) != (ck >> 16)) return false;                      // same SQO and EQO: duplicates if they are the same piece of the reference on the same strand
+        const ygpu_clump &c1 = cl[ci], &c2 = cl[S.keys[j].clump];
+        return c1.sro == c2.sro && c1.refLen == c2.refLen && ((c1.status ^ c2.status) & stReversed) == 0;
+    }
+    YQ_FN int dedup(int n)                                              // survivors compacted to keys[0..return)
+    {
+        SortKey *sk = S.keys; int cnt = 0;
+        for (int i = 0; i < n; i++) {
+            if (sk[i].clump < 0) continue;
+            const uint64_t ck = sk[i].key; const int ci = sk[i].clump, curEQO = keyEQO(ck);
+            sk[cnt++] = sk[i];
+            for (int j = i + 1; j < n; j++) {
+                if (sk[j].clump < 0) continue;
+                if (keyEQO(sk[j].key) > curEQO) break;
+                if (dupKill(ck, ci, j)) sk[j].clump = ~sk[j].clump;
             }
         }
-        return S.pool + off;
+        return cnt;
     }
-    YQ_FN int scoreForLength(int c, int length, bool forward)           // calcScoreForLength, :705-732
+
+    // ---- nodes (initcGraphNode :342-363), for the survivors only ---------------------------------------------------------------------------------------------------
+    YQ_FN void makeNode(int p, const Seqs &g, int qlen, int seqHint)
+    {
+        const int i = S.keys[p].clump;
+        CNode nd; const ygpu_clump &c = cl[i]; const bool rev = (c.status & stReversed) != 0;
+        nd.bestPrev = -1; nd.pathLength = 1; nd.clump = i;
+        nd.bestScore = nd.nodeScore = (int16_t)(int)c.totScore; nd.nodeLength = (int16_t)c.totLength;
+        nd.SQO = rev ? (uint16_t)((qlen - 1) - c.eqo) : c.sqo; nd.EQO = rev ? (uint16_t)((qlen - 1) - c.sqo) : c.eqo;
+        nd.SRO = c.sro; nd.ERO = c.sro + c.refLen - 1; nd.reversed = rev; nd.qLenInOQC = (uint16_t)(1 + c.eqo - c.sqo);
+        if (seqHint >= 0 && (uint32_t)seqHint < g.n && nd.SRO >= g.start[seqHint] && nd.SRO < g.start[seqHint] + g.length[seqHint]) nd.seqNum = (uint8_t)seqHint;
+        else nd.seqNum = (uint8_t)findSeq(g, nd.SRO);
+        S.nodes[p] = nd; S.tbl[p] = -1;
+    }
+
+    // ---- calcScoreForLength (:705-732) --------------------------------------------------------------------------------------------------------------------------
+    // It walks a clump's edit list from one end until `length` query bases are covered; the graph loop asks it ~120 times a read for the same few clumps.  Every
+    // node that is asked about gets (once) the running sums Q[m], S[m] = query bases and score after its first m ops, untruncated; a call is then a binary search
+    // for the op the walk stops in plus that op's truncated share.  The walk from the other end reads the same table backwards (Qb[m] = Q[n] - Q[n-m]).  Same
+    // arithmetic, same results: only the order of the integer additions differs.
+    YQ_FN void assignTable(int p)                                       // a place for node p's table (sequential: the pools are bump allocators)
+    {
+        const int need = 2 * ((int)cl[S.nodes[p].clump].n_ops + 1);
+        if (poolUsed + need <= S.poolCap) { S.tbl[p] = poolUsed; poolUsed += need; } else { S.tbl[p] = -2 - pool2Used; pool2Used += need; }
+    }
+    YQ_FN int *tablePtr(int p) const { const int off = S.tbl[p]; return off >= 0 ? S.pool + off : S.pool2 + (-2 - off); }
+    YQ_FN void fillTable(int p)
+    {
+        const int c = S.nodes[p].clump; const uint32_t *o = ops + cl[c].op_start; const int n = (int)cl[c].n_ops;
+        int *Q = tablePtr(p), *Sc = Q + n + 1; int q = 0, sc = 0; Q[0] = 0; Sc[0] = 0;
+        for (int k = 0; k < n; k++) {
+            const char op = YGPU_OP_CODE(o[k]); const int len = (int)YGPU_OP_LEN(o[k]);
+            if (op == 'D') sc -= (P.GOCost + P.GECost * len); else { q += len; sc += opScore(op, len); }
+            Q[k + 1] = q; Sc[k + 1] = sc;
+        }
+    }
+    YQ_FN const int *table(int p) { if (S.tbl[p] == -1) { assignTable(p); fillTable(p); } return tablePtr(p); }
+    YQ_FN int scoreForLength(int p, int length, bool forward)           // node p's edit list
     {
         if (length <= 0) return 0;
-        const int n = nOps(c); if (n <= 0) return 0;
-        const uint32_t *o = opsOf(c);
-        const int *Q = table(c), *Sc = Q + n + 1;
+        const int c = S.nodes[p].clump, n = (int)cl[c].n_ops; if (n <= 0) return 0;
+        const uint32_t *o = ops + cl[c].op_start;
+        const int *Q = table(p), *Sc = Q + n + 1;
         if (Q[n] < length) return Sc[n];                                 // the list ends first: every op counted in full
         // (host, measured: forcing these searches branch-free -- an AND with the comparison's mask -- made a call slower, 14.9 -> 18.2 us a read: the walks of one
         // read stop in similar places, the branches predict; the reference's own loop for the first four ops before any table is touched: 14.9 -> 16.7 -- the
@@ -115,12 +214,12 @@ struct Run {
     YQ_FN int accurateOverlapScore(int left, int right, int overlap, bool *rightBest)   // :744-800
     {
         const CNode &rn = S.nodes[right];
-        int rightScore = scoreForLength(rn.clump, overlap, !rn.reversed);
+        int rightScore = scoreForLength(right, overlap, !rn.reversed);
         int pathScore = 0, remaining = overlap, cur = left;
         for (;;) {
             const CNode &cn = S.nodes[cur];
             int q = remaining < (int)cn.qLenInOQC ? remaining : (int)cn.qLenInOQC; remaining -= q;
-            pathScore += scoreForLength(cn.clump, q, cn.reversed != 0);
+            pathScore += scoreForLength(cur, q, cn.reversed != 0);
             if (remaining <= 0) break;
             cur = cn.bestPrev;
         }
@@ -152,193 +251,124 @@ struct Run {
             else rn.qLenInOQC = (uint16_t)qLen;
         }
     }
+    // ---- the graph (:973-1063) ----------------------------------------------------------------------------------------------------------------------------------
+    // node j as a successor of node i (i < j, SQO_j - SQO_i >= minNonOverlap already checked; cachePath(i) has run).  Reads node i and its path, writes node j only:
+    // the successors of one node are independent of each other.
+    YQ_FN void relax(int i, int j)
+    {
+        const CNode &ln = S.nodes[i]; CNode &rn = S.nodes[j];
+        const int leftEQO = ln.EQO, rightSQO = rn.SQO, rightEQO = rn.EQO;
+        if ((rightEQO - leftEQO) < P.minNonOverlap) return;
+        int16_t newScore = (int16_t)(ln.bestScore + rn.nodeScore);
+        if (rn.bestScore > newScore) return;
+        int BPP;
+        if (ln.seqNum == rn.seqNum) {
+            uint32_t distance;
+            if (ln.SRO > rn.ERO) distance = ln.SRO - rn.ERO; else if (rn.SRO > ln.ERO) distance = rn.SRO - ln.ERO; else distance = 0;
+            if (distance <= 10) BPP = P.BPCost;
+            else if (P.bppN >= 0) { int k = 0; while (k < P.bppN && P.bppThr[k] <= distance) k++; BPP = P.bppVmin + k; }
+            else BPP = exactBPP(distance, P.BPCost, P.maxBPLog);
+        } else BPP = P.maxBPLog * P.BPCost;
+        newScore = (int16_t)(newScore - BPP);
+        if (rn.bestScore > newScore) return;
+        const int overlap = (leftEQO >= rightSQO) ? (leftEQO - rightSQO) + 1 : 0;
+        bool rightBest = false;
+        if (overlap > 0) { newScore = (int16_t)(newScore - accurateOverlapScore(i, j, overlap, &rightBest)); if (rn.bestScore > newScore) return; }
+        if (rn.bestScore < newScore || (rn.bestPrev >= 0 && ln.pathLength < S.nodes[rn.bestPrev].pathLength)) {
+            if (overlap > 0) { const int ql = 1 + rn.EQO - rn.SQO; rn.qLenInOQC = (uint16_t)(rightBest ? ql : ql - overlap); }   // cacheQlenInRightNode :873-878
+            rn.bestScore = newScore; rn.bestPrev = i; rn.pathLength = (int16_t)(ln.pathLength + 1);
+        }
+    }
+    YQ_FN void considerBest(int i, int &bestScore, int &bestNode) const
+    {
+        const CNode &ln = S.nodes[i];
+        if (ln.bestScore < bestScore) return;
+        if (ln.bestScore > bestScore || (bestNode >= 0 && ln.pathLength < S.nodes[bestNode].pathLength)) { bestNode = i; bestScore = ln.bestScore; }
+    }
+    // ---- filterBySimilarity :571-692, calcMQfromPAs :559-569 ---------------------------------------------------------------------------------------------------------
+    YQ_FN int finish(int curNodeCount, int bestNode, OutRec *out, int *primaryCount)
+    {
+        CNode *gn = S.nodes;
+        const int primeCount = gn[bestNode].pathLength;
+        CNode *primaries = S.prim; PAttr *PA = S.pa; OutRec *push = S.push; int nPush = 0;      // push-to-head order; reversed at the end
+        {
+            int pi = primeCount - 1;
+            for (int p = bestNode; p >= 0; p = gn[p].bestPrev) {
+                primaries[pi] = gn[p];
+                PAttr a; a.alignedQueryLength = 1 + gn[p].EQO - gn[p].SQO; a.numOutputSecondaries = 0; a.secondScore = 0; a.thirdScore = 0; PA[pi] = a;
+                OutRec o; o.clump = gn[p].clump; o.status = (uint8_t)(cl[gn[p].clump].status | stPrimary); o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(pi + 1); o.pad = 0;
+                push[nPush++] = o;
+                gn[p].clump = -1; pi--;
+            }
+        }
+        const double targetOverlap = (double)P.FBS_PSLength;
+        for (int i = 0; i < curNodeCount; i++) {
+            const CNode &cn = gn[i];
+            if (cn.clump < 0) continue;
+            const int curSQO = cn.SQO, curEQO = cn.EQO, curQLen = 1 + curEQO - curSQO; int maxOverlap = 0, maxIndex = 0;
+            for (int k = 0; k < primeCount; k++) {
+                const int e = curEQO < (int)primaries[k].EQO ? curEQO : (int)primaries[k].EQO, s = curSQO > (int)primaries[k].SQO ? curSQO : (int)primaries[k].SQO;
+                const int overlap = 1 + e - s;
+                if (overlap > maxOverlap) { maxOverlap = overlap; maxIndex = k; }
+            }
+            if (maxOverlap > 0) {
+                PAttr &pa = PA[maxIndex];
+                if (cn.nodeScore > pa.secondScore) { pa.thirdScore = pa.secondScore; pa.secondScore = cn.nodeScore; }      // memoPAsFromOverlappingNode :545-557
+                else if (cn.nodeScore > pa.thirdScore) pa.thirdScore = cn.nodeScore;
+                const CNode &pn = primaries[maxIndex];
+                if (similarEnough(cn.nodeScore, pn.nodeScore, P.FBS_PSScore)) {
+                    const int e = curEQO < (int)pn.EQO ? curEQO : (int)pn.EQO, s = curSQO > (int)pn.SQO ? curSQO : (int)pn.SQO;
+                    const int overlap = 1 + e - s, pathQLen = pa.alignedQueryLength;
+                    if (overlapsEnough(overlap, curQLen, targetOverlap) && overlapsEnough(overlap, pathQLen, targetOverlap)) {
+                        pa.numOutputSecondaries += 1;
+                        if (P.FBS) {
+                            OutRec o; o.clump = cn.clump; o.status = cl[cn.clump].status; o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(maxIndex + 1); o.pad = 0;
+                            push[nPush++] = o; continue;
+                        }
+                    }
+                }
+            }
+        }
+        *primaryCount = primeCount;
+        for (int k = 0; k < primeCount; k++) {                          // primaries are push[0..primeCount) holding index primeCount-1 .. 0
+            OutRec &o = push[k]; const PAttr &pa = PA[primeCount - 1 - k];
+            o.mapQuality = mapQuality((int)cl[o.clump].totScore, pa.secondScore, pa.thirdScore);
+            o.numSecondaries = (uint16_t)pa.numOutputSecondaries;
+        }
+        for (int k = nPush - 1; k >= 0; k--) out[nPush - 1 - k] = push[k];
+        return nPush;
+    }
 };
 
-// bppN < 0 (negative costs: not a non-decreasing step function): the expression itself, on the host only -- the device stage is not used for such runs
-#if defined(__HIP_DEVICE_COMPILE__)
-YQ_FN int exactBPP(uint32_t, int, int) { return 0; }
-#else
-inline int exactBPP(uint32_t distance, int BPCost, int MBPL) { double lg = log10((double)distance); if (lg > MBPL) lg = (double)MBPL; return (int)(lg * BPCost + 0.5); }
-#endif
-
-// The sort (myQuickSortHelper :427-453 on getCompareKey, ties broken by the per-read generator) decides which of two equal-keyed clumps survives, so its
-// comparisons must happen in the reference's order.  They depend on keys and positions only: the routine runs on (key, clump) pairs with the keys computed
-// once; the reference's recursion (left part first) is an explicit stack of ranges.
-YQ_FN void quickSort(SortKey *arr, int n, int *stack, Rand &rs)
+YQ_FN int single(const ygpu_clump *cl, OutRec *out, int *primaryCount)      // a read with one clump, :907-916
 {
-    int sp = 0; stack[sp++] = 0; stack[sp++] = n - 1;
-    while (sp > 0) {
-        const int right = stack[--sp], left = stack[--sp];
-        if (left >= right) continue;
-        const int pivot = (left + right) / 2;
-        { const SortKey t = arr[pivot]; arr[pivot] = arr[right]; arr[right] = t; }
-        int store = left;
-        const uint64_t pk = arr[right].key;
-        for (int i = left; i < right; i++) {                            // "if less: swap(arr[i], arr[store]), store++" written with masks (host: the outcome of a
-            const uint64_t xk = arr[i].key, yk = arr[store].key; const uint32_t xc = (uint32_t)arr[i].clump, yc = (uint32_t)arr[store].clump;   // comparison is a coin toss to the branch predictor)
-            bool less = xk < pk;
-            if (xk == pk) less = (randBits(rs) & 1) != 0;
-            const uint64_t m = (uint64_t)0 - (uint64_t)less; const uint64_t dk = (xk ^ yk) & m; const uint32_t dc = (xc ^ yc) & (uint32_t)m;
-            arr[i].key = xk ^ dk; arr[i].clump = (int)(xc ^ dc); arr[store].key = yk ^ dk; arr[store].clump = (int)(yc ^ dc); store += (int)less;
-        }
-        { const SortKey t = arr[store]; arr[store] = arr[right]; arr[right] = t; }
-        // the reference sorts [left, store-1] completely before it touches [store+1, right]: the right part goes on the stack first
-        stack[sp++] = store + 1; stack[sp++] = right;
-        stack[sp++] = left; stack[sp++] = store - 1;
-    }
+    OutRec o; o.clump = 0; o.status = (uint8_t)(cl[0].status | stPrimary); o.mapQuality = 250; o.numSecondaries = 0; o.matchedPrimary = 1; o.pad = 0;
+    out[0] = o; *primaryCount = 1; return 1;
 }
-
-// double-precision pieces of the filter, defined at the end of this file under "no contraction" (a fused multiply-add would round once where the reference rounds twice)
-YQ_FN uint8_t mapQuality(int totScore, int secondScore, int thirdScore);
-YQ_FN bool similarEnough(int nodeScore, int primaryScore, float PSScore);
-YQ_FN bool overlapsEnough(int overlap, int len, double target);
-
-// postFilterBySimilarity (:897-1086) for the n clumps of one read (QS->clumps head -> tail).  out[0..return) = the clumps to print, in print order;
+// postFilterBySimilarity (:897-1086) for the n clumps of one read (QS->clumps head -> tail), one thread.  out[0..return) = the clumps to print, in print order;
 // *primaryCount = QS->primaryCount.  Needs n >= 1.
 YQ_FN int run(const Params &P, const Seqs &g, const ygpu_clump *cl, int n, const uint32_t *ops, int qlen, const uint8_t *fwdCodes, Scratch S, OutRec *out, int *primaryCount)
 {
-    if (n == 1) {                                                       // :907-916
-        OutRec o; o.clump = 0; o.status = (uint8_t)(cl[0].status | stPrimary); o.mapQuality = 250; o.numSecondaries = 0; o.matchedPrimary = 1; o.pad = 0;
-        out[0] = o; *primaryCount = 1; return 1;
-    }
-    Run X{P, cl, ops, S, 0};
-    for (int i = 0; i < n; i++) S.pfxOff[i] = -1;
-    // keys in list order head->tail (:929-934), sorted
-    for (int i = 0; i < n; i++) {
-        const ygpu_clump &c = cl[i]; const bool rev = (c.status & stReversed) != 0;
-        SortKey k; k.key = compareKey(rev ? (qlen - 1) - c.eqo : c.sqo, rev ? (qlen - 1) - c.sqo : c.eqo, (int)c.totScore); k.clump = i; k.pad = 0; S.keys[i] = k;
-    }
-    Rand rs; seedFromCodes(fwdCodes, qlen, rs);
-    quickSort(S.keys, n, S.stack, rs);
-    // deleteSubsumedDups :488-517, run on the sorted keys: all it reads of a node -- SQO, EQO, score -- is in the key (SQO<<32 | (-EQO & 0xffff)<<16 | -score & 0xffff),
-    // and only two nodes of equal SQO and EQO are ever compared by reference position.  A dead node is marked in its clump field (~clump); nodes are then made
-    // (initcGraphNode :342-363) for the survivors only -- a quarter of what the hot path returns for a 1 kbp read.
-    int cnt = 0;
-    {
-        SortKey *sk = S.keys;
-        for (int i = 0; i < n; i++) {
-            if (sk[i].clump < 0) continue;
-            const uint64_t ck = sk[i].key; const int ci = sk[i].clump;
-            sk[cnt++] = sk[i];                                          // survivors compacted in place (cnt <= i)
-            const int curEQO = (int)(uint16_t)(0u - (uint32_t)((ck >> 16) & 0xffff)), thr = (int)(int16_t)(uint16_t)(0u - (uint32_t)(ck & 0xffff)) / 8; const uint64_t cur32 = ck >> 16;
-            for (int j = i + 1; j < n; j++) {
-                if (sk[j].clump < 0) continue;
-                const uint64_t k = sk[j].key; const int e = (int)(uint16_t)(0u - (uint32_t)((k >> 16) & 0xffff));
-                if (e > curEQO) break;
-                bool kill = (curEQO > e && (int)(int16_t)(uint16_t)(0u - (uint32_t)(k & 0xffff)) < thr);
-                if (!kill && (k >> 16) == cur32) {                      // same SQO and EQO: duplicates if they are the same piece of the reference on the same strand
-                    const ygpu_clump &c1 = cl[ci], &c2 = cl[sk[j].clump];
-                    kill = (c1.sro == c2.sro && c1.refLen == c2.refLen && ((c1.status ^ c2.status) & stReversed) == 0);
-                }
-                if (kill) sk[j].clump = ~sk[j].clump;
-            }
-        }
-    }
-    CNode *gn = S.nodes;
-    {
-        int last = 0;                                                   // the sequence of a node (break point penalty): most nodes of a read lie in one or two sequences
-        for (int p = 0; p < cnt; p++) {
-            const int i = S.keys[p].clump;
-            CNode nd; const ygpu_clump &c = cl[i]; const bool rev = (c.status & stReversed) != 0;
-            nd.bestPrev = -1; nd.pathLength = 1; nd.clump = i;
-            nd.bestScore = nd.nodeScore = (int16_t)(int)c.totScore; nd.nodeLength = (int16_t)c.totLength;
-            nd.SQO = rev ? (uint16_t)((qlen - 1) - c.eqo) : c.sqo; nd.EQO = rev ? (uint16_t)((qlen - 1) - c.sqo) : c.eqo;
-            nd.SRO = c.sro; nd.ERO = c.sro + c.refLen - 1; nd.reversed = rev; nd.qLenInOQC = (uint16_t)(1 + c.eqo - c.sqo);
-            if (g.n && nd.SRO >= g.start[last] && nd.SRO < g.start[last] + g.length[last]) nd.seqNum = (uint8_t)last;
-            else { const int f = findSeq(g, nd.SRO); nd.seqNum = (uint8_t)f; if (f >= 0) last = f; }
-            gn[p] = nd;
-        }
-    }
-    const int curNodeCount = cnt;
+    if (n == 1) return single(cl, out, primaryCount);
+    Run X{P, cl, ops, S, 0, 0};
+    for (int i = 0; i < n; i++) X.makeKey(i, qlen);
+    X.sortKeys(n, fwdCodes, qlen);
+    const int cnt = X.dedup(n);
+    { int last = 0; for (int p = 0; p < cnt; p++) { X.makeNode(p, g, qlen, last); const int f = S.nodes[p].seqNum; if (f != 255) last = f; } }      // (most nodes of a read lie in one or two sequences)
     int bestScore = YQ_WORST, bestNode = -1, startj = 1;
-    const int minNonOverlap = P.minNonOverlap, BPCost = P.BPCost, MBPL = P.maxBPLog;
-    for (int i = 0; i < curNodeCount; i++) {                            // :973-1063
+    for (int i = 0; i < cnt; i++) {                                     // :973-1063
         X.cachePath(i);
-        CNode &ln = gn[i];
-        const int leftSQO = ln.SQO, leftEQO = ln.EQO; bool foundstartj = false;
-        for (int j = startj; j < curNodeCount; j++) {
-            CNode &rn = gn[j];
-            const int rightSQO = rn.SQO;
-            if ((rightSQO - leftSQO) >= minNonOverlap) {
+        const int leftSQO = S.nodes[i].SQO; bool foundstartj = false;
+        for (int j = startj; j < cnt; j++) {
+            if (((int)S.nodes[j].SQO - leftSQO) >= P.minNonOverlap) {
                 if (!foundstartj) { startj = j; foundstartj = true; }
-                const int rightEQO = rn.EQO;
-                if ((rightEQO - leftEQO) >= minNonOverlap) {
-                    int16_t newScore = (int16_t)(ln.bestScore + rn.nodeScore);
-                    if (rn.bestScore > newScore) continue;
-                    int BPP;
-                    if (ln.seqNum == rn.seqNum) {
-                        uint32_t distance;
-                        if (ln.SRO > rn.ERO) distance = ln.SRO - rn.ERO; else if (rn.SRO > ln.ERO) distance = rn.SRO - ln.ERO; else distance = 0;
-                        if (distance <= 10) BPP = BPCost;
-                        else if (P.bppN >= 0) { int k = 0; while (k < P.bppN && P.bppThr[k] <= distance) k++; BPP = P.bppVmin + k; }
-                        else BPP = exactBPP(distance, BPCost, MBPL);
-                    } else BPP = MBPL * BPCost;
-                    newScore = (int16_t)(newScore - BPP);
-                    if (rn.bestScore > newScore) continue;
-                    const int overlap = (leftEQO >= rightSQO) ? (leftEQO - rightSQO) + 1 : 0;
-                    bool rightBest = false;
-                    if (overlap > 0) { newScore = (int16_t)(newScore - X.accurateOverlapScore(i, j, overlap, &rightBest)); if (rn.bestScore > newScore) continue; }
-                    if (rn.bestScore < newScore || (rn.bestPrev >= 0 && ln.pathLength < gn[rn.bestPrev].pathLength)) {
-                        if (overlap > 0) { const int ql = 1 + rn.EQO - rn.SQO; rn.qLenInOQC = (uint16_t)(rightBest ? ql : ql - overlap); }   // cacheQlenInRightNode :873-878
-                        rn.bestScore = newScore; rn.bestPrev = i; rn.pathLength = (int16_t)(ln.pathLength + 1);
-                    }
-                }
+                X.relax(i, j);
             }
-            if (!foundstartj) startj = curNodeCount;
+            if (!foundstartj) startj = cnt;
         }
-        if (ln.bestScore < bestScore) continue;
-        if (ln.bestScore > bestScore || (bestNode >= 0 && ln.pathLength < gn[bestNode].pathLength)) { bestNode = i; bestScore = ln.bestScore; }
+        X.considerBest(i, bestScore, bestNode);
     }
-    // filterBySimilarity :571-692
-    const int primeCount = gn[bestNode].pathLength;
-    CNode *primaries = S.prim; PAttr *PA = S.pa; OutRec *push = S.push; int nPush = 0;      // push-to-head order; reversed at the end
-    {
-        int pi = primeCount - 1;
-        for (int p = bestNode; p >= 0; p = gn[p].bestPrev) {
-            primaries[pi] = gn[p];
-            PAttr a; a.alignedQueryLength = 1 + gn[p].EQO - gn[p].SQO; a.numOutputSecondaries = 0; a.secondScore = 0; a.thirdScore = 0; PA[pi] = a;
-            OutRec o; o.clump = gn[p].clump; o.status = (uint8_t)(cl[gn[p].clump].status | stPrimary); o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(pi + 1); o.pad = 0;
-            push[nPush++] = o;
-            gn[p].clump = -1; pi--;
-        }
-    }
-    const double targetOverlap = (double)P.FBS_PSLength;
-    for (int i = 0; i < curNodeCount; i++) {
-        const CNode &cn = gn[i];
-        if (cn.clump < 0) continue;
-        const int curSQO = cn.SQO, curEQO = cn.EQO, curQLen = 1 + curEQO - curSQO; int maxOverlap = 0, maxIndex = 0;
-        for (int k = 0; k < primeCount; k++) {
-            const int e = curEQO < (int)primaries[k].EQO ? curEQO : (int)primaries[k].EQO, s = curSQO > (int)primaries[k].SQO ? curSQO : (int)primaries[k].SQO;
-            const int overlap = 1 + e - s;
-            if (overlap > maxOverlap) { maxOverlap = overlap; maxIndex = k; }
-        }
-        if (maxOverlap > 0) {
-            PAttr &pa = PA[maxIndex];
-            if (cn.nodeScore > pa.secondScore) { pa.thirdScore = pa.secondScore; pa.secondScore = cn.nodeScore; }      // memoPAsFromOverlappingNode :545-557
-            else if (cn.nodeScore > pa.thirdScore) pa.thirdScore = cn.nodeScore;
-            const CNode &pn = primaries[maxIndex];
-            if (similarEnough(cn.nodeScore, pn.nodeScore, P.FBS_PSScore)) {
-                const int e = curEQO < (int)pn.EQO ? curEQO : (int)pn.EQO, s = curSQO > (int)pn.SQO ? curSQO : (int)pn.SQO;
-                const int overlap = 1 + e - s, pathQLen = pa.alignedQueryLength;
-                if (overlapsEnough(overlap, curQLen, targetOverlap) && overlapsEnough(overlap, pathQLen, targetOverlap)) {
-                    pa.numOutputSecondaries += 1;
-                    if (P.FBS) {
-                        OutRec o; o.clump = cn.clump; o.status = cl[cn.clump].status; o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(maxIndex + 1); o.pad = 0;
-                        push[nPush++] = o; continue;
-                    }
-                }
-            }
-        }
-    }
-    *primaryCount = primeCount;
-    // calcMQfromPAs :559-569 -- primaries are push[0..primeCount) holding index primeCount-1 .. 0
-    for (int k = 0; k < primeCount; k++) {
-        OutRec &o = push[k]; const PAttr &pa = PA[primeCount - 1 - k];
-        o.mapQuality = mapQuality((int)cl[o.clump].totScore, pa.secondScore, pa.thirdScore);
-        o.numSecondaries = (uint16_t)pa.numOutputSecondaries;
-    }
-    for (int k = nPush - 1; k >= 0; k--) out[nPush - 1 - k] = push[k];
-    return nPush;
+    return X.finish(cnt, bestNode, out, primaryCount);
 }
 }  // namespace yoqc
 
