@@ -979,10 +979,13 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     A.keys = ctx->oqKeys.as<yoqc::SortKey>(); A.stack = ctx->oqStack.as<int>(); A.nodes = ctx->oqNodes.as<yoqc::CNode>(); A.pfxOff = ctx->oqPfx.as<int>(); A.path = ctx->oqPath.as<int>();
     // the classes: clumps a read may have -> LDS of its workgroup; ints of LDS pool (the first tables; later ones go to the read's slice of the HBM pool)
     static const int capN[YQ_NCLASS] = {112, 448, 1000, 0}, poolLds[YQ_NCLASS] = {768, 1536, 0, 0};
-    for (int c = 0; c < YQ_NCLASS; c++) if (nCls[c]) {
+    // (the stream is idle here: fetchU32 waited for it.)  The classes run side by side: the few reads of the heavy classes take milliseconds each -- a kernel lasts as
+    // long as its slowest read -- and leave nearly all of the device to the thousands of light ones, which go out on the second stream.
+    for (int c = YQ_NCLASS - 1; c >= 0; c--) if (nCls[c]) {
         const unsigned lds = c == YQ_NCLASS - 1 ? YQ_LDS_MAX : std::min(YQ_LDS_MAX, oqcLdsBytes(capN[c], poolLds[c]));
-        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, ctx->stream, A, lists + (size_t)c * n, nCls[c], lds, poolLds[c]);
+        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, c < 2 ? ctx->stream2 : ctx->stream, A, lists + (size_t)c * n, nCls[c], lds, poolLds[c]);
     }
+    HIPCHK(hipEventRecord(ctx->evTail, ctx->stream2)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0));
     if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 448 / 1000 clumps: %u / %u / %u, more %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3], nCls[0], nCls[1], nCls[2], nCls[3], poolInts * 4.0 / 1e6);
     rc = cubScan(ctx, ctx->oqOutCnt.as<uint32_t>(), ctx->oqOutStart.as<uint32_t>(), n + 1); if (rc) return rc;
     rc = cubScan(ctx, ctx->oqOutOps.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), n + 1); if (rc) return rc;

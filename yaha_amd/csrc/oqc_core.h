@@ -111,12 +111,20 @@ struct Run {
             { const SortKey t = arr[pivot]; arr[pivot] = arr[right]; arr[right] = t; }
             int store = left;
             const uint64_t pk = arr[right].key;
-            for (int i = left; i < right; i++) {                        // "if less: swap(arr[i], arr[store]), store++" written with masks (host: the outcome of a
-                const uint64_t xk = arr[i].key, yk = arr[store].key; const uint32_t xc = (uint32_t)arr[i].clump, yc = (uint32_t)arr[store].clump;   // comparison is a coin toss to the branch predictor)
-                bool less = xk < pk;
-                if (xk == pk) less = (randBits(rs) & 1) != 0;
-                const uint64_t m = (uint64_t)0 - (uint64_t)less; const uint64_t dk = (xk ^ yk) & m; const uint32_t dc = (xc ^ yc) & (uint32_t)m;
-                arr[i].key = xk ^ dk; arr[i].clump = (int)(xc ^ dc); arr[store].key = yk ^ dk; arr[store].clump = (int)(yc ^ dc); store += (int)less;
+            // "if less: swap(arr[i], arr[store]), store++".  The element at `store` and the next element of the scan are kept in registers: on the device every
+            // access is a round trip of a hundred cycles and more, and the two loads an iteration would otherwise start with are most of the sort's time.  The
+            // next element is fetched one iteration ahead (an iteration writes positions i and store <= i only); the one at `store` changes only after a swap.
+            SortKey y = arr[store], nx = arr[left];
+            for (int i = left; i < right; i++) {
+                const SortKey x = nx;
+                if (i + 1 < right) nx = arr[i + 1];
+                bool less = x.key < pk;
+                if (x.key == pk) less = (randBits(rs) & 1) != 0;
+                if (less) {
+                    if (i != store) { arr[i] = y; arr[store] = x; }
+                    store++;
+                    y = store == i + 1 ? nx : arr[store];                // (store == i: the element just written there, read back in order)
+                }
             }
             { const SortKey t = arr[store]; arr[store] = arr[right]; arr[right] = t; }
             // the reference sorts [left, store-1] completely before it touches [store+1, right]: the right part goes on the stack first
