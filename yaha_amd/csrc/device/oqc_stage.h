@@ -22,11 +22,11 @@ struct OqcArgs {
 // only).  What must stay in the reference's order stays on the first lane: the sort (it consumes the read's random bits in comparison order), the walk along
 // the best path before each node's successors, the choice of the best node, the similarity filter.
 // Reads come in classes by their number of clumps (the LDS a workgroup gets is fixed at launch): keys + sort stack, then nodes + table index + path share it.
-#define YQ_NCLASS 4
+#define YQ_NCLASS 5
 #define YQ_STACK_LDS 256              // ints of the sort's stack kept in LDS (depth ~2 log2 n ranges); deeper recursion continues in HBM
 #define YQ_LDS_MAX 65536u
-__device__ __constant__ const int kOqcCapN[YQ_NCLASS] = {112, 448, 1000, 0x7fffffff};      // clumps a read of the class may have (the last class: keys in LDS while 16 n fits, the rest in HBM)
-__host__ __device__ inline unsigned oqcLdsBytes(int capN, int poolInts) { return 64u * (unsigned)capN + 4u * YQ_STACK_LDS + 4u * (unsigned)poolInts + 64u; }
+__device__ __constant__ const int kOqcCapN[YQ_NCLASS] = {112, 224, 448, 1000, 0x7fffffff};      // clumps a read of the class may have (the last class: keys in LDS while 16 n fits, the rest in HBM)
+__host__ __device__ inline unsigned oqcLdsBytes(int capN) { return 64u * (unsigned)capN + 4u * YQ_STACK_LDS + 64u; }
 // classes of the reads with two or more clumps (lists[c * nReads ...], cnt[c]); reads with one clump are settled here (GraphPath.cpp:907-916); ints of running-sum
 // tables a read may need in HBM: two per op and clump of the read (every clump's table built)
 __global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *lists, unsigned int *cnt)
@@ -53,21 +53,22 @@ __global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *li
         if (cls == c) lists[(size_t)c * A.nReads + base + (unsigned)__builtin_popcountll(mk & ((1ull << lane) - 1ull))] = r;
     }
 }
-// One read per workgroup of one wave.  LDS (dynamic, `ldsBytes`): [sort stack | pool | keys ... ] during the sort and the duplicate scan, then [sort stack | pool |
-// nodes, tbl, path] over the keys' place (the surviving keys are parked in HBM for the moment the nodes are made).  What does not fit LDS lives in the read's
-// slices of the batch-wide HBM arrays (inLds* say which).
-__global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list, uint32_t count, unsigned ldsBytes, int poolInts)
+// One read per workgroup of one wave.  LDS (dynamic, `ldsBytes`): [sort stack | keys ...] during the sort and the duplicate scan, then [sort stack | nodes, tbl,
+// path | running-sum tables ...] over the keys' place (the surviving keys are parked in HBM for the moment the nodes are made): a quarter of a read's clumps survive
+// the duplicate scan, so most of the tables -- a lane's binary searches in the graph loop -- find room in LDS as well; what does not fit lives in the read's slices
+// of the batch-wide HBM arrays.
+__global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list, uint32_t count, unsigned ldsBytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sOqc[];
     if (blockIdx.x >= count) return;
     const int lane = (int)threadIdx.x;
     const uint32_t r = list[blockIdx.x], b = A.cs[r]; const int n = (int)(A.cs[r + 1] - b);
     const uint32_t o = A.readOff[r]; const int qlen = (int)(A.readOff[r + 1] - o);
-    int *const sStack = (int *)sOqc, *const sPool = sStack + YQ_STACK_LDS; unsigned char *const sMain = (unsigned char *)(sPool + poolInts);
+    int *const sStack = (int *)sOqc; unsigned char *const sMain = (unsigned char *)(sStack + YQ_STACK_LDS);
     const unsigned mainBytes = ldsBytes - (unsigned)(sMain - sOqc);
     yoqc::Scratch S;
     S.stack = sStack; S.stackCap = YQ_STACK_LDS; S.stack2 = A.stack + 4ull * b + 8ull * r;
-    S.pool = sPool; S.poolCap = poolInts; S.pool2 = A.pool + A.poolOff[r];
+    S.pool = A.pool + A.poolOff[r]; S.poolCap = 0; S.pool2 = S.pool;            // (the LDS pool is set up once the nodes are placed)
     S.prim = A.prim + b; S.pa = A.pa + b; S.push = A.push + b;
     const bool keysInLds = 16u * (unsigned)n <= mainBytes;
     S.keys = keysInLds ? (yoqc::SortKey *)sMain : A.keys + b;
@@ -102,7 +103,10 @@ __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list
         __syncthreads();
         X.S.keys = A.keys + b;
     }
-    if (nodesInLds) { X.S.nodes = (yoqc::CNode *)sMain; X.S.tbl = (int *)(sMain + 40u * (unsigned)cnt); X.S.path = X.S.tbl + cnt; }
+    if (nodesInLds) {
+        X.S.nodes = (yoqc::CNode *)sMain; X.S.tbl = (int *)(sMain + 40u * (unsigned)cnt); X.S.path = X.S.tbl + cnt;
+        if (keysInLds) { X.S.pool = X.S.path + cnt; X.S.poolCap = (int)((mainBytes - 48u * (unsigned)cnt) / 4u); }      // the rest of the keys' place: tables
+    }
     for (int p = lane; p < cnt; p += 64) X.makeNode(p, A.G, qlen, -1);
     __syncthreads();
     if (lane == 0) for (int p = 0; p < cnt; p++) X.assignTable(p);          // bump allocation: sequential, a few instructions a node

@@ -970,7 +970,7 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     uint32_t *lists = ctx->oqLists.as<uint32_t>();
     KL(k_oqc_classify, dim3(gridFor(n + 1, 256)), dim3(256), 0, ctx->stream, A, ctx->oqNeed.as<unsigned long long>(), lists, ctx->oqClsCnt.as<unsigned int>());
     int rc = cubScan64(ctx, ctx->oqNeed.as<unsigned long long>(), ctx->oqPoolOff.as<unsigned long long>(), n + 1); if (rc) return rc;
-    unsigned long long poolInts = 0; uint32_t nCls[YQ_NCLASS] = {0, 0, 0, 0};
+    unsigned long long poolInts = 0; uint32_t nCls[YQ_NCLASS] = {0, 0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(&poolInts, ctx->oqPoolOff.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
     rc = fetchU32(ctx, ctx->oqClsCnt.p, nCls, YQ_NCLASS); if (rc) return rc;
     ENSURE(ctx->oqPool, 4ull * (poolInts + 16)); A.pool = ctx->oqPool.as<int>();
@@ -978,15 +978,15 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     ENSURE(ctx->oqKeys, sizeof(yoqc::SortKey) * (uint64_t)C); ENSURE(ctx->oqStack, 4ull * (4ull * C + 8ull * n + 16)); ENSURE(ctx->oqNodes, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(ctx->oqPfx, 4ull * C); ENSURE(ctx->oqPath, 4ull * C);
     A.keys = ctx->oqKeys.as<yoqc::SortKey>(); A.stack = ctx->oqStack.as<int>(); A.nodes = ctx->oqNodes.as<yoqc::CNode>(); A.pfxOff = ctx->oqPfx.as<int>(); A.path = ctx->oqPath.as<int>();
     // the classes: clumps a read may have -> LDS of its workgroup; ints of LDS pool (the first tables; later ones go to the read's slice of the HBM pool)
-    static const int capN[YQ_NCLASS] = {112, 448, 1000, 0}, poolLds[YQ_NCLASS] = {768, 1536, 0, 0};
+    static const int capN[YQ_NCLASS] = {112, 224, 448, 1000, 0};
     // (the stream is idle here: fetchU32 waited for it.)  The classes run side by side: the few reads of the heavy classes take milliseconds each -- a kernel lasts as
     // long as its slowest read -- and leave nearly all of the device to the thousands of light ones, which go out on the second stream.
     for (int c = YQ_NCLASS - 1; c >= 0; c--) if (nCls[c]) {
-        const unsigned lds = c == YQ_NCLASS - 1 ? YQ_LDS_MAX : std::min(YQ_LDS_MAX, oqcLdsBytes(capN[c], poolLds[c]));
-        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, c < 2 ? ctx->stream2 : ctx->stream, A, lists + (size_t)c * n, nCls[c], lds, poolLds[c]);
+        const unsigned lds = c == YQ_NCLASS - 1 ? YQ_LDS_MAX : std::min(YQ_LDS_MAX, oqcLdsBytes(capN[c]));
+        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, (c & 1) ? ctx->stream2 : ctx->stream, A, lists + (size_t)c * n, nCls[c], lds);
     }
     HIPCHK(hipEventRecord(ctx->evTail, ctx->stream2)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0));
-    if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 448 / 1000 clumps: %u / %u / %u, more %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3], nCls[0], nCls[1], nCls[2], nCls[3], poolInts * 4.0 / 1e6);
+    if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 224 / 448 / 1000 clumps: %u / %u / %u / %u, more %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3] + nCls[4], nCls[0], nCls[1], nCls[2], nCls[3], nCls[4], poolInts * 4.0 / 1e6);
     rc = cubScan(ctx, ctx->oqOutCnt.as<uint32_t>(), ctx->oqOutStart.as<uint32_t>(), n + 1); if (rc) return rc;
     rc = cubScan(ctx, ctx->oqOutOps.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), n + 1); if (rc) return rc;
     uint32_t tot[2] = {0, 0};
