@@ -24,9 +24,10 @@ struct OqcArgs {
 // Reads come in classes by their number of clumps (the LDS a workgroup gets is fixed at launch): keys + sort stack, then nodes + table index + path share it.
 #define YQ_NCLASS 5
 #define YQ_STACK_LDS 256              // ints of the sort's stack kept in LDS (depth ~2 log2 n ranges); deeper recursion continues in HBM
+#define YQ_THR_LDS 64                 // break point thresholds copied to LDS (every lane searches them for every successor it relaxes); a longer table stays in HBM
 #define YQ_LDS_MAX 65536u
 __device__ __constant__ const int kOqcCapN[YQ_NCLASS] = {112, 224, 448, 1000, 0x7fffffff};      // clumps a read of the class may have (the last class: keys in LDS while 16 n fits, the rest in HBM)
-__host__ __device__ inline unsigned oqcLdsBytes(int capN) { return 64u * (unsigned)capN + 4u * YQ_STACK_LDS + 64u; }
+__host__ __device__ inline unsigned oqcLdsBytes(int capN) { return 64u * (unsigned)capN + 4u * (YQ_STACK_LDS + YQ_THR_LDS) + 64u; }
 // classes of the reads with two or more clumps (lists[c * nReads ...], cnt[c]); reads with one clump are settled here (GraphPath.cpp:907-916); ints of running-sum
 // tables a read may need in HBM: two per op and clump of the read (every clump's table built)
 __global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *lists, unsigned int *cnt)
@@ -64,7 +65,9 @@ __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list
     const int lane = (int)threadIdx.x;
     const uint32_t r = list[blockIdx.x], b = A.cs[r]; const int n = (int)(A.cs[r + 1] - b);
     const uint32_t o = A.readOff[r]; const int qlen = (int)(A.readOff[r + 1] - o);
-    int *const sStack = (int *)sOqc; unsigned char *const sMain = (unsigned char *)(sStack + YQ_STACK_LDS);
+    int *const sStack = (int *)sOqc; uint32_t *const sThr = (uint32_t *)(sStack + YQ_STACK_LDS); unsigned char *const sMain = (unsigned char *)(sThr + YQ_THR_LDS);
+    yoqc::Params P = A.P;
+    if (P.bppN <= YQ_THR_LDS) { if (lane < P.bppN) sThr[lane] = A.P.bppThr[lane]; P.bppThr = sThr; }
     const unsigned mainBytes = ldsBytes - (unsigned)(sMain - sOqc);
     yoqc::Scratch S;
     S.stack = sStack; S.stackCap = YQ_STACK_LDS; S.stack2 = A.stack + 4ull * b + 8ull * r;
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list
     const bool keysInLds = 16u * (unsigned)n <= mainBytes;
     S.keys = keysInLds ? (yoqc::SortKey *)sMain : A.keys + b;
     S.nodes = A.nodes + b; S.tbl = A.pfxOff + b; S.path = A.path + b;             // set for good once the number of survivors is known
-    yoqc::Run X{A.P, A.cl + b, A.ops, S, 0, 0};
+    yoqc::Run X{P, A.cl + b, A.ops, S, 0, 0};
     for (int i = lane; i < n; i += 64) X.makeKey(i, qlen);
     __syncthreads();
     if (lane == 0) X.sortKeys(n, A.fwd + o, qlen);
@@ -121,7 +124,7 @@ __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list
         const int leftSQO = X.S.nodes[i].SQO; int first = -1;
         for (int base = startj; base < cnt; base += 64) {
             const int j = base + lane;
-            const bool far = j < cnt && ((int)X.S.nodes[j].SQO - leftSQO) >= A.P.minNonOverlap;
+            const bool far = j < cnt && ((int)X.S.nodes[j].SQO - leftSQO) >= P.minNonOverlap;
             if (far) X.relax(i, j);
             const unsigned long long fm = __ballot(far);
             if (first < 0 && fm) first = base + __builtin_ctzll(fm);

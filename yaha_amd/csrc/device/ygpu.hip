@@ -983,7 +983,7 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     // long as its slowest read -- and leave nearly all of the device to the thousands of light ones, which go out on the second stream.
     for (int c = YQ_NCLASS - 1; c >= 0; c--) if (nCls[c]) {
         const unsigned lds = c == YQ_NCLASS - 1 ? YQ_LDS_MAX : std::min(YQ_LDS_MAX, oqcLdsBytes(capN[c]));
-        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, (c & 1) ? ctx->stream2 : ctx->stream, A, lists + (size_t)c * n, nCls[c], lds);
+        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, c >= 3 ? ctx->stream2 : ctx->stream, A, lists + (size_t)c * n, nCls[c], lds);
     }
     HIPCHK(hipEventRecord(ctx->evTail, ctx->stream2)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0));
     if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 224 / 448 / 1000 clumps: %u / %u / %u / %u, more %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3] + nCls[4], nCls[0], nCls[1], nCls[2], nCls[3], nCls[4], poolInts * 4.0 / 1e6);

@@ -274,7 +274,11 @@ struct Run {
             uint32_t distance;
             if (ln.SRO > rn.ERO) distance = ln.SRO - rn.ERO; else if (rn.SRO > ln.ERO) distance = rn.SRO - ln.ERO; else distance = 0;
             if (distance <= 10) BPP = P.BPCost;
-            else if (P.bppN >= 0) { int k = 0; while (k < P.bppN && P.bppThr[k] <= distance) k++; BPP = P.bppVmin + k; }
+            else if (P.bppN >= 0) {                                    // number of thresholds <= distance (ascending): upper bound by bisection
+                int lo = 0, hi = P.bppN;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.bppThr[mid] <= distance) lo = mid + 1; else hi = mid; }
+                BPP = P.bppVmin + lo;
+            }
             else BPP = exactBPP(distance, P.BPCost, P.maxBPLog);
         } else BPP = P.maxBPLog * P.BPCost;
         newScore = (int16_t)(newScore - BPP);
