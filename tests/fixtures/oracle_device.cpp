@@ -72,7 +72,7 @@ int ygpu_postfilter(ygpu_ctx *c)
     for (uint32_t r = 0; r < R.n_reads; r++) {
         const uint32_t b = R.clump_start[r], n = R.clump_start[r + 1] - b;
         if (n) {
-            size_t pool = 0; for (uint32_t i = 0; i < n; i++) pool += 2 * ((size_t)R.clumps[b + i].n_ops + 1);
+            size_t pool = 0; for (uint32_t i = 0; i < n; i++) pool += 2 * (size_t)R.clumps[b + i].n_ops + 3;
             std::vector<yoqc::SortKey> keys(n); std::vector<int> stack(4 * (size_t)n + 8), pfx(n), path(n), pl(pool + 1); std::vector<yoqc::CNode> nodes(n), prim(n); std::vector<yoqc::PAttr> pa(n); std::vector<yoqc::OutRec> push(n), out(n);
             yoqc::Scratch S{keys.data(), stack.data(), 0x7fffffff, nullptr, nodes.data(), pfx.data(), path.data(), pl.data(), 0x7fffffff, nullptr, prim.data(), pa.data(), push.data()};
             int pc = 0; const int qlen = (int)(c->offs[r + 1] - c->offs[r]);

@@ -29,14 +29,14 @@ struct OqcArgs {
 __device__ __constant__ const int kOqcCapN[YQ_NCLASS] = {112, 224, 448, 1000, 0x7fffffff};      // clumps a read of the class may have (the last class: keys in LDS while 16 n fits, the rest in HBM)
 __host__ __device__ inline unsigned oqcLdsBytes(int capN) { return 64u * (unsigned)capN + 4u * (YQ_STACK_LDS + YQ_THR_LDS) + 64u; }
 // classes of the reads with two or more clumps (lists[c * nReads ...], cnt[c]); reads with one clump are settled here (GraphPath.cpp:907-916); ints of running-sum
-// tables a read may need in HBM: two per op and clump of the read (every clump's table built)
+// tables a read may need in HBM: 2 n_ops + 3 per clump of the read (every clump's table built)
 __global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *lists, unsigned int *cnt)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63);
     unsigned long long v = 0; int cls = -1;
     if (r < A.nReads) {
         const uint32_t b = A.cs[r], n = A.cs[r + 1] - b;
-        if (n >= 2) { for (uint32_t c = b; c < b + n; c++) v += 2ull * ((unsigned long long)A.cl[c].n_ops + 1ull); cls = 0; while (n > (uint32_t)kOqcCapN[cls]) cls++; }
+        if (n >= 2) { for (uint32_t c = b; c < b + n; c++) v += 2ull * (unsigned long long)A.cl[c].n_ops + 3ull; cls = 0; while (n > (uint32_t)kOqcCapN[cls]) cls++; }
         else {
             uint32_t m = 0, nops = 0; int pc = 0;
             if (n == 1) { m = (uint32_t)yoqc::single(A.cl + b, A.out + b, &pc); nops = A.cl[b].n_ops; }

@@ -77,7 +77,7 @@ void postFilter(const Args &a, const Genome &g, const Read &r, const ygpu_clump 
     yoqc::Seqs Sq{tlSeqStart.data(), tlSeqLen.data(), (uint32_t)tlSeqStart.size()};
     static thread_local std::vector<yoqc::SortKey> tlKeys; static thread_local std::vector<int> tlStack, tlPfx, tlPath, tlPool; static thread_local std::vector<yoqc::CNode> tlNodes, tlPrim;
     static thread_local std::vector<yoqc::PAttr> tlPA; static thread_local std::vector<yoqc::OutRec> tlPush, tlOut;      // scratch reused from read to read
-    size_t poolInts = 0; for (uint32_t i = 0; i < n; i++) poolInts += 2 * ((size_t)cl[i].n_ops + 1);
+    size_t poolInts = 0; for (uint32_t i = 0; i < n; i++) poolInts += 2 * (size_t)cl[i].n_ops + 3;
     if (tlKeys.size() < n) { tlKeys.resize(n); tlStack.resize(4 * (size_t)n + 8); tlPfx.resize(n); tlPath.resize(n); tlNodes.resize(n); tlPrim.resize(n); tlPA.resize(n); tlPush.resize(n); tlOut.resize(n); }
     if (tlPool.size() < poolInts) tlPool.resize(poolInts);
     yoqc::Scratch S{tlKeys.data(), tlStack.data(), 0x7fffffff, nullptr, tlNodes.data(), tlPfx.data(), tlPath.data(), tlPool.data(), 0x7fffffff, nullptr, tlPrim.data(), tlPA.data(), tlPush.data()};

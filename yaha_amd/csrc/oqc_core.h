@@ -41,7 +41,7 @@ struct PAttr { int alignedQueryLength, numOutputSecondaries; int16_t secondScore
 struct OutRec { int clump; uint8_t status, mapQuality; uint16_t numSecondaries, matchedPrimary, pad; };   // one clump as it reaches printClump, in print order
 // Per-read work space (n = clumps of the read, cnt <= n = nodes that survive the duplicate removal):
 //   keys n; the sort's stack: stackCap ints in `stack`, what goes beyond in `stack2` (4n + 8 ints hold any recursion); nodes, tbl, path: cnt each;
-//   running-sum tables: `pool` while they fit its poolCap ints, `pool2` after that (2 * (sum over the read's clumps of n_ops + 1) ints hold every table);
+//   running-sum tables: `pool` while they fit its poolCap ints, `pool2` after that (the sum over the read's clumps of 2 n_ops + 3 ints holds every table);
 //   prim, pa, push: n each (touched once at the end).
 // The device keeps keys, stack, nodes, tbl, path and a small pool in LDS (device/oqc_stage.h); the host has one of everything.
 struct Scratch { SortKey *keys; int *stack; int stackCap; int *stack2; CNode *nodes; int *tbl; int *path; int *pool; int poolCap; int *pool2; CNode *prim; PAttr *pa; OutRec *push; };
@@ -180,44 +180,46 @@ struct Run {
     // node that is asked about gets (once) the running sums Q[m], S[m] = query bases and score after its first m ops, untruncated; a call is then a binary search
     // for the op the walk stops in plus that op's truncated share.  The walk from the other end reads the same table backwards (Qb[m] = Q[n] - Q[n-m]).  Same
     // arithmetic, same results: only the order of the integer additions differs.
+    // table of a node with n ops: [n | Q[0..n] | S[0..n]], 2n + 3 ints; Q[m] = query bases after the first m ops in its low 24 bits and the code of op m-1 in its
+    // high 8 (a call then needs nothing but the table: on the device the clump record and the op list are HBM round trips, the table sits in LDS)
+    YQ_FN static int tableInts(int nOps) { return 2 * nOps + 3; }
     YQ_FN void assignTable(int p)                                       // a place for node p's table (sequential: the pools are bump allocators)
     {
-        const int need = 2 * ((int)cl[S.nodes[p].clump].n_ops + 1);
+        const int need = tableInts((int)cl[S.nodes[p].clump].n_ops);
         if (poolUsed + need <= S.poolCap) { S.tbl[p] = poolUsed; poolUsed += need; } else { S.tbl[p] = -2 - pool2Used; pool2Used += need; }
     }
     YQ_FN int *tablePtr(int p) const { const int off = S.tbl[p]; return off >= 0 ? S.pool + off : S.pool2 + (-2 - off); }
     YQ_FN void fillTable(int p)
     {
         const int c = S.nodes[p].clump; const uint32_t *o = ops + cl[c].op_start; const int n = (int)cl[c].n_ops;
-        int *Q = tablePtr(p), *Sc = Q + n + 1; int q = 0, sc = 0; Q[0] = 0; Sc[0] = 0;
+        int *T = tablePtr(p), *Q = T + 1, *Sc = Q + n + 1; int q = 0, sc = 0; T[0] = n; Q[0] = 0; Sc[0] = 0;
         for (int k = 0; k < n; k++) {
             const char op = YGPU_OP_CODE(o[k]); const int len = (int)YGPU_OP_LEN(o[k]);
             if (op == 'D') sc -= (P.GOCost + P.GECost * len); else { q += len; sc += opScore(op, len); }
-            Q[k + 1] = q; Sc[k + 1] = sc;
+            Q[k + 1] = q | ((int)(unsigned char)op << 24); Sc[k + 1] = sc;
         }
     }
     YQ_FN const int *table(int p) { if (S.tbl[p] == -1) { assignTable(p); fillTable(p); } return tablePtr(p); }
     YQ_FN int scoreForLength(int p, int length, bool forward)           // node p's edit list
     {
         if (length <= 0) return 0;
-        const int c = S.nodes[p].clump, n = (int)cl[c].n_ops; if (n <= 0) return 0;
-        const uint32_t *o = ops + cl[c].op_start;
-        const int *Q = table(p), *Sc = Q + n + 1;
-        if (Q[n] < length) return Sc[n];                                 // the list ends first: every op counted in full
+        const int *T = table(p); const int n = T[0]; if (n <= 0) return 0;
+        const int *Q = T + 1, *Sc = Q + n + 1; const int M = 0xFFFFFF;
+        if ((Q[n] & M) < length) return Sc[n];                           // the list ends first: every op counted in full
         // (host, measured: forcing these searches branch-free -- an AND with the comparison's mask -- made a call slower, 14.9 -> 18.2 us a read: the walks of one
         // read stop in similar places, the branches predict; the reference's own loop for the first four ops before any table is touched: 14.9 -> 16.7 -- the
         // overlaps that reach this function are long)
         if (forward) {
             const int *base = Q + 1; int len = n;                        // first m in 1..n with Q[m] >= length (exists: Q[n] >= length); op m-1 is the one the walk stops in
-            while (len > 1) { const int half = len >> 1; base = (base[half - 1] < length) ? base + half : base; len -= half; }
+            while (len > 1) { const int half = len >> 1; base = ((base[half - 1] & M) < length) ? base + half : base; len -= half; }
             const int j = (int)(base - Q) - 1;
-            return Sc[j] + opScore(YGPU_OP_CODE(o[j]), length - Q[j]);
+            return Sc[j] + opScore((char)((unsigned)Q[j + 1] >> 24), length - (Q[j] & M));
         }
-        const int X = Q[n] - length;                                     // last t in 0..n-1 with Q[t] <= X (Q[0] = 0 <= X < Q[n]); op t is the one the backward walk stops in
+        const int X = (Q[n] & M) - length;                               // last t in 0..n-1 with Q[t] <= X (Q[0] = 0 <= X < Q[n]); op t is the one the backward walk stops in
         const int *base = Q; int len = n;
-        while (len > 1) { const int half = len >> 1; base = (base[half] <= X) ? base + half : base; len -= half; }
+        while (len > 1) { const int half = len >> 1; base = ((base[half] & M) <= X) ? base + half : base; len -= half; }
         const int t = (int)(base - Q);
-        return (Sc[n] - Sc[t + 1]) + opScore(YGPU_OP_CODE(o[t]), length - (Q[n] - Q[t + 1]));
+        return (Sc[n] - Sc[t + 1]) + opScore((char)((unsigned)Q[t + 1] >> 24), length - ((Q[n] & M) - (Q[t + 1] & M)));
     }
     YQ_FN int accurateOverlapScore(int left, int right, int overlap, bool *rightBest)   // :744-800
     {
