@@ -141,7 +141,9 @@ void  ygpu_host_free(void *p);
  * similarity, mapping quality) and prints what is left -- for a 1 kbp read one or two of the ~75 clumps the hot path returns.  ygpu_postfilter runs that step
  * for the whole batch on the device (same routine as the host's, yaha_amd/csrc/oqc_core.h) and ygpu_collect_filtered returns, per read and in PRINT order,
  * only the clumps printClumps would see (QS->clumps after the filter) with the fields the filter sets (Math.h Clump_t: status, mapQuality, numSecondaries,
- * matchedPrimary; QS->primaryCount), and only their edit ops.  Bit-identical to filtering ygpu_collect's output on the host; -OQC N runs keep the host filter. */
+ * matchedPrimary; QS->primaryCount), and only their edit ops.  Bit-identical to filtering ygpu_collect's output on the host; -OQC N runs keep the host filter.
+ * A read with more clumps than the device stage takes (448: the filter's sort is sequential, and a kernel lasts as long as its slowest read) comes back
+ * UNFILTERED -- all its clumps in ygpu_collect's order, primaryCount == 0xFFFF in each -- for the caller to filter (yaha_session_emit_filtered does). */
 typedef struct ygpu_postfilter_params {
     int32_t  minNonOverlap, BPCost, maxBPLog, FBS;     /* AlignArgs: OQCMinNonOverlap, BPCost, maxBPLog, FBS (0/1) */
     float    FBS_PSLength, FBS_PSScore;

@@ -71,7 +71,13 @@ int ygpu_postfilter(ygpu_ctx *c)
     yoqc::Seqs G{c->ss.data(), c->sl.data(), (uint32_t)c->ss.size()};
     for (uint32_t r = 0; r < R.n_reads; r++) {
         const uint32_t b = R.clump_start[r], n = R.clump_start[r + 1] - b;
-        if (n) {
+        const char *rawAbove = getenv("YTEST_RAW_ABOVE");               // reads with more clumps than this come back unfiltered and marked, as from the device stage
+        if (n && rawAbove && n > (uint32_t)atoi(rawAbove)) {
+            for (uint32_t k = 0; k < n; k++) {
+                ygpu_out_clump f; f.c = R.clumps[b + k]; const uint32_t *src = R.ops + f.c.op_start; f.c.op_start = (uint32_t)c->fops.size(); c->fops.insert(c->fops.end(), src, src + f.c.n_ops);
+                f.status = f.c.status; f.mapQuality = 255; f.numSecondaries = 0; f.matchedPrimary = 0; f.primaryCount = 0xFFFF; c->fcl.push_back(f);
+            }
+        } else if (n) {
             size_t pool = 0; for (uint32_t i = 0; i < n; i++) pool += 2 * (size_t)R.clumps[b + i].n_ops + 3;
             std::vector<yoqc::SortKey> keys(n); std::vector<int> stack(4 * (size_t)n + 8), pfx(n), path(n), pl(pool + 1); std::vector<yoqc::CNode> nodes(n), prim(n); std::vector<yoqc::PAttr> pa(n); std::vector<yoqc::OutRec> push(n), out(n);
             yoqc::Scratch S{keys.data(), stack.data(), 0x7fffffff, nullptr, nodes.data(), pfx.data(), path.data(), pl.data(), 0x7fffffff, nullptr, prim.data(), pa.data(), push.data()};

@@ -119,7 +119,9 @@ def test_lane_pipeline_parameter_corners(work, index11, reads, extra, tmp_path):
     ("r1k.fa", []), ("rchim.fa", []), ("rchim.fa", ["-FBS", "Y"]), ("rchim.fa", ["-FBS", "Y", "-PRL", "0.5", "-PSS", "0.5"]), ("rchim.fa", ["-BP", "0"]), ("rchim.fa", ["-BP", "17", "-MGDP", "9"]),
     ("rchim.fa", ["-MGDP", "1", "-MNO", "3"]), ("rchim.fa", ["-MNO", "200", "-FBS", "Y", "-PSS", "0.2", "-PRL", "0.1"]), ("r10k.fa", ["-FBS", "Y"]), ("rq.fq", ["-M", "15", "-P", "0.8", "-FBS", "Y", "-PSS", "0.3"]),
     ("rchim.fa", ["-GOC", "9", "-GEC", "3", "-RC", "1", "-FBS", "Y"]), ("r100.fa", ["-M", "15", "-FBS", "Y", "-PRL", "0.3", "-PSS", "0.3"])])
-def test_postfilter_on_the_device_equals_the_host_filter(work, index11, reads, extra):
+def test_postfilter_on_the_device_equals_the_host_filter(work, index11, reads, extra, monkeypatch):
+    if reads == "rchim.fa" and not extra:
+        monkeypatch.setenv("YGPU_OQC_MAX", "4")             # reads of more than four clumps take the hand-over path (unfiltered, marked, filtered by the host)
     with ya.Session(["-x", index11, "-q", os.path.join(work, reads), "-osh", "stdout"] + list(extra)) as s:
         with ya.Context(s.index, s.params) as ctx:
             ctx.set_postfilter(s)

@@ -85,7 +85,7 @@ struct ygpu_ctx {
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
     bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // post-filter stage (oqc_stage.h)
-    DevBuf oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
+    DevBuf oqProf, oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
     bool oqSet = false, oqDone = false; yoqc::Params oqP{}; yoqc::Seqs oqG{}; uint32_t nFOut = 0, nFOps = 0;
     // stage state
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
@@ -829,7 +829,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
                          &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
-                         &ctx->oqLists, &ctx->oqClsCnt, &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
+                         &ctx->oqProf, &ctx->oqLists, &ctx->oqClsCnt, &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
@@ -966,11 +966,14 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     OqcArgs A; A.P = ctx->oqP; A.G = ctx->oqG; A.cs = ctx->readStart.as<uint32_t>(); A.cl = ctx->outClumps2.as<ygpu_clump>(); A.ops = ctx->outOps.as<uint32_t>(); A.fwd = ctx->dFwd.as<uint8_t>(); A.readOff = ctx->dReadOff.as<uint32_t>(); A.nReads = n;
     A.poolOff = ctx->oqPoolOff.as<unsigned long long>(); A.prim = ctx->oqPrim.as<yoqc::CNode>(); A.pa = ctx->oqPA.as<yoqc::PAttr>(); A.push = ctx->oqPush.as<yoqc::OutRec>(); A.out = ctx->oqOut.as<yoqc::OutRec>();
     A.outCnt = ctx->oqOutCnt.as<uint32_t>(); A.outOpsCnt = ctx->oqOutOps.as<uint32_t>(); A.primCnt = ctx->oqPrimCnt.as<uint32_t>();
-    A.keys = nullptr; A.stack = nullptr; A.nodes = nullptr; A.pfxOff = nullptr; A.path = nullptr; A.pool = nullptr;
+    A.keys = nullptr; A.stack = nullptr; A.nodes = nullptr; A.pfxOff = nullptr; A.path = nullptr; A.pool = nullptr; A.prof = nullptr;
+    { const char *e = getenv("YGPU_OQC_MAX"); const int v = e ? atoi(e) : YQ_DEVICE_MAX; A.devMax = v >= 1 && v < YQ_DEVICE_MAX ? v : YQ_DEVICE_MAX; }     // (read at every call: tests lower it to send small reads down the hand-over path)
+    static const bool oqProf = getenv("YGPU_OQC_PROF") != nullptr;
+    if (oqProf) { ENSURE(ctx->oqProf, 8ull * 16 * YQ_NCLASS); HIPCHK(hipMemsetAsync(ctx->oqProf.p, 0, 8ull * 16 * YQ_NCLASS, ctx->stream)); A.prof = ctx->oqProf.as<unsigned long long>(); }
     uint32_t *lists = ctx->oqLists.as<uint32_t>();
     KL(k_oqc_classify, dim3(gridFor(n + 1, 256)), dim3(256), 0, ctx->stream, A, ctx->oqNeed.as<unsigned long long>(), lists, ctx->oqClsCnt.as<unsigned int>());
     int rc = cubScan64(ctx, ctx->oqNeed.as<unsigned long long>(), ctx->oqPoolOff.as<unsigned long long>(), n + 1); if (rc) return rc;
-    unsigned long long poolInts = 0; uint32_t nCls[YQ_NCLASS] = {0, 0, 0, 0, 0};
+    unsigned long long poolInts = 0; uint32_t nCls[YQ_NCLASS] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(&poolInts, ctx->oqPoolOff.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
     rc = fetchU32(ctx, ctx->oqClsCnt.p, nCls, YQ_NCLASS); if (rc) return rc;
     ENSURE(ctx->oqPool, 4ull * (poolInts + 16)); A.pool = ctx->oqPool.as<int>();
@@ -978,15 +981,16 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     ENSURE(ctx->oqKeys, sizeof(yoqc::SortKey) * (uint64_t)C); ENSURE(ctx->oqStack, 4ull * (4ull * C + 8ull * n + 16)); ENSURE(ctx->oqNodes, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(ctx->oqPfx, 4ull * C); ENSURE(ctx->oqPath, 4ull * C);
     A.keys = ctx->oqKeys.as<yoqc::SortKey>(); A.stack = ctx->oqStack.as<int>(); A.nodes = ctx->oqNodes.as<yoqc::CNode>(); A.pfxOff = ctx->oqPfx.as<int>(); A.path = ctx->oqPath.as<int>();
     // the classes: clumps a read may have -> LDS of its workgroup; ints of LDS pool (the first tables; later ones go to the read's slice of the HBM pool)
-    static const int capN[YQ_NCLASS] = {112, 224, 448, 1000, 0};
+    static const int capN[YQ_NCLASS] = {112, 224, YQ_DEVICE_MAX, 0};
     // (the stream is idle here: fetchU32 waited for it.)  The classes run side by side: the few reads of the heavy classes take milliseconds each -- a kernel lasts as
     // long as its slowest read -- and leave nearly all of the device to the thousands of light ones, which go out on the second stream.
-    for (int c = YQ_NCLASS - 1; c >= 0; c--) if (nCls[c]) {
-        const unsigned lds = c == YQ_NCLASS - 1 ? YQ_LDS_MAX : std::min(YQ_LDS_MAX, oqcLdsBytes(capN[c]));
-        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, c >= 3 ? ctx->stream2 : ctx->stream, A, lists + (size_t)c * n, nCls[c], lds);
+    if (nCls[YQ_NCLASS - 1]) KL(k_oqc_raw, dim3(gridFor(nCls[YQ_NCLASS - 1], 64)), dim3(64), 0, ctx->stream, A, lists + (size_t)(YQ_NCLASS - 1) * n, nCls[YQ_NCLASS - 1]);      // left to the host, marked
+    for (int c = YQ_NCLASS - 2; c >= 0; c--) if (nCls[c]) {
+        const unsigned lds = std::min(YQ_LDS_MAX, oqcLdsBytes(capN[c]));
+        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, c == YQ_NCLASS - 2 ? ctx->stream2 : ctx->stream, A, lists + (size_t)c * n, nCls[c], lds);
     }
     HIPCHK(hipEventRecord(ctx->evTail, ctx->stream2)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0));
-    if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 224 / 448 / 1000 clumps: %u / %u / %u / %u, more %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3] + nCls[4], nCls[0], nCls[1], nCls[2], nCls[3], nCls[4], poolInts * 4.0 / 1e6);
+    if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 224 / 448 clumps: %u / %u / %u, left to the host %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3], nCls[0], nCls[1], nCls[2], nCls[3], poolInts * 4.0 / 1e6);
     rc = cubScan(ctx, ctx->oqOutCnt.as<uint32_t>(), ctx->oqOutStart.as<uint32_t>(), n + 1); if (rc) return rc;
     rc = cubScan(ctx, ctx->oqOutOps.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), n + 1); if (rc) return rc;
     uint32_t tot[2] = {0, 0};
@@ -995,6 +999,15 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     ctx->nFOut = tot[0]; ctx->nFOps = tot[1];
     ENSURE(ctx->oqFClumps, sizeof(ygpu_out_clump) * ((uint64_t)tot[0] + 1)); ENSURE(ctx->oqFOps, 4ull * ((uint64_t)tot[1] + 1));
     KL(k_oqc_gather, dim3(gridFor(n, 64)), dim3(64), 0, ctx->stream, A, ctx->oqOutStart.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), ctx->oqFClumps.as<ygpu_out_clump>(), ctx->oqFOps.as<uint32_t>());
+    if (oqProf) {
+        unsigned long long h[16 * YQ_NCLASS]; HIPCHK(hipMemcpyAsync(h, ctx->oqProf.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+        static const char *nm[7] = {"keys", "sort", "dup scan", "nodes+tables", "path walk", "successors", "finish"};
+        for (int c = 0; c < YQ_NCLASS; c++) if (h[16 * c + 7]) {
+            const unsigned long long *q = h + 16 * c; fprintf(stderr, "[ygpu] post-filter class %d: %llu reads, %.0f clumps, %.0f survivors a read; us a read:", c, q[7], (double)q[8] / q[7], (double)q[9] / q[7]);
+            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f", nm[k], q[k] / 100.0 / q[7]);
+            fprintf(stderr, "; slowest read %.0f us\n", q[10] / 100.0);
+        }
+    }
     ctx->oqDone = true;
     return 0;
 }

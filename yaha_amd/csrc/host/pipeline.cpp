@@ -133,12 +133,23 @@ static void formatRange(const yaha_session *s, const ygpu_result_batch *r, uint3
 static void formatFiltered(const yaha_session *s, const ygpu_filtered_batch *r, Text &text)
 {
     const Args &a = s->args; text.clear();
-    for (uint32_t i = 0; i < r->n_reads; i++)
-        for (uint32_t k = r->clump_start[i]; k < r->clump_start[i + 1]; k++) {
-            const ygpu_out_clump &f = r->clumps[k];
-            OutClump oc; oc.c = f.c; oc.ops = r->ops + f.c.op_start; oc.status = f.status; oc.mapQuality = f.mapQuality; oc.numSecondaries = f.numSecondaries; oc.matchedPrimary = f.matchedPrimary;
-            printClump(a, s->genome, s->reads[i], oc, (int)f.primaryCount, text);
+    std::vector<ygpu_clump> raw; std::vector<OutClump> oc;
+    for (uint32_t i = 0; i < r->n_reads; i++) {
+        const uint32_t k0 = r->clump_start[i], k1 = r->clump_start[i + 1];
+        if (k1 > k0 && r->clumps[k0].primaryCount == 0xFFFFu) {
+            // a read the device left unfiltered (more clumps than its stage takes, device/oqc_stage.h): all its clumps in the hot path's order -- the host's filter, same routine
+            raw.resize(k1 - k0); for (uint32_t k = k0; k < k1; k++) raw[k - k0] = r->clumps[k].c;
+            int primaryCount = 0;
+            postFilter(a, s->genome, s->reads[i], raw.data(), k1 - k0, r->ops, oc, primaryCount);
+            for (auto &o : oc) printClump(a, s->genome, s->reads[i], o, primaryCount, text);
+            continue;
         }
+        for (uint32_t k = k0; k < k1; k++) {
+            const ygpu_out_clump &f = r->clumps[k];
+            OutClump o; o.c = f.c; o.ops = r->ops + f.c.op_start; o.status = f.status; o.mapQuality = f.mapQuality; o.numSecondaries = f.numSecondaries; o.matchedPrimary = f.matchedPrimary;
+            printClump(a, s->genome, s->reads[i], o, (int)f.primaryCount, text);
+        }
+    }
 }
 static void formatBatch(yaha_session *s, const ygpu_result_batch *r, Text &text, int nt)
 {

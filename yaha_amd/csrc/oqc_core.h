@@ -17,6 +17,7 @@
 #else
 #define YQ_FN inline
 #endif
+#define YQ_INLINE __attribute__((always_inline))
 
 namespace yoqc {
 
@@ -54,15 +55,14 @@ YQ_FN uint32_t randBits(Rand &r)
     r.s[4] = (r.s[4] ^ (r.s[4] << 6)) ^ (t ^ (t << 13));
     return (r.s[1] + r.s[1] + 1) * r.s[4];
 }
-YQ_FN void seedFromCodes(const uint8_t *codes, int n, Rand &rs)        // generateRandomSeed, QueryState.c:172-187
+// generateRandomSeed, QueryState.c:172-187: word i of the seed = the two low bits of codes 16 i .. 16 i + 15, the index wrapping around the read
+YQ_FN uint32_t seedWord(const uint8_t *codes, int n, int i)
 {
-    int q = 0;
-    for (int i = 0; i < 5; i++) {
-        uint32_t w = 0;
-        for (int j = 0; j < 16; j++) { w = (w << 2) | (codes[q] & 0x3); q++; if (q >= n) q = 0; }
-        rs.s[i] = w;
-    }
+    uint32_t w = 0; int q = (16 * i) % n;
+    for (int j = 0; j < 16; j++) { w = (w << 2) | (codes[q] & 0x3); q++; if (q >= n) q = 0; }
+    return w;
 }
+YQ_FN void seedFromCodes(const uint8_t *codes, int n, Rand &rs) { for (int i = 0; i < 5; i++) rs.s[i] = seedWord(codes, n, i); }
 YQ_FN uint64_t compareKey(int SQO, int EQO, int score)                // getCompareKey :377-380
 { return ((((uint64_t)(uint16_t)SQO << 16) + (uint16_t)(-(int)(int16_t)(uint16_t)EQO)) << 16) + (uint16_t)(-(int)(int16_t)score); }
 YQ_FN int keyEQO(uint64_t k) { return (int)(uint16_t)(0u - (uint32_t)((k >> 16) & 0xffff)); }
@@ -95,25 +95,26 @@ struct Run {
         const ygpu_clump &c = cl[i]; const bool rev = (c.status & stReversed) != 0;
         SortKey k; k.key = compareKey(rev ? (qlen - 1) - c.eqo : c.sqo, rev ? (qlen - 1) - c.sqo : c.eqo, (int)c.totScore); k.clump = i; k.pad = 0; S.keys[i] = k;
     }
-    YQ_FN int &stackAt(int k) { return k < S.stackCap ? S.stack[k] : S.stack2[k - S.stackCap]; }
     // The sort (myQuickSortHelper :427-453 on getCompareKey, ties broken by the per-read generator) decides which of two equal-keyed clumps comes first -- which
     // duplicate survives, which copy of a repeat becomes the primary -- so its comparisons must happen in the reference's order.  They depend on keys and positions
-    // only: the routine runs on (key, clump) pairs with the keys computed once; the reference's recursion (left part first) is an explicit stack of ranges.
-    YQ_FN void sortKeys(int n, const uint8_t *fwdCodes, int qlen)
+    // only: the routine runs on (key, clump) pairs with the keys computed once; the reference's recursion (left part first) is an explicit stack of ranges (its first
+    // stkCap ints in stk, what goes beyond in stk2).  Array and stack are parameters, and the function is always inlined: the device calls it once with pointers into
+    // LDS and once with pointers into HBM, and the compiler turns each copy's accesses into the instructions of that address space (through a pointer that may be
+    // either, every access is a "flat" one that waits for all memory traffic of the wave: 1 400 cycles a comparison, measured).
+    YQ_FN YQ_INLINE static void stPush(int *stk, int stkCap, int *stk2, int &sp, int v) { if (sp < stkCap) stk[sp] = v; else stk2[sp - stkCap] = v; sp++; }
+    YQ_FN YQ_INLINE static int stPop(int *stk, int stkCap, int *stk2, int &sp) { sp--; int v; if (sp < stkCap) v = stk[sp]; else v = stk2[sp - stkCap]; return v; }
+    YQ_FN YQ_INLINE static void sortRange(SortKey *arr, int n, int *stk, int stkCap, int *stk2, Rand rs)
     {
-        Rand rs; seedFromCodes(fwdCodes, qlen, rs);
-        SortKey *arr = S.keys;
-        int sp = 0; stackAt(sp++) = 0; stackAt(sp++) = n - 1;
+        int sp = 0; stPush(stk, stkCap, stk2, sp, 0); stPush(stk, stkCap, stk2, sp, n - 1);
         while (sp > 0) {
-            const int right = stackAt(--sp), left = stackAt(--sp);
+            const int right = stPop(stk, stkCap, stk2, sp), left = stPop(stk, stkCap, stk2, sp);
             if (left >= right) continue;
             const int pivot = (left + right) / 2;
             { const SortKey t = arr[pivot]; arr[pivot] = arr[right]; arr[right] = t; }
             int store = left;
             const uint64_t pk = arr[right].key;
-            // "if less: swap(arr[i], arr[store]), store++".  The element at `store` and the next element of the scan are kept in registers: on the device every
-            // access is a round trip of a hundred cycles and more, and the two loads an iteration would otherwise start with are most of the sort's time.  The
-            // next element is fetched one iteration ahead (an iteration writes positions i and store <= i only); the one at `store` changes only after a swap.
+            // "if less: swap(arr[i], arr[store]), store++".  The element at `store` and the next element of the scan are kept in registers: the next element is
+            // fetched one iteration ahead (an iteration writes positions i and store <= i only); the one at `store` changes only after a swap.
             SortKey y = arr[store], nx = arr[left];
             for (int i = left; i < right; i++) {
                 const SortKey x = nx;
@@ -128,10 +129,11 @@ struct Run {
             }
             { const SortKey t = arr[store]; arr[store] = arr[right]; arr[right] = t; }
             // the reference sorts [left, store-1] completely before it touches [store+1, right]: the right part goes on the stack first
-            stackAt(sp++) = store + 1; stackAt(sp++) = right;
-            stackAt(sp++) = left; stackAt(sp++) = store - 1;
+            stPush(stk, stkCap, stk2, sp, store + 1); stPush(stk, stkCap, stk2, sp, right);
+            stPush(stk, stkCap, stk2, sp, left); stPush(stk, stkCap, stk2, sp, store - 1);
         }
     }
+    YQ_FN void sortKeys(int n, const uint8_t *fwdCodes, int qlen) { Rand rs; seedFromCodes(fwdCodes, qlen, rs); sortRange(S.keys, n, S.stack, S.stackCap, S.stack2, rs); }
 
     // ---- deleteSubsumedDups :488-517, on the sorted keys --------------------------------------------------------------------------------------------------------
     // All the scan reads of a node -- SQO, EQO, score -- is in the key (SQO<<32 | (-EQO & 0xffff)<<16 | -score & 0xffff); only two nodes of equal SQO and EQO are
