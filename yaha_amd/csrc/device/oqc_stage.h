@@ -182,18 +182,28 @@ __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list
         }
     }
 }
-// the printed clumps of read r, in print order, with their ops copied behind one another: out clump k of the read = fClumps[outStart[r] + k]
-__global__ void k_oqc_gather(OqcArgs A, const uint32_t *outStart, const uint32_t *opsStart, ygpu_out_clump *fClumps, uint32_t *fOps)
+// the printed clumps of read r, in print order, with their ops copied behind one another: out clump k of the read = fClumps[outStart[r] + k].  A wave per read, a lane
+// per clump (a read handed to the host unfiltered brings hundreds): the ops' places from a scan of the clumps' op counts across the wave.
+__global__ void __launch_bounds__(256) k_oqc_gather(OqcArgs A, const uint32_t *outStart, const uint32_t *opsStart, ygpu_out_clump *fClumps, uint32_t *fOps)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; const int lane = (int)(threadIdx.x & 63);
     if (r >= A.nReads) return;
-    const uint32_t b = A.cs[r], m = A.outCnt[r]; uint32_t d = outStart[r], od = opsStart[r];
-    for (uint32_t k = 0; k < m; k++) {
-        const yoqc::OutRec o = A.out[b + k]; ygpu_clump c = A.cl[b + (uint32_t)o.clump];
-        const uint32_t *src = A.ops + c.op_start;
-        for (uint32_t i = 0; i < c.n_ops; i++) fOps[od + i] = src[i];
-        c.op_start = od; od += c.n_ops;
-        ygpu_out_clump f; f.c = c; f.status = o.status; f.mapQuality = o.mapQuality; f.numSecondaries = o.numSecondaries; f.matchedPrimary = o.matchedPrimary; f.primaryCount = (uint16_t)A.primCnt[r];
-        fClumps[d + k] = f;
+    const uint32_t b = A.cs[r], m = A.outCnt[r], d = outStart[r]; uint32_t od = opsStart[r]; const uint16_t pc = (uint16_t)A.primCnt[r];
+    for (uint32_t k0 = 0; k0 < m; k0 += 64) {
+        const uint32_t k = k0 + (uint32_t)lane; const bool have = k < m;
+        yoqc::OutRec o; ygpu_clump c; uint32_t nops = 0;
+        if (have) { o = A.out[b + k]; c = A.cl[b + (uint32_t)o.clump]; nops = c.n_ops; }
+        uint32_t incl = nops;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, s2, 64); if (lane >= s2) incl += v; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        if (have) {
+            const uint32_t dst = od + incl - nops; const uint32_t *src = A.ops + c.op_start;
+            for (uint32_t i = 0; i < nops; i++) fOps[dst + i] = src[i];
+            c.op_start = dst;
+            ygpu_out_clump f; f.c = c; f.status = o.status; f.mapQuality = o.mapQuality; f.numSecondaries = o.numSecondaries; f.matchedPrimary = o.matchedPrimary; f.primaryCount = pc;
+            fClumps[d + k] = f;
+        }
+        od += total;
     }
 }

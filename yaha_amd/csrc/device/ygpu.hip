@@ -998,7 +998,7 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     rc = fetchU32(ctx, ctx->oqOpsStart.as<uint32_t>() + n, &tot[1]); if (rc) return rc;
     ctx->nFOut = tot[0]; ctx->nFOps = tot[1];
     ENSURE(ctx->oqFClumps, sizeof(ygpu_out_clump) * ((uint64_t)tot[0] + 1)); ENSURE(ctx->oqFOps, 4ull * ((uint64_t)tot[1] + 1));
-    KL(k_oqc_gather, dim3(gridFor(n, 64)), dim3(64), 0, ctx->stream, A, ctx->oqOutStart.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), ctx->oqFClumps.as<ygpu_out_clump>(), ctx->oqFOps.as<uint32_t>());
+    KL(k_oqc_gather, dim3(gridFor((uint64_t)n * 64, 256)), dim3(256), 0, ctx->stream, A, ctx->oqOutStart.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), ctx->oqFClumps.as<ygpu_out_clump>(), ctx->oqFOps.as<uint32_t>());
     if (oqProf) {
         unsigned long long h[16 * YQ_NCLASS]; HIPCHK(hipMemcpyAsync(h, ctx->oqProf.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
         static const char *nm[7] = {"keys", "sort", "dup scan", "nodes+tables", "path walk", "successors", "finish"};
