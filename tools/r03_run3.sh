@@ -13,6 +13,6 @@ for mode in dev host; do
   YAHA_TIMING=1 yaha_amd/csrc/yaha -x $X -q $R -osh /dev/shm/o_$mode.sam 2> $O/r03_cli_timing3_$mode.txt; echo "== $mode filter"; grep -v ticket $O/r03_cli_timing3_$mode.txt | tail -3; grep ticket $O/r03_cli_timing3_$mode.txt | sed -n '10,12p'
 done
 unset YAHA_HOST_OQC
-cmp /dev/shm/o_dev.sam /dev/shm/o_host.sam && echo "device-filtered and host-filtered SAM of 1 M reads: identical"; rm -f /dev/shm/o_dev.sam /dev/shm/o_host.sam
+cmp <(grep -v "^@PG" /dev/shm/o_dev.sam) <(grep -v "^@PG" /dev/shm/o_host.sam) && echo "device-filtered and host-filtered SAM of 1 M reads: identical (minus @PG)"; rm -f /dev/shm/o_dev.sam /dev/shm/o_host.sam
 YAHA_PARITY_GENOME=g3100m_s42 python tools/big_parity.py 16384 > $O/r03_at_scale_validation_vs_reference_3100Mbp.log 2>&1; cat $O/r03_at_scale_validation_vs_reference_3100Mbp.log
 YAHA_PARITY_GENOME=g3100m_s42 python tools/big_parity_opts.py 4000 > $O/r03_at_scale_validation_option_sets_3100Mbp.log 2>&1; tail -20 $O/r03_at_scale_validation_option_sets_3100Mbp.log
