@@ -324,8 +324,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (YAHA_BENCH_BACKEND=gloo, with fewer GPUs than ranks: the ranks share devices and torch.distributed runs on the CPU -- a dry run of the N > 1 path on a 1-GPU box)
+        backend = os.environ.get("YAHA_BENCH_BACKEND", "nccl")
+        local = local % max(1, torch.cuda.device_count()) if backend == "gloo" else local
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # the waits AFTER the timed region go through a CPU group: a rank parked in an RCCL barrier keeps a kernel spinning on its GPU, and rank 0 runs the whole
+        # command line over all the devices meanwhile (end_to_end)
+        cpu_group = dist.new_group(backend="gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -394,12 +400,13 @@ def main():
         k = s.params.wordLen
         for c in reversed(ctxs):
             c.close()
-    dt = max_over_ranks(dt, dist)
+    dt = max_over_ranks(dt, dist, device="cpu" if os.environ.get("YAHA_BENCH_BACKEND") == "gloo" else "cuda")
     if dist is not None:
-        dist.barrier()                                   # every rank has closed its contexts: the devices are free for the command-line leg below
+        dist.barrier(group=cpu_group)                    # every rank has closed its contexts: the devices are free for the command-line leg below
     if rank != 0:
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=cpu_group)
+            dist.destroy_process_group()
         return
 
     steps = args.steps
@@ -513,7 +520,8 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": os.cpu_count(), "kind": "error", "sample": str(e)[:200]}
     print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=cpu_group)
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
