@@ -509,7 +509,7 @@ def main():
     if world > 1 and not args.no_extras:
         # N > 1: the whole command line over the N devices (`yaha -gpus N`, one process, N x 3 contexts, index image uploaded to every device), the other ranks idle
         try:
-            out["end_to_end"] = end_to_end(ya, idx, fa, cache, args.e2e_reads, 3000, gpus=world)
+            out["end_to_end"] = end_to_end(ya, idx, fa, cache, args.e2e_reads, 3000, gpus=min(world, max(1, torch.cuda.device_count())))
             out["e2e_reads_per_s"] = out["end_to_end"]["e2e_reads_per_s"]; out["steady_reads_per_s"] = out["end_to_end"]["steady_reads_per_s"]
         except Exception as e:
             out["end_to_end"] = {"error": str(e)[:300]}
