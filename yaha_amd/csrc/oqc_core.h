@@ -110,24 +110,27 @@ struct Run {
             const int right = stPop(stk, stkCap, stk2, sp), left = stPop(stk, stkCap, stk2, sp);
             if (left >= right) continue;
             const int pivot = (left + right) / 2;
-            { const SortKey t = arr[pivot]; arr[pivot] = arr[right]; arr[right] = t; }
+            // (elements move as (key, clump) scalars, never as structs: a SortKey temporary ends up in private memory -- scratch, on the device: a trip to HBM per access)
+            { const uint64_t pk0 = arr[pivot].key, rk0 = arr[right].key; const int pc0 = arr[pivot].clump, rc0 = arr[right].clump;
+              arr[pivot].key = rk0; arr[pivot].clump = rc0; arr[right].key = pk0; arr[right].clump = pc0; }
             int store = left;
             const uint64_t pk = arr[right].key;
             // "if less: swap(arr[i], arr[store]), store++".  The element at `store` and the next element of the scan are kept in registers: the next element is
             // fetched one iteration ahead (an iteration writes positions i and store <= i only); the one at `store` changes only after a swap.
-            SortKey y = arr[store], nx = arr[left];
+            uint64_t yk = arr[store].key, nk = arr[left].key; int yc = arr[store].clump, nc = arr[left].clump;
             for (int i = left; i < right; i++) {
-                const SortKey x = nx;
-                if (i + 1 < right) nx = arr[i + 1];
-                bool less = x.key < pk;
-                if (x.key == pk) less = (randBits(rs) & 1) != 0;
+                const uint64_t xk = nk; const int xc = nc;
+                if (i + 1 < right) { nk = arr[i + 1].key; nc = arr[i + 1].clump; }
+                bool less = xk < pk;
+                if (xk == pk) less = (randBits(rs) & 1) != 0;
                 if (less) {
-                    if (i != store) { arr[i] = y; arr[store] = x; }
+                    if (i != store) { arr[i].key = yk; arr[i].clump = yc; arr[store].key = xk; arr[store].clump = xc; }
                     store++;
-                    y = store == i + 1 ? nx : arr[store];                // (store == i: the element just written there, read back in order)
+                    if (store == i + 1) { yk = nk; yc = nc; } else { yk = arr[store].key; yc = arr[store].clump; }      // (store == i: the element just written there, read back in order)
                 }
             }
-            { const SortKey t = arr[store]; arr[store] = arr[right]; arr[right] = t; }
+            { const uint64_t sk0 = arr[store].key, rk0 = arr[right].key; const int sc0 = arr[store].clump, rc0 = arr[right].clump;
+              arr[store].key = rk0; arr[store].clump = rc0; arr[right].key = sk0; arr[right].clump = sc0; }
             // the reference sorts [left, store-1] completely before it touches [store+1, right]: the right part goes on the stack first
             stPush(stk, stkCap, stk2, sp, store + 1); stPush(stk, stkCap, stk2, sp, right);
             stPush(stk, stkCap, stk2, sp, left); stPush(stk, stkCap, stk2, sp, store - 1);
