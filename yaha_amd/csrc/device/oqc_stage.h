@@ -1,8 +1,8 @@
 // oqc_stage.h -- the post-filter on the device (SURVEY.md 8(f)-1 widened onto the GPU): Optimal Query Coverage, filter-by-similarity and mapping quality
 // (reference GraphPath.cpp:897-1086) for every read of the batch, right where the hot path left its clumps, so that only the clumps that are PRINTED -- one or
 // two of the ~75 a 1 kbp read produces -- and their edit ops travel to the host (9 KB a read -> ~0.2 KB) and the host's share of a read is parsing and
-// printing.  The routine itself is ../oqc_core.h, the very source the host compiles (host/oqc.cpp): one read per lane, sequential, all of its work space in
-// per-read slices of batch-wide arrays (the hot ones staged in LDS, see k_oqc_lds).
+// printing.  The routine itself is ../oqc_core.h, the very source the host compiles (host/oqc.cpp), its steps called from k_oqc_wave: a wave per read, the work
+// space in LDS, the independent steps on the wave's lanes.
 #pragma once
 #include "common.h"
 #include "../oqc_core.h"
@@ -17,13 +17,13 @@ struct OqcArgs {
     unsigned long long *prof;          // YGPU_OQC_PROF=1: 100 MHz ticks per step of k_oqc_wave, summed over the reads (keys, sort, duplicate scan, nodes + tables, walk along the path, successors, finish) and per class
 };
 // What the routine costs on a GPU, measured: one read per lane with its work space in HBM took 75 ms a batch (a few thousand DEPENDENT accesses a read, microseconds
-// each); one read per wave with the work space in LDS still 39 ms for the reads of 320..640 clumps -- the graph loop is quadratic in the nodes that survive the
+// each); one read per wave, first lane only, with the work space in LDS still 39 ms for the reads of 320..640 clumps -- the graph loop is quadratic in the nodes that survive the
 // duplicate scan, and reads in repeats have hundreds.  So a read gets a WAVE, the work space in LDS, and the steps oqc_core.h marks as independent run on its
 // 64 lanes: the scan behind a node in the duplicate removal (64 candidates at a time, the ballot finds where the scan ends), the nodes and their running-sum
 // tables, and the successors of a node in the graph loop (each lane relaxes a different successor: it reads the node and its path and writes its own successor
 // only).  What must stay in the reference's order stays on the first lane: the sort (it consumes the read's random bits in comparison order), the walk along
 // the best path before each node's successors, the choice of the best node, the similarity filter.
-// Reads come in classes by their number of clumps (the LDS a workgroup gets is fixed at launch): keys + sort stack, then nodes + table index + path share it.
+// Reads come in classes by their number of clumps (the LDS a workgroup gets is fixed at launch): keys + sort stack, then nodes + table index + path + tables share it.
 #define YQ_NCLASS 4
 #define YQ_DEVICE_MAX 448            // clumps of the largest read the device stage filters (see k_oqc_raw)
 #define YQ_STACK_LDS 128              // ints of the sort's stack kept in LDS (depth ~2 log2 n ranges); deeper recursion continues in HBM
