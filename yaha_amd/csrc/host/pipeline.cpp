@@ -380,7 +380,7 @@ int runQueries(Args &a, FILE *log)
     // page-locked buffers in one go, instead of a hipFree per buffer (a second of waiting at the end of every run, measured).  Library users get the orderly path.
     const bool fastExit = getenv("YAHA_FAST_EXIT") != nullptr;
     if (!fastExit) for (int d = ngpu - 1; d >= 0; d--) if (ctx[d]) ygpu_destroy(ctx[d]);     // clones before their parents
-    if (fastExit) { BatchP b; while (!pool.free.empty()) { b = std::move(pool.free.back()); pool.free.pop_back(); b->clumpStart.p = b->clumps.p = b->ops.p = nullptr; } }   // (their page-locked memory goes with the process as well)
+    if (fastExit) (void)new std::vector<BatchP>(std::move(pool.free));     // (the batches -- a million small strings, the page-locked buffers -- go with the process as well: freeing them one by one was 0.3 s)
     if (fflush(out) != 0 || ferror(out)) { if (!stop) fprintf(log, "Failure writing the output file.\n"); rcAll = 1; }
     if (out != stdout && fclose(out) != 0) { fprintf(log, "Failure closing the output file.\n"); rcAll = 1; }
     if (timing) fprintf(stderr, "[yaha] batches done %.1f ms after start, teardown %.1f ms\n", tDone - tEnter, now() - tDone);
