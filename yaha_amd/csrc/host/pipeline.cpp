@@ -235,7 +235,9 @@ int runQueries(Args &a, FILE *log)
     // Thread counts follow the CPUs the process may use (effectiveCpus: affinity and the control group's quota).  -t is the reference's thread count and is
     // echoed in @PG; given explicitly (> 1) it is the number of formatter threads, otherwise every CPU that is not a parser, the splitter or the writer is one.
     const int cpus = effectiveCpus();
-    const int nParse = std::max(1, std::min(8, (cpus + 7) / 10)), nFmt = A.numThreads > 1 ? A.numThreads : std::max(1, cpus - nParse - 2);
+    // (a parser thread does 1.4 M reads/s, a formatter 0.1 M with the host's post-filter and 0.65 M when the filter ran on the device: with several devices
+    // behind a small CPU quota the parsers are what must not run short -- one for every two devices)
+    const int nParse = std::max(1, std::min(8, std::min(std::max((cpus + 7) / 10, (nDev + 1) / 2), std::max(1, cpus / 3)))), nFmt = A.numThreads > 1 ? A.numThreads : std::max(1, cpus - nParse - 2);
     StageQueue<BatchP> parseQ((size_t)nParse + 2, 1), inQ((size_t)ngpu + 2, nParse), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu + nParse), outQ((size_t)nFmt + 4, nFmt);
     std::atomic<bool> stop(false); std::atomic<int> rcAll(0);
     auto fail = [&](const char *what) { if (!stop.exchange(true)) fprintf(log, "%s -- stopping; the output ends with the last batch completed before this one.\n", what); rcAll = 1; };
