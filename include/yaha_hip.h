@@ -168,6 +168,12 @@ int  ygpu_postfilter(ygpu_ctx *ctx);                                           /
 int  ygpu_filtered_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops);
 int  ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump *clumps, uint32_t *ops, ygpu_filtered_batch *out);
 
+/* Stage-level entry for tests of the post-filter (as ygpu_dp_batch is for the DP kernels): place a result batch on the device as if ygpu_run had produced it
+ * for the reads uploaded last (r->n_reads must equal the uploaded batch's; clump_start / clumps / ops as ygpu_collect returns them).  ygpu_postfilter,
+ * ygpu_collect and their siblings then work on it -- so that the device filter can be driven with clump lists no real read produces (hundreds of exact ties,
+ * chains of overlaps) and compared with the host's on the same data. */
+int  ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r);
+
 /* Asynchronous form: ygpu_submit hands the batch to the context and returns at once; the context's own worker thread does
  * upload + run + collect; ygpu_wait blocks until the ticket is complete and returns the results (ygpu_poll: 1 = complete, 0 = still running).
  * One host thread can so keep several contexts (devices) busy -- the reference needs one thread per QueryState for that (Query.c:642-684).

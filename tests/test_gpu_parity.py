@@ -412,3 +412,76 @@ def test_device_stages_match_the_instrumented_reference(work, index11, name):
             assert got == frags
             for kernels in (ya.DP_KERNELS_AUTO, ya.DP_KERNELS_WAVE, ya.DP_KERNELS_LANES, ya.DP_KERNELS_LANES_CAREFUL):
                 _dp_check(ctx, probs, exp, kernels)
+
+
+def _synthetic_results(s, b, rng, max_clumps):
+    """Clump lists no real read produces, for the reads of batch b: hundreds of clumps a read, scores from a handful of values, exact duplicates (same span, same place, same
+    strand), the same span at other places (copies of a repeat), nested and overlapping spans with edit lists of all four ops -- consistent records (query bases of the ops =
+    the span, reference bases = refLen, everything inside the genome)."""
+    import numpy as np
+    offs = C.cast(b.offsets, C.POINTER(C.c_uint64))
+    gmax = int(s.index.maxROff)
+    starts, recs, ops = [0], [], []
+
+    def make_ops(qspan):
+        out, q, r = [], 0, 0
+        while q < qspan:
+            kind = "MMMMMRID"[int(rng.integers(0, 8))]
+            ln = int(min(qspan - q, rng.integers(1, 40))) if kind != "D" else int(rng.integers(1, 6))
+            if kind == "D" and (not out or q == 0):
+                kind = "M"; ln = int(min(qspan - q, rng.integers(1, 40)))
+            out.append((ln, kind)); q += ln if kind != "D" else 0; r += ln if kind in "MRD" else 0
+        merged = []
+        for ln, k in out:                               # adjacent ops of one kind are one op
+            if merged and merged[-1][1] == k:
+                merged[-1] = (merged[-1][0] + ln, k)
+            else:
+                merged.append((ln, k))
+        r = sum(l for l, k in merged if k in "MRD")
+        return merged, r
+
+    for i in range(b.n_reads):
+        qlen = int(offs[i + 1] - offs[i])
+        n = int(rng.integers(0, max_clumps + 1)) if rng.random() < 0.9 else int(rng.integers(0, 4))
+        mine = []
+        while len(mine) < n:
+            sqo = int(rng.integers(0, max(1, qlen - 30))); eqo = int(min(qlen - 1, sqo + rng.integers(24, max(25, qlen // int(rng.integers(1, 6))))))
+            o, rlen = make_ops(eqo - sqo + 1)
+            sro = int(rng.integers(1000, gmax - 40000)); score = int(rng.choice([25, 30, 30, 40, 60, 60, 100, 200, 400, 800])); rev = int(rng.random() < 0.5)
+            rec = (sro, sqo, eqo, rlen, score, o, rev)
+            mine.append(rec)
+            for _ in range(int(rng.integers(0, 4))):      # copies: exact duplicates, or the same span elsewhere / on the other strand
+                if len(mine) >= n:
+                    break
+                mine.append(rec if rng.random() < 0.4 else (int(rng.integers(1000, gmax - 40000)), sqo, eqo, rlen, score, o, int(rng.random() < 0.5)))
+        order = rng.permutation(len(mine))
+        for k in order:
+            sro, sqo, eqo, rlen, score, o, rev = mine[k]
+            recs.append((sro, sqo, eqo, rlen, score, eqo - sqo + 1, sum(l for l, c in o if c == "M"), sum(l for l, c in o if c == "R"), sum(l for l, c in o if c in "ID"), rev, 0, len(ops), len(o)))
+            ops.extend(l | (ord(c) << 16) for l, c in o)
+        starts.append(len(recs))
+    cs = (C.c_uint32 * len(starts))(*starts); cl = (ya.Clump * max(1, len(recs)))(*[ya.Clump(*r) for r in recs]); op = (C.c_uint32 * max(1, len(ops)))(*ops)
+    r = ya.ResultBatch(); r.n_reads = b.n_reads; r.clump_start = cs; r.clumps = cl; r.ops = op; r.n_clumps = len(recs); r.n_ops = len(ops)
+    return r, (cs, cl, op)
+
+
+# The device filter against the host's on synthetic clump lists (ygpu_inject_results): ties by the hundred, duplicates, copies, nests, up to 448 clumps a read and beyond
+# (the hand-over path), under the filter's parameter sets.  What is compared is the SAM text of both.
+@pytest.mark.parametrize("seed,max_clumps,extra", [(1, 60, []), (2, 300, []), (3, 460, ["-FBS", "Y", "-PSS", "0.5", "-PRL", "0.5"]), (4, 120, ["-BP", "11", "-MGDP", "7", "-MNO", "5"]),
+                                                   (5, 200, ["-FBS", "Y", "-MNO", "60", "-GOC", "3", "-GEC", "1", "-RC", "2"]), (6, 40, ["-oss", "stdout", "-FBS", "Y", "-PSS", "0.1", "-PRL", "0.1"])])
+def test_postfilter_on_synthetic_clump_lists(work, index11, seed, max_clumps, extra):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa"), "-osh", "stdout"] + list(extra)) as s:
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.set_postfilter(s)
+            b = s.next_batch(48)
+            ctx.upload(b)
+            r, _keep = _synthetic_results(s, b, rng, max_clumps)
+            ctx.inject_results(r)
+            host = s.emit(r)
+            f = ctx.postfilter()
+            assert f.n_reads == b.n_reads
+            dev = s.emit_filtered(f)
+            assert dev == host
+            assert len(host) > 1000

@@ -85,7 +85,7 @@ DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
 DP_KERNELS_AUTO, DP_KERNELS_WAVE, DP_KERNELS_LANES, DP_KERNELS_LANES_CAREFUL = 0, 1, 2, 3
 
 EXPORTS = (
-    "ygpu_init", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
+    "ygpu_init", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter", "ygpu_inject_results", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
     "ygpu_submit", "ygpu_poll", "ygpu_wait", "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch", "ygpu_dp_batch_ex",
     "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
     "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit", "yaha_session_postfilter_params", "yaha_session_emit_filtered",
@@ -209,6 +209,10 @@ class Context:
         if lib().yaha_session_postfilter_params(session._h, C.byref(p)) != 0:
             raise RuntimeError("yaha_session_postfilter_params: " + lib().yaha_session_error(session._h).decode())
         self._check(lib().ygpu_set_postfilter(self._h, C.byref(p)), "ygpu_set_postfilter")
+
+    def inject_results(self, result):
+        """Stage-level test entry: a ResultBatch placed on the device as if ygpu_run had produced it for the uploaded reads."""
+        self._check(lib().ygpu_inject_results(self._h, C.byref(result)), "ygpu_inject_results")
 
     def postfilter(self):
         """OQC, filter by similarity and mapping quality on the device; returns the clumps that are printed (FilteredBatch; arrays owned by this object)."""

@@ -1032,6 +1032,19 @@ int ygpu_postfilter(ygpu_ctx *ctx)
     ctx->oqDone = true;
     return 0;
 }
+int ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r)
+{
+    if (!ctx || !ctx->stream || !r || r->n_reads != ctx->nReads || !r->clump_start || (r->n_clumps && !r->clumps) || (r->n_ops && !r->ops) || r->n_clumps > 0x7FFFFFF0ull || r->n_ops > 0x7FFFFFF0ull) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->nReads;
+    ENSURE(ctx->readStart, 4ull * (n + 1)); ENSURE(ctx->outClumps2, sizeof(ygpu_clump) * (r->n_clumps + 1)); ENSURE(ctx->outOps, 4ull * (r->n_ops + 1)); ENSURE(ctx->ctr, sizeof(DevCounters));
+    HIPCHK(hipMemcpyAsync(ctx->readStart.p, r->clump_start, 4ull * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (r->n_clumps) HIPCHK(hipMemcpyAsync(ctx->outClumps2.p, r->clumps, sizeof(ygpu_clump) * r->n_clumps, hipMemcpyHostToDevice, ctx->stream));
+    if (r->n_ops) HIPCHK(hipMemcpyAsync(ctx->outOps.p, r->ops, 4ull * r->n_ops, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(streamSync(ctx));
+    ctx->nOut = (uint32_t)r->n_clumps; ctx->nOutOps = (uint32_t)r->n_ops; ctx->stageDone = 3; ctx->oqDone = false;
+    return 0;
+}
 int ygpu_filtered_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops)
 {
     if (!ctx || ctx->stageDone < 3 || !ctx->oqDone) return YGPU_EINVAL;
