@@ -1,5 +1,6 @@
 """GPU tier: the HIP hot path (through the C-ABI, include/yaha_hip.h) against the oracle, stage by stage and
 end to end, bit-exact; and the `yaha` CLI against SAM produced by the real reference (tests/golden)."""
+import ctypes as C
 import os
 import subprocess
 
