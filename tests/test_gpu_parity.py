@@ -469,7 +469,9 @@ def _synthetic_results(s, b, rng, max_clumps):
 # The device filter against the host's on synthetic clump lists (ygpu_inject_results): ties by the hundred, duplicates, copies, nests, up to 448 clumps a read and beyond
 # (the hand-over path), under the filter's parameter sets.  What is compared is the SAM text of both.
 @pytest.mark.parametrize("seed,max_clumps,extra", [(1, 60, []), (2, 300, []), (3, 460, ["-FBS", "Y", "-PSS", "0.5", "-PRL", "0.5"]), (4, 120, ["-BP", "11", "-MGDP", "7", "-MNO", "5"]),
-                                                   (5, 200, ["-FBS", "Y", "-MNO", "60", "-GOC", "3", "-GEC", "1", "-RC", "2"]), (6, 40, ["-oss", "stdout", "-FBS", "Y", "-PSS", "0.1", "-PRL", "0.1"])])
+                                                   (5, 200, ["-FBS", "Y", "-MNO", "60", "-GOC", "3", "-GEC", "1", "-RC", "2"]), (6, 40, ["-oss", "stdout", "-FBS", "Y", "-PSS", "0.1", "-PRL", "0.1"]),
+                                                   (7, 448, []), (8, 448, ["-FBS", "Y"]), (9, 224, ["-BP", "1", "-MGDP", "2"]), (10, 112, ["-MNO", "1", "-FBS", "Y", "-PSS", "0.99", "-PRL", "0.99"]),
+                                                   (11, 30, ["-BP", "40", "-MGDP", "9", "-MS", "3", "-RC", "7"]), (12, 330, ["-MNO", "120"])])
 def test_postfilter_on_synthetic_clump_lists(work, index11, seed, max_clumps, extra):
     import numpy as np
     rng = np.random.default_rng(seed)
