@@ -45,6 +45,7 @@ def _clean(p):
     ("r1k_default", "r1k.fa", []),                                                           # defaults: one batch of ~16 M bases, -ctx 3
     ("rq_default", "rq.fq", ["-batch", "5", "-t", "3"]),                                     # FASTQ, explicit formatter count
     ("r10k_default", "r10k.fa", ["-batch", "3", "-ctx", "1"]),
+    ("rchim_default", "rchim.fa", ["-batch", "29", "-dpf", "N"]),                             # the host's post-filter by option
 ])
 def test_command_line_pipeline_matches_the_reference(exes, work, index11, san, name, reads, extra):
     p = _run(exes[san], ["-x", index11, "-q", os.path.join(work, reads), "-osh", "stdout"] + extra, env={"YTEST_DEVICES": "2", "YAHA_CPUS": "6"})

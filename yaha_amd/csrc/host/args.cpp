@@ -18,7 +18,7 @@ static void usage(FILE *o)
           "       (built on the GPU when one is visible and -S is 1; -cpuindex forces the host builder; the files are identical)\n\n"
           "Query alignment (hot path on MI355X):\n"
           "  yaha -x indexFile [-q queryFile|(stdin)] [-o8|(-osh)|-oss outFile|(stdout)] [-t hostThreads (1)]\n"
-          "       [-gpus N (1)] [-ctx contextsPerGpu (3)] [-device D (0)] [-batch readsPerBatch (about 16 M bases)]\n"
+          "       [-gpus N (1)] [-ctx contextsPerGpu (3)] [-device D (0)] [-batch readsPerBatch (about 16 M bases)] [-dpf Y|N (Y: post-filter on the device)]\n"
           "  general : [-BW 5] [-G 50] [-H 650] [-M 25] [-MD 50] [-P 0.9] [-X 25]\n"
           "  scoring : [-AGS Y|N] [-GEC 2] [-GOC 5] [-MS 1] [-RC 3]\n"
           "  OQC     : [-OQC Y|N] [-BP 5] [-MGDP 5] [-MNO minMatch]   FBS: [-FBS Y|N] [-PRL 0.9] [-PSS 0.9]\n"
@@ -88,6 +88,7 @@ int parseArgs(int argc, char **argv, Args &a)
         else if (is("-ctx")) { if (!parseInt(val(), "-ctx", a.ctxPerGpu)) return 2; if (a.ctxPerGpu < 1 || a.ctxPerGpu > 8) { fprintf(stderr, "-ctx must be between 1 and 8.\n\n"); usage(stderr); return 2; } }
         else if (is("-device")) { if (!parseInt(val(), "-device", a.device)) return 2; }
         else if (is("-cpuindex")) a.cpuIndex = true;
+        else if (is("-dpf")) { if (!parseBool(val(), "-dpf", a.devicePostFilter)) return 2; }        // post-filter (OQC / FBS / MAPQ) on the device (default) or on the host
         else if (is("-batch")) { if (!parseInt(val(), "-batch", a.batchReads)) return 2;
                                  if (a.batchReads < 1 || a.batchReads > 65536) { fprintf(stderr, "-batch must be between 1 and 65536 (reads per device batch).\n\n"); usage(stderr); return 2; } }
         else { fprintf(stderr, "%s is not a valid option.\n\n", k); usage(stderr); return 2; }

@@ -277,10 +277,10 @@ int runQueries(Args &a, FILE *log)
     // a time and hold back the other contexts' new batches meanwhile, instead of fighting their kernels for every allocation (0.6 s per context otherwise, measured).
     // The post-filter (OQC, filter by similarity, mapping quality) runs on the device behind the hot path (ygpu_postfilter; the same routine as the host's,
     // oqc_core.h): the results that cross PCIe and reach the formatters are the clumps that get printed.  The host filter remains for -OQC N (duplicate
-    // removal only), for break point costs that are no step function, and on request (YAHA_HOST_OQC=1).
+    // removal only), for break point costs that are no step function, and on request (-dpf N, YAHA_HOST_OQC=1).
     yoqc::Params oqP; std::vector<uint32_t> oqThr, oqSeqStart, oqSeqLen; oqcParamsFromArgs(A, oqP, oqThr);
     for (auto &sq : S->genome.seqs) { oqSeqStart.push_back(sq.start); oqSeqLen.push_back(sq.length); }
-    const bool deviceFilter = A.OQC && oqP.bppN >= 0 && getenv("YAHA_HOST_OQC") == nullptr;
+    const bool deviceFilter = A.OQC && A.devicePostFilter && oqP.bppN >= 0 && getenv("YAHA_HOST_OQC") == nullptr;
     ygpu_postfilter_params PF; memset(&PF, 0, sizeof PF);
     PF.minNonOverlap = oqP.minNonOverlap; PF.BPCost = oqP.BPCost; PF.maxBPLog = oqP.maxBPLog; PF.FBS = oqP.FBS; PF.FBS_PSLength = oqP.FBS_PSLength; PF.FBS_PSScore = oqP.FBS_PSScore;
     PF.bppVmin = oqP.bppVmin; PF.bppN = std::max(0, oqP.bppN); PF.bppThr = oqThr.data(); PF.n_seqs = (uint32_t)oqSeqStart.size(); PF.seq_start = oqSeqStart.data(); PF.seq_length = oqSeqLen.data();
