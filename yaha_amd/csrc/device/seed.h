@@ -137,49 +137,123 @@ __device__ __forceinline__ uint32_t hitClass(const unsigned long long *keys, uin
     const bool dead = (maxGapDrop >= 0) & head & last & !nearA & !nearC;
     return (head ? 1u : 0u) | (last ? 2u : 0u) | (dead ? 4u : 0u);
 }
-// the scan's input: the head flags computed from the keys on the fly (no flag array: 0.8 GB written and read twice for 200 M hits)
-struct HitHeadFlag {
-    const unsigned long long *keys; uint32_t nHits; int wordLen, maxGapDrop;
-    __host__ __device__ __forceinline__ uint32_t operator()(uint32_t t) const
-    {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (t >= nHits) return 0u;
-        const uint32_t c = hitClass(keys, t, nHits, wordLen, maxGapDrop);
-        return c & ~(c >> 2) & 1u;                                               // a head that is not dropped
-#else
-        (void)t; return 0u;
-#endif
-    }
-};
-__global__ void __launch_bounds__(256) k_frag_build(const unsigned long long *keys, const uint32_t *fragIdx /* exclusive scan of the head flags */,
-                             uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
+// the same from the three keys in registers
+__device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned long long b, unsigned long long c, bool first, bool end, int wordLen, int maxGapDrop)
 {
-    __shared__ unsigned sDead;
-    if (threadIdx.x == 0) sDead = 0;
+    const uint32_t qa = (uint32_t)(a & 0x7FFFu), qb = (uint32_t)(b & 0x7FFFu), qc = (uint32_t)(c & 0x7FFFu);
+    const uint32_t da = (uint32_t)(a >> 15), db = (uint32_t)(b >> 15), dc = (uint32_t)(c >> 15);
+    const bool sameA = (uint32_t)(a >> 47) == (uint32_t)(b >> 47), sameC = (uint32_t)(c >> 47) == (uint32_t)(b >> 47);
+    const bool head = first | !sameA | (da != db) | (qb > qa + (uint32_t)wordLen);
+    const bool last = end | !sameC | (dc != db) | (qc > qb + (uint32_t)wordLen);
+    const bool nearA = !first & sameA & (absDiffU(da, db) <= (uint32_t)maxGapDrop), nearC = !end & sameC & (absDiffU(dc, db) <= (uint32_t)maxGapDrop);
+    const bool dead = (maxGapDrop >= 0) & head & last & !nearA & !nearC;
+    return (head ? 1u : 0u) | (last ? 2u : 0u) | (dead ? 4u : 0u);
+}
+// A2b in one pass over the sorted keys: head flags, their batch-wide exclusive scan (= the fragment index of every hit) and the fragment records.  A workgroup
+// owns a tile of 4 096 consecutive hits, each of its waves 16 rows of 64: a hit's neighbours are in the neighbouring lanes (or the edge lanes of the rows above
+// and below), the rank of a head inside the tile comes from the ballots of the 4 x 16 (wave, row) groups -- their 64 counts scanned by one wave -- and the tile's
+// offset from the tiles before it by decoupled look-back: a tile publishes its own count as soon as it has it, then adds up the published counts behind it until
+// it meets a tile that already knows its inclusive prefix (tile states: one 64-bit word, status in the high half so that value and status arrive together;
+// workgroups start in blockIdx order, so the tiles waited for are resident or finished).  Before: the library's scan over the flags (2.6 GB of keys read,
+// 1.3 GB of indices written) and a build kernel that read both again.  Records beyond cap are not written: the caller reads *total and comes back with room.
+#ifndef YD_FRAG_BS
+#define YD_FRAG_BS 512
+#endif
+#define YD_FRAG_IPT 16
+#define YD_FRAG_TILE (YD_FRAG_BS * YD_FRAG_IPT)
+__global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap,
+                                                                unsigned long long *tileState, unsigned int *total, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
+{
+    constexpr int NW = YD_FRAG_BS / 64;
+    __shared__ uint32_t sCnt[YD_FRAG_IPT * NW]; __shared__ uint32_t sPrefix; __shared__ unsigned sDead;
+    const uint32_t tile = blockIdx.x, base = tile * (uint32_t)YD_FRAG_TILE, t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    if (t == 0) sDead = 0;
+    unsigned long long key[YD_FRAG_IPT]; uint32_t cls = 0, cls2 = 0;           // three class bits per hit: ten in cls, six in cls2
+    unsigned long long headMask[YD_FRAG_IPT];                                  // wave-uniform: the live heads of row k in this wave
+    unsigned nDead = 0;
+    // wave w owns the hits wbase + k * 64 + lane: all its loads are issued together (16 rows and the two hits around the wave's range), a row's outer neighbours
+    // are the edge lanes of the rows above and below
+    const uint32_t wbase = base + w * (uint32_t)(64 * YD_FRAG_IPT);
+#pragma unroll
+    for (int k = 0; k < YD_FRAG_IPT; k++) { const uint32_t idx = wbase + (uint32_t)k * 64u + lane; key[k] = idx < nHits ? keys[idx] : 0ull; }
+    unsigned long long edge = 0ull;                                            // lane 0: the hit before the wave's range; lane 63: the one behind it
+    if (lane == 0u && wbase > 0u && wbase <= nHits) edge = keys[wbase - 1u];
+    if (lane == 63u && wbase + (uint32_t)(64 * YD_FRAG_IPT) < nHits) edge = keys[wbase + (uint32_t)(64 * YD_FRAG_IPT)];
+#pragma unroll
+    for (int k = 0; k < YD_FRAG_IPT; k++) {
+        const uint32_t idx = wbase + (uint32_t)k * 64u + lane; const bool in = idx < nHits;
+        const unsigned long long b = key[k];
+        const unsigned long long up = k > 0 ? key[k - 1] : edge, dn = k + 1 < YD_FRAG_IPT ? key[k + 1] : edge;      // rows whose lanes 63 / 0 are this row's outer neighbours
+        const uint32_t a0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)up, k > 0 ? 63 : 0), a0hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(up >> 32), k > 0 ? 63 : 0);
+        const uint32_t c0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dn, k + 1 < YD_FRAG_IPT ? 0 : 63), c0hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dn >> 32), k + 1 < YD_FRAG_IPT ? 0 : 63);
+        const unsigned long long a = ((unsigned long long)(uint32_t)laneUp1((int)(uint32_t)(b >> 32), (int)a0hi) << 32) | (uint32_t)laneUp1((int)(uint32_t)b, (int)a0lo);
+        const unsigned long long c = ((unsigned long long)(uint32_t)laneDown1((int)(uint32_t)(b >> 32), (int)c0hi) << 32) | (uint32_t)laneDown1((int)(uint32_t)b, (int)c0lo);
+        uint32_t cl = 0;
+        if (in) cl = hitClassOf(a, b, c, idx == 0u, idx + 1u >= nHits, wordLen, maxGapDrop);
+        if (k < 10) cls |= cl << (3 * k); else cls2 |= cl << (3 * (k - 10));
+        const bool liveHead = (cl & 5u) == 1u;
+        const unsigned long long m = __ballot(liveHead); headMask[k] = m;
+        if (lane == 0u) sCnt[(int)w * YD_FRAG_IPT + k] = (uint32_t)__builtin_popcountll(m);
+        nDead += (cl >> 2) & 1u;
+    }
     __syncthreads();
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    bool dead = false;
-    if (t < nHits) {
-        const uint32_t cls = hitClass(keys, t, nHits, wordLen, maxGapDrop);
-        const bool head = (cls & 1u) != 0u, last = (cls & 2u) != 0u; dead = (cls & 4u) != 0u;
-        if (!dead) {
-            const unsigned long long k = keys[t];
-            const uint32_t qo = (uint32_t)(k & 0x7FFFu), diag = (uint32_t)(k >> 15), rs = (uint32_t)(k >> 47);
-            const uint32_t f = fragIdx[t] + (head ? 1u : 0u) - 1u;                // index of the fragment this hit belongs to
-            if (head && last) {                                                  // a fragment of one hit: the whole record in one 16-byte store
-                const uint32_t eqo = qo + (uint32_t)wordLen - 1u;
-                uint4 v; v.x = diag + qo; v.y = qo | (eqo << 16); v.z = (uint32_t)wordLen /* refLen, used = 0 */; v.w = rs;
-                *(uint4 *)&frags[f] = v;
-            } else {
-                if (head) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
-                if (last) frags[f].eqo = (uint16_t)(qo + (uint32_t)wordLen - 1u);
+    if (w == 0u) {
+        // exclusive scan of the NW x 16 (wave, row) counts, NW / 4 consecutive ones per lane; then the look-back
+        constexpr int E = YD_FRAG_IPT * NW / 64;
+        uint32_t v[E], sum = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) { v[e] = sum; sum += sCnt[(int)lane * E + e]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
+#pragma unroll
+        for (int e = 0; e < E; e++) sCnt[(int)lane * E + e] = incl - sum + v[e];
+        const uint32_t agg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t excl = 0;
+        if (tile == 0u) { if (lane == 0u) __hip_atomic_store(&tileState[0], (2ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else {
+            if (lane == 0u) __hip_atomic_store(&tileState[tile], (1ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int back = (int)tile - 1;                                            // lane l looks at tile back - l
+            for (;;) {
+                const int j = back - (int)lane;
+                unsigned long long st = 2ull << 32;                              // before the first tile: a known prefix of zero
+                if (j >= 0) { do { st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st >> 32) == 0ull); }
+                const unsigned long long known = __ballot((st >> 32) == 2ull);
+                const int stop = __builtin_ctzll(known | (1ull << 63));          // the nearest tile that knows its prefix (lane 63 at the latest if any)
+                const bool use = known ? (int)lane <= stop : true;
+                excl += (uint32_t)waveSumI(use ? (int)(uint32_t)st : 0);
+                if (known) break;
+                back -= 64;
             }
+            if (lane == 0u) __hip_atomic_store(&tileState[tile], (2ull << 32) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0u) { sPrefix = excl; if (tile + 1u == gridDim.x) *total = excl + agg; }
+    }
+    __syncthreads();
+    const uint32_t prefix = sPrefix; const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < YD_FRAG_IPT; k++) {
+        const uint32_t cl = (k < 10 ? cls >> (3 * k) : cls2 >> (3 * (k - 10))) & 7u;
+        const bool head = (cl & 1u) != 0u, last = (cl & 2u) != 0u, dead = (cl & 4u) != 0u;
+        const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
+        if (idx >= nHits || dead) continue;
+        const uint32_t f = prefix + sCnt[(int)w * YD_FRAG_IPT + k] + (uint32_t)__builtin_popcountll(headMask[k] & below) + (head ? 1u : 0u) - 1u;   // the fragment this hit belongs to
+        if (f >= cap) continue;
+        const unsigned long long kk = key[k];
+        const uint32_t qo = (uint32_t)(kk & 0x7FFFu), diag = (uint32_t)(kk >> 15), rs = (uint32_t)(kk >> 47);
+        if (head && last) {                                                  // a fragment of one hit: the whole record in one 16-byte store
+            const uint32_t eqo = qo + (uint32_t)wordLen - 1u;
+            uint4 v; v.x = diag + qo; v.y = qo | (eqo << 16); v.z = (uint32_t)wordLen /* refLen, used = 0 */; v.w = rs;
+            *(uint4 *)&frags[f] = v;
+        } else {
+            if (head) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
+            if (last) frags[f].eqo = (uint16_t)(qo + (uint32_t)wordLen - 1u);
         }
     }
-    const unsigned long long dm = __ballot(dead);
-    if ((threadIdx.x & 63u) == 0 && dm) atomicAdd(&sDead, (unsigned)__builtin_popcountll(dm));
+    nDead = (unsigned)waveSumI((int)nDead);
+    if (lane == 0u && nDead) atomicAdd(&sDead, nDead);
     __syncthreads();
-    if (threadIdx.x == 0 && sDead) atomicAdd(&deadParts[blockIdx.x & 1023u], sDead);
+    if (t == 0 && sDead) atomicAdd(&deadParts[blockIdx.x & 1023u], sDead);
 }
 __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
 {

@@ -63,7 +63,7 @@ struct DevBuf {
     int ensureExact(size_t bytes) { if (bytes <= cap) return 0; release(); void *np = nullptr; if (hipMalloc(&np, bytes) != hipSuccess) return -1; p = np; cap = bytes; return 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* five: the segments of the four workgroup-sort classes, the long ones */, CNT_N = CNT_SEGC + 5 + 3 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* five: the segments of the four workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 5, CNT_N = CNT_NFRAGS + 3 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_XROWS_PK, T_N };
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
@@ -245,29 +245,33 @@ static int stageSeed(ygpu_ctx *ctx)
         }
     }
     EV1(T_SORT);
-    EV0(T_FRAGS);
-    ENSURE(ctx->scanOut, 4ull * (H + 1));
-    {   // fragment index of every hit = exclusive scan of the head flags, which the scan computes from the sorted keys as it reads them
-        hipcub::TransformInputIterator<uint32_t, HitHeadFlag, hipcub::CountingInputIterator<uint32_t>> flags(hipcub::CountingInputIterator<uint32_t>(0u), HitHeadFlag{ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, fragDropGap(ctx)});
-        size_t bytes = 0;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags, ctx->scanOut.as<uint32_t>(), (int)(H + 1), ctx->stream));
-        if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp.p, bytes, flags, ctx->scanOut.as<uint32_t>(), (int)(H + 1), ctx->stream));
-    }
-    uint32_t F = 0; rc = fetchU32(ctx, ctx->scanOut.as<uint32_t>() + H, &F); if (rc) return rc;
-    ctx->nFrags = F;
-    ENSURE(ctx->frags, 16ull * (F + 1));
     return 0;
 }
-static int buildFrags(ygpu_ctx *ctx)       // (re)creates the fragment array from the sorted keys: the chain stage trims it in place
+// (Re)creates the fragment array from the sorted keys -- the chain stage trims it in place, so a redo of that stage comes back here.  One kernel (seed.h:
+// k_frag_scan_build) counts and writes; the array is sized from the last batch's count, and a batch that needs more is run again with room (the first batch of
+// a context always is: its first pass only counts).
+static int buildFrags(ygpu_ctx *ctx)
 {
-    const uint32_t H = ctx->nHits, F = ctx->nFrags;
+    const uint32_t H = ctx->nHits;
+    ctx->nFrags = 0;
     if (!H) return 0;
-    // the fragments that are dropped (seed.h: hitIsDeadSingle) are counted: the counters report every fragment and region of the reference
-    ENSURE(ctx->kmerParts, 4096); HIPCHK(hipMemsetAsync(ctx->kmerParts.p, 0, 4096, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_FRAGS, 0, 8, ctx->stream));
-    KL(k_frag_build, dim3(gridFor(H, 256)), dim3(256), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), ctx->scanOut.as<uint32_t>(), H, ctx->P.wordLen, fragDropGap(ctx), ctx->frags.as<DevFrag>(), ctx->kmerParts.as<unsigned int>());
+    const uint32_t nTiles = (uint32_t)gridFor(H, YD_FRAG_TILE);
+    ENSURE(ctx->scanOut, 8ull * nTiles);
+    unsigned int *total = ctx->counters.as<unsigned int>() + CNT_NFRAGS;
+    for (int pass = 0;; pass++) {
+        const uint32_t cap = ctx->frags.cap >= 32 ? (uint32_t)std::min<uint64_t>(ctx->frags.cap / 16 - 1, 0xFFFFFFF0u) : 0u;
+        // the fragments that are dropped (seed.h: hitClass) are counted: the counters report every fragment and region of the reference
+        ENSURE(ctx->kmerParts, 4096); HIPCHK(hipMemsetAsync(ctx->kmerParts.p, 0, 4096, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_FRAGS, 0, 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->scanOut.p, 0, 8ull * nTiles, ctx->stream));
+        KL(k_frag_scan_build, dim3(nTiles), dim3(YD_FRAG_BS), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, fragDropGap(ctx), ctx->frags.as<DevFrag>(), cap,
+           ctx->scanOut.as<unsigned long long>(), total, ctx->kmerParts.as<unsigned int>());
+        uint32_t F = 0; int rc = fetchU32(ctx, total, &F); if (rc) return rc;
+        if (F <= cap) { ctx->nFrags = F; break; }
+        if (pass >= 2) { ctx->err = "fragment build: the count changed between passes"; return YGPU_EINTERNAL; }
+        ENSURE(ctx->frags, 16ull * ((uint64_t)F + F / 8 + 4096));
+    }
     KL(k_sum_parts, dim3(1), dim3(1024), 0, ctx->stream, ctx->kmerParts.as<unsigned int>(), ctx->ctr.as<DevCounters>()->v + C_FRAGS);
-    KL(k_frag_finish, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F);
+    if (ctx->nFrags) KL(k_frag_finish, dim3(gridFor(ctx->nFrags, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), ctx->nFrags);
     return 0;
 }
 
