@@ -17,8 +17,21 @@ __global__ void k_revcomp(const uint8_t *fwd, uint8_t *rev, const uint32_t *read
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) rev[o + k] = kComp4[fwd[o + n - 1 - k] & 0xF];
 }
 
+// Once per index: a bit per k-mer (its low 22 bits: exact up to -L 11, a filter above) that has a reference offset below 2^15 anywhere in its list -- the only
+// lists whose first offset can be below a query offset (QueryMatch.c:56-69).  One pass over the offsets; the few that qualify find their k-mer by bisection.
+#define YD_LOW_BITS (1u << 22)
+__global__ void __launch_bounds__(256) k_low_offsets(const uint32_t *SO, uint32_t nKmerSlots /* 4^L */, const uint32_t *ROA, uint32_t total, uint32_t *low)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (uint64_t)gridDim.x * blockDim.x) {
+        if (ROA[j] >= 32768u) continue;
+        uint32_t lo = 0, hi = nKmerSlots;                                          // largest h with SO[h] <= j
+        while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (SO[mid] <= (uint32_t)j) lo = mid; else hi = mid; }
+        atomicOr(&low[(lo & (YD_LOW_BITS - 1u)) >> 5], 1u << (lo & 31u));
+    }
+}
+
 // A1: one workgroup per (read, strand); thread per k-mer start.  posS/posC are indexed by kmerOff[rs] + i.
-__global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const uint32_t *ROA, const uint32_t *kmerOff,
+__global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const uint32_t *ROA, const uint32_t *low, const uint32_t *kmerOff,
                               uint32_t *posS, uint32_t *posC, uint32_t *posRsI, unsigned int *parts)
 {
     const uint32_t rs = blockIdx.x; const uint32_t read = rs >> 1;
@@ -36,8 +49,11 @@ __global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const
             s = SO[h]; cnt = SO[h + 1] - s; lookups++;
             if (cnt > (uint32_t)P.maxHits) cnt = 0;
             if (cnt) {                                                            // QueryMatch.c:56-69: wrapping diagonals / read past the list
+                // (the walk only starts when the list's first offset is below i < 2^15: k_low_offsets marked the k-mers that have such an offset, for all others
+                // the list is not touched here -- it was a second scattered line per k-mer in a kernel that runs at the chip's rate of scattered lines)
                 uint32_t w = 0;
-                while (s + w < P.totalMatches && ROA[s + w] < (uint32_t)i) w++;
+                if ((low[(h & (YD_LOW_BITS - 1u)) >> 5] >> (h & 31u)) & 1u)
+                    while (s + w < P.totalMatches && ROA[s + w] < (uint32_t)i) w++;
                 uint32_t eff = (w < cnt) ? cnt : w + 1;
                 if (s + eff > P.totalMatches) eff = P.totalMatches - s;
                 cnt = eff;
@@ -67,35 +83,63 @@ __global__ void __launch_bounds__(1024) k_sum_parts(const unsigned int *parts, u
     if (threadIdx.x == 0 && sSum) atomicAdd(counter, sSum);
 }
 
-// A2a: thread per hit -> 64-bit key  rs(17) | diag(32) | qo(15).  A block owns 1024 consecutive hits; they belong to at most
-// 1025 consecutive k-mers, whose offsets are staged in LDS: one global binary search per block, then LDS-only searches.
+// A2a: thread per hit -> 64-bit key  rs(17) | diag(32) | qo(15).  A block owns 1024 consecutive hits; they belong to at most 1025 consecutive k-mers with hits,
+// whose offsets, list starts and (read, strand, offset) words are staged in LDS.  The k-mer of every hit without a search: each k-mer of the window marks
+// the slot of its first hit, a running maximum over the 1024 slots carries the mark forward (four slots per thread, one scan per wave, four waves).  The first
+// k-mer of every block comes from k_expand_starts (one thread per k-mer writes the blocks that begin inside its list; a binary search over all k-mers by one
+// thread per block was most of a block's life: 25 dependent loads).  Each thread then has four independent list reads in flight.
 #define YD_EXPAND_HITS 1024
-__global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
+__global__ void k_expand_starts(const uint32_t *hitOff, uint32_t nKmers, uint32_t *blockG0)
 {
-    __shared__ uint32_t sOff[YD_EXPAND_HITS + 2]; __shared__ uint32_t sG0;
-    const uint32_t t0 = blockIdx.x * YD_EXPAND_HITS;
-    if (threadIdx.x == 0) {                                                       // largest g with hitOff[g] <= t0
-        uint32_t lo = 0, hi = nKmers;
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= t0) lo = mid; else hi = mid; }
-        sG0 = lo;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nKmers) return;
+    const uint32_t a = hitOff[g], b = hitOff[g + 1u];
+    for (uint32_t blk = (a + (uint32_t)YD_EXPAND_HITS - 1u) / (uint32_t)YD_EXPAND_HITS; (unsigned long long)blk * YD_EXPAND_HITS < b; blk++) blockG0[blk] = g;
+}
+__global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, const uint32_t *blockG0, uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
+{
+    __shared__ uint32_t sOff[YD_EXPAND_HITS + 2], sS[YD_EXPAND_HITS + 2], sRsI[YD_EXPAND_HITS + 2]; __shared__ __attribute__((aligned(16))) uint32_t sK[YD_EXPAND_HITS]; __shared__ uint32_t sWave[4];
+    const uint32_t t0 = blockIdx.x * YD_EXPAND_HITS, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t g0 = blockG0[blockIdx.x], span = min(nKmers + 1u - g0, (uint32_t)YD_EXPAND_HITS + 2u);          // hitOff has nKmers + 1 entries
+    for (uint32_t k = tid; k < span; k += 256u) { sOff[k] = hitOff[g0 + k]; sS[k] = posS[g0 + k]; sRsI[k] = posRsI[g0 + k]; }
+    *(uint4 *)&sK[4u * tid] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    for (uint32_t k = 1u + tid; k + 1u < span; k += 256u) { const uint32_t o = sOff[k]; if (o > t0 && o - t0 < (uint32_t)YD_EXPAND_HITS && sOff[k + 1u] > o) sK[o - t0] = k; }
+    __syncthreads();
+    {
+        const uint4 v = *(const uint4 *)&sK[4u * tid];
+        const uint32_t a0 = v.x, a1 = max(a0, v.y), a2 = max(a1, v.z), a3 = max(a2, v.w);
+        const uint32_t incl = waveInclMaxU(a3), excl = (uint32_t)laneUp1((int)incl, 0);
+        if (lane == 63u) sWave[w] = incl;
+        __syncthreads();
+        uint32_t carry = excl;
+        for (uint32_t k = 0; k < w; k++) carry = max(carry, sWave[k]);
+        *(uint4 *)&sK[4u * tid] = make_uint4(max(carry, a0), max(carry, a1), max(carry, a2), max(carry, a3));
     }
     __syncthreads();
-    const uint32_t g0 = sG0, span = min(nKmers + 1u - g0, (uint32_t)YD_EXPAND_HITS + 2u);          // hitOff has nKmers + 1 entries
-    for (uint32_t k = threadIdx.x; k < span; k += blockDim.x) sOff[k] = hitOff[g0 + k];
-    __syncthreads();
-    for (uint32_t t = t0 + threadIdx.x; t < min(t0 + (uint32_t)YD_EXPAND_HITS, nHits); t += blockDim.x) {
-        uint32_t lo = 0, hi = span;                                                // largest k with sOff[k] <= t (k-mers without hits repeat an offset)
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sOff[mid] <= t) lo = mid; else hi = mid; }
-        uint32_t g = g0 + lo;
-        if (lo == span - 1u && g + 1u < nKmers) {                                  // long run of k-mers without hits: the window ended early
-            uint32_t l2 = g, h2 = nKmers;
-            while (h2 - l2 > 1) { uint32_t mid = (l2 + h2) >> 1; if (hitOff[mid] <= t) l2 = mid; else h2 = mid; }
-            g = l2;
+    const uint32_t endOff = g0 + span - 1u >= nKmers ? nHits : sOff[span - 1u];          // hits from here on belong to k-mers behind the window (long runs of k-mers without hits)
+    uint32_t at[4], rsi[4]; bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t p = tid + 256u * (uint32_t)i, t = t0 + p; in[i] = t < nHits; at[i] = 0; rsi[i] = 0;
+        if (!in[i]) continue;
+        const uint32_t k = sK[p];
+        uint32_t off = sOff[k], s = sS[k]; rsi[i] = sRsI[k];
+        if (t >= endOff) {
+            uint32_t l2 = g0 + span - 1u, h2 = nKmers;                                  // largest g with hitOff[g] <= t
+            while (h2 - l2 > 1) { const uint32_t mid = (l2 + h2) >> 1; if (hitOff[mid] <= t) l2 = mid; else h2 = mid; }
+            off = hitOff[l2]; s = posS[l2]; rsi[i] = posRsI[l2];
         }
-        const uint32_t j = t - hitOff[g], rsi = posRsI[g];
-        const uint32_t i = rsi & 0x7FFFu, rs = rsi >> 15;
-        const uint32_t roff = ROA[posS[g] + j];
-        keys[t] = ((unsigned long long)rs << 47) | ((unsigned long long)(uint32_t)(roff - i) << 15) | (unsigned long long)i;
+        at[i] = s + (t - off);
+    }
+    uint32_t roff[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) roff[i] = in[i] ? ROA[at[i]] : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (!in[i]) continue;
+        const uint32_t q = rsi[i] & 0x7FFFu, rs = rsi[i] >> 15;
+        keys[t0 + tid + 256u * (uint32_t)i] = ((unsigned long long)rs << 47) | ((unsigned long long)(uint32_t)(roff[i] - q) << 15) | (unsigned long long)q;
     }
 }
 

@@ -72,14 +72,14 @@ const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regi
 
 struct ygpu_ctx {
     int device = 0; hipStream_t stream = nullptr; DevParams P{}; std::string err; int nCU = 256;
-    DevBuf dBases, dSO, dROA;
+    DevBuf dBases, dSO, dROA, dLow;
     // batch
     uint32_t nReads = 0; int maxQ = 0; uint64_t totalBases = 0; uint32_t nKmers = 0;
     std::vector<uint32_t> hReadOff, hKmerOff;
     DevBuf dFwd, dRev, dReadOff, dKmerOff;
     // arenas
     DevBuf bigB, bigE;
-    DevBuf posS, posC, posRsI, hitOff, keysA, keysB, segOff, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
+    DevBuf posS, posC, posRsI, hitOff, expandStart, keysA, keysB, segOff, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
@@ -164,7 +164,7 @@ static int stageSeed(ygpu_ctx *ctx)
     ENSURE(ctx->posS, 4ull * (K + 1)); ENSURE(ctx->posC, 4ull * (K + 1)); ENSURE(ctx->posRsI, 4ull * (K + 1)); ENSURE(ctx->hitOff, 4ull * (K + 1));
     HIPCHK(hipMemsetAsync(ctx->posC.p, 0, 4ull * (K + 1), ctx->stream));
     ENSURE(ctx->kmerParts, 4096); HIPCHK(hipMemsetAsync(ctx->kmerParts.p, 0, 4096, ctx->stream));
-    KL(k_kmer_lookup, dim3(2 * n), dim3(128), 0, ctx->stream, ctx->P, B, ctx->dSO.as<uint32_t>(), ctx->dROA.as<uint32_t>(), ctx->dKmerOff.as<uint32_t>(),
+    KL(k_kmer_lookup, dim3(2 * n), dim3(128), 0, ctx->stream, ctx->P, B, ctx->dSO.as<uint32_t>(), ctx->dROA.as<uint32_t>(), ctx->dLow.as<uint32_t>(), ctx->dKmerOff.as<uint32_t>(),
                        ctx->posS.as<uint32_t>(), ctx->posC.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), ctx->kmerParts.as<unsigned int>());
     KL(k_sum_parts, dim3(1), dim3(1024), 0, ctx->stream, ctx->kmerParts.as<unsigned int>(), ctx->ctr.as<DevCounters>()->v + C_KMER);
     int rc = cubScan(ctx, ctx->posC.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), K + 1); if (rc) return rc;
@@ -175,7 +175,9 @@ static int stageSeed(ygpu_ctx *ctx)
     if (H > 0x7FFFFFF0u) { ctx->err = "too many seed hits in one batch; use a smaller batch"; return YGPU_EOVERFLOW; }
     EV0(T_SORT);
     ENSURE(ctx->keysA, 8ull * H); ENSURE(ctx->keysB, 8ull * H);
-    KL(k_expand_hits, dim3(gridFor(H, YD_EXPAND_HITS)), dim3(256), 0, ctx->stream, ctx->dROA.as<uint32_t>(), ctx->posS.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), K, H, ctx->keysA.as<unsigned long long>());
+    ENSURE(ctx->expandStart, 4ull * gridFor(H, YD_EXPAND_HITS));
+    KL(k_expand_starts, dim3(gridFor(K, 256)), dim3(256), 0, ctx->stream, ctx->hitOff.as<uint32_t>(), K, ctx->expandStart.as<uint32_t>());
+    KL(k_expand_hits, dim3(gridFor(H, YD_EXPAND_HITS)), dim3(256), 0, ctx->stream, ctx->dROA.as<uint32_t>(), ctx->posS.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), ctx->expandStart.as<uint32_t>(), K, H, ctx->keysA.as<unsigned long long>());
     {
         // The sort is stable and k_expand_hits writes the hits of one (read, strand) in ascending query offset (k-mers in order, each
         // k-mer's reference offsets ascending), so two hits of one diagonal are already in qo order: the low 15 key bits need no pass.
@@ -822,6 +824,9 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     }
     ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
     HIPCHK(streamSync(ctx));
+    ENSURE(ctx->dLow, YD_LOW_BITS / 8); HIPCHK(hipMemsetAsync(ctx->dLow.p, 0, YD_LOW_BITS / 8, ctx->stream));
+    if (ix->totalMatches) KL(k_low_offsets, dim3((unsigned)std::min<uint64_t>(gridFor(ix->totalMatches, 256), (uint64_t)ctx->nCU * 64)), dim3(256), 0, ctx->stream, ctx->dSO.as<uint32_t>(), (uint32_t)HT, ctx->dROA.as<uint32_t>(), (uint32_t)ix->totalMatches, ctx->dLow.as<uint32_t>());
+    HIPCHK(streamSync(ctx));
     return 0;
 }
 
@@ -835,7 +840,7 @@ int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
     ygpu_ctx *ctx = new ygpu_ctx; *out = ctx; ctx->device = parent->device;
     int rc = initCommon(ctx, parent->device); if (rc) return rc;
     ctx->P = parent->P;
-    ctx->dBases.p = parent->dBases.p; ctx->dBases.cap = parent->dBases.cap; ctx->dSO.p = parent->dSO.p; ctx->dSO.cap = parent->dSO.cap; ctx->dROA.p = parent->dROA.p; ctx->dROA.cap = parent->dROA.cap;
+    ctx->dBases.p = parent->dBases.p; ctx->dBases.cap = parent->dBases.cap; ctx->dSO.p = parent->dSO.p; ctx->dSO.cap = parent->dSO.cap; ctx->dROA.p = parent->dROA.p; ctx->dROA.cap = parent->dROA.cap; ctx->dLow.p = parent->dLow.p; ctx->dLow.cap = parent->dLow.cap;
     ctx->sharedIndex = true;
     ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
     HIPCHK(streamSync(ctx));
@@ -849,8 +854,8 @@ void ygpu_destroy(ygpu_ctx *ctx)
     if (ctx->counted) gCtxPerDevice[ctx->device & 63]--;
     if (ctx->stream) {
         hipSetDevice(ctx->device);
-        if (ctx->sharedIndex) { ctx->dBases.p = nullptr; ctx->dBases.cap = 0; ctx->dSO.p = nullptr; ctx->dSO.cap = 0; ctx->dROA.p = nullptr; ctx->dROA.cap = 0; }
-        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->scanOut,
+        if (ctx->sharedIndex) { ctx->dBases.p = nullptr; ctx->dBases.cap = 0; ctx->dSO.p = nullptr; ctx->dSO.cap = 0; ctx->dROA.p = nullptr; ctx->dROA.cap = 0; ctx->dLow.p = nullptr; ctx->dLow.cap = 0; }
+        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->scanOut,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
                          &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
