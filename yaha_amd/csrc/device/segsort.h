@@ -41,18 +41,27 @@ __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, u
     Store().store(out + b, keys, len, st.store);
 }
 
-// Size classes of the segments [segB[s], segE[s]): class c (0..3) = at most hi[c] hits -> lists[c] (the workgroup sorts above: one launch per class over exactly
-// its segments; launching every class over all segments and letting the wrong ones leave cost 0.1 ms per 10 000 workgroups of 128 KB of LDS); longer ones =
-// class 4 -> lists[4], and begin/end offsets for the library's segmented sort (every other segment empty there).  counts[0..4]; one atomic per wave and class.
-__global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segB, const uint32_t *segE, uint32_t nSeg, uint32_t hi0, uint32_t hi1, uint32_t hi2, uint32_t hi3,
+// Size classes of the segments [segB[s], segE[s]): class c (0..YD_SEG_NCLASS-1) = at most hi[c] hits -> lists[c] (the workgroup sorts above: one launch per class
+// over exactly its segments; launching every class over all segments and letting the wrong ones leave cost 0.1 ms per 10 000 workgroups of 128 KB of LDS); longer
+// ones = the last class -> lists[YD_SEG_NCLASS], and begin/end offsets for the library's segmented sort (every other segment empty there).  Twelve workgroup
+// shapes (a sort costs what its shape holds, not what the segment has: with four shapes a segment filled its workgroup to 75 % on average).
+// counts[0..YD_SEG_NCLASS]; one atomic per wave and class.
+#define YD_SEG_NCLASS 12
+struct SegClassHi { uint32_t hi[YD_SEG_NCLASS]; };
+__global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segB, const uint32_t *segE, uint32_t nSeg, SegClassHi H,
                                                       uint32_t *lists, uint32_t *bigB, uint32_t *bigE, unsigned int *counts)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63u);
     uint32_t b = 0, e = 0; int cls = -1;
-    if (s < nSeg) { b = segB[s]; e = segE[s]; const uint32_t len = e - b; cls = len == 0 ? -1 : (len <= hi0 ? 0 : (len <= hi1 ? 1 : (len <= hi2 ? 2 : (len <= hi3 ? 3 : 4)))); }
-    if (s < nSeg) { bigB[s] = cls == 4 ? b : 0u; bigE[s] = cls == 4 ? e : 0u; }
+    if (s < nSeg) {
+        b = segB[s]; e = segE[s]; const uint32_t len = e - b;
+        if (len) { cls = YD_SEG_NCLASS;
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
+            for (int c = YD_SEG_NCLASS - 1; c >= 0; c--) if (len <= H.hi[c]) cls = c; }
+        bigB[s] = cls == YD_SEG_NCLASS ? b : 0u; bigE[s] = cls == YD_SEG_NCLASS ? e : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c <= YD_SEG_NCLASS; c++) {
         const unsigned long long m = __ballot(cls == c);
         if (m == 0ull) continue;                                             // wave-uniform
         unsigned base = 0; const int first = __builtin_ctzll(m);

@@ -63,7 +63,7 @@ struct DevBuf {
     int ensureExact(size_t bytes) { if (bytes <= cap) return 0; release(); void *np = nullptr; if (hipMalloc(&np, bytes) != hipSuccess) return -1; p = np; cap = bytes; return 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* five: the segments of the four workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 5, CNT_N = CNT_NFRAGS + 3 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* YD_SEG_NCLASS + 1: the segments of the workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 16, CNT_N = CNT_NFRAGS + 3 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_XROWS_PK, T_N };
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
@@ -187,49 +187,57 @@ static int stageSeed(ygpu_ctx *ctx)
             ENSURE(ctx->segOff, 4ull * (2 * n + 2));
             KL(k_seg_offsets, dim3(gridFor(2 * n + 1, 256)), dim3(256), 0, ctx->stream, ctx->dKmerOff.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), 2 * n, ctx->segOff.as<uint32_t>());
             if (ctx->segSort >= 2) {
-                // segments of up to 16 384 hits: one workgroup each (segsort.h), in four size classes, one launch per class over exactly its segments
+                // segments of up to 16 384 hits: one workgroup each (segsort.h), in twelve size classes, one launch per class over exactly its segments
                 const unsigned long long *in = ctx->keysA.as<unsigned long long>(); unsigned long long *out = ctx->keysB.as<unsigned long long>(); const uint32_t *so = ctx->segOff.as<uint32_t>();
-                ENSURE(ctx->bigB, 4ull * (2 * n + 1)); ENSURE(ctx->bigE, 4ull * (2 * n + 1)); ENSURE(ctx->segLists, 20ull * (2 * n + 1));
+                ENSURE(ctx->bigB, 4ull * (2 * n + 1)); ENSURE(ctx->bigE, 4ull * (2 * n + 1)); ENSURE(ctx->segLists, 4ull * (YD_SEG_NCLASS + 1) * (2 * n + 1));
                 uint32_t *segCnt = ctx->counters.as<uint32_t>() + CNT_SEGC;
-                HIPCHK(hipMemsetAsync(segCnt, 0, 20, ctx->stream));
                 const uint32_t mx = ctx->segSortMax;                                  // YD_SEGSORT_MAX; lower only to drive the long-segment path in tests
-                const uint32_t hi0 = std::min(mx, 1024u), hi1 = std::min(mx, 4096u), hi2 = std::min(mx, 8192u), hi3 = std::min(mx, 16384u);
+                // threads x hits a thread: 128 x 8, 128 x 16, 256 x 12 / 16, 512 x 10 / 12 / 14 / 16, 1024 x 10 / 12 / 14 / 16 (384 and 768 threads x 16 sorted slower than the next shape up)
+                static const uint32_t kShape[YD_SEG_NCLASS] = {1024u, 2048u, 3072u, 4096u, 5120u, 6144u, 7168u, 8192u, 10240u, 12288u, 14336u, 16384u};
+                SegClassHi HI; for (int c = 0; c < YD_SEG_NCLASS; c++) HI.hi[c] = std::min(mx, kShape[c]);
+                // one launch per class over exactly its segments: in[inB..inE) sorted into out[inB..)
+                auto sortClasses = [&](const unsigned long long *src, unsigned long long *dst, const uint32_t *sB, const uint32_t *sE, uint32_t nSeg, const uint32_t *lists, const uint32_t *nc) -> int {
+#define YD_SORT_CLASS(c, BS, IPT) if (nc[c]) KL((k_seg_sort<BS, IPT>), dim3(nc[c]), dim3(BS), 0, ctx->stream, src, dst, sB, sE, lists + (size_t)(c) * nSeg)
+                    YD_SORT_CLASS(11, 1024, 16); YD_SORT_CLASS(10, 1024, 14); YD_SORT_CLASS(9, 1024, 12); YD_SORT_CLASS(8, 1024, 10);
+                    YD_SORT_CLASS(7, 512, 16); YD_SORT_CLASS(6, 512, 14); YD_SORT_CLASS(5, 512, 12); YD_SORT_CLASS(4, 512, 10);
+                    YD_SORT_CLASS(3, 256, 16); YD_SORT_CLASS(2, 256, 12); YD_SORT_CLASS(1, 128, 16); YD_SORT_CLASS(0, 128, 8);
+#undef YD_SORT_CLASS
+                    return 0;
+                };
+                HIPCHK(hipMemsetAsync(segCnt, 0, 4 * (YD_SEG_NCLASS + 1), ctx->stream));
                 uint32_t *lists = ctx->segLists.as<uint32_t>();
-                KL(k_seg_classify, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, so + 1, 2 * n, hi0, hi1, hi2, hi3, lists, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), segCnt);
-                uint32_t nc[5] = {0, 0, 0, 0, 0}; rc = fetchU32(ctx, segCnt, nc, 5); if (rc) return rc;
-                if (nc[3]) KL((k_seg_sort<1024, 16>), dim3(nc[3]), dim3(1024), 0, ctx->stream, in, out, so, so + 1, lists + 3ull * (2 * n));
-                if (nc[2]) KL((k_seg_sort<512, 16>), dim3(nc[2]), dim3(512), 0, ctx->stream, in, out, so, so + 1, lists + 2ull * (2 * n));
-                if (nc[1]) KL((k_seg_sort<256, 16>), dim3(nc[1]), dim3(256), 0, ctx->stream, in, out, so, so + 1, lists + 1ull * (2 * n));
-                if (nc[0]) KL((k_seg_sort<128, 8>), dim3(nc[0]), dim3(128), 0, ctx->stream, in, out, so, so + 1, lists);
-                const uint32_t nBig = nc[4];
-                if (kTrace) { std::vector<uint32_t> so2(2 * (size_t)n + 1); hipMemcpy(so2.data(), so, 4ull * (2 * n + 1), hipMemcpyDeviceToHost); unsigned long long hb = 0, mxl = 0, c8 = 0, c4 = 0, c1 = 0, c0 = 0;
-                    for (uint32_t k = 0; k < 2 * n; k++) { const unsigned long long l = so2[k + 1] - so2[k]; if (l > mx) { hb += l; mxl = std::max(mxl, l); } else if (l > 8192) c8 += l; else if (l > 4096) c4 += l; else if (l > 1024) c1 += l; else c0 += l; }
-                    fprintf(stderr, "[ygpu] hit sort: %u hits; segments above %u hits: %u holding %llu hits (%.1f%%, longest %llu); classes 8k-16k %.1f%%, 4k-8k %.1f%%, 1k-4k %.1f%%, <=1k %.1f%%\n", H, mx, nBig, hb, 100.0 * hb / H, mxl, 100.0 * c8 / H, 100.0 * c4 / H, 100.0 * c1 / H, 100.0 * c0 / H); }
+                KL(k_seg_classify, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, so + 1, 2 * n, HI, lists, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), segCnt);
+                uint32_t nc[YD_SEG_NCLASS + 1] = {0}; rc = fetchU32(ctx, segCnt, nc, YD_SEG_NCLASS + 1); if (rc) return rc;
+                rc = sortClasses(in, out, so, so + 1, 2 * n, lists, nc); if (rc) return rc;
+                const uint32_t nBig = nc[YD_SEG_NCLASS];
+                if (kTrace) { std::vector<uint32_t> so2(2 * (size_t)n + 1); hipMemcpy(so2.data(), so, 4ull * (2 * n + 1), hipMemcpyDeviceToHost); unsigned long long hb = 0, mxl = 0, cl[YD_SEG_NCLASS] = {0};
+                    for (uint32_t k = 0; k < 2 * n; k++) { const unsigned long long l = so2[k + 1] - so2[k]; if (l > mx) { hb += l; mxl = std::max(mxl, l); } else for (int c = 0; c < YD_SEG_NCLASS; c++) if (l <= HI.hi[c]) { cl[c] += l; break; } }
+                    fprintf(stderr, "[ygpu] hit sort: %u hits; segments above %u hits: %u holding %llu hits (%.1f%%, longest %llu); %% of the hits by class:", H, mx, nBig, hb, 100.0 * hb / H, mxl);
+                    for (int c = 0; c < YD_SEG_NCLASS; c++) fprintf(stderr, " <=%u: %.1f", HI.hi[c], 100.0 * cl[c] / H);
+                    fprintf(stderr, "\n"); }
                 if (nBig) {
                     // long segments: cut by diagonal into buckets that fit the workgroup sort (k_seg_split: keysA -> keysB), the buckets sorted in place; what still
                     // does not fit (a bucket above the limit) goes through the library's segmented sort (keysB -> keysA) and is copied back
                     const uint32_t nSub = nBig * YD_SPLIT_NB;
-                    ENSURE(ctx->subB, 4ull * nSub + 64); ENSURE(ctx->subE, 4ull * nSub + 64); ENSURE(ctx->subLists, 20ull * nSub + 64); ENSURE(ctx->subBigB, 4ull * nSub + 64); ENSURE(ctx->subBigE, 4ull * nSub + 64);
+                    ENSURE(ctx->subB, 4ull * nSub + 64); ENSURE(ctx->subE, 4ull * nSub + 64); ENSURE(ctx->subLists, 4ull * (YD_SEG_NCLASS + 1) * nSub + 64); ENSURE(ctx->subBigB, 4ull * nSub + 64); ENSURE(ctx->subBigE, 4ull * nSub + 64);
                     int diagBits = 1; while (diagBits < 32 && (ctx->P.maxROff >> diagBits)) diagBits++;
                     uint32_t *sB = ctx->subB.as<uint32_t>(), *sE = ctx->subE.as<uint32_t>(), *l2 = ctx->subLists.as<uint32_t>();
-                    KL(k_seg_split, dim3(nBig), dim3(1024), 0, ctx->stream, in, out, so, so + 1, lists + 4ull * (2 * n), diagBits, sB, sE);
-                    HIPCHK(hipMemsetAsync(segCnt, 0, 20, ctx->stream));
-                    KL(k_seg_classify, dim3(gridFor(nSub, 256)), dim3(256), 0, ctx->stream, sB, sE, nSub, hi0, hi1, hi2, hi3, l2, ctx->subBigB.as<uint32_t>(), ctx->subBigE.as<uint32_t>(), segCnt);
-                    uint32_t ns[5] = {0, 0, 0, 0, 0}; rc = fetchU32(ctx, segCnt, ns, 5); if (rc) return rc;
-                    if (ns[3]) KL((k_seg_sort<1024, 16>), dim3(ns[3]), dim3(1024), 0, ctx->stream, out, out, sB, sE, l2 + 3ull * nSub);
-                    if (ns[2]) KL((k_seg_sort<512, 16>), dim3(ns[2]), dim3(512), 0, ctx->stream, out, out, sB, sE, l2 + 2ull * nSub);
-                    if (ns[1]) KL((k_seg_sort<256, 16>), dim3(ns[1]), dim3(256), 0, ctx->stream, out, out, sB, sE, l2 + 1ull * nSub);
-                    if (ns[0]) KL((k_seg_sort<128, 8>), dim3(ns[0]), dim3(128), 0, ctx->stream, out, out, sB, sE, l2);
-                    if (kTrace) fprintf(stderr, "[ygpu] hit sort: %u long segments cut into buckets: %u / %u / %u / %u in the workgroup classes, %u left to the library\n", nBig, ns[0], ns[1], ns[2], ns[3], ns[4]);
-                    if (ns[4]) {
+                    KL(k_seg_split, dim3(nBig), dim3(1024), 0, ctx->stream, in, out, so, so + 1, lists + (size_t)YD_SEG_NCLASS * (2 * n), diagBits, sB, sE);
+                    HIPCHK(hipMemsetAsync(segCnt, 0, 4 * (YD_SEG_NCLASS + 1), ctx->stream));
+                    KL(k_seg_classify, dim3(gridFor(nSub, 256)), dim3(256), 0, ctx->stream, sB, sE, nSub, HI, l2, ctx->subBigB.as<uint32_t>(), ctx->subBigE.as<uint32_t>(), segCnt);
+                    uint32_t ns[YD_SEG_NCLASS + 1] = {0}; rc = fetchU32(ctx, segCnt, ns, YD_SEG_NCLASS + 1); if (rc) return rc;
+                    rc = sortClasses(out, out, sB, sE, nSub, l2, ns); if (rc) return rc;
+                    const uint32_t nLib = ns[YD_SEG_NCLASS];
+                    if (kTrace) { fprintf(stderr, "[ygpu] hit sort: %u long segments cut into buckets, by class:", nBig); for (int c = 0; c < YD_SEG_NCLASS; c++) fprintf(stderr, " %u", ns[c]); fprintf(stderr, "; %u left to the library\n", nLib); }
+                    if (nLib) {
                         unsigned long long *tmp = ctx->keysA.as<unsigned long long>();
-                        uint32_t *cB = ctx->subBigB.as<uint32_t>(), *cE = ctx->subBigE.as<uint32_t>();           // compact bounds of the ns[4] buckets that did not fit
-                        KL(k_seg_gather_bounds, dim3(gridFor(ns[4], 256)), dim3(256), 0, ctx->stream, sB, sE, l2 + 4ull * nSub, ns[4], cB, cE);
+                        uint32_t *cB = ctx->subBigB.as<uint32_t>(), *cE = ctx->subBigE.as<uint32_t>();           // compact bounds of the buckets that did not fit
+                        KL(k_seg_gather_bounds, dim3(gridFor(nLib, 256)), dim3(256), 0, ctx->stream, sB, sE, l2 + (size_t)YD_SEG_NCLASS * nSub, nLib, cB, cE);
                         size_t bytes = 0;
-                        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, (const unsigned long long *)out, tmp, (int)H, (int)ns[4], cB, cE, 15, 47, ctx->stream));
+                        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, (const unsigned long long *)out, tmp, (int)H, (int)nLib, cB, cE, 15, 47, ctx->stream));
                         if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-                        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, (const unsigned long long *)out, tmp, (int)H, (int)ns[4], cB, cE, 15, 47, ctx->stream));
-                        KL(k_seg_copy_back, dim3(ns[4]), dim3(256), 0, ctx->stream, tmp, out, sB, sE, l2 + 4ull * nSub);
+                        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, (const unsigned long long *)out, tmp, (int)H, (int)nLib, cB, cE, 15, 47, ctx->stream));
+                        KL(k_seg_copy_back, dim3(nLib), dim3(256), 0, ctx->stream, tmp, out, sB, sE, l2 + (size_t)YD_SEG_NCLASS * nSub);
                     }
                 }
             } else {
