@@ -94,13 +94,15 @@ __global__ void k_expand_starts(const uint32_t *hitOff, uint32_t nKmers, uint32_
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nKmers) return;
     const uint32_t a = hitOff[g], b = hitOff[g + 1u];
+    if (g == 0u) blockG0[(hitOff[nKmers] + (uint32_t)YD_EXPAND_HITS - 1u) / (uint32_t)YD_EXPAND_HITS] = nKmers;       // behind the last block: the end of the k-mers
     for (uint32_t blk = (a + (uint32_t)YD_EXPAND_HITS - 1u) / (uint32_t)YD_EXPAND_HITS; (unsigned long long)blk * YD_EXPAND_HITS < b; blk++) blockG0[blk] = g;
 }
 __global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, const uint32_t *blockG0, uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
 {
     __shared__ uint32_t sOff[YD_EXPAND_HITS + 2], sS[YD_EXPAND_HITS + 2], sRsI[YD_EXPAND_HITS + 2]; __shared__ __attribute__((aligned(16))) uint32_t sK[YD_EXPAND_HITS]; __shared__ uint32_t sWave[4];
     const uint32_t t0 = blockIdx.x * YD_EXPAND_HITS, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t g0 = blockG0[blockIdx.x], span = min(nKmers + 1u - g0, (uint32_t)YD_EXPAND_HITS + 2u);          // hitOff has nKmers + 1 entries
+    // the window: from this block's first k-mer to the next block's (k-mers without hits in between included), at most 1026 offsets (hitOff has nKmers + 1 entries)
+    const uint32_t g0 = blockG0[blockIdx.x], span = min(min(nKmers + 1u - g0, blockG0[blockIdx.x + 1u] + 2u - g0), (uint32_t)YD_EXPAND_HITS + 2u);
     for (uint32_t k = tid; k < span; k += 256u) { sOff[k] = hitOff[g0 + k]; sS[k] = posS[g0 + k]; sRsI[k] = posRsI[g0 + k]; }
     *(uint4 *)&sK[4u * tid] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();

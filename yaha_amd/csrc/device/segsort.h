@@ -18,27 +18,32 @@
 template <unsigned BS, unsigned IPT>
 __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
 {
-    using Load = rocprim::block_load<unsigned long long, BS, IPT, rocprim::block_load_method::block_load_transpose>;
-    using Store = rocprim::block_store<unsigned long long, BS, IPT, rocprim::block_store_method::block_store_transpose>;
     using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t>;
-    __shared__ union { typename Load::storage_type load; typename Store::storage_type store; typename Sort::storage_type sort; } st;
+    __shared__ typename Sort::storage_type st;
     const uint32_t seg = list[blockIdx.x];                                   // the segments of this launch's size class (k_seg_classify)
     const uint32_t b = segB[seg], len = segE[seg] - b;
     const unsigned long long rs = in[b] & ~((1ull << 47) - 1ull);            // the (read, strand) bits: the same in every key of a segment
-    unsigned long long keys[IPT];
-    // blocked arrangement = the order the hits were written in; the padding keys sort last and, the sort being stable, stay behind real keys with the same bits
-    // (in == out is fine: the workgroup has read its whole segment before it stores)
-    Load().load(in + b, keys, len, ~0ull, st.load);
-    __syncthreads();
-    // what moves through the sort's LDS passes is the 32-bit diagonal with the 15-bit query offset as payload (6 bytes a hit instead of 8)
+    // The library's ranking works on a wave-striped arrangement (wave w holds the items [w * 64 * IPT, (w + 1) * 64 * IPT), item k of lane l = k * 64 + l of
+    // them) and can leave the result striped over the workgroup (item k of thread t = k * BS + t): both are what coalesced loads and stores give, so the keys
+    // go from HBM to registers to HBM without the two transpositions through LDS that the blocked arrangement needs (in == out is fine: the workgroup has
+    // read its whole segment before it stores).  The order of the hits = the index in that arrangement; the padding keys sort last and, the sort being
+    // stable, stay behind real keys with the same bits.
+    // What moves through the sort's LDS passes is the 32-bit diagonal with the 15-bit query offset as payload (6 bytes a hit instead of 8).
     uint32_t dg[IPT]; uint16_t qo[IPT];
+    const uint32_t w0 = (threadIdx.x >> 6) * (64u * IPT) + (threadIdx.x & 63u);
 #pragma unroll
-    for (unsigned k = 0; k < IPT; k++) { dg[k] = (uint32_t)(keys[k] >> 15); qo[k] = (uint16_t)(keys[k] & 0x7FFFull); }
-    Sort().sort(dg, qo, st.sort, 0, 32);
+    for (unsigned k = 0; k < IPT; k++) {
+        const uint32_t idx = w0 + k * 64u;
+        const unsigned long long key = idx < len ? in[b + idx] : ~0ull;
+        dg[k] = (uint32_t)(key >> 15); qo[k] = (uint16_t)(key & 0x7FFFull);
+    }
     __syncthreads();
+    Sort().sort_warp_striped_to_striped(dg, qo, st, 0, 32);
 #pragma unroll
-    for (unsigned k = 0; k < IPT; k++) keys[k] = rs | ((unsigned long long)dg[k] << 15) | (unsigned long long)qo[k];
-    Store().store(out + b, keys, len, st.store);
+    for (unsigned k = 0; k < IPT; k++) {
+        const uint32_t idx = k * BS + threadIdx.x;
+        if (idx < len) out[b + idx] = rs | ((unsigned long long)dg[k] << 15) | (unsigned long long)qo[k];
+    }
 }
 
 // Size classes of the segments [segB[s], segE[s]): class c (0..YD_SEG_NCLASS-1) = at most hi[c] hits -> lists[c] (the workgroup sorts above: one launch per class

@@ -175,7 +175,7 @@ static int stageSeed(ygpu_ctx *ctx)
     if (H > 0x7FFFFFF0u) { ctx->err = "too many seed hits in one batch; use a smaller batch"; return YGPU_EOVERFLOW; }
     EV0(T_SORT);
     ENSURE(ctx->keysA, 8ull * H); ENSURE(ctx->keysB, 8ull * H);
-    ENSURE(ctx->expandStart, 4ull * gridFor(H, YD_EXPAND_HITS));
+    ENSURE(ctx->expandStart, 4ull * (gridFor(H, YD_EXPAND_HITS) + 1));
     KL(k_expand_starts, dim3(gridFor(K, 256)), dim3(256), 0, ctx->stream, ctx->hitOff.as<uint32_t>(), K, ctx->expandStart.as<uint32_t>());
     KL(k_expand_hits, dim3(gridFor(H, YD_EXPAND_HITS)), dim3(256), 0, ctx->stream, ctx->dROA.as<uint32_t>(), ctx->posS.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), ctx->posRsI.as<uint32_t>(), ctx->expandStart.as<uint32_t>(), K, H, ctx->keysA.as<unsigned long long>());
     {
