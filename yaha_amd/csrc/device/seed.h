@@ -183,6 +183,29 @@ __device__ __forceinline__ uint32_t hitClass(const unsigned long long *keys, uin
     const bool dead = (maxGapDrop >= 0) & head & last & !nearA & !nearC;
     return (head ? 1u : 0u) | (last ? 2u : 0u) | (dead ? 4u : 0u);
 }
+// Decoupled look-back of a single-pass scan over tiles (one 64-bit state word per tile, zeroed before the launch: status in the high half -- 1 = the tile's own
+// count, 2 = its inclusive prefix -- and the value in the low half, so that both arrive together).  Called by one whole wave of tile `tile` with the tile's
+// count; returns the sum of the counts of all tiles before it.  Workgroups start in blockIdx order, so the tiles waited for are resident or finished.
+__device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, uint32_t tile, uint32_t agg, uint32_t lane)
+{
+    uint32_t excl = 0;
+    if (tile == 0u) { if (lane == 0u) __hip_atomic_store(&tileState[0], (2ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0u; }
+    if (lane == 0u) __hip_atomic_store(&tileState[tile], (1ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int back = (int)tile - 1;                                            // lane l looks at tile back - l
+    for (;;) {
+        const int j = back - (int)lane;
+        unsigned long long st = 2ull << 32;                              // before the first tile: a known prefix of zero
+        if (j >= 0) { do { st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st >> 32) == 0ull); }
+        const unsigned long long known = __ballot((st >> 32) == 2ull);
+        const int stop = __builtin_ctzll(known | (1ull << 63));          // the nearest tile that knows its prefix (lane 63 at the latest if any)
+        const bool use = known ? (int)lane <= stop : true;
+        excl += (uint32_t)waveSumI(use ? (int)(uint32_t)st : 0);
+        if (known) break;
+        back -= 64;
+    }
+    if (lane == 0u) __hip_atomic_store(&tileState[tile], (2ull << 32) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
 // the same from the three keys in registers
 __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned long long b, unsigned long long c, bool first, bool end, int wordLen, int maxGapDrop)
 {
@@ -255,24 +278,7 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
 #pragma unroll
         for (int e = 0; e < E; e++) sCnt[(int)lane * E + e] = incl - sum + v[e];
         const uint32_t agg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint32_t excl = 0;
-        if (tile == 0u) { if (lane == 0u) __hip_atomic_store(&tileState[0], (2ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        else {
-            if (lane == 0u) __hip_atomic_store(&tileState[tile], (1ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int back = (int)tile - 1;                                            // lane l looks at tile back - l
-            for (;;) {
-                const int j = back - (int)lane;
-                unsigned long long st = 2ull << 32;                              // before the first tile: a known prefix of zero
-                if (j >= 0) { do { st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st >> 32) == 0ull); }
-                const unsigned long long known = __ballot((st >> 32) == 2ull);
-                const int stop = __builtin_ctzll(known | (1ull << 63));          // the nearest tile that knows its prefix (lane 63 at the latest if any)
-                const bool use = known ? (int)lane <= stop : true;
-                excl += (uint32_t)waveSumI(use ? (int)(uint32_t)st : 0);
-                if (known) break;
-                back -= 64;
-            }
-            if (lane == 0u) __hip_atomic_store(&tileState[tile], (2ull << 32) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const uint32_t excl = tileLookBack(tileState, tile, agg, lane);
         if (lane == 0u) { sPrefix = excl; if (tile + 1u == gridDim.x) *total = excl + agg; }
     }
     __syncthreads();
@@ -308,24 +314,54 @@ __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
     frags[f].refLen = (uint16_t)(1 + (int)frags[f].eqo - (int)frags[f].sqo);      // setRefLen, FragsClumps.inl:44-47
 }
 
-// A3: region heads: consecutive fragments of one (read,strand) whose diagonals differ by <= maxGap (QueryMatch.c:146-158)
-__global__ void k_region_heads(const DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *isHead)
+// A3: regions = runs of consecutive fragments of one (read, strand) whose diagonals differ by <= maxGap (QueryMatch.c:146-158).  One pass over the fresh
+// fragment array: head flags, their exclusive scan (the look-back of k_frag_scan_build) and regStart[r] = first fragment of region r; the same pass sets
+// refLen (setRefLen, FragsClumps.inl:44-47), which needs the head's and the last hit's stores of the build kernel to have landed.  regStart[nRegions] = nFrags
+// is set by the host.  A tile = 4 waves x 8 rows of 64 fragments.
+#define YD_REG_IPT 8
+#define YD_REG_TILE (256 * YD_REG_IPT)
+__global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *regStart, unsigned long long *tileState, unsigned int *total)
 {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nFrags) return;
-    uint32_t head = 1;
-    if (f > 0) {
-        const DevFrag a = frags[f - 1], b = frags[f];
-        if (a.rs == b.rs) { const uint32_t da = a.sro - (uint32_t)a.sqo, db = b.sro - (uint32_t)b.sqo; head = absDiffU(da, db) > (uint32_t)maxGap; }
+    __shared__ uint32_t sCnt[4 * YD_REG_IPT]; __shared__ uint32_t sPrefix;
+    const uint32_t tile = blockIdx.x, t = threadIdx.x, lane = t & 63u, w = t >> 6, wbase = tile * (uint32_t)YD_REG_TILE + w * (uint32_t)(64 * YD_REG_IPT);
+    uint32_t rs[YD_REG_IPT], dg[YD_REG_IPT]; unsigned long long headMask[YD_REG_IPT];
+#pragma unroll
+    for (int k = 0; k < YD_REG_IPT; k++) {
+        const uint32_t f = wbase + (uint32_t)k * 64u + lane; rs[k] = 0xFFFFFFFFu; dg[k] = 0;
+        if (f < nFrags) {
+            const uint4 v = *(const uint4 *)&frags[f];                        // sro | sqo, eqo | refLen, used | rs
+            const uint32_t sqo = v.y & 0xFFFFu, eqo = v.y >> 16;
+            rs[k] = v.w; dg[k] = v.x - sqo;
+            frags[f].refLen = (uint16_t)(1u + eqo - sqo);
+        }
     }
-    isHead[f] = head;
-}
-// regStart[r] = first fragment of region r (regIdx = exclusive scan of isHead); regStart[nRegions] = nFrags set by host
-__global__ void k_region_starts(const uint32_t *isHead, const uint32_t *regIdx, uint32_t nFrags, uint32_t *regStart)
-{
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nFrags) return;
-    if (isHead[f]) regStart[regIdx[f]] = f;
+    uint32_t eRs = 0xFFFFFFFFu, eDg = 0;                                        // lane 0: the fragment before the wave's range
+    if (lane == 0u && wbase > 0u && wbase <= nFrags) { const DevFrag a = frags[wbase - 1u]; eRs = a.rs; eDg = a.sro - (uint32_t)a.sqo; }
+#pragma unroll
+    for (int k = 0; k < YD_REG_IPT; k++) {
+        const uint32_t f = wbase + (uint32_t)k * 64u + lane;
+        const uint32_t upRs = k > 0 ? rs[k - 1] : eRs, upDg = k > 0 ? dg[k - 1] : eDg;
+        const uint32_t a0rs = (uint32_t)__builtin_amdgcn_readlane((int)upRs, k > 0 ? 63 : 0), a0dg = (uint32_t)__builtin_amdgcn_readlane((int)upDg, k > 0 ? 63 : 0);
+        const uint32_t prs = (uint32_t)laneUp1((int)rs[k], (int)a0rs), pdg = (uint32_t)laneUp1((int)dg[k], (int)a0dg);
+        const bool head = f < nFrags && (f == 0u || prs != rs[k] || absDiffU(pdg, dg[k]) > (uint32_t)maxGap);
+        const unsigned long long m = __ballot(head); headMask[k] = m;
+        if (lane == 0u) sCnt[(int)w * YD_REG_IPT + k] = (uint32_t)__builtin_popcountll(m);
+    }
+    __syncthreads();
+    if (w == 0u) {
+        const uint32_t v = lane < 4u * YD_REG_IPT ? sCnt[lane] : 0u; uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
+        if (lane < 4u * YD_REG_IPT) sCnt[lane] = incl - v;
+        const uint32_t agg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t excl = tileLookBack(tileState, tile, agg, lane);
+        if (lane == 0u) { sPrefix = excl; if (tile + 1u == gridDim.x) *total = excl + agg; }
+    }
+    __syncthreads();
+    const uint32_t prefix = sPrefix; const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < YD_REG_IPT; k++)
+        if ((headMask[k] >> lane) & 1ull) regStart[prefix + sCnt[(int)w * YD_REG_IPT + k] + (uint32_t)__builtin_popcountll(headMask[k] & below)] = wbase + (uint32_t)k * 64u + lane;
 }
 // multi-fragment region list + largest region
 // smallList: regions with 2..8 fragments (k_chain_lanes); multiList: 9..64 (k_chain); bigList: more than 64 (k_chain_big)

@@ -63,7 +63,7 @@ struct DevBuf {
     int ensureExact(size_t bytes) { if (bytes <= cap) return 0; release(); void *np = nullptr; if (hipMalloc(&np, bytes) != hipSuccess) return -1; p = np; cap = bytes; return 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* YD_SEG_NCLASS + 1: the segments of the workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 16, CNT_N = CNT_NFRAGS + 3 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* YD_SEG_NCLASS + 1: the segments of the workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 16, CNT_NREG, CNT_N = CNT_NREG + 3 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_XROWS_PK, T_N };
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
@@ -260,7 +260,7 @@ static int stageSeed(ygpu_ctx *ctx)
 // (Re)creates the fragment array from the sorted keys -- the chain stage trims it in place, so a redo of that stage comes back here.  One kernel (seed.h:
 // k_frag_scan_build) counts and writes; the array is sized from the last batch's count, and a batch that needs more is run again with room (the first batch of
 // a context always is: its first pass only counts).
-static int buildFrags(ygpu_ctx *ctx)
+static int buildFrags(ygpu_ctx *ctx, bool redo = false)      // redo: the regions stand, only the records are rebuilt (refLen is otherwise set by k_region_scan)
 {
     const uint32_t H = ctx->nHits;
     ctx->nFrags = 0;
@@ -281,7 +281,7 @@ static int buildFrags(ygpu_ctx *ctx)
         ENSURE(ctx->frags, 16ull * ((uint64_t)F + F / 8 + 4096));
     }
     KL(k_sum_parts, dim3(1), dim3(1024), 0, ctx->stream, ctx->kmerParts.as<unsigned int>(), ctx->ctr.as<DevCounters>()->v + C_FRAGS);
-    if (ctx->nFrags) KL(k_frag_finish, dim3(gridFor(ctx->nFrags, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), ctx->nFrags);
+    if (ctx->nFrags && (redo || ctx->keepAllFrags)) KL(k_frag_finish, dim3(gridFor(ctx->nFrags, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), ctx->nFrags);
     return 0;
 }
 
@@ -293,16 +293,15 @@ static int stageChain(ygpu_ctx *ctx)
     int rc;
     // region boundaries (uses a second head/scan pair sized by F; the hit-level pair is still needed by buildFrags on a retry)
     ENSURE(ctx->regStart, 4ull * (F + 2)); ENSURE(ctx->multiList, 4ull * (F + 1)); ENSURE(ctx->smallList, 4ull * (F + 1)); ENSURE(ctx->bigList, 4ull * (F / 64 + 2)); ENSURE(ctx->regionCount, 4ull * (F + 2)); ENSURE(ctx->regionBase, 4ull * (F + 2));
-    DevBuf &rHead = ctx->rootPush, &rScan = ctx->rootBase;           // borrowed as temporaries (not yet in use at this point)
-    ENSURE(rHead, 4ull * (F + 1)); ENSURE(rScan, 4ull * (F + 1));
-    HIPCHK(hipMemsetAsync((uint32_t *)rHead.p + F, 0, 4, ctx->stream));
-    KL(k_region_heads, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, rHead.as<uint32_t>());
-    rc = cubScan(ctx, rHead.as<uint32_t>(), rScan.as<uint32_t>(), F + 1); if (rc) return rc;
-    uint32_t R = 0; rc = fetchU32(ctx, rScan.as<uint32_t>() + F, &R); if (rc) return rc;
-    ctx->nRegions = R;
-    KL(k_region_starts, dim3(gridFor(F, 256)), dim3(256), 0, ctx->stream, rHead.as<uint32_t>(), rScan.as<uint32_t>(), F, ctx->regStart.as<uint32_t>());
-    HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
+    // (the fragment scan's tile states are free again: reused for the region scan)
+    const uint32_t nRegTiles = (uint32_t)gridFor(F, YD_REG_TILE);
+    ENSURE(ctx->scanOut, 8ull * nRegTiles);
     uint32_t *cnt = ctx->counters.as<uint32_t>();
+    HIPCHK(hipMemsetAsync(ctx->scanOut.p, 0, 8ull * nRegTiles, ctx->stream));
+    KL(k_region_scan, dim3(nRegTiles), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, ctx->regStart.as<uint32_t>(), ctx->scanOut.as<unsigned long long>(), cnt + CNT_NREG);
+    uint32_t R = 0; rc = fetchU32(ctx, cnt + CNT_NREG, &R); if (rc) return rc;
+    ctx->nRegions = R;
+    HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NBIG, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NSMALL, 0, 4, ctx->stream));
     KL(k_region_classify, dim3(gridFor(R, 1024)), dim3(1024), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN, ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG, ctx->smallList.as<uint32_t>(), cnt + CNT_NSMALL);
     uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NMULTI, two, 2); if (rc) return rc;
@@ -343,7 +342,7 @@ static int stageChain(ygpu_ctx *ctx)
         if (ef == 0 && got[0] <= clumpCap && got[1] <= fragCap) { ctx->nClumpSlots = got[0]; ctx->nClumpFrags = got[1]; ctx->lastClumpSlots = got[0]; break; }
         if (attempt >= 6) { ctx->err = "chain stage: arena overflow persists"; return YGPU_EOVERFLOW; }
         if (clumpCap < clumpCapFull) clumpCap = clumpCapFull; else { clumpCap *= 2; fragCap *= 2; }      // grow and redo: the fragment array was modified in place
-        rc = buildFrags(ctx); if (rc) return rc;
+        rc = buildFrags(ctx, true); if (rc) return rc;
     }
     // creation-order rank of every root clump
     rc = cubScan(ctx, ctx->regionCount.as<uint32_t>(), ctx->regionBase.as<uint32_t>(), R + 1); if (rc) return rc;
