@@ -69,6 +69,45 @@ def test_seed_join_and_chain_bit_exact(work, index11, reads, extra):
             assert got == oracle.chain(s.index, s.params, b)
 
 
+def test_hits_either_side_of_long_runs_of_k_mers_without_hits(work, index11, tmp_path):
+    """k_expand_hits stages the k-mers of a block of 1 024 hits in a window of 1 026 offsets; a run of k-mers without hits longer than that (reads of N,
+    reads that match nowhere) between two k-mers with hits sends the hits behind it through the bisection path.  Fragments and chains against the oracle."""
+    import random
+    rng = random.Random(77)
+    src = [l.rstrip("\n") for l in open(os.path.join(work, "r1k.fa"))]
+    recs, cur = [], None
+    for l in src:
+        if l.startswith(">"):
+            cur = [l, ""]; recs.append(cur)
+        else:
+            cur[1] += l
+    out = []
+    for k, (h, seq) in enumerate(recs[:120]):
+        out.append((h, seq))
+        if k % 3 == 0:
+            out.append((">allN_%d" % k, "N" * rng.choice((1100, 2500, 4000))))
+        if k % 7 == 0:
+            out.append((">poly_%d" % k, "".join(rng.choice("ACGT") for _ in range(40)) + "N" * 1500 + seq[:300]))
+    path = os.path.join(str(tmp_path), "mixed.fa")
+    with open(path, "w") as f:
+        for h, seq in out:
+            f.write(h + "\n" + seq + "\n")
+    with ya.Session(["-x", index11, "-q", path]) as s:
+        b = s.next_batch(1000)
+        assert b.n_reads == len(out)
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.upload(b)
+            f, n = ctx.seed_join()
+            assert frag_tuples(f, n) == oracle.seed_join(s.index, s.params, b)
+            cf, cs, crs, nc = ctx.chain()
+            got = [(crs[k], tuple((cf[i].startRefOff, cf[i].startQueryOff, cf[i].endQueryOff, cf[i].refLen) for i in range(cs[k], cs[k + 1]))) for k in range(nc)]
+            assert got == oracle.chain(s.index, s.params, b)
+            ctx.run()
+            r = ctx.collect()
+            ro, _own = oracle.run(s.index, s.params, b, threads=8)
+            assert ya.result_records(r) == ya.result_records(ro)
+
+
 def device_pipeline(index, reads, oflag, extra, batch=4096):
     out = []
     with ya.Session(["-x", index, "-q", reads] + oflag_args(oflag) + list(extra)) as s:
