@@ -26,6 +26,11 @@ __global__ void __launch_bounds__(64) k_gap_band(AlignArgs A, PhaseArgs X)
     YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
     const uint32_t tBegin = GW == 12 ? 0u : X.nDPb[0], tEnd = GW == 12 ? X.nDPb[0] : X.nDPb[1];
     constexpr int RD = GW / 4;                                              // trace dwords per row
+    // The joint's query codes (at most 60) and reference nibbles (indices -left .. qGap - left + GW - 1: at most 91) are staged in LDS once, [dword][lane], by
+    // whole dwords issued together.  A byte load per row for each of them was a memory round trip per row: the loads of a row return behind the trace stores
+    // of the row before (one counter, in order).
+    __shared__ uint32_t sQ[16 * 64], sR[13 * 64];
+    typedef uint32_t yd_u32u __attribute__((aligned(1)));
     for (uint32_t base = tBegin + blockIdx.x * 64u; base < tEnd; base += gridDim.x * 64u) {
         const uint32_t t = base + (uint32_t)lane; const bool live = t < tEnd;
         int nT = 0, score = 0; unsigned cells = 0; uint32_t ji = 0;
@@ -35,7 +40,20 @@ __global__ void __launch_bounds__(64) k_gap_band(AlignArgs A, PhaseArgs X)
             int left, right; if (rGap > qGap) { right = bw + (rGap - qGap); left = bw; } else { left = bw + (qGap - rGap); right = bw; }
             const int W = left + right + 1;
             YD_GLOBAL const uint8_t *q = toGlobal((j.flags & 1u) ? A.B.rev : A.B.fwd) + j.qBase + j.nsqo;
-            auto refAt = [&](int idx) -> uint32_t { if (idx < 0 && (uint32_t)(-idx) > j.nsro) return 15u; const uint32_t off = j.nsro + (uint32_t)idx; const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
+            const uint32_t rB0 = ((j.nsro >= (uint32_t)left ? j.nsro - (uint32_t)left : 0u) >> 1) & ~3u;      // first staged byte of the reference (dword-aligned)
+            {
+                const int nQ = (qGap + 3) >> 2, nR = (int)((((j.nsro + (uint32_t)(qGap - left + GW - 1)) >> 1) - rB0) >> 2) + 1;
+#pragma unroll
+                for (int k = 0; k < 16; k++) if (k < nQ) sQ[k * 64 + lane] = *(YD_GLOBAL const yd_u32u *)(q + 4 * k);
+#pragma unroll
+                for (int k = 0; k < 13; k++) if (k < nR) sR[k * 64 + lane] = *(YD_GLOBAL const uint32_t *)(gB + rB0 + 4u * (uint32_t)k);
+            }
+            auto qAt = [&](int idx) -> int { return (int)((sQ[(idx >> 2) * 64 + lane] >> (8 * (idx & 3))) & 0xFFu); };
+            auto refAt = [&](int idx) -> uint32_t {
+                if (idx < 0 && (uint32_t)(-idx) > j.nsro) return 15u;
+                const uint32_t off = j.nsro + (uint32_t)idx, rel = (off >> 1) - rB0; const uint32_t b = (sR[(rel >> 2) * 64 + lane] >> (8u * (rel & 3u))) & 0xFFu;
+                return (off & 1u) ? (b & 15u) : (b >> 4);
+            };
             int PV[GW], PF[GW], PI[GW];
 #pragma unroll
             for (int c = 0; c < GW; c++) { PV[c] = c == left ? 0 : ((c > left && c < W) ? -(GO + (c - left) * GE) : YD_LWORST); PF[c] = c == left ? -GO : YD_LWORST; PI[c] = 0; }
@@ -51,9 +69,9 @@ __global__ void __launch_bounds__(64) k_gap_band(AlignArgs A, PhaseArgs X)
             unsigned long long win = 0;
 #pragma unroll
             for (int c = 0; c < GW; c++) win |= (unsigned long long)refAt(c - left) << (4 * c);
-            int qc = (int)q[0];
+            int qc = qAt(0);
             for (int i = 1; i <= qGap; i++) {
-                const int qcNext = (int)q[i < qGap ? i : qGap - 1];           // next row's query code and top reference base: issued now, needed at the row's end
+                const int qcNext = qAt(i < qGap ? i : qGap - 1);              // next row's query code and top reference base
                 const uint32_t nbNext = refAt(i - left + GW - 1);
                 { int sc = left + 1 - i; if (sc < 0) sc = 0; int ec = left + rGap - i; if (ec > W - 1) ec = W - 1; if (ec >= sc) cells += (unsigned)(ec - sc + 1); }
                 int PVCol = YD_LWORST, PE = YD_LWORST, PD = 0, dV = PV[0];
