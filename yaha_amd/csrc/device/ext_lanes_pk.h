@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     for (int k = 0; k < YD_NP; k++) { PV[k] = LWp; PF[k] = LWp; rc[k] = 0x7FFF7FFFu; }
 
     int poolCount = 0, poolNext = 0; bool exhausted = false;
-    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0, eQwLo = 0, eQwHi = 0, eRwLo = 0, eRwHi = 0, eHave = 0;
+    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0, eQwLo = 0, eQwHi = 0, eRwLo = 0, eRwHi = 0;      // eMisc: flags | first query code << 8 | buffered entries (query | reference << 8) << 16
     bool pendFlush = false; int pendRes = -1; unsigned pStart = 0;      // pendRes: the problem whose result this lane stores in its next pass (its state stays untouched until then)
     int wslot = 0; unsigned flush = 0; bool dirty = false, justDone = false;
     YD_GLOBAL uint32_t *chunkPtr = toGlobal(A.trace); bool noMem = false;
@@ -163,14 +163,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 if (!exhausted) { if (lane == 0) base = atomicAdd(A.queue, 64u); base = uniU(base); if (base >= A.nProb) exhausted = true; }
                 if (exhausted) { if (p < 0) done = true; break; }
                 poolCount = (int)min(64u, A.nProb - base); poolNext = 0;
-                eLens = 0;
+                eLens = 0; bool isCall = false;
                 if (lane < poolCount) {
                     const unsigned np = A.order ? A.order[base + (unsigned)lane] : base + (unsigned)lane;
                     ePidx = np;
                     const ExtProb pr = A.probs[np];
                     int ql = 0; uint32_t rl = 0; const bool rv_ = (pr.flags & XP_REV) != 0;
                     if (pr.flags & XP_VALID) {                              // findAGSExtension, SW.cpp:479-516
-                        calls++;
+                        isCall = true;
                         ql = pr.qLen;
                         rl = (uint32_t)(ql + bandwidth);
                         if (rv_ && rl > pr.rOff) { rl = pr.rOff + 1; ql = (int)rl - bandwidth; }
@@ -214,9 +214,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                             const unsigned long long t = (unsigned long long)v1 | (c1 < 16u ? ((unsigned long long)v2 << (4u * c1)) : 0ull);
                             eRwLo = (uint32_t)t; eRwHi = (uint32_t)(t >> 32);
                         }
-                        eHave = qh | (rh << 8);
+                        eMisc |= (qh | (rh << 8)) << 16;
                     }
                 }
+                calls += (unsigned)__builtin_popcountll(__ballot(isCall));      // (wave-uniform: a scalar register)
             }
             const int nNeed = __builtin_popcountll(need), avail = poolCount - poolNext;
             const int e = poolNext + __builtin_popcountll(need & lanesBelow);
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64);
             const uint32_t gPidx = (uint32_t)__shfl((int)ePidx, src, 64);
             const uint32_t gQwLo = (uint32_t)__shfl((int)eQwLo, src, 64), gQwHi = (uint32_t)__shfl((int)eQwHi, src, 64), gRwLo = (uint32_t)__shfl((int)eRwLo, src, 64), gRwHi = (uint32_t)__shfl((int)eRwHi, src, 64);
-            const uint32_t gHave = (uint32_t)__shfl((int)eHave, src, 64);
+            const uint32_t gHave = gMisc >> 16;
             const bool init = take && gLens != 0u;
             // A fresh problem: low halves = row 0 of columns 0..10 (the origin (0, 10): V = 0, F = -GO; sentinel left of it), high halves = the sentinel
             // ("row -1"; the first iteration turns it into row 0 of columns 11..20).  Reference codes: low halves of pairs 0..9 lie left of the matrix in
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     { const unsigned long long f = __ballot(pendFlush); if (!noMem && f != 0ull) { flushBlocks(f, chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u); nextFlush(); } }
     // (a result still pending here belongs to a launch that ran out of arena: the host zeroes the results and redoes the stage)
     if (!SECOND && A.clock && lane == 0) atomicMax(&A.clock[1], (unsigned long long)wall_clock64());
-    unsigned c0 = (unsigned)waveSumI((int)calls), c1 = (unsigned)waveSumI((int)rows);
+    unsigned c0 = calls, c1 = (unsigned)waveSumI((int)rows);
     unsigned long long cc = cells;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { cc += (unsigned long long)__shfl_xor((long long)cc, d, 64); }
