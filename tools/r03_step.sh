@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT; TAG=${1:-step}; K=${2:-"seed or sort or stage or golden or 
 python -m pytest tests -m gpu -x -q -k "$K" 2>&1 | tail -3
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 for rep in 1 2 3; do
-  python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('three contexts', round(j['value']), round(j['ms_per_step'],2))"
+  python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('default contexts', round(j['value']), round(j['ms_per_step'],2))"
 done
 python bench.py --steps 6 --warmup 2 --contexts 1 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('one context', round(j['value']), round(j['ms_per_step'],2))"
 cd /tmp && export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r03_$TAG; mkdir -p $O

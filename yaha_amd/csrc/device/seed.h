@@ -226,9 +226,9 @@ __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned lo
 // workgroups start in blockIdx order, so the tiles waited for are resident or finished).  Before: the library's scan over the flags (2.6 GB of keys read,
 // 1.3 GB of indices written) and a build kernel that read both again.  Records beyond cap are not written: the caller reads *total and comes back with room.
 #ifndef YD_FRAG_BS
-#define YD_FRAG_BS 512
+#define YD_FRAG_BS 1024
 #endif
-#define YD_FRAG_IPT 16
+#define YD_FRAG_IPT 8
 #define YD_FRAG_TILE (YD_FRAG_BS * YD_FRAG_IPT)
 __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap,
                                                                 unsigned long long *tileState, unsigned int *total, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
