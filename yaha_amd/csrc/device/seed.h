@@ -185,8 +185,9 @@ __device__ __forceinline__ uint32_t hitClass(const unsigned long long *keys, uin
 }
 // Decoupled look-back of a single-pass scan over tiles (one 64-bit state word per tile, zeroed before the launch: status in the high half -- 1 = the tile's own
 // count, 2 = its inclusive prefix -- and the value in the low half, so that both arrive together).  Called by one whole wave of tile `tile` with the tile's
-// count; returns the sum of the counts of all tiles before it.  Workgroups start in blockIdx order, so the tiles waited for are resident or finished.
-__device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, uint32_t tile, uint32_t agg, uint32_t lane)
+// count; returns the sum of the counts of all tiles before it.  Workgroups start in blockIdx order, so the tiles waited for are resident or finished
+// (*failed is raised otherwise, after a bounded wait).
+__device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, uint32_t tile, uint32_t agg, uint32_t lane, unsigned int *failed)
 {
     uint32_t excl = 0;
     if (tile == 0u) { if (lane == 0u) __hip_atomic_store(&tileState[0], (2ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0u; }
@@ -195,7 +196,12 @@ __device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, 
     for (;;) {
         const int j = back - (int)lane;
         unsigned long long st = 2ull << 32;                              // before the first tile: a known prefix of zero
-        if (j >= 0) { do { st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st >> 32) == 0ull); }
+        if (j >= 0) {
+            // (bounded: a tile that never publishes -- only possible if workgroups did not start in blockIdx order -- ends the wait after some seconds; the caller sees the flag)
+            unsigned spins = 0;
+            do { st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st >> 32) == 0ull && ++spins < (1u << 22));
+            if ((st >> 32) == 0ull) { st = 2ull << 32; atomicMax(failed, 1u); }
+        }
         const unsigned long long known = __ballot((st >> 32) == 2ull);
         const int stop = __builtin_ctzll(known | (1ull << 63));          // the nearest tile that knows its prefix (lane 63 at the latest if any)
         const bool use = known ? (int)lane <= stop : true;
@@ -231,7 +237,7 @@ __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned lo
 #define YD_FRAG_IPT 8
 #define YD_FRAG_TILE (YD_FRAG_BS * YD_FRAG_IPT)
 __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap,
-                                                                unsigned long long *tileState, unsigned int *total, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
+                                                                unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
 {
     constexpr int NW = YD_FRAG_BS / 64;
     __shared__ uint32_t sCnt[YD_FRAG_IPT * NW]; __shared__ uint32_t sPrefix; __shared__ unsigned sDead;
@@ -278,7 +284,7 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
 #pragma unroll
         for (int e = 0; e < E; e++) sCnt[(int)lane * E + e] = incl - sum + v[e];
         const uint32_t agg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t excl = tileLookBack(tileState, tile, agg, lane);
+        const uint32_t excl = tileLookBack(tileState, tile, agg, lane, total + 1);
         if (lane == 0u) { sPrefix = excl; if (tile + 1u == gridDim.x) *total = excl + agg; }
     }
     __syncthreads();
@@ -320,7 +326,7 @@ __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
 // is set by the host.  A tile = 4 waves x 8 rows of 64 fragments.
 #define YD_REG_IPT 8
 #define YD_REG_TILE (256 * YD_REG_IPT)
-__global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *regStart, unsigned long long *tileState, unsigned int *total)
+__global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *regStart, unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */)
 {
     __shared__ uint32_t sCnt[4 * YD_REG_IPT]; __shared__ uint32_t sPrefix;
     const uint32_t tile = blockIdx.x, t = threadIdx.x, lane = t & 63u, w = t >> 6, wbase = tile * (uint32_t)YD_REG_TILE + w * (uint32_t)(64 * YD_REG_IPT);
@@ -354,7 +360,7 @@ __global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nF
         for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
         if (lane < 4u * YD_REG_IPT) sCnt[lane] = incl - v;
         const uint32_t agg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t excl = tileLookBack(tileState, tile, agg, lane);
+        const uint32_t excl = tileLookBack(tileState, tile, agg, lane, total + 1);
         if (lane == 0u) { sPrefix = excl; if (tile + 1u == gridDim.x) *total = excl + agg; }
     }
     __syncthreads();

@@ -63,7 +63,7 @@ struct DevBuf {
     int ensureExact(size_t bytes) { if (bytes <= cap) return 0; release(); void *np = nullptr; if (hipMalloc(&np, bytes) != hipSuccess) return -1; p = np; cap = bytes; return 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* YD_SEG_NCLASS + 1: the segments of the workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 16, CNT_NREG, CNT_N = CNT_NREG + 3 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* YD_SEG_NCLASS + 1: the segments of the workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 16 /* + the look-back's flag */, CNT_NREG = CNT_NFRAGS + 2 /* + flag */, CNT_N = CNT_NREG + 4 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_XROWS_PK, T_N };
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
@@ -275,7 +275,9 @@ static int buildFrags(ygpu_ctx *ctx, bool redo = false)      // redo: the region
         HIPCHK(hipMemsetAsync(ctx->scanOut.p, 0, 8ull * nTiles, ctx->stream));
         KL(k_frag_scan_build, dim3(nTiles), dim3(YD_FRAG_BS), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, fragDropGap(ctx), ctx->frags.as<DevFrag>(), cap,
            ctx->scanOut.as<unsigned long long>(), total, ctx->kmerParts.as<unsigned int>());
-        uint32_t F = 0; int rc = fetchU32(ctx, total, &F); if (rc) return rc;
+        uint32_t two[2] = {0, 0}; int rc = fetchU32(ctx, total, two, 2); if (rc) return rc;
+        if (two[1]) { ctx->err = "fragment scan: a tile's look-back gave up (workgroups out of order)"; return YGPU_EINTERNAL; }
+        const uint32_t F = two[0];
         if (F <= cap) { ctx->nFrags = F; break; }
         if (pass >= 2) { ctx->err = "fragment build: the count changed between passes"; return YGPU_EINTERNAL; }
         ENSURE(ctx->frags, 16ull * ((uint64_t)F + F / 8 + 4096));
@@ -299,7 +301,7 @@ static int stageChain(ygpu_ctx *ctx)
     uint32_t *cnt = ctx->counters.as<uint32_t>();
     HIPCHK(hipMemsetAsync(ctx->scanOut.p, 0, 8ull * nRegTiles, ctx->stream));
     KL(k_region_scan, dim3(nRegTiles), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, ctx->regStart.as<uint32_t>(), ctx->scanOut.as<unsigned long long>(), cnt + CNT_NREG);
-    uint32_t R = 0; rc = fetchU32(ctx, cnt + CNT_NREG, &R); if (rc) return rc;
+    uint32_t R = 0; { uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NREG, two, 2); if (rc) return rc; if (two[1]) { ctx->err = "region scan: a tile's look-back gave up (workgroups out of order)"; return YGPU_EINTERNAL; } R = two[0]; }
     ctx->nRegions = R;
     HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NBIG, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NSMALL, 0, 4, ctx->stream));
