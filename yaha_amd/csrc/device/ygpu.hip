@@ -647,6 +647,16 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         }
         if (c + 1 == nRanges) hipEventRecord(ctx->ev[T_P3][1], ctx->stream);
         TRACE("lanes: p3");
+        if (kTrace && getenv("YGPU_LIST_HIST")) {      // what k_p3_lanes walks: lengths of the three lists of a root (backward extension, phase-1 list, forward extension)
+            const uint32_t nr2 = r1 - r0; std::vector<ExtRes> hr2(2 * (size_t)nr2); std::vector<RootState> hs(nr2);
+            hipMemcpy(hr2.data(), ctx->extRes.as<ExtRes>() + 2 * (size_t)r0, sizeof(ExtRes) * hr2.size(), hipMemcpyDeviceToHost); hipMemcpy(hs.data(), ctx->rootState.as<RootState>() + r0, sizeof(RootState) * nr2, hipMemcpyDeviceToHost);
+            unsigned long long hx[8] = {0}, hb[8] = {0}, ht[8] = {0}, sumx = 0, sumb = 0; const unsigned edges[7] = {0, 1, 2, 4, 8, 16, 32};
+            auto bin = [&](unsigned v) { int k = 0; while (k < 7 && v > edges[k]) k++; return k; };
+            for (uint32_t k = 0; k < nr2; k++) { const unsigned a = hr2[2 * k].score > 0 ? hr2[2 * k].nOps : 0u, c2 = hr2[2 * k + 1].score > 0 ? hr2[2 * k + 1].nOps : 0u, b = hs[k].len; hx[bin(a)]++; hx[bin(c2)]++; hb[bin(b)]++; ht[bin(a + b + c2)]++; sumx += a + c2; sumb += b; }
+            fprintf(stderr, "[ygpu] list lengths over %u roots (bins: 0, 1, 2, 3-4, 5-8, 9-16, 17-32, more): extension lists", nr2); for (int k = 0; k < 8; k++) fprintf(stderr, " %llu", hx[k]);
+            fprintf(stderr, "; phase-1 lists"); for (int k = 0; k < 8; k++) fprintf(stderr, " %llu", hb[k]); fprintf(stderr, "; merged"); for (int k = 0; k < 8; k++) fprintf(stderr, " %llu", ht[k]);
+            fprintf(stderr, "; mean ops per root: extensions %.1f, phase 1 %.1f\n", (double)sumx / nr2, (double)sumb / nr2);
+        }
     }
     HIPCHK(hipMemcpyAsync(ctx->hRowsClock, ctx->rowsClock.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     // errors of the trace memory: grow what overflowed and have the caller redo the stage
