@@ -152,37 +152,13 @@ __global__ void k_seg_offsets(const uint32_t *kmerOff, const uint32_t *hitOff, u
     if (s <= nSeg) segOff[s] = hitOff[kmerOff[s]];
 }
 
-// A2b: fragment heads.  A hit starts a new fragment when (read,strand) or diagonal changes or the k-mer neither overlaps
-// nor abuts the previous one (QueryMatch.c:99).
-// head flag of hit t in the sorted key array: a new (read, strand, diagonal), or a query offset more than one word beyond the previous hit's
-// (QueryMatch.c:84-121).  t == nHits (the scan's extra element): 0.
-__device__ __forceinline__ uint32_t hitIsHead(const unsigned long long *keys, uint32_t t, uint32_t nHits, int wordLen)
-{
-    if (t >= nHits) return 0u;
-    if (t == 0) return 1u;
-    const unsigned long long a = keys[t - 1], b = keys[t];
-    if ((a >> 15) != (b >> 15)) return 1u;
-    return (uint32_t)(b & 0x7FFFu) > (uint32_t)(a & 0x7FFFu) + (uint32_t)wordLen ? 1u : 0u;
-}
+// A2b: fragment heads.  A hit starts a new fragment when (read, strand) or diagonal changes or the k-mer neither overlaps nor abuts the previous one: a query
+// offset more than one word beyond the previous hit's (QueryMatch.c:84-121).
 // A fragment of ONE hit that is alone in its region (QueryMatch.c:146-158: the fragments before and after it are of another (read, strand) or more than maxGap
 // diagonals away) can only become a clump if one word is a whole match (refLen = wordLen >= minMatch, QueryMatch.c:281-290).  With the defaults (15 < 25) it
 // is dead on arrival, and on a large genome these chance hits are most fragments (3.1 Gbp: 128 M fragments a batch, ~100 M of them dead): they are counted
 // and not written.  Dropping them changes nothing for the others: the diagonals are sorted, so the fragments on either side of a dropped run are further
 // apart than the dropped fragment was from them -- every region boundary stays where it was.  maxGapDrop < 0: keep every fragment (ygpu_seed_join).
-// head / last / dead of hit t from its two neighbours, loaded once, without branches (bit 0 head, bit 1 last hit of its fragment, bit 2 dead single)
-__device__ __forceinline__ uint32_t hitClass(const unsigned long long *keys, uint32_t t, uint32_t nHits, int wordLen, int maxGapDrop)
-{
-    const bool first = t == 0, end = t + 1 >= nHits;
-    const unsigned long long b = keys[t], a = keys[first ? t : t - 1], c = keys[end ? t : t + 1];
-    const uint32_t qa = (uint32_t)(a & 0x7FFFu), qb = (uint32_t)(b & 0x7FFFu), qc = (uint32_t)(c & 0x7FFFu);
-    const uint32_t da = (uint32_t)(a >> 15), db = (uint32_t)(b >> 15), dc = (uint32_t)(c >> 15);
-    const bool sameA = (uint32_t)(a >> 47) == (uint32_t)(b >> 47), sameC = (uint32_t)(c >> 47) == (uint32_t)(b >> 47);
-    const bool head = first | !sameA | (da != db) | (qb > qa + (uint32_t)wordLen);
-    const bool last = end | !sameC | (dc != db) | (qc > qb + (uint32_t)wordLen);
-    const bool nearA = !first & sameA & (absDiffU(da, db) <= (uint32_t)maxGapDrop), nearC = !end & sameC & (absDiffU(dc, db) <= (uint32_t)maxGapDrop);
-    const bool dead = (maxGapDrop >= 0) & head & last & !nearA & !nearC;
-    return (head ? 1u : 0u) | (last ? 2u : 0u) | (dead ? 4u : 0u);
-}
 // Decoupled look-back of a single-pass scan over tiles (one 64-bit state word per tile, zeroed before the launch: status in the high half -- 1 = the tile's own
 // count, 2 = its inclusive prefix -- and the value in the low half, so that both arrive together).  Called by one whole wave of tile `tile` with the tile's
 // count; returns the sum of the counts of all tiles before it.  Workgroups start in blockIdx order, so the tiles waited for are resident or finished
@@ -212,7 +188,7 @@ __device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, 
     if (lane == 0u) __hip_atomic_store(&tileState[tile], (2ull << 32) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return excl;
 }
-// the same from the three keys in registers
+// head / last / dead of a hit from its two neighbours in the sorted order, without branches (bit 0 head, bit 1 last hit of its fragment, bit 2 dead single)
 __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned long long b, unsigned long long c, bool first, bool end, int wordLen, int maxGapDrop)
 {
     const uint32_t qa = (uint32_t)(a & 0x7FFFu), qb = (uint32_t)(b & 0x7FFFu), qc = (uint32_t)(c & 0x7FFFu);

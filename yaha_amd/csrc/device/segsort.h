@@ -8,8 +8,6 @@
 // hipcub::DeviceSegmentedRadixSort through begin/end arrays that are empty for all others.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rocprim/block/block_load.hpp>
-#include <rocprim/block/block_store.hpp>
 #include <rocprim/block/block_radix_sort.hpp>
 #include <cstdint>
 

@@ -79,7 +79,7 @@ struct ygpu_ctx {
     DevBuf dFwd, dRev, dReadOff, dKmerOff;
     // arenas
     DevBuf bigB, bigE;
-    DevBuf posS, posC, posRsI, hitOff, expandStart, keysA, keysB, segOff, isHead, scanOut, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
+    DevBuf posS, posC, posRsI, hitOff, expandStart, keysA, keysB, segOff, isHead, tileState, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
@@ -266,15 +266,15 @@ static int buildFrags(ygpu_ctx *ctx, bool redo = false)      // redo: the region
     ctx->nFrags = 0;
     if (!H) return 0;
     const uint32_t nTiles = (uint32_t)gridFor(H, YD_FRAG_TILE);
-    ENSURE(ctx->scanOut, 8ull * nTiles);
+    ENSURE(ctx->tileState, 8ull * nTiles);
     unsigned int *total = ctx->counters.as<unsigned int>() + CNT_NFRAGS;
     for (int pass = 0;; pass++) {
         const uint32_t cap = ctx->frags.cap >= 32 ? (uint32_t)std::min<uint64_t>(ctx->frags.cap / 16 - 1, 0xFFFFFFF0u) : 0u;
         // the fragments that are dropped (seed.h: hitClass) are counted: the counters report every fragment and region of the reference
         ENSURE(ctx->kmerParts, 4096); HIPCHK(hipMemsetAsync(ctx->kmerParts.p, 0, 4096, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_FRAGS, 0, 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->scanOut.p, 0, 8ull * nTiles, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->tileState.p, 0, 8ull * nTiles, ctx->stream));
         KL(k_frag_scan_build, dim3(nTiles), dim3(YD_FRAG_BS), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, fragDropGap(ctx), ctx->frags.as<DevFrag>(), cap,
-           ctx->scanOut.as<unsigned long long>(), total, ctx->kmerParts.as<unsigned int>());
+           ctx->tileState.as<unsigned long long>(), total, ctx->kmerParts.as<unsigned int>());
         uint32_t two[2] = {0, 0}; int rc = fetchU32(ctx, total, two, 2); if (rc) return rc;
         if (two[1]) { ctx->err = "fragment scan: a tile's look-back gave up (workgroups out of order)"; return YGPU_EINTERNAL; }
         const uint32_t F = two[0];
@@ -297,10 +297,10 @@ static int stageChain(ygpu_ctx *ctx)
     ENSURE(ctx->regStart, 4ull * (F + 2)); ENSURE(ctx->multiList, 4ull * (F + 1)); ENSURE(ctx->smallList, 4ull * (F + 1)); ENSURE(ctx->bigList, 4ull * (F / 64 + 2)); ENSURE(ctx->regionCount, 4ull * (F + 2)); ENSURE(ctx->regionBase, 4ull * (F + 2));
     // (the fragment scan's tile states are free again: reused for the region scan)
     const uint32_t nRegTiles = (uint32_t)gridFor(F, YD_REG_TILE);
-    ENSURE(ctx->scanOut, 8ull * nRegTiles);
+    ENSURE(ctx->tileState, 8ull * nRegTiles);
     uint32_t *cnt = ctx->counters.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(ctx->scanOut.p, 0, 8ull * nRegTiles, ctx->stream));
-    KL(k_region_scan, dim3(nRegTiles), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, ctx->regStart.as<uint32_t>(), ctx->scanOut.as<unsigned long long>(), cnt + CNT_NREG);
+    HIPCHK(hipMemsetAsync(ctx->tileState.p, 0, 8ull * nRegTiles, ctx->stream));
+    KL(k_region_scan, dim3(nRegTiles), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, ctx->regStart.as<uint32_t>(), ctx->tileState.as<unsigned long long>(), cnt + CNT_NREG);
     uint32_t R = 0; { uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NREG, two, 2); if (rc) return rc; if (two[1]) { ctx->err = "region scan: a tile's look-back gave up (workgroups out of order)"; return YGPU_EINTERNAL; } R = two[0]; }
     ctx->nRegions = R;
     HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
@@ -874,7 +874,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
     if (ctx->stream) {
         hipSetDevice(ctx->device);
         if (ctx->sharedIndex) { ctx->dBases.p = nullptr; ctx->dBases.cap = 0; ctx->dSO.p = nullptr; ctx->dSO.cap = 0; ctx->dROA.p = nullptr; ctx->dROA.cap = 0; ctx->dLow.p = nullptr; ctx->dLow.cap = 0; }
-        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->scanOut,
+        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->tileState,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
                          &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
