@@ -233,7 +233,8 @@ def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1):
     def settle():
         """The driver scrubs device memory a process has freed in the background, and a process that allocates meanwhile waits for it: a command line started right
         after the bench contexts (or the previous command line) freed ~200 GB spends seconds in its first allocations -- a property of what ran before it.  Tiny
-        runs, 5 s apart, until the contexts are up within a second again (45 s at most)."""
+        runs, 5 s apart, after 20 s of waiting, until the contexts are up within a second again (another 45 s at most)."""
+        time.sleep(20)                                   # (the arenas of a full run ask for ten times what the tiny run's index does: give the scrubbing its head start)
         t0 = time.time(); ups = []
         while True:
             p = subprocess.run([ya.CLI_PATH, "-x", idx, "-q", tiny, "-osh", out] + more, stderr=subprocess.PIPE, check=True, env=env)

@@ -161,8 +161,16 @@ __global__ void k_seg_offsets(const uint32_t *kmerOff, const uint32_t *hitOff, u
 // apart than the dropped fragment was from them -- every region boundary stays where it was.  maxGapDrop < 0: keep every fragment (ygpu_seed_join).
 // Decoupled look-back of a single-pass scan over tiles (one 64-bit state word per tile, zeroed before the launch: status in the high half -- 1 = the tile's own
 // count, 2 = its inclusive prefix -- and the value in the low half, so that both arrive together).  Called by one whole wave of tile `tile` with the tile's
-// count; returns the sum of the counts of all tiles before it.  Workgroups start in blockIdx order, so the tiles waited for are resident or finished
-// (*failed is raised otherwise, after a bounded wait).
+// count; returns the sum of the counts of all tiles before it.  A workgroup's tile is the TICKET it draws when it starts (tileTicket), not its blockIdx: every
+// tile before it has then started as well and publishes its count without waiting for anybody.  (With tile = blockIdx two such kernels running side by side --
+// two batches in flight, or two processes on one device -- can fill each other's XCD with waiting workgroups while the tile both are waiting for has not been
+// dispatched there: seen as a stall with two processes on one GPU.  *failed is raised, after a bounded wait, should a tile ever not show up.)
+__device__ __forceinline__ uint32_t tileTicket(unsigned long long *ticketWord /* zeroed with the tile states */, uint32_t *sSlot)
+{
+    if (threadIdx.x == 0) *sSlot = (uint32_t)atomicAdd(ticketWord, 1ull);
+    __syncthreads();
+    return *sSlot;
+}
 __device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, uint32_t tile, uint32_t agg, uint32_t lane, unsigned int *failed)
 {
     uint32_t excl = 0;
@@ -217,7 +225,7 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
 {
     constexpr int NW = YD_FRAG_BS / 64;
     __shared__ uint32_t sCnt[YD_FRAG_IPT * NW]; __shared__ uint32_t sPrefix; __shared__ unsigned sDead;
-    const uint32_t tile = blockIdx.x, base = tile * (uint32_t)YD_FRAG_TILE, t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const uint32_t tile = tileTicket(tileState + gridDim.x, &sPrefix), base = tile * (uint32_t)YD_FRAG_TILE, t = threadIdx.x, lane = t & 63u, w = t >> 6;
     if (t == 0) sDead = 0;
     unsigned long long key[YD_FRAG_IPT]; uint32_t cls = 0, cls2 = 0;           // three class bits per hit: ten in cls, six in cls2
     unsigned long long headMask[YD_FRAG_IPT];                                  // wave-uniform: the live heads of row k in this wave
@@ -305,7 +313,7 @@ __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
 __global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *regStart, unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */)
 {
     __shared__ uint32_t sCnt[4 * YD_REG_IPT]; __shared__ uint32_t sPrefix;
-    const uint32_t tile = blockIdx.x, t = threadIdx.x, lane = t & 63u, w = t >> 6, wbase = tile * (uint32_t)YD_REG_TILE + w * (uint32_t)(64 * YD_REG_IPT);
+    const uint32_t tile = tileTicket(tileState + gridDim.x, &sPrefix), t = threadIdx.x, lane = t & 63u, w = t >> 6, wbase = tile * (uint32_t)YD_REG_TILE + w * (uint32_t)(64 * YD_REG_IPT);
     uint32_t rs[YD_REG_IPT], dg[YD_REG_IPT]; unsigned long long headMask[YD_REG_IPT];
 #pragma unroll
     for (int k = 0; k < YD_REG_IPT; k++) {

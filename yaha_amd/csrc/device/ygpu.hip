@@ -266,13 +266,13 @@ static int buildFrags(ygpu_ctx *ctx, bool redo = false)      // redo: the region
     ctx->nFrags = 0;
     if (!H) return 0;
     const uint32_t nTiles = (uint32_t)gridFor(H, YD_FRAG_TILE);
-    ENSURE(ctx->tileState, 8ull * nTiles);
+    ENSURE(ctx->tileState, 8ull * (nTiles + 1));                             // + the ticket word
     unsigned int *total = ctx->counters.as<unsigned int>() + CNT_NFRAGS;
     for (int pass = 0;; pass++) {
         const uint32_t cap = ctx->frags.cap >= 32 ? (uint32_t)std::min<uint64_t>(ctx->frags.cap / 16 - 1, 0xFFFFFFF0u) : 0u;
         // the fragments that are dropped (seed.h: hitClass) are counted: the counters report every fragment and region of the reference
         ENSURE(ctx->kmerParts, 4096); HIPCHK(hipMemsetAsync(ctx->kmerParts.p, 0, 4096, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_FRAGS, 0, 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->tileState.p, 0, 8ull * nTiles, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->tileState.p, 0, 8ull * (nTiles + 1), ctx->stream));
         KL(k_frag_scan_build, dim3(nTiles), dim3(YD_FRAG_BS), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, fragDropGap(ctx), ctx->frags.as<DevFrag>(), cap,
            ctx->tileState.as<unsigned long long>(), total, ctx->kmerParts.as<unsigned int>());
         uint32_t two[2] = {0, 0}; int rc = fetchU32(ctx, total, two, 2); if (rc) return rc;
@@ -297,9 +297,9 @@ static int stageChain(ygpu_ctx *ctx)
     ENSURE(ctx->regStart, 4ull * (F + 2)); ENSURE(ctx->multiList, 4ull * (F + 1)); ENSURE(ctx->smallList, 4ull * (F + 1)); ENSURE(ctx->bigList, 4ull * (F / 64 + 2)); ENSURE(ctx->regionCount, 4ull * (F + 2)); ENSURE(ctx->regionBase, 4ull * (F + 2));
     // (the fragment scan's tile states are free again: reused for the region scan)
     const uint32_t nRegTiles = (uint32_t)gridFor(F, YD_REG_TILE);
-    ENSURE(ctx->tileState, 8ull * nRegTiles);
+    ENSURE(ctx->tileState, 8ull * (nRegTiles + 1));
     uint32_t *cnt = ctx->counters.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(ctx->tileState.p, 0, 8ull * nRegTiles, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->tileState.p, 0, 8ull * (nRegTiles + 1), ctx->stream));
     KL(k_region_scan, dim3(nRegTiles), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, ctx->regStart.as<uint32_t>(), ctx->tileState.as<unsigned long long>(), cnt + CNT_NREG);
     uint32_t R = 0; { uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NREG, two, 2); if (rc) return rc; if (two[1]) { ctx->err = "region scan: a tile's look-back gave up (workgroups out of order)"; return YGPU_EINTERNAL; } R = two[0]; }
     ctx->nRegions = R;
