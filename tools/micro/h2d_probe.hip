@@ -1,0 +1,106 @@
+// h2d_probe.hip -- how fast can an index image in the page cache reach HBM on this box, and through which path?
+// The command line's start-up is the 16.7 GB index image going from a memory-mapped file to the device (23-30 GB/s through the runtime's
+// pageable path).  This program measures the alternatives on a file of its own:
+//   pinned      hipHostMalloc'ed memory -> device: the link's ceiling
+//   pageable    the memory-mapped file -> device with one plain hipMemcpy (what ygpu_init did)
+//   register    hipHostRegister on the mapping (in slices, T threads), then asynchronous copies of the registered slices
+//   pread       T threads pread() the file into page-locked double buffers of their own and copy those
+//   d2d         device -> device on one GPU (the rate a peer copy cannot exceed here; the box has one GPU)
+// Run: ./h2d_probe [GB (default 4)] [path of the scratch file (default /tmp/h2d_probe.bin)]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <thread>
+#include <atomic>
+#include <chrono>
+#include <algorithm>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+static double now() { using namespace std::chrono; return duration<double>(steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv)
+{
+    const double gb = argc > 1 ? atof(argv[1]) : 4.0; const char *path = argc > 2 ? argv[2] : "/tmp/h2d_probe.bin";
+    const size_t bytes = ((size_t)(gb * (1ull << 30))) & ~((size_t)(64 << 20) - 1);
+    int ndev = 0; CK(hipGetDeviceCount(&ndev)); printf("devices: %d\n", ndev);
+    int lo = 0, hi = 0; CK(hipDeviceGetStreamPriorityRange(&lo, &hi)); printf("stream priority range: least %d, greatest %d\n", lo, hi);
+    for (int a = 0; a < ndev; a++) for (int b = 0; b < ndev; b++) if (a != b) { int can = 0; hipDeviceCanAccessPeer(&can, a, b); printf("peer %d -> %d: %d\n", a, b, can); }
+    char *dev; CK(hipMalloc(&dev, bytes)); char *dev2; CK(hipMalloc(&dev2, bytes));
+    // the file, written once and read back so that it sits in the page cache
+    { int fd = open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644); if (fd < 0) { perror("open"); return 1; }
+      std::vector<char> blk(64 << 20); for (size_t i = 0; i < blk.size(); i++) blk[i] = (char)(i * 2654435761u >> 13);
+      for (size_t o = 0; o < bytes; o += blk.size()) if (write(fd, blk.data(), blk.size()) != (ssize_t)blk.size()) { perror("write"); return 1; }
+      close(fd); }
+    int fd = open(path, O_RDONLY); if (fd < 0) { perror("open"); return 1; }
+    char *map = (char *)mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0); if (map == MAP_FAILED) { perror("mmap"); return 1; }
+    { volatile char s = 0; for (size_t o = 0; o < bytes; o += 4096) s += map[o]; }
+    auto report = [&](const char *what, double t) { printf("%-58s %7.1f ms  %6.1f GB/s\n", what, t * 1e3, bytes / t / 1e9); fflush(stdout); };
+    // pinned
+    { char *pin; double t = now(); CK(hipHostMalloc((void **)&pin, bytes, hipHostMallocDefault)); printf("hipHostMalloc of %.1f GB: %.1f ms\n", bytes / 1e9, (now() - t) * 1e3);
+      memset(pin, 1, bytes);
+      for (int rep = 0; rep < 2; rep++) { t = now(); CK(hipMemcpy(dev, pin, bytes, hipMemcpyHostToDevice)); report("pinned -> device, one copy", now() - t); }
+      { hipStream_t s[2]; CK(hipStreamCreate(&s[0])); CK(hipStreamCreate(&s[1])); t = now();
+        CK(hipMemcpyAsync(dev, pin, bytes / 2, hipMemcpyHostToDevice, s[0])); CK(hipMemcpyAsync(dev + bytes / 2, pin + bytes / 2, bytes / 2, hipMemcpyHostToDevice, s[1]));
+        CK(hipStreamSynchronize(s[0])); CK(hipStreamSynchronize(s[1])); report("pinned -> device, two streams", now() - t); }
+      CK(hipHostFree(pin)); }
+    // pageable
+    for (int rep = 0; rep < 2; rep++) { double t = now(); CK(hipMemcpy(dev, map, bytes, hipMemcpyHostToDevice)); report("mapped file -> device, plain hipMemcpy", now() - t); }
+    // register the mapping in slices, T threads, copies follow each slice's registration
+    for (int T : {1, 4, 8, 16}) for (size_t sliceMB : {64, 256}) {
+        const size_t slice = sliceMB << 20; std::atomic<size_t> next(0); std::atomic<int> bad(0); double tReg = 0; std::atomic<long long> regNs(0);
+        double t = now();
+        auto work = [&]() {
+            CK(hipSetDevice(0)); hipStream_t st; CK(hipStreamCreate(&st)); std::vector<char *> mine;
+            for (;;) { const size_t o = next.fetch_add(slice); if (o >= bytes || bad) break; const size_t n = std::min(slice, bytes - o);
+                const double r0 = now();
+                hipError_t e = hipHostRegister(map + o, n, hipHostRegisterReadOnly); if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister(map + o, n, hipHostRegisterDefault); }
+                regNs += (long long)((now() - r0) * 1e9);
+                if (e != hipSuccess) { if (!bad.exchange(1)) fprintf(stderr, "hipHostRegister: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); break; }
+                mine.push_back(map + o);
+                if (hipMemcpyAsync(dev + o, map + o, n, hipMemcpyHostToDevice, st) != hipSuccess) { bad = 1; break; } }
+            hipStreamSynchronize(st); for (char *p : mine) hipHostUnregister(p); hipStreamDestroy(st); };
+        std::vector<std::thread> th; for (int k = 1; k < T; k++) th.emplace_back(work); work(); for (auto &x : th) x.join();
+        tReg = regNs.load() / 1e9; char nm[128]; snprintf(nm, sizeof nm, "register %zu MB slices + copy, %d threads (reg %.0f ms cpu)%s", sliceMB, T, tReg * 1e3, bad ? " FAILED" : "");
+        report(nm, now() - t);     // (includes the unregister calls)
+    }
+    // pread into page-locked double buffers
+    for (int T : {2, 4, 8, 12, 16}) for (size_t pieceMB : {8, 32}) {
+        const size_t piece = pieceMB << 20; std::atomic<size_t> next(0);
+        std::vector<char *> bufs(2 * T); for (auto &b : bufs) CK(hipHostMalloc((void **)&b, piece, hipHostMallocDefault));
+        double t = now();
+        auto work = [&](int id) {
+            CK(hipSetDevice(0)); hipStream_t st; CK(hipStreamCreate(&st)); hipEvent_t ev[2]; CK(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming)); bool used[2] = {false, false};
+            for (int k = 0;; k ^= 1) { const size_t o = next.fetch_add(piece); if (o >= bytes) break; const size_t n = std::min(piece, bytes - o);
+                if (used[k]) CK(hipEventSynchronize(ev[k]));
+                char *b = bufs[2 * id + k]; size_t got = 0; while (got < n) { ssize_t r = pread(fd, b + got, n - got, o + got); if (r <= 0) { perror("pread"); exit(1); } got += r; }
+                CK(hipMemcpyAsync(dev + o, b, n, hipMemcpyHostToDevice, st)); CK(hipEventRecord(ev[k], st)); used[k] = true; }
+            CK(hipStreamSynchronize(st)); hipStreamDestroy(st); };
+        std::vector<std::thread> th; for (int k = 1; k < T; k++) th.emplace_back(work, k); work(0); for (auto &x : th) x.join();
+        char nm[128]; snprintf(nm, sizeof nm, "pread into pinned %zu MB double buffers, %d threads", pieceMB, T); report(nm, now() - t);
+        for (auto &b : bufs) CK(hipHostFree(b));
+    }
+    // memcpy from the mapping into page-locked double buffers (no system call per piece)
+    for (int T : {4, 8, 16}) {
+        const size_t piece = 16 << 20; std::atomic<size_t> next(0);
+        std::vector<char *> bufs(2 * T); for (auto &b : bufs) CK(hipHostMalloc((void **)&b, piece, hipHostMallocDefault));
+        double t = now();
+        auto work = [&](int id) {
+            CK(hipSetDevice(0)); hipStream_t st; CK(hipStreamCreate(&st)); hipEvent_t ev[2]; CK(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming)); bool used[2] = {false, false};
+            for (int k = 0;; k ^= 1) { const size_t o = next.fetch_add(piece); if (o >= bytes) break; const size_t n = std::min(piece, bytes - o);
+                if (used[k]) CK(hipEventSynchronize(ev[k]));
+                memcpy(bufs[2 * id + k], map + o, n);
+                CK(hipMemcpyAsync(dev + o, bufs[2 * id + k], n, hipMemcpyHostToDevice, st)); CK(hipEventRecord(ev[k], st)); used[k] = true; }
+            CK(hipStreamSynchronize(st)); hipStreamDestroy(st); };
+        std::vector<std::thread> th; for (int k = 1; k < T; k++) th.emplace_back(work, k); work(0); for (auto &x : th) x.join();
+        char nm[128]; snprintf(nm, sizeof nm, "memcpy from the mapping into pinned 16 MB buffers, %d threads", T); report(nm, now() - t);
+        for (auto &b : bufs) CK(hipHostFree(b));
+    }
+    { double t = now(); CK(hipMemcpy(dev2, dev, bytes, hipMemcpyDeviceToDevice)); CK(hipDeviceSynchronize()); report("device -> device (same GPU)", now() - t); }
+    munmap(map, bytes); close(fd); unlink(path);
+    return 0;
+}

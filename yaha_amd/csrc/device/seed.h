@@ -181,10 +181,16 @@ __device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, 
         const int j = back - (int)lane;
         unsigned long long st = 2ull << 32;                              // before the first tile: a known prefix of zero
         if (j >= 0) {
-            // (bounded: a tile that never publishes -- only possible if workgroups did not start in blockIdx order -- ends the wait after some seconds; the caller sees the flag)
-            unsigned spins = 0;
-            do { st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st >> 32) == 0ull && ++spins < (1u << 22));
-            if ((st >> 32) == 0ull) { st = 2ull << 32; atomicMax(failed, 1u); }
+            // (every tile waited for has drawn its ticket, so its workgroup is resident and publishes without waiting for anybody: the wait is bounded by WALL TIME
+            // only -- a device that is time-sliced between processes, or stopped under a debugger, may take long -- 30 s of the 100 MHz clock, asleep between polls
+            // after the first few; the caller sees the flag)
+            st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((st >> 32) == 0ull) {
+                const unsigned long long t0 = wall_clock64(); unsigned polls = 0;
+                do { if (++polls > 64u) __builtin_amdgcn_s_sleep(32); st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                while ((st >> 32) == 0ull && wall_clock64() - t0 < 3000000000ull);
+                if ((st >> 32) == 0ull) { st = 2ull << 32; atomicMax(failed, 1u); }
+            }
         }
         const unsigned long long known = __ballot((st >> 32) == 2ull);
         const int stop = __builtin_ctzll(known | (1ull << 63));          // the nearest tile that knows its prefix (lane 63 at the latest if any)
@@ -209,17 +215,18 @@ __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned lo
     return (head ? 1u : 0u) | (last ? 2u : 0u) | (dead ? 4u : 0u);
 }
 // A2b in one pass over the sorted keys: head flags, their batch-wide exclusive scan (= the fragment index of every hit) and the fragment records.  A workgroup
-// owns a tile of 4 096 consecutive hits, each of its waves 16 rows of 64: a hit's neighbours are in the neighbouring lanes (or the edge lanes of the rows above
-// and below), the rank of a head inside the tile comes from the ballots of the 4 x 16 (wave, row) groups -- their 64 counts scanned by one wave -- and the tile's
-// offset from the tiles before it by decoupled look-back: a tile publishes its own count as soon as it has it, then adds up the published counts behind it until
-// it meets a tile that already knows its inclusive prefix (tile states: one 64-bit word, status in the high half so that value and status arrive together;
-// workgroups start in blockIdx order, so the tiles waited for are resident or finished).  Before: the library's scan over the flags (2.6 GB of keys read,
-// 1.3 GB of indices written) and a build kernel that read both again.  Records beyond cap are not written: the caller reads *total and comes back with room.
-#ifndef YD_FRAG_BS
+// of 16 waves owns a tile of 8 192 consecutive hits, each of its waves 8 rows of 64: a hit's neighbours are in the neighbouring lanes (or the edge lanes of the
+// rows above and below), the rank of a head inside the tile comes from the ballots of the 16 x 8 (wave, row) groups -- their 128 counts scanned by one wave, two
+// per lane -- and the tile's offset from the tiles before it by decoupled look-back: a tile publishes its own count as soon as it has it, then adds up the
+// published counts behind it until it meets a tile that already knows its inclusive prefix (tile states: one 64-bit word, status in the high half so that value
+// and status arrive together).  The tile IS the ticket the workgroup drew when it started (tileTicket): every earlier ticket holder is therefore resident (or
+// done) and publishes before it waits for anything -- no assumption about the order in which workgroups are dispatched.  Before: the library's scan over the
+// flags (2.6 GB of keys read, 1.3 GB of indices written) and a build kernel that read both again.  Records beyond cap are not written: the caller reads *total
+// and comes back with room.
 #define YD_FRAG_BS 1024
-#endif
 #define YD_FRAG_IPT 8
 #define YD_FRAG_TILE (YD_FRAG_BS * YD_FRAG_IPT)
+static_assert((YD_FRAG_IPT * (YD_FRAG_BS / 64)) % 64 == 0 && YD_FRAG_IPT <= 10, "k_frag_scan_build: wave 0 scans IPT x waves counts, a whole number per lane; the class bits of ten rows fit one word");
 __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap,
                                                                 unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
 {
@@ -230,7 +237,7 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
     unsigned long long key[YD_FRAG_IPT]; uint32_t cls = 0, cls2 = 0;           // three class bits per hit: ten in cls, six in cls2
     unsigned long long headMask[YD_FRAG_IPT];                                  // wave-uniform: the live heads of row k in this wave
     unsigned nDead = 0;
-    // wave w owns the hits wbase + k * 64 + lane: all its loads are issued together (16 rows and the two hits around the wave's range), a row's outer neighbours
+    // wave w owns the hits wbase + k * 64 + lane: all its loads are issued together (its rows and the two hits around the wave's range), a row's outer neighbours
     // are the edge lanes of the rows above and below
     const uint32_t wbase = base + w * (uint32_t)(64 * YD_FRAG_IPT);
 #pragma unroll
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
     }
     __syncthreads();
     if (w == 0u) {
-        // exclusive scan of the NW x 16 (wave, row) counts, NW / 4 consecutive ones per lane; then the look-back
+        // exclusive scan of the NW x IPT (wave, row) counts, E consecutive ones per lane; then the look-back
         constexpr int E = YD_FRAG_IPT * NW / 64;
         uint32_t v[E], sum = 0;
 #pragma unroll
@@ -310,6 +317,7 @@ __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
 // is set by the host.  A tile = 4 waves x 8 rows of 64 fragments.
 #define YD_REG_IPT 8
 #define YD_REG_TILE (256 * YD_REG_IPT)
+static_assert(4 * YD_REG_IPT <= 64, "k_region_scan: one lane of wave 0 per (wave, row) count");
 __global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *regStart, unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */)
 {
     __shared__ uint32_t sCnt[4 * YD_REG_IPT]; __shared__ uint32_t sPrefix;

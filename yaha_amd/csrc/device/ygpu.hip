@@ -276,7 +276,7 @@ static int buildFrags(ygpu_ctx *ctx, bool redo = false)      // redo: the region
         KL(k_frag_scan_build, dim3(nTiles), dim3(YD_FRAG_BS), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, fragDropGap(ctx), ctx->frags.as<DevFrag>(), cap,
            ctx->tileState.as<unsigned long long>(), total, ctx->kmerParts.as<unsigned int>());
         uint32_t two[2] = {0, 0}; int rc = fetchU32(ctx, total, two, 2); if (rc) return rc;
-        if (two[1]) { ctx->err = "fragment scan: a tile's look-back gave up (workgroups out of order)"; return YGPU_EINTERNAL; }
+        if (two[1]) { ctx->err = "fragment scan: a tile was not published within 30 s (look-back gave up)"; return YGPU_EINTERNAL; }
         const uint32_t F = two[0];
         if (F <= cap) { ctx->nFrags = F; break; }
         if (pass >= 2) { ctx->err = "fragment build: the count changed between passes"; return YGPU_EINTERNAL; }
@@ -301,7 +301,7 @@ static int stageChain(ygpu_ctx *ctx)
     uint32_t *cnt = ctx->counters.as<uint32_t>();
     HIPCHK(hipMemsetAsync(ctx->tileState.p, 0, 8ull * (nRegTiles + 1), ctx->stream));
     KL(k_region_scan, dim3(nRegTiles), dim3(256), 0, ctx->stream, ctx->frags.as<DevFrag>(), F, ctx->P.maxGap, ctx->regStart.as<uint32_t>(), ctx->tileState.as<unsigned long long>(), cnt + CNT_NREG);
-    uint32_t R = 0; { uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NREG, two, 2); if (rc) return rc; if (two[1]) { ctx->err = "region scan: a tile's look-back gave up (workgroups out of order)"; return YGPU_EINTERNAL; } R = two[0]; }
+    uint32_t R = 0; { uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NREG, two, 2); if (rc) return rc; if (two[1]) { ctx->err = "region scan: a tile was not published within 30 s (look-back gave up)"; return YGPU_EINTERNAL; } R = two[0]; }
     ctx->nRegions = R;
     HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NBIG, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NSMALL, 0, 4, ctx->stream));
@@ -988,6 +988,8 @@ int ygpu_set_postfilter(ygpu_ctx *ctx, const ygpu_postfilter_params *p)
 {
     if (!ctx || !ctx->stream || !p) return YGPU_EINVAL;
     if (p->bppN < 0 || p->bppN > 65536 || (p->bppN && !p->bppThr) || (p->n_seqs && (!p->seq_start || !p->seq_length))) { ctx->err = "ygpu_set_postfilter: bad break point table or sequence table"; return YGPU_EINVAL; }
+    // (the wave's successor relaxation writes node j > i only while it reads node i: with a non-overlap requirement below one base a node could be its own successor, oqc_stage.h)
+    if (p->minNonOverlap < 1) { ctx->err = "ygpu_set_postfilter: minNonOverlap (-MNO) must be at least 1 for the device stage; use the host filter"; return YGPU_EINVAL; }
     HIPCHK(hipSetDevice(ctx->device));
     ENSURE(ctx->oqThr, 4ull * (p->bppN + 1)); ENSURE(ctx->oqSeqStart, 4ull * (p->n_seqs + 1)); ENSURE(ctx->oqSeqLen, 4ull * (p->n_seqs + 1));
     if (p->bppN) HIPCHK(hipMemcpyAsync(ctx->oqThr.p, p->bppThr, 4ull * p->bppN, hipMemcpyHostToDevice, ctx->stream));

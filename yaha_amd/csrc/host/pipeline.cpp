@@ -280,7 +280,9 @@ int runQueries(Args &a, FILE *log)
     // removal only), for break point costs that are no step function, and on request (-dpf N, YAHA_HOST_OQC=1).
     yoqc::Params oqP; std::vector<uint32_t> oqThr, oqSeqStart, oqSeqLen; oqcParamsFromArgs(A, oqP, oqThr);
     for (auto &sq : S->genome.seqs) { oqSeqStart.push_back(sq.start); oqSeqLen.push_back(sq.length); }
-    const bool deviceFilter = A.OQC && A.devicePostFilter && oqP.bppN >= 0 && getenv("YAHA_HOST_OQC") == nullptr;
+    // (-MNO below 1: the graph's successor test then also lets a node relax itself and nodes before it, which the device stage's one-successor-per-lane step does not order
+    // the way the sequential loop does, GraphPath.cpp:633-700 -- those runs keep the host filter, as ygpu_set_postfilter insists)
+    const bool deviceFilter = A.OQC && A.devicePostFilter && oqP.bppN >= 0 && oqP.minNonOverlap >= 1 && getenv("YAHA_HOST_OQC") == nullptr;
     ygpu_postfilter_params PF; memset(&PF, 0, sizeof PF);
     PF.minNonOverlap = oqP.minNonOverlap; PF.BPCost = oqP.BPCost; PF.maxBPLog = oqP.maxBPLog; PF.FBS = oqP.FBS; PF.FBS_PSLength = oqP.FBS_PSLength; PF.FBS_PSScore = oqP.FBS_PSScore;
     PF.bppVmin = oqP.bppVmin; PF.bppN = std::max(0, oqP.bppN); PF.bppThr = oqThr.data(); PF.n_seqs = (uint32_t)oqSeqStart.size(); PF.seq_start = oqSeqStart.data(); PF.seq_length = oqSeqLen.data();
@@ -431,7 +433,7 @@ int yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **
 int yaha_session_postfilter_params(yaha_session *s, ygpu_postfilter_params *p)
 {
     yoqc::Params P; oqcParamsFromArgs(s->args, P, s->pfThr);
-    if (!s->args.OQC || P.bppN < 0) { s->err = "the device post-filter takes OQC runs with non-negative break point costs only"; return YGPU_EINVAL; }
+    if (!s->args.OQC || P.bppN < 0 || P.minNonOverlap < 1) { s->err = "the device post-filter takes OQC runs with non-negative break point costs and -MNO of at least 1 only"; return YGPU_EINVAL; }
     s->pfSeqStart.clear(); s->pfSeqLen.clear(); for (auto &sq : s->genome.seqs) { s->pfSeqStart.push_back(sq.start); s->pfSeqLen.push_back(sq.length); }
     memset(p, 0, sizeof *p);
     p->minNonOverlap = P.minNonOverlap; p->BPCost = P.BPCost; p->maxBPLog = P.maxBPLog; p->FBS = P.FBS; p->FBS_PSLength = P.FBS_PSLength; p->FBS_PSScore = P.FBS_PSScore;
