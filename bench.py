@@ -225,6 +225,15 @@ def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1):
     /dev/shm) on n_reads x 1 kbp reads -- BASELINE config 4's size by default -- over `gpus` devices.  `steady_reads_per_s` is the command line's own figure
     (YAHA_STATS=1): reads written after the first batch / time between the first and the last batch's write, i.e. without start-up."""
     reads = make_reads(cache, fa, "e2e", n_reads, 1000, 0.017, seed)
+    if gpus > 1:                                         # N devices: N times the reads (BASELINE config 4's size per device), the one file repeated
+        many = os.path.join(cache, "e2e_x%d_%s" % (gpus, os.path.basename(reads)))
+        if not os.path.exists(many):
+            with open(many + ".tmp", "wb") as o:
+                for _ in range(gpus):
+                    with open(reads, "rb") as f:
+                        shutil.copyfileobj(f, o, 16 << 20)
+            os.replace(many + ".tmp", many)
+        reads, n_reads = many, n_reads * gpus
     out = "/dev/shm/yaha_bench_e2e_%d.sam" % os.getpid()
     tiny = os.path.join(cache, "tiny.fa")
     head_reads(reads, tiny, 16)
@@ -257,7 +266,10 @@ def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1):
     finally:
         if os.path.exists(out):
             os.remove(out)
-    return {"reads": n_reads, "gpus": gpus, "seconds": dt, "e2e_reads_per_s": n_reads / dt, "steady_reads_per_s": stats[best].get("steady_reads_per_s"), "seconds_each_run": runs, "contexts_up_ms_of_the_settling_runs": settled, "sam_records": nrec, "cli_stats": stats[best],
+    per_dev = stats[best].get("reads_per_device") or []
+    steady = stats[best].get("steady_reads_per_s")
+    return {"reads": n_reads, "gpus": gpus, "seconds": dt, "e2e_reads_per_s": n_reads / dt, "steady_reads_per_s": steady, "contexts_up_ms": stats[best].get("contexts_up_ms"), "reads_per_device": per_dev,
+            "device_steady_reads_per_s": [round(steady * n / max(1, sum(per_dev))) for n in per_dev] if steady else None, "seconds_each_run": runs, "contexts_up_ms_of_the_settling_runs": settled, "sam_records": nrec, "cli_stats": stats[best],
             "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam%s (defaults: -ctx 3, batches of ~16 M bases, host threads from the usable CPUs)" % (n_reads, " -gpus %d" % gpus if gpus > 1 else "")}
 
 

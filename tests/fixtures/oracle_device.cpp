@@ -24,6 +24,13 @@ int ygpu_init(int device, const ygpu_index_view *v, const ygpu_params *p, ygpu_c
     if (const char *ms = getenv("YTEST_INIT_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(ms)));
     return 0;
 }
+int ygpu_device_count(void) { const char *nd = getenv("YTEST_DEVICES"); return nd ? atoi(nd) : 1; }
+int ygpu_init_multi(const int *devices, int n, const ygpu_index_view *v, const ygpu_params *p, ygpu_ctx **out, int *rc_each)
+{
+    int rc = 0;
+    for (int k = 0; k < n; k++) { const int r = ygpu_init(devices[k], v, p, &out[k]); if (rc_each) rc_each[k] = r; if (r && !rc) rc = r; }
+    return rc;
+}
 int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out) { ygpu_ctx *c = new ygpu_ctx; c->V = parent->V; c->P = parent->P; c->device = parent->device; memset(&c->res, 0, sizeof c->res); *out = c; return 0; }
 void ygpu_destroy(ygpu_ctx *c) { if (!c) return; if (c->have) yoracle_free_result(&c->res); delete c; }
 const char *ygpu_last_error(const ygpu_ctx *c) { return c ? c->err.c_str() : "no context"; }

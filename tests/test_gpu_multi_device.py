@@ -1,0 +1,137 @@
+"""GPU tier: more than one index image, more than one device.
+
+The reference runs N threads over ONE mapped index (Query.c:565-626, 642-690).  Here N devices each need the image in HBM and take it through ygpu_init_multi: the
+first from the host, every further one piece by piece from the device before it.  On the 1-GPU box the chain is driven with the same device listed twice (two
+images on one device, the second one a device-to-device copy of the first); the tests marked `two_devices` run where the box has a second GPU -- `yaha -gpus 2`
+against the real reference, a context on device 1, the peer copy itself and its host fall-back, and `bench.py --gpus 2` over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import oracle
+import yaha_amd as ya
+from conftest import ROOT, strip_pg, golden_lines
+from test_gpu_long_reads import by_read
+
+pytestmark = pytest.mark.gpu
+SIM = os.path.join(ROOT, "tools", "yaha_sim")
+
+
+def _ndev():
+    try:
+        return ya.device_count()
+    except Exception:
+        return 0
+
+
+two_devices = pytest.mark.skipif(_ndev() < 2, reason="needs a box with two GPUs")
+
+
+def _golden_batch_equals_oracle(s, b, ctxs):
+    exp, _own = oracle.run(s.index, s.params, b, threads=4)
+    exp = ya.result_records(exp)
+    for c in ctxs:
+        c.upload(b)
+        c.run()
+        assert ya.result_records(c.collect()) == exp
+
+
+def test_two_images_on_one_device_the_second_copied_from_the_first(work, index11):
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "rchim.fa")]) as s:
+        b = s.next_batch(300)
+        ctxs = ya.Context.on_devices(s.index, s.params, [0, 0])
+        try:
+            clone = ya.Context(s.index, s.params, parent=ctxs[1])          # a context that shares the COPIED image
+            _golden_batch_equals_oracle(s, b, ctxs + [clone])
+            clone.close()
+        finally:
+            for c in reversed(ctxs):
+                c.close()
+
+
+def test_three_images_chain_and_the_host_fall_back(work, index11, monkeypatch):
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
+        b = s.next_batch(120)
+        for peer in ("1", "0"):                                              # YGPU_PEER_COPY=0: every image from the host
+            monkeypatch.setenv("YGPU_PEER_COPY", peer)
+            ctxs = ya.Context.on_devices(s.index, s.params, [0, 0, 0])
+            try:
+                _golden_batch_equals_oracle(s, b, ctxs[1:])
+            finally:
+                for c in reversed(ctxs):
+                    c.close()
+
+
+def test_init_multi_reports_the_device_that_does_not_exist(work, index11):
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
+        with pytest.raises(RuntimeError, match="device 63: -2 device index out of range"):
+            ya.Context.on_devices(s.index, s.params, [0, 63])
+
+
+@two_devices
+def test_context_on_the_second_device(work, index11):
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "rchim.fa")]) as s:
+        b = s.next_batch(300)
+        with ya.Context(s.index, s.params, device=1) as c1:
+            with ya.Context(s.index, s.params, parent=c1) as c1b:
+                _golden_batch_equals_oracle(s, b, [c1, c1b])
+
+
+@two_devices
+def test_image_copied_between_two_devices_and_uploaded_to_both(work, index11, monkeypatch):
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "rchim.fa")]) as s:
+        b = s.next_batch(300)
+        for peer in ("1", "0"):
+            monkeypatch.setenv("YGPU_PEER_COPY", peer)
+            ctxs = ya.Context.on_devices(s.index, s.params, [0, 1])
+            try:
+                _golden_batch_equals_oracle(s, b, ctxs)
+            finally:
+                for c in reversed(ctxs):
+                    c.close()
+
+
+@two_devices
+def test_command_line_over_two_devices_against_the_reference(work, tmp_path):
+    """`yaha -gpus 2 -ctx 2` on 4 096 reads of 1 kbp at -L 15 (BASELINE config 4's shape, two shards) == the real reference (or the oracle port without it)."""
+    g = str(tmp_path / "g.fa")
+    subprocess.check_call([SIM, "genome", "--seed", "4242", "--out", g, "--seqs", "6", "--len", "20000000", "--repeat-frac", "0.4"])
+    ya.build_index(["-g", g, "-L", "15"])
+    idx = str(tmp_path / "g.X15_01_65525S")
+    reads = str(tmp_path / "r.fa")
+    subprocess.check_call([SIM, "reads", "--genome", g, "--out", reads, "--seed", "91", "--n", "4096", "--len", "1000", "--div", "0.017", "--chimeric", "0.1"])
+    mine = str(tmp_path / "mine.sam")
+    p = subprocess.run([ya.CLI_PATH, "-x", idx, "-q", reads, "-osh", mine, "-gpus", "2", "-ctx", "2", "-batch", "512"], stderr=subprocess.PIPE, env=dict(os.environ, YAHA_STATS="1"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    st = [l for l in p.stderr.decode().split("\n") if l.startswith("[yaha] stats ")]
+    stats = json.loads(st[0][len("[yaha] stats "):])
+    assert stats["gpus"] == 2 and all(n > 0 for n in stats["reads_per_device"])          # both devices took batches
+    ref = str(tmp_path / "ref.sam")
+    if oracle.have_reference():
+        oracle.run_reference(["-x", idx, "-q", reads, "-osh", ref, "-t", str(min(64, os.cpu_count() or 1))])
+        exp = strip_pg(open(ref, newline="").read())
+    else:
+        exp = strip_pg(subprocess.run([ya.CLI_PATH, "-x", idx, "-q", reads, "-osh", "stdout"], stdout=subprocess.PIPE, check=True).stdout.decode())
+    h1, r1, o1 = by_read(strip_pg(open(mine, newline="").read()))
+    h2, r2, _ = by_read(exp)
+    assert h1 == h2 and r1 == r2
+    names = [l[1:].split()[0] for l in open(reads) if l.startswith(">")]
+    assert o1 == [n for n in names if n in r1]                                            # input order over both devices
+
+
+@two_devices
+def test_bench_two_gpus_over_rccl(tmp_path):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "YAHA_BENCH_BACKEND")}
+    env.update(YAHA_BENCH_CACHE=os.environ.get("YAHA_BENCH_CACHE", str(tmp_path / "cache")), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--genome-mbp", "100", "--contexts", "2", "--e2e-reads", "65536"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0
+    e = j["end_to_end"]
+    assert "error" not in e and e["gpus"] == 2 and len(e["reads_per_device"]) == 2 and all(n > 0 for n in e["reads_per_device"])

@@ -527,3 +527,30 @@ def test_postfilter_on_synthetic_clump_lists(work, index11, seed, max_clumps, ex
             dev = s.emit_filtered(f)
             assert dev == host
             assert len(host) > 1000
+
+
+def test_real_human_sequence_command_line_equals_the_reference(tmp_path):
+    """The whole command line (HIP hot path, post-filter on the device) on real human sequence == SAM of the real reference (tests/golden/human: a 10 Mbp
+    pseudo-reference of hg18 reads from the reference's testdata, 2 000 real 1 kbp + 2 000 real 200 bp hg18 reads that reach it through its repeat families, 1 500
+    reads sampled from it), -L 15, defaults; line for line, in the reference's -t 1 order.  Also with the filter on the host."""
+    from test_oracle_golden import unpack_human, human_golden
+    d = str(tmp_path)
+    meta = unpack_human(d)
+    ya.build_index(["-g", os.path.join(d, "hs_pseudo.fa"), "-L", "15"])
+    idx = os.path.join(d, "hs_pseudo.X15_01_65525S")
+    for name, run in sorted(meta["runs"].items()):
+        for extra in ([], ["-dpf", "N"]):
+            p = subprocess.run([ya.CLI_PATH, "-x", idx, "-q", os.path.join(d, run["reads"]), "-osh", "stdout"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            assert strip_pg(p.stdout.decode()) == human_golden(name), "command line differs from the reference on %s %s" % (name, extra)
+    # the hot path's work counters on this set, next to the synthetic genome's (DESIGN.md section 5)
+    with ya.Session(["-x", idx, "-q", os.path.join(d, "hs_real1k.fa")]) as s:
+        b = s.next_batch(2000)
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.upload(b); ctx.run(); r = ctx.collect()
+            ro, _own = oracle.run(s.index, s.params, b, threads=8)
+            assert ya.result_records(r) == ya.result_records(ro) and r.counters.as_dict() == ro.counters.as_dict()
+            c = r.counters.as_dict(); n = float(b.n_reads)
+            print("human 1 kbp reads on the 10 Mbp pseudo-reference, per read: hits %.0f, fragments %.0f, clumps aligned %.0f, X-drop calls %.0f, extension cells %.0f, gap cells %.0f" %
+                  (c["hits"] / n, c["fragments"] / n, c["clumps_formed"] / n, c["dp_ext_calls"] / n, c["dp_ext_cells"] / n, c["dp_gap_cells"] / n))
+    os.remove(idx)

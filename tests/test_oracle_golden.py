@@ -206,3 +206,40 @@ def test_oracle_stages_match_the_instrumented_reference(work, index11, name):
         res = oracle.dp_batch(s.index, s.params, b, probs)
         bad = [k for k in range(len(probs)) if res[k] != exp[k]]
         assert not bad, "%d of %d DP calls differ from the reference, first: %r got %r exp %r" % (len(bad), len(probs), (probs[bad[0]].mode, probs[bad[0]].rOff, probs[bad[0]].qOff, probs[bad[0]].qLen), res[bad[0]], exp[bad[0]])
+
+
+# ---- real human sequence (tests/golden/human, made by tests/golden/make_human_golden.py with the real reference binary at -L 15) -----------------------------
+HUMAN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "human")
+
+
+def unpack_human(d):
+    """The pseudo-reference (1 000 hg18 reads of 10 kbp from the reference's testdata, concatenated), the two real read sets, and the simulated set (regenerated
+    from its seed by this repo's simulator).  Returns the directory's file names."""
+    import gzip, json, shutil, subprocess
+    from conftest import ROOT
+    for f in ("hs_pseudo.fa", "hs_real1k.fa", "hs_real200.fa"):
+        with gzip.open(os.path.join(HUMAN, f + ".gz"), "rb") as g, open(os.path.join(d, f), "wb") as o:
+            shutil.copyfileobj(g, o)
+    meta = json.load(open(os.path.join(HUMAN, "human.json")))
+    subprocess.check_call([os.path.join(ROOT, "tools", "yaha_sim"), "reads", "--genome", os.path.join(d, "hs_pseudo.fa"), "--out", os.path.join(d, "hs_sim1k.fa")] + meta["sim_args"])
+    return meta
+
+
+def human_golden(name):
+    import gzip
+    with gzip.open(os.path.join(HUMAN, name + ".out.gz"), "rb") as g:
+        return g.read().decode().split("\n")
+
+
+def test_real_human_sequence_at_the_default_seed_length(work, tmp_path):
+    """Oracle + host stages == the real reference on human sequence: a 10 Mbp pseudo-reference of real hg18 reads (Alu / L1 / satellite content), real 1 kbp and
+    200 bp hg18 reads that hit it through its repeat families, and reads sampled from it -- the reference's default -L 15 index (a 4.3 GB table), built by this
+    repo's host builder."""
+    d = str(tmp_path)
+    meta = unpack_human(d)
+    ya.build_index(["-g", os.path.join(d, "hs_pseudo.fa"), "-L", "15", "-cpuindex"])
+    idx = os.path.join(d, "hs_pseudo.X15_01_65525S")
+    for name, run in sorted(meta["runs"].items()):
+        mine = run_oracle_pipeline(idx, os.path.join(d, run["reads"]), "-osh", [], batch=500, threads=8)
+        assert mine == human_golden(name), "oracle + host stages differ from the reference on " + name
+    os.remove(idx)

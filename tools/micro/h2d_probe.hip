@@ -101,6 +101,60 @@ int main(int argc, char **argv)
         for (auto &b : bufs) CK(hipHostFree(b));
     }
     { double t = now(); CK(hipMemcpy(dev2, dev, bytes, hipMemcpyDeviceToDevice)); CK(hipDeviceSynchronize()); report("device -> device (same GPU)", now() - t); }
+    // ---- what a fresh process pays: device memory that was never written, and a mapping whose pages were never touched by this process ----
+    { char *pin; CK(hipHostMalloc((void **)&pin, bytes, hipHostMallocDefault)); memset(pin, 1, bytes);
+      for (int variant = 0; variant < 4; variant++) {
+          char *fresh; double t = now(); CK(hipMalloc(&fresh, bytes)); const double tAlloc = now() - t; double tTouch = 0;
+          if (variant == 1) { t = now(); CK(hipMemset(fresh, 0, bytes)); CK(hipDeviceSynchronize()); tTouch = now() - t; }
+          if (variant == 2) { t = now(); for (size_t o = 0; o < bytes; o += (2u << 20)) CK(hipMemsetAsync(fresh + o, 0, 4, 0)); CK(hipDeviceSynchronize()); tTouch = now() - t; }
+          if (variant == 3) { t = now(); CK(hipMemset(fresh, 0, bytes)); CK(hipDeviceSynchronize()); tTouch = now() - t; t = now(); CK(hipMemset(fresh, 0, bytes)); CK(hipDeviceSynchronize()); printf("   second hipMemset of the same buffer: %.1f ms\n", (now() - t) * 1e3); }
+          t = now(); CK(hipMemcpy(fresh, pin, bytes, hipMemcpyHostToDevice)); const double tCopy = now() - t;
+          t = now(); CK(hipMemcpy(fresh, pin, bytes, hipMemcpyHostToDevice)); const double tCopy2 = now() - t;
+          printf("fresh hipMalloc (%.1f ms), %s (%.1f ms): pinned -> device %.1f ms (%.1f GB/s), again %.1f ms\n", tAlloc * 1e3,
+                 variant == 0 ? "untouched" : variant == 2 ? "4 bytes set per 2 MB" : "hipMemset of all of it", tTouch * 1e3, tCopy * 1e3, bytes / tCopy / 1e9, tCopy2 * 1e3);
+          CK(hipFree(fresh)); }
+      CK(hipHostFree(pin)); }
+    for (int variant = 0; variant < 5; variant++) {
+        // a new mapping: its pages are in the page cache but not in this process's page table
+        munmap(map, bytes); map = (char *)mmap(nullptr, bytes, PROT_READ, variant == 1 ? MAP_SHARED | MAP_POPULATE : MAP_SHARED, fd, 0); if (map == MAP_FAILED) { perror("mmap"); return 1; }
+        double tPrep = 0, t = now();
+        if (variant >= 2) {      // MADV_POPULATE_READ (22) by T threads over slices
+            const int T = variant == 2 ? 1 : variant == 3 ? 4 : 16; std::atomic<size_t> next(0); const size_t slice = 64u << 20; std::atomic<int> bad(0);
+            auto work = [&]() { for (;;) { const size_t o = next.fetch_add(slice); if (o >= bytes) break; if (madvise(map + o, std::min(slice, bytes - o), 22) != 0) bad = 1; } };
+            std::vector<std::thread> th; for (int k = 1; k < T; k++) th.emplace_back(work); work(); for (auto &x : th) x.join();
+            tPrep = now() - t; if (bad) printf("   (MADV_POPULATE_READ refused)\n");
+        } else if (variant == 1) tPrep = 0;
+        t = now(); CK(hipMemcpy(dev, map, bytes, hipMemcpyHostToDevice)); const double tCopy = now() - t;
+        printf("new mapping, %s (%.1f ms): plain hipMemcpy %.1f ms (%.1f GB/s)\n", variant == 0 ? "nothing done" : variant == 1 ? "MAP_POPULATE (inside mmap)" : variant == 2 ? "MADV_POPULATE_READ, 1 thread" : variant == 3 ? "MADV_POPULATE_READ, 4 threads" : "MADV_POPULATE_READ, 16 threads",
+               tPrep * 1e3, tCopy * 1e3, bytes / tCopy / 1e9);
+    }
+    for (int variant = 0; variant < 4; variant++) {
+        // what ygpu_init did until round 4: a PRIVATE read-only mapping, copied with hipMemcpyAsync + hipStreamSynchronize in 256 MB slices by one or two threads
+        munmap(map, bytes); map = (char *)mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0); if (map == MAP_FAILED) { perror("mmap"); return 1; }
+        double t = now();
+        if (variant == 0) CK(hipMemcpy(dev, map, bytes, hipMemcpyHostToDevice));
+        else if (variant == 1) { CK(hipMemcpyAsync(dev, map, bytes, hipMemcpyHostToDevice, 0)); CK(hipStreamSynchronize(0)); }
+        else { const int T = variant == 2 ? 1 : 2; std::atomic<size_t> next(0); const size_t slice = 256u << 20;
+            auto work = [&]() { CK(hipSetDevice(0)); hipStream_t st; CK(hipStreamCreate(&st));
+                for (;;) { const size_t o = next.fetch_add(slice); if (o >= bytes) break; CK(hipMemcpyAsync(dev + o, map + o, std::min(slice, bytes - o), hipMemcpyHostToDevice, st)); CK(hipStreamSynchronize(st)); }
+                (void)hipStreamDestroy(st); };
+            std::vector<std::thread> th; for (int k = 1; k < T; k++) th.emplace_back(work); work(); for (auto &x : th) x.join(); }
+        report(variant == 0 ? "PRIVATE mapping, plain hipMemcpy" : variant == 1 ? "PRIVATE mapping, one hipMemcpyAsync + synchronize" : variant == 2 ? "PRIVATE mapping, 256 MB slices async + sync, 1 thread" : "PRIVATE mapping, 256 MB slices async + sync, 2 threads", now() - t);
+    }
+    {   // pread into pinned buffers, 4 threads, into device memory that was never written
+        char *fresh; CK(hipMalloc(&fresh, bytes)); const int T = 4; const size_t piece = 8u << 20; std::atomic<size_t> next(0);
+        std::vector<char *> bufs(2 * T); for (auto &b : bufs) CK(hipHostMalloc((void **)&b, piece, hipHostMallocDefault));
+        double t = now();
+        auto work = [&](int id) {
+            CK(hipSetDevice(0)); hipStream_t st; CK(hipStreamCreate(&st)); hipEvent_t ev[2]; CK(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming)); bool used[2] = {false, false};
+            for (int k = 0;; k ^= 1) { const size_t o = next.fetch_add(piece); if (o >= bytes) break; const size_t n = std::min(piece, bytes - o);
+                if (used[k]) CK(hipEventSynchronize(ev[k]));
+                char *b = bufs[2 * id + k]; size_t got = 0; while (got < n) { ssize_t r = pread(fd, b + got, n - got, o + got); if (r <= 0) { perror("pread"); exit(1); } got += r; }
+                CK(hipMemcpyAsync(fresh + o, b, n, hipMemcpyHostToDevice, st)); CK(hipEventRecord(ev[k], st)); used[k] = true; }
+            CK(hipStreamSynchronize(st)); (void)hipStreamDestroy(st); };
+        std::vector<std::thread> th; for (int k = 1; k < T; k++) th.emplace_back(work, k); work(0); for (auto &x : th) x.join();
+        report("pread, 4 threads, 8 MB pieces, into never-written device memory", now() - t);
+        for (auto &b : bufs) CK(hipHostFree(b)); CK(hipFree(fresh)); }
     munmap(map, bytes); close(fd); unlink(path);
     return 0;
 }

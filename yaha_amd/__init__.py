@@ -85,7 +85,7 @@ DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
 DP_KERNELS_AUTO, DP_KERNELS_WAVE, DP_KERNELS_LANES, DP_KERNELS_LANES_CAREFUL = 0, 1, 2, 3
 
 EXPORTS = (
-    "ygpu_init", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter", "ygpu_inject_results", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
+    "ygpu_device_count", "ygpu_init", "ygpu_init_multi", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter", "ygpu_inject_results", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
     "ygpu_submit", "ygpu_poll", "ygpu_wait", "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch", "ygpu_dp_batch_ex",
     "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
     "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit", "yaha_session_postfilter_params", "yaha_session_emit_filtered",
@@ -174,6 +174,11 @@ class Session:
         self.close()
 
 
+def device_count():
+    """HIP devices visible to this process (ygpu_device_count)."""
+    return int(lib().ygpu_device_count())
+
+
 class Context:
     """One device context = the reference's per-thread QueryState, batched (include/yaha_hip.h)."""
 
@@ -186,6 +191,23 @@ class Context:
         if rc != 0:
             msg = lib().ygpu_last_error(self._h).decode() if self._h else ""
             raise RuntimeError("ygpu_init failed: %d %s (the HIP path is mandatory; there is no CPU fallback)" % (rc, msg))
+
+    @classmethod
+    def on_devices(cls, index_view, params, devices):
+        """One context per listed device through ygpu_init_multi: the first device takes the index image from the host, every further one from the device before
+        it (the same device may be listed twice: two images on one device)."""
+        n = len(devices)
+        devs = (C.c_int * n)(*devices); hs = (C.c_void_p * n)(); rcs = (C.c_int * n)()
+        rc = lib().ygpu_init_multi(devs, n, C.byref(index_view), C.byref(params), hs, rcs)
+        ctxs = []
+        for k in range(n):
+            c = cls.__new__(cls); c._h = C.c_void_p(hs[k]); ctxs.append(c)
+        if rc != 0:
+            msgs = ["device %d: %d %s" % (devices[k], rcs[k], lib().ygpu_last_error(ctxs[k]._h).decode() if hs[k] else "") for k in range(n) if rcs[k]]
+            for c in ctxs:
+                c.close()
+            raise RuntimeError("ygpu_init_multi failed: %d (%s)" % (rc, "; ".join(msgs)))
+        return ctxs
 
     def _check(self, rc, what):
         if rc != 0:

@@ -791,16 +791,81 @@ static int initCommon(ygpu_ctx *ctx, int device)
     return 0;
 }
 
-extern "C" {
 
-int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_ctx **out)
+// ---- the index image: one copy from the host, the other devices from their neighbour ---------------------------------------------------------------------
+// The reference maps the index once for all its threads (Query.c:565-626).  Here every device needs the image in its own HBM -- 16.7 GB at hg18 scale -- and N uploads
+// from the host at once share the host's memory and its PCIe root ports.  So the image is cut into pieces (one linear sequence over bases, table, offsets), the FIRST
+// device takes them from the host, and every further device takes piece k from the device before it as soon as that one has it (hipMemcpyPeerAsync over xGMI; a chain,
+// pipelined by piece: the last device has the image a few pieces after the first).  A device that cannot reach its neighbour (hipDeviceCanAccessPeer) uploads from the
+// host itself.  While the pieces travel the device's thread creates streams and events and has the code object loaded (a first kernel launch), which used to follow the copy.
+namespace {
+struct ImagePiece { size_t part; size_t off, bytes; };                                    // part: 0 bases, 1 table, 2 offsets
+struct ImagePlan {
+    const char *src[3]; size_t bytes[3]; std::vector<ImagePiece> pieces;
+    void build(const ygpu_index_view *ix, size_t pieceBytes)
+    {
+        const uint64_t HT = 1ull << (2 * ix->wordLen);
+        src[0] = (const char *)ix->bases; bytes[0] = (size_t)ix->n_base_bytes; src[1] = (const char *)ix->startingOffs; bytes[1] = (size_t)(4 * (HT + 1)); src[2] = (const char *)ix->ROA; bytes[2] = (size_t)(4ull * ix->totalMatches);
+        for (size_t part = 0; part < 3; part++) for (size_t o = 0; o < bytes[part]; o += pieceBytes) pieces.push_back({part, o, std::min(pieceBytes, bytes[part] - o)});
+    }
+};
+struct ImageState {                                                                       // one per device of a ygpu_init_multi call
+    std::unique_ptr<std::atomic<int>[]> done; std::atomic<int> failed{0}; char *dst[3] = {nullptr, nullptr, nullptr};
+};
+__global__ void k_touch(unsigned int *p) { if (p && threadIdx.x == 1000) *p = 0; }      // (the first launch loads the library's code object: ~20 ms that need not follow the image)
+
+// pieces from host memory: `nt` threads, each with a stream of its own, pieces taken from a common counter (the runtime's own path for unpinned memory pins a piece
+// and lets the DMA engines read it in place: 55 GB/s for a single hipMemcpy of a mapped file, tools/micro/h2d_probe.hip); staged = the threads copy the pieces
+// into page-locked buffers of their own first (YGPU_UPLOAD=staged:T)
+static void uploadFromHost(int device, const ImagePlan &plan, ImageState &me, int nt, bool staged)
 {
-    *out = nullptr;
-    if (!ix || !p) return YGPU_EINVAL;
-    ygpu_ctx *ctx = new ygpu_ctx; *out = ctx; ctx->device = device;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { ctx->err = "no HIP device visible: the hot path needs an MI355X (there is no CPU fallback)"; return YGPU_ENODEV; }
-    if (device < 0 || device >= ndev) { ctx->err = "device index out of range"; return YGPU_ENODEV; }
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        if (hipSetDevice(device) != hipSuccess) { me.failed = 1; return; }
+        hipStream_t st; if (hipStreamCreate(&st) != hipSuccess) { me.failed = 1; return; }
+        char *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2]; bool used[2] = {false, false}; size_t pend[2] = {0, 0}; size_t maxPiece = 0; for (auto &q : plan.pieces) maxPiece = std::max(maxPiece, q.bytes);
+        if (staged) for (int k = 0; k < 2; k++) if (hipHostMalloc((void **)&buf[k], maxPiece, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { me.failed = 1; }
+        for (int k = 0; !me.failed; k ^= 1) {
+            const size_t i = next.fetch_add(1); if (i >= plan.pieces.size()) break;
+            const ImagePiece &q = plan.pieces[i]; char *d = me.dst[q.part] + q.off; const char *sp = plan.src[q.part] + q.off;
+            if (!staged) { if (hipMemcpyAsync(d, sp, q.bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) me.failed = 1; else me.done[i].store(1, std::memory_order_release); continue; }
+            if (used[k]) { if (hipEventSynchronize(ev[k]) != hipSuccess) { me.failed = 1; break; } me.done[pend[k]].store(1, std::memory_order_release); used[k] = false; }
+            memcpy(buf[k], sp, q.bytes);
+            if (hipMemcpyAsync(d, buf[k], q.bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { me.failed = 1; break; }
+            used[k] = true; pend[k] = i;
+        }
+        if (staged) { if (hipStreamSynchronize(st) != hipSuccess) me.failed = 1; for (int k = 0; k < 2; k++) { if (used[k] && !me.failed) me.done[pend[k]].store(1, std::memory_order_release); if (buf[k]) { (void)hipHostFree(buf[k]); (void)hipEventDestroy(ev[k]); } } }
+        (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> th; for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work(); for (auto &x : th) x.join();
+    if (me.failed) (void)hipGetLastError();
+}
+// pieces from the neighbour's image, each as soon as the neighbour has it
+static void copyFromPeer(int device, int srcDevice, const ImagePlan &plan, ImageState &me, ImageState &from)
+{
+    if (hipSetDevice(device) != hipSuccess) { me.failed = 1; return; }
+    hipStream_t st; if (hipStreamCreate(&st) != hipSuccess) { me.failed = 1; return; }
+    // (a window of copies in flight: the events of the last W pieces; a piece is published once its event has completed)
+    const int W = 4; hipEvent_t ev[W]; size_t pend[W]; bool used[W]; for (int k = 0; k < W; k++) { used[k] = false; if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) me.failed = 1; }
+    for (size_t i = 0; i < plan.pieces.size() && !me.failed; i++) {
+        const int k = (int)(i % W);
+        if (used[k]) { if (hipEventSynchronize(ev[k]) != hipSuccess) { me.failed = 1; break; } me.done[pend[k]].store(1, std::memory_order_release); used[k] = false; }
+        while (!from.done[i].load(std::memory_order_acquire)) { if (from.failed) { me.failed = 1; break; } std::this_thread::yield(); }
+        if (me.failed) break;
+        const ImagePiece &q = plan.pieces[i];
+        const hipError_t e = device == srcDevice ? hipMemcpyAsync(me.dst[q.part] + q.off, from.dst[q.part] + q.off, q.bytes, hipMemcpyDeviceToDevice, st)
+                                                 : hipMemcpyPeerAsync(me.dst[q.part] + q.off, device, from.dst[q.part] + q.off, srcDevice, q.bytes, st);
+        if (e != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { me.failed = 1; break; }
+        used[k] = true; pend[k] = i;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) me.failed = 1;
+    for (int k = 0; k < W; k++) { if (used[k] && !me.failed) me.done[pend[k]].store(1, std::memory_order_release); (void)hipEventDestroy(ev[k]); }
+    (void)hipStreamDestroy(st);
+    if (me.failed) (void)hipGetLastError();
+}
+static int checkParams(ygpu_ctx *ctx, const ygpu_index_view *ix, const ygpu_params *p)
+{
     // supported parameter ranges of the wave-parallel DP (dp_wave.h)
     long big = 32000L * std::max(std::max(p->MScore, p->RCost), p->GECost) + p->GOCost + 128L * p->GECost;
     if (p->wordLen < 1 || p->wordLen > 15 || ix->wordLen != p->wordLen) { ctx->err = "wordLen must be 1..15 and match the index"; return YGPU_EINVAL; }
@@ -809,44 +874,93 @@ int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_
     if (p->bandWidth < 0 || p->bandWidth > 255) { ctx->err = "bandWidth must be between 0 and 255"; return YGPU_EINVAL; }
     if (p->maxGap < 0 || p->maxGap > 16383 || p->maxIntron < 0 || p->maxHits < 0 || p->maxHits > 65525) { ctx->err = "maxGap/maxIntron/maxHits out of range"; return YGPU_EINVAL; }
     if (p->MScore < 0 || p->RCost < 0 || p->GECost < 0 || p->GOCost < 0 || big >= (1L << 23)) { ctx->err = "scoring parameters out of the supported range"; return YGPU_EINVAL; }
-    { int rc0 = initCommon(ctx, device); if (rc0) return rc0; }
     DevParams &P = ctx->P;
     P.wordLen = p->wordLen; P.maxHits = p->maxHits; P.bandWidth = p->bandWidth; P.maxGap = p->maxGap; P.maxIntron = p->maxIntron; P.minMatch = p->minMatch; P.maxDesert = p->maxDesert;
     P.minNonOverlap = p->minNonOverlap; P.minRawScore = p->minRawScore; P.minExtLength = p->minExtLength & 0xFF; P.GO = p->GOCost; P.GE = p->GECost; P.RC = p->RCost; P.MS = p->MScore; P.X = p->XCutoff;
     P.minIdentity = p->minIdentity; P.maxROff = ix->maxROff; P.totalMatches = ix->totalMatches;
+    return 0;
+}
+// one device of ygpu_init_multi: image memory, then the copy (its own thread) beside streams / events / code object, then the bit table of seed.h
+static int initDevice(ygpu_ctx *ctx, int device, int srcIndex /* -1: the host */, int srcDevice, const ygpu_index_view *ix, const ImagePlan &plan, ImageState *states, int self, std::atomic<int> *imageReady)
+{
+    const bool phases = getenv("YGPU_INIT_PHASES") != nullptr; double tPh = nowMs(); const double tPh0 = tPh;      // where a context's start-up goes
+    auto phase = [&](const char *what) { if (phases) { const double t = nowMs(); fprintf(stderr, "[ygpu] init device %d: %-40s %8.1f ms\n", device, what, t - tPh); tPh = t; } };
+    ImageState &me = states[self];
+    auto giveUp = [&](int rc) { me.failed = 1; imageReady[self] = -1; return rc; };
+    if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; (void)hipGetLastError(); return giveUp(YGPU_ENODEV); }
     const uint64_t HT = 1ull << (2 * ix->wordLen);
-    ENSURE(ctx->dBases, ix->n_base_bytes + 64); ENSURE(ctx->dSO, 4 * (HT + 1)); ENSURE(ctx->dROA, 4ull * ix->totalMatches + 64);
-    HIPCHK(hipMemsetAsync(ctx->dBases.p, 0xEE, ctx->dBases.cap, ctx->stream)); HIPCHK(streamSync(ctx));
-    // The image -- 16.7 GB at hg18 scale, memory-mapped file pages -- goes up in slices, a few host threads at once, each with a stream of its own: from pageable
-    // memory the runtime stages every copy through its page-locked buffers on the calling thread, and one thread's staging is what bounds a single copy
-    // (YGPU_UPLOAD_THREADS, default 2; 1 = the three plain copies.  Measured on the command line's "contexts up" time, runs right after one another: 1.15 s with one
-    // thread, 0.83-0.95 with two, 0.98-1.49 with four, 0.84-1.16 with eight -- the spread is what the previous process's freed memory costs the next one's allocations.)
-    {
-        struct Piece { char *dst; const char *src; size_t bytes; };
-        const Piece whole[3] = {{(char *)ctx->dBases.p, (const char *)ix->bases, (size_t)ix->n_base_bytes}, {(char *)ctx->dSO.p, (const char *)ix->startingOffs, (size_t)(4 * (HT + 1))}, {(char *)ctx->dROA.p, (const char *)ix->ROA, (size_t)(4ull * ix->totalMatches)}};
-        int nt = 2; if (const char *e = getenv("YGPU_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 32) nt = v; }
-        const size_t slice = 256ull << 20; std::vector<Piece> pieces;
-        for (const Piece &w : whole) for (size_t o = 0; o < w.bytes; o += slice) pieces.push_back({w.dst + o, w.src + o, std::min(slice, w.bytes - o)});
-        if (nt == 1 || pieces.size() < 4) { for (const Piece &w : whole) if (w.bytes) HIPCHK(hipMemcpyAsync(w.dst, w.src, w.bytes, hipMemcpyHostToDevice, ctx->stream)); }
-        else {
-            std::atomic<size_t> next(0); std::atomic<int> bad(0);
-            auto work = [&]() {
-                if (hipSetDevice(device) != hipSuccess) { bad = 1; return; }
-                hipStream_t st; if (hipStreamCreate(&st) != hipSuccess) { bad = 1; return; }
-                for (;;) { const size_t k = next.fetch_add(1); if (k >= pieces.size() || bad) break; if (hipMemcpyAsync(pieces[k].dst, pieces[k].src, pieces[k].bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) bad = 1; }
-                hipStreamDestroy(st);
-            };
-            std::vector<std::thread> th; for (int t = 1; t < nt; t++) th.emplace_back(work);
-            work(); for (auto &x : th) x.join();
-            if (bad) { (void)hipGetLastError(); ctx->err = "copying the index image to the device failed"; return YGPU_ENODEV; }
-        }
-    }
-    ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
-    HIPCHK(streamSync(ctx));
-    ENSURE(ctx->dLow, YD_LOW_BITS / 8); HIPCHK(hipMemsetAsync(ctx->dLow.p, 0, YD_LOW_BITS / 8, ctx->stream));
+    if (ctx->dBases.ensureExact(ix->n_base_bytes + 4096) || ctx->dSO.ensureExact(4 * (HT + 1) + 64) || ctx->dROA.ensureExact(4ull * ix->totalMatches + 64)) {      /* exact: a growth margin on 16.7 GB is 4 GB */ ctx->err = "hipMalloc failed for the index image"; (void)hipGetLastError(); return giveUp(YGPU_ENOMEM); }
+    me.dst[0] = (char *)ctx->dBases.p; me.dst[1] = (char *)ctx->dSO.p; me.dst[2] = (char *)ctx->dROA.p;
+    imageReady[self] = 1;                                                    // the memory is there: the next device in the chain may start asking for pieces
+    // (slack behind the bases reads as 0xEE: the lane kernels load whole dwords around a window)
+    if (hipMemset((char *)ctx->dBases.p + ix->n_base_bytes, 0xEE, ctx->dBases.cap - ix->n_base_bytes) != hipSuccess) { ctx->err = "hipMemset failed"; (void)hipGetLastError(); return giveUp(YGPU_ENODEV); }
+    phase("device memory for the image");
+    bool staged = false; int nt = 2;                                         // YGPU_UPLOAD=direct:T | staged:T  (YGPU_UPLOAD_THREADS=T: the earlier spelling of direct:T)
+    if (const char *e = getenv("YGPU_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 32) nt = v; }
+    if (const char *e = getenv("YGPU_UPLOAD")) { staged = strncmp(e, "staged", 6) == 0; const char *c = strchr(e, ':'); if (c) { const int v = atoi(c + 1); if (v >= 1 && v <= 32) nt = v; } }
+    std::thread copier;
+    if (srcIndex < 0) copier = std::thread([&, nt, staged]() { uploadFromHost(device, plan, me, nt, staged); });
+    else copier = std::thread([&]() { while (imageReady[srcIndex].load() == 0) std::this_thread::yield(); if (imageReady[srcIndex].load() < 0) { me.failed = 1; return; } copyFromPeer(device, srcDevice, plan, me, states[srcIndex]); });
+    int rc0 = initCommon(ctx, device);
+    if (rc0 == 0) { if (ctx->counters.ensure(4 * CNT_N) || ctx->ctr.ensure(sizeof(DevCounters)) || ctx->errFlag.ensure(64) || ctx->dLow.ensure(YD_LOW_BITS / 8)) { ctx->err = "hipMalloc failed"; rc0 = YGPU_ENOMEM; } }
+    if (rc0 == 0) { hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, ctx->stream, (unsigned int *)nullptr); if (hipMemsetAsync(ctx->dLow.p, 0, YD_LOW_BITS / 8, ctx->stream) != hipSuccess || streamSync(ctx) != hipSuccess) { ctx->err = "first kernel launch failed"; (void)hipGetLastError(); rc0 = YGPU_ENODEV; } }
+    phase("streams, events, code object (beside the copy)");
+    copier.join();
+    if (rc0) { me.failed = 1; return rc0; }
+    if (me.failed) { ctx->err = srcIndex < 0 ? "copying the index image to the device failed" : "copying the index image from the neighbouring device failed"; return YGPU_ENODEV; }
+    phase(srcIndex < 0 ? "image copied from the host" : "image copied from the device before");
     if (ix->totalMatches) KL(k_low_offsets, dim3((unsigned)std::min<uint64_t>(gridFor(ix->totalMatches, 256), (uint64_t)ctx->nCU * 64)), dim3(256), 0, ctx->stream, ctx->dSO.as<uint32_t>(), (uint32_t)HT, ctx->dROA.as<uint32_t>(), (uint32_t)ix->totalMatches, ctx->dLow.as<uint32_t>());
     HIPCHK(streamSync(ctx));
+    phase("low-offset bit table");
+    if (phases) fprintf(stderr, "[ygpu] init device %d: total %.1f ms\n", device, nowMs() - tPh0);
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int ygpu_init_multi(const int *devices, int n, const ygpu_index_view *ix, const ygpu_params *p, ygpu_ctx **out, int *rc_each)
+{
+    if (!out || n < 1 || n > 64 || !devices) return YGPU_EINVAL;
+    for (int k = 0; k < n; k++) { out[k] = nullptr; if (rc_each) rc_each[k] = YGPU_EINVAL; }
+    if (!ix || !p) return YGPU_EINVAL;
+    for (int k = 0; k < n; k++) { out[k] = new ygpu_ctx; out[k]->device = devices[k]; }
+    std::vector<int> rcs(n, 0);
+    // a failure before anything was started: the devices it is about say why, the others that they were not started
+    auto notStarted = [&](int rc) { for (int k = 0; k < n; k++) { if (!rcs[k]) { rcs[k] = YGPU_EINVAL; out[k]->err = "not started: another device of the call failed"; } if (rc_each) rc_each[k] = rcs[k]; } return rc; };
+    const double t0 = nowMs();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { for (int k = 0; k < n; k++) { rcs[k] = YGPU_ENODEV; out[k]->err = "no HIP device visible: the hot path needs an MI355X (there is no CPU fallback)"; } return notStarted(YGPU_ENODEV); }
+    if (getenv("YGPU_INIT_PHASES")) fprintf(stderr, "[ygpu] init: runtime up (hipGetDeviceCount) %8.1f ms\n", nowMs() - t0);
+    { bool bad = false; for (int k = 0; k < n; k++) if (devices[k] < 0 || devices[k] >= ndev) { rcs[k] = YGPU_ENODEV; out[k]->err = "device index out of range"; bad = true; } if (bad) return notStarted(YGPU_ENODEV); }
+    { int bad = 0; for (int k = 0; k < n; k++) { rcs[k] = checkParams(out[k], ix, p); if (rcs[k]) bad = rcs[k]; } if (bad) return notStarted(bad); }
+    ImagePlan plan; plan.build(ix, n > 1 ? (64ull << 20) : (256ull << 20));
+    std::vector<ImageState> states(n); for (auto &st : states) { st.done.reset(new std::atomic<int>[plan.pieces.size() + 1]); for (size_t i = 0; i <= plan.pieces.size(); i++) st.done[i] = 0; }
+    std::unique_ptr<std::atomic<int>[]> ready(new std::atomic<int>[n]); for (int k = 0; k < n; k++) ready[k] = 0;
+    // the chain: device k takes the image from device k - 1 when it can reach it (YGPU_PEER_COPY=0: every device from the host)
+    std::vector<int> srcIndex(n, -1); const bool peer = !(getenv("YGPU_PEER_COPY") && atoi(getenv("YGPU_PEER_COPY")) == 0);
+    for (int k = 1; k < n && peer; k++) {
+        int can = devices[k] == devices[k - 1] ? 1 : 0;
+        if (!can && hipDeviceCanAccessPeer(&can, devices[k], devices[k - 1]) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+        if (can && devices[k] != devices[k - 1]) { if (hipSetDevice(devices[k]) == hipSuccess) { const hipError_t e = hipDeviceEnablePeerAccess(devices[k - 1], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0; } else can = 0; (void)hipGetLastError(); }
+        if (can) srcIndex[k] = k - 1;
+    }
+    if (getenv("YGPU_INIT_PHASES")) { fprintf(stderr, "[ygpu] init: image sources:"); for (int k = 0; k < n; k++) { if (srcIndex[k] < 0) fprintf(stderr, " device %d <- host;", devices[k]); else fprintf(stderr, " device %d <- device %d;", devices[k], devices[srcIndex[k]]); } fprintf(stderr, " %zu pieces\n", plan.pieces.size()); }
+    std::vector<std::thread> th;
+    for (int k = 1; k < n; k++) th.emplace_back([&, k]() { rcs[k] = initDevice(out[k], devices[k], srcIndex[k], srcIndex[k] >= 0 ? devices[srcIndex[k]] : -1, ix, plan, states.data(), k, ready.get()); });
+    rcs[0] = initDevice(out[0], devices[0], -1, -1, ix, plan, states.data(), 0, ready.get());
+    for (auto &x : th) x.join();
+    int rc = 0; for (int k = 0; k < n; k++) { if (rc_each) rc_each[k] = rcs[k]; if (rcs[k] && !rc) rc = rcs[k]; }
+    return rc;
+}
+
+int ygpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+
+/* Create a context on HIP device `device`: the index image goes from the host to that device. */
+int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_ctx **out)
+{
+    if (!out) return YGPU_EINVAL;
+    return ygpu_init_multi(&device, 1, ix, p, out, nullptr);
 }
 
 /* A second context on the same device that shares the parent's index image in HBM (nothing is uploaded again).  Two contexts on

@@ -289,12 +289,24 @@ int runQueries(Args &a, FILE *log)
     struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
     std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < nDev; k++) warm.emplace_back(new Warm);
     std::atomic<int> ctxUp(0); double tCtxUp = 0;
+    std::vector<std::atomic<uint64_t>> devReads(nDev); for (auto &x : devReads) x = 0;       // reads each device took (the stats line: do all devices pull their weight?)
+    // The index image reaches the devices through ONE call (ygpu_init_multi): the first device takes it from the host, the others from their neighbour over xGMI,
+    // piece by piece -- the reference maps its index once for all threads (Query.c:565-626); N uploads of 16.7 GB at once would share the host's memory instead.
+    std::vector<int> leadRc(nDev, 0);
+    auto bringUpDevices = [&]() {
+        std::vector<int> devs(nDev); for (int k = 0; k < nDev; k++) devs[k] = A.device + k;
+        std::vector<ygpu_ctx *> leads(nDev, nullptr);
+        const int rc = ygpu_init_multi(devs.data(), nDev, &V, &P, leads.data(), leadRc.data());
+        for (int k = 0; k < nDev; k++) { ctx[k * perDev] = leads[k]; if (rc != 0 && !leads[k]) leadRc[k] = rc; }
+        // (the device that failed is reported before the ones that were merely not started because of it)
+        if (rc != 0) for (int k = 0; k < nDev; k++) if (leadRc[k] != 0 && leads[k] && strncmp(ygpu_last_error(leads[k]), "not started", 11) != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", devs[k], leadRc[k], ygpu_last_error(leads[k])); fail(m); break; }
+    };
     auto device = [&](int d) {
         BatchP b; bool first = true; Warm &W = *warm[d / perDev]; const int dev = A.device + d / perDev, lead = d - d % perDev;
         int rc0;
         if (d == lead) {
-            rc0 = ygpu_init(dev, &V, &P, &ctx[d]);
-            { std::lock_guard<std::mutex> lk(W.mu); W.ready = rc0 == 0 ? 1 : -1; } W.cv.notify_all();
+            if (d == 0) { bringUpDevices(); for (int k = 0; k < nDev; k++) { Warm &Wk = *warm[k]; { std::lock_guard<std::mutex> lk(Wk.mu); Wk.ready = leadRc[k] == 0 ? 1 : -1; } Wk.cv.notify_all(); } }
+            { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : (leadRc[d / perDev] ? leadRc[d / perDev] : YGPU_ENODEV); }
         } else {
             { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : YGPU_EINVAL; }
             if (rc0 == 0) { std::lock_guard<std::mutex> one(W.first); rc0 = ygpu_clone(ctx[lead], &ctx[d]); }
@@ -331,7 +343,7 @@ int runQueries(Args &a, FILE *log)
             }
             if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, rc == YGPU_ENOMEM && !b->ops.p ? "host memory for the results" : ygpu_last_error(ctx[d])); fail(m); b->nReads = 0; fmtQ.push(std::move(b)); continue; }
             b->nClumps = res.n_clumps; b->nOps = res.n_ops;
-            b->tDev = now() - t0;
+            b->tDev = now() - t0; devReads[d / perDev] += b->nReads;
             fmtQ.push(std::move(b));
         }
         fmtQ.producerDone();
@@ -390,8 +402,9 @@ int runQueries(Args &a, FILE *log)
     if (timing) fprintf(stderr, "[yaha] batches done %.1f ms after start, teardown %.1f ms\n", tDone - tEnter, now() - tDone);
     if (stats) {    // one line for scripts (bench.py): steady = reads written after the first batch / time from the first batch's write to the last one's
         const double steady = (nWritten > nFirst && tLastOut > tFirstOut) ? (nWritten - nFirst) / ((tLastOut - tFirstOut) * 1e-3) : 0.0;
-        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, \"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d}\n",
-                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev);
+        std::string per = "["; for (int k = 0; k < nDev; k++) { char t[32]; snprintf(t, sizeof t, "%s%llu", k ? ", " : "", (unsigned long long)devReads[k].load()); per += t; } per += "]";
+        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, \"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d, \"reads_per_device\": %s}\n",
+                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev, per.c_str());
     }
     return rcAll;
 }
