@@ -114,13 +114,14 @@ int  ygpu_device_count(void);
 /* Create a context on HIP device `device`: copies the index view into HBM (replicated per GPU; reads shard
  * across GPUs, no collective).  Replaces the per-thread makeQueryState/initializeQueries (QueryState.c:36-104). */
 int  ygpu_init(int device, const ygpu_index_view *index, const ygpu_params *params, ygpu_ctx **out);
-/* The same for n devices at once -- the reference maps its index ONCE for all its threads (Query.c:565-626, 642-690); here every device needs the image in its own
- * HBM, and it crosses the host's memory and PCIe only once: devices[0] takes it from the host in pieces, every further device takes each piece from the device
- * before it as soon as that one has it (hipMemcpyPeerAsync over xGMI, a chain pipelined by piece).  A device that cannot reach its neighbour
- * (hipDeviceCanAccessPeer) uploads from the host itself.  out[0..n) are filled (also on failure, for ygpu_last_error; destroy them all); rc_each[0..n), when
- * given, receives every device's own result code, the return value is the first that is not 0.  The same device may be listed twice (two images on one device:
- * what the 1-GPU tests use to drive the chain). */
-int  ygpu_init_multi(const int *devices, int n, const ygpu_index_view *index, const ygpu_params *params, ygpu_ctx **out, int *rc_each);
+/* The same for n devices at once, ctx_per_device contexts each -- the reference maps its index ONCE for all its threads (Query.c:565-626, 642-690); here every
+ * device needs the image in its own HBM, and it crosses the host's memory and PCIe only once: devices[0] takes it from the host in pieces, every further device
+ * takes each piece from the device before it as soon as that one has it (hipMemcpyPeerAsync over xGMI, a chain pipelined by piece).  A device that cannot reach
+ * its neighbour (hipDeviceCanAccessPeer) uploads from the host itself.  The contexts of a device share its image (as ygpu_clone's do); their streams and events
+ * are made while the image travels.  out[k * ctx_per_device + j] = context j of devices[k]; all are filled (also on failure, for ygpu_last_error; destroy them
+ * all, a device's first context last); rc_each[0..n), when given, receives every device's own result code, the return value is the first that is not 0.  The
+ * same device may be listed twice (two images on one device: what the 1-GPU tests use to drive the chain). */
+int  ygpu_init_multi(const int *devices, int n, int ctx_per_device, const ygpu_index_view *index, const ygpu_params *params, ygpu_ctx **out, int *rc_each);
 /* A further context on the same device sharing the parent's index image (no second upload; the parent must outlive it).  Two
  * contexts per GPU, one host thread and one stream of batches each, overlap one context's latency-bound stages and host work
  * with the other's compute -- the counterpart of running the reference with more threads than one per core is not needed:

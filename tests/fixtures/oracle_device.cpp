@@ -25,10 +25,12 @@ int ygpu_init(int device, const ygpu_index_view *v, const ygpu_params *p, ygpu_c
     return 0;
 }
 int ygpu_device_count(void) { const char *nd = getenv("YTEST_DEVICES"); return nd ? atoi(nd) : 1; }
-int ygpu_init_multi(const int *devices, int n, const ygpu_index_view *v, const ygpu_params *p, ygpu_ctx **out, int *rc_each)
+int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out);
+int ygpu_init_multi(const int *devices, int n, int cpd, const ygpu_index_view *v, const ygpu_params *p, ygpu_ctx **out, int *rc_each)
 {
     int rc = 0;
-    for (int k = 0; k < n; k++) { const int r = ygpu_init(devices[k], v, p, &out[k]); if (rc_each) rc_each[k] = r; if (r && !rc) rc = r; }
+    for (int k = 0; k < n * cpd; k++) out[k] = nullptr;
+    for (int k = 0; k < n; k++) { int r = ygpu_init(devices[k], v, p, &out[k * cpd]); for (int j = 1; j < cpd && r == 0; j++) r = ygpu_clone(out[k * cpd], &out[k * cpd + j]); if (rc_each) rc_each[k] = r; if (r && !rc) rc = r; }
     return rc;
 }
 int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out) { ygpu_ctx *c = new ygpu_ctx; c->V = parent->V; c->P = parent->P; c->device = parent->device; memset(&c->res, 0, sizeof c->res); *out = c; return 0; }

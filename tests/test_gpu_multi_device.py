@@ -42,9 +42,9 @@ def _golden_batch_equals_oracle(s, b, ctxs):
 def test_two_images_on_one_device_the_second_copied_from_the_first(work, index11):
     with ya.Session(["-x", index11, "-q", os.path.join(work, "rchim.fa")]) as s:
         b = s.next_batch(300)
-        ctxs = ya.Context.on_devices(s.index, s.params, [0, 0])
+        ctxs = ya.Context.on_devices(s.index, s.params, [0, 0], ctx_per_device=2)     # [image A: two contexts, image B (copied from A): two contexts]
         try:
-            clone = ya.Context(s.index, s.params, parent=ctxs[1])          # a context that shares the COPIED image
+            clone = ya.Context(s.index, s.params, parent=ctxs[3])          # and a context made later that shares the COPIED image
             _golden_batch_equals_oracle(s, b, ctxs + [clone])
             clone.close()
         finally:
@@ -69,6 +69,18 @@ def test_init_multi_reports_the_device_that_does_not_exist(work, index11):
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
         with pytest.raises(RuntimeError, match="device 63: -2 device index out of range"):
             ya.Context.on_devices(s.index, s.params, [0, 63])
+
+
+def test_command_line_with_two_logical_devices_on_one_gpu(work, index11):
+    """`yaha -gpus 2 -ctx 2` with YAHA_DEVICES=0,0: the command line's whole multi-device path (ygpu_init_multi with two images, batches dealt to the contexts of both,
+    output restored to input order) on the box's one GPU, against the reference's golden SAM."""
+    p = subprocess.run([ya.CLI_PATH, "-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", "stdout", "-gpus", "2", "-ctx", "2", "-batch", "25"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, YAHA_STATS="1", YAHA_DEVICES="0,0"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert strip_pg(p.stdout.decode()) == golden_lines("rchim_default")
+    st = [l for l in p.stderr.decode().split("\n") if l.startswith("[yaha] stats ")]
+    stats = json.loads(st[0][len("[yaha] stats "):])
+    assert stats["gpus"] == 2 and stats["ctx_per_gpu"] == 2 and len(stats["reads_per_device"]) == 2 and all(n > 0 for n in stats["reads_per_device"])
 
 
 @two_devices

@@ -23,8 +23,73 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 static double now() { using namespace std::chrono; return duration<double>(steady_clock::now().time_since_epoch()).count(); }
 
+#include <sched.h>
+static void pinTo(int cpu) { cpu_set_t m; CPU_ZERO(&m); CPU_SET(cpu, &m); if (sched_setaffinity(0, sizeof m, &m) != 0) perror("sched_setaffinity"); }
+// ./h2d_probe numa GB cpuA cpuB: does it matter on which NUMA node the page cache holds the file?  The file is written by a thread pinned to cpuA, then to cpuB (new
+// pages each time), and copied to the device by a plain hipMemcpy of its mapping and by pread into page-locked buffers from threads pinned next to cpuA / cpuB.
+static int numaMode(double gb, int cpuA, int cpuB)
+{
+    const size_t bytes = ((size_t)(gb * (1ull << 30))) & ~((size_t)(64 << 20) - 1);
+    char *dev; CK(hipMalloc(&dev, bytes));
+    { char *pin; CK(hipHostMalloc((void **)&pin, 1 << 30, hipHostMallocDefault)); memset(pin, 1, 1 << 30); CK(hipMemcpy(dev, pin, 1 << 30, hipMemcpyHostToDevice)); double t = now(); for (int r = 0; r < 4; r++) CK(hipMemcpy(dev, pin, 1 << 30, hipMemcpyHostToDevice)); printf("pinned (hipHostMalloc) -> device: %.1f GB/s\n", 4.0 * (1 << 30) / (now() - t) / 1e9); CK(hipHostFree(pin)); }
+    for (int which = 0; which < 2; which++) {
+        const int wcpu = which ? cpuB : cpuA; char path[64]; snprintf(path, sizeof path, "/tmp/h2d_numa_%d.bin", which);
+        std::thread w([&]() { pinTo(wcpu); int fd = open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644); std::vector<char> blk(64 << 20); for (size_t i = 0; i < blk.size(); i++) blk[i] = (char)(i * 2654435761u >> 13);
+                              for (size_t o = 0; o < bytes; o += blk.size()) if (write(fd, blk.data(), blk.size()) != (ssize_t)blk.size()) { perror("write"); exit(1); } close(fd); });
+        w.join();
+        int fd = open(path, O_RDONLY); char *map = (char *)mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0); if (map == MAP_FAILED) { perror("mmap"); return 1; }
+        for (int rep = 0; rep < 2; rep++) { double t = now(); CK(hipMemcpy(dev, map, bytes, hipMemcpyHostToDevice)); printf("file written on cpu %3d: plain hipMemcpy of the mapping            %7.1f ms  %5.1f GB/s\n", wcpu, (now() - t) * 1e3, bytes / (now() - t) / 1e9); }
+        for (int rcpu : {cpuA, cpuB}) for (int T : {4, 8}) {
+            const size_t piece = 8u << 20; std::atomic<size_t> next(0); std::vector<char *> bufs(2 * T);
+            double t = now();
+            auto work = [&](int id) {
+                pinTo(rcpu + id); CK(hipSetDevice(0)); CK(hipHostMalloc((void **)&bufs[2 * id], piece, hipHostMallocDefault)); CK(hipHostMalloc((void **)&bufs[2 * id + 1], piece, hipHostMallocDefault));
+                hipStream_t st; CK(hipStreamCreate(&st)); hipEvent_t ev[2]; CK(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming)); bool used[2] = {false, false};
+                for (int k = 0;; k ^= 1) { const size_t o = next.fetch_add(piece); if (o >= bytes) break; const size_t n = std::min(piece, bytes - o);
+                    if (used[k]) CK(hipEventSynchronize(ev[k]));
+                    char *b = bufs[2 * id + k]; size_t got = 0; while (got < n) { ssize_t r = pread(fd, b + got, n - got, o + got); if (r <= 0) { perror("pread"); exit(1); } got += r; }
+                    CK(hipMemcpyAsync(dev + o, b, n, hipMemcpyHostToDevice, st)); CK(hipEventRecord(ev[k], st)); used[k] = true; }
+                CK(hipStreamSynchronize(st)); (void)hipStreamDestroy(st); CK(hipHostFree(bufs[2 * id])); CK(hipHostFree(bufs[2 * id + 1])); };
+            std::vector<std::thread> th; for (int k = 1; k < T; k++) th.emplace_back(work, k); work(0); for (auto &x : th) x.join();
+            printf("file written on cpu %3d: pread by %d threads on cpus %3d.., pinned 8 MB  %7.1f ms  %5.1f GB/s (incl. the buffers' hipHostMalloc)\n", wcpu, T, rcpu, (now() - t) * 1e3, bytes / (now() - t) / 1e9);
+        }
+        munmap(map, bytes); close(fd); unlink(path);
+    }
+    return 0;
+}
+
+// ./h2d_probe file PATH: an existing file (the bench's 16.7 GB index), mapped privately, copied whole by plain hipMemcpy calls -- what ygpu_init does, nothing else running
+static int fileMode(const char *path)
+{
+    int fd = open(path, O_RDONLY); if (fd < 0) { perror("open"); return 1; }
+    const size_t bytes = (size_t)lseek(fd, 0, SEEK_END); char *dev; CK(hipMalloc(&dev, bytes));
+    for (int rep = 0; rep < 3; rep++) {
+        char *map = (char *)mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0); if (map == MAP_FAILED) { perror("mmap"); return 1; }
+        double t = now();
+        if (rep < 2) CK(hipMemcpy(dev, map, bytes, hipMemcpyHostToDevice));
+        else for (size_t o = 0; o < bytes; o += (1ull << 30)) CK(hipMemcpy(dev + o, map + o, std::min<size_t>(1ull << 30, bytes - o), hipMemcpyHostToDevice));
+        printf("%s (%.1f GB), %s: %7.1f ms  %5.1f GB/s\n", path, bytes / 1e9, rep < 2 ? "one hipMemcpy" : "1 GB pieces", (now() - t) * 1e3, bytes / (now() - t) / 1e9);
+        munmap(map, bytes);
+    }
+    return 0;
+}
+
+// ./h2d_probe write GB PATH [chunkMB]: writes a file of that size with write() calls of chunkMB (0: one call for everything, as the index writer does) and leaves it there
+static int writeMode(double gb, const char *path, size_t chunkMB)
+{
+    const size_t bytes = ((size_t)(gb * (1ull << 30))) & ~((size_t)(64 << 20) - 1);
+    std::vector<char> blk(chunkMB ? (chunkMB << 20) : bytes); for (size_t i = 0; i < blk.size(); i += 61) blk[i] = (char)(i * 2654435761u >> 13);
+    int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0744); if (fd < 0) { perror("open"); return 1; }
+    double t = now();
+    for (size_t o = 0; o < bytes;) { const size_t n = std::min(blk.size(), bytes - o); size_t done = 0; while (done < n) { ssize_t w = write(fd, blk.data() + done, n - done); if (w < 0) { perror("write"); return 1; } done += (size_t)w; } o += n; }
+    close(fd); printf("wrote %s (%.1f GB) in %.2f s\n", path, bytes / 1e9, now() - t); return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 3 && strcmp(argv[1], "write") == 0) return writeMode(atof(argv[2]), argv[3], argc > 4 ? (size_t)atoi(argv[4]) : 0);
+    if (argc > 2 && strcmp(argv[1], "file") == 0) return fileMode(argv[2]);
+    if (argc > 1 && strcmp(argv[1], "numa") == 0) return numaMode(argc > 2 ? atof(argv[2]) : 8.0, argc > 3 ? atoi(argv[3]) : 0, argc > 4 ? atoi(argv[4]) : 64);
     const double gb = argc > 1 ? atof(argv[1]) : 4.0; const char *path = argc > 2 ? argv[2] : "/tmp/h2d_probe.bin";
     const size_t bytes = ((size_t)(gb * (1ull << 30))) & ~((size_t)(64 << 20) - 1);
     int ndev = 0; CK(hipGetDeviceCount(&ndev)); printf("devices: %d\n", ndev);

@@ -193,18 +193,18 @@ class Context:
             raise RuntimeError("ygpu_init failed: %d %s (the HIP path is mandatory; there is no CPU fallback)" % (rc, msg))
 
     @classmethod
-    def on_devices(cls, index_view, params, devices):
-        """One context per listed device through ygpu_init_multi: the first device takes the index image from the host, every further one from the device before
-        it (the same device may be listed twice: two images on one device)."""
-        n = len(devices)
-        devs = (C.c_int * n)(*devices); hs = (C.c_void_p * n)(); rcs = (C.c_int * n)()
-        rc = lib().ygpu_init_multi(devs, n, C.byref(index_view), C.byref(params), hs, rcs)
+    def on_devices(cls, index_view, params, devices, ctx_per_device=1):
+        """Contexts on the listed devices through ygpu_init_multi: the first device takes the index image from the host, every further one from the device before
+        it (the same device may be listed twice: two images on one device); ctx_per_device contexts a device share its image.  Returns them device-major."""
+        n = len(devices); m = n * ctx_per_device
+        devs = (C.c_int * n)(*devices); hs = (C.c_void_p * m)(); rcs = (C.c_int * n)()
+        rc = lib().ygpu_init_multi(devs, n, ctx_per_device, C.byref(index_view), C.byref(params), hs, rcs)
         ctxs = []
-        for k in range(n):
+        for k in range(m):
             c = cls.__new__(cls); c._h = C.c_void_p(hs[k]); ctxs.append(c)
         if rc != 0:
-            msgs = ["device %d: %d %s" % (devices[k], rcs[k], lib().ygpu_last_error(ctxs[k]._h).decode() if hs[k] else "") for k in range(n) if rcs[k]]
-            for c in ctxs:
+            msgs = ["device %d: %d %s" % (devices[k], rcs[k], lib().ygpu_last_error(ctxs[k * ctx_per_device]._h).decode() if hs[k * ctx_per_device] else "") for k in range(n) if rcs[k]]
+            for c in reversed(ctxs):
                 c.close()
             raise RuntimeError("ygpu_init_multi failed: %d (%s)" % (rc, "; ".join(msgs)))
         return ctxs

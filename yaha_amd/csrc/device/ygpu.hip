@@ -772,8 +772,11 @@ static int runTo(ygpu_ctx *ctx, int stage)
 
 static int initCommon(ygpu_ctx *ctx, int device)
 {
+    const bool phases = getenv("YGPU_INIT_PHASES") != nullptr; double tPh = nowMs();
+    auto phase = [&](const char *what) { if (phases) { const double t = nowMs(); fprintf(stderr, "[ygpu] ctx %p: %-20s %8.1f ms\n", (void *)ctx, what, t - tPh); tPh = t; } };
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreate(&ctx->stream)); HIPCHK(hipStreamCreate(&ctx->stream2));
+    phase("two streams");
     for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evTail, hipEventDisableTiming));
     if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
@@ -784,10 +787,13 @@ static int initCommon(ygpu_ctx *ctx, int device)
     if (const char *e = getenv("YGPU_ROWS2_PER_CU")) ctx->rows2PerCU = atoi(e);
     if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
     gCtxPerDevice[device & 63]++; ctx->counted = true;
-    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); ctx->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { cu = 0; (void)hipGetLastError(); } ctx->nCU = cu > 0 ? cu : 256; }
+    phase("device attribute");
     for (int t = 0; t < T_N; t++) { HIPCHK(hipEventCreate(&ctx->ev[t][0])); HIPCHK(hipEventCreate(&ctx->ev[t][1])); ctx->names[t] = kStageNames[t]; }
     if (hipEventCreateWithFlags(&ctx->evSync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { ctx->evSync = nullptr; (void)hipGetLastError(); }
+    phase("events");
     if (hipHostMalloc((void **)&ctx->pinned, 256, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; (void)hipGetLastError(); }
+    phase("pinned words");
     return 0;
 }
 
@@ -881,8 +887,18 @@ static int checkParams(ygpu_ctx *ctx, const ygpu_index_view *ix, const ygpu_para
     return 0;
 }
 // one device of ygpu_init_multi: image memory, then the copy (its own thread) beside streams / events / code object, then the bit table of seed.h
-static int initDevice(ygpu_ctx *ctx, int device, int srcIndex /* -1: the host */, int srcDevice, const ygpu_index_view *ix, const ImagePlan &plan, ImageState *states, int self, std::atomic<int> *imageReady)
+static void shareImage(ygpu_ctx *ctx, const ygpu_ctx *parent)
 {
+    ctx->P = parent->P;
+    ctx->dBases.p = parent->dBases.p; ctx->dBases.cap = parent->dBases.cap; ctx->dSO.p = parent->dSO.p; ctx->dSO.cap = parent->dSO.cap; ctx->dROA.p = parent->dROA.p; ctx->dROA.cap = parent->dROA.cap; ctx->dLow.p = parent->dLow.p; ctx->dLow.cap = parent->dLow.cap;
+    ctx->sharedIndex = true;
+}
+static int initDevice(ygpu_ctx *ctx, int device, int srcIndex /* -1: the host */, int srcDevice, const ygpu_index_view *ix, const ImagePlan &plan, ImageState *states, int self, std::atomic<int> *imageReady, ygpu_ctx **more, int nMore)
+{
+    // the device's further contexts (they share this one's image): streams, events and counters are made beside the copy as well
+    std::vector<int> moreRc(nMore, 0); std::vector<std::thread> moreTh;
+    for (int j = 0; j < nMore; j++) moreTh.emplace_back([&, j]() { ygpu_ctx *c = more[j]; int rc = initCommon(c, device); if (rc == 0 && (c->counters.ensure(4 * CNT_N) || c->ctr.ensure(sizeof(DevCounters)) || c->errFlag.ensure(64))) { c->err = "hipMalloc failed"; rc = YGPU_ENOMEM; } moreRc[j] = rc; });
+    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{moreTh};
     const bool phases = getenv("YGPU_INIT_PHASES") != nullptr; double tPh = nowMs(); const double tPh0 = tPh;      // where a context's start-up goes
     auto phase = [&](const char *what) { if (phases) { const double t = nowMs(); fprintf(stderr, "[ygpu] init device %d: %-40s %8.1f ms\n", device, what, t - tPh); tPh = t; } };
     ImageState &me = states[self];
@@ -895,7 +911,10 @@ static int initDevice(ygpu_ctx *ctx, int device, int srcIndex /* -1: the host */
     // (slack behind the bases reads as 0xEE: the lane kernels load whole dwords around a window)
     if (hipMemset((char *)ctx->dBases.p + ix->n_base_bytes, 0xEE, ctx->dBases.cap - ix->n_base_bytes) != hipSuccess) { ctx->err = "hipMemset failed"; (void)hipGetLastError(); return giveUp(YGPU_ENODEV); }
     phase("device memory for the image");
-    bool staged = false; int nt = 2;                                         // YGPU_UPLOAD=direct:T | staged:T  (YGPU_UPLOAD_THREADS=T: the earlier spelling of direct:T)
+    // One thread, one plain copy per piece: the runtime pins the piece and the DMA engines read it in place -- 41-48 GB/s for the 16.7 GB index out of the page cache
+    // (55 GB/s, the link's rate, for a file whose pages the kernel could keep in large folios; tools/micro/h2d_probe.hip).  Measured on the command line, 16.7 GB, runs
+    // 6 s apart: one thread 404 ms, two 450-500, four 640; six threads staging through page-locked buffers of their own 590-630 (profiles/r04_index_upload.txt).
+    bool staged = false; int nt = 1;                                         // YGPU_UPLOAD=direct:T | staged:T  (YGPU_UPLOAD_THREADS=T: the earlier spelling of direct:T)
     if (const char *e = getenv("YGPU_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 32) nt = v; }
     if (const char *e = getenv("YGPU_UPLOAD")) { staged = strncmp(e, "staged", 6) == 0; const char *c = strchr(e, ':'); if (c) { const int v = atoi(c + 1); if (v >= 1 && v <= 32) nt = v; } }
     std::thread copier;
@@ -912,29 +931,34 @@ static int initDevice(ygpu_ctx *ctx, int device, int srcIndex /* -1: the host */
     if (ix->totalMatches) KL(k_low_offsets, dim3((unsigned)std::min<uint64_t>(gridFor(ix->totalMatches, 256), (uint64_t)ctx->nCU * 64)), dim3(256), 0, ctx->stream, ctx->dSO.as<uint32_t>(), (uint32_t)HT, ctx->dROA.as<uint32_t>(), (uint32_t)ix->totalMatches, ctx->dLow.as<uint32_t>());
     HIPCHK(streamSync(ctx));
     phase("low-offset bit table");
-    if (phases) fprintf(stderr, "[ygpu] init device %d: total %.1f ms\n", device, nowMs() - tPh0);
+    for (auto &x : moreTh) x.join();
+    for (int j = 0; j < nMore; j++) { if (moreRc[j]) { ctx->err = "a further context of the device failed: " + more[j]->err; return moreRc[j]; } shareImage(more[j], ctx); }
+    if (phases) fprintf(stderr, "[ygpu] init device %d: total %.1f ms (%d contexts)\n", device, nowMs() - tPh0, 1 + nMore);
     return 0;
 }
 }  // namespace
 
 extern "C" {
 
-int ygpu_init_multi(const int *devices, int n, const ygpu_index_view *ix, const ygpu_params *p, ygpu_ctx **out, int *rc_each)
+int ygpu_init_multi(const int *devices, int n, int ctx_per_device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_ctx **all, int *rc_each)
 {
-    if (!out || n < 1 || n > 64 || !devices) return YGPU_EINVAL;
-    for (int k = 0; k < n; k++) { out[k] = nullptr; if (rc_each) rc_each[k] = YGPU_EINVAL; }
+    if (!all || n < 1 || n > 64 || !devices || ctx_per_device < 1 || ctx_per_device > 16) return YGPU_EINVAL;
+    const int cpd = ctx_per_device;
+    for (int k = 0; k < n * cpd; k++) all[k] = nullptr;
+    for (int k = 0; k < n; k++) if (rc_each) rc_each[k] = YGPU_EINVAL;
     if (!ix || !p) return YGPU_EINVAL;
-    for (int k = 0; k < n; k++) { out[k] = new ygpu_ctx; out[k]->device = devices[k]; }
+    for (int k = 0; k < n * cpd; k++) { all[k] = new ygpu_ctx; all[k]->device = devices[k / cpd]; }
+    std::vector<ygpu_ctx *> out(n); for (int k = 0; k < n; k++) out[k] = all[k * cpd];      // every device's first context: the one that owns its image
     std::vector<int> rcs(n, 0);
     // a failure before anything was started: the devices it is about say why, the others that they were not started
-    auto notStarted = [&](int rc) { for (int k = 0; k < n; k++) { if (!rcs[k]) { rcs[k] = YGPU_EINVAL; out[k]->err = "not started: another device of the call failed"; } if (rc_each) rc_each[k] = rcs[k]; } return rc; };
+    auto notStarted = [&](int rc) { for (int k = 0; k < n; k++) { if (!rcs[k]) { rcs[k] = YGPU_EINVAL; out[k]->err = "not started: another device of the call failed"; } if (rc_each) rc_each[k] = rcs[k]; for (int j = 1; j < cpd; j++) all[k * cpd + j]->err = out[k]->err; } return rc; };
     const double t0 = nowMs();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { for (int k = 0; k < n; k++) { rcs[k] = YGPU_ENODEV; out[k]->err = "no HIP device visible: the hot path needs an MI355X (there is no CPU fallback)"; } return notStarted(YGPU_ENODEV); }
     if (getenv("YGPU_INIT_PHASES")) fprintf(stderr, "[ygpu] init: runtime up (hipGetDeviceCount) %8.1f ms\n", nowMs() - t0);
     { bool bad = false; for (int k = 0; k < n; k++) if (devices[k] < 0 || devices[k] >= ndev) { rcs[k] = YGPU_ENODEV; out[k]->err = "device index out of range"; bad = true; } if (bad) return notStarted(YGPU_ENODEV); }
     { int bad = 0; for (int k = 0; k < n; k++) { rcs[k] = checkParams(out[k], ix, p); if (rcs[k]) bad = rcs[k]; } if (bad) return notStarted(bad); }
-    ImagePlan plan; plan.build(ix, n > 1 ? (64ull << 20) : (256ull << 20));
+    ImagePlan plan; plan.build(ix, n > 1 ? (64ull << 20) : (1024ull << 20));
     std::vector<ImageState> states(n); for (auto &st : states) { st.done.reset(new std::atomic<int>[plan.pieces.size() + 1]); for (size_t i = 0; i <= plan.pieces.size(); i++) st.done[i] = 0; }
     std::unique_ptr<std::atomic<int>[]> ready(new std::atomic<int>[n]); for (int k = 0; k < n; k++) ready[k] = 0;
     // the chain: device k takes the image from device k - 1 when it can reach it (YGPU_PEER_COPY=0: every device from the host)
@@ -947,10 +971,10 @@ int ygpu_init_multi(const int *devices, int n, const ygpu_index_view *ix, const 
     }
     if (getenv("YGPU_INIT_PHASES")) { fprintf(stderr, "[ygpu] init: image sources:"); for (int k = 0; k < n; k++) { if (srcIndex[k] < 0) fprintf(stderr, " device %d <- host;", devices[k]); else fprintf(stderr, " device %d <- device %d;", devices[k], devices[srcIndex[k]]); } fprintf(stderr, " %zu pieces\n", plan.pieces.size()); }
     std::vector<std::thread> th;
-    for (int k = 1; k < n; k++) th.emplace_back([&, k]() { rcs[k] = initDevice(out[k], devices[k], srcIndex[k], srcIndex[k] >= 0 ? devices[srcIndex[k]] : -1, ix, plan, states.data(), k, ready.get()); });
-    rcs[0] = initDevice(out[0], devices[0], -1, -1, ix, plan, states.data(), 0, ready.get());
+    for (int k = 1; k < n; k++) th.emplace_back([&, k]() { rcs[k] = initDevice(out[k], devices[k], srcIndex[k], srcIndex[k] >= 0 ? devices[srcIndex[k]] : -1, ix, plan, states.data(), k, ready.get(), all + k * cpd + 1, cpd - 1); });
+    rcs[0] = initDevice(out[0], devices[0], -1, -1, ix, plan, states.data(), 0, ready.get(), all + 1, cpd - 1);
     for (auto &x : th) x.join();
-    int rc = 0; for (int k = 0; k < n; k++) { if (rc_each) rc_each[k] = rcs[k]; if (rcs[k] && !rc) rc = rcs[k]; }
+    int rc = 0; for (int k = 0; k < n; k++) { if (rc_each) rc_each[k] = rcs[k]; if (rcs[k] && !rc) rc = rcs[k]; if (rcs[k]) for (int j = 1; j < cpd; j++) if (all[k * cpd + j]->err.empty()) all[k * cpd + j]->err = "the device's first context failed: " + out[k]->err; }
     return rc;
 }
 
@@ -960,7 +984,7 @@ int ygpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess
 int ygpu_init(int device, const ygpu_index_view *ix, const ygpu_params *p, ygpu_ctx **out)
 {
     if (!out) return YGPU_EINVAL;
-    return ygpu_init_multi(&device, 1, ix, p, out, nullptr);
+    return ygpu_init_multi(&device, 1, 1, ix, p, out, nullptr);
 }
 
 /* A second context on the same device that shares the parent's index image in HBM (nothing is uploaded again).  Two contexts on
@@ -972,9 +996,7 @@ int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
     if (!parent || !parent->stream) return YGPU_EINVAL;
     ygpu_ctx *ctx = new ygpu_ctx; *out = ctx; ctx->device = parent->device;
     int rc = initCommon(ctx, parent->device); if (rc) return rc;
-    ctx->P = parent->P;
-    ctx->dBases.p = parent->dBases.p; ctx->dBases.cap = parent->dBases.cap; ctx->dSO.p = parent->dSO.p; ctx->dSO.cap = parent->dSO.cap; ctx->dROA.p = parent->dROA.p; ctx->dROA.cap = parent->dROA.cap; ctx->dLow.p = parent->dLow.p; ctx->dLow.cap = parent->dLow.cap;
-    ctx->sharedIndex = true;
+    shareImage(ctx, parent);
     ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
     HIPCHK(streamSync(ctx));
     return 0;

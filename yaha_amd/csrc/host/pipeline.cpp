@@ -293,24 +293,22 @@ int runQueries(Args &a, FILE *log)
     // The index image reaches the devices through ONE call (ygpu_init_multi): the first device takes it from the host, the others from their neighbour over xGMI,
     // piece by piece -- the reference maps its index once for all threads (Query.c:565-626); N uploads of 16.7 GB at once would share the host's memory instead.
     std::vector<int> leadRc(nDev, 0);
+    // logical GPU k of -gpus N is HIP device -device + k, or the k-th entry of YAHA_DEVICES (a comma-separated list; the same device may appear twice: two
+    // images on one device, which is how the multi-device path is exercised on a box with one GPU)
+    std::vector<int> devs(nDev); for (int k = 0; k < nDev; k++) devs[k] = A.device + k;
+    if (const char *e = getenv("YAHA_DEVICES")) { int k = 0; for (const char *q = e; *q && k < nDev; k++) { devs[k] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; } }
     auto bringUpDevices = [&]() {
-        std::vector<int> devs(nDev); for (int k = 0; k < nDev; k++) devs[k] = A.device + k;
-        std::vector<ygpu_ctx *> leads(nDev, nullptr);
-        const int rc = ygpu_init_multi(devs.data(), nDev, &V, &P, leads.data(), leadRc.data());
-        for (int k = 0; k < nDev; k++) { ctx[k * perDev] = leads[k]; if (rc != 0 && !leads[k]) leadRc[k] = rc; }
+        const int rc = ygpu_init_multi(devs.data(), nDev, perDev, &V, &P, ctx.data(), leadRc.data());      // ctx[k * perDev + j] = context j of device k
+        for (int k = 0; k < nDev; k++) if (rc != 0 && !ctx[k * perDev]) leadRc[k] = rc;
         // (the device that failed is reported before the ones that were merely not started because of it)
-        if (rc != 0) for (int k = 0; k < nDev; k++) if (leadRc[k] != 0 && leads[k] && strncmp(ygpu_last_error(leads[k]), "not started", 11) != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", devs[k], leadRc[k], ygpu_last_error(leads[k])); fail(m); break; }
+        if (rc != 0) for (int k = 0; k < nDev; k++) { ygpu_ctx *c = ctx[k * perDev]; if (leadRc[k] != 0 && c && strncmp(ygpu_last_error(c), "not started", 11) != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", devs[k], leadRc[k], ygpu_last_error(c)); fail(m); break; } }
     };
     auto device = [&](int d) {
-        BatchP b; bool first = true; Warm &W = *warm[d / perDev]; const int dev = A.device + d / perDev, lead = d - d % perDev;
+        BatchP b; bool first = true; Warm &W = *warm[d / perDev]; const int dev = devs[d / perDev], lead = d - d % perDev;
         int rc0;
-        if (d == lead) {
-            if (d == 0) { bringUpDevices(); for (int k = 0; k < nDev; k++) { Warm &Wk = *warm[k]; { std::lock_guard<std::mutex> lk(Wk.mu); Wk.ready = leadRc[k] == 0 ? 1 : -1; } Wk.cv.notify_all(); } }
-            { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : (leadRc[d / perDev] ? leadRc[d / perDev] : YGPU_ENODEV); }
-        } else {
-            { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : YGPU_EINVAL; }
-            if (rc0 == 0) { std::lock_guard<std::mutex> one(W.first); rc0 = ygpu_clone(ctx[lead], &ctx[d]); }
-        }
+        if (d == 0) { bringUpDevices(); for (int k = 0; k < nDev; k++) { Warm &Wk = *warm[k]; { std::lock_guard<std::mutex> lk(Wk.mu); Wk.ready = leadRc[k] == 0 ? 1 : -1; } Wk.cv.notify_all(); } }
+        { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : (leadRc[d / perDev] ? leadRc[d / perDev] : YGPU_ENODEV); }
+        (void)lead;
         if (rc0 == 0 && deviceFilter) rc0 = ygpu_set_postfilter(ctx[d], &PF);
         if (rc0 != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", dev, rc0, ctx[d] ? ygpu_last_error(ctx[d]) : (d == lead ? "" : "(the device's first context failed)")); fail(m); }
         if (++ctxUp == ngpu) { tCtxUp = now(); if (timing) fprintf(stderr, "[yaha] %d device contexts up (index image on %d device%s) %.1f ms after start\n", ngpu, nDev, nDev > 1 ? "s" : "", tCtxUp - tEnter); }
@@ -319,12 +317,17 @@ int runQueries(Args &a, FILE *log)
             const double t0 = now();
             ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res; memset(&res, 0, sizeof res);
             auto hotPath = [&]() -> int {                                      // upload, run (+ post-filter), results straight into the batch's own buffers
-                int rc = ygpu_upload(ctx[d], &rb); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;
+                const double h0 = now();
+                int rc = ygpu_upload(ctx[d], &rb); const double h1 = now(); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;
+                const double h2 = now();
                 uint64_t nc = 0, no = 0; b->filtered = deviceFilter;
                 if (deviceFilter) {
                     rc = ygpu_postfilter(ctx[d]); if (rc == 0) rc = ygpu_filtered_size(ctx[d], &nc, &no); if (rc != 0) return rc;
+                    const double h3 = now();
                     if (!b->clumpStart.ensure(4 * (b->nReads + 1)) || !b->clumps.ensure(sizeof(ygpu_out_clump) * nc) || !b->ops.ensure(4 * no)) return YGPU_ENOMEM;
+                    const double h4 = now();
                     ygpu_filtered_batch fr; rc = ygpu_collect_filtered(ctx[d], (uint32_t *)b->clumpStart.p, (ygpu_out_clump *)b->clumps.p, (uint32_t *)b->ops.p, &fr);
+                    if (timing && first) fprintf(stderr, "[yaha] context %d, first batch: upload %.1f  run %.1f  post-filter %.1f  result buffers %.1f  collect %.1f ms\n", d, h1 - h0, h2 - h1, h3 - h2, h4 - h3, now() - h4);
                     res.n_clumps = fr.n_clumps; res.n_ops = fr.n_ops; return rc;
                 }
                 rc = ygpu_result_size(ctx[d], &nc, &no); if (rc != 0) return rc;
