@@ -46,7 +46,7 @@ kstats)
   TAG=${1:-kstats}; CT=${2:-1}; shift; shift; warm
   O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
   rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o stats -- python3 $R/bench.py --steps 8 --warmup 2 --contexts $CT --no-cpu-baseline --no-extras "$@" > $O/bench.json 2> $O/bench.err
-  kernel_table $O/stats $((8 + 3 * CT)); cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; rm -rf $O/stats; tail -1 $O/bench.json | line "under the profiler" ;;      # 8 timed steps + (first pass + 2 warm-up) per context
+  kernel_table $O/stats $((8 + 3 * CT)); cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; cp $(find $O/stats -name "*kernel_trace.csv" | head -1) $O/kernel_trace.csv; rm -rf $O/stats; tail -1 $O/bench.json | line "under the profiler" ;;      # 8 timed steps + (first pass + 2 warm-up) per context
 cli|cli10k)
   TAG=${1:-cli}; shift; warm
   if [ $MODE = cli ]; then reads1k; Q=$R1; else reads10k; Q=$R10; fi

@@ -53,8 +53,11 @@ __device__ __forceinline__ uint32_t pkSignMaskAsm(uint32_t a, uint32_t c15) { ui
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }                      // v_bfi_b32
 __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) * 0x10001u; }
 
+#ifndef YD_ROWS_WAVES
+#define YD_ROWS_WAVES 3                        // waves per SIMD of k_ext_rows_pk (a build switch for experiments: make variant VARIANT_FLAGS=-DYD_ROWS_WAVES=2)
+#endif
 template <bool SECOND>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ext_rows_pk(ExtArgs A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROWS_WAVES, YD_ROWS_WAVES))) k_ext_rows_pk(ExtArgs A)
 {
     __shared__ uint32_t sBlk[256 * YD_LDS_STRIDE];   // per lane: the current block of eight 16-byte records, lane stride 33
     if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());

@@ -775,6 +775,9 @@ static int initCommon(ygpu_ctx *ctx, int device)
     const bool phases = getenv("YGPU_INIT_PHASES") != nullptr; double tPh = nowMs();
     auto phase = [&](const char *what) { if (phases) { const double t = nowMs(); fprintf(stderr, "[ygpu] ctx %p: %-20s %8.1f ms\n", (void *)ctx, what, t - tPh); tPh = t; } };
     HIPCHK(hipSetDevice(device));
+    // (Measured in round 4 and dropped: the context's streams at the highest priority and the long X-drop kernels on a stream of the lowest --
+    // hipStreamCreateWithPriority, range -1..1 here -- 46.2-46.4 ms a step against 45.0-45.9 with four contexts, profiles/r04_ab_prio_and_waves.txt: the rows kernel's
+    // waves are persistent, a slot they hold is not handed to anybody before the launch ends.)
     HIPCHK(hipStreamCreate(&ctx->stream)); HIPCHK(hipStreamCreate(&ctx->stream2));
     phase("two streams");
     for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
