@@ -498,7 +498,7 @@ def main():
                    % (args.genome_mbp, n_reads, args.read_len, 100 * args.div),
                    "reads_per_gpu": n_reads, "read_len": args.read_len, "parallelism": "reads sharded x%d, index replicated, no collective; %d contexts (batches in flight) per GPU" % (world, max(1, args.contexts))},
         "roofline": {"bound": "hbm", "kernel": kname, "unshared": ({"kernel_ms_per_launch": unshared_rows_ms, "achieved": kbytes / (unshared_rows_ms * 1e-3) / 1e9, "frac": kbytes / (unshared_rows_ms * 1e-3) / 8.0e12,
-                                                                   "note": "the same launch with one context on the GPU (two steps after the timed region): what rocprofv3 reports for the kernel in profiles/*_one_context.csv"} if (rows_ms > 0 and unshared_rows_ms) else None), "kernel_variant": ("k_ext_rows_pk (packed 16-bit, two cells per instruction)" if (rows_ms > 0 and packed) else ("k_ext_rows (32-bit)" if rows_ms > 0 else kname)), "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                                                                   "note": "the same launch with one context on the GPU (two steps after the timed region): what rocprofv3 reports for the kernel in profiles/*_one_context.csv"} if (rows_ms > 0 and unshared_rows_ms) else None), "kernel_variant": ("k_ext_rows_pk (packed 16-bit, two cells per instruction)" if (rows_ms > 0 and packed) else ("k_ext_rows (32-bit)" if rows_ms > 0 else kname)), "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "whole_path_traffic": ((pmc or {}).get("whole_path") or {}).get("hbm_bytes_per_step"),
                      "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_read": B, "reads_per_launch": n_reads, "kernel_ms_per_launch": kernel_ms,
                      "kernel_ms_hip_events": rows_ms, "kernel_ms_device_clock": rows_dev_ms,
                      "kernel_stream_bytes_per_launch": stream_bytes, "kernel_stream_frac": (stream_bytes / (kernel_ms * 1e-3) / 8.0e12) if (stream_bytes and kernel_ms > 0) else None,

@@ -129,6 +129,9 @@ int  ygpu_init_multi(const int *devices, int n, int ctx_per_device, const ygpu_i
 int  ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out);
 void ygpu_destroy(ygpu_ctx *ctx);
 const char *ygpu_last_error(const ygpu_ctx *ctx);
+/* Device memory as the context sees it: free and total bytes of its device, and the bytes its own buffers hold (arenas grow with the first batches; the
+ * reference's per-thread QueryState grows the same way, Query.c:81-100, 313).  A batching host uses it to decide how many contexts a device can carry. */
+int  ygpu_memory(ygpu_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes, uint64_t *ctx_bytes);
 
 /* Stage reads into HBM (H2D).  Separate from ygpu_run so that a benchmark can time the hot path with inputs
  * already resident. */

@@ -35,6 +35,7 @@ int ygpu_init_multi(const int *devices, int n, int cpd, const ygpu_index_view *v
 }
 int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out) { ygpu_ctx *c = new ygpu_ctx; c->V = parent->V; c->P = parent->P; c->device = parent->device; memset(&c->res, 0, sizeof c->res); *out = c; return 0; }
 void ygpu_destroy(ygpu_ctx *c) { if (!c) return; if (c->have) yoracle_free_result(&c->res); delete c; }
+int ygpu_memory(ygpu_ctx *, uint64_t *f, uint64_t *t, uint64_t *m) { if (f) *f = 1ull << 40; if (t) *t = 1ull << 40; if (m) *m = 0; return 0; }
 const char *ygpu_last_error(const ygpu_ctx *c) { return c ? c->err.c_str() : "no context"; }
 int ygpu_upload(ygpu_ctx *c, const ygpu_read_batch *b)
 {

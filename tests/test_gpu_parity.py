@@ -160,6 +160,10 @@ def test_lane_pipeline_parameter_corners(work, index11, reads, extra, tmp_path):
     ("rchim.fa", ["-MGDP", "1", "-MNO", "3"]), ("rchim.fa", ["-MNO", "200", "-FBS", "Y", "-PSS", "0.2", "-PRL", "0.1"]), ("r10k.fa", ["-FBS", "Y"]), ("rq.fq", ["-M", "15", "-P", "0.8", "-FBS", "Y", "-PSS", "0.3"]),
     ("rchim.fa", ["-GOC", "9", "-GEC", "3", "-RC", "1", "-FBS", "Y"]), ("r100.fa", ["-M", "15", "-FBS", "Y", "-PRL", "0.3", "-PSS", "0.3"])])
 def test_postfilter_on_the_device_equals_the_host_filter(work, index11, reads, extra, monkeypatch):
+    """Two compilations of ONE routine (csrc/oqc_core.h) against each other: the device stage vs the host's copy, over the same hot-path results.  The pin to the
+    REFERENCE is indirect and lives elsewhere: the host's copy == the reference's SAM in every golden of the CPU tier (test_oracle_golden.py, Session.emit) and in the
+    live-reference comparisons; the device stage == the reference's SAM in the command-line tests of this tier (the device filter is the CLI's default:
+    test_cli_drop_in*, test_real_human_sequence*, test_gpu_long_reads.py, test_gpu_at_scale.py)."""
     if reads == "rchim.fa" and not extra:
         monkeypatch.setenv("YGPU_OQC_MAX", "4")             # reads of more than four clumps take the hand-over path (unfiltered, marked, filtered by the host)
     with ya.Session(["-x", index11, "-q", os.path.join(work, reads), "-osh", "stdout"] + list(extra)) as s:
@@ -512,6 +516,8 @@ def _synthetic_results(s, b, rng, max_clumps):
                                                    (7, 448, []), (8, 448, ["-FBS", "Y"]), (9, 224, ["-BP", "1", "-MGDP", "2"]), (10, 112, ["-MNO", "1", "-FBS", "Y", "-PSS", "0.99", "-PRL", "0.99"]),
                                                    (11, 30, ["-BP", "40", "-MGDP", "9", "-MS", "3", "-RC", "7"]), (12, 330, ["-MNO", "120"])])
 def test_postfilter_on_synthetic_clump_lists(work, index11, seed, max_clumps, extra):
+    """Device stage vs the host's copy of the same routine (oqc_core.h) on clump lists no real read produces; as above, the pin to the reference is the host
+    copy's (goldens, live reference) and the command line's with the device filter -- this test only shows that the two compilations agree where real reads do not go."""
     import numpy as np
     rng = np.random.default_rng(seed)
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa"), "-osh", "stdout"] + list(extra)) as s:

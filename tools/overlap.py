@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How do the kernels of several batches in flight share the device?  Reads a rocprofv3 kernel trace (…_kernel_trace.csv of `tools/measure.sh kstats TAG N`) and prints, over
 the run's busiest window (from the first to the last k_ext_rows_pk launch): the share of the time with at least one kernel running, with a rows kernel running, how much of
-every kernel's duration overlaps a rows kernel, and each kernel's mean duration (to set beside the one-context run's).   tools/overlap.py trace.csv [trace_one_context.csv]"""
+every kernel's duration overlaps a rows kernel, and each kernel's mean duration (to set beside the one-context run's).   tools/overlap.py trace.csv [trace_one_context.csv [timed steps (8)]]"""
 import csv, sys, collections
 
 def load(path):
@@ -40,11 +40,12 @@ def merge(iv):
 
 rows = load(sys.argv[1])
 rk = [(s, e) for s, e, n in rows if n.startswith("k_ext_rows_pk<false>")]
-t0, t1 = rk[len(rk) // 4][0], rk[-1][1]          # skip the first passes
+nlast = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+t0, t1 = rk[-nlast][0], rk[-1][1]               # the timed steps (bench.py warms the contexts up one after the other: no overlap there)
 win = [(max(s, t0), min(e, t1), n) for s, e, n in rows if e > t0 and s < t1]
 span = t1 - t0
 busy = union([(s, e) for s, e, n in win]); rowsM = merge([(s, e) for s, e, n in win if n.startswith("k_ext_rows_pk")]); rowsBusy = sum(e - s for s, e in rowsM)
-nrows = sum(1 for s, e, n in win if n.startswith("k_ext_rows_pk<false>"))
+nrows = sum(1 for s, e, n in win if n.startswith("k_ext_rows_pk<false>")) - 1       # from the first launch's start to the last one's end: n - 1 batch periods, roughly
 print("window %.1f ms, %d batches: %.2f ms a batch; some kernel running %.1f%% of it, a rows kernel %.1f%%; sum of kernel durations %.1f ms a batch" % (span / 1e6, nrows, span / 1e6 / nrows, 100.0 * busy / span, 100.0 * rowsBusy / span, sum(e - s for s, e, n in win) / 1e6 / nrows))
 one = {}
 if len(sys.argv) > 2:

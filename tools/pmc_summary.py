@@ -55,6 +55,11 @@ if emit and kernel:
           "valu_issue_frac": (valu * 4.0 / (1024 * 2.4 * dur_ns)) if dur_ns else None,
           "sq": {c: biggest("sq", c) for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU")},
           "source": "rocprofv3 --pmc, separate passes with --kernel-trace only (tools/pmc_pass.sh); FETCH_SIZE x2 per the gfx950 note (see the calibration of byte-wide loads in profiles/); valu_cycles_per_inst = SIMD cycles (1024 SIMDs, 2.4 GHz) per wave64 VALU instruction over the launch; valu_issue_frac prices every instruction at 4 cycles (tools/micro/pk_rate.hip measures 2.5-2.9 for plain two-operand 32-bit ops and 4.3-4.7 for compares, selects, max and three-operand ops)"}
+    # the whole path: FETCH_SIZE x 2 + WRITE_SIZE summed over EVERY kernel of the pass, per step (a pass runs the pipeline once per launch of the dominant kernel)
+    nsteps = max(1, out[k].get("_dispatches_fetch", 1))
+    wf = sum(v.get("FETCH_SIZE", 0.0) for v in out.values()) * 1024.0 * 2.0 / nsteps; ww = sum(v.get("WRITE_SIZE", 0.0) for v in out.values()) * 1024.0 / max(1, out[k].get("_dispatches_write", nsteps))
+    js["whole_path"] = {"fetch_bytes_per_step": wf, "write_bytes_per_step": ww, "hbm_bytes_per_step": wf + ww, "steps_in_the_pass": nsteps,
+                        "note": "sum over all kernels of one context's pass (the first batch's extra counting passes included), FETCH_SIZE x 2 + WRITE_SIZE as for the kernel above"}
     json.dump(js, open(emit, "w"), indent=1); print("wrote", emit, js)
 
 # FETCH_SIZE calibration (tools/micro/fetch_calib.hip): counter per kernel against the bytes each kernel reads exactly once

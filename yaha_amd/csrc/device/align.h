@@ -484,6 +484,7 @@ struct Aligner {
 // Persistent waves pull root clumps from a queue (one 64-thread workgroup = one wavefront).
 __global__ void __launch_bounds__(64) k_align(AlignArgs A)
 {
+    YD_HIGH_PRIO();
     const unsigned wave = blockIdx.x;
     WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];
@@ -512,6 +513,7 @@ struct DPBatchArgs {
 };
 __global__ void __launch_bounds__(64) k_dp_batch(DPBatchArgs A)
 {
+    YD_HIGH_PRIO();
     const int lane = laneId();
     WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];

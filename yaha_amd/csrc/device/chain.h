@@ -337,6 +337,7 @@ __device__ inline uint32_t chainGeneral(const ChainArgs &A, ChainAlloc &al, cons
 
 __global__ void __launch_bounds__(64) k_chain(ChainArgs A)
 {
+    YD_HIGH_PRIO();
     __shared__ ChainLds sT;
     const int lane = laneId();
     unsigned formed = 0; ChainAlloc al;
@@ -371,6 +372,7 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A)
 // serial steps of the chain DP wait on LDS instead of L2
 __global__ void __launch_bounds__(64) k_chain_big(ChainArgs A, const uint32_t *bigList, uint32_t nBig, unsigned int *queueHead)
 {
+    YD_HIGH_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t smem[YD_CHAIN_LDS_N * 80 + 64];
     const int lane = laneId();
     ChainMem G = carveChain(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxN), Lm = carveChain(smem, YD_CHAIN_LDS_N);
@@ -396,6 +398,7 @@ __global__ void __launch_bounds__(64) k_chain_big(ChainArgs A, const uint32_t *b
 // Two atomics per 1024-thread block (a single L2 word takes only ~88 atomics/us; there are ~10^5 waves here).
 __global__ void __launch_bounds__(1024) k_regions_single(ChainArgs A)
 {
+    YD_HIGH_PRIO();
     __shared__ unsigned sCnt[16], sBase[2];
     const uint32_t reg = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId(), wv = (int)(threadIdx.x >> 6);
     bool make = false; DevFrag f; f.refLen = 0; f.rs = 0;

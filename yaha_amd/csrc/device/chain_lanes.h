@@ -19,6 +19,7 @@ struct ChainLaneLds {
 
 __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t *smallList, uint32_t nSmall)
 {
+    YD_HIGH_PRIO();
     __shared__ ChainLaneLds T;
     const int lane = laneId(); const DevParams &P = A.P;
     const int MS = P.MS, GO = P.GO, GE = P.GE, maxGap = P.maxGap, maxDesert = P.maxDesert, minMatch = P.minMatch, minLeft = P.minNonOverlap - 1;

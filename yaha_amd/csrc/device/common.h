@@ -8,6 +8,15 @@
 #define YD_WORST   (-(0x7fffff00))          // reference DPWorstScore, SW.cpp:356
 #define YD_BIAS    (1 << 24)                 // keeps (score + BIAS) positive and below 2^25 (checked in ygpu_init)
 #define YD_WAVE    64
+// Wave priority.  A SIMD issues for the wave of the highest priority that is ready, the oldest one among equals -- and the waves of the X-drop rows kernels
+// (k_ext_rows*: persistent, 3 per SIMD, always an instruction ready) are older than anything launched beside them: with every wave at the default priority a kernel of
+// another batch in flight that shares their SIMDs is starved of issue slots until the rows launch ends (a 0.3 ms kernel took 17 ms there, a buffer copy 14 ms,
+// profiles/r04_timeline_four_contexts_before_priorities.txt).  So every kernel BUT the rows kernels raises its waves at entry: memory-bound as they are, they take
+// the few issue slots they need when they need them and wait for memory the rest of the time, and the rows kernel runs in what they leave.
+#ifndef YD_PRIO
+#define YD_PRIO 3
+#endif
+#define YD_HIGH_PRIO() __builtin_amdgcn_s_setprio(YD_PRIO)
 
 enum { stReversed = 0x01, stAligned = 0x04, stScored = 0x08, stSplit = 0x10 };   // FragsClumps.inl:235-240
 enum { OP_M = 0, OP_R = 1, OP_D = 2, OP_I = 3 };

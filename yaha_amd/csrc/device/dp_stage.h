@@ -7,6 +7,7 @@
 // classify a gap problem as k_p1_joints does (phase_lanes.h): pure diagonal or DP; sort key = (class, strip width, rows)
 __global__ void k_dp_classify(DevParams P, const uint8_t *bases, const uint8_t *fwd, const uint8_t *rev, JointRec *joints, uint32_t n, uint32_t *keys, uint32_t *diagOps)
 {
+    YD_HIGH_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     JointRec j = joints[t];
@@ -28,6 +29,7 @@ __global__ void k_dp_classify(DevParams P, const uint8_t *bases, const uint8_t *
 __global__ void k_dp_gather_ext(const ExtProb *probs, const ExtRes *res, const uint32_t *extOps, const uint32_t *outOff, const uint32_t *dst, uint32_t n,
                                 ygpu_dp_result *out, uint32_t *outOps)
 {
+    YD_HIGH_PRIO();
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const ExtRes r = res[p]; ygpu_dp_result o; o.score = 0; o.addedQLen = o.addedRLen = 0; o.op_start = outOff[p]; o.n_ops = 0;
@@ -41,6 +43,7 @@ __global__ void k_dp_gather_ext(const ExtProb *probs, const ExtRes *res, const u
 __global__ void k_dp_gather_gap(DevParams P, const uint8_t *bases, const uint8_t *fwd, const uint8_t *rev, const JointRec *joints, const uint32_t *gapOps, const uint32_t *outOff, const uint32_t *dst,
                                 uint32_t n, ygpu_dp_result *out, uint32_t *outOps)
 {
+    YD_HIGH_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const JointRec j = joints[t]; ygpu_dp_result o; o.score = j.score; o.addedQLen = o.addedRLen = 0; o.op_start = outOff[t]; o.n_ops = j.nOps;

@@ -329,6 +329,7 @@ __device__ __forceinline__ int extRowWord(int y) { return ((y - 1) / 10) * 32 + 
 #define YD_TRACE_DEPTH 8
 __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 {
+    YD_HIGH_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId();
     if (*toGlobal(A.errFlag) != 0) return;                                   // k_ext_rows ran out of arena (or an earlier kernel failed): the stage is redone, its strips are incomplete
     // problems in the order k_ext_rows took them: the 64 problems of a pool ran in one wave at the same time, so the lanes of a wave here walk neighbouring blocks
@@ -440,6 +441,7 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 // key = arena region (physical chunk >> regionLog) | length bucket : 5 (32 buckets of the longest read's length: two radix passes for the bench batch)
 __global__ void k_trace_keys(const ExtRes *res, const uint32_t *order, uint32_t n, const uint32_t *waveChunks, uint32_t maxCh, int regionLog, int lenShift, int lenBits, uint32_t *keys, uint32_t *vals)
 {
+    YD_HIGH_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t p = order ? order[t] : t;
@@ -455,6 +457,7 @@ __global__ void k_trace_keys(const ExtRes *res, const uint32_t *order, uint32_t 
 // order values are global problem indices; a chunk's kernels index from the chunk's first problem
 __global__ void k_rebase_u32(uint32_t *v, uint32_t n, uint32_t sub)
 {
+    YD_HIGH_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] -= sub;
 }
@@ -462,6 +465,7 @@ __global__ void k_rebase_u32(uint32_t *v, uint32_t n, uint32_t sub)
 // sort keys for a problem list that has none yet: longest row bound first
 __global__ void k_prob_keys(const ExtProb *probs, uint32_t n, uint32_t *keys, uint32_t *vals)
 {
+    YD_HIGH_PRIO();
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) { keys[p] = (probs[p].flags & XP_VALID) ? 0xFFFFu - probs[p].qLen : 0xFFFFu; vals[p] = p; }
 }

@@ -380,6 +380,7 @@ __device__ __forceinline__ bool pkContF(const PkRec &r, int k, int h) { const ui
 #define YD_TSTRIDE 36          // dwords per problem in the traceback's block cache (32 + padding; 16-byte aligned).  (32 with an XOR swizzle -- a fifth workgroup per CU -- was no faster.)
 __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
 {
+    YD_HIGH_PRIO();
     // The 64 lanes of a wave read 64 different 128-byte blocks per pass.  Read by their own lanes -- eight 8-byte pieces each -- that is 512 line requests a
     // pass, and the kernel's time followed the number of such requests, not the bytes.  Here the wave fetches the blocks TOGETHER: eight loads of 16 bytes per
     // lane, each covering eight whole blocks (eight lanes per block), through LDS ([problem][36 dwords], 36 KB a workgroup); a lane then reads its own records there, and a gap

@@ -18,6 +18,7 @@
 template <int GW>
 __global__ void __launch_bounds__(64) k_gap_band(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     static_assert(GW == 12 || GW == 16, "two instances");
     const int lane = laneId(); const DevParams &P = A.P;
     const int GO = P.GO, GE = P.GE, GOE = P.GO + P.GE, RC = P.RC, MS = P.MS, maxIntron = P.maxIntron, maxGapP = P.maxGap, bw = P.bandWidth;

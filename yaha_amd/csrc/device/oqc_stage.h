@@ -35,6 +35,7 @@ __host__ __device__ inline unsigned oqcLdsBytes(int capN) { return 64u * (unsign
 // tables a read may need in HBM: 2 n_ops + 3 per clump of the read (every clump's table built)
 __global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *lists, unsigned int *cnt)
 {
+    YD_HIGH_PRIO();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63);
     unsigned long long v = 0; int cls = -1;
     if (r < A.nReads) {
@@ -66,6 +67,7 @@ __global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *li
 // the reads left to the host: all their clumps, in the hot path's order
 __global__ void k_oqc_raw(OqcArgs A, const uint32_t *list, uint32_t count)
 {
+    YD_HIGH_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const uint32_t r = list[t], b = A.cs[r], n = A.cs[r + 1] - b; uint32_t nops = 0;
@@ -78,6 +80,7 @@ __global__ void k_oqc_raw(OqcArgs A, const uint32_t *list, uint32_t count)
 // of the batch-wide HBM arrays.
 __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list, uint32_t count, unsigned ldsBytes)
 {
+    YD_HIGH_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char sOqc[];
     if (blockIdx.x >= count) return;
     const int lane = (int)threadIdx.x;
@@ -186,6 +189,7 @@ __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list
 // per clump (a read handed to the host unfiltered brings hundreds): the ops' places from a scan of the clumps' op counts across the wave.
 __global__ void __launch_bounds__(256) k_oqc_gather(OqcArgs A, const uint32_t *outStart, const uint32_t *opsStart, ygpu_out_clump *fClumps, uint32_t *fOps)
 {
+    YD_HIGH_PRIO();
     const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; const int lane = (int)(threadIdx.x & 63);
     if (r >= A.nReads) return;
     const uint32_t b = A.cs[r], m = A.outCnt[r], d = outStart[r]; uint32_t od = opsStart[r]; const uint16_t pc = (uint16_t)A.primCnt[r];

@@ -209,6 +209,7 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
 
 __global__ void k_joint_counts(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < A.nRoots) X.jointCount[r] = A.clumps[A.order[r]].nFrags - 1u;
     if (r == A.nRoots) X.jointCount[r] = 0u;
@@ -260,6 +261,7 @@ __device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, bool banded,
 // lane per root: exact-match extensions of every joint (AlignHelpers.c:216-232), then the gap's kind (AlignExtFrag.cpp:190-231)
 __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
     unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0, nB12 = 0, nB16 = 0;
@@ -318,6 +320,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
 template <int GW>
 __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     __shared__ int sPV[GW + 1][64], sPF[GW + 1][64];
     __shared__ uint8_t sPI[GW + 1][64]; __shared__ uint32_t sRefW[YD_GRW][64], sQW[YD_GQW][64];
     const int lane = laneId(); const DevParams &P = A.P;
@@ -362,6 +365,7 @@ __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
 // wave per DP joint (dp_wave.h) for the joints beyond gapDPLane's limits
 __global__ void __launch_bounds__(64) k_gap_wave(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     const int lane = laneId();
     WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];
@@ -388,6 +392,7 @@ __global__ void __launch_bounds__(64) k_gap_wave(AlignArgs A, PhaseArgs X)
 // two X-drop extension problems
 __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
     ChainClumpRec rec; rec.nFrags = 0; rec.rs = 0; rec.fragOff = 0;
@@ -605,6 +610,7 @@ __device__ __forceinline__ P3Root p3Merged(const PhaseArgs &X, uint32_t r)
 
 __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     const int lane = laneId(); const uint32_t r = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
     int verdict = -1;                                  // -1 none, 0 rejected, 1 split needed, 2 scored
@@ -670,6 +676,7 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
 // ask for -> probs2 (the second k_ext_rows / k_ext_trace round) and the root's memo keys.  Persistent 64-thread blocks over the split list.
 __global__ void __launch_bounds__(64) k_p3_predict(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     const int lane = laneId(); const DevParams &P = A.P; const uint32_t nSlow = *X.slowCount;
     for (uint32_t base = blockIdx.x * 64u; base < nSlow; base += gridDim.x * 64u) {
         const uint32_t slot = base + (uint32_t)lane; const bool live = slot < nSlow;
@@ -702,6 +709,7 @@ __global__ void __launch_bounds__(64) k_p3_predict(AlignArgs A, PhaseArgs X)
 // merge the extension results, then scoreClump / splitClump as in k_align
 __global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
 {
+    YD_HIGH_PRIO();
     const unsigned wave = blockIdx.x; const int lane = laneId();
     WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];

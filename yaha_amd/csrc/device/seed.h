@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256) k_low_offsets(const uint32_t *SO, uint32_
 __global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const uint32_t *ROA, const uint32_t *low, const uint32_t *kmerOff,
                               uint32_t *posS, uint32_t *posC, uint32_t *posRsI, unsigned int *parts)
 {
+    YD_HIGH_PRIO();
     const uint32_t rs = blockIdx.x; const uint32_t read = rs >> 1;
     const uint32_t o = B.readOff[read]; const int qlen = (int)(B.readOff[read + 1] - o);
     const int L = P.wordLen, nPos = qlen - L + 1;
@@ -74,6 +75,7 @@ __global__ void k_kmer_lookup(DevParams P, DevBatch B, const uint32_t *SO, const
 // counter += sum of its 1 024 partial sums (one workgroup of 1 024 threads)
 __global__ void __launch_bounds__(1024) k_sum_parts(const unsigned int *parts, unsigned long long *counter)
 {
+    YD_HIGH_PRIO();
     __shared__ unsigned long long sSum;
     if (threadIdx.x == 0) sSum = 0;
     __syncthreads();
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(1024) k_sum_parts(const unsigned int *parts, u
 #define YD_EXPAND_HITS 1024
 __global__ void k_expand_starts(const uint32_t *hitOff, uint32_t nKmers, uint32_t *blockG0)
 {
+    YD_HIGH_PRIO();
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nKmers) return;
     const uint32_t a = hitOff[g], b = hitOff[g + 1u];
@@ -99,6 +102,7 @@ __global__ void k_expand_starts(const uint32_t *hitOff, uint32_t nKmers, uint32_
 }
 __global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, const uint32_t *blockG0, uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
 {
+    YD_HIGH_PRIO();
     __shared__ uint32_t sOff[YD_EXPAND_HITS + 2], sS[YD_EXPAND_HITS + 2], sRsI[YD_EXPAND_HITS + 2]; __shared__ __attribute__((aligned(16))) uint32_t sK[YD_EXPAND_HITS]; __shared__ uint32_t sWave[4];
     const uint32_t t0 = blockIdx.x * YD_EXPAND_HITS, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     // the window: from this block's first k-mer to the next block's (k-mers without hits in between included), at most 1026 offsets (hitOff has nKmers + 1 entries)
@@ -148,6 +152,7 @@ __global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const 
 // segment offsets of the hit sort: the hits of (read, strand) rs are [hitOff[kmerOff[rs]], hitOff[kmerOff[rs + 1]])
 __global__ void k_seg_offsets(const uint32_t *kmerOff, const uint32_t *hitOff, uint32_t nSeg, uint32_t *segOff)
 {
+    YD_HIGH_PRIO();
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s <= nSeg) segOff[s] = hitOff[kmerOff[s]];
 }
@@ -230,6 +235,7 @@ static_assert((YD_FRAG_IPT * (YD_FRAG_BS / 64)) % 64 == 0 && YD_FRAG_IPT <= 10, 
 __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap,
                                                                 unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
 {
+    YD_HIGH_PRIO();
     constexpr int NW = YD_FRAG_BS / 64;
     __shared__ uint32_t sCnt[YD_FRAG_IPT * NW]; __shared__ uint32_t sPrefix; __shared__ unsigned sDead;
     const uint32_t tile = tileTicket(tileState + gridDim.x, &sPrefix), base = tile * (uint32_t)YD_FRAG_TILE, t = threadIdx.x, lane = t & 63u, w = t >> 6;
@@ -306,6 +312,7 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
 }
 __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
 {
+    YD_HIGH_PRIO();
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nFrags) return;
     frags[f].refLen = (uint16_t)(1 + (int)frags[f].eqo - (int)frags[f].sqo);      // setRefLen, FragsClumps.inl:44-47
@@ -320,6 +327,7 @@ __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
 static_assert(4 * YD_REG_IPT <= 64, "k_region_scan: one lane of wave 0 per (wave, row) count");
 __global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *regStart, unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */)
 {
+    YD_HIGH_PRIO();
     __shared__ uint32_t sCnt[4 * YD_REG_IPT]; __shared__ uint32_t sPrefix;
     const uint32_t tile = tileTicket(tileState + gridDim.x, &sPrefix), t = threadIdx.x, lane = t & 63u, w = t >> 6, wbase = tile * (uint32_t)YD_REG_TILE + w * (uint32_t)(64 * YD_REG_IPT);
     uint32_t rs[YD_REG_IPT], dg[YD_REG_IPT]; unsigned long long headMask[YD_REG_IPT];
@@ -365,6 +373,7 @@ __global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nF
 // smallList: regions with 2..8 fragments (k_chain_lanes); multiList: 9..64 (k_chain); bigList: more than 64 (k_chain_big)
 __global__ void __launch_bounds__(1024) k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned int *nSmall)
 {
+    YD_HIGH_PRIO();
     __shared__ unsigned sM[16], sS[16], sBase[2];                            // one atomic per list and 1024-thread block (a single L2 word takes ~88 atomics per microsecond)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
     const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
@@ -386,6 +395,7 @@ __global__ void __launch_bounds__(1024) k_region_classify(const uint32_t *regSta
 // order[base[region] + seq] = clump index  (rank of a root clump = creation order)
 __global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, const uint32_t *regionBase, uint32_t *order)
 {
+    YD_HIGH_PRIO();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nClumps) return;
     if (clumps[c].nFrags == 0xFFFFFFFFu) return;                              // unused slot of a wave's reservation chunk
@@ -394,6 +404,7 @@ __global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, con
 // final layout: clump ci of root r with push number p goes to rootBase[r] + (pushCount[r] - 1 - p)
 __global__ void k_out_layout(const uint32_t *outRoot, const uint32_t *outPush, const uint32_t *rootBase, const unsigned int *rootPushCount, uint32_t nOut, uint32_t *dstIdx)
 {
+    YD_HIGH_PRIO();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nOut) return;
     const uint32_t r = outRoot[c];
@@ -401,6 +412,7 @@ __global__ void k_out_layout(const uint32_t *outRoot, const uint32_t *outPush, c
 }
 __global__ void k_out_scatter(const ygpu_clump *src, const uint32_t *dstIdx, uint32_t nOut, ygpu_clump *dst)
 {
+    YD_HIGH_PRIO();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nOut) return;
     dst[dstIdx[c]] = src[c];
@@ -408,6 +420,7 @@ __global__ void k_out_scatter(const ygpu_clump *src, const uint32_t *dstIdx, uin
 // clumps per read: root r belongs to read (clumps[order[r]].rs >> 1)
 __global__ void k_read_counts(const ChainClumpRec *clumps, const uint32_t *order, const unsigned int *rootPushCount, uint32_t nRoots, unsigned int *readCount)
 {
+    YD_HIGH_PRIO();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nRoots) return;
     const unsigned n = rootPushCount[r];

@@ -16,6 +16,7 @@
 template <unsigned BS, unsigned IPT>
 __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
 {
+    YD_HIGH_PRIO();
     using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t>;
     __shared__ typename Sort::storage_type st;
     const uint32_t seg = list[blockIdx.x];                                   // the segments of this launch's size class (k_seg_classify)
@@ -54,6 +55,7 @@ struct SegClassHi { uint32_t hi[YD_SEG_NCLASS]; };
 __global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segB, const uint32_t *segE, uint32_t nSeg, SegClassHi H,
                                                       uint32_t *lists, uint32_t *bigB, uint32_t *bigE, unsigned int *counts)
 {
+    YD_HIGH_PRIO();
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63u);
     uint32_t b = 0, e = 0; int cls = -1;
     if (s < nSeg) {
@@ -82,6 +84,7 @@ __global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segB, cons
 __global__ void __launch_bounds__(1024) k_seg_split(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *bigList,
                                                     int diagBits, uint32_t *subB, uint32_t *subE)
 {
+    YD_HIGH_PRIO();
     // Wave w owns the w-th sixteenth of the segment and walks it 64 hits at a time (coalesced); the stable order is (wave, group, lane).
     __shared__ uint32_t sCnt[YD_SPLIT_NB][16];                                // [bucket][wave]: counts, then running write positions
     const uint32_t seg = bigList[blockIdx.x], b = segB[seg], len = segE[seg] - b, t = threadIdx.x, lane = t & 63u, w = t >> 6;
@@ -127,12 +130,14 @@ __global__ void __launch_bounds__(1024) k_seg_split(const unsigned long long *in
 // begin/end of the listed sub-segments only (the library's segmented sort costs 0.3 ms over 56 k mostly empty segments, nothing over the nine that need it)
 __global__ void k_seg_gather_bounds(const uint32_t *segB, const uint32_t *segE, const uint32_t *list, uint32_t n, uint32_t *outB, uint32_t *outE)
 {
+    YD_HIGH_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { outB[i] = segB[list[i]]; outE[i] = segE[list[i]]; }
 }
 // sorted long sub-segments of the library path back to where the others are: dst[range] = src[range] for the listed sub-segments
 __global__ void k_seg_copy_back(const unsigned long long *src, unsigned long long *dst, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
 {
+    YD_HIGH_PRIO();
     const uint32_t seg = list[blockIdx.x], b = segB[seg], e = segE[seg];
     for (uint32_t k = b + threadIdx.x; k < e; k += blockDim.x) dst[k] = src[k];
 }

@@ -28,6 +28,7 @@ struct SFrame { uint32_t sro; int sqo, eqo, refLen, score, status, start, len, p
 
 __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, SplitArgs Sx)
 {
+    YD_HIGH_PRIO();
     const int lane = laneId(); const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane; const DevParams &P = A.P;
     const bool live = slot < Sx.nSlots;
     uint32_t *lists = (uint32_t *)(Sx.scratch + (size_t)slot * YD_SL_BYTES); uint32_t *outOps = lists + YD_SL_DEPTH * YD_SL_CAP; ygpu_clump *outCl = (ygpu_clump *)(outOps + YD_SL_OUT);

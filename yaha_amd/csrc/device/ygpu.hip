@@ -83,7 +83,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; int runsDone = 0; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // post-filter stage (oqc_stage.h)
     DevBuf oqProf, oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
     bool oqSet = false, oqDone = false; yoqc::Params oqP{}; yoqc::Seqs oqG{}; uint32_t nFOut = 0, nFOps = 0;
@@ -675,6 +675,16 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         // bound is a hundred times their use, forces the ranges)
         ctx->traceRatio = std::max(0.01, usedRatio * 1.3);
         ctx->opsRatio = std::max(0.002, std::max(1.3 * (double)usedOps / ((double)boundBlocks * 10.0), ctx->opsRatio * 0.7));
+        // A context's FIRST batch guesses, and a guess that was too small is doubled: the arena it ends up with can be far above what the batches need (10 kbp reads:
+        // 40 GB for 30 -- memory the device's other contexts then lack, the third one was left with ranges and a first batch of 1.8 s).  Once, after that first
+        // batch, an arena more than 4 GB and a quarter above the next estimate is given back; the next batch asks for what the estimate says.
+        if (ctx->runsDone == 0 && nRanges == 1) {
+            const double nextBytes = ((double)boundBlocks * ctx->traceRatio / chunkBlocks + slackChunks) * (YD_CHUNK_DWORDS * 4.0);
+            if ((double)ctx->extTrace.cap > 1.25 * nextBytes && (double)ctx->extTrace.cap - nextBytes > 4.0e9) {
+                if (kStats) fprintf(stderr, "[ygpu] ctx %p: trace arena of the first batch %.2f GB given back (the next batches need %.2f GB)\n", (void *)ctx, ctx->extTrace.cap / 1e9, nextBytes / 1e9);
+                HIPCHK(streamSync(ctx)); ctx->extTrace.release();
+            }
+        }
     }
     TRACE("lanes: ranges done");
     return 0;
@@ -700,7 +710,10 @@ static int stageAlign(ygpu_ctx *ctx)
         // waves of the wave-per-root kernels (and their scratch, ~1 KB per query base each): the whole stage without the lane kernels, only the roots those
         // hand back with them
         const unsigned wavesPerCU = ctx->alignWavesPerCU > 0 ? (unsigned)ctx->alignWavesPerCU : (useLanes ? 4u : 12u);
-        const unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * wavesPerCU), maxWaves);      // 3 waves per SIMD (137 VGPRs)
+        unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * wavesPerCU), maxWaves);      // 3 waves per SIMD (137 VGPRs)
+        // (with the lane kernels doing the bulk the wave kernels see the roots those hand back -- none on ordinary batches -- and the gap fills beyond the lane kernels'
+        // limits: their scratch, ~1 KB per query base and wave, is held to 3 GB -- 10 kbp reads took 10.7 GB a context for 1 024 waves that had nothing to do)
+        if (useLanes && per * waves > (3ull << 30)) waves = (unsigned)std::max<uint64_t>(64, (3ull << 30) / per);
         ENSURE(ctx->scratchAlign, per * waves);
         ENSURE(ctx->clumpFrags0, 16ull * (ctx->nClumpFrags + 1));
         HIPCHK(hipMemcpyAsync(ctx->clumpFrags0.p, ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
@@ -736,6 +749,7 @@ static int stageAlign(ygpu_ctx *ctx)
             if (laneOverflow || traceOverflow) ef = YERR_OUT;
             else { rc = fetchU32(ctx, cnt + CNT_OUTCLUMPS, got, 2); if (rc) return rc; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc; }
             if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
+            if (kStats) fprintf(stderr, "[ygpu] ctx %p: align attempt %d repeated (%s); trace ratio %.3f, ops ratio %.4f\n", (void *)ctx, attempt + 1, traceOverflow ? "trace / extension-op arena" : (laneOverflow ? "phase-1 arenas (state ops, gap ops)" : "output arenas"), ctx->traceRatio, ctx->opsRatio);
             if (ef != YERR_OUT || attempt >= 12) { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
             if (!traceOverflow) {                                            // (a full trace arena has grown its own estimate)
                 outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
@@ -1005,6 +1019,18 @@ int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
     return 0;
 }
 
+}  // extern "C"
+static std::vector<DevBuf *> allBuffers(ygpu_ctx *ctx)
+{
+    DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->tileState,
+                         &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
+                         &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
+                         &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
+                         &ctx->oqProf, &ctx->oqLists, &ctx->oqClsCnt, &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
+    return std::vector<DevBuf *>(all, all + sizeof all / sizeof all[0]);
+}
+extern "C" {
+
 void ygpu_destroy(ygpu_ctx *ctx)
 {
     if (!ctx) return;
@@ -1013,11 +1039,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
     if (ctx->stream) {
         hipSetDevice(ctx->device);
         if (ctx->sharedIndex) { ctx->dBases.p = nullptr; ctx->dBases.cap = 0; ctx->dSO.p = nullptr; ctx->dSO.cap = 0; ctx->dROA.p = nullptr; ctx->dROA.cap = 0; ctx->dLow.p = nullptr; ctx->dLow.cap = 0; }
-        DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->tileState,
-                         &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
-                         &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
-                         &ctx->oqProf, &ctx->oqLists, &ctx->oqClsCnt, &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
+        const std::vector<DevBuf *> all = allBuffers(ctx);
         for (auto b : all) b->release();
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
@@ -1027,6 +1049,16 @@ void ygpu_destroy(ygpu_ctx *ctx)
         hipStreamDestroy(ctx->stream);
     }
     delete ctx;
+}
+/* Device memory: free and total bytes of the context's device, and what this context's own buffers hold (a shared index image counts for the context that owns it). */
+int ygpu_memory(ygpu_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes, uint64_t *ctx_bytes)
+{
+    if (!ctx || !ctx->stream) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t fb = 0, tb = 0; HIPCHK(hipMemGetInfo(&fb, &tb));
+    uint64_t mine = 0; for (DevBuf *b : allBuffers(ctx)) if (b->p && !(ctx->sharedIndex && (b == &ctx->dBases || b == &ctx->dSO || b == &ctx->dROA || b == &ctx->dLow))) mine += b->cap;
+    if (free_bytes) *free_bytes = fb; if (total_bytes) *total_bytes = tb; if (ctx_bytes) *ctx_bytes = mine;
+    return 0;
 }
 const char *ygpu_last_error(const ygpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -1067,6 +1099,7 @@ int ygpu_run(ygpu_ctx *ctx)
     int rc = runTo(ctx, 3);
     if (kStats) { size_t fb = 0, tb = 0; hipMemGetInfo(&fb, &tb); fprintf(stderr, "[ygpu] ctx %p run: %u reads, rc %d, %.1f ms; align attempts %d, ranges %d, trace arena %.2f GB (ratio %.3f), free %.1f GB\n", (void *)ctx, ctx->nReads, rc, nowMs() - t0, ctx->statAttempts, ctx->statRanges, ctx->extTrace.cap / 1e9, ctx->traceRatio, fb / 1e9); }
     if (rc) return rc;
+    ctx->runsDone++;
     ctx->totalMs = 0;
     for (int t = 0; t < T_N; t++) {
         float m = 0; ctx->ms[t] = (ctx->evUsed[t] && hipEventElapsedTime(&m, ctx->ev[t][0], ctx->ev[t][1]) == hipSuccess) ? m : 0;

@@ -286,9 +286,9 @@ int runQueries(Args &a, FILE *log)
     ygpu_postfilter_params PF; memset(&PF, 0, sizeof PF);
     PF.minNonOverlap = oqP.minNonOverlap; PF.BPCost = oqP.BPCost; PF.maxBPLog = oqP.maxBPLog; PF.FBS = oqP.FBS; PF.FBS_PSLength = oqP.FBS_PSLength; PF.FBS_PSScore = oqP.FBS_PSScore;
     PF.bppVmin = oqP.bppVmin; PF.bppN = std::max(0, oqP.bppN); PF.bppThr = oqThr.data(); PF.n_seqs = (uint32_t)oqSeqStart.size(); PF.seq_start = oqSeqStart.data(); PF.seq_length = oqSeqLen.data();
-    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
+    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; uint64_t footprint = 0; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
     std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < nDev; k++) warm.emplace_back(new Warm);
-    std::atomic<int> ctxUp(0); double tCtxUp = 0;
+    std::atomic<int> ctxUp(0), parked(0); double tCtxUp = 0;
     std::vector<std::atomic<uint64_t>> devReads(nDev); for (auto &x : devReads) x = 0;       // reads each device took (the stats line: do all devices pull their weight?)
     // The index image reaches the devices through ONE call (ygpu_init_multi): the first device takes it from the host, the others from their neighbour over xGMI,
     // piece by piece -- the reference maps its index once for all threads (Query.c:565-626); N uploads of 16.7 GB at once would share the host's memory instead.
@@ -337,8 +337,20 @@ int runQueries(Args &a, FILE *log)
             int rc;
             if (first) {
                 std::lock_guard<std::mutex> one(W.first);
+                // Does the device still have room for this context's arenas?  What the device's first context holds after its first batch is the measure (arenas
+                // follow the batches: ~55 GB a context for 16 M bases of 1 kbp reads, ~75 GB for 10 kbp reads): a context that would start with less than 0.9 of
+                // that free is left out -- its batches go to the others -- instead of squeezing its arenas into what is left (10 kbp reads at -ctx 3: a first batch of
+                // 1.8 s, cut into ranges, with every other context waiting behind it).
+                if (d != lead && W.footprint > 0) {
+                    uint64_t fb = 0, tb = 0, mine = 0;
+                    if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0 && (double)fb < 0.9 * (double)W.footprint) {
+                        if (timing || stats) fprintf(stderr, "[yaha] context %d left out: %.1f GB free on device %d, the first context's arenas hold %.1f GB\n", d, fb / 1e9, dev, W.footprint / 1e9);
+                        inQ.push(std::move(b)); parked++; break;
+                    }
+                }
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning++; }
                 rc = hotPath(); first = false;
+                if (d == lead && rc == 0) { uint64_t fb = 0, tb = 0, mine = 0; if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0) W.footprint = mine > (uint64_t)V.n_base_bytes + 4ull * V.totalMatches ? mine - (V.n_base_bytes + 4ull * V.totalMatches + 4ull * ((1ull << (2 * V.wordLen)) + 1)) : mine; }
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning--; } W.cv.notify_all();
             } else {
                 { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.firstRunning == 0; }); }
@@ -406,8 +418,8 @@ int runQueries(Args &a, FILE *log)
     if (stats) {    // one line for scripts (bench.py): steady = reads written after the first batch / time from the first batch's write to the last one's
         const double steady = (nWritten > nFirst && tLastOut > tFirstOut) ? (nWritten - nFirst) / ((tLastOut - tFirstOut) * 1e-3) : 0.0;
         std::string per = "["; for (int k = 0; k < nDev; k++) { char t[32]; snprintf(t, sizeof t, "%s%llu", k ? ", " : "", (unsigned long long)devReads[k].load()); per += t; } per += "]";
-        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, \"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d, \"reads_per_device\": %s}\n",
-                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev, per.c_str());
+        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, \"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d, \"ctx_left_out\": %d, \"reads_per_device\": %s}\n",
+                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev, parked.load(), per.c_str());
     }
     return rcAll;
 }
