@@ -220,11 +220,11 @@ def side_workload(ya, idx, reads_path, n_reads, device, contexts, steps, label):
             "k_ext_rows_ms_per_step": st.get("ext_rows_device_clock", 0.0) / steps, "dp_cells_per_read": (cnt["dp_ext_cells"] + cnt["dp_gap_cells"]) / max(n, 1), "hits_per_read": cnt["hits"] / max(n, 1)}
 
 
-def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1):
+def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1, read_len=1000, div=0.017):
     """The whole `yaha` command line with its defaults (process start, index mmap + upload to every device, input parsing, device, OQC, SAM text to a file in
     /dev/shm) on n_reads x 1 kbp reads -- BASELINE config 4's size by default -- over `gpus` devices.  `steady_reads_per_s` is the command line's own figure
     (YAHA_STATS=1): reads written after the first batch / time between the first and the last batch's write, i.e. without start-up."""
-    reads = make_reads(cache, fa, "e2e", n_reads, 1000, 0.017, seed)
+    reads = make_reads(cache, fa, "e2e", n_reads, read_len, div, seed)
     if gpus > 1:                                         # N devices: N times the reads (BASELINE config 4's size per device), the one file repeated
         many = os.path.join(cache, "e2e_x%d_%s" % (gpus, os.path.basename(reads)))
         if not os.path.exists(many):
@@ -270,7 +270,7 @@ def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1):
     steady = stats[best].get("steady_reads_per_s")
     return {"reads": n_reads, "gpus": gpus, "seconds": dt, "e2e_reads_per_s": n_reads / dt, "steady_reads_per_s": steady, "contexts_up_ms": stats[best].get("contexts_up_ms"), "reads_per_device": per_dev,
             "device_steady_reads_per_s": [round(steady * n / max(1, sum(per_dev))) for n in per_dev] if steady else None, "seconds_each_run": runs, "contexts_up_ms_of_the_settling_runs": settled, "sam_records": nrec, "cli_stats": stats[best],
-            "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam%s (defaults: -ctx 3, batches of ~16 M bases, host threads from the usable CPUs)" % (n_reads, " -gpus %d" % gpus if gpus > 1 else "")}
+            "read_len": read_len, "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam%s (defaults: -ctx 3, batches of ~16 M bases, host threads from the usable CPUs)" % (n_reads, " -gpus %d" % gpus if gpus > 1 else "")}
 
 
 def stub_rank(args, rank, world):
@@ -541,6 +541,8 @@ def main():
         try:
             out["end_to_end"] = end_to_end(ya, idx, fa, cache, args.e2e_reads, 3000)
             out["e2e_reads_per_s"] = out["end_to_end"]["e2e_reads_per_s"]; out["steady_reads_per_s"] = out["end_to_end"]["steady_reads_per_s"]
+            if args.e2e_reads >= 262144:     # BASELINE config 3's shape through the command line as well: 32 768 reads of 10 kbp (20 batches of ~16 M bases), r = 0.10 (realised 3.4 %)
+                out["end_to_end_c3"] = end_to_end(ya, idx, fa, cache, 32768, 3100, read_len=10000, div=0.034)
         except Exception as e:
             out["end_to_end"] = {"error": str(e)[:200]}
     if world > 1 and not args.no_extras:

@@ -465,7 +465,10 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         // first batch: an X-drop run stops after ~100-200 rows whatever its bound (most roots are chance hits), so the share of the bound that gets used
         // follows the mean bound; too small an estimate costs a redo of this stage (the arena doubles), too large a one memory the other contexts need
         const double meanBoundRows = 10.0 * (double)boundBlocks / std::max(1u, nProb);
-        ctx->traceRatio = std::min(0.6, std::max(0.02, 170.0 / std::max(1.0, meanBoundRows)));
+        // (rows an X-drop run computes, as the first batches of real runs showed them, with the 1.3 margin: 170 for 1 kbp reads -- mean bound 425 rows -- and 230 for
+        // 10 kbp reads -- mean bound 5 000; a guess that is too small costs a redo of the stage with an arena half as large again, and an arena that was made too
+        // large stays: giving 40 GB back and asking for 26 stalled every context of the device for 3.4 s, measured, profiles/r04_cli_10kbp.txt)
+        ctx->traceRatio = std::min(0.6, std::max(0.02, (165.0 + 0.02 * meanBoundRows) / std::max(1.0, meanBoundRows)));
     }
     const double slackChunks = (double)maxWavesK + (double)ctx->nCU * 8.0 + 64.0;   // every wave's open chunk, and the careful-extension round's
     const double wantChunks = (double)boundBlocks * ctx->traceRatio / chunkBlocks + slackChunks;
@@ -665,7 +668,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     if (ctx->splitLanes) ctx->lastFall = (long long)ctx->hFall;              // (the fetch above synchronised the stream)
     if (ef == YERR_TRACEMEM) {
         if (ctx->traceRatio >= 64.0) { ctx->err = "the extension trace arena overflows even at 64 times the problems' bound"; return YGPU_ENOMEM; }
-        ctx->traceRatio = std::min(64.0, ctx->traceRatio * 2.0); return -3;
+        ctx->traceRatio = std::min(64.0, ctx->traceRatio * 1.5); return -3;
     }
     if (ef == YERR_OUT && usedOps > extOpsCap) { ctx->opsRatio = std::min(4.0, std::max(ctx->opsRatio * 2.0, 1.3 * (double)usedOps / std::max(1.0, (double)boundBlocks * 10.0))); return -3; }
     if (ef == 0 && boundBlocks) {
@@ -675,16 +678,6 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         // bound is a hundred times their use, forces the ranges)
         ctx->traceRatio = std::max(0.01, usedRatio * 1.3);
         ctx->opsRatio = std::max(0.002, std::max(1.3 * (double)usedOps / ((double)boundBlocks * 10.0), ctx->opsRatio * 0.7));
-        // A context's FIRST batch guesses, and a guess that was too small is doubled: the arena it ends up with can be far above what the batches need (10 kbp reads:
-        // 40 GB for 30 -- memory the device's other contexts then lack, the third one was left with ranges and a first batch of 1.8 s).  Once, after that first
-        // batch, an arena more than 4 GB and a quarter above the next estimate is given back; the next batch asks for what the estimate says.
-        if (ctx->runsDone == 0 && nRanges == 1) {
-            const double nextBytes = ((double)boundBlocks * ctx->traceRatio / chunkBlocks + slackChunks) * (YD_CHUNK_DWORDS * 4.0);
-            if ((double)ctx->extTrace.cap > 1.25 * nextBytes && (double)ctx->extTrace.cap - nextBytes > 4.0e9) {
-                if (kStats) fprintf(stderr, "[ygpu] ctx %p: trace arena of the first batch %.2f GB given back (the next batches need %.2f GB)\n", (void *)ctx, ctx->extTrace.cap / 1e9, nextBytes / 1e9);
-                HIPCHK(streamSync(ctx)); ctx->extTrace.release();
-            }
-        }
     }
     TRACE("lanes: ranges done");
     return 0;
