@@ -19,6 +19,7 @@ def short(n):
 out = {}; perDispatch = collections.defaultdict(lambda: collections.defaultdict(dict))     # kernel -> pass -> dispatch -> counters
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     pas = os.path.basename(os.path.dirname(f))
+    if pas == "calib" or os.sep + "calib" + os.sep in f: continue          # the FETCH_SIZE calibration program's kernels (summarised below) are not the hot path's
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
     for row in csv.DictReader(open(f)):
         k = short(row.get("Kernel_Name", "?")); c = row.get("Counter_Name"); v = float(row.get("Counter_Value", 0) or 0); d = row.get("Dispatch_Id")
