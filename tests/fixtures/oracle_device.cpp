@@ -35,7 +35,13 @@ int ygpu_init_multi(const int *devices, int n, int cpd, const ygpu_index_view *v
 }
 int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out) { ygpu_ctx *c = new ygpu_ctx; c->V = parent->V; c->P = parent->P; c->device = parent->device; memset(&c->res, 0, sizeof c->res); *out = c; return 0; }
 void ygpu_destroy(ygpu_ctx *c) { if (!c) return; if (c->have) yoracle_free_result(&c->res); delete c; }
-int ygpu_memory(ygpu_ctx *, uint64_t *f, uint64_t *t, uint64_t *m) { if (f) *f = 1ull << 40; if (t) *t = 1ull << 40; if (m) *m = 0; return 0; }
+// (YTEST_FREE_GB / YTEST_CTX_GB: what the double reports as free on the device and as held by a context -- drives the command line's "context left out" path)
+int ygpu_memory(ygpu_ctx *, uint64_t *f, uint64_t *t, uint64_t *m)
+{
+    const char *fg = getenv("YTEST_FREE_GB"), *cg = getenv("YTEST_CTX_GB");
+    if (f) *f = fg ? (uint64_t)atoll(fg) << 30 : 1ull << 40; if (t) *t = 1ull << 40; if (m) *m = cg ? (uint64_t)atoll(cg) << 30 : 0;
+    return 0;
+}
 const char *ygpu_last_error(const ygpu_ctx *c) { return c ? c->err.c_str() : "no context"; }
 int ygpu_upload(ygpu_ctx *c, const ygpu_read_batch *b)
 {

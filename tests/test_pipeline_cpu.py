@@ -98,6 +98,16 @@ def test_results_in_plain_memory_when_nothing_can_be_page_locked_and_the_fast_ex
     assert strip_pg(p.stdout.decode()) == golden_lines("rchim_default")
 
 
+def test_contexts_without_room_for_their_arenas_are_left_out(exes, work, index11):
+    # the device's first context holds 60 GB after its first batch, 50 GB are free: the other two contexts of -ctx 3 take no batches, the output is unchanged
+    p = _run(exes["tsan"], ["-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", "stdout", "-batch", "20", "-ctx", "3"], env={"YTEST_FREE_GB": "50", "YTEST_CTX_GB": "60", "YAHA_STATS": "1"})
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    _clean(p)
+    err = p.stderr.decode()
+    assert err.count("left out") == 2 and '"ctx_left_out": 2' in err
+    assert strip_pg(p.stdout.decode()) == golden_lines("rchim_default")
+
+
 def test_no_such_device(exes, work, index11):
     p = _run(exes["asan"], ["-x", index11, "-q", os.path.join(work, "r1k.fa"), "-osh", "stdout", "-gpus", "2"], env={"YTEST_DEVICES": "1"})
     _clean(p)

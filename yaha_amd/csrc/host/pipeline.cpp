@@ -341,7 +341,7 @@ int runQueries(Args &a, FILE *log)
                 // follow the batches: ~55 GB a context for 16 M bases of 1 kbp reads, ~75 GB for 10 kbp reads): a context that would start with less than 0.9 of
                 // that free is left out -- its batches go to the others -- instead of squeezing its arenas into what is left (10 kbp reads at -ctx 3: a first batch of
                 // 1.8 s, cut into ranges, with every other context waiting behind it).
-                if (d != lead && W.footprint > 0) {
+                if (W.footprint > 0) {
                     uint64_t fb = 0, tb = 0, mine = 0;
                     if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0 && (double)fb < 0.9 * (double)W.footprint) {
                         if (timing || stats) fprintf(stderr, "[yaha] context %d left out: %.1f GB free on device %d, the first context's arenas hold %.1f GB\n", d, fb / 1e9, dev, W.footprint / 1e9);
@@ -350,7 +350,10 @@ int runQueries(Args &a, FILE *log)
                 }
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning++; }
                 rc = hotPath(); first = false;
-                if (d == lead && rc == 0) { uint64_t fb = 0, tb = 0, mine = 0; if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0) W.footprint = mine > (uint64_t)V.n_base_bytes + 4ull * V.totalMatches ? mine - (V.n_base_bytes + 4ull * V.totalMatches + 4ull * ((1ull << (2 * V.wordLen)) + 1)) : mine; }
+                if (W.footprint == 0 && rc == 0) {                           // (first batches run one at a time: the first one to finish is the measure)
+                    uint64_t fb = 0, tb = 0, mine = 0; const uint64_t image = (uint64_t)V.n_base_bytes + 4ull * V.totalMatches + 4ull * ((1ull << (2 * V.wordLen)) + 1);
+                    if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0) W.footprint = std::max<uint64_t>(1, d == lead && mine > image ? mine - image : mine);
+                }
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning--; } W.cv.notify_all();
             } else {
                 { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.firstRunning == 0; }); }
