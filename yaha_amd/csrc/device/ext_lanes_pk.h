@@ -442,20 +442,36 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
             };
             const int h = x >= YD_NP ? 1 : 0, k = x - YD_NP * h;
             const int second = k < 8 ? 0 : 1, bt = k < 8 ? k : k - 3, sT = 8 * h + bt, sU = 16 + sT, sM = 16 * h + 10 - k;
-            uint32_t dTU[YD_TRACE_DEPTH], dM[YD_TRACE_DEPTH];
             int lim = u.rr + 1; lim = lim < y ? lim : y;                      // to the start of the 128-byte block: a line is fetched once, by one batch
-#pragma unroll
-            for (int d = 0; d < YD_TRACE_DEPTH; d++) { const int sl = rr0 - d < 0 ? 0 : rr0 - d; dTU[d] = myRec[sl * 4 + (second ? 0 : 2)]; dM[d] = myRec[sl * 4 + 1]; }
-            int took = 0, op = 0;
+            // The straight run of this block, all rows at once: bit d of `diag` = the cell d rows up in this column took the diagonal (notT and notU), bit d of `mis` =
+            // it is a mismatch.  The run's length is the number of trailing ones of diag below lim; its ops are the groups of equal bits of mis.  (Row by row this was
+            // ~25 instructions a row with a branch each; a run of eight rows is the common case: reads differ from the reference every sixty bases.)
+            uint32_t diag = 0u, mis = 0u;
 #pragma unroll
             for (int d = 0; d < YD_TRACE_DEPTH; d++) {
-                if (d >= lim) break;
-                const uint32_t notT = (dTU[d] >> sT) & 1u, notU = (dTU[d] >> sU) & 1u, mmb = (dM[d] >> sM) & 1u;
-                op = notU == 0u ? OP_I : (notT == 0u ? OP_D : (mmb ? OP_R : OP_M));
-                if (op >= OP_D || y <= 0) break;
-                if (prev != op) { if (prev >= 0) flush(); prev = op; acc = 1; } else acc++;
-                y--; took++;
-                if (took < lim) { u.cp -= 4; u.w -= 4; u.fb -= u.rr == 0 ? 1u : 0u; u.rr = u.rr == 0 ? 7 : u.rr - 1; }   // inside the chunk: no look-up
+                const int sl = rr0 - d < 0 ? 0 : rr0 - d;
+                const uint32_t tu = myRec[sl * 4 + (second ? 0 : 2)], mw = myRec[sl * 4 + 1];
+                diag |= (((tu >> sT) & (tu >> sU)) & 1u) << d; mis |= ((mw >> sM) & 1u) << d;
+            }
+            const uint32_t inLim = (1u << lim) - 1u;
+            const int took = __builtin_ctz(~diag | ~inLim);                  // rows of the run (0 .. lim)
+            int op = 0;
+            if (took < lim) { const int sl = rr0 - took; const uint32_t tu = myRec[sl * 4 + (second ? 0 : 2)]; op = ((tu >> sU) & 1u) == 0u ? OP_I : OP_D; }      // what stops the run: a gap op (the row is inside the block: took < lim <= rr0 + 1)
+            y -= took;
+            if (took > 0) {                                                   // the cursor moves up took rows inside the block (the step out of it is stepUp's); before the
+                const int mv = took < lim ? took : took - 1;                  // ops are staged: every row of the run has been decoded, its records are free
+                u.cp -= 4 * mv; u.w -= 4 * mv; u.rr -= mv;
+            }
+            {
+                const uint32_t m = mis & ((1u << took) - 1u); int pos = 0;
+                while (pos < took) {
+                    const uint32_t cur = (m >> pos) & 1u;
+                    const uint32_t same = (cur ? ~m : m) >> pos;              // zeros where the following rows have the same bit
+                    const int g = __builtin_ctz(same | (1u << (took - pos)));
+                    const int code = cur ? OP_R : OP_M;
+                    if (prev != code) { if (prev >= 0) flush(); prev = code; acc = g; } else acc += g;
+                    pos += g;
+                }
             }
             if (took == lim) { if (y > 0) stepUp(u); else u.w = row0w; continue; }
             if (op == OP_D) {                                                    // deletion run: the continue bits along the row, leftwards (the row's low half is one record up)
