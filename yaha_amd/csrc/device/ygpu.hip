@@ -839,8 +839,11 @@ static void uploadFromHost(int device, const ImagePlan &plan, ImageState &me, in
     auto work = [&]() {
         if (hipSetDevice(device) != hipSuccess) { me.failed = 1; return; }
         hipStream_t st; if (hipStreamCreate(&st) != hipSuccess) { me.failed = 1; return; }
-        char *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2]; bool used[2] = {false, false}; size_t pend[2] = {0, 0}; size_t maxPiece = 0; for (auto &q : plan.pieces) maxPiece = std::max(maxPiece, q.bytes);
-        if (staged) for (int k = 0; k < 2; k++) if (hipHostMalloc((void **)&buf[k], maxPiece, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { me.failed = 1; }
+        char *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; size_t pend[2] = {0, 0}; size_t maxPiece = 0; for (auto &q : plan.pieces) maxPiece = std::max(maxPiece, q.bytes);
+        if (staged) for (int k = 0; k < 2; k++) {
+            if (hipHostMalloc((void **)&buf[k], maxPiece, hipHostMallocDefault) != hipSuccess) { buf[k] = nullptr; me.failed = 1; }
+            if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { ev[k] = nullptr; me.failed = 1; }
+        }
         for (int k = 0; !me.failed; k ^= 1) {
             const size_t i = next.fetch_add(1); if (i >= plan.pieces.size()) break;
             const ImagePiece &q = plan.pieces[i]; char *d = me.dst[q.part] + q.off; const char *sp = plan.src[q.part] + q.off;
@@ -850,7 +853,7 @@ static void uploadFromHost(int device, const ImagePlan &plan, ImageState &me, in
             if (hipMemcpyAsync(d, buf[k], q.bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { me.failed = 1; break; }
             used[k] = true; pend[k] = i;
         }
-        if (staged) { if (hipStreamSynchronize(st) != hipSuccess) me.failed = 1; for (int k = 0; k < 2; k++) { if (used[k] && !me.failed) me.done[pend[k]].store(1, std::memory_order_release); if (buf[k]) { (void)hipHostFree(buf[k]); (void)hipEventDestroy(ev[k]); } } }
+        if (staged) { if (hipStreamSynchronize(st) != hipSuccess) me.failed = 1; for (int k = 0; k < 2; k++) { if (used[k] && !me.failed) me.done[pend[k]].store(1, std::memory_order_release); if (buf[k]) (void)hipHostFree(buf[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); } }
         (void)hipStreamDestroy(st);
     };
     std::vector<std::thread> th; for (int t = 1; t < nt; t++) th.emplace_back(work);
