@@ -52,6 +52,23 @@ def test_two_images_on_one_device_the_second_copied_from_the_first(work, index11
                 c.close()
 
 
+def test_context_memory_accounting(work, index11):
+    """ygpu_memory: the device's free and total bytes, and what a context's own buffers hold -- the shared index image counts for the context that owns it."""
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
+        b = s.next_batch(120)
+        ctxs = ya.Context.on_devices(s.index, s.params, [0], ctx_per_device=2)
+        try:
+            f0, t0, own0 = ctxs[0].memory(); _f, _t, clone0 = ctxs[1].memory()
+            image = s.index.n_base_bytes + 4 * s.index.totalMatches + 4 * (4 ** s.index.wordLen + 1)
+            assert 0 < f0 < t0 and own0 >= image and clone0 < own0 - image + (1 << 20)
+            _golden_batch_equals_oracle(s, b, ctxs)
+            f1, _t1, own1 = ctxs[0].memory(); _f2, _t2, clone1 = ctxs[1].memory()
+            assert own1 > own0 and clone1 > clone0 and f1 < f0                 # the arenas of a first batch
+        finally:
+            for c in reversed(ctxs):
+                c.close()
+
+
 def test_three_images_chain_and_the_host_fall_back(work, index11, monkeypatch):
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
         b = s.next_batch(120)
