@@ -42,6 +42,10 @@ rows = load(sys.argv[1])
 rk = [(s, e) for s, e, n in rows if n.startswith("k_ext_rows_pk<false>")]
 nlast = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 t0, t1 = rk[-nlast][0], rk[-1][1]               # the timed steps (bench.py warms the contexts up one after the other: no overlap there)
+if len(sys.argv) > 4:                            # a window by kernel name instead: from the first to the last launch of kernels whose name contains argv[4] (e.g. k_oqc: the post-filter leg)
+    sel = [(s, e) for s, e, n in rows if sys.argv[4] in n]
+    t0, t1 = sel[0][0], sel[-1][1]
+    rk = [x for x in rk if x[0] >= t0 and x[1] <= t1]
 win = [(max(s, t0), min(e, t1), n) for s, e, n in rows if e > t0 and s < t1]
 span = t1 - t0
 busy = union([(s, e) for s, e, n in win]); rowsM = merge([(s, e) for s, e, n in win if n.startswith("k_ext_rows_pk")]); rowsBusy = sum(e - s for s, e in rowsM)
