@@ -17,6 +17,12 @@
 #define YD_PRIO 3
 #endif
 #define YD_HIGH_PRIO() __builtin_amdgcn_s_setprio(YD_PRIO)
+// Stores of data that the storing kernel never reads again and that no kernel reads soon (trace records, sorted keys, ...): non-temporal, so that they do not push
+// out of L2 what the kernel does come back to.  k_ext_rows_pk's 20.5 GB of trace records a launch evicted the sectors of its lanes' query / reference streams
+// between two of their dword refills: 25.5 GB fetched for 2.2 GB of input, 15.2 GB with the records stored non-temporally (round 4, profiles/r04_nt_stores.txt).
+#define YD_STORE_NT(ptr, val) __builtin_nontemporal_store((val), (ptr))
+// (Only there: the same on the sorted keys, k_expand_hits' keys and the traceback's staged ops made a step 7 ms slower -- partial lines written non-temporally do not
+// combine in L2, k_ext_trace_pk wrote 6.96 GB instead of 4.47.)
 
 enum { stReversed = 0x01, stAligned = 0x04, stScored = 0x08, stSplit = 0x10 };   // FragsClumps.inl:235-240
 enum { OP_M = 0, OP_R = 1, OP_D = 2, OP_I = 3 };

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
                 const int o = g * 8 + (ln >> 3);
                 const uint32_t *src = &sBlk[(wv * 64 + o) * YD_LDS_STRIDE + piece * 4];
                 yd_u32x4 v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-                if ((f >> o) & 1ull) *(YD_GLOBAL yd_u32x4 *)(slot + o * YD_LANE_DWORDS + piece * 4) = v;
+                if ((f >> o) & 1ull) YD_STORE_NT((YD_GLOBAL yd_u32x4 *)(slot + o * YD_LANE_DWORDS + piece * 4), v);      // (non-temporal: see common.h)
             }
         }
     };
