@@ -50,6 +50,7 @@ enum { XP_STRAND = 1, XP_REV = 2, XP_VALID = 4 };
 // opsOff = the flush index of its first block as k_ext_rows leaves it.  After k_ext_trace (where, opsOff) = high and low word of the op list's place:
 // a signed dword offset from the trace arena's base (the list stays where the walk staged it unless it straddles two chunks; then it is in the ops arena).
 struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, where, rows, cells; };
+static_assert(sizeof(ExtProb) == 16 && sizeof(ExtRes) == 32, "k_ext_rows_pk moves these as 16-byte vectors (non-temporal loads / stores)");
 __device__ __forceinline__ const uint32_t *extOpsPtr(const uint32_t *traceBase, const ExtRes &r) { return traceBase + (long long)(((unsigned long long)r.where << 32) | (unsigned long long)r.opsOff); }
 
 struct ExtArgs {

@@ -168,9 +168,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
                 poolCount = (int)min(64u, A.nProb - base); poolNext = 0;
                 eLens = 0; bool isCall = false;
                 if (lane < poolCount) {
-                    const unsigned np = A.order ? A.order[base + (unsigned)lane] : base + (unsigned)lane;
+                    const unsigned np = A.order ? __builtin_nontemporal_load(toGlobal(&A.order[base + (unsigned)lane])) : base + (unsigned)lane;
                     ePidx = np;
-                    const ExtProb pr = A.probs[np];
+                    ExtProb pr; { const yd_u32x4 v = __builtin_nontemporal_load((YD_GLOBAL const yd_u32x4 *)toGlobal(&A.probs[np])); pr.qBase = v.x; pr.rOff = v.y; pr.qOff = (uint16_t)(v.z & 0xFFFFu); pr.qLen = (uint16_t)(v.z >> 16); pr.flags = v.w; }
                     int ql = 0; uint32_t rl = 0; const bool rv_ = (pr.flags & XP_REV) != 0;
                     if (pr.flags & XP_VALID) {                              // findAGSExtension, SW.cpp:479-516
                         isCall = true;
@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
             for (int k = YD_NP - 1; k >= 0; k--) { const int v = maxSide ? (int)(short)(SV[k] >> 16) : (int)(short)(SV[k] & 0xFFFFu); if (v == maxScore) maxj = k + (maxSide ? YD_NP : 0); }
             ExtRes r; r.score = maxScore > 0 ? maxScore : 0; r.maxi = maxi; r.maxj = maxj; r.opsOff = pStart >> 4; r.nOps = 0;
             r.where = (pStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = rowF; r.cells = nCells;
-            A.res[pendRes] = r; pendRes = -1;
+            // (the result, like the trace blocks, is stored non-temporally, and the pool's problem records are loaded so: neither comes back to this kernel's L2)
+            { const yd_u32x4 lo = {(uint32_t)r.score, (uint32_t)r.maxi, (uint32_t)r.maxj, r.opsOff}, hi = {r.nOps, r.where, r.rows, r.cells}; YD_GLOBAL yd_u32x4 *dst = (YD_GLOBAL yd_u32x4 *)toGlobal(&A.res[pendRes]); YD_STORE_NT(dst, lo); YD_STORE_NT(dst + 1, hi); } pendRes = -1;
         }
         flushBlocks(flushNow, flushSlot);
         if (last) break;
