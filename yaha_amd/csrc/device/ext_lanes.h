@@ -55,6 +55,7 @@ __device__ __forceinline__ const uint32_t *extOpsPtr(const uint32_t *traceBase, 
 
 struct ExtArgs {
     DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
+    const uint8_t *fwd4, *rev4;                 // the same codes packed two to the byte (high nibble = even offset, as the reference's bases): k_ext_rows_pk's query stream
     const ExtProb *probs; uint32_t nProb;
     const uint32_t *order;                      // problem indices in processing order (longest bound first), or nullptr
     unsigned long long *clock;                  // optional: [0] = earliest start, [1] = latest end of the launch in wall_clock64() ticks (100 MHz)

@@ -78,16 +78,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
     uint32_t SV[YD_NP]; int maxSide = 0;                                    // the strip of the iteration that set the maximum (the column is found when the problem ends)
 #pragma unroll
     for (int k = 0; k < YD_NP; k++) SV[k] = 0;
-    // The two input streams -- a query code and a reference nibble per iteration -- come through per-lane WINDOWS: 64-bit shift registers of the next codes /
-    // nibbles in the order the lane consumes them (low end first), refilled with whole aligned dwords: 4 codes every 4th iteration, 8 nibbles every 8th (the
-    // iterations are the wave's: (wslot & 3) == 0 and wslot == 0).  A byte load per lane and iteration made every lane's stream a line of its own in L1 and
-    // L2, 196-262 k lines that evict each other: 61 GB of fetches per launch for 2 GB of input.  qHave / rHave = buffered entries, qNext / rNext = index
-    // (inside the extension) of the first one not buffered; after the pool's first fill (a partial dword + a full one) the buffered end is dword-aligned, so
-    // every refill is one full dword.  Nothing outside the extension's own range is ever addressed (a dword is loaded only if it holds an entry of the range).
-    uint32_t qwLo = 0, qwHi = 0, rwLo = 0, rwHi = 0, qLd = 0, rLd = 0, rOffP = 0, qSel = 0x03020100u;
+    // The two input streams -- a query code and a reference nibble per iteration -- come through per-lane WINDOWS: 64-bit shift registers of the next sixteen
+    // entries in the order the lane consumes them (low end first), refilled with whole aligned dwords of eight entries every 8th iteration (the iterations are
+    // the wave's: wslot == 0).  Both are NIBBLE streams: the reference's packed bases, and the batch's query codes packed the same way (k_pack4; round 4 -- a
+    // byte per code was a dword refill every 4th iteration and a 64-byte sector every 64 rows; packed, a lane comes back to a sector for 128 rows, as for the
+    // reference).  A byte load per lane and iteration (rounds 1-2) made every lane's stream a line of its own in L1 and L2, 196-262 k lines that evict each other:
+    // 61 GB of fetches per launch for 2 GB of input.  qHave / rHave = buffered entries, qNext / rNext = index (inside the extension) of the first one not
+    // buffered; after the pool's first fill (a partial dword + a full one) the buffered end is dword-aligned, so every refill is one full dword.  Nothing outside
+    // the extension's own range is ever addressed (a dword is loaded only if it holds an entry of the range).
+    uint32_t qwLo = 0, qwHi = 0, rwLo = 0, rwHi = 0, qLd = 0, rLd = 0, rOffP = 0, qPos = 0;
     int qHave = 0, rHave = 0, qNext = 0, rNext = 0, rLenP = 0, qStep = 0, rLeft = 0; bool pendQ = false, pendR = false, done = false;
     bool insQ = false, insR = false;                                         // wave-uniform: the previous pass ran the query / reference refill
-    YD_GLOBAL const uint8_t *q = toGlobal(A.fwd);
+    YD_GLOBAL const uint8_t *q4 = toGlobal(A.fwd4);                          // the strand's PACKED codes (two to the byte, as the reference: k_pack4): entry idx of the extension = nibble qPos +- idx
     unsigned calls = 0, rows = 0, cells = 0;
 #pragma unroll
     for (int k = 0; k < YD_NP; k++) { PV[k] = LWp; PF[k] = LWp; rc[k] = 0x7FFF7FFFu; }
@@ -137,9 +139,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
         // the dwords the previous pass loaded go to the ends of the windows (entries in consumption order: a reverse extension's bytes, and its nibbles, swapped)
         if (insQ) {
             if (pendQ) {
-                const uint32_t v = __builtin_amdgcn_perm(0u, qLd, qSel);
-                const unsigned long long t = (unsigned long long)v << (8 * (qHave & 7));
-                qwLo |= (uint32_t)t; qwHi |= (uint32_t)(t >> 32); qHave += 4; qNext += 4;
+                const uint32_t sw = ((qLd & 0x0F0F0F0Fu) << 4) | ((qLd >> 4) & 0x0F0F0F0Fu);      // forward: the even offset (high nibble) first
+                const uint32_t v = qStep < 0 ? __builtin_amdgcn_perm(0u, qLd, 0x00010203u) : sw;   // reverse: bytes swapped, each byte's low nibble (the higher offset) first
+                const unsigned long long t = (unsigned long long)v << (4 * (qHave & 15));
+                qwLo |= (uint32_t)t; qwHi |= (uint32_t)(t >> 32); qHave += 8; qNext += 8;
             }
             insQ = false;
         }
@@ -183,8 +186,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
                     if (ql <= 0) { ExtRes r; r.score = 0; r.maxi = r.maxj = 0; r.opsOff = r.nOps = 0; r.where = 0; r.rows = r.cells = 0; A.res[np] = r; }
                     else {
                         eLens = (uint32_t)ql | (rl << 16); eROff = pr.rOff; eQ = pr.qBase + pr.qOff;
-                        YD_GLOBAL const uint8_t *qp = toGlobal((pr.flags & XP_STRAND) ? A.rev : A.fwd) + eQ;
-                        eMisc = (pr.flags & 3u) | ((uint32_t)qp[0] << 8);
+                        YD_GLOBAL const uint8_t *qb4 = toGlobal((pr.flags & XP_STRAND) ? A.rev4 : A.fwd4);
+                        { const uint32_t b0 = qb4[eQ >> 1]; eMisc = (pr.flags & 3u) | (((eQ & 1u) ? (b0 & 15u) : (b0 >> 4)) << 8); }
                         eW1 = 0; eW2 = 0;                                     // reference indices 0..10 (nibble c - leftR of the window, as in k_ext_rows)
                         for (int c = leftR; c < YD_LW; c++) {
                             const int idx = c - leftR; uint32_t nib = 15u;
@@ -195,13 +198,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
                         // first fill of the stream windows: query codes from index 1 (index 0 is in eMisc), reference nibbles from index 11 (0..10 are in eW1/eW2);
                         // a partial aligned dword, then a full one -- each only if it holds an entry of the extension
                         uint32_t qh = 0, rh = 0; eQwLo = eQwHi = eRwLo = eRwHi = 0;
-                        {
-                            const size_t a1 = (size_t)(qp + (rv_ ? -1 : 1)); const uint32_t lo2 = (uint32_t)(a1 & 3u), c1 = rv_ ? lo2 + 1u : 4u - lo2;
-                            YD_GLOBAL const uint32_t *d1 = (YD_GLOBAL const uint32_t *)(a1 - lo2);
+                        {   // query codes from index 1, out of the packed array: the reference's nibble logic below with 1 for 11
+                            const uint32_t n1 = rv_ ? eQ - 1u : eQ + 1u, lo3 = n1 & 7u, c1 = rv_ ? lo3 + 1u : 8u - lo3;
                             uint32_t v1 = 0, v2 = 0;
-                            if (ql >= 2) { const uint32_t w = *d1; v1 = rv_ ? __builtin_amdgcn_perm(0u, w, 0x00010203u) >> (8u * (3u - lo2)) : w >> (8u * lo2); qh = c1; }
-                            if (ql > (int)(1u + c1)) { const uint32_t w = rv_ ? d1[-1] : d1[1]; v2 = rv_ ? __builtin_amdgcn_perm(0u, w, 0x00010203u) : w; qh = c1 + 4u; }
-                            const unsigned long long t = (unsigned long long)v1 | ((unsigned long long)v2 << (8u * c1));
+                            if (ql >= 2) {
+                                YD_GLOBAL const uint32_t *d1 = (YD_GLOBAL const uint32_t *)(qb4 + ((n1 >> 1) & ~3u));
+                                const uint32_t w = *d1;
+                                v1 = rv_ ? __builtin_amdgcn_perm(0u, w, 0x00010203u) >> (4u * (7u - lo3)) : (((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu)) >> (4u * lo3);
+                                qh = c1;
+                                if (ql > (int)(1u + c1)) { const uint32_t w2 = rv_ ? d1[-1] : d1[1]; v2 = rv_ ? __builtin_amdgcn_perm(0u, w2, 0x00010203u) : (((w2 & 0x0F0F0F0Fu) << 4) | ((w2 >> 4) & 0x0F0F0F0Fu)); qh = c1 + 8u; }
+                            }
+                            const unsigned long long t = (unsigned long long)v1 | (c1 < 16u ? ((unsigned long long)v2 << (4u * c1)) : 0ull);
                             eQwLo = (uint32_t)t; eQwHi = (uint32_t)(t >> 32);
                         }
                         {
@@ -245,7 +252,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
             if (init) {
                 p = (int)gPidx; qLen = (int)(gLens & 0xFFFFu); i = 0; maxScore = YD_LWORST; maxi = 0; carryE = LWp; rvLo = YD_LWORST;
                 const bool rev = (gMisc & XP_REV) != 0;
-                q = toGlobal((gMisc & XP_STRAND) ? A.rev : A.fwd) + gQ; qStep = rev ? -1 : 1; qSel = rev ? 0x00010203u : 0x03020100u;
+                q4 = toGlobal((gMisc & XP_STRAND) ? A.rev4 : A.fwd4); qPos = gQ; qStep = rev ? -1 : 1;
                 qcNext = (int)((gMisc >> 8) & 0xFFu); qcPrev = 0;
                 qwLo = gQwLo; qwHi = gQwHi; qHave = (int)(gHave & 0xFFu); qNext = 1 + qHave; pendQ = false;
                 // iteration i takes reference index i + 10 from the window (valid while below rLen)
@@ -263,15 +270,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
         ++i;
         const int qc = qcNext;
         // next iteration's query code (index i) and the reference nibble that enters the window (index i + 10; 15 beyond the reference): off the windows' low ends
-        qcNext = (int)(qwLo & 0xFFu); qwLo = __builtin_amdgcn_alignbit(qwHi, qwLo, 8); qwHi >>= 8; qHave--;
+        qcNext = (int)(qwLo & 15u); qwLo = __builtin_amdgcn_alignbit(qwHi, qwLo, 4); qwHi >>= 4; qHave--;
         { rLeft--; nbNext = rLeft > 0 ? (rwLo & 15u) : 15u; rwLo = __builtin_amdgcn_alignbit(rwHi, rwLo, 4); rwHi >>= 4; rHave--; }
         // refills (wave-uniform schedule): the loads are consumed at the top of the next pass
-        if ((wslot & 3) == 0) {
-            pendQ = qHave <= 4 && qNext < qLen;
-            if (pendQ) { const int k = qStep < 0 ? -qNext - 3 : qNext; qLd = *(YD_GLOBAL const uint32_t *)(q + k); }      // (q + qNext * qStep is dword-aligned going up, the last byte of a dword going down)
-            insQ = true;
-        }
         if (wslot == 0) {
+            pendQ = qHave <= 8 && qNext < qLen;
+            if (pendQ) { const uint32_t n = qStep < 0 ? qPos - (uint32_t)qNext - 7u : qPos + (uint32_t)qNext; qLd = *(YD_GLOBAL const uint32_t *)(q4 + (n >> 1)); }      // (nibble qPos + qNext * qStep is dword-aligned going up, the last nibble of a dword going down)
+            insQ = true;
             pendR = rHave <= 8 && rNext < rLenP;
             if (pendR) { const uint32_t n = qStep < 0 ? rOffP - (uint32_t)rNext - 7u : rOffP + (uint32_t)rNext; rLd = *(YD_GLOBAL const uint32_t *)(gBases + (n >> 1)); }
             insR = true;

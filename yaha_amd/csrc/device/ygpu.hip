@@ -76,7 +76,7 @@ struct ygpu_ctx {
     // batch
     uint32_t nReads = 0; int maxQ = 0; uint64_t totalBases = 0; uint32_t nKmers = 0;
     std::vector<uint32_t> hReadOff, hKmerOff;
-    DevBuf dFwd, dRev, dReadOff, dKmerOff;
+    DevBuf dFwd, dRev, dFwd4, dRev4, dReadOff, dKmerOff;
     // arenas
     DevBuf bigB, bigE;
     DevBuf posS, posC, posRsI, hitOff, expandStart, keysA, keysB, segOff, isHead, tileState, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
@@ -440,7 +440,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     // What a launch will need is not known before it ran (an X-drop run stops where it stops); the arena is sized from the bound scaled by the ratio
     // the last batches showed (ctx->traceRatio; the first batch guesses from the mean bound) and the stage is redone with a larger one when it overflows.
     // When even the budget (this context's share of the free memory) is not enough, the roots are cut into ranges that use the arena one after the other.
-    ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>();
+    ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>(); E.fwd4 = ctx->dFwd4.as<uint8_t>(); E.rev4 = ctx->dRev4.as<uint8_t>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
     const bool pk = extRowsPacked(ctx, caps); ctx->rowsPacked = pk;
     auto rowsKernel = pk ? k_ext_rows_pk<false> : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
@@ -1018,7 +1018,7 @@ int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
 }  // extern "C"
 static std::vector<DevBuf *> allBuffers(ygpu_ctx *ctx)
 {
-    DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->tileState,
+    DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dFwd4, &ctx->dRev4, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->tileState,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
                          &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
@@ -1077,12 +1077,16 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
     }
     ctx->hKmerOff[2 * n] = k; ctx->nKmers = k; ctx->totalBases = n ? b->offsets[n] - base0 : 0;
     if (ctx->totalBases > 0x7FFFFFF0ull) { ctx->err = "batch larger than 2 Gbases"; return YGPU_EINVAL; }
-    ENSURE(ctx->dFwd, ctx->totalBases + 256); ENSURE(ctx->dRev, ctx->totalBases + 256);   /* slack: lane kernels read whole dwords around a segment */ ENSURE(ctx->dReadOff, 4ull * (n + 1)); ENSURE(ctx->dKmerOff, 4ull * (2 * n + 1));
+    ENSURE(ctx->dFwd, ctx->totalBases + 256); ENSURE(ctx->dRev, ctx->totalBases + 256); ENSURE(ctx->dFwd4, ctx->totalBases / 2 + 256); ENSURE(ctx->dRev4, ctx->totalBases / 2 + 256);   /* slack: lane kernels read whole dwords around a segment */ ENSURE(ctx->dReadOff, 4ull * (n + 1)); ENSURE(ctx->dKmerOff, 4ull * (2 * n + 1));
     if (n) {
         HIPCHK(hipMemcpyAsync(ctx->dFwd.p, b->codes + base0, ctx->totalBases, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->dReadOff.p, ctx->hReadOff.data(), 4ull * (n + 1), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->dKmerOff.p, ctx->hKmerOff.data(), 4ull * (2 * n + 1), hipMemcpyHostToDevice, ctx->stream));
         KL(k_revcomp, dim3(n), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->dReadOff.as<uint32_t>(), n);
+        // (both strands packed two codes to the byte for the X-drop kernel's query windows; the byte arrays have 256 bytes of slack behind the last code)
+        const uint32_t nPacked = (uint32_t)((ctx->totalBases + 1) / 2);
+        KL(k_pack4, dim3(gridFor(nPacked, 256)), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dFwd4.as<uint8_t>(), nPacked);
+        KL(k_pack4, dim3(gridFor(nPacked, 256)), dim3(256), 0, ctx->stream, ctx->dRev.as<uint8_t>(), ctx->dRev4.as<uint8_t>(), nPacked);
     }
     HIPCHK(streamSync(ctx));
     return 0;
@@ -1409,7 +1413,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         const uint32_t maxCh = (uint32_t)nCh;
         ENSURE(ctx->extTrace, nCh * (YD_CHUNK_DWORDS * 4ull) + 256); ENSURE(ctx->waveChunks, 4ull * (size_t)wavesK * maxCh + 64); ENSURE(ctx->extOps, 4ull * opsBound + 64); ENSURE(ctx->traceCnt, 64);
         HIPCHK(hipMemsetAsync(ctx->traceCnt.p, 0, 64, ctx->stream));
-        ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>(); E.probs = ctx->extProbs.as<ExtProb>(); E.nProb = nX;
+        ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>(); E.fwd4 = ctx->dFwd4.as<uint8_t>(); E.rev4 = ctx->dRev4.as<uint8_t>(); E.probs = ctx->extProbs.as<ExtProb>(); E.nProb = nX;
         E.order = nullptr; E.clock = nullptr; E.trace = ctx->extTrace.as<uint32_t>(); E.nChunks = (uint32_t)nCh; E.chunkCount = ctx->traceCnt.as<unsigned int>(); E.waveChunks = ctx->waveChunks.as<uint32_t>(); E.maxCh = maxCh;
         E.ops = ctx->extOps.as<uint32_t>(); E.opsCount = ctx->traceCnt.as<unsigned int>() + 1; E.opsCap = (uint32_t)opsBound; E.res = ctx->extRes.as<ExtRes>();
         E.queue = ctx->chunkCnt.as<unsigned int>(); E.ctr = nullptr; E.errFlag = ctx->errFlag.as<int>(); E.dbgMode = 0;
