@@ -464,7 +464,7 @@ def main():
     if rows_ms > 0:
         packed = stage_ms.get("ext_rows_packed16", 0.0) > 0       # a flag among the timings: the packed 16-bit kernel ran (16-byte trace records instead of 12-byte rows)
         kname, kernel_ms = "k_ext_rows", (rows_dev_ms if rows_dev_ms > 0 else rows_ms)
-        stream_bytes = (17.5 if packed else 13.5) * counters["dp_ext_rows"] + 48.0 * counters["dp_ext_calls"]     # what the kernel itself streams: per row 1 query code + 1/2 B reference + 16 (12) B of trace cells; 48 B per problem
+        stream_bytes = (17.0 if packed else 13.5) * counters["dp_ext_rows"] + 48.0 * counters["dp_ext_calls"]     # what the kernel itself streams: per row a query code (1/2 B packed in the 16-bit kernel, 1 B in the 32-bit one) + 1/2 B reference + 16 (12) B of trace cells; 48 B per problem
     else:                                                    # other band widths run the wave-per-root kernel
         packed = False
         kname, kernel_ms, stream_bytes = "k_align", align_ms, None
