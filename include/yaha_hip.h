@@ -132,6 +132,10 @@ const char *ygpu_last_error(const ygpu_ctx *ctx);
 /* Device memory as the context sees it: free and total bytes of its device, and the bytes its own buffers hold (arenas grow with the first batches; the
  * reference's per-thread QueryState grows the same way, Query.c:81-100, 313).  A batching host uses it to decide how many contexts a device can carry. */
 int  ygpu_memory(ygpu_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes, uint64_t *ctx_bytes);
+/* A context the batching host leaves out (its device has no room for another set of arenas): releases the context's own buffers and takes it out of the count of
+ * contexts that share the device's memory budget, so that the contexts that do run are not held to a share sized for it.  The reference has no counterpart -- a
+ * thread of Query.c:642-690 that cannot allocate its QueryState is fatal (FragsClumps.c:74).  The context can only be destroyed afterwards. */
+int  ygpu_park(ygpu_ctx *ctx);
 
 /* Stage reads into HBM (H2D).  Separate from ygpu_run so that a benchmark can time the hot path with inputs
  * already resident. */

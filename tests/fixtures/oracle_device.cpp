@@ -39,9 +39,12 @@ void ygpu_destroy(ygpu_ctx *c) { if (!c) return; if (c->have) yoracle_free_resul
 int ygpu_memory(ygpu_ctx *, uint64_t *f, uint64_t *t, uint64_t *m)
 {
     const char *fg = getenv("YTEST_FREE_GB"), *cg = getenv("YTEST_CTX_GB");
+    if (const char *ms = getenv("YTEST_MEMORY_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(ms)));      // (a real hipSetDevice + hipMemGetInfo takes its time: the race of ADVICE r04 needed that)
     if (f) *f = fg ? (uint64_t)atoll(fg) << 30 : 1ull << 40; if (t) *t = 1ull << 40; if (m) *m = cg ? (uint64_t)atoll(cg) << 30 : 0;
     return 0;
 }
+static std::atomic<int> gParked(0);
+int ygpu_park(ygpu_ctx *) { gParked++; return 0; }
 const char *ygpu_last_error(const ygpu_ctx *c) { return c ? c->err.c_str() : "no context"; }
 int ygpu_upload(ygpu_ctx *c, const ygpu_read_batch *b)
 {

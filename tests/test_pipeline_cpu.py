@@ -108,6 +108,20 @@ def test_contexts_without_room_for_their_arenas_are_left_out(exes, work, index11
     assert strip_pg(p.stdout.decode()) == golden_lines("rchim_default")
 
 
+@pytest.mark.parametrize("batch", ["100", "200", "500"])
+def test_left_out_contexts_never_hold_a_batch(exes, work, index11, batch):
+    """As many batches as contexts or fewer, and a ygpu_memory call that takes its time (a real hipSetDevice + hipMemGetInfo does): round 4's pipeline let a context
+    take a batch, found no room, and pushed the batch back into a queue whose other consumers had already seen it empty and left -- a truncated SAM with exit
+    code 0.  A context now decides before it takes a batch, and the run fails loudly if a batch is ever lost between two stages."""
+    for _ in range(3):
+        p = _run(exes["tsan"], ["-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", "stdout", "-batch", batch, "-ctx", "3"],
+                 env={"YTEST_FREE_GB": "50", "YTEST_CTX_GB": "60", "YTEST_MEMORY_MS": "5", "YAHA_STATS": "1"})
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        _clean(p)
+        assert strip_pg(p.stdout.decode()) == golden_lines("rchim_default")
+        assert '"ctx_left_out": 2' in p.stderr.decode()
+
+
 def test_no_such_device(exes, work, index11):
     p = _run(exes["asan"], ["-x", index11, "-q", os.path.join(work, "r1k.fa"), "-osh", "stdout", "-gpus", "2"], env={"YTEST_DEVICES": "1"})
     _clean(p)

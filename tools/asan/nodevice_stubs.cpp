@@ -10,6 +10,7 @@ int  ygpu_init_multi(const int *, int n, int cpd, const ygpu_index_view *, const
 int  ygpu_clone(const ygpu_ctx *, ygpu_ctx **out) { if (out) *out = nullptr; return YGPU_ENODEV; }
 void ygpu_destroy(ygpu_ctx *) {}
 int  ygpu_memory(ygpu_ctx *, uint64_t *, uint64_t *, uint64_t *) { return YGPU_ENODEV; }
+int  ygpu_park(ygpu_ctx *) { return YGPU_ENODEV; }
 const char *ygpu_last_error(const ygpu_ctx *) { return "sanitizer build of the host stages: no device code linked"; }
 int  ygpu_upload(ygpu_ctx *, const ygpu_read_batch *) { return YGPU_ENODEV; }
 int  ygpu_run(ygpu_ctx *) { return YGPU_ENODEV; }

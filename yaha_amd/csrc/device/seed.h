@@ -19,11 +19,12 @@ __global__ void k_revcomp(const uint8_t *fwd, uint8_t *rev, const uint32_t *read
 
 // the batch's codes packed two to the byte (high nibble = the even offset, as .nib2 packs the reference): what k_ext_rows_pk's query windows are refilled from -- a dword
 // then holds eight codes, like a dword of reference bases, and a lane comes back to a 64-byte sector for 128 rows instead of 64
-__global__ void k_pack4(const uint8_t *codes, uint8_t *packed, uint32_t nBytesOut)
+__global__ void k_pack4(const uint8_t *codes, uint8_t *packed, uint32_t nBytesOut, uint32_t nCodes)
 {
     YD_HIGH_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nBytesOut) packed[i] = (uint8_t)(((codes[2u * i] & 15u) << 4) | (codes[2u * i + 1u] & 15u));
+    // (an odd number of codes: the last byte's low nibble has no code -- 15, never the slack byte behind the codes, which nobody wrote)
+    if (i < nBytesOut) packed[i] = (uint8_t)(((codes[2u * i] & 15u) << 4) | (2u * i + 1u < nCodes ? (codes[2u * i + 1u] & 15u) : 15u));
 }
 
 // Once per index: a bit per k-mer (its low 22 bits: exact up to -L 11, a filter above) that has a reference offset below 2^15 anywhere in its list -- the only

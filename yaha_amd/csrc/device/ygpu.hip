@@ -83,7 +83,7 @@ struct ygpu_ctx {
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
-    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; int runsDone = 0; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
+    bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; bool parked = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; int runsDone = 0; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // post-filter stage (oqc_stage.h)
     DevBuf oqProf, oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
     bool oqSet = false, oqDone = false; yoqc::Params oqP{}; yoqc::Seqs oqG{}; uint32_t nFOut = 0, nFOps = 0;
@@ -706,7 +706,7 @@ static int stageAlign(ygpu_ctx *ctx)
         unsigned waves = (unsigned)std::min<uint64_t>(std::min<uint64_t>(NC, (uint64_t)ctx->nCU * wavesPerCU), maxWaves);      // 3 waves per SIMD (137 VGPRs)
         // (with the lane kernels doing the bulk the wave kernels see the roots those hand back -- none on ordinary batches -- and the gap fills beyond the lane kernels'
         // limits: their scratch, ~1 KB per query base and wave, is held to 3 GB -- 10 kbp reads took 10.7 GB a context for 1 024 waves that had nothing to do)
-        if (useLanes && per * waves > (3ull << 30)) waves = (unsigned)std::max<uint64_t>(64, (3ull << 30) / per);
+        if (useLanes && per * waves > (3ull << 30)) waves = (unsigned)std::min<uint64_t>(waves, std::max<uint64_t>(64, (3ull << 30) / per));      // (the cap only ever lowers the count)
         ENSURE(ctx->scratchAlign, per * waves);
         ENSURE(ctx->clumpFrags0, 16ull * (ctx->nClumpFrags + 1));
         HIPCHK(hipMemcpyAsync(ctx->clumpFrags0.p, ctx->clumpFrags.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
@@ -743,7 +743,7 @@ static int stageAlign(ygpu_ctx *ctx)
             else { rc = fetchU32(ctx, cnt + CNT_OUTCLUMPS, got, 2); if (rc) return rc; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc; }
             if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
             if (kStats) fprintf(stderr, "[ygpu] ctx %p: align attempt %d repeated (%s); trace ratio %.3f, ops ratio %.4f\n", (void *)ctx, attempt + 1, traceOverflow ? "trace / extension-op arena" : (laneOverflow ? "phase-1 arenas (state ops, gap ops)" : "output arenas"), ctx->traceRatio, ctx->opsRatio);
-            if (ef != YERR_OUT || attempt >= 12) { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
+            if (ef != YERR_OUT || attempt >= 24)      /* the trace estimate grows by half a time: 1.5^20 covers the floor-to-cap range */ { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
             if (!traceOverflow) {                                            // (a full trace arena has grown its own estimate)
                 outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
                 gapOpsPerJoint *= 2; stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap);
@@ -1056,11 +1056,24 @@ int ygpu_memory(ygpu_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes, uint
     if (free_bytes) *free_bytes = fb; if (total_bytes) *total_bytes = tb; if (ctx_bytes) *ctx_bytes = mine;
     return 0;
 }
+/* A context the host decides not to use (no room for its arenas beside the others): its own buffers are released and it no longer counts among the contexts that
+ * share the device's memory budget (the trace arena's fair share, the wave kernels' scratch).  The index image stays (other contexts may share it); the context
+ * can only be destroyed afterwards. */
+int ygpu_park(ygpu_ctx *ctx)
+{
+    if (!ctx || !ctx->stream) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device)); HIPCHK(streamSync(ctx));
+    for (DevBuf *b : allBuffers(ctx)) if (b != &ctx->dBases && b != &ctx->dSO && b != &ctx->dROA && b != &ctx->dLow) b->release();
+    if (ctx->counted) { gCtxPerDevice[ctx->device & 63]--; ctx->counted = false; }
+    ctx->stageDone = 0; ctx->parked = true;
+    return 0;
+}
 const char *ygpu_last_error(const ygpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
 {
     if (!ctx || !ctx->stream || !b) return YGPU_EINVAL;
+    if (ctx->parked) { ctx->err = "the context was parked (ygpu_park)"; return YGPU_EINVAL; }
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = b->n_reads;
     if (n > 65536) { ctx->err = "at most 65536 reads per batch"; return YGPU_EINVAL; }
@@ -1085,8 +1098,8 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
         KL(k_revcomp, dim3(n), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dRev.as<uint8_t>(), ctx->dReadOff.as<uint32_t>(), n);
         // (both strands packed two codes to the byte for the X-drop kernel's query windows; the byte arrays have 256 bytes of slack behind the last code)
         const uint32_t nPacked = (uint32_t)((ctx->totalBases + 1) / 2);
-        KL(k_pack4, dim3(gridFor(nPacked, 256)), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dFwd4.as<uint8_t>(), nPacked);
-        KL(k_pack4, dim3(gridFor(nPacked, 256)), dim3(256), 0, ctx->stream, ctx->dRev.as<uint8_t>(), ctx->dRev4.as<uint8_t>(), nPacked);
+        KL(k_pack4, dim3(gridFor(nPacked, 256)), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dFwd4.as<uint8_t>(), nPacked, (uint32_t)ctx->totalBases);
+        KL(k_pack4, dim3(gridFor(nPacked, 256)), dim3(256), 0, ctx->stream, ctx->dRev.as<uint8_t>(), ctx->dRev4.as<uint8_t>(), nPacked, (uint32_t)ctx->totalBases);
     }
     HIPCHK(streamSync(ctx));
     return 0;

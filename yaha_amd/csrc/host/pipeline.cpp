@@ -239,7 +239,7 @@ int runQueries(Args &a, FILE *log)
     // behind a small CPU quota the parsers are what must not run short -- one for every two devices)
     const int nParse = std::max(1, std::min(8, std::min(std::max((cpus + 7) / 10, (nDev + 1) / 2), std::max(1, cpus / 3)))), nFmt = A.numThreads > 1 ? A.numThreads : std::max(1, cpus - nParse - 2);
     StageQueue<BatchP> parseQ((size_t)nParse + 2, 1), inQ((size_t)ngpu + 2, nParse), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu + nParse), outQ((size_t)nFmt + 4, nFmt);
-    std::atomic<bool> stop(false); std::atomic<int> rcAll(0);
+    std::atomic<bool> stop(false); std::atomic<int> rcAll(0); std::atomic<uint64_t> ticketsIssued(0), ticketsWritten(0);
     auto fail = [&](const char *what) { if (!stop.exchange(true)) fprintf(log, "%s -- stopping; the output ends with the last batch completed before this one.\n", what); rcAll = 1; };
     // batches follow the read length: about 16 M bases each (16 384 reads of 1 kbp, 1 600 of 10 kbp, 65 536 of 100 bp), unless -batch gives a read count
     const size_t maxReads = A.batchReads > 0 ? (size_t)A.batchReads : 65536, maxBases = A.batchReads > 0 ? ~(size_t)0 : ((size_t)16 << 20);
@@ -248,7 +248,7 @@ int runQueries(Args &a, FILE *log)
         while (!stop) {
             BatchP b = pool.get();
             if (S->reader.split.nextSpans(maxReads, maxBases, b->spans) == 0) break;
-            b->ticket = ticket++;
+            b->ticket = ticket++; ticketsIssued = ticket;
             parseQ.push(std::move(b));
         }
         parseQ.producerDone();
@@ -286,7 +286,7 @@ int runQueries(Args &a, FILE *log)
     ygpu_postfilter_params PF; memset(&PF, 0, sizeof PF);
     PF.minNonOverlap = oqP.minNonOverlap; PF.BPCost = oqP.BPCost; PF.maxBPLog = oqP.maxBPLog; PF.FBS = oqP.FBS; PF.FBS_PSLength = oqP.FBS_PSLength; PF.FBS_PSScore = oqP.FBS_PSScore;
     PF.bppVmin = oqP.bppVmin; PF.bppN = std::max(0, oqP.bppN); PF.bppThr = oqThr.data(); PF.n_seqs = (uint32_t)oqSeqStart.size(); PF.seq_start = oqSeqStart.data(); PF.seq_length = oqSeqLen.data();
-    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; uint64_t footprint = 0; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
+    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; uint64_t footprint = 0; bool claimed = false, measured = false; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
     std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < nDev; k++) warm.emplace_back(new Warm);
     std::atomic<int> ctxUp(0), parked(0); double tCtxUp = 0;
     std::vector<std::atomic<uint64_t>> devReads(nDev); for (auto &x : devReads) x = 0;       // reads each device took (the stats line: do all devices pull their weight?)
@@ -304,15 +304,36 @@ int runQueries(Args &a, FILE *log)
         if (rc != 0) for (int k = 0; k < nDev; k++) { ygpu_ctx *c = ctx[k * perDev]; if (leadRc[k] != 0 && c && strncmp(ygpu_last_error(c), "not started", 11) != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", devs[k], leadRc[k], ygpu_last_error(c)); fail(m); break; } }
     };
     auto device = [&](int d) {
-        BatchP b; bool first = true; Warm &W = *warm[d / perDev]; const int dev = devs[d / perDev], lead = d - d % perDev;
+        BatchP b; bool first = true; Warm &W = *warm[d / perDev]; const int dev = devs[d / perDev], leadCtx = d - d % perDev;
         int rc0;
         if (d == 0) { bringUpDevices(); for (int k = 0; k < nDev; k++) { Warm &Wk = *warm[k]; { std::lock_guard<std::mutex> lk(Wk.mu); Wk.ready = leadRc[k] == 0 ? 1 : -1; } Wk.cv.notify_all(); } }
         { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : (leadRc[d / perDev] ? leadRc[d / perDev] : YGPU_ENODEV); }
-        (void)lead;
         if (rc0 == 0 && deviceFilter) rc0 = ygpu_set_postfilter(ctx[d], &PF);
-        if (rc0 != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", dev, rc0, ctx[d] ? ygpu_last_error(ctx[d]) : (d == lead ? "" : "(the device's first context failed)")); fail(m); }
+        if (rc0 != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", dev, rc0, ctx[d] ? ygpu_last_error(ctx[d]) : (d == leadCtx ? "" : "(the device's first context failed)")); fail(m); }
         if (++ctxUp == ngpu) { tCtxUp = now(); if (timing) fprintf(stderr, "[yaha] %d device contexts up (index image on %d device%s) %.1f ms after start\n", ngpu, nDev, nDev > 1 ? "s" : "", tCtxUp - tEnter); }
-        while (inQ.pop(b)) {
+        // A context's FIRST batch.  The first context of a device to get here leads: its first batch allocates its arenas, and what it then holds is the measure of what
+        // a context needs.  The others wait for that measure BEFORE they take a batch, then go one at a time: a context that would start with less free memory than 0.9
+        // of the measure is left out -- parked without ever holding a batch (round 4 took the batch first and pushed it back: a queue whose other consumers had already
+        // seen it empty and finished never delivered it, and the output ended early with exit code 0).  Its share of the device's memory budget goes back to the
+        // contexts that run (ygpu_park).
+        bool lead = false;
+        auto measured = [&]() { { std::lock_guard<std::mutex> lk(W.mu); W.measured = true; } W.cv.notify_all(); };
+        for (;;) {
+            std::unique_lock<std::mutex> one(W.first, std::defer_lock);
+            if (first) {
+                if (!lead) { std::unique_lock<std::mutex> lk(W.mu); if (!W.claimed) { W.claimed = true; lead = true; } else W.cv.wait(lk, [&] { return W.measured; }); }
+                one.lock();
+                // Does the device still have room for this context's arenas?  (~55 GB a context for 16 M bases of 1 kbp reads, ~75 GB for 10 kbp reads; squeezed into
+                // what is left, a first batch of 10 kbp reads at -ctx 3 took 1.8 s, cut into ranges, with every other context waiting behind it.)
+                if (!lead && W.footprint > 0 && rc0 == 0) {
+                    uint64_t fb = 0, tb = 0, mine = 0;
+                    if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0 && (double)fb < 0.9 * (double)W.footprint) {
+                        if (timing || stats) fprintf(stderr, "[yaha] context %d left out: %.1f GB free on device %d, the first context's arenas hold %.1f GB\n", d, fb / 1e9, dev, W.footprint / 1e9);
+                        (void)ygpu_park(ctx[d]); parked++; break;
+                    }
+                }
+            }
+            if (!inQ.pop(b)) break;
             if (stop) { b->nReads = 0; fmtQ.push(std::move(b)); continue; }
             const double t0 = now();
             ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res; memset(&res, 0, sizeof res);
@@ -336,25 +357,15 @@ int runQueries(Args &a, FILE *log)
             };
             int rc;
             if (first) {
-                std::lock_guard<std::mutex> one(W.first);
-                // Does the device still have room for this context's arenas?  What the device's first context holds after its first batch is the measure (arenas
-                // follow the batches: ~55 GB a context for 16 M bases of 1 kbp reads, ~75 GB for 10 kbp reads): a context that would start with less than 0.9 of
-                // that free is left out -- its batches go to the others -- instead of squeezing its arenas into what is left (10 kbp reads at -ctx 3: a first batch of
-                // 1.8 s, cut into ranges, with every other context waiting behind it).
-                if (W.footprint > 0) {
-                    uint64_t fb = 0, tb = 0, mine = 0;
-                    if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0 && (double)fb < 0.9 * (double)W.footprint) {
-                        if (timing || stats) fprintf(stderr, "[yaha] context %d left out: %.1f GB free on device %d, the first context's arenas hold %.1f GB\n", d, fb / 1e9, dev, W.footprint / 1e9);
-                        inQ.push(std::move(b)); parked++; break;
-                    }
-                }
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning++; }
                 rc = hotPath(); first = false;
-                if (W.footprint == 0 && rc == 0) {                           // (first batches run one at a time: the first one to finish is the measure)
+                if (lead) {                                                  // the measure: what this context holds after its first batch (without the index image)
                     uint64_t fb = 0, tb = 0, mine = 0; const uint64_t image = (uint64_t)V.n_base_bytes + 4ull * V.totalMatches + 4ull * ((1ull << (2 * V.wordLen)) + 1);
-                    if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0) W.footprint = std::max<uint64_t>(1, d == lead && mine > image ? mine - image : mine);
+                    if (rc == 0 && ygpu_memory(ctx[d], &fb, &tb, &mine) == 0) W.footprint = std::max<uint64_t>(1, d == leadCtx && mine > image ? mine - image : mine);
                 }
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning--; } W.cv.notify_all();
+                one.unlock();
+                if (lead) measured();
             } else {
                 { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.firstRunning == 0; }); }
                 rc = hotPath();
@@ -364,6 +375,7 @@ int runQueries(Args &a, FILE *log)
             b->tDev = now() - t0; devReads[d / perDev] += b->nReads;
             fmtQ.push(std::move(b));
         }
+        if (lead) measured();                                                 // (a leader that never saw a batch: the others must not wait for its measure)
         fmtQ.producerDone();
     };
     auto formatter = [&]() {
@@ -391,7 +403,7 @@ int runQueries(Args &a, FILE *log)
         while (outQ.pop(b)) {
             done[b->ticket] = std::move(b);
             while (!done.empty() && done.begin()->first == nextOut) {
-                BatchP w = std::move(done.begin()->second); done.erase(done.begin()); nextOut++;
+                BatchP w = std::move(done.begin()->second); done.erase(done.begin()); nextOut++; ticketsWritten = nextOut;
                 if (!stop) {
                     if (w->text.len && fwrite(w->text.p, 1, w->text.len, out) != w->text.len) fail("Failure writing the output file");
                     else { const double t = now(); if (nWritten == 0) { tFirstOut = t; nFirst = w->nReads; } tLastOut = t; nWritten += w->nReads; }
@@ -410,6 +422,8 @@ int runQueries(Args &a, FILE *log)
     th.emplace_back(writer);
     for (auto &x : th) x.join();
     const double tDone = now();
+    // every batch the splitter cut must have reached the writer, in order: a batch lost between two stages would otherwise be a shorter SAM with exit code 0
+    if (!stop && ticketsWritten.load() != ticketsIssued.load()) { fprintf(log, "internal error: %llu of %llu batches were written -- the output is incomplete.\n", (unsigned long long)ticketsWritten.load(), (unsigned long long)ticketsIssued.load()); rcAll = 1; }
     // The command line (csrc/main.cpp) leaves right after this function: it sets YAHA_FAST_EXIT and lets the process exit release the device memory and the
     // page-locked buffers in one go, instead of a hipFree per buffer (a second of waiting at the end of every run, measured).  Library users get the orderly path.
     const bool fastExit = getenv("YAHA_FAST_EXIT") != nullptr;
