@@ -3,6 +3,9 @@
   * config 5 -- CGR-like contigs of ~30 kbp (2..6 rearranged segments: deletions, tandem duplications, inversions, distal pieces) at 0 / 1 / 4 %
     divergence, run with -OQC Y -FBS Y (testdata/README.txt:25-29), plus one read of exactly 32 000 bases (the longest the reference takes,
     AlignArgs.c:82) and one of 32 001 (skipped with a warning, Query.c:148-156);
+  * config 5 -- the 500-mer split-read sets (testdata/README.txt:9-23): reads sampled at 2 % from SV event contigs -- deletions, tandem duplications, inversions and
+    distal insertions of 100 .. 10 000 bp (RandomSV_Events.sim:1-4) and insertions of a 300-bp repeat-family copy flanked on both sides (Alu_Insertions.sim) --
+    run with -OQC Y -FBS Y: the break point penalties and the -M 25 / -MNO corner of GraphPath.cpp:897-1086 (three segments inside 500 bases);
   * config 3 -- 10 kbp reads at the realised divergence of the bundled "E10" sets (3.4 %).
 
 The whole `yaha` command line of this repo (HIP hot path) against the REAL reference binary when it travelled with the snapshot (oracle/_ref/yaha),
@@ -26,7 +29,7 @@ SIM = os.path.join(ROOT, "tools", "yaha_sim")
 def g40(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("g40"))
     g = os.path.join(d, "g.fa")
-    subprocess.check_call([SIM, "genome", "--seed", "1234", "--out", g, "--seqs", "12", "--len", "40000000", "--repeat-frac", "0.45", "--nrun", "3", "--lowcomplex", "6"])
+    subprocess.check_call([SIM, "genome", "--seed", "1234", "--out", g, "--seqs", "12", "--len", "40000000", "--repeat-frac", "0.45", "--nrun", "3", "--lowcomplex", "6", "--repeat-bed", os.path.join(d, "repeats.bed")])
     ya.build_index(["-g", g, "-L", "15"])
     return d, g, os.path.join(d, "g.X15_01_65525S")
 
@@ -113,3 +116,41 @@ def test_10kbp_reads_at_default_seed_length(g40, tmp_path):
     reads = str(tmp_path / "r10k.fa")
     subprocess.check_call([SIM, "reads", "--genome", g, "--out", reads, "--seed", "78", "--n", "192", "--len", "10000", "--div", "0.034"])
     check(index, reads, [], tmp_path, min_records=192)
+
+
+def sv_events(d, n_ins=40):
+    """An events file in the reference's two line formats: RandomSV_Events.sim:1-4 as it stands, plus INS lines (Alu_Insertions.sim) for the least diverged full-length
+    Alu-like copies of the genome."""
+    rows = [l.split("\t") for l in open(os.path.join(d, "repeats.bed")).read().split("\n") if l]
+    rows = sorted((r for r in rows if int(r[2]) - int(r[1]) >= 295), key=lambda r: (float(r[5]), r[0], int(r[1])))[:n_ins]
+    path = os.path.join(d, "events.sim")
+    with open(path, "w") as f:
+        f.write("DEL\t100\t10000\t100\nDUP\t100\t10000\t100\nINR\t100\t10000\t100\nINV\t100\t10000\t100\n")
+        for r in rows:
+            f.write("INS\t%s\t%s\t%s\t%s\t%s\n" % (r[0], r[1], r[2], r[3], r[4]))
+    return path
+
+
+@pytest.mark.parametrize("opts", [["-OQC", "Y", "-FBS", "Y"], []])
+def test_sv_500mers_oqc_fbs(g40, tmp_path, opts):
+    """BASELINE config 5's split-read sets: every size of RandomSV_Events.sim (100 .. 10 000 in steps of 100, four event types) once, 40 repeat-family insertions
+    once each per size step, 500-mers at 2 %, coverage 1.5 -- about 7 400 reads, a sixth of them across a break point (the others lie inside the larger events'
+    contigs, as in the reference's sets)."""
+    d, g, index = g40
+    reads = str(tmp_path / "sv.fa")
+    subprocess.check_call([SIM, "sv", "--genome", g, "--events", sv_events(d), "--out", reads, "--seed", "91", "--per", "1", "--cov", "1.5", "--div", "0.02"], stderr=subprocess.DEVNULL)
+    n = len(names_in(reads))
+    assert n >= 5000
+    mine_out, ref_out = str(tmp_path / "mine.sam"), str(tmp_path / "ref.sam")
+    subprocess.check_call([ya.CLI_PATH, "-x", index, "-q", reads, "-osh", mine_out] + opts, stderr=subprocess.DEVNULL)
+    mh, mr, morder = by_read(strip_pg(open(mine_out, newline="").read()))
+    rh, rr, _ = by_read(referee(index, reads, opts, ref_out))
+    assert mh == rh and set(mr) == set(rr)
+    bad = [q for q in rr if rr[q] != mr[q]]
+    assert not bad, "records differ for %d reads, e.g. %s" % (len(bad), bad[0])
+    pos = {q: i for i, q in enumerate(names_in(reads))}
+    assert [pos[q] for q in morder] == sorted(pos[q] for q in morder), "output is not in input order"
+    # the sets are about split reads: a good share of the reads comes back in more than one primary piece, and the three-segment reads (flank, repeat copy, flank) exist
+    multi = sum(1 for v in mr.values() if any("YP:i:1" not in l for l in v))
+    assert multi >= n // 10
+    assert any(q.startswith("sv_AluLike") and sum(1 for l in v if "YS:i:" in l) >= 2 for q, v in mr.items())

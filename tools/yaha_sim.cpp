@@ -13,6 +13,15 @@
 //       --chimeric P : fraction of reads built from two loci (deletion / inversion / distal) for OQC tests.
 //       --cgr K      : every read is a contig of 2 .. K+1 rearranged segments (CGR-like, testdata/README.txt:25-29).
 //       --edges      : additionally emit reads touching offset 0 and the last base of every sequence.
+//   yaha_sim sv     --seed S --genome g.fa --events E.sim --out r.fa [--per N] [--pad 500] [--len 500] [--cov 5] [--div 0.02]
+//       Split-read sets after the reference's testdata/README.txt:9-23 (BASELINE config 5): SV event contigs as SVsim writes them, sampled wgsim-style.
+//       E.sim has the two line formats of the reference's own inputs: `TYPE min max step` with TYPE in DEL / DUP / INR / INV (RandomSV_Events.sim:1-4) --
+//       for every size min, min+step .. max, N events of that size at random loci -- and `INS chr start end strand name` (Alu_Insertions.sim) -- N
+//       insertions of the source segment chr:[start,end) at random loci.  An event contig is `pad` bases of flank on either side of: nothing (DEL: the s
+//       bases are gone), the segment twice (DUP, tandem), the segment reverse-complemented (INV), a distal segment of s bases (INR), the source segment (INS:
+//       a 300-bp repeat-family copy flanked on both sides -- three segments inside one 500-mer).  Reads: `len`-mers at uniform positions of the contig,
+//       either strand, cov x contig length / len of them, mutated like `reads` does.
+//   yaha_sim genome ... --repeat-bed F  additionally lists the Alu-like copies it placed (chr, start, end, strand, family, divergence): sources for INS lines.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -116,17 +125,21 @@ static int cmdGenome(int argc, char **argv)
     std::vector<std::string> alu;   for (int f = 0; f < nAlu; f++) { std::string c(300, 'A'); for (auto &ch : c) ch = randBase(r, 0.55); alu.push_back(c); }
     std::vector<std::string> l1;    for (int f = 0; f < nL1; f++) { std::string c(6000, 'A'); for (auto &ch : c) ch = randBase(r, 0.40); l1.push_back(c); }
     uint64_t target = (uint64_t)(repFrac * total), placed = 0;
+    const char *bedPath = argval(argc, argv, "--repeat-bed", nullptr); FILE *bed = bedPath ? fopen(bedPath, "w") : nullptr;      // (written beside the genome; consumes no random numbers)
     while (placed < target) {
         int si = (int)r.below(nseq); std::string &s = g.seqs[si];
-        std::string copy; double u = r.uni();
-        if (u < 0.60) { const std::string &c = alu[r.below(alu.size())]; copy = mutate(r, c, 0.03 + 0.12 * r.uni(), 0.12); }
+        std::string copy; double u = r.uni(); int fam = -1; double famDiv = 0;
+        if (u < 0.60) { fam = (int)r.below(alu.size()); const std::string &c = alu[fam]; famDiv = 0.03 + 0.12 * r.uni(); copy = mutate(r, c, famDiv, 0.12); }
         else if (u < 0.92) { const std::string &c = l1[r.below(l1.size())]; size_t fl = 300 + r.below(3000); size_t st = r.below(c.size() - fl); copy = mutate(r, c.substr(st, fl), 0.02 + 0.15 * r.uni(), 0.10); }
         else { int ul = 1 + (int)r.below(5); std::string unit(ul, 'A'); for (auto &ch : unit) ch = BASES[r.below(4)]; size_t reps = 8 + r.below(40); std::string ms; for (size_t k = 0; k < reps; k++) ms += unit; copy = mutate(r, ms, 0.02, 0.2); }
-        if (r.uni() < 0.5) { std::reverse(copy.begin(), copy.end()); for (auto &ch : copy) ch = comp(ch); }
+        bool flip = false;
+        if (r.uni() < 0.5) { flip = true; std::reverse(copy.begin(), copy.end()); for (auto &ch : copy) ch = comp(ch); }
         if (copy.size() + 2 >= s.size()) continue;
         size_t pos = r.below(s.size() - copy.size());
         memcpy(&s[pos], copy.data(), copy.size()); placed += copy.size();
+        if (bed && fam >= 0) fprintf(bed, "%s\t%zu\t%zu\t%c\tAluLike%d\t%.3f\n", g.names[si].c_str(), pos, pos + copy.size(), flip ? '-' : '+', fam, famDiv);
     }
+    if (bed) fclose(bed);
     for (int k = 0; k < lowc; k++) { std::string &s = g.seqs[r.below(nseq)]; size_t len = std::min<size_t>(400 + r.below(600), s.size() / 4); size_t pos = r.below(s.size() - len); char a = BASES[r.below(4)], b = BASES[r.below(4)]; for (size_t i = 0; i < len; i++) s[pos + i] = (r.uni() < 0.9) ? a : b; }
     for (int k = 0; k < nruns; k++) { std::string &s = g.seqs[r.below(nseq)]; size_t len = std::min<size_t>(200 + r.below(2000), s.size() / 8); size_t pos = r.below(s.size() - len); for (size_t i = 0; i < len; i++) s[pos + i] = 'N'; }
     writeFasta(out, g);
@@ -211,10 +224,75 @@ static int cmdReads(int argc, char **argv)
     return 0;
 }
 
+// Split-read sets: SV event contigs sampled as 500-mers (testdata/README.txt:9-23, RandomSV_Events.sim, Alu_Insertions.sim)
+static int cmdSV(int argc, char **argv)
+{
+    uint64_t seed = strtoull(argval(argc, argv, "--seed", "11"), 0, 10);
+    const char *gpath = argval(argc, argv, "--genome", "genome.fa"), *epath = argval(argc, argv, "--events", "events.sim"), *out = argval(argc, argv, "--out", "sv.fa");
+    const int per = atoi(argval(argc, argv, "--per", "25")), pad = atoi(argval(argc, argv, "--pad", "500")), len = atoi(argval(argc, argv, "--len", "500"));
+    const double cov = atof(argval(argc, argv, "--cov", "5")), div = atof(argval(argc, argv, "--div", "0.02"));
+    Genome g = readFasta(gpath); Rng r(seed);
+    uint64_t total = 0; for (auto &s : g.seqs) total += s.size();
+    FILE *ef = fopen(epath, "r"); if (!ef) { perror(epath); return 1; }
+    FILE *f = fopen(out, "w"); if (!f) { perror(out); return 1; }
+    // a locus with `need` bases of room and no N inside (SVsim draws from the assembled part of hg18)
+    auto pick = [&](size_t need, int &si, size_t &pos) {
+        for (int tries = 0; tries < 100000; tries++) {
+            uint64_t t = r.below(total); si = 0; while (t >= g.seqs[si].size()) { t -= g.seqs[si].size(); si++; }
+            if (g.seqs[si].size() < need + 2) continue;
+            pos = std::min<size_t>(t, g.seqs[si].size() - need);
+            if (g.seqs[si].find('N', pos) >= pos + need) return true;
+        }
+        return false;
+    };
+    auto seqIndex = [&](const char *name) { for (size_t i = 0; i < g.names.size(); i++) if (g.names[i] == name) return (int)i; return -1; };
+    unsigned long long ev = 0, nreads = 0;
+    auto sample = [&](const std::string &contig, const char *type, int si, size_t p, size_t sz) {
+        if ((int)contig.size() < len) return;
+        const int n = (int)(cov * contig.size() / len + 0.5);
+        for (int k = 0; k < n; k++) {
+            const size_t st = r.below(contig.size() - len + 1);
+            std::string seq = div > 0 ? mutate(r, contig.substr(st, len), div, 1.0 / 4.3) : contig.substr(st, len);
+            const bool rc = r.uni() < 0.5; if (rc) seq = revcomp(seq);
+            fprintf(f, ">sv_%s_%s_%zu_%zu_e%llu_at%zu_%llu_%c\n%s\n", type, g.names[si].c_str(), p, sz, ev, st, nreads++, rc ? 'r' : 'f', seq.c_str());
+        }
+        ev++;
+    };
+    char line[512];
+    while (fgets(line, sizeof line, ef)) {
+        char type[16], chr[128], strand[8], name[128]; long a = 0, b = 0, c = 0;
+        if (sscanf(line, "%15s", type) != 1 || type[0] == '#') continue;
+        if (!strcmp(type, "INS")) {
+            if (sscanf(line, "%*s %127s %ld %ld %7s %127s", chr, &a, &b, strand, name) != 5) { fprintf(stderr, "bad INS line: %s", line); return 1; }
+            const int sj = seqIndex(chr); if (sj < 0 || a < 0 || b <= a || (size_t)b > g.seqs[sj].size()) { fprintf(stderr, "INS source outside the genome: %s", line); return 1; }
+            std::string src = g.seqs[sj].substr(a, b - a); if (strand[0] == '-') src = revcomp(src);
+            for (int k = 0; k < per; k++) {
+                int si; size_t p; if (!pick(2 * (size_t)pad, si, p)) break; p += pad;                                  // insertion AT p: flank, source, flank
+                sample(g.seqs[si].substr(p - pad, pad) + src + g.seqs[si].substr(p, pad), name, si, p, src.size());
+            }
+            continue;
+        }
+        if (sscanf(line, "%*s %ld %ld %ld", &a, &b, &c) != 3 || a < 1 || b < a || c < 1) { fprintf(stderr, "bad event line: %s", line); return 1; }
+        for (long sz = a; sz <= b; sz += c) for (int k = 0; k < per; k++) {
+            int si; size_t p; if (!pick((size_t)sz + 2 * (size_t)pad, si, p)) break; p += pad;                       // the event's segment is [p, p + sz)
+            const std::string &s = g.seqs[si]; const std::string L = s.substr(p - pad, pad), M = s.substr(p, sz), R = s.substr(p + sz, pad);
+            if (!strcmp(type, "DEL")) sample(L + R, "DEL", si, p, sz);
+            else if (!strcmp(type, "DUP")) sample(L + M + M + R, "DUP", si, p, sz);
+            else if (!strcmp(type, "INV")) sample(L + revcomp(M) + R, "INV", si, p, sz);
+            else if (!strcmp(type, "INR")) { int sj; size_t q; if (!pick((size_t)sz, sj, q)) break; sample(L + g.seqs[sj].substr(q, sz) + s.substr(p, pad), "INR", si, p, sz); }      // distal insertion AT p
+            else { fprintf(stderr, "unknown event type %s\n", type); return 1; }
+        }
+    }
+    fclose(ef); fclose(f);
+    fprintf(stderr, "yaha_sim sv: %llu events, %llu reads of %d bases\n", ev, nreads, len);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: yaha_sim genome|reads [options]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: yaha_sim genome|reads|sv [options]\n"); return 2; }
     if (!strcmp(argv[1], "genome")) return cmdGenome(argc, argv);
     if (!strcmp(argv[1], "reads")) return cmdReads(argc, argv);
+    if (!strcmp(argv[1], "sv")) return cmdSV(argc, argv);
     fprintf(stderr, "unknown command %s\n", argv[1]); return 2;
 }
