@@ -72,7 +72,7 @@ def ensure_inputs(cache, genome_mbp, seed):
     done = idx + ".done"
     if not os.path.exists(done):
         t = time.time()
-        subprocess.check_call([sim, "genome", "--seed", str(seed), "--out", fa, "--seqs", "24", "--len", str(genome_mbp * 1000000), "--repeat-frac", "0.45", "--nrun", "6", "--lowcomplex", "8"])
+        subprocess.check_call([sim, "genome", "--seed", str(seed), "--out", fa, "--seqs", "24", "--len", str(genome_mbp * 1000000), "--repeat-frac", "0.45", "--nrun", "6", "--lowcomplex", "8", "--repeat-bed", fa + ".repeats.bed"])
         ya.build_index(["-g", fa, "-L", "15"])
         open(done, "w").write("ok")
         log("built genome + index in %.1fs" % (time.time() - t))
@@ -105,6 +105,134 @@ def make_reads(cache, fa, tag, n, length, div, seed):
         subprocess.check_call([os.path.join(ROOT, "tools", "yaha_sim"), "reads", "--genome", fa, "--out", tmp, "--seed", str(seed), "--n", str(n), "--len", str(length), "--div", str(div)])
         os.replace(tmp, path)
     return path
+
+
+def make_sv_reads(cache, fa, tag, seed, per=5, cov=1.5, n_ins=40):
+    """BASELINE config 5's split-read set on the bench genome (tools/yaha_sim.cpp `sv`): RandomSV_Events.sim's four lines as they stand (DEL / DUP / INR / INV, 100 .. 10 000 bp
+    in steps of 100) and INS lines for the genome's least diverged Alu-like copies (Alu_Insertions.sim's format), 500-mers at 2 %."""
+    path = os.path.join(cache, "%s_sv_s%d_p%d.fa" % (tag, seed, per))
+    if not os.path.exists(path):
+        ev = path + ".events.sim"
+        with open(ev, "w") as f:
+            bed = fa + ".repeats.bed"
+            if os.path.exists(bed):                      # (INS lines first: a bench batch is the file's first reads)
+                rows = []
+                for l in open(bed):
+                    r = l.rstrip("\n").split("\t")
+                    if len(r) == 6 and int(r[2]) - int(r[1]) >= 295 and float(r[5]) < 0.04:
+                        rows.append(r)
+                        if len(rows) >= 50 * n_ins:
+                            break
+                for r in sorted(rows, key=lambda r: float(r[5]))[:n_ins]:
+                    f.write("INS\t%s\t%s\t%s\t%s\t%s\n" % (r[0], r[1], r[2], r[3], r[4]))
+            f.write("DEL\t100\t10000\t100\nDUP\t100\t10000\t100\nINR\t100\t10000\t100\nINV\t100\t10000\t100\n")
+        tmp = path + ".tmp%d" % os.getpid()
+        subprocess.check_call([os.path.join(ROOT, "tools", "yaha_sim"), "sv", "--genome", fa, "--events", ev, "--out", tmp, "--seed", str(seed), "--per", str(per), "--cov", str(cov), "--div", "0.02"], stderr=subprocess.DEVNULL)
+        os.replace(tmp, path)
+    return path
+
+
+def cli_run(ya, args, env_extra=None):
+    """One run of the `yaha` command line; returns (seconds, stats dict of YAHA_STATS=1)."""
+    env = dict(os.environ, YAHA_STATS="1"); env.update(env_extra or {})
+    t = time.time()
+    p = subprocess.run([ya.CLI_PATH] + list(args), stderr=subprocess.PIPE, check=True, env=env)
+    dt = time.time() - t
+    st = [l for l in p.stderr.decode().split("\n") if l.startswith("[yaha] stats ")]
+    return dt, (json.loads(st[0][len("[yaha] stats "):]) if st else {})
+
+
+def config5_leg(ya, idx, fa, cache, device, contexts, tag):
+    """BASELINE config 5 on one GPU: the hot path on a resident batch of 32 768 SV 500-mers, the whole command line with -OQC Y -FBS Y on the whole set, and -- where the
+    reference binary is present -- the command line's records for the set's first 8 192 reads against the reference's."""
+    import oracle
+    sv = make_sv_reads(cache, fa, tag, 5000)
+    n_all = sum(1 for l in open(sv) if l.startswith(">"))
+    out = side_workload(ya, idx, sv, 32768, device, contexts, 4, "c5: SV / repeat-insertion 500-mers at 2 % (RandomSV_Events.sim + Alu_Insertions.sim shapes), hot path", blocks=3)
+    sam = "/dev/shm/yaha_bench_c5_%d.sam" % os.getpid()
+    try:
+        time.sleep(10)
+        dt, st = cli_run(ya, ["-x", idx, "-q", sv, "-osh", sam, "-OQC", "Y", "-FBS", "Y"])
+        out["command_line"] = {"reads": n_all, "seconds": dt, "e2e_reads_per_s": n_all / dt, "steady_reads_per_s": st.get("steady_reads_per_s"), "contexts_up_ms": st.get("contexts_up_ms"), "options": "-OQC Y -FBS Y"}
+        if oracle.have_reference():
+            head, ref = os.path.join(cache, "c5_head.fa"), os.path.join(cache, "c5_head_reference.sam")
+            head_reads(sv, head, 8192)
+            oracle.run_reference(["-x", idx, "-q", head, "-osh", ref, "-OQC", "Y", "-FBS", "Y", "-t", str(usable_cpus())])
+            names = set(l[1:].split()[0] for l in open(head) if l.startswith(">"))
+            v = compare_sam(sam, ref, names); v["reads"] = 8192
+            out["verified"] = v
+            os.remove(head); os.remove(ref)
+    finally:
+        if os.path.exists(sam):
+            os.remove(sam)
+    return out
+
+
+def host_ceiling(ya, idx, reads_path, n_devices=8):
+    """What the host stages around the device sustain on this box, for the thread counts the command line would pick with `n_devices` devices (host/pipeline.cpp): the
+    product's splitter + parsers (tools/host_ceiling.cpp) and its SAM formatter over device-filtered results of a real batch, replayed.  The smaller of the two is the
+    rate up to which the host does not cap a node."""
+    cpus = usable_cpus()
+    n_parse = max(1, min(8, min(max((cpus + 7) // 10, (n_devices + 1) // 2), max(1, cpus // 3))))
+    n_fmt = max(1, cpus - n_parse - 2)
+    exe = os.path.join(ROOT, "tools", "host_ceiling")
+    res = {"usable_cpus": cpus, "hardware_threads": os.cpu_count(), "devices_assumed": n_devices, "parser_threads": n_parse, "formatter_threads": n_fmt}
+    lines = subprocess.run([exe, reads_path, "4096", str(n_parse)], stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
+    for l in lines:
+        if '"split+parse"' in l:
+            res["parse_reads_per_s"] = json.loads(l)["reads_per_s"]
+        elif '"split"' in l:
+            res["split_reads_per_s"] = json.loads(l)["reads_per_s"]
+    import threading
+    N = 8192
+    with ya.Session(["-x", idx, "-q", reads_path]) as s0:
+        b0 = s0.next_batch(N)
+        ctx = ya.Context(s0.index, s0.params)
+        ctx.upload(b0); ctx.run(); ctx.set_postfilter(s0); f = ctx.postfilter()
+        sessions = [ya.Session(["-x", idx, "-q", reads_path, "-t", "1"]) for _ in range(n_fmt)]
+        for x in sessions:
+            assert x.next_batch(N).n_reads == N
+        reps = 12
+
+        def work(x):
+            t_, n_ = C.c_char_p(), C.c_size_t()
+            for _ in range(reps):
+                assert ya.lib().yaha_session_emit_filtered(x._h, C.byref(f), C.byref(t_), C.byref(n_)) == 0
+        th = [threading.Thread(target=work, args=(x,)) for x in sessions]
+        t = time.time()
+        for x in th: x.start()
+        for x in th: x.join()
+        res["format_reads_per_s"] = N * n_fmt * reps / (time.time() - t)
+        for x in sessions:
+            x.close()
+        ctx.close()
+    res["host_ceiling_reads_per_s"] = min(res.get("parse_reads_per_s", 0.0), res["format_reads_per_s"])
+    return res
+
+
+def eight_logical_devices(ya, cache, seed, n_reads=1048576):
+    """The host path of an 8-GPU node on a 1-GPU box (Query.c:642-690 is the reference's parallel driver): `YAHA_DEVICES=0,0,0,0,0,0,0,0 yaha -gpus 8 -ctx 1` -- eight index
+    images (a chain of seven device-to-device copies behind one upload), eight context threads, one splitter / parser pool / formatter pool / writer -- on the 100 Mbp index
+    (eight images fit), 1 M reads.  The one physical GPU bounds the rate; what the leg shows is that the host side deals and re-orders for eight devices: every device gets
+    reads, the output equals the one-device output."""
+    fa, idx = ensure_inputs(cache, 100, seed)
+    reads = make_reads(cache, fa, "g100m_8dev", n_reads, 1000, 0.017, 3200)
+    one, eight = "/dev/shm/yaha_bench_1dev_%d.sam" % os.getpid(), "/dev/shm/yaha_bench_8dev_%d.sam" % os.getpid()
+    try:
+        time.sleep(15)
+        dt1, st1 = cli_run(ya, ["-x", idx, "-q", reads, "-osh", one, "-batch", "4096"])
+        time.sleep(15)
+        dt8, st8 = cli_run(ya, ["-x", idx, "-q", reads, "-osh", eight, "-gpus", "8", "-ctx", "1", "-batch", "4096"], {"YAHA_DEVICES": "0,0,0,0,0,0,0,0"})
+        same = subprocess.run(["cmp", "-s", one, eight]).returncode == 0
+        if not same:                                      # (the @PG line echoes -gpus / -ctx when they are given: compare without it)
+            same = [l for l in open(one) if not l.startswith("@PG")] == [l for l in open(eight) if not l.startswith("@PG")]
+        return {"reads": n_reads, "index": "100 Mbp -L 15", "command": "YAHA_DEVICES=0,0,0,0,0,0,0,0 yaha -gpus 8 -ctx 1 -batch 4096", "seconds": dt8, "e2e_reads_per_s": n_reads / dt8, "steady_reads_per_s": st8.get("steady_reads_per_s"),
+                "contexts_up_ms": st8.get("contexts_up_ms"), "reads_per_device": st8.get("reads_per_device"), "parsers": st8.get("parsers"), "formatters": st8.get("formatters"), "ctx_left_out": st8.get("ctx_left_out"),
+                "one_device": {"command": "yaha -batch 4096 (-ctx 3)", "seconds": dt1, "steady_reads_per_s": st1.get("steady_reads_per_s")}, "output_identical_to_one_device": same}
+    finally:
+        for f in (one, eight):
+            if os.path.exists(f):
+                os.remove(f)
 
 
 def head_reads(src, dst, n):
@@ -608,6 +736,10 @@ def main():
             wl.append({"workload": "c2 int32", "error": str(e)[:200]})
         finally:
             del os.environ["YGPU_EXT32"]
+        try:
+            wl.append(config5_leg(ya, idx, fa, cache, local, args.contexts, "g%dm" % args.genome_mbp))
+        except Exception as e:
+            wl.append({"workload": "c5", "error": str(e)[:300]})
         wl.insert(1, {"workload": "c2: 1 kbp reads, r=0.05 (realised 1.7%) = the headline", "reads_per_step": n_reads, "steps": steps, "reads_per_s": value, "bases_per_s": value * Lq, "ms_per_step": 1e3 * dt / steps,
                       "k_ext_rows_ms_per_step": rows_dev_ms})
         out["workloads"] = wl
@@ -618,6 +750,16 @@ def main():
                 out["end_to_end_c3"] = end_to_end(ya, idx, fa, cache, 32768, 3100, read_len=10000, div=0.034)
         except Exception as e:
             out["end_to_end"] = {"error": str(e)[:200]}
+        try:
+            out["host_ceiling"] = host_ceiling(ya, idx, os.path.join(cache, "e2e_n%d_l%d_s%d.fa" % (args.e2e_reads, 1000, 3000)))
+            out["host_ceiling_reads_per_s"] = out["host_ceiling"]["host_ceiling_reads_per_s"]
+        except Exception as e:
+            out["host_ceiling"] = {"error": str(e)[:300]}
+        if args.e2e_reads >= 262144:
+            try:
+                out["eight_logical_devices"] = eight_logical_devices(ya, cache, args.seed, args.e2e_reads)
+            except Exception as e:
+                out["eight_logical_devices"] = {"error": str(e)[:300]}
     if world > 1 and not args.no_extras:
         # N > 1: the whole command line over the N devices (`yaha -gpus N`, one process, N x 3 contexts, index image uploaded to every device), the other ranks idle
         try:

@@ -100,6 +100,28 @@ def test_command_line_with_two_logical_devices_on_one_gpu(work, index11):
     assert stats["gpus"] == 2 and stats["ctx_per_gpu"] == 2 and len(stats["reads_per_device"]) == 2 and all(n > 0 for n in stats["reads_per_device"])
 
 
+def test_eight_logical_devices_shake_the_host_path(tmp_path):
+    """The host side of an 8-GPU node on the 1-GPU box: `YAHA_DEVICES=0,0,0,0,0,0,0,0 yaha -gpus 8 -ctx 1` -- eight index images (seven device-to-device copies behind one
+    upload), eight context threads fed by one splitter / parser pool and drained by one formatter pool / ordered writer (the reference's parallel driver: Query.c:642-690)
+    -- on a 40 Mbp -L 15 index, 131 072 reads of 1 kbp in batches of 2 048: every logical device takes reads, and the SAM is byte-identical to the one-device run."""
+    g = str(tmp_path / "g.fa")
+    subprocess.check_call([SIM, "genome", "--seed", "777", "--out", g, "--seqs", "8", "--len", "40000000", "--repeat-frac", "0.45"])
+    ya.build_index(["-g", g, "-L", "15"])
+    idx = str(tmp_path / "g.X15_01_65525S")
+    reads = str(tmp_path / "r.fa")
+    subprocess.check_call([SIM, "reads", "--genome", g, "--out", reads, "--seed", "92", "--n", "131072", "--len", "1000", "--div", "0.017", "--chimeric", "0.05"])
+    one, eight = str(tmp_path / "one.sam"), str(tmp_path / "eight.sam")
+    subprocess.check_call([ya.CLI_PATH, "-x", idx, "-q", reads, "-osh", one, "-batch", "2048"], stderr=subprocess.DEVNULL)
+    p = subprocess.run([ya.CLI_PATH, "-x", idx, "-q", reads, "-osh", eight, "-gpus", "8", "-ctx", "1", "-batch", "2048"], stderr=subprocess.PIPE, env=dict(os.environ, YAHA_STATS="1", YAHA_DEVICES="0,0,0,0,0,0,0,0"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    st = [l for l in p.stderr.decode().split("\n") if l.startswith("[yaha] stats ")]
+    stats = json.loads(st[0][len("[yaha] stats "):])
+    assert stats["gpus"] == 8 and stats["ctx_per_gpu"] == 1 and len(stats["reads_per_device"]) == 8 and all(n > 0 for n in stats["reads_per_device"]), stats
+    assert sum(stats["reads_per_device"]) == stats["reads"] == 131072 and stats["ctx_left_out"] == 0
+    a, b = strip_pg(open(one, newline="").read()), strip_pg(open(eight, newline="").read())
+    assert len(a) > 131072 and a == b
+
+
 @two_devices
 def test_context_on_the_second_device(work, index11):
     with ya.Session(["-x", index11, "-q", os.path.join(work, "rchim.fa")]) as s:

@@ -101,3 +101,13 @@ def test_bench_picks_the_genome_the_box_can_hold(tmp_path, monkeypatch):
     assert bench.pick_genome_mbp(str(tmp_path), 42) == 100
     (tmp_path / "g3100m_s42.X15_01_65525S.done").write_text("ok")
     assert bench.pick_genome_mbp(str(tmp_path), 42) == 3100
+
+
+def test_no_kernel_spills_vector_registers():
+    """Every kernel of the built library keeps its vector registers out of scratch memory (tools/kernel_resources.py reads the code object's notes): round 4's 32-bit
+    rows kernel spilled four and lost 1.2 %."""
+    import subprocess, sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    out = p.stdout.decode()
+    assert "k_ext_rows_pk" in out and "k_frag_scan_build" in out, p.stderr.decode()[-500:]
+    assert p.returncode == 0 and "SPILLS" not in out, [l for l in out.split("\n") if "SPILLS" in l]

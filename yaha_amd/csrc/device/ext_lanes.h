@@ -72,9 +72,10 @@ enum { YERR_TRACEMEM = 9 };                     // the trace arena (or a wave's 
 // columns): the run-length state (PI, PD) is then dead and is compiled out.
 // SECOND = the careful-extension round of splitClump (split_lanes.h): same code, its own kernel name in profiles, work counted by
 // the consumer of the results.
-// three waves per SIMD: the register allocation is held at 168 (a fourth wave would cost more in spills than it hides, a third one is needed to cover the row's loads)
+// three waves per SIMD: the register allocation is held at 168 (a fourth wave would cost more in spills than it hides, a third one is needed to cover the row's loads).
+// With the run-length state (CAPS: 22 more registers, -G or the intron cap below 21 -- rare) two waves per SIMD: at three it spilled four registers to scratch memory.
 template <bool CAPS, bool SECOND>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ext_rows(ExtArgs A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ? 2 : 3, CAPS ? 2 : 3))) k_ext_rows(ExtArgs A)
 {
     __shared__ uint32_t sBlk[256 * YD_LDS_STRIDE];   // per lane: the current 10-row trace block (30 dwords), lane stride 33
     if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());
@@ -104,7 +105,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     int poolCount = 0, poolNext = 0; bool exhausted = false;
     uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0;
     // deferred stores (see the row code)
-    bool pendFlush = false; int pendRes = -1, pendScore = 0, pendI = 0, pendJ = 0; unsigned pendRows = 0, pendCells = 0, pendStart = 0, pStart = 0;   // pStart = the flush and the row slot a problem started in: flush << 4 | slot
+    // (a finished problem's result is stored in the lane's NEXT pass; the refill leaves such a lane alone for that pass -- justDone -- so maxScore / maxi / maxj, the row
+    // count i and pStart are still the problem's when the store is issued: no copies of them are kept -- six registers that the allocation of 168 did not have)
+    bool pendFlush = false; int pendRes = -1; unsigned pStart = 0;   // pStart = the flush and the row slot a problem started in: flush << 4 | slot
+    auto storeResult = [&]() {
+        // work of this call: i rows; row r has 21 - max(11 - r, 0) real cells (the columns left of the origin come into the band one row at a time)
+        const unsigned m = i < leftR ? (unsigned)i : (unsigned)leftR, nCells = (unsigned)YD_LW * (unsigned)i - ((unsigned)(leftR + 1) * m - m * (m + 1u) / 2u);
+        rows += (unsigned)i; cells += nCells;
+        ExtRes r; r.score = maxScore > 0 ? maxScore : 0; r.maxi = maxi; r.maxj = maxj; r.opsOff = pStart >> 4; r.nOps = 0;
+        r.where = (pStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = (unsigned)i; r.cells = nCells;
+        A.res[pendRes] = r; pendRes = -1; i = 0;
+    };
     // Trace memory: the wave's 64 blocks of ten rows leave together (a "flush"), into slot (flush & 15) of the wave's current arena chunk.  wslot = the row
     // slot all lanes write in this iteration, flush = flushes done so far; a problem notes (flush, wslot) when it starts.  A lane whose problem ended inside
     // the block keeps the block `dirty` until the next hand-over; a lane that starts a problem inside a block shares it with its previous problem.
@@ -216,11 +227,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         // All memory operations of an iteration are issued at its top: the previous ten rows' trace cells (above) and a finished
         // problem's result (both deferred), and the loads the row needs at its END (next query base, next reference base).
         // The wait the compiler puts at the loop header then finds them ~1000 instructions old.
-        if (pendRes >= 0) {
-            ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendStart >> 4; r.nOps = 0;
-            r.where = (pendStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows; r.cells = pendCells;
-            A.res[pendRes] = r; pendRes = -1;
-        }
+        if (pendRes >= 0) storeResult();
         const bool busy = p >= 0;
         ++i;
         const int qc = qcNext;
@@ -274,22 +281,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (busy) dirty = true;
         if (wslot == 9) { pendFlush = dirty; dirty = false; wslot = 0; } else wslot++;      // wave-uniform
         justDone = fin;                                                      // the next row slot stays empty behind a finished problem (its traceback's spare row)
-        if (fin) {
-            // work of this call: i rows; row r has 21 - max(11 - r, 0) real cells (the columns left of the origin come into the band one row at a time)
-            const unsigned m = i < leftR ? (unsigned)i : (unsigned)leftR, nCells = (unsigned)YD_LW * (unsigned)i - ((unsigned)(leftR + 1) * m - m * (m + 1u) / 2u);
-            rows += (unsigned)i; cells += nCells;
-            pendRes = p; pendScore = maxScore; pendI = maxi; pendJ = maxj; pendRows = (unsigned)i; pendCells = nCells; pendStart = pStart;
-            p = -1; qStep = 0; rLen = 0; qLen = 0; i = 0;
-        }
+        if (fin) { pendRes = p; p = -1; qStep = 0; rLen = 0; qLen = 0; }      // (i, maxScore, maxi, maxj, pStart stay as they are until storeResult)
     }
     // the last deferred stores; one more flush slot stays reserved behind the last block (the spare row of a problem that ended in row slot 9)
     if (wslot != 0 && dirty) pendFlush = true;
     if (!noMem && __ballot(pendFlush) != 0ull) { flushBlocks(); nextFlush(); }
-    if (pendRes >= 0) {
-        ExtRes r; r.score = pendScore > 0 ? pendScore : 0; r.maxi = pendI; r.maxj = pendJ; r.opsOff = pendStart >> 4; r.nOps = 0;
-        r.where = (pendStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = pendRows; r.cells = pendCells;
-        A.res[pendRes] = r;
-    }
+    if (pendRes >= 0) storeResult();
     if (!SECOND && A.clock && lane == 0) atomicMax(&A.clock[1], (unsigned long long)wall_clock64());
     // work counters
     unsigned c0 = (unsigned)waveSumI((int)calls), c1 = (unsigned)waveSumI((int)rows);
