@@ -190,6 +190,10 @@ int  ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump 
  * ygpu_collect and their siblings then work on it -- so that the device filter can be driven with clump lists no real read produces (hundreds of exact ties,
  * chains of overlaps) and compared with the host's on the same data. */
 int  ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r);
+/* Stage-level test entry for the exclusive sums and orderings the hot path lays its variable-size outputs out with (device/scan.h: single-pass look-back sums of
+ * u32 / u64, orderings by a small key): runs them on n pseudo-random elements and compares with the plain host loops.  0, or YGPU_EINTERNAL with the first
+ * difference in ygpu_last_error.  (The reference needs neither: it handles one read at a time, Query.c:306-497.) */
+int  ygpu_selftest_primitives(ygpu_ctx *ctx, uint32_t n, uint32_t seed, int key_bits);
 
 /* Asynchronous form: ygpu_submit hands the batch to the context and returns at once; the context's own worker thread does
  * upload + run + collect; ygpu_wait blocks until the ticket is complete and returns the results (ygpu_poll: 1 = complete, 0 = still running).

@@ -206,10 +206,11 @@ def test_trace_memory_chunks(work, index11, meta, budget, monkeypatch):
         assert mine == golden_lines(name), "chunked trace path differs from the reference on " + name
 
 
-@pytest.mark.parametrize("mode", [("1", None), ("2", "16384"), ("2", "700"), ("2", "3000")])
+@pytest.mark.parametrize("mode", [("2", "16384"), ("2", "700"), ("2", "3000"), ("2", "64")])
 def test_hit_sort_paths(work, index11, meta, mode, monkeypatch):
-    # A2's sort: library segmented sort (YGPU_SEG_SORT=1), or one workgroup per (read, strand) in size classes with the library sort for the
-    # segments above YGPU_SEGSORT_MAX hits -- lowered here so that the 10 kbp reads' segments take every class and the long-segment path.
+    # A2's sort: one workgroup per (read, strand) in size classes; segments above YGPU_SEGSORT_MAX hits are cut by diagonal, and a piece that still does not fit is cut
+    # again over its own range of diagonals until it fits or holds one diagonal -- the limit is lowered here so that the 10 kbp reads' segments take every class, the
+    # long-segment path and (64: a true alignment's thousands of hits on one diagonal) several levels of cuts down to single-diagonal pieces.
     monkeypatch.setenv("YGPU_SEG_SORT", mode[0])
     if mode[1]:
         monkeypatch.setenv("YGPU_SEGSORT_MAX", mode[1])
@@ -560,3 +561,14 @@ def test_real_human_sequence_command_line_equals_the_reference(tmp_path):
             print("human 1 kbp reads on the 10 Mbp pseudo-reference, per read: hits %.0f, fragments %.0f, clumps aligned %.0f, X-drop calls %.0f, extension cells %.0f, gap cells %.0f" %
                   (c["hits"] / n, c["fragments"] / n, c["clumps_formed"] / n, c["dp_ext_calls"] / n, c["dp_ext_cells"] / n, c["dp_gap_cells"] / n))
     os.remove(idx)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 3), (7, 7), (8, 8), (8191, 8), (8192, 12), (8193, 10), (100003, 16), (5000000, 7), (33000001, 10)])
+def test_own_sums_and_orderings(work, index11, n, bits):
+    """device/scan.h -- the exclusive sums (single pass, decoupled look-back, u32 and u64, in place) and the orderings by a small key that lay out the batch's
+    variable-size outputs -- against plain host loops: tile edges (8 192 elements a tile), one element, tens of millions (4 029 tiles), sums beyond 2^32, keys with an
+    offset and a shift, crowded buckets; every call twice over the same work words (they clean themselves up)."""
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
+        with ya.Context(s.index, s.params) as c:
+            for seed in (1, 2):
+                c.selftest_primitives(n, seed=seed, key_bits=bits)

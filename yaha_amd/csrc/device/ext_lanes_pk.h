@@ -384,6 +384,12 @@ __device__ __forceinline__ int pkRecWord(int n) { return ((n - 1) >> 3) * 32 + (
 __device__ __forceinline__ bool pkContE(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6; return ((d >> (8 * h + bit)) & 1u) == 0u; }
 __device__ __forceinline__ bool pkContF(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6; return ((d >> (16 + 8 * h + bit)) & 1u) == 0u; }
 #define YD_TSTRIDE 36          // dwords per problem in the traceback's block cache (32 + padding; 16-byte aligned).  (32 with an XOR swizzle -- a fifth workgroup per CU -- was no faster.)
+// Inside a problem's block the four dwords of every 16-byte record are stored XOR-ed by (problem >> 3) & 3 (YD_TSWZ).  A lane reads single dwords of its own
+// problem's records (ds_read_b32: 32 lanes a group, bank = dword address mod 32): with stride 36 and whole records in place lane l's dword c of slot s sits on bank
+// 4 (l + s) + c -- the 32 lanes of a group on the eight banks that are c modulo 4, four lanes each (33.6 % of the kernel's LDS cycles were such conflicts, rounds 3-4).
+// With the dword index XOR-ed by the lane's (l >> 3) & 3 the four lanes that shared a bank read four different ones.  The staging store writes whole records, eight
+// lanes to a problem, (problem >> 3) & 3 = g & 3 a compile-time constant of the unrolled loop: the permutation is a renaming of the four registers it stores.
+#define YD_TSWZ(problem) (((problem) >> 3) & 3)
 __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
 {
     YD_HIGH_PRIO();
@@ -436,14 +442,16 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
                     const int src = g * 8 + (lane >> 3);
                     const unsigned long long b = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(myBase >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myBase, src, 64);
                     const yd_u32x4 v = *(YD_GLOBAL const yd_u32x4 *)((YD_GLOBAL const uint32_t *)b + (lane & 7) * 4);
-                    *(yd_u32x4 *)(wBlk + src * YD_TSTRIDE + (lane & 7) * 4) = v;
+                    yd_u32x4 sw; { const uint32_t c[4] = {v.x, v.y, v.z, v.w}; sw.x = c[(0 ^ g) & 3]; sw.y = c[(1 ^ g) & 3]; sw.z = c[(2 ^ g) & 3]; sw.w = c[(3 ^ g) & 3]; }      // YD_TSWZ(src) = g & 3
+                    *(yd_u32x4 *)(wBlk + src * YD_TSTRIDE + (lane & 7) * 4) = sw;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
             if (!act) continue;
             const int rr0 = u.rr;                                            // the cursor's slot when the block was fetched
+            const int swz = YD_TSWZ(lane);                                   // this lane's records: dword c is stored at c ^ swz
             auto blkRec = [&](int slot, YD_GLOBAL const uint32_t *cp) -> PkRec {  // the record in `slot` of the fetched block, or (slot < 0: a block further up) the one at cp
-                if (slot >= 0) { const uint32_t *q = myRec + slot * 4; PkRec r2; r2.ab2 = q[0]; r2.m = q[1]; r2.a = q[2]; r2.b = q[3]; return r2; }
+                if (slot >= 0) { const uint32_t *q = myRec + slot * 4; PkRec r2; r2.ab2 = q[0 ^ swz]; r2.m = q[1 ^ swz]; r2.a = q[2 ^ swz]; r2.b = q[3 ^ swz]; return r2; }
                 return pkLoadRec(cp);
             };
             const int h = x >= YD_NP ? 1 : 0, k = x - YD_NP * h;
@@ -453,16 +461,17 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
             // it is a mismatch.  The run's length is the number of trailing ones of diag below lim; its ops are the groups of equal bits of mis.  (Row by row this was
             // ~25 instructions a row with a branch each; a run of eight rows is the common case: reads differ from the reference every sixty bases.)
             uint32_t diag = 0u, mis = 0u;
+            const int iTU = (second ? 0 : 2) ^ swz, iM = 1 ^ swz;
 #pragma unroll
             for (int d = 0; d < YD_TRACE_DEPTH; d++) {
                 const int sl = rr0 - d < 0 ? 0 : rr0 - d;
-                const uint32_t tu = myRec[sl * 4 + (second ? 0 : 2)], mw = myRec[sl * 4 + 1];
+                const uint32_t tu = myRec[sl * 4 + iTU], mw = myRec[sl * 4 + iM];
                 diag |= (((tu >> sT) & (tu >> sU)) & 1u) << d; mis |= ((mw >> sM) & 1u) << d;
             }
             const uint32_t inLim = (1u << lim) - 1u;
             const int took = __builtin_ctz(~diag | ~inLim);                  // rows of the run (0 .. lim)
             int op = 0;
-            if (took < lim) { const int sl = rr0 - took; const uint32_t tu = myRec[sl * 4 + (second ? 0 : 2)]; op = ((tu >> sU) & 1u) == 0u ? OP_I : OP_D; }      // what stops the run: a gap op (the row is inside the block: took < lim <= rr0 + 1)
+            if (took < lim) { const int sl = rr0 - took; const uint32_t tu = myRec[sl * 4 + iTU]; op = ((tu >> sU) & 1u) == 0u ? OP_I : OP_D; }      // what stops the run: a gap op (the row is inside the block: took < lim <= rr0 + 1)
             y -= took;
             if (took > 0) {                                                   // the cursor moves up took rows inside the block (the step out of it is stepUp's); before the
                 const int mv = took < lim ? took : took - 1;                  // ops are staged: every row of the run has been decoded, its records are free

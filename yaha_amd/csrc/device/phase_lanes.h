@@ -244,18 +244,18 @@ __device__ __forceinline__ int matchRun(YD_GLOBAL const uint8_t *q, int qi, YD_G
     return m;
 }
 
-// sort key of a DP joint, 16 bits (two radix passes): class : 2 | strip width : 7 | rows : 7, both clamped (the order only groups similar shapes; the class
-// boundaries are exact).  Class 0 / 1: banded, within k_gap_band's limits, W <= 12 / 16; 2: other W <= 16; 3: the rest.  Joints without a DP: YD_JKEY_NONE, last.
-#define YD_JKEY_NONE 0xFFFFu
-#define YD_JKEY_BITS 16
-__device__ __forceinline__ uint32_t gapJointClass(uint32_t key) { return key >> 14; }
+// order key of a DP joint, 12 bits (one bucket pass, scan.h): class : 2 | strip width : 5 | rows / 2 : 5, both clamped (the order only groups similar shapes; the
+// class boundaries are exact).  Class 0 / 1: banded, within k_gap_band's limits, W <= 12 / 16; 2: other W <= 16; 3: the rest.  Joints without a DP: YD_JKEY_NONE, last.
+#define YD_JKEY_NONE 0xFFFu
+#define YD_JKEY_BITS 12
+__host__ __device__ __forceinline__ uint32_t gapJointClass(uint32_t key) { return key >> 10; }
 __device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, bool banded, int qGap, int rGap)
 {
     const int lenDiff = qGap > rGap ? qGap - rGap : rGap - qGap;
     const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1;
     uint32_t cls = W <= 16 ? 2u : 3u;
     if (banded && W <= 16 && P.bandWidth >= 5 && P.maxGap >= 16 && qGap <= YD_GROWS && rGap <= YD_GREF) cls = W <= 12 ? 0u : 1u;
-    return (cls << 14) | ((uint32_t)min(W, 127) << 7) | (uint32_t)min(qGap, 126);
+    return (cls << 10) | ((uint32_t)min(W, 31) << 5) | (uint32_t)min(qGap >> 1, 30);      // (0xFFF = class 3, W 31, rows 31 is kept for YD_JKEY_NONE)
 }
 
 // lane per root: exact-match extensions of every joint (AlignHelpers.c:216-232), then the gap's kind (AlignExtFrag.cpp:190-231)

@@ -4,8 +4,8 @@
 // (diagonal, query offset) order.  k_expand_hits (seed.h) writes the hits of one (read, strand) -- one segment, a few thousand 64-bit keys --
 // in ascending query offset, so a STABLE sort on the 32 diagonal bits [15, 47) of the key finishes the job.  A segment of up to 16 384 keys
 // fits in a workgroup's registers and LDS: one read and one write of HBM per key instead of the library's digit passes over global memory.
-// Longer segments (repeat-rich reads) are first cut by diagonal into buckets that fit (k_seg_split); what still does not fit is left to
-// hipcub::DeviceSegmentedRadixSort through begin/end arrays that are empty for all others.
+// Longer segments (repeat-rich reads) are first cut by diagonal into buckets that fit (k_seg_split); a bucket that still does not fit is cut again by its OWN range of
+// diagonals (k_seg_split_range), level by level, until every piece fits or holds a single diagonal (then it is in order as it stands: the cuts are stable).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rocprim/block/block_radix_sort.hpp>
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, u
 
 // Size classes of the segments [segB[s], segE[s]): class c (0..YD_SEG_NCLASS-1) = at most hi[c] hits -> lists[c] (the workgroup sorts above: one launch per class
 // over exactly its segments; launching every class over all segments and letting the wrong ones leave cost 0.1 ms per 10 000 workgroups of 128 KB of LDS); longer
-// ones = the last class -> lists[YD_SEG_NCLASS], and begin/end offsets for the library's segmented sort (every other segment empty there).  Twelve workgroup
+// ones = the last class -> lists[YD_SEG_NCLASS] (bigB / bigE, when given: their begin / end, empty for every other segment).  Twelve workgroup
 // shapes (a sort costs what its shape holds, not what the segment has: with four shapes a segment filled its workgroup to 75 % on average).
 // counts[0..YD_SEG_NCLASS]; one atomic per wave and class.
 #define YD_SEG_NCLASS 12
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segB, cons
         if (len) { cls = YD_SEG_NCLASS;
 #pragma unroll
             for (int c = YD_SEG_NCLASS - 1; c >= 0; c--) if (len <= H.hi[c]) cls = c; }
-        bigB[s] = cls == YD_SEG_NCLASS ? b : 0u; bigE[s] = cls == YD_SEG_NCLASS ? e : 0u;
+        if (bigB) { bigB[s] = cls == YD_SEG_NCLASS ? b : 0u; bigE[s] = cls == YD_SEG_NCLASS ? e : 0u; }
     }
 #pragma unroll
     for (int c = 0; c <= YD_SEG_NCLASS; c++) {
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segB, cons
 // A long segment (more than 16 384 hits: 44 % of the hits of a repeat-rich batch) is cut by DIAGONAL into up to 16 buckets that fit the workgroup sort: one
 // stable counting pass by a workgroup per segment -- thread t owns a contiguous run of the segment's hits (count per bucket, exclusive scan over (bucket,
 // thread), scatter in order) -- instead of the library's four digit passes.  Bucket = the diagonal's top bits (monotone, so sorting the buckets one by one
-// sorts the segment); sub-segment sb * 16 + k = bucket k of the sb-th long segment.  A bucket that still exceeds the workgroup sort goes to the library.
+// sorts the segment); sub-segment sb * 16 + k = bucket k of the sb-th long segment.  A bucket that still exceeds the workgroup sort is cut again (k_seg_split_range).
 #define YD_SPLIT_NB 16
 __global__ void __launch_bounds__(1024) k_seg_split(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *bigList,
                                                     int diagBits, uint32_t *subB, uint32_t *subE)
@@ -127,17 +127,62 @@ __global__ void __launch_bounds__(1024) k_seg_split(const unsigned long long *in
         __builtin_amdgcn_wave_barrier();
     }
 }
-// begin/end of the listed sub-segments only (the library's segmented sort costs 0.3 ms over 56 k mostly empty segments, nothing over the nine that need it)
-__global__ void k_seg_gather_bounds(const uint32_t *segB, const uint32_t *segE, const uint32_t *list, uint32_t n, uint32_t *outB, uint32_t *outE)
+// A piece that is still too long for the workgroup sort after k_seg_split (a read inside a tandem repeat: tens of thousands of hits on neighbouring diagonals): cut
+// again into 16 buckets over the piece's OWN range of diagonals [mn, mx] -- bucket = (d - mn) * 16 / (mx - mn + 1), monotone; the first and the last bucket are never
+// empty, so every bucket is shorter than the piece, and the range a bucket spans shrinks sixteen-fold a level: at most eight levels for 32-bit diagonals.  A piece of ONE
+// diagonal (mn == mx) is in order already -- k_expand_hits wrote ascending query offsets and every cut so far was stable: it is copied to `final` as it stands and
+// gets no sub-pieces.  in -> out for the cut pieces (the caller sorts them out -> final or cuts them again), sub-piece sb * 16 + k = bucket k of the sb-th listed piece.
+__global__ void __launch_bounds__(1024) k_seg_split_range(const unsigned long long *in, unsigned long long *out, unsigned long long *final, const uint32_t *segB, const uint32_t *segE, const uint32_t *list,
+                                                          uint32_t *subB, uint32_t *subE)
 {
     YD_HIGH_PRIO();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { outB[i] = segB[list[i]]; outE[i] = segE[list[i]]; }
-}
-// sorted long sub-segments of the library path back to where the others are: dst[range] = src[range] for the listed sub-segments
-__global__ void k_seg_copy_back(const unsigned long long *src, unsigned long long *dst, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
-{
-    YD_HIGH_PRIO();
-    const uint32_t seg = list[blockIdx.x], b = segB[seg], e = segE[seg];
-    for (uint32_t k = b + threadIdx.x; k < e; k += blockDim.x) dst[k] = src[k];
+    __shared__ uint32_t sCnt[YD_SPLIT_NB][16]; __shared__ uint32_t sMin, sMax;
+    const uint32_t seg = list[blockIdx.x], b = segB[seg], len = segE[seg] - b, t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    if (t < YD_SPLIT_NB * 16u) sCnt[t >> 4][t & 15u] = 0u;
+    if (t == 0) { sMin = 0xFFFFFFFFu; sMax = 0u; }
+    __syncthreads();
+    { uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+      for (uint32_t k = t; k < len; k += 1024u) { const uint32_t d = (uint32_t)(in[b + k] >> 15); mn = min(mn, d); mx = max(mx, d); }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64)); }
+      if (lane == 0u) { atomicMin(&sMin, mn); atomicMax(&sMax, mx); } }
+    __syncthreads();
+    const uint32_t mn = sMin, mx = sMax;
+    if (mn == mx) {                                                          // (workgroup-uniform)
+        if (final != in) for (uint32_t k = t; k < len; k += 1024u) final[b + k] = in[b + k];
+        if (t < YD_SPLIT_NB) { subB[blockIdx.x * YD_SPLIT_NB + t] = b; subE[blockIdx.x * YD_SPLIT_NB + t] = b; }
+        return;
+    }
+    const unsigned long long range = (unsigned long long)(mx - mn) + 1ull;
+    auto bucket = [&](unsigned long long key) { return (uint32_t)((((unsigned long long)((uint32_t)(key >> 15) - mn)) * (unsigned long long)YD_SPLIT_NB) / range); };
+    const uint32_t per = ((len + 15u) / 16u + 63u) & ~63u, k0 = min(len, w * per), k1 = min(len, k0 + per);   // the wave's range, whole groups of 64 (as k_seg_split)
+    for (uint32_t k = k0 + lane; k < k1; k += 64u) atomicAdd(&sCnt[bucket(in[b + k])][w], 1u);
+    __syncthreads();
+    if (w == 0) {
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = sum; sum += (&sCnt[0][0])[4u * lane + (uint32_t)k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
+        const uint32_t excl = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) (&sCnt[0][0])[4u * lane + (uint32_t)k] = excl + v[k];
+    }
+    __syncthreads();
+    if (t < YD_SPLIT_NB) { subB[blockIdx.x * YD_SPLIT_NB + t] = b + sCnt[t][0]; subE[blockIdx.x * YD_SPLIT_NB + t] = t + 1u < YD_SPLIT_NB ? b + sCnt[t + 1u][0] : b + len; }
+    __syncthreads();
+    for (uint32_t g = k0; g < k1; g += 64u) {
+        const uint32_t k = g + lane; const bool live = k < k1;
+        const unsigned long long key = live ? in[b + k] : 0ull;
+        const uint32_t bk = live ? bucket(key) : 0u;
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int bit = 0; bit < 4; bit++) { const unsigned long long m = __ballot((bk >> bit) & 1u); peers &= ((bk >> bit) & 1u) ? m : ~m; }
+        const uint32_t rank = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
+        if (live) out[b + sCnt[bk][w] + rank] = key;
+        __builtin_amdgcn_wave_barrier();
+        if (live && rank == 0u) sCnt[bk][w] += (uint32_t)__builtin_popcountll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
 }

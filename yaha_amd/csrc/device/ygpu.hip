@@ -14,7 +14,6 @@
 //   results : clump records in QS->clumps order, ops arena, clump_start per read
 // Every stage is a handful of launches on one stream; sizes that the next stage needs cross the PCIe as single words.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <string>
 #include <vector>
 #include <cstring>
@@ -29,6 +28,7 @@
 #include "chain.h"
 #include "chain_lanes.h"
 #include "seed.h"
+#include "scan.h"
 #include "segsort.h"
 #include "phase_lanes.h"
 #include "gap_band_lanes.h"
@@ -63,7 +63,7 @@ struct DevBuf {
     int ensureExact(size_t bytes) { if (bytes <= cap) return 0; release(); void *np = nullptr; if (hipMalloc(&np, bytes) != hipSuccess) return -1; p = np; cap = bytes; return 0; }
     template <class T> T *as() const { return (T *)p; }
 };
-enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* YD_SEG_NCLASS + 1: the segments of the workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 16 /* + the look-back's flag */, CNT_NREG = CNT_NFRAGS + 2 /* + flag */, CNT_N = CNT_NREG + 4 };
+enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG, CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_SEGC /* YD_SEG_NCLASS + 1: the segments of the workgroup-sort classes, the long ones */, CNT_NFRAGS = CNT_SEGC + 16 /* + the look-back's flag */, CNT_NREG = CNT_NFRAGS + 2 /* + flag */, CNT_SCANFAIL = CNT_NREG + 2 /* raised by a look-back of scan.h that gave up */, CNT_N = CNT_NREG + 4 };
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_XROWS_PK, T_N };
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
@@ -81,8 +81,8 @@ struct ygpu_ctx {
     DevBuf bigB, bigE;
     DevBuf posS, posC, posRsI, hitOff, expandStart, keysA, keysB, segOff, isHead, tileState, frags, regStart, multiList, smallList, bigList, regionCount, regionBase;
     DevBuf clumps, clumpFrags, clumpFrags0, order, rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
-    DevBuf counters, ctr, errFlag, cubTemp, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
-    DevBuf segLists, subB, subE, subLists, subBigB, subBigE, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
+    DevBuf counters, ctr, errFlag, cubTemp, scanState, bucketWork, scratchAlign, scratchChain, dpProbs, dpRes, dpOps;
+    DevBuf segLists, subB, subE, subLists, subBigB, subBigE, sub2B, sub2E, sub2Lists, sub3B, sub3E, sub3Lists, kmerParts, rootState, stateOps, extProbs, rowsBound, stripOff, extRes, extTrace, chunkCnt, cubTemp2, memoKeys, memoCount, probs2, rowsBound2, stripOff2, extRes2, extTrace2, splitScratch, fallList, keys2a, keys2b, vals2a, vals2b, extKeys, extVals, extKeys2, extOrder, slowList, gapScratch, jointCount, jointBase, joints, sortKeys, sortVals, sortKeys2, sortVals2, gapOps;
     bool evUsed[16] = {false}; double traceT = 0; hipStream_t stream2 = nullptr; hipEvent_t evChunk[YD_MAX_CHUNK_EV], evTail; bool sharedIndex = false; bool counted = false; bool parked = false; long long traceBudgetBlocks = 0; uint32_t lastClumpSlots = 0; bool keepAllFrags = false; DevBuf rowsClock; unsigned long long hRowsClock[2] = {0, 0}; int laneChunks = 0; int segSort = 2; uint32_t segSortMax = YD_SEGSORT_MAX; int splitLanes = 1; int rows2PerCU = 0; int alignWavesPerCU = 0; int laneExt = 1; std::vector<unsigned long long> hStripOff; int runsDone = 0; double traceRatio = 0.0, opsRatio = 0.03; int statRanges = 0, statAttempts = 0; double statT0 = 0; DevBuf waveChunks, extOps, traceCnt;
     // post-filter stage (oqc_stage.h)
     DevBuf oqProf, oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
@@ -102,21 +102,31 @@ struct ygpu_ctx {
 static DevBatch devBatch(ygpu_ctx *c) { DevBatch b; b.fwd = c->dFwd.as<uint8_t>(); b.rev = c->dRev.as<uint8_t>(); b.readOff = c->dReadOff.as<uint32_t>(); b.nReads = c->nReads; return b; }
 static inline unsigned gridFor(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
-static int cubScan(ygpu_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n)
+// Exclusive sums and orderings of the hot path: scan.h (own kernels; one launch a scan, two an ordering; their work words clean themselves up)
+template <class T> static int ownScanT(ygpu_ctx *ctx, const T *in, T *out, uint32_t n, hipStream_t st)
 {
-    size_t bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
-    if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp.p, bytes, in, out, (int)n, ctx->stream));
+    if (n == 0) return 0;
+    const size_t need = scanStateBytes(n);
+    if (ctx->scanState.cap < need) {                                         // (zeroed when it is made; every launch leaves it zero)
+        if (ctx->scanState.ensure(std::max<size_t>(need, 1u << 16))) { ctx->err = "hipMalloc(scan state)"; return YGPU_ENOMEM; }
+        HIPCHK(hipMemsetAsync(ctx->scanState.p, 0, ctx->scanState.cap, st));
+    }
+    hipLaunchKernelGGL((k_scan_excl<T>), dim3(scanTiles(n)), dim3(YD_SCAN_BS), 0, st, in, out, n, ctx->scanState.as<unsigned long long>(), ctx->counters.as<unsigned int>() + CNT_SCANFAIL);
+    hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ctx->err = std::string("launch of k_scan_excl failed: ") + hipGetErrorString(e_); return YGPU_ENODEV; }
     return 0;
 }
-static int cubScan64(ygpu_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint32_t n, hipStream_t st = nullptr)
+static int cubScan(ygpu_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n) { return ownScanT<uint32_t>(ctx, in, out, n, ctx->stream); }
+static int cubScan64(ygpu_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint32_t n) { return ownScanT<unsigned long long>(ctx, in, out, n, ctx->stream); }
+// order[] = the items' values grouped by bucket((key - sub) >> shift), ascending; vals == nullptr: the values are the items' indices + valBase
+static int bucketOrder(ygpu_ctx *ctx, const uint32_t *keys, const uint32_t *vals, uint32_t valBase, uint32_t n, uint32_t sub, int shift, uint32_t nb, uint32_t *outVals, hipStream_t st)
 {
-    if (!st) st = ctx->stream;
-    size_t bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
-    if (ctx->cubTemp2.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cubTemp2.p, bytes, in, out, (int)n, st));
+    if (n == 0) return 0;
+    nb = std::min<uint32_t>(std::max<uint32_t>(nb, 1u), YD_BKT_MAX);
+    if (!ctx->bucketWork.p) { if (ctx->bucketWork.ensure(bucketWorkBytes())) { ctx->err = "hipMalloc(bucket work)"; return YGPU_ENOMEM; } HIPCHK(hipMemsetAsync(ctx->bucketWork.p, 0, ctx->bucketWork.cap, st)); }
+    const unsigned grid = (unsigned)((n + YD_BKT_TILE - 1) / YD_BKT_TILE);
+    hipLaunchKernelGGL(k_bucket_count, dim3(grid), dim3(YD_BKT_BS), 0, st, keys, n, sub, shift, nb, ctx->bucketWork.as<unsigned int>());
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(grid), dim3(YD_BKT_BS), 0, st, keys, vals, valBase, n, sub, shift, nb, ctx->bucketWork.as<unsigned int>(), outVals, (uint32_t *)nullptr);
+    hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ctx->err = std::string("launch of k_bucket_count / k_bucket_scatter failed: ") + hipGetErrorString(e_); return YGPU_ENODEV; }
     return 0;
 }
 #include <chrono>
@@ -181,15 +191,15 @@ static int stageSeed(ygpu_ctx *ctx)
     {
         // The sort is stable and k_expand_hits writes the hits of one (read, strand) in ascending query offset (k-mers in order, each
         // k-mer's reference offsets ascending), so two hits of one diagonal are already in qo order: the low 15 key bits need no pass.
-        // The hits of one (read, strand) are one segment: a segmented sort on the 32 diagonal bits only (short segments are sorted
-        // inside one workgroup, one pass over HBM) instead of a batch-wide sort that also has to order the (read, strand) bits.
-        if (ctx->segSort) {
+        // The hits of one (read, strand) are one segment: sorted on the 32 diagonal bits only, inside one workgroup (one pass over HBM), instead of a
+        // batch-wide sort that also has to order the (read, strand) bits.
+        {
             ENSURE(ctx->segOff, 4ull * (2 * n + 2));
             KL(k_seg_offsets, dim3(gridFor(2 * n + 1, 256)), dim3(256), 0, ctx->stream, ctx->dKmerOff.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), 2 * n, ctx->segOff.as<uint32_t>());
-            if (ctx->segSort >= 2) {
+            {
                 // segments of up to 16 384 hits: one workgroup each (segsort.h), in twelve size classes, one launch per class over exactly its segments
                 const unsigned long long *in = ctx->keysA.as<unsigned long long>(); unsigned long long *out = ctx->keysB.as<unsigned long long>(); const uint32_t *so = ctx->segOff.as<uint32_t>();
-                ENSURE(ctx->bigB, 4ull * (2 * n + 1)); ENSURE(ctx->bigE, 4ull * (2 * n + 1)); ENSURE(ctx->segLists, 4ull * (YD_SEG_NCLASS + 1) * (2 * n + 1));
+                ENSURE(ctx->segLists, 4ull * (YD_SEG_NCLASS + 1) * (2 * n + 1));
                 uint32_t *segCnt = ctx->counters.as<uint32_t>() + CNT_SEGC;
                 const uint32_t mx = ctx->segSortMax;                                  // YD_SEGSORT_MAX; lower only to drive the long-segment path in tests
                 // threads x hits a thread: 128 x 8, 128 x 16, 256 x 12 / 16, 512 x 10 / 12 / 14 / 16, 1024 x 10 / 12 / 14 / 16 (384 and 768 threads x 16 sorted slower than the next shape up)
@@ -206,7 +216,7 @@ static int stageSeed(ygpu_ctx *ctx)
                 };
                 HIPCHK(hipMemsetAsync(segCnt, 0, 4 * (YD_SEG_NCLASS + 1), ctx->stream));
                 uint32_t *lists = ctx->segLists.as<uint32_t>();
-                KL(k_seg_classify, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, so + 1, 2 * n, HI, lists, ctx->bigB.as<uint32_t>(), ctx->bigE.as<uint32_t>(), segCnt);
+                KL(k_seg_classify, dim3(gridFor(2 * n, 256)), dim3(256), 0, ctx->stream, so, so + 1, 2 * n, HI, lists, (uint32_t *)nullptr, (uint32_t *)nullptr, segCnt);
                 uint32_t nc[YD_SEG_NCLASS + 1] = {0}; rc = fetchU32(ctx, segCnt, nc, YD_SEG_NCLASS + 1); if (rc) return rc;
                 rc = sortClasses(in, out, so, so + 1, 2 * n, lists, nc); if (rc) return rc;
                 const uint32_t nBig = nc[YD_SEG_NCLASS];
@@ -216,42 +226,38 @@ static int stageSeed(ygpu_ctx *ctx)
                     for (int c = 0; c < YD_SEG_NCLASS; c++) fprintf(stderr, " <=%u: %.1f", HI.hi[c], 100.0 * cl[c] / H);
                     fprintf(stderr, "\n"); }
                 if (nBig) {
-                    // long segments: cut by diagonal into buckets that fit the workgroup sort (k_seg_split: keysA -> keysB), the buckets sorted in place; what still
-                    // does not fit (a bucket above the limit) goes through the library's segmented sort (keysB -> keysA) and is copied back
+                    // long segments: cut by diagonal into buckets that fit the workgroup sort (k_seg_split: keysA -> keysB), the buckets sorted in place
                     const uint32_t nSub = nBig * YD_SPLIT_NB;
-                    ENSURE(ctx->subB, 4ull * nSub + 64); ENSURE(ctx->subE, 4ull * nSub + 64); ENSURE(ctx->subLists, 4ull * (YD_SEG_NCLASS + 1) * nSub + 64); ENSURE(ctx->subBigB, 4ull * nSub + 64); ENSURE(ctx->subBigE, 4ull * nSub + 64);
+                    ENSURE(ctx->subB, 4ull * nSub + 64); ENSURE(ctx->subE, 4ull * nSub + 64); ENSURE(ctx->subLists, 4ull * (YD_SEG_NCLASS + 1) * nSub + 64);
                     int diagBits = 1; while (diagBits < 32 && (ctx->P.maxROff >> diagBits)) diagBits++;
                     uint32_t *sB = ctx->subB.as<uint32_t>(), *sE = ctx->subE.as<uint32_t>(), *l2 = ctx->subLists.as<uint32_t>();
                     KL(k_seg_split, dim3(nBig), dim3(1024), 0, ctx->stream, in, out, so, so + 1, lists + (size_t)YD_SEG_NCLASS * (2 * n), diagBits, sB, sE);
                     HIPCHK(hipMemsetAsync(segCnt, 0, 4 * (YD_SEG_NCLASS + 1), ctx->stream));
-                    KL(k_seg_classify, dim3(gridFor(nSub, 256)), dim3(256), 0, ctx->stream, sB, sE, nSub, HI, l2, ctx->subBigB.as<uint32_t>(), ctx->subBigE.as<uint32_t>(), segCnt);
+                    KL(k_seg_classify, dim3(gridFor(nSub, 256)), dim3(256), 0, ctx->stream, sB, sE, nSub, HI, l2, (uint32_t *)nullptr, (uint32_t *)nullptr, segCnt);
                     uint32_t ns[YD_SEG_NCLASS + 1] = {0}; rc = fetchU32(ctx, segCnt, ns, YD_SEG_NCLASS + 1); if (rc) return rc;
                     rc = sortClasses(out, out, sB, sE, nSub, l2, ns); if (rc) return rc;
-                    const uint32_t nLib = ns[YD_SEG_NCLASS];
-                    if (kTrace) { fprintf(stderr, "[ygpu] hit sort: %u long segments cut into buckets, by class:", nBig); for (int c = 0; c < YD_SEG_NCLASS; c++) fprintf(stderr, " %u", ns[c]); fprintf(stderr, "; %u left to the library\n", nLib); }
-                    if (nLib) {
-                        unsigned long long *tmp = ctx->keysA.as<unsigned long long>();
-                        uint32_t *cB = ctx->subBigB.as<uint32_t>(), *cE = ctx->subBigE.as<uint32_t>();           // compact bounds of the buckets that did not fit
-                        KL(k_seg_gather_bounds, dim3(gridFor(nLib, 256)), dim3(256), 0, ctx->stream, sB, sE, l2 + (size_t)YD_SEG_NCLASS * nSub, nLib, cB, cE);
-                        size_t bytes = 0;
-                        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, (const unsigned long long *)out, tmp, (int)H, (int)nLib, cB, cE, 15, 47, ctx->stream));
-                        if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-                        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, (const unsigned long long *)out, tmp, (int)H, (int)nLib, cB, cE, 15, 47, ctx->stream));
-                        KL(k_seg_copy_back, dim3(nLib), dim3(256), 0, ctx->stream, tmp, out, sB, sE, l2 + (size_t)YD_SEG_NCLASS * nSub);
+                    // pieces that still do not fit: cut again over their own range of diagonals, level by level (segsort.h: k_seg_split_range), until every piece
+                    // fits the workgroup sort or holds one diagonal only.  Level L reads the pieces where level L-1 left them (keysB after the first cut, then
+                    // keysA / keysB in turn) and sorts what fits into keysB.
+                    uint32_t nOver = ns[YD_SEG_NCLASS]; const uint32_t *oB = sB, *oE = sE, *oList = l2 + (size_t)YD_SEG_NCLASS * nSub;
+                    const unsigned long long *cur = out; unsigned long long *other = ctx->keysA.as<unsigned long long>();
+                    if (kTrace) { fprintf(stderr, "[ygpu] hit sort: %u long segments cut into buckets, by class:", nBig); for (int c = 0; c < YD_SEG_NCLASS; c++) fprintf(stderr, " %u", ns[c]); fprintf(stderr, "; %u to be cut again\n", nOver); }
+                    for (int level = 0; nOver; level++) {
+                        if (level >= 12) { ctx->err = "hit sort: a segment does not fit the workgroup sort after twelve cuts"; return YGPU_EINTERNAL; }
+                        DevBuf &xB = level & 1 ? ctx->sub3B : ctx->sub2B, &xE = level & 1 ? ctx->sub3E : ctx->sub2E, &xL = level & 1 ? ctx->sub3Lists : ctx->sub2Lists;
+                        const uint32_t nSub2 = nOver * YD_SPLIT_NB;
+                        ENSURE(xB, 4ull * nSub2 + 64); ENSURE(xE, 4ull * nSub2 + 64); ENSURE(xL, 4ull * (YD_SEG_NCLASS + 1) * nSub2 + 64);
+                        KL(k_seg_split_range, dim3(nOver), dim3(1024), 0, ctx->stream, cur, other, out, oB, oE, oList, xB.as<uint32_t>(), xE.as<uint32_t>());
+                        HIPCHK(hipMemsetAsync(segCnt, 0, 4 * (YD_SEG_NCLASS + 1), ctx->stream));
+                        KL(k_seg_classify, dim3(gridFor(nSub2, 256)), dim3(256), 0, ctx->stream, xB.as<uint32_t>(), xE.as<uint32_t>(), nSub2, HI, xL.as<uint32_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, segCnt);
+                        uint32_t n3[YD_SEG_NCLASS + 1] = {0}; rc = fetchU32(ctx, segCnt, n3, YD_SEG_NCLASS + 1); if (rc) return rc;
+                        rc = sortClasses(other, out, xB.as<uint32_t>(), xE.as<uint32_t>(), nSub2, xL.as<uint32_t>(), n3); if (rc) return rc;
+                        if (kTrace) fprintf(stderr, "[ygpu] hit sort: cut %d: %u pieces cut again, %u of their buckets still too long\n", level + 2, nOver, n3[YD_SEG_NCLASS]);
+                        nOver = n3[YD_SEG_NCLASS]; oB = xB.as<uint32_t>(); oE = xE.as<uint32_t>(); oList = xL.as<uint32_t>() + (size_t)YD_SEG_NCLASS * nSub2;
+                        const unsigned long long *was = cur; cur = other; other = (unsigned long long *)was;
                     }
                 }
-            } else {
-            size_t bytes = 0;
-            HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, (int)(2 * n), ctx->segOff.as<uint32_t>(), ctx->segOff.as<uint32_t>() + 1, 15, 47, ctx->stream));
-            if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-            HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(ctx->cubTemp.p, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, (int)(2 * n), ctx->segOff.as<uint32_t>(), ctx->segOff.as<uint32_t>() + 1, 15, 47, ctx->stream));
             }
-        } else {
-        int rsBits = 1; while ((1u << rsBits) < 2 * n) rsBits++;
-        size_t bytes = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 15, 47 + rsBits, ctx->stream));
-        if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(ctx->cubTemp.p, bytes, ctx->keysA.as<unsigned long long>(), ctx->keysB.as<unsigned long long>(), (int)H, 15, 47 + rsBits, ctx->stream));
         }
     }
     EV1(T_SORT);
@@ -411,10 +417,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 12, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NB12, 0, 8, ctx->stream));      // ndp, ndp16, gapops; nb12, nb16
     if (J) {
         KL(k_p1_joints, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
-        size_t bytes = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, YD_JKEY_BITS, ctx->stream));
-        if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, X.sortKeys, ctx->sortKeys2.as<uint32_t>(), X.sortVals, ctx->sortVals2.as<uint32_t>(), (int)J, 0, YD_JKEY_BITS, ctx->stream));
+        rc = bucketOrder(ctx, X.sortKeys, X.sortVals, 0, J, 0, 0, 1u << YD_JKEY_BITS, ctx->sortVals2.as<uint32_t>(), ctx->stream); if (rc) return rc;      // joints of one (class, width, rows / 2) together
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 6);   // 17 / 26 KB of LDS per 64-thread block
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
         KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
@@ -547,12 +550,11 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         E.queue = cc + 8 * c;
         HIPCHK(hipMemsetAsync(ctx->traceCnt.p, 0, 4, ctx->stream));          // the arena starts empty for every range (the previous one's lists are in the ops arena)
         HIPCHK(hipMemsetAsync(E.res, 0, sizeof(ExtRes) * (uint64_t)np, ctx->stream));   // a launch that runs out of arena leaves problems unfinished: they must read as "no extension", not as the last batch's results
-        {   // longest bound first: the launch's drain phase is then left with short problems only
-            size_t bytes = 0; uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, 16, ctx->stream));
-            if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, 16, ctx->stream));
-            KL(k_rebase_u32, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, v1, np, p0);
+        {   // longest bound first: the launch's drain phase is then left with short problems only.  Keys 0xFFFF - qLen (invalid: 0xFFFF, last): one bucket per
+            // length while the longest read has fewer than 4 096 bases, per 2^k lengths beyond; the values are the problems' indices inside the range
+            const uint32_t sub = 0xFFFFu - (uint32_t)std::min(ctx->maxQ, 0xFFFF); int shift = 0; while (((uint32_t)ctx->maxQ >> shift) >= YD_BKT_MAX - 1u) shift++;
+            uint32_t *v1 = ctx->extOrder.as<uint32_t>() + p0;
+            rc = bucketOrder(ctx, ctx->extKeys.as<uint32_t>() + p0, nullptr, 0, np, sub, shift, ((uint32_t)ctx->maxQ >> shift) + 2u, v1, ctx->stream); if (rc) return rc;
             E.order = v1;
         }
         const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + 255) / 256, (uint64_t)maxBlocksK);
@@ -571,15 +573,12 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             fprintf(stderr, "[ygpu] walk length histogram (0..7, 8.., 16.., 32.., 64.., 128.., 256.., 512..):"); for (int b = 0; b < 8; b++) fprintf(stderr, " %llu", hist[b]); fprintf(stderr, "\n");
         }
         if (traceSort > 0 && np > 4096u) {                                    // traceback order: by arena region, then by walk length (k_trace_keys)
-            uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *k1 = ctx->extKeys2.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *v1 = ctx->extOrder.as<uint32_t>() + p0;
+            uint32_t *k0 = ctx->extKeys.as<uint32_t>() + p0, *v0 = ctx->extVals.as<uint32_t>() + p0, *v1 = ctx->extKeys2.as<uint32_t>() + p0;      // (v1: not extOrder, which k_trace_keys reads)
             static const int lenBits = getenv("YGPU_TRACE_LENBITS") ? std::min(8, std::max(1, atoi(getenv("YGPU_TRACE_LENBITS")))) : 7;
             int lenShift = 0; while ((ctx->maxQ >> lenShift) > (1 << lenBits) - 1) lenShift++;
             int keyBits = lenBits; while (keyBits < 32 && ((unsigned long long)E.nChunks >> std::min(traceSort, 31)) >> (keyBits - lenBits)) keyBits++;        // region bits above the length bits
             KL(k_trace_keys, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E.res, E.order, np, E.waveChunks, E.maxCh, std::min(traceSort, 31), lenShift, lenBits, k0, v0);
-            size_t bytes = 0;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, v0, v1, (int)np, 0, keyBits, ctx->stream));
-            if (ctx->cubTemp.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp.p, bytes, k0, k1, v0, v1, (int)np, 0, keyBits, ctx->stream));
+            rc = bucketOrder(ctx, k0, v0, 0, np, 0, std::max(0, keyBits - 12), 1u << std::min(keyBits, 12), v1, ctx->stream); if (rc) return rc;
             E.order = v1;
         }
         KL(traceKernel, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E);
@@ -620,10 +619,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                     {   // longest bound first here too: this launch is small and ends when its longest problem ends
                         ENSURE(ctx->keys2a, 4ull * (cap2 + 1)); ENSURE(ctx->keys2b, 4ull * (cap2 + 1)); ENSURE(ctx->vals2a, 4ull * (cap2 + 1)); ENSURE(ctx->vals2b, 4ull * (cap2 + 1));
                         KL(k_prob_keys, dim3(gridFor(n2, 256)), dim3(256), 0, ctx->stream, ctx->probs2.as<ExtProb>(), n2, ctx->keys2a.as<uint32_t>(), ctx->vals2a.as<uint32_t>());
-                        size_t bytes = 0;
-                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 16, ctx->stream));
-                        if (ctx->cubTemp2.ensure(bytes)) { ctx->err = "hipMalloc(cub temp)"; return YGPU_ENOMEM; }
-                        HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cubTemp2.p, bytes, ctx->keys2a.as<uint32_t>(), ctx->keys2b.as<uint32_t>(), ctx->vals2a.as<uint32_t>(), ctx->vals2b.as<uint32_t>(), (int)n2, 0, 16, ctx->stream));
+                        { const uint32_t sub = 0xFFFFu - (uint32_t)std::min(ctx->maxQ, 0xFFFF); int shift = 0; while (((uint32_t)ctx->maxQ >> shift) >= YD_BKT_MAX - 1u) shift++;
+                          rc = bucketOrder(ctx, ctx->keys2a.as<uint32_t>(), nullptr, 0, n2, sub, shift, ((uint32_t)ctx->maxQ >> shift) + 2u, ctx->vals2b.as<uint32_t>(), ctx->stream); if (rc) return rc; }
                     }
                     E2.order = ctx->vals2b.as<uint32_t>(); E2.res = ctx->extRes2.as<ExtRes>(); E2.queue = cc + 8 * c + 4; E2.ctr = nullptr;   // counted by k_split_lanes
                     {   // a small launch: a few problems per lane, so its length is set by the lanes' chains of problems, not by the chip's throughput.  One wave
@@ -773,7 +770,9 @@ static int runTo(ygpu_ctx *ctx, int stage)
     if (ctx->stageDone < 1) { rc = stageSeed(ctx); if (rc) return rc; EV0(T_FRAGS); rc = buildFrags(ctx); if (rc) return rc; if (!ctx->nFrags) EV1(T_FRAGS); ctx->stageDone = 1; }
     if (stage >= 2 && ctx->stageDone < 2) { if (ctx->nFrags) { rc = stageChain(ctx); if (rc) return rc; } ctx->stageDone = 2; }
     if (stage >= 3 && ctx->stageDone < 3) { rc = stageAlign(ctx); if (rc) return rc; ctx->stageDone = 3; }
-    HIPCHK(streamSync(ctx));
+    // (the stream is drained by this fetch: the flag a look-back of scan.h raises when a tile never showed up -- the state words are then made clean again)
+    uint32_t scanFail = 0; rc = fetchU32(ctx, ctx->counters.as<uint32_t>() + CNT_SCANFAIL, &scanFail); if (rc) return rc;
+    if (scanFail) { if (ctx->scanState.p) HIPCHK(hipMemsetAsync(ctx->scanState.p, 0, ctx->scanState.cap, ctx->stream)); ctx->err = "exclusive sum: a tile was not published within 30 s (look-back gave up)"; return YGPU_EINTERNAL; }
     return 0;
 }
 
@@ -791,8 +790,7 @@ static int initCommon(ygpu_ctx *ctx, int device)
     HIPCHK(hipEventCreateWithFlags(&ctx->evTail, hipEventDisableTiming));
     if (const char *e = getenv("YGPU_LANE_CHUNKS")) ctx->laneChunks = atoi(e);
     if (const char *e = getenv("YGPU_TRACE_BUDGET_BLOCKS")) ctx->traceBudgetBlocks = atoll(e);
-    if (const char *e = getenv("YGPU_SEG_SORT")) ctx->segSort = atoi(e);
-    if (const char *e = getenv("YGPU_SEGSORT_MAX")) { long v = atol(e); if (v >= 1 && v <= (long)YD_SEGSORT_MAX) ctx->segSortMax = (uint32_t)v; }
+        if (const char *e = getenv("YGPU_SEGSORT_MAX")) { long v = atol(e); if (v >= 1 && v <= (long)YD_SEGSORT_MAX) ctx->segSortMax = (uint32_t)v; }
     if (const char *e = getenv("YGPU_SPLIT_LANES")) ctx->splitLanes = atoi(e);
     if (const char *e = getenv("YGPU_ROWS2_PER_CU")) ctx->rows2PerCU = atoi(e);
     if (const char *e = getenv("YGPU_ALIGN_WAVES")) ctx->alignWavesPerCU = atoi(e);
@@ -1020,8 +1018,8 @@ static std::vector<DevBuf *> allBuffers(ygpu_ctx *ctx)
 {
     DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dFwd4, &ctx->dRev4, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC, &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->tileState,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
-                         &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scratchAlign,
-                         &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
+                         &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scanState, &ctx->bucketWork, &ctx->scratchAlign,
+                         &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->sub2B, &ctx->sub2E, &ctx->sub2Lists, &ctx->sub3B, &ctx->sub3E, &ctx->sub3Lists, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
                          &ctx->oqProf, &ctx->oqLists, &ctx->oqClsCnt, &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
     return std::vector<DevBuf *>(all, all + sizeof all / sizeof all[0]);
 }
@@ -1245,6 +1243,46 @@ int ygpu_postfilter(ygpu_ctx *ctx)
         }
     }
     ctx->oqDone = true;
+    return 0;
+}
+/* Stage-level test entry for the path's own exclusive sums and orderings (scan.h): n pseudo-random elements from `seed` -- a u32 sum, a u64 sum whose values pass
+ * 2^32, an in-place sum, and an ordering by a `key_bits`-bit key (with an offset and, above 12 bits, a shift) -- each checked against the plain host loop. */
+int ygpu_selftest_primitives(ygpu_ctx *ctx, uint32_t n, uint32_t seed, int key_bits)
+{
+    if (!ctx || !ctx->stream || n == 0 || key_bits < 1 || key_bits > 16) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1; auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    std::vector<uint32_t> h32(n), o32(n); std::vector<unsigned long long> h64(n), o64(n);
+    for (uint32_t i = 0; i < n; i++) { const uint64_t r = rnd(); h32[i] = (uint32_t)(r % 97u) * ((r >> 40) % 5u == 0 ? 1000u : 1u); h64[i] = (r >> 8) % (1ull << 36); }
+    DevBuf a, b; struct Rel { DevBuf &a, &b; ~Rel() { a.release(); b.release(); } } rel{a, b};
+    if (a.ensure(8ull * n + 64) || b.ensure(8ull * n + 64)) { ctx->err = "hipMalloc failed"; return YGPU_ENOMEM; }
+    auto fail = [&](const char *what, uint64_t at) { char m[160]; snprintf(m, sizeof m, "selftest: %s differs from the host at element %llu of %u", what, (unsigned long long)at, n); ctx->err = m; return YGPU_EINTERNAL; };
+    int rc;
+    HIPCHK(hipMemcpyAsync(a.p, h32.data(), 4ull * n, hipMemcpyHostToDevice, ctx->stream));
+    rc = cubScan(ctx, a.as<uint32_t>(), b.as<uint32_t>(), n); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(o32.data(), b.p, 4ull * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+    { uint32_t sum = 0; for (uint32_t i = 0; i < n; i++) { if (o32[i] != sum) return fail("the u32 sum", i); sum += h32[i]; } }
+    rc = cubScan(ctx, a.as<uint32_t>(), a.as<uint32_t>(), n); if (rc) return rc;                                   // in place
+    HIPCHK(hipMemcpyAsync(o32.data(), a.p, 4ull * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+    { uint32_t sum = 0; for (uint32_t i = 0; i < n; i++) { if (o32[i] != sum) return fail("the in-place u32 sum", i); sum += h32[i]; } }
+    HIPCHK(hipMemcpyAsync(a.p, h64.data(), 8ull * n, hipMemcpyHostToDevice, ctx->stream));
+    rc = cubScan64(ctx, a.as<unsigned long long>(), b.as<unsigned long long>(), n); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(o64.data(), b.p, 8ull * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+    { unsigned long long sum = 0; for (uint32_t i = 0; i < n; i++) { if (o64[i] != sum) return fail("the u64 sum", i); sum += h64[i]; } }
+    // ordering: keys in [sub, sub + 2^key_bits), values = indices + 7; shift as the callers choose it (at most 4 096 buckets)
+    const uint32_t sub = 1000u, span = 1u << key_bits; const int shift = std::max(0, key_bits - 12); const uint32_t nb = (span >> shift) + 1u;
+    for (uint32_t i = 0; i < n; i++) { const uint64_t r = rnd(); h32[i] = sub + (uint32_t)((r >> 20) % span) / ((r & 3u) == 0 ? 7u : 1u); }      // (skewed: some buckets crowded)
+    HIPCHK(hipMemcpyAsync(a.p, h32.data(), 4ull * n, hipMemcpyHostToDevice, ctx->stream));
+    rc = bucketOrder(ctx, a.as<uint32_t>(), nullptr, 7u, n, sub, shift, nb, b.as<uint32_t>(), ctx->stream); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(o32.data(), b.p, 4ull * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+    { std::vector<uint8_t> seen(n, 0); uint32_t last = 0;
+      for (uint32_t i = 0; i < n; i++) { const uint32_t v = o32[i] - 7u; if (v >= n || seen[v]) return fail("the ordering (not a permutation)", i); seen[v] = 1; const uint32_t bk = std::min((h32[v] - sub) >> shift, nb - 1u); if (bk < last) return fail("the ordering (buckets not ascending)", i); last = bk; } }
+    // and once more right away: the work words of both must have cleaned themselves up
+    rc = bucketOrder(ctx, a.as<uint32_t>(), nullptr, 7u, n, sub, shift, nb, b.as<uint32_t>(), ctx->stream); if (rc) return rc;
+    std::vector<uint32_t> again(n); HIPCHK(hipMemcpyAsync(again.data(), b.p, 4ull * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+    { uint32_t last = 0; for (uint32_t i = 0; i < n; i++) { const uint32_t v = again[i] - 7u; if (v >= n) return fail("the second ordering", i); const uint32_t bk = std::min((h32[v] - sub) >> shift, nb - 1u); if (bk < last) return fail("the second ordering (buckets not ascending)", i); last = bk; } }
+    uint32_t sf = 0; rc = fetchU32(ctx, ctx->counters.as<uint32_t>() + CNT_SCANFAIL, &sf); if (rc) return rc;
+    if (sf) { ctx->err = "selftest: a look-back gave up"; return YGPU_EINTERNAL; }
     return 0;
 }
 int ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r)
