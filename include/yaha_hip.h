@@ -136,6 +136,16 @@ int  ygpu_memory(ygpu_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes, uin
  * contexts that share the device's memory budget, so that the contexts that do run are not held to a share sized for it.  The reference has no counterpart -- a
  * thread of Query.c:642-690 that cannot allocate its QueryState is fatal (FragsClumps.c:74).  The context can only be destroyed afterwards. */
 int  ygpu_park(ygpu_ctx *ctx);
+/* The capacities of a context's arenas and the estimates it carries from batch to batch (trace rows per bound row, clump slots ...), as they stand after a batch;
+ * ygpu_presize gives another context of the same build the same capacities in one go and seeds its estimates, so that its first batch runs like any later one
+ * instead of growing a hundred buffers one by one (each growth frees a buffer, and a free waits for every kernel on the device: first batches used to run one
+ * at a time with the device's other contexts held back).  The reference's per-thread QueryState grows lazily as well (Query.c:81-100, 313); its threads do not
+ * share an allocator that stalls the others. */
+typedef struct ygpu_arena_profile {
+    uint32_t n; uint32_t last_clump_slots; uint64_t cap[224]; double trace_ratio, ops_ratio; int64_t last_fall; uint64_t bases;
+} ygpu_arena_profile;
+int  ygpu_get_arena_profile(ygpu_ctx *ctx, ygpu_arena_profile *out);
+int  ygpu_presize(ygpu_ctx *ctx, const ygpu_arena_profile *profile);
 
 /* Stage reads into HBM (H2D).  Separate from ygpu_run so that a benchmark can time the hot path with inputs
  * already resident. */

@@ -45,6 +45,9 @@ int ygpu_memory(ygpu_ctx *, uint64_t *f, uint64_t *t, uint64_t *m)
 }
 static std::atomic<int> gParked(0);
 int ygpu_park(ygpu_ctx *) { gParked++; return 0; }
+static std::atomic<int> gPresized(0);
+int ygpu_get_arena_profile(ygpu_ctx *, ygpu_arena_profile *p) { memset(p, 0, sizeof *p); p->n = 3; p->cap[0] = 1 << 20; return 0; }
+int ygpu_presize(ygpu_ctx *, const ygpu_arena_profile *p) { if (p->n != 3) return YGPU_EINVAL; gPresized++; if (const char *ms = getenv("YTEST_PRESIZE_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(ms))); return 0; }
 const char *ygpu_last_error(const ygpu_ctx *c) { return c ? c->err.c_str() : "no context"; }
 int ygpu_upload(ygpu_ctx *c, const ygpu_read_batch *b)
 {

@@ -11,6 +11,8 @@ int  ygpu_clone(const ygpu_ctx *, ygpu_ctx **out) { if (out) *out = nullptr; ret
 void ygpu_destroy(ygpu_ctx *) {}
 int  ygpu_memory(ygpu_ctx *, uint64_t *, uint64_t *, uint64_t *) { return YGPU_ENODEV; }
 int  ygpu_park(ygpu_ctx *) { return YGPU_ENODEV; }
+int  ygpu_get_arena_profile(ygpu_ctx *, ygpu_arena_profile *) { return YGPU_ENODEV; }
+int  ygpu_presize(ygpu_ctx *, const ygpu_arena_profile *) { return YGPU_ENODEV; }
 const char *ygpu_last_error(const ygpu_ctx *) { return "sanitizer build of the host stages: no device code linked"; }
 int  ygpu_upload(ygpu_ctx *, const ygpu_read_batch *) { return YGPU_ENODEV; }
 int  ygpu_run(ygpu_ctx *) { return YGPU_ENODEV; }

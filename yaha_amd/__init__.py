@@ -81,11 +81,15 @@ class FilteredBatch(C.Structure):
                 ("n_clumps", C.c_uint64), ("n_ops", C.c_uint64), ("counters", Counters)]
 
 
+class ArenaProfile(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("last_clump_slots", C.c_uint32), ("cap", C.c_uint64 * 224), ("trace_ratio", C.c_double), ("ops_ratio", C.c_double), ("last_fall", C.c_int64), ("bases", C.c_uint64)]
+
+
 DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
 DP_KERNELS_AUTO, DP_KERNELS_WAVE, DP_KERNELS_LANES, DP_KERNELS_LANES_CAREFUL = 0, 1, 2, 3
 
 EXPORTS = (
-    "ygpu_device_count", "ygpu_init", "ygpu_init_multi", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_memory", "ygpu_park", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter", "ygpu_inject_results", "ygpu_selftest_primitives", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
+    "ygpu_device_count", "ygpu_init", "ygpu_init_multi", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_memory", "ygpu_park", "ygpu_get_arena_profile", "ygpu_presize", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter", "ygpu_inject_results", "ygpu_selftest_primitives", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
     "ygpu_submit", "ygpu_poll", "ygpu_wait", "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch", "ygpu_dp_batch_ex",
     "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
     "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit", "yaha_session_postfilter_params", "yaha_session_emit_filtered",
@@ -222,6 +226,16 @@ class Context:
     def selftest_primitives(self, n, seed=1, key_bits=8):
         """The path's own exclusive sums and orderings (device/scan.h) against the host's loops (ygpu_selftest_primitives); raises on a difference."""
         self._check(lib().ygpu_selftest_primitives(self._h, C.c_uint32(n), C.c_uint32(seed), C.c_int(key_bits)), "ygpu_selftest_primitives")
+
+    def arena_profile(self):
+        """Capacities of this context's arenas and its batch-to-batch estimates (ygpu_get_arena_profile)."""
+        p = ArenaProfile()
+        self._check(lib().ygpu_get_arena_profile(self._h, C.byref(p)), "ygpu_get_arena_profile")
+        return p
+
+    def presize(self, profile):
+        """Give this context the arenas of `profile` in one go (ygpu_presize)."""
+        self._check(lib().ygpu_presize(self._h, C.byref(profile)), "ygpu_presize")
 
     def park(self):
         """Release this context's arenas and its share of the device's memory budget (ygpu_park); it can only be closed afterwards."""

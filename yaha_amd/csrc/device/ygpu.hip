@@ -88,6 +88,7 @@ struct ygpu_ctx {
     DevBuf oqProf, oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
     bool oqSet = false, oqDone = false; yoqc::Params oqP{}; yoqc::Seqs oqG{}; uint32_t nFOut = 0, nFOps = 0;
     // stage state
+    uint32_t hOutCounts[2] = {0, 0}, hOutEf = 0; bool hOutValid = false;
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
     // host results
@@ -156,6 +157,18 @@ static int fetchU32(ygpu_ctx *ctx, const void *dptr, uint32_t *out, size_t n = 1
         memcpy(out, ctx->pinned, 4 * n); return 0;
     }
     HIPCHK(hipMemcpyAsync(out, dptr, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx)); return 0;
+}
+
+// several small pieces in ONE wait (the copies queue up behind the kernels, one event is waited for): every wait of the host is a gap on the device when one context runs alone
+struct FetchPiece { const void *src; uint32_t *dst; uint32_t n; };
+static int fetchMany(ygpu_ctx *ctx, const FetchPiece *pc, int np)
+{
+    uint32_t tot = 0; for (int k = 0; k < np; k++) tot += pc[k].n;
+    if (!ctx->pinned || tot > 64) { for (int k = 0; k < np; k++) { int rc = fetchU32(ctx, pc[k].src, pc[k].dst, pc[k].n); if (rc) return rc; } return 0; }
+    uint32_t o = 0; for (int k = 0; k < np; k++) { HIPCHK(hipMemcpyAsync(ctx->pinned + o, pc[k].src, 4ull * pc[k].n, hipMemcpyDeviceToHost, ctx->stream)); o += pc[k].n; }
+    HIPCHK(streamSync(ctx));
+    o = 0; for (int k = 0; k < np; k++) { memcpy(pc[k].dst, ctx->pinned + o, 4ull * pc[k].n); o += pc[k].n; }
+    return 0;
 }
 
 // ---- A1 + A2 (+ fragment array) --------------------------------------------------------------------------------
@@ -312,10 +325,9 @@ static int stageChain(ygpu_ctx *ctx)
     HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NBIG, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NSMALL, 0, 4, ctx->stream));
     KL(k_region_classify, dim3(gridFor(R, 1024)), dim3(1024), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN, ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG, ctx->smallList.as<uint32_t>(), cnt + CNT_NSMALL);
-    uint32_t two[2] = {0, 0}; rc = fetchU32(ctx, cnt + CNT_NMULTI, two, 2); if (rc) return rc;
+    uint32_t two[2] = {0, 0};
+    { const FetchPiece pc[3] = {{cnt + CNT_NMULTI, two, 2}, {cnt + CNT_NBIG, &ctx->nBig, 1}, {cnt + CNT_NSMALL, &ctx->nSmall, 1}}; rc = fetchMany(ctx, pc, 3); if (rc) return rc; }
     ctx->nMulti = two[0]; ctx->maxN = two[1];
-    rc = fetchU32(ctx, cnt + CNT_NBIG, &ctx->nBig); if (rc) return rc;
-    rc = fetchU32(ctx, cnt + CNT_NSMALL, &ctx->nSmall); if (rc) return rc;
     EV1(T_FRAGS);
 
     EV0(T_CHAIN);
@@ -345,16 +357,17 @@ static int stageChain(ygpu_ctx *ctx)
         if (ctx->nSmall) KL(k_chain_lanes, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nSmall, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, A, ctx->smallList.as<uint32_t>(), ctx->nSmall);
         if (ctx->nMulti) KL(k_chain, dim3(waves), dim3(64), 0, ctx->stream, A);
         if (ctx->nBig) KL(k_chain_big, dim3(wavesBig), dim3(64), 0, ctx->stream, A, ctx->bigList.as<uint32_t>(), ctx->nBig, cnt + CNT_QBIG);
-        uint32_t got[2]; rc = fetchU32(ctx, cnt + CNT_CLUMPS, got, 2); if (rc) return rc;
-        uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+        // creation-order rank of every root clump: the sum over the regions' counts is launched before anybody knows whether the attempt fitted -- an attempt that did not
+        // is redone, sum included -- so that the counts, the error flag and the number of clumps cross in ONE wait
+        rc = cubScan(ctx, ctx->regionCount.as<uint32_t>(), ctx->regionBase.as<uint32_t>(), R + 1); if (rc) return rc;
+        uint32_t got[2] = {0, 0}, ef = 0;
+        { const FetchPiece pc[3] = {{cnt + CNT_CLUMPS, got, 2}, {ctx->errFlag.p, &ef, 1}, {ctx->regionBase.as<uint32_t>() + R, &ctx->nClumps, 1}}; rc = fetchMany(ctx, pc, 3); if (rc) return rc; }
         if (ef == 0 && got[0] <= clumpCap && got[1] <= fragCap) { ctx->nClumpSlots = got[0]; ctx->nClumpFrags = got[1]; ctx->lastClumpSlots = got[0]; break; }
         if (attempt >= 6) { ctx->err = "chain stage: arena overflow persists"; return YGPU_EOVERFLOW; }
         if (clumpCap < clumpCapFull) clumpCap = clumpCapFull; else { clumpCap *= 2; fragCap *= 2; }      // grow and redo: the fragment array was modified in place
         rc = buildFrags(ctx, true); if (rc) return rc;
     }
-    // creation-order rank of every root clump
-    rc = cubScan(ctx, ctx->regionCount.as<uint32_t>(), ctx->regionBase.as<uint32_t>(), R + 1); if (rc) return rc;
-    rc = fetchU32(ctx, ctx->regionBase.as<uint32_t>() + R, &ctx->nClumps); if (rc) return rc;          // clumps actually formed (slots minus chunk slack)
+    // (ctx->nClumps: clumps actually formed -- slots minus chunk slack)
     ENSURE(ctx->order, 4ull * (ctx->nClumps + 1));
     if (ctx->nClumpSlots) KL(k_clump_order, dim3(gridFor(ctx->nClumpSlots, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->nClumpSlots, ctx->regionBase.as<uint32_t>(), ctx->order.as<uint32_t>());
     EV1(T_CHAIN);
@@ -661,7 +674,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     HIPCHK(hipMemcpyAsync(ctx->hRowsClock, ctx->rowsClock.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     // errors of the trace memory: grow what overflowed and have the caller redo the stage
     unsigned int usedOps = 0; HIPCHK(hipMemcpyAsync(&usedOps, ctx->traceCnt.as<unsigned int>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
+    { const FetchPiece pc[2] = {{ctx->errFlag.p, &ef, 1}, {cnt + CNT_OUTCLUMPS, ctx->hOutCounts, 2}}; rc = fetchMany(ctx, pc, 2); if (rc) return rc; }      // (stageAlign reads the output counts from here)
+    ctx->hOutEf = ef; ctx->hOutValid = true;
     if (ctx->splitLanes) ctx->lastFall = (long long)ctx->hFall;              // (the fetch above synchronised the stream)
     if (ef == YERR_TRACEMEM) {
         if (ctx->traceRatio >= 64.0) { ctx->err = "the extension trace arena overflows even at 64 times the problems' bound"; return YGPU_ENOMEM; }
@@ -727,7 +741,7 @@ static int stageAlign(ygpu_ctx *ctx)
 #ifdef YD_PROF
             { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); }
 #endif
-            bool laneOverflow = false, traceOverflow = false;
+            bool laneOverflow = false, traceOverflow = false; ctx->hOutValid = false;
             if (!useLanes) KL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
             else { rc = alignWithLaneExtensions(ctx, A, waves, stateOpsCap, gapOpsPerJoint); if (rc == -2) laneOverflow = true; else if (rc == -3) traceOverflow = true; else if (rc) return rc; }
 #ifdef YD_PROF
@@ -737,7 +751,8 @@ static int stageAlign(ygpu_ctx *ctx)
 #endif
             uint32_t got[2] = {0, 0}, ef = 0;
             if (laneOverflow || traceOverflow) ef = YERR_OUT;
-            else { rc = fetchU32(ctx, cnt + CNT_OUTCLUMPS, got, 2); if (rc) return rc; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc; }
+            else if (ctx->hOutValid) { got[0] = ctx->hOutCounts[0]; got[1] = ctx->hOutCounts[1]; ef = ctx->hOutEf; }      // (fetched with the lane pipeline's last wait)
+            else { const FetchPiece pc[2] = {{cnt + CNT_OUTCLUMPS, got, 2}, {ctx->errFlag.p, &ef, 1}}; rc = fetchMany(ctx, pc, 2); if (rc) return rc; }
             if (ef == 0) { ctx->nOut = got[0]; ctx->nOutOps = got[1]; break; }
             if (kStats) fprintf(stderr, "[ygpu] ctx %p: align attempt %d repeated (%s); trace ratio %.3f, ops ratio %.4f\n", (void *)ctx, attempt + 1, traceOverflow ? "trace / extension-op arena" : (laneOverflow ? "phase-1 arenas (state ops, gap ops)" : "output arenas"), ctx->traceRatio, ctx->opsRatio);
             if (ef != YERR_OUT || attempt >= 24)      /* the trace estimate grows by half a time: 1.5^20 covers the floor-to-cap range */ { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
@@ -1064,6 +1079,38 @@ int ygpu_park(ygpu_ctx *ctx)
     for (DevBuf *b : allBuffers(ctx)) if (b != &ctx->dBases && b != &ctx->dSO && b != &ctx->dROA && b != &ctx->dLow) b->release();
     if (ctx->counted) { gCtxPerDevice[ctx->device & 63]--; ctx->counted = false; }
     ctx->stageDone = 0; ctx->parked = true;
+    return 0;
+}
+/* What a context's arenas hold after a batch, and the estimates it carries from batch to batch -- so that the device's other contexts can be given the same
+ * capacities in one go (ygpu_presize) instead of growing theirs buffer by buffer during a first batch of their own. */
+int ygpu_get_arena_profile(ygpu_ctx *ctx, ygpu_arena_profile *out)
+{
+    if (!ctx || !ctx->stream || !out) return YGPU_EINVAL;
+    memset(out, 0, sizeof *out);
+    const std::vector<DevBuf *> all = allBuffers(ctx);
+    if (all.size() > sizeof out->cap / sizeof out->cap[0]) { ctx->err = "arena profile: more buffers than the profile holds"; return YGPU_EINTERNAL; }
+    out->n = (uint32_t)all.size();
+    for (size_t k = 0; k < all.size(); k++) { DevBuf *b = all[k]; out->cap[k] = (b == &ctx->dBases || b == &ctx->dSO || b == &ctx->dROA || b == &ctx->dLow) ? 0ull : (uint64_t)b->cap; }
+    out->trace_ratio = ctx->traceRatio; out->ops_ratio = ctx->opsRatio; out->last_clump_slots = ctx->lastClumpSlots; out->last_fall = ctx->lastFall; out->bases = ctx->totalBases;
+    return 0;
+}
+int ygpu_presize(ygpu_ctx *ctx, const ygpu_arena_profile *prof)
+{
+    if (!ctx || !ctx->stream || !prof) return YGPU_EINVAL;
+    if (ctx->parked) { ctx->err = "the context was parked (ygpu_park)"; return YGPU_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const std::vector<DevBuf *> all = allBuffers(ctx);
+    if (prof->n != all.size()) { ctx->err = "arena profile of another build"; return YGPU_EINVAL; }
+    for (size_t k = 0; k < all.size(); k++) {
+        DevBuf *b = all[k];
+        if (b == &ctx->dBases || b == &ctx->dSO || b == &ctx->dROA || b == &ctx->dLow || b == &ctx->counters || b == &ctx->ctr || b == &ctx->errFlag) continue;
+        if (prof->cap[k] > b->cap && b->ensureExact((size_t)prof->cap[k])) { (void)hipGetLastError(); ctx->err = "hipMalloc failed while presizing the arenas"; return YGPU_ENOMEM; }
+    }
+    // (work words that their kernels expect zeroed when they are made)
+    if (ctx->scanState.p) HIPCHK(hipMemsetAsync(ctx->scanState.p, 0, ctx->scanState.cap, ctx->stream));
+    if (ctx->bucketWork.p) HIPCHK(hipMemsetAsync(ctx->bucketWork.p, 0, ctx->bucketWork.cap, ctx->stream));
+    if (ctx->runsDone == 0) { ctx->traceRatio = prof->trace_ratio; ctx->opsRatio = prof->ops_ratio > 0 ? prof->ops_ratio : ctx->opsRatio; ctx->lastClumpSlots = prof->last_clump_slots; ctx->lastFall = (long long)prof->last_fall; }
+    HIPCHK(streamSync(ctx));
     return 0;
 }
 const char *ygpu_last_error(const ygpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }

@@ -286,7 +286,7 @@ int runQueries(Args &a, FILE *log)
     ygpu_postfilter_params PF; memset(&PF, 0, sizeof PF);
     PF.minNonOverlap = oqP.minNonOverlap; PF.BPCost = oqP.BPCost; PF.maxBPLog = oqP.maxBPLog; PF.FBS = oqP.FBS; PF.FBS_PSLength = oqP.FBS_PSLength; PF.FBS_PSScore = oqP.FBS_PSScore;
     PF.bppVmin = oqP.bppVmin; PF.bppN = std::max(0, oqP.bppN); PF.bppThr = oqThr.data(); PF.n_seqs = (uint32_t)oqSeqStart.size(); PF.seq_start = oqSeqStart.data(); PF.seq_length = oqSeqLen.data();
-    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; uint64_t footprint = 0; bool claimed = false, measured = false; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
+    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; uint64_t footprint = 0; bool claimed = false, measured = false, haveProfile = false; ygpu_arena_profile profile; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
     std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < nDev; k++) warm.emplace_back(new Warm);
     std::atomic<int> ctxUp(0), parked(0); double tCtxUp = 0;
     std::vector<std::atomic<uint64_t>> devReads(nDev); for (auto &x : devReads) x = 0;       // reads each device took (the stats line: do all devices pull their weight?)
@@ -332,6 +332,18 @@ int runQueries(Args &a, FILE *log)
                         (void)ygpu_park(ctx[d]); parked++; break;
                     }
                 }
+                // The other contexts of the device get the leader's arenas in ONE go (ygpu_presize: its capacities after its first batch, its estimates) while the
+                // device's running contexts are held back for those few milliseconds; their own first batch then runs like any later batch, beside the others'.
+                // (Before: every context grew its hundred buffers during a first batch of its own, first batches ran one at a time and held the others back --
+                // 64 + 106 + 158 ms for the first three batches of a run, a fourth context cost more at the start than it gained later.)
+                if (!lead && rc0 == 0 && W.haveProfile && getenv("YAHA_NO_PRESIZE") == nullptr) {
+                    { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning++; }
+                    const double p0 = now(); const int prc = ygpu_presize(ctx[d], &W.profile);
+                    { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning--; } W.cv.notify_all();
+                    if (timing) fprintf(stderr, "[yaha] context %d: arenas presized from the device's first context in %.1f ms (rc %d)\n", d, now() - p0, prc);
+                    if (prc == YGPU_ENOMEM) { if (timing || stats) fprintf(stderr, "[yaha] context %d left out: no room for its arenas on device %d\n", d, dev); (void)ygpu_park(ctx[d]); parked++; break; }
+                    if (prc == 0) { first = false; one.unlock(); }
+                }
             }
             if (!inQ.pop(b)) break;
             if (stop) { b->nReads = 0; fmtQ.push(std::move(b)); continue; }
@@ -362,6 +374,7 @@ int runQueries(Args &a, FILE *log)
                 if (lead) {                                                  // the measure: what this context holds after its first batch (without the index image)
                     uint64_t fb = 0, tb = 0, mine = 0; const uint64_t image = (uint64_t)V.n_base_bytes + 4ull * V.totalMatches + 4ull * ((1ull << (2 * V.wordLen)) + 1);
                     if (rc == 0 && ygpu_memory(ctx[d], &fb, &tb, &mine) == 0) W.footprint = std::max<uint64_t>(1, d == leadCtx && mine > image ? mine - image : mine);
+                    if (rc == 0 && ygpu_get_arena_profile(ctx[d], &W.profile) == 0) W.haveProfile = true;
                 }
                 { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning--; } W.cv.notify_all();
                 one.unlock();
