@@ -15,7 +15,7 @@
 // k-mers never span sequences and skip any window holding a code > 3 (Index.c:98-127); any skip distance (walkKmers states which starts the reference's scan
 // visits when -S > 1).  The host builder (host/formats.cpp) remains for machines without a GPU.  Output: the complete file image, byte-identical to the reference's.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "scan.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -110,12 +110,12 @@ __global__ void k_ix_order_small(const uint32_t *so, uint64_t nKmers, uint32_t *
     for (uint32_t i = 1; i < n; i++) { const uint32_t v = a[i]; uint32_t j = i; while (j > 0 && a[j - 1] > v) { a[j] = a[j - 1]; j--; } a[j] = v; }
 }
 // lists of IX_SMALL+1 .. IX_BLOCK entries: bitonic sort in LDS, one workgroup per list
-__global__ void __launch_bounds__(256) k_ix_order_block(const uint32_t *so, const uint32_t *bigList, uint32_t nBig, uint32_t *roa)
+__global__ void __launch_bounds__(256) k_ix_order_block(const uint32_t *so, const uint32_t *bigList, uint32_t nBig, uint32_t *roa, uint32_t hugeMin)
 {
     __shared__ uint32_t s[IX_BLOCK];
     for (uint32_t li = blockIdx.x; li < nBig; li += gridDim.x) {
         const uint32_t h = bigList[li], b = so[h], n = so[h + 1] - b;
-        if (n > IX_BLOCK) continue;                                           // left to the device radix sort
+        if (n > hugeMin) continue;                                            // left to the multi-workgroup sort below
         uint32_t m = 64; while (m < n) m <<= 1;
         for (uint32_t i = threadIdx.x; i < m; i += 256) s[i] = i < n ? roa[b + i] : 0xFFFFFFFFu;
         __syncthreads();
@@ -131,6 +131,42 @@ __global__ void __launch_bounds__(256) k_ix_order_block(const uint32_t *so, cons
         for (uint32_t i = threadIdx.x; i < n; i += 256) roa[b + i] = s[i];
         __syncthreads();
     }
+}
+// A list beyond a workgroup's LDS (a satellite k-mer: tens of thousands to millions of offsets): a bitonic network over a copy padded to a power of two with
+// 0xFFFFFFFF -- the strides of 4 096 and below of a merge step inside workgroups of 8 192 elements (LDS), the wider ones one launch each.  A few dozen launches
+// for a million entries; the hot path never comes here (once per index, a handful of lists).
+__global__ void __launch_bounds__(256) k_ix_bitonic_global(uint32_t *a, uint32_t m, uint32_t size, uint32_t stride)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m / 2) return;
+    const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
+    const bool up = (i & size) == 0; const uint32_t x = a[i], y = a[j];
+    if ((x > y) == up) { a[i] = y; a[j] = x; }
+}
+// first == true: the whole network up to merge size IX_BLOCK inside the workgroup's 8 192 elements; else the strides IX_BLOCK / 2 .. 1 of merge step `size`
+__global__ void __launch_bounds__(256) k_ix_bitonic_local(uint32_t *a, uint32_t m, uint32_t size, bool first)
+{
+    __shared__ uint32_t s[IX_BLOCK];
+    const uint32_t base = blockIdx.x * IX_BLOCK, cnt = min(IX_BLOCK, m - base);      // (m is a power of two: cnt = IX_BLOCK, or m itself when m < IX_BLOCK)
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) s[i] = a[base + i];
+    __syncthreads();
+    for (uint32_t sz = first ? 2u : size; sz <= (first ? min(cnt, size) : size); sz <<= 1) {
+        for (uint32_t stride = min(sz >> 1, cnt >> 1); stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < cnt / 2; t += 256) {
+                const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool up = ((base + i) & sz) == 0; const uint32_t x = s[i], y = s[j];
+                if ((x > y) == up) { s[i] = y; s[j] = x; }
+            }
+            __syncthreads();
+        }
+        if (!first) break;
+    }
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) a[base + i] = s[i];
+}
+__global__ void k_ix_pad_copy(const uint32_t *src, uint32_t n, uint32_t *dst, uint32_t m)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[i] = i < n ? src[i] : 0xFFFFFFFFu;
 }
 __global__ void k_ix_clamp(const uint32_t *so, uint64_t nKmers, uint32_t maxHits, uint32_t *cnt2)
 {
@@ -220,8 +256,11 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
     IXCHK(hipGetLastError());
     // startingOffs = exclusive prefix sums (4^k + 1 entries, the last one = total)
     IXCHK(hipMalloc(&dSO.p, 4ull * (HT + 1)));
-    size_t tb = 0; IXCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (int)(HT + 1)));
-    IXCHK(hipMalloc(&dTemp.p, tb)); IXCHK(hipcub::DeviceScan::ExclusiveSum(dTemp.p, tb, dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (int)(HT + 1)));
+    // (scan.h: single pass, decoupled look-back; its state words clean themselves up, so the second sum below needs no memset)
+    const size_t tb = scanStateBytes(HT + 1) + 64; IXCHK(hipMalloc(&dTemp.p, tb)); IXCHK(hipMemset(dTemp.p, 0, tb));
+    unsigned int *scanFail = (unsigned int *)((char *)dTemp.p + scanStateBytes(HT + 1));
+    hipLaunchKernelGGL((k_scan_excl<uint32_t>), dim3(scanTiles(HT + 1)), dim3(YD_SCAN_BS), 0, 0, (const uint32_t *)dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (uint32_t)(HT + 1), dTemp.as<unsigned long long>(), scanFail);
+    IXCHK(hipGetLastError());
     uint32_t total = 0; IXCHK(hipMemcpy(&total, dSO.as<uint32_t>() + HT, 4, hipMemcpyDeviceToHost));
     lap("count + scan");
     // fill (the counters become the cursors)
@@ -247,23 +286,31 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
     const uint32_t nBig = two[0], nOver = two[1];
     std::vector<uint32_t> hSOpair;                       // startingOffs of the long lists
     if (nBig) {
-        hipLaunchKernelGGL(k_ix_order_block, dim3(std::min<uint32_t>(nBig, 4096u)), dim3(256), 0, 0, dSO.as<uint32_t>(), dBig.as<uint32_t>(), nBig, dROA.as<uint32_t>());
+        // (YAHA_IX_HUGE_MIN: a test hook -- lists above that many entries take the multi-workgroup sort, 8 192 = what a workgroup's LDS holds otherwise)
+        uint32_t hugeMin = IX_BLOCK; if (const char *e = getenv("YAHA_IX_HUGE_MIN")) { const long v = atol(e); if (v >= (long)IX_SMALL && v < (long)IX_BLOCK) hugeMin = (uint32_t)v; }
+        hipLaunchKernelGGL(k_ix_order_block, dim3(std::min<uint32_t>(nBig, 4096u)), dim3(256), 0, 0, dSO.as<uint32_t>(), dBig.as<uint32_t>(), nBig, dROA.as<uint32_t>(), hugeMin);
         IXCHK(hipGetLastError());
-        // the few lists beyond a workgroup's LDS: one device radix sort each
+        // the few lists beyond a workgroup's LDS: a bitonic network over a padded copy each (k_ix_bitonic_*)
         Buf dHuge; IXCHK(hipMalloc(&dHuge.p, 16ull * nBig + 16)); IXCHK(hipMemset(dN.p, 0, 4));
-        hipLaunchKernelGGL(k_ix_gather, dim3((nBig + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), (const uint32_t *)nullptr, dBig.as<uint32_t>(), nBig, IX_BLOCK, dHuge.as<uint32_t>(), dN.as<unsigned int>());
+        hipLaunchKernelGGL(k_ix_gather, dim3((nBig + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), (const uint32_t *)nullptr, dBig.as<uint32_t>(), nBig, hugeMin, dHuge.as<uint32_t>(), dN.as<unsigned int>());
         IXCHK(hipGetLastError());
         unsigned int nHuge = 0; IXCHK(hipMemcpy(&nHuge, dN.p, 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> huge(4ull * nHuge); if (nHuge) IXCHK(hipMemcpy(huge.data(), dHuge.p, 16ull * nHuge, hipMemcpyDeviceToHost));
-        Buf dAlt; size_t altCap = 0; size_t tb2 = 0; Buf dTemp2; size_t temp2Cap = 0;
+        Buf dAlt; size_t altCap = 0;
         for (unsigned int k = 0; k < nHuge; k++) {
             const uint32_t b0 = huge[4ull * k + 1], n = huge[4ull * k + 2] - b0;
-            if (n > altCap) { if (dAlt.p) hipFree(dAlt.p); dAlt.p = nullptr; altCap = (size_t)n + n / 4; IXCHK(hipMalloc(&dAlt.p, 4ull * altCap)); }
-            uint32_t *seg = dROA.as<uint32_t>() + b0;
-            IXCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb2, seg, dAlt.as<uint32_t>(), (int)n));
-            if (tb2 > temp2Cap) { if (dTemp2.p) hipFree(dTemp2.p); dTemp2.p = nullptr; temp2Cap = tb2 * 2; IXCHK(hipMalloc(&dTemp2.p, temp2Cap)); }
-            IXCHK(hipcub::DeviceRadixSort::SortKeys(dTemp2.p, tb2, seg, dAlt.as<uint32_t>(), (int)n));
-            IXCHK(hipMemcpyAsync(seg, dAlt.p, 4ull * n, hipMemcpyDeviceToDevice, 0));
+            uint32_t m = 64; while (m < n) m <<= 1;
+            if (m > altCap) { if (dAlt.p) hipFree(dAlt.p); dAlt.p = nullptr; altCap = m; IXCHK(hipMalloc(&dAlt.p, 4ull * altCap)); }
+            uint32_t *seg = dROA.as<uint32_t>() + b0, *alt = dAlt.as<uint32_t>();
+            hipLaunchKernelGGL(k_ix_pad_copy, dim3((m + 255) / 256), dim3(256), 0, 0, (const uint32_t *)seg, n, alt, m);
+            const unsigned lblocks = (m + IX_BLOCK - 1) / IX_BLOCK;
+            hipLaunchKernelGGL(k_ix_bitonic_local, dim3(lblocks), dim3(256), 0, 0, alt, m, (uint32_t)IX_BLOCK, true);
+            for (uint32_t size = 2 * IX_BLOCK; size <= m && size != 0; size <<= 1) {
+                for (uint32_t stride = size >> 1; stride >= IX_BLOCK; stride >>= 1) hipLaunchKernelGGL(k_ix_bitonic_global, dim3((m / 2 + 255) / 256), dim3(256), 0, 0, alt, m, size, stride);
+                hipLaunchKernelGGL(k_ix_bitonic_local, dim3(lblocks), dim3(256), 0, 0, alt, m, size, false);
+            }
+            IXCHK(hipGetLastError());
+            IXCHK(hipMemcpyAsync(seg, alt, 4ull * n, hipMemcpyDeviceToDevice, 0));
         }
     }
     IXCHK(hipDeviceSynchronize());
@@ -277,7 +324,8 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
         IXCHK(hipMalloc(&dSO2.p, 4ull * (HT + 1)));
         hipLaunchKernelGGL(k_ix_clamp, dim3((unsigned)((HT + 1 + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), HT, (uint32_t)maxHits, dCnt.as<uint32_t>());
         IXCHK(hipGetLastError());
-        IXCHK(hipcub::DeviceScan::ExclusiveSum(dTemp.p, tb, dCnt.as<uint32_t>(), dSO2.as<uint32_t>(), (int)(HT + 1)));
+        hipLaunchKernelGGL((k_scan_excl<uint32_t>), dim3(scanTiles(HT + 1)), dim3(YD_SCAN_BS), 0, 0, (const uint32_t *)dCnt.as<uint32_t>(), dSO2.as<uint32_t>(), (uint32_t)(HT + 1), dTemp.as<unsigned long long>(), scanFail);
+        IXCHK(hipGetLastError());
         IXCHK(hipMemcpy(&newTotal, dSO2.as<uint32_t>() + HT, 4, hipMemcpyDeviceToHost));
         IXCHK(hipMalloc(&dROA2.p, 4ull * ((uint64_t)newTotal + 16)));
         hipLaunchKernelGGL(k_ix_compact, dim3((unsigned)((HT + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), HT, (uint32_t)maxHits, dROA.as<uint32_t>(), dROA2.as<uint32_t>());

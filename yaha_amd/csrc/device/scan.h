@@ -133,7 +133,7 @@ __host__ __device__ inline size_t bucketWorkBytes() { return 4ull * (2 * YD_BKT_
 // bucket of a key: (key - sub) >> shift, clamped to [0, nb) (keys below `sub` go to bucket 0)
 __device__ __forceinline__ uint32_t bucketOf(uint32_t key, uint32_t sub, int shift, uint32_t nb) { const uint32_t b = (key > sub ? key - sub : 0u) >> shift; return b < nb ? b : nb - 1u; }
 
-__global__ void __launch_bounds__(YD_BKT_BS) k_bucket_count(const uint32_t *keys, uint32_t n, uint32_t sub, int shift, uint32_t nb, unsigned int *work)
+static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_count(const uint32_t *keys, uint32_t n, uint32_t sub, int shift, uint32_t nb, unsigned int *work)
 {
     YD_HIGH_PRIO();
     __shared__ unsigned int sHist[YD_BKT_MAX];
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_count(const uint32_t *keys
     for (uint32_t b = threadIdx.x; b < nb; b += YD_BKT_BS) { const unsigned c = sHist[b]; if (c) atomicAdd(&work[b], c); }
 }
 // vals == nullptr: the value of item i is i + valBase
-__global__ void __launch_bounds__(YD_BKT_BS) k_bucket_scatter(const uint32_t *keys, const uint32_t *vals, uint32_t valBase, uint32_t n, uint32_t sub, int shift, uint32_t nb, unsigned int *work, uint32_t *outVals, uint32_t *outKeys /* or nullptr */)
+static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_scatter(const uint32_t *keys, const uint32_t *vals, uint32_t valBase, uint32_t n, uint32_t sub, int shift, uint32_t nb, unsigned int *work, uint32_t *outVals, uint32_t *outKeys /* or nullptr */)
 {
     YD_HIGH_PRIO();
     __shared__ unsigned int sPos[YD_BKT_MAX]; __shared__ unsigned int sCnt[YD_BKT_MAX]; __shared__ unsigned int sWave[YD_BKT_BS / 64]; __shared__ unsigned int sLast;
