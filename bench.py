@@ -146,7 +146,7 @@ def config5_leg(ya, idx, fa, cache, device, contexts, tag):
     """BASELINE config 5 on one GPU: the hot path on a resident batch of 32 768 SV 500-mers, the whole command line with -OQC Y -FBS Y on the whole set, and -- where the
     reference binary is present -- the command line's records for the set's first 8 192 reads against the reference's."""
     import oracle
-    sv = make_sv_reads(cache, fa, tag, 5000)
+    sv = make_sv_reads(cache, fa, tag, 5000, per=40)         # ~300 k reads of 500 bases: nine batches of 16 M bases for the command line (the reference's own sets hold 25 events a size)
     n_all = sum(1 for l in open(sv) if l.startswith(">"))
     out = side_workload(ya, idx, sv, 32768, device, contexts, 4, "c5: SV / repeat-insertion 500-mers at 2 % (RandomSV_Events.sim + Alu_Insertions.sim shapes), hot path", blocks=3)
     sam = "/dev/shm/yaha_bench_c5_%d.sam" % os.getpid()

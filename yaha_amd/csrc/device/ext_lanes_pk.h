@@ -389,7 +389,10 @@ __device__ __forceinline__ bool pkContF(const PkRec &r, int k, int h) { const ui
 // 4 (l + s) + c -- the 32 lanes of a group on the eight banks that are c modulo 4, four lanes each (33.6 % of the kernel's LDS cycles were such conflicts, rounds 3-4).
 // With the dword index XOR-ed by the lane's (l >> 3) & 3 the four lanes that shared a bank read four different ones.  The staging store writes whole records, eight
 // lanes to a problem, (problem >> 3) & 3 = g & 3 a compile-time constant of the unrolled loop: the permutation is a renaming of the four registers it stores.
-#define YD_TSWZ(problem) (((problem) >> 3) & 3)
+#ifndef YD_TRACE_SWZ
+#define YD_TRACE_SWZ 0                          // (measured: 3.23 -> 3.39 ms a launch WITH the swizzle, profiles/r05_trace_swizzle.txt -- the XORs and six more registers cost more than the conflicts)
+#endif
+#define YD_TSWZ(problem) (YD_TRACE_SWZ ? (((problem) >> 3) & 3) : 0)
 __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
 {
     YD_HIGH_PRIO();

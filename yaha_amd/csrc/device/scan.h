@@ -3,7 +3,7 @@
 // exist only because a batch's variable-size outputs are laid out as count -> exclusive sum -> fill, and because lanes of a wave should run problems of one shape.
 //
 //   k_scan_excl<T>      out[i] = in[0] + ... + in[i-1] over n elements of u32 or u64, ONE launch, one read and one write of HBM per element: a workgroup owns a tile
-//                       of 8 192 elements (eight consecutive ones a thread: a serial prefix in registers, the lanes' totals by DPP-free shuffles, the waves' through
+//                       of 4 096 elements (sixteen consecutive ones a thread: a serial prefix in registers, the lanes' totals by DPP, the four waves' through
 //                       LDS), the tile's offset comes from the tiles before it by decoupled look-back over 64-bit state words (status : 2 | value : 62).  The tile is
 //                       the TICKET a workgroup draws when it starts (seed.h: tileTicket -- no assumption about dispatch order).  The state is SELF-CLEANING: the last
 //                       workgroup to finish zeroes the words the launch used, so that the next launch needs no memset (the host zeroes the buffer when it makes it and
@@ -16,12 +16,19 @@
 #pragma once
 #include "common.h"
 
-#define YD_SCAN_BS 1024
-#define YD_SCAN_IPT 8
+#define YD_SCAN_BS 256
+#define YD_SCAN_IPT 16
 #define YD_SCAN_TILE (YD_SCAN_BS * YD_SCAN_IPT)
 __host__ __device__ inline uint32_t scanTiles(uint64_t n) { return (uint32_t)((n + YD_SCAN_TILE - 1) / YD_SCAN_TILE); }
 __host__ __device__ inline size_t scanStateBytes(uint64_t n) { return 8ull * ((size_t)scanTiles(n) + 4); }       // tile words, ticket, done counter
 
+// inclusive sum over the 64 lanes by DPP (VALU rate; __shfl_up is a trip through the LDS crossbar): row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast 15 / 31
+__device__ __forceinline__ uint32_t waveInclSumU(uint32_t v)
+{
+    v += (uint32_t)dppMov<0x111>(0, (int)v); v += (uint32_t)dppMov<0x112>(0, (int)v); v += (uint32_t)dppMov<0x114>(0, (int)v); v += (uint32_t)dppMov<0x118>(0, (int)v);
+    v += (uint32_t)dppMov<0x142, 0xa>(0, (int)v); v += (uint32_t)dppMov<0x143, 0xc>(0, (int)v);
+    return v;
+}
 __device__ __forceinline__ unsigned long long shflUp64(unsigned long long v, int d)
 { return ((unsigned long long)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)v, d, 64); }
 __device__ __forceinline__ unsigned long long waveSum64(unsigned long long v)
@@ -30,6 +37,16 @@ __device__ __forceinline__ unsigned long long waveSum64(unsigned long long v)
     for (int d = 32; d >= 1; d >>= 1) v += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
     return v;
 }
+// inclusive sum over the lanes in the width of T: u32 by DPP, u64 by shuffles (one or two such sums a batch)
+__device__ __forceinline__ uint32_t waveInclSumT(uint32_t v, uint32_t) { return waveInclSumU(v); }
+__device__ __forceinline__ unsigned long long waveInclSumT(unsigned long long v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long x = shflUp64(v, d); if ((int)lane >= d) v += x; }
+    return v;
+}
+__device__ __forceinline__ uint32_t readLaneT(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ unsigned long long readLaneT(unsigned long long v, int l) { return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l); }
 
 // decoupled look-back on 62-bit values; called by one whole wave; returns the sum of the aggregates of all tiles before `tile`
 __device__ __forceinline__ unsigned long long tileLookBack64(unsigned long long *state, uint32_t tile, unsigned long long agg, uint32_t lane, unsigned int *failed)
@@ -61,12 +78,13 @@ __device__ __forceinline__ unsigned long long tileLookBack64(unsigned long long 
     return excl;
 }
 
+// T = uint32_t: every sum is kept in 32 bits (the caller's total fits its own output type); T = unsigned long long: 62 bits.
 template <class T>
 __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, uint32_t n, unsigned long long *state /* scanStateBytes(n), zero */, unsigned int *failed)
 {
     YD_HIGH_PRIO();
     constexpr int NW = YD_SCAN_BS / 64;
-    __shared__ unsigned long long sWave[NW]; __shared__ unsigned long long sPrefix; __shared__ uint32_t sTile;
+    __shared__ T sWave[NW]; __shared__ T sPrefix; __shared__ uint32_t sTile;
     const uint32_t nTiles = gridDim.x, t = threadIdx.x, lane = t & 63u, w = t >> 6;
     if (t == 0) sTile = (uint32_t)atomicAdd(&state[nTiles], 1ull);
     __syncthreads();
@@ -75,46 +93,48 @@ __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, u
     T v[YD_SCAN_IPT];
     const bool vec = i0 + YD_SCAN_IPT <= n && ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0u;      // whole threads of 16-byte aligned arrays move as vectors
     if (vec) {
-        if (sizeof(T) == 4) { const uint4 a = *(const uint4 *)(in + i0), b = *(const uint4 *)(in + i0 + 4); v[0] = (T)a.x; v[1] = (T)a.y; v[2] = (T)a.z; v[3] = (T)a.w; v[4] = (T)b.x; v[5] = (T)b.y; v[6] = (T)b.z; v[7] = (T)b.w; }
-        else {
+        constexpr int PER = 16 / (int)sizeof(T);
 #pragma unroll
-            for (int k = 0; k < YD_SCAN_IPT; k += 2) { const ulonglong2 a = *(const ulonglong2 *)(in + i0 + k); v[k] = (T)a.x; v[k + 1] = (T)a.y; }
+        for (int k = 0; k < YD_SCAN_IPT; k += PER) {
+            const uint4 a = *(const uint4 *)(in + i0 + k);
+            if (sizeof(T) == 4) { v[k] = (T)a.x; v[k + 1] = (T)a.y; v[k + 2] = (T)a.z; v[k + 3] = (T)a.w; }
+            else { v[k] = (T)(((unsigned long long)a.y << 32) | a.x); v[k + 1] = (T)(((unsigned long long)a.w << 32) | a.z); }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < YD_SCAN_IPT; k++) v[k] = i0 + k < n ? in[i0 + k] : (T)0;
     }
-    unsigned long long sum = 0ull;                                           // the thread's serial prefix: v[k] becomes the sum of the elements before it in the thread
+    T sum = 0;                                                               // the thread's serial prefix: v[k] becomes the sum of the elements before it in the thread
 #pragma unroll
-    for (int k = 0; k < YD_SCAN_IPT; k++) { const T x = v[k]; v[k] = (T)sum; sum += (unsigned long long)x; }
-    unsigned long long incl = sum;                                           // inclusive over the wave's lanes
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const unsigned long long x = shflUp64(incl, d); if ((int)lane >= d) incl += x; }
+    for (int k = 0; k < YD_SCAN_IPT; k++) { const T x = v[k]; v[k] = sum; sum += x; }
+    const T incl = waveInclSumT(sum, lane);                                  // inclusive over the wave's lanes
     if (lane == 63u) sWave[w] = incl;
     __syncthreads();
     if (w == 0u) {
-        const unsigned long long wv = lane < (uint32_t)NW ? sWave[lane] : 0ull; unsigned long long wi = wv;
+        T wsum[NW], agg = 0;
 #pragma unroll
-        for (int d = 1; d < NW; d <<= 1) { const unsigned long long x = shflUp64(wi, d); if ((int)lane >= d) wi += x; }
-        if (lane < (uint32_t)NW) sWave[lane] = wi - wv;                       // exclusive over the waves
-        const unsigned long long agg = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wi >> 32), NW - 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wi, NW - 1);
-        const unsigned long long excl = tileLookBack64(state, tile, agg, lane, failed);
-        if (lane == 0u) sPrefix = excl;
+        for (int k = 0; k < NW; k++) { wsum[k] = agg; agg += sWave[k]; }     // (four waves: every lane of wave 0 adds them up itself)
+        const unsigned long long excl = tileLookBack64(state, tile, (unsigned long long)agg, lane, failed);
+        if (lane < (uint32_t)NW) { T mine = wsum[0];
+#pragma unroll
+            for (int k = 1; k < NW; k++) mine = lane == (uint32_t)k ? wsum[k] : mine;
+            sWave[lane] = mine; }
+        if (lane == 0u) sPrefix = (T)excl;
     }
     __syncthreads();
-    const unsigned long long base = sPrefix + sWave[w] + (incl - sum);
+    const T base = sPrefix + sWave[w] + (incl - sum);
     if (vec) {
-        if (sizeof(T) == 4) {
-            uint4 a, b; a.x = (uint32_t)(base + v[0]); a.y = (uint32_t)(base + v[1]); a.z = (uint32_t)(base + v[2]); a.w = (uint32_t)(base + v[3]);
-            b.x = (uint32_t)(base + v[4]); b.y = (uint32_t)(base + v[5]); b.z = (uint32_t)(base + v[6]); b.w = (uint32_t)(base + v[7]);
-            *(uint4 *)(out + i0) = a; *(uint4 *)(out + i0 + 4) = b;
-        } else {
+        constexpr int PER = 16 / (int)sizeof(T);
 #pragma unroll
-            for (int k = 0; k < YD_SCAN_IPT; k += 2) { ulonglong2 a; a.x = base + v[k]; a.y = base + v[k + 1]; *(ulonglong2 *)(out + i0 + k) = a; }
+        for (int k = 0; k < YD_SCAN_IPT; k += PER) {
+            uint4 a;
+            if (sizeof(T) == 4) { a.x = (uint32_t)(base + v[k]); a.y = (uint32_t)(base + v[k + 1]); a.z = (uint32_t)(base + v[k + 2]); a.w = (uint32_t)(base + v[k + 3]); }
+            else { const unsigned long long p = (unsigned long long)(base + v[k]), q = (unsigned long long)(base + v[k + 1]); a.x = (uint32_t)p; a.y = (uint32_t)(p >> 32); a.z = (uint32_t)q; a.w = (uint32_t)(q >> 32); }
+            *(uint4 *)(out + i0 + k) = a;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < YD_SCAN_IPT; k++) if (i0 + k < n) out[i0 + k] = (T)(base + v[k]);
+        for (int k = 0; k < YD_SCAN_IPT; k++) if (i0 + k < n) out[i0 + k] = base + v[k];
     }
     // self-cleaning: whoever finishes last has seen every other workgroup leave its look-back
     __syncthreads();
@@ -124,8 +144,8 @@ __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, u
 }
 
 // ---- ordering by a small key ------------------------------------------------------------------------------------------------------------------------------
-#define YD_BKT_BS 256
-#define YD_BKT_IPT 16
+#define YD_BKT_BS 1024
+#define YD_BKT_IPT 8
 #define YD_BKT_TILE (YD_BKT_BS * YD_BKT_IPT)
 #define YD_BKT_MAX 4096                         // buckets (12 key bits)
 // work words of one ordering: hist[nb] | cursor[nb] | done; zero before the first use, left zero by k_bucket_scatter
@@ -151,31 +171,30 @@ static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_scatter(const uint3
     YD_HIGH_PRIO();
     __shared__ unsigned int sPos[YD_BKT_MAX]; __shared__ unsigned int sCnt[YD_BKT_MAX]; __shared__ unsigned int sWave[YD_BKT_BS / 64]; __shared__ unsigned int sLast;
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
-    // every workgroup scans the global histogram itself: thread t owns the buckets [t * per, (t + 1) * per)
-    const uint32_t per = (nb + YD_BKT_BS - 1u) / YD_BKT_BS;
+    // the tile's keys first (their latency covers the histogram's), then every workgroup scans the global histogram itself: thread t owns buckets [t * per, (t + 1) * per)
+    const uint32_t base = blockIdx.x * (uint32_t)YD_BKT_TILE;
+    uint32_t key[YD_BKT_IPT];
+#pragma unroll
+    for (int k = 0; k < YD_BKT_IPT; k++) { const uint32_t i = base + (uint32_t)k * YD_BKT_BS + t; key[k] = i < n ? keys[i] : 0u; }
+    const uint32_t per = (nb + YD_BKT_BS - 1u) / YD_BKT_BS;               // 1 .. 4
     unsigned int sum = 0;
     for (uint32_t k = 0; k < per; k++) { const uint32_t b = t * per + k; const unsigned c = b < nb ? __hip_atomic_load(&work[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; if (b < nb) { sPos[b] = sum; sCnt[b] = 0u; } sum += c; }
-    unsigned int incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const unsigned x = (unsigned)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
+    const unsigned int incl = waveInclSumU(sum);
     if (lane == 63u) sWave[w] = incl;
     __syncthreads();
     unsigned int wbase = 0; for (uint32_t k = 0; k < w; k++) wbase += sWave[k];
     const unsigned int tbase = wbase + incl - sum;
     for (uint32_t k = 0; k < per; k++) { const uint32_t b = t * per + k; if (b < nb) sPos[b] += tbase; }
-    __syncthreads();
-    // the tile's own histogram, then one reservation per non-empty bucket: sPos[b] = where this workgroup's items of bucket b go
-    const uint32_t base = blockIdx.x * (uint32_t)YD_BKT_TILE;
-    uint32_t key[YD_BKT_IPT];
 #pragma unroll
-    for (int k = 0; k < YD_BKT_IPT; k++) { const uint32_t i = base + (uint32_t)k * YD_BKT_BS + t; key[k] = i < n ? keys[i] : 0u; if (i < n) atomicAdd(&sCnt[bucketOf(key[k], sub, shift, nb)], 1u); }
+    for (int k = 0; k < YD_BKT_IPT; k++) { const uint32_t i = base + (uint32_t)k * YD_BKT_BS + t; if (i < n) { key[k] = bucketOf(key[k], sub, shift, nb); atomicAdd(&sCnt[key[k]], 1u); } }      // (key[] holds the bucket from here on)
     __syncthreads();
+    // one reservation per non-empty bucket: sPos[b] = where this workgroup's items of bucket b go
     for (uint32_t b = t; b < nb; b += YD_BKT_BS) { const unsigned c = sCnt[b]; if (c) sPos[b] += atomicAdd(&work[YD_BKT_MAX + b], c); }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < YD_BKT_IPT; k++) {
         const uint32_t i = base + (uint32_t)k * YD_BKT_BS + t;
-        if (i < n) { const unsigned p = atomicAdd(&sPos[bucketOf(key[k], sub, shift, nb)], 1u); outVals[p] = vals ? vals[i] : i + valBase; if (outKeys) outKeys[p] = key[k]; }
+        if (i < n) { const unsigned p = atomicAdd(&sPos[key[k]], 1u); outVals[p] = vals ? vals[i] : i + valBase; if (outKeys) outKeys[p] = keys[i]; }
     }
     // self-cleaning (the last workgroup to finish: every other one has read the histogram and made its reservations)
     __syncthreads();

@@ -923,7 +923,7 @@ static int initDevice(ygpu_ctx *ctx, int device, int srcIndex /* -1: the host */
 {
     // the device's further contexts (they share this one's image): streams, events and counters are made beside the copy as well
     std::vector<int> moreRc(nMore, 0); std::vector<std::thread> moreTh;
-    for (int j = 0; j < nMore; j++) moreTh.emplace_back([&, j]() { ygpu_ctx *c = more[j]; int rc = initCommon(c, device); if (rc == 0 && (c->counters.ensure(4 * CNT_N) || c->ctr.ensure(sizeof(DevCounters)) || c->errFlag.ensure(64))) { c->err = "hipMalloc failed"; rc = YGPU_ENOMEM; } moreRc[j] = rc; });
+    for (int j = 0; j < nMore; j++) moreTh.emplace_back([&, j]() { ygpu_ctx *c = more[j]; int rc = initCommon(c, device); if (rc == 0 && (c->counters.ensure(4 * CNT_N) || c->ctr.ensure(sizeof(DevCounters)) || c->errFlag.ensure(64))) { c->err = "hipMalloc failed"; rc = YGPU_ENOMEM; } if (rc == 0 && hipMemsetAsync(c->counters.p, 0, 4 * CNT_N, c->stream) != hipSuccess) { c->err = "hipMemset failed"; rc = YGPU_ENODEV; } moreRc[j] = rc; });
     struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{moreTh};
     const bool phases = getenv("YGPU_INIT_PHASES") != nullptr; double tPh = nowMs(); const double tPh0 = tPh;      // where a context's start-up goes
     auto phase = [&](const char *what) { if (phases) { const double t = nowMs(); fprintf(stderr, "[ygpu] init device %d: %-40s %8.1f ms\n", device, what, t - tPh); tPh = t; } };
@@ -948,7 +948,7 @@ static int initDevice(ygpu_ctx *ctx, int device, int srcIndex /* -1: the host */
     else copier = std::thread([&]() { while (imageReady[srcIndex].load() == 0) std::this_thread::yield(); if (imageReady[srcIndex].load() < 0) { me.failed = 1; return; } copyFromPeer(device, srcDevice, plan, me, states[srcIndex]); });
     int rc0 = initCommon(ctx, device);
     if (rc0 == 0) { if (ctx->counters.ensure(4 * CNT_N) || ctx->ctr.ensure(sizeof(DevCounters)) || ctx->errFlag.ensure(64) || ctx->dLow.ensure(YD_LOW_BITS / 8)) { ctx->err = "hipMalloc failed"; rc0 = YGPU_ENOMEM; } }
-    if (rc0 == 0) { hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, ctx->stream, (unsigned int *)nullptr); if (hipMemsetAsync(ctx->dLow.p, 0, YD_LOW_BITS / 8, ctx->stream) != hipSuccess || streamSync(ctx) != hipSuccess) { ctx->err = "first kernel launch failed"; (void)hipGetLastError(); rc0 = YGPU_ENODEV; } }
+    if (rc0 == 0) { hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, ctx->stream, (unsigned int *)nullptr); if (hipMemsetAsync(ctx->counters.p, 0, 4 * CNT_N, ctx->stream) != hipSuccess || hipMemsetAsync(ctx->dLow.p, 0, YD_LOW_BITS / 8, ctx->stream) != hipSuccess || streamSync(ctx) != hipSuccess) { ctx->err = "first kernel launch failed"; (void)hipGetLastError(); rc0 = YGPU_ENODEV; } }
     phase("streams, events, code object (beside the copy)");
     copier.join();
     if (rc0) { me.failed = 1; return rc0; }
@@ -1024,6 +1024,7 @@ int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out)
     int rc = initCommon(ctx, parent->device); if (rc) return rc;
     shareImage(ctx, parent);
     ENSURE(ctx->counters, 4 * CNT_N); ENSURE(ctx->ctr, sizeof(DevCounters)); ENSURE(ctx->errFlag, 64);
+    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 4 * CNT_N, ctx->stream));
     HIPCHK(streamSync(ctx));
     return 0;
 }
@@ -1301,6 +1302,7 @@ int ygpu_selftest_primitives(ygpu_ctx *ctx, uint32_t n, uint32_t seed, int key_b
     uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1; auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
     std::vector<uint32_t> h32(n), o32(n); std::vector<unsigned long long> h64(n), o64(n);
     for (uint32_t i = 0; i < n; i++) { const uint64_t r = rnd(); h32[i] = (uint32_t)(r % 97u) * ((r >> 40) % 5u == 0 ? 1000u : 1u); h64[i] = (r >> 8) % (1ull << 36); }
+    HIPCHK(hipMemsetAsync(ctx->counters.as<uint32_t>() + CNT_SCANFAIL, 0, 4, ctx->stream));
     DevBuf a, b; struct Rel { DevBuf &a, &b; ~Rel() { a.release(); b.release(); } } rel{a, b};
     if (a.ensure(8ull * n + 64) || b.ensure(8ull * n + 64)) { ctx->err = "hipMalloc failed"; return YGPU_ENOMEM; }
     auto fail = [&](const char *what, uint64_t at) { char m[160]; snprintf(m, sizeof m, "selftest: %s differs from the host at element %llu of %u", what, (unsigned long long)at, n); ctx->err = m; return YGPU_EINTERNAL; };
@@ -1535,7 +1537,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         rc = fetchU32(ctx, ctx->sortKeys.p, keys.data(), nJ); if (rc) return rc;
         for (uint32_t k = 0; k < nJ; k++) idx[k] = k;
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });           // the production path sorts the DP joints by (strip width, rows) as well
-        uint32_t nd[3] = {0, 0, 0}, nb[2] = {0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != YD_JKEY_NONE) { const uint32_t cls = keys[k] >> 14; nd[0]++; nd[1] += cls <= 2u; nb[0] += cls == 0u; nb[1] += cls <= 1u; }
+        uint32_t nd[3] = {0, 0, 0}, nb[2] = {0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != YD_JKEY_NONE) { const uint32_t cls = gapJointClass(keys[k]); nd[0]++; nd[1] += cls <= 2u; nb[0] += cls == 0u; nb[1] += cls <= 1u; }
         HIPCHK(hipMemcpyAsync(cnt + CNT_NB12, nb, 8, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->sortVals2.p, idx.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(cnt + CNT_NDP, nd, 12, hipMemcpyHostToDevice, ctx->stream));
