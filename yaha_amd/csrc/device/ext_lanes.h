@@ -80,7 +80,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
     __shared__ uint32_t sBlk[256 * YD_LDS_STRIDE];   // per lane: the current 10-row trace block (30 dwords), lane stride 33
     if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());
     const int lane = laneId();
-    const int GO = A.P.GO, GE = A.P.GE, GOE = A.P.GO + A.P.GE, RC = A.P.RC, MS = A.P.MS, XC = A.P.X, maxIntron = A.P.maxIntron, maxGap = A.P.maxGap;
+    const int GO = A.P.GO, GE = A.P.GE, GOE = A.P.GO + A.P.GE, XC = A.P.X, maxIntron = A.P.maxIntron, maxGap = A.P.maxGap;
+    // (the strip keeps Vg = V - GOE, as k_ext_rows_pk does since round 5: one subtraction per cell instead of one per use -- the gap a neighbour opens to the right
+    // and below-left -- and the diagonal step adds GOE back inside its two constants)
+    const int MSG = A.P.MS + GOE, RCG = GOE - A.P.RC, LWG = YD_LWORST - GOE;
     constexpr int bandwidth = YD_LBAND, leftR = YD_LBAND;
     const uint32_t maxROff = A.P.maxROff;
     YD_GLOBAL const uint8_t *gBases = toGlobal(A.bases);
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
     YD_GLOBAL const uint8_t *q = toGlobal(A.fwd);
     unsigned calls = 0, rows = 0, cells = 0;
 #pragma unroll
-    for (int j = 0; j < YD_LW; j++) { PV[j] = YD_LWORST; PF[j] = YD_LWORST; PI[j] = 0; }
+    for (int j = 0; j < YD_LW; j++) { PV[j] = LWG; PF[j] = YD_LWORST; PI[j] = 0; }
 
     // Pool of claimed problems: lane l holds entry l, completely set up (clamped lengths, first reference window, first
     // query base), so that handing an entry to an idle lane is a few cross-lane moves and no memory latency.  One atomic
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
             // so that the state registers have one definition here and one in the row code
 #pragma unroll
             for (int j = 0; j < YD_LW; j++) {
-                const int iV = j == leftR ? 0 : (j > leftR ? -(GO + (j - leftR) * GE) : YD_LWORST), iF = j == leftR ? -GO : YD_LWORST;
+                const int iV = (j == leftR ? 0 : (j > leftR ? -(GO + (j - leftR) * GE) : YD_LWORST)) - GOE, iF = j == leftR ? -GO : YD_LWORST;      // (Vg)
                 PV[j] = init ? iV : PV[j]; PF[j] = init ? iF : PF[j]; if (CAPS) PI[j] = init ? 0 : PI[j];
             }
             if (init) {
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
         // (both clamps keep that relation, SW.cpp:499-516), so endCol = min(left + rLen - i, W - 1) = W - 1 on every row i <= qLen:
         // only the first `left` rows have cells to keep out of the row maximum, and only in the columns left of the origin.
         int sc = leftR + 1 - i; if (sc < 0) sc = 0;
-        int PVCol = YD_LWORST, PE = YD_LWORST, PD = 0;
+        int PVCol = LWG, PE = YD_LWORST, PD = 0;
         uint32_t t0 = 0, t1 = 0, t2 = 0, rowKey = 0;
         int dV = PV[0];
 #pragma unroll
@@ -247,14 +250,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
             const uint32_t wsrc = j < 8 ? w0 : (j < 16 ? w1 : w2);
             const int rc = (int)((wsrc >> ((j & 7) * 4)) & 15u);
             const bool eq = rc == qc;
-            int V = dV + (eq ? MS : -RC);
-            const int CE = PE - GE, NE = PVCol - GOE;
+            int V = dV + (eq ? MSG : RCG);
+            const int CE = PE - GE, NE = PVCol;
             const bool cE = CE >= NE && (!CAPS || PD < maxIntron);
             PE = cE ? CE : NE; if (CAPS) PD = cE ? PD + 1 : 1;
             const bool tE = PE >= V; V = tE ? PE : V;
             int upV, upF, upI;
-            if (j + 1 < YD_LW) { upV = PV[j + 1]; upF = PF[j + 1]; upI = PI[j + 1]; } else { upV = YD_LWORST; upF = YD_LWORST; upI = 0; }
-            const int CF = upF - GE, NF = upV - GOE;
+            if (j + 1 < YD_LW) { upV = PV[j + 1]; upF = PF[j + 1]; upI = PI[j + 1]; } else { upV = LWG; upF = YD_LWORST; upI = 0; }
+            const int CF = upF - GE, NF = upV;
             const bool cF = CF >= NF && (!CAPS || upI < maxGap);
             const int F = cF ? CF : NF, I = CAPS ? (cF ? upI + 1 : 1) : 0;
             const bool tF = F >= V; V = tF ? F : V;
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
             uint32_t key = ((uint32_t)(V + YD_BIAS)) << 5 | (uint32_t)(31 - j);
             if (j < leftR) key = j >= sc ? key : 0u;
             rowKey = key > rowKey ? key : rowKey;
-            PV[j] = V; PF[j] = F; PI[j] = I; PVCol = V;
+            { const int Vg = V - GOE; PV[j] = Vg; PVCol = Vg; } PF[j] = F; PI[j] = I;
             dV = upV;                                                        // the next column's diagonal predecessor
             __builtin_amdgcn_sched_barrier(0);                               // keep the cells in program order: their many condition masks stay short-lived
         }

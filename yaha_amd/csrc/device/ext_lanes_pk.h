@@ -69,9 +69,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     uint32_t *const myBlk = &sBlk[threadIdx.x * YD_LDS_STRIDE];
-    const uint32_t GEp = pk2(GE), GOEp = pk2(GO + GE), MSp = pk2(A.P.MS), NEGK = pk2(-(A.P.MS + A.P.RC)), LWp = pk2(YD_LW16), ONEp = 0x00010001u, LWlo = (uint32_t)YD_LW16 & 0xFFFFu;
+    const uint32_t GEp = pk2(GE), GOEp = pk2(GO + GE), NEGK = pk2(-(A.P.MS + A.P.RC)), LWp = pk2(YD_LW16), ONEp = 0x00010001u, LWlo = (uint32_t)YD_LW16 & 0xFFFFu;
+    // The strip keeps every cell's value as Vg = V - (GO + GE) (round 5): that is what both of a cell's later uses subtract -- the gap a neighbour opens from it, to its
+    // right in the same row (NE) and below-left in the next (NF) -- so one subtraction per cell replaces two; the diagonal step adds GO + GE back inside the constant of
+    // its multiply-add (MS + GO + GE | -RC + GO + GE), for nothing.  Eleven instructions fewer a row; all values as before (nothing here saturates: see the header).
+    const uint32_t MSGp = pk2(A.P.MS + GO + GE), LWg = pk2(YD_LW16 - (GO + GE)), LWgLo = (uint32_t)(YD_LW16 - (GO + GE)) & 0xFFFFu;
 
-    uint32_t NEGKv = NEGK, MSv = MSp, ONEv = ONEp, C15v = 0x000F000Fu;      // operands of the inline-assembly instructions: kept in VGPRs (copied from SGPRs at every use otherwise)
+    uint32_t NEGKv = NEGK, MSv = MSGp, ONEv = ONEp, C15v = 0x000F000Fu;      // operands of the inline-assembly instructions: kept in VGPRs (copied from SGPRs at every use otherwise)
     asm volatile("" : "+v"(NEGKv), "+v"(MSv), "+v"(ONEv), "+v"(C15v));
     uint32_t PV[YD_NP], PF[YD_NP], rc[YD_NP], carryE = LWp, nbNext = 15u;
     int p = -1, i = 0, qLen = 0, maxScore = YD_LWORST, maxi = 0, qcNext = 0, qcPrev = 0, rvLo = YD_LWORST;
@@ -92,7 +96,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
     YD_GLOBAL const uint8_t *q4 = toGlobal(A.fwd4);                          // the strand's PACKED codes (two to the byte, as the reference: k_pack4): entry idx of the extension = nibble qPos +- idx
     unsigned calls = 0, rows = 0, cells = 0;
 #pragma unroll
-    for (int k = 0; k < YD_NP; k++) { PV[k] = LWp; PF[k] = LWp; rc[k] = 0x7FFF7FFFu; }
+    for (int k = 0; k < YD_NP; k++) { PV[k] = LWg; PF[k] = LWp; rc[k] = 0x7FFF7FFFu; }      // (PV holds Vg = V - GOE throughout)
 
     int poolCount = 0, poolNext = 0; bool exhausted = false;
     uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0, eQwLo = 0, eQwHi = 0, eRwLo = 0, eRwHi = 0;      // eMisc: flags | first query code << 8 | buffered entries (query | reference << 8) << 16
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
             // row 1 (bit 15: not a cell; it slides out with the window), pair 10 low = index 0, pair k high = index k.
 #pragma unroll
             for (int k = 0; k < YD_NP; k++) {
-                const uint32_t iV = k == leftR ? (LWp & 0xFFFF0000u) : LWp, iF = k == leftR ? ((LWp & 0xFFFF0000u) | ((uint32_t)(-GO) & 0xFFFFu)) : LWp;
+                const uint32_t iV = k == leftR ? ((LWg & 0xFFFF0000u) | ((uint32_t)(-(GO + GE)) & 0xFFFFu)) : LWg, iF = k == leftR ? ((LWp & 0xFFFF0000u) | ((uint32_t)(-GO) & 0xFFFFu)) : LWp;      // the origin: V = 0, i.e. Vg = -GOE
                 const int c = leftR + k;                                      // window nibble of reference index k
                 const uint32_t nibHi = (((c < 16 ? gW1 : gW2) >> ((c & 7) * 4)) & 15u) | YD_RCREAL, nibLo = k == leftR ? (((gW1 >> ((leftR & 7) * 4)) & 15u) | YD_RCREAL) : 0x800Fu;
                 PV[k] = init ? iV : PV[k]; PF[k] = init ? iF : PF[k]; rc[k] = init ? (nibLo | (nibHi << 16)) : rc[k];
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
             rows += rowF; cells += nCells;
             int maxj = 0;                                                     // the first column of the kept strip's half that holds the maximum
 #pragma unroll
-            for (int k = YD_NP - 1; k >= 0; k--) { const int v = maxSide ? (int)(short)(SV[k] >> 16) : (int)(short)(SV[k] & 0xFFFFu); if (v == maxScore) maxj = k + (maxSide ? YD_NP : 0); }
+            for (int k = YD_NP - 1; k >= 0; k--) { const int v = maxSide ? (int)(short)(SV[k] >> 16) : (int)(short)(SV[k] & 0xFFFFu); if (v == maxScore - (GO + GE)) maxj = k + (maxSide ? YD_NP : 0); }      // (the strip holds Vg)
             ExtRes r; r.score = maxScore > 0 ? maxScore : 0; r.maxi = maxi; r.maxj = maxj; r.opsOff = pStart >> 4; r.nOps = 0;
             r.where = (pStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = rowF; r.cells = nCells;
             // (the result, like the trace blocks, is stored non-temporally, and the pool's problem records are loaded so: neither comes back to this kernel's L2)
@@ -300,22 +304,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
         const uint32_t qcP = ((uint32_t)qc | ((uint32_t)qcPrev << 16)) ^ (YD_RCREAL * 0x10001u);      // code ^ qcP = nibble ^ query code
         qcPrev = qc;
         uint32_t qcPv = qcP; asm volatile("" : "+v"(qcPv));                   // (opaque: else the constant is re-applied in every pair)
-        uint32_t PVCol = (PV[YD_NP - 1] << 16) | LWlo;                       // low: nothing left of column 0; high: V(i-1, 10)
+        uint32_t PVCol = (PV[YD_NP - 1] << 16) | LWgLo;                      // (Vg) low: nothing left of column 0; high: V(i-1, 10)
         uint32_t PE = (carryE << 16) | LWlo;                                 //                                       E(i-1, 10)
         uint32_t rowMax = LWp, dV = PV[0];
         uint32_t accA = 0, accB = 0, accA2 = 0, accB2 = 0, accM = 0;
 #pragma unroll
         for (int k = 0; k < YD_NP; k++) {
             const uint32_t mm = pkMinU(rc[k] ^ qcPv, ONEv);                   // 0 = match, 1 = mismatch, per half
-            uint32_t V = pkAdd(dV, pkMad(mm, NEGKv, MSv));                     // G = diagonal + (MS | -RC)
-            const uint32_t CE = pkSub(PE, GEp), NE = pkSub(PVCol, GOEp);
+            uint32_t V = pkAdd(dV, pkMad(mm, NEGKv, MSv));                     // G = diagonal's Vg + (MS + GOE | -RC + GOE)
+            const uint32_t CE = pkSub(PE, GEp), NE = PVCol;                  // (the left neighbour's Vg IS the gap opened from it)
             PE = pkMax(CE, NE);
             const uint32_t dE = pkSub(CE, NE);                               // >= 0: the E run continues (ties continue, SW.cpp:1029-1033)
             const uint32_t dT = pkSub(PE, V);                                // >= 0: E wins over G ('>=' in extension mode, SW.cpp:1036)
             V = pkMax(V, PE);
             uint32_t upV, upF;
             if (k + 1 < YD_NP) { upV = PV[k + 1]; upF = PF[k + 1]; } else { upV = PV[0] >> 16; upF = PF[0] >> 16; }      // column 10's upper neighbour = column 11 of row i-1, just computed
-            const uint32_t CF = pkSub(upF, GEp), NF = pkSub(upV, GOEp);
+            const uint32_t CF = pkSub(upF, GEp), NF = upV;
             const uint32_t F = pkMax(CF, NF);
             const uint32_t dF = pkSub(CF, NF);
             const uint32_t dU = pkSub(F, V);
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
             if (k < leftR) Vm = pkMin(V, rc[k]);
             if (k == YD_NP - 1) { V = bfi(0x0000FFFFu, V, LWp); Vm = V; }
             rowMax = pkMax(rowMax, Vm);
-            PV[k] = V; PF[k] = k == YD_NP - 1 ? bfi(0x0000FFFFu, F, LWp) : F; PVCol = V; dV = upV;
+            { const uint32_t Vg = pkSub(V, GOEp); PV[k] = Vg; PVCol = Vg; } PF[k] = k == YD_NP - 1 ? bfi(0x0000FFFFu, F, LWp) : F; dV = upV;
             __builtin_amdgcn_sched_barrier(0);
         }
         carryE = PE;
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
                     const int src = g * 8 + (lane >> 3);
                     const unsigned long long b = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(myBase >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myBase, src, 64);
                     const yd_u32x4 v = *(YD_GLOBAL const yd_u32x4 *)((YD_GLOBAL const uint32_t *)b + (lane & 7) * 4);
-                    yd_u32x4 sw; { const uint32_t c[4] = {v.x, v.y, v.z, v.w}; sw.x = c[(0 ^ g) & 3]; sw.y = c[(1 ^ g) & 3]; sw.z = c[(2 ^ g) & 3]; sw.w = c[(3 ^ g) & 3]; }      // YD_TSWZ(src) = g & 3
+                    yd_u32x4 sw; { const uint32_t c[4] = {v.x, v.y, v.z, v.w}; constexpr int z = YD_TRACE_SWZ ? 3 : 0; sw.x = c[(0 ^ g) & z]; sw.y = c[1 ^ (g & z)]; sw.z = c[2 ^ (g & z)]; sw.w = c[3 ^ (g & z)]; }      // YD_TSWZ(src) = g & 3 (a renaming: g is a constant of the unrolled loop)
                     *(yd_u32x4 *)(wBlk + src * YD_TSTRIDE + (lane & 7) * 4) = sw;
                 }
                 __builtin_amdgcn_wave_barrier();

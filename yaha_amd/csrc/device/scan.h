@@ -3,8 +3,8 @@
 // exist only because a batch's variable-size outputs are laid out as count -> exclusive sum -> fill, and because lanes of a wave should run problems of one shape.
 //
 //   k_scan_excl<T>      out[i] = in[0] + ... + in[i-1] over n elements of u32 or u64, ONE launch, one read and one write of HBM per element: a workgroup owns a tile
-//                       of 4 096 elements (sixteen consecutive ones a thread: a serial prefix in registers, the lanes' totals by DPP, the four waves' through
-//                       LDS), the tile's offset comes from the tiles before it by decoupled look-back over 64-bit state words (status : 2 | value : 62).  The tile is
+//                       of 4 096 elements (a wave moves 1 KB of consecutive memory per instruction; sums inside 16-byte pieces, over the lanes by DPP, the four
+//                       waves' through LDS), the tile's offset comes from the tiles before it by decoupled look-back over 64-bit state words (status : 2 | value : 62).  The tile is
 //                       the TICKET a workgroup draws when it starts (seed.h: tileTicket -- no assumption about dispatch order).  The state is SELF-CLEANING: the last
 //                       workgroup to finish zeroes the words the launch used, so that the next launch needs no memset (the host zeroes the buffer when it makes it and
 //                       after a launch that reported a failure).
@@ -79,36 +79,45 @@ __device__ __forceinline__ unsigned long long tileLookBack64(unsigned long long 
 }
 
 // T = uint32_t: every sum is kept in 32 bits (the caller's total fits its own output type); T = unsigned long long: 62 bits.
+// A wave owns 64 * IPT consecutive elements and moves them in 16-byte pieces, piece (k, lane) = piece number k * 64 + lane of the wave's range: every load and
+// store instruction covers 1 KB of consecutive memory (a thread that owned IPT consecutive elements touched a 64-byte sector per lane and instruction: twice
+// as slow, measured).  Order of the sum: pieces by (k, lane), elements inside a piece.
 template <class T>
 __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, uint32_t n, unsigned long long *state /* scanStateBytes(n), zero */, unsigned int *failed)
 {
     YD_HIGH_PRIO();
-    constexpr int NW = YD_SCAN_BS / 64;
+    constexpr int NW = YD_SCAN_BS / 64, PER = 16 / (int)sizeof(T), NP = YD_SCAN_IPT / PER;      // elements a piece, pieces a lane
     __shared__ T sWave[NW]; __shared__ T sPrefix; __shared__ uint32_t sTile;
     const uint32_t nTiles = gridDim.x, t = threadIdx.x, lane = t & 63u, w = t >> 6;
     if (t == 0) sTile = (uint32_t)atomicAdd(&state[nTiles], 1ull);
     __syncthreads();
     const uint32_t tile = sTile;
-    const uint64_t i0 = (uint64_t)tile * YD_SCAN_TILE + (uint64_t)t * YD_SCAN_IPT;
-    T v[YD_SCAN_IPT];
-    const bool vec = i0 + YD_SCAN_IPT <= n && ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0u;      // whole threads of 16-byte aligned arrays move as vectors
-    if (vec) {
-        constexpr int PER = 16 / (int)sizeof(T);
+    const uint64_t wbase = (uint64_t)tile * YD_SCAN_TILE + (uint64_t)w * (64u * YD_SCAN_IPT);
+    const bool aligned = ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0u;
+    T v[NP][PER], pre[NP];
 #pragma unroll
-        for (int k = 0; k < YD_SCAN_IPT; k += PER) {
-            const uint4 a = *(const uint4 *)(in + i0 + k);
-            if (sizeof(T) == 4) { v[k] = (T)a.x; v[k + 1] = (T)a.y; v[k + 2] = (T)a.z; v[k + 3] = (T)a.w; }
-            else { v[k] = (T)(((unsigned long long)a.y << 32) | a.x); v[k + 1] = (T)(((unsigned long long)a.w << 32) | a.z); }
+    for (int k = 0; k < NP; k++) {
+        const uint64_t g0 = wbase + ((uint64_t)k * 64u + lane) * PER;
+        if (aligned && g0 + PER <= n) {
+            const uint4 a = *(const uint4 *)(in + g0);
+            if (sizeof(T) == 4) { v[k][0] = (T)a.x; v[k][1 % PER] = (T)a.y; v[k][2 % PER] = (T)a.z; v[k][3 % PER] = (T)a.w; }
+            else { v[k][0] = (T)(((unsigned long long)a.y << 32) | a.x); v[k][1] = (T)(((unsigned long long)a.w << 32) | a.z); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; j++) v[k][j] = g0 + j < n ? in[g0 + j] : (T)0;
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < YD_SCAN_IPT; k++) v[k] = i0 + k < n ? in[i0 + k] : (T)0;
     }
-    T sum = 0;                                                               // the thread's serial prefix: v[k] becomes the sum of the elements before it in the thread
+    T carry = 0;                                                             // sum of the wave's pieces (k' < k, any lane)
 #pragma unroll
-    for (int k = 0; k < YD_SCAN_IPT; k++) { const T x = v[k]; v[k] = sum; sum += x; }
-    const T incl = waveInclSumT(sum, lane);                                  // inclusive over the wave's lanes
-    if (lane == 63u) sWave[w] = incl;
+    for (int k = 0; k < NP; k++) {
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { const T x = v[k][j]; v[k][j] = s; s += x; }      // inside the piece: exclusive
+        const T incl = waveInclSumT(s, lane);
+        pre[k] = carry + incl - s;
+        carry += readLaneT(incl, 63);
+    }
+    if (lane == 0u) sWave[w] = carry;
     __syncthreads();
     if (w == 0u) {
         T wsum[NW], agg = 0;
@@ -122,19 +131,19 @@ __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, u
         if (lane == 0u) sPrefix = (T)excl;
     }
     __syncthreads();
-    const T base = sPrefix + sWave[w] + (incl - sum);
-    if (vec) {
-        constexpr int PER = 16 / (int)sizeof(T);
+    const T base = sPrefix + sWave[w];
 #pragma unroll
-        for (int k = 0; k < YD_SCAN_IPT; k += PER) {
+    for (int k = 0; k < NP; k++) {
+        const uint64_t g0 = wbase + ((uint64_t)k * 64u + lane) * PER; const T b = base + pre[k];
+        if (aligned && g0 + PER <= n) {
             uint4 a;
-            if (sizeof(T) == 4) { a.x = (uint32_t)(base + v[k]); a.y = (uint32_t)(base + v[k + 1]); a.z = (uint32_t)(base + v[k + 2]); a.w = (uint32_t)(base + v[k + 3]); }
-            else { const unsigned long long p = (unsigned long long)(base + v[k]), q = (unsigned long long)(base + v[k + 1]); a.x = (uint32_t)p; a.y = (uint32_t)(p >> 32); a.z = (uint32_t)q; a.w = (uint32_t)(q >> 32); }
-            *(uint4 *)(out + i0 + k) = a;
-        }
-    } else {
+            if (sizeof(T) == 4) { a.x = (uint32_t)(b + v[k][0]); a.y = (uint32_t)(b + v[k][1 % PER]); a.z = (uint32_t)(b + v[k][2 % PER]); a.w = (uint32_t)(b + v[k][3 % PER]); }
+            else { const unsigned long long p = (unsigned long long)(b + v[k][0]), q = (unsigned long long)(b + v[k][1]); a.x = (uint32_t)p; a.y = (uint32_t)(p >> 32); a.z = (uint32_t)q; a.w = (uint32_t)(q >> 32); }
+            *(uint4 *)(out + g0) = a;
+        } else {
 #pragma unroll
-        for (int k = 0; k < YD_SCAN_IPT; k++) if (i0 + k < n) out[i0 + k] = base + v[k];
+            for (int j = 0; j < PER; j++) if (g0 + j < n) out[g0 + j] = b + v[k][j];
+        }
     }
     // self-cleaning: whoever finishes last has seen every other workgroup leave its look-back
     __syncthreads();
