@@ -3,7 +3,7 @@
 TAG=${1:-kstats}; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-B="python3 $R/bench.py --no-cpu-baseline --no-extras"
+B="python3 $R/bench.py --no-cpu-baseline --no-extras --blocks 1"
 $B --steps 1 --warmup 0 > $OUT/warm.json 2> $OUT/warm.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats1 -o stats1 -- $B --steps 6 --warmup 2 --contexts 1 "$@" > $OUT/stats1.json 2> $OUT/stats1.err
 f=$(find $OUT/stats1 -name "*kernel_stats.csv" | head -1); cp $f $OUT/kernel_stats.csv

@@ -36,7 +36,7 @@ step)
   for rep in 1 2 3; do $B --steps 12 --warmup 2 2>/dev/null | line "default contexts"; done
   $B --steps 6 --warmup 2 --contexts 1 2>/dev/null | line "one context"
   O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-  rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o stats -- python3 $R/bench.py --steps 8 --warmup 2 --contexts 1 --no-cpu-baseline --no-extras > $O/bench.json 2> $O/bench.err
+  rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o stats -- python3 $R/bench.py --steps 8 --warmup 2 --contexts 1 --blocks 1 --no-cpu-baseline --no-extras > $O/bench.json 2> $O/bench.err
   kernel_table $O/stats 10; cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; rm -rf $O/stats ;;
 ab)
   V=$1; A=$2; Bv=$3; CT=${4:-}; warm
@@ -45,7 +45,7 @@ ab)
 kstats)
   TAG=${1:-kstats}; CT=${2:-1}; shift; shift; warm
   O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-  rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o stats -- python3 $R/bench.py --steps 8 --warmup 2 --contexts $CT --no-cpu-baseline --no-extras "$@" > $O/bench.json 2> $O/bench.err
+  rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o stats -- python3 $R/bench.py --steps 8 --warmup 2 --contexts $CT --blocks 1 --no-cpu-baseline --no-extras "$@" > $O/bench.json 2> $O/bench.err
   kernel_table $O/stats $((8 + 3 * CT)); cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; cp $(find $O/stats -name "*kernel_trace.csv" | head -1) $O/kernel_trace.csv; rm -rf $O/stats; tail -1 $O/bench.json | line "under the profiler" ;;      # 8 timed steps + (first pass + 2 warm-up) per context
 cli|cli10k)
   TAG=${1:-cli}; shift; warm

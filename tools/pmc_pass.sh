@@ -4,7 +4,7 @@
 TAG=${1:-pmc}; READS=${2:-16384}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-B="python3 $R/bench.py --reads-per-gpu $READS --no-cpu-baseline --no-extras"
+B="python3 $R/bench.py --reads-per-gpu $READS --no-cpu-baseline --no-extras --blocks 1"
 $B --steps 1 --warmup 0 > $OUT/warm.json 2> $OUT/warm.err   # builds the index cache
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $B --steps 6 --warmup 2 > $OUT/stats.json 2> $OUT/stats.err

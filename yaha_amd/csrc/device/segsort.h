@@ -86,30 +86,31 @@ __global__ void __launch_bounds__(1024) k_seg_split(const unsigned long long *in
 {
     YD_HIGH_PRIO();
     // Wave w owns the w-th sixteenth of the segment and walks it 64 hits at a time (coalesced); the stable order is (wave, group, lane).
-    __shared__ uint32_t sCnt[YD_SPLIT_NB][16];                                // [bucket][wave]: counts, then running write positions
+    __shared__ uint32_t sCnt[16][YD_SPLIT_NB];                                // [wave][bucket]: counts, then running write positions (a wave's 64 atomics go to 16 banks; as
+                                                                              // [bucket][wave] they went to two: 85 % of the kernel's LDS cycles were bank conflicts)
     const uint32_t seg = bigList[blockIdx.x], b = segB[seg], len = segE[seg] - b, t = threadIdx.x, lane = t & 63u, w = t >> 6;
     int lg = 0; while (lg < 4 && ((len + 6143u) / 6144u) > (1u << lg)) lg++;                     // ~6 k hits a bucket on average, 16 buckets at most
     const uint32_t nb = 1u << lg; const int sh = diagBits > lg ? diagBits - lg : 0;
     const uint32_t per = ((len + 15u) / 16u + 63u) & ~63u, k0 = min(len, w * per), k1 = min(len, k0 + per);   // the wave's range, whole groups of 64
-    if (t < YD_SPLIT_NB * 16u) sCnt[t >> 4][t & 15u] = 0u;
+    if (t < YD_SPLIT_NB * 16u) sCnt[t & 15u][t >> 4] = 0u;
     __syncthreads();
     // pass 1: hits per (bucket, wave)
-    for (uint32_t k = k0 + lane; k < k1; k += 64u) { const uint32_t d = (uint32_t)(in[b + k] >> 15); atomicAdd(&sCnt[min(d >> sh, nb - 1u)][w], 1u); }
+    for (uint32_t k = k0 + lane; k < k1; k += 64u) { const uint32_t d = (uint32_t)(in[b + k] >> 15); atomicAdd(&sCnt[w][min(d >> sh, nb - 1u)], 1u); }
     __syncthreads();
     // exclusive scan in (bucket, wave) order: 256 entries, one wave does it (4 per lane)
     if (w == 0) {
         uint32_t v[4], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { v[k] = sum; sum += (&sCnt[0][0])[4u * lane + (uint32_t)k]; }
+        for (int k = 0; k < 4; k++) { v[k] = sum; sum += sCnt[(4u * lane + (uint32_t)k) & 15u][lane >> 2]; }      // entry e = bucket * 16 + wave, e = 4 lane + k
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
         const uint32_t excl = incl - sum;
 #pragma unroll
-        for (int k = 0; k < 4; k++) (&sCnt[0][0])[4u * lane + (uint32_t)k] = excl + v[k];
+        for (int k = 0; k < 4; k++) sCnt[(4u * lane + (uint32_t)k) & 15u][lane >> 2] = excl + v[k];
     }
     __syncthreads();
-    if (t < YD_SPLIT_NB) { subB[blockIdx.x * YD_SPLIT_NB + t] = b + sCnt[t][0]; subE[blockIdx.x * YD_SPLIT_NB + t] = t + 1u < YD_SPLIT_NB ? b + sCnt[t + 1u][0] : b + len; }
+    if (t < YD_SPLIT_NB) { subB[blockIdx.x * YD_SPLIT_NB + t] = b + sCnt[0][t]; subE[blockIdx.x * YD_SPLIT_NB + t] = t + 1u < YD_SPLIT_NB ? b + sCnt[0][t + 1u] : b + len; }
     __syncthreads();
     // pass 2: every group of 64 is split by bucket with four ballots (the lanes of one bucket keep their order), written behind what the wave has already
     // written into that bucket
@@ -121,9 +122,9 @@ __global__ void __launch_bounds__(1024) k_seg_split(const unsigned long long *in
 #pragma unroll
         for (int bit = 0; bit < 4; bit++) { const unsigned long long m = __ballot((bk >> bit) & 1u); peers &= ((bk >> bit) & 1u) ? m : ~m; }
         const uint32_t rank = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
-        if (live) out[b + sCnt[bk][w] + rank] = key;
+        if (live) out[b + sCnt[w][bk] + rank] = key;
         __builtin_amdgcn_wave_barrier();
-        if (live && rank == 0u) sCnt[bk][w] += (uint32_t)__builtin_popcountll(peers);          // the bucket's first lane moves the wave's position on
+        if (live && rank == 0u) sCnt[w][bk] += (uint32_t)__builtin_popcountll(peers);          // the bucket's first lane moves the wave's position on
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -136,9 +137,9 @@ __global__ void __launch_bounds__(1024) k_seg_split_range(const unsigned long lo
                                                           uint32_t *subB, uint32_t *subE)
 {
     YD_HIGH_PRIO();
-    __shared__ uint32_t sCnt[YD_SPLIT_NB][16]; __shared__ uint32_t sMin, sMax;
+    __shared__ uint32_t sCnt[16][YD_SPLIT_NB]; __shared__ uint32_t sMin, sMax;
     const uint32_t seg = list[blockIdx.x], b = segB[seg], len = segE[seg] - b, t = threadIdx.x, lane = t & 63u, w = t >> 6;
-    if (t < YD_SPLIT_NB * 16u) sCnt[t >> 4][t & 15u] = 0u;
+    if (t < YD_SPLIT_NB * 16u) sCnt[t & 15u][t >> 4] = 0u;
     if (t == 0) { sMin = 0xFFFFFFFFu; sMax = 0u; }
     __syncthreads();
     { uint32_t mn = 0xFFFFFFFFu, mx = 0u;
@@ -156,21 +157,21 @@ __global__ void __launch_bounds__(1024) k_seg_split_range(const unsigned long lo
     const unsigned long long range = (unsigned long long)(mx - mn) + 1ull;
     auto bucket = [&](unsigned long long key) { return (uint32_t)((((unsigned long long)((uint32_t)(key >> 15) - mn)) * (unsigned long long)YD_SPLIT_NB) / range); };
     const uint32_t per = ((len + 15u) / 16u + 63u) & ~63u, k0 = min(len, w * per), k1 = min(len, k0 + per);   // the wave's range, whole groups of 64 (as k_seg_split)
-    for (uint32_t k = k0 + lane; k < k1; k += 64u) atomicAdd(&sCnt[bucket(in[b + k])][w], 1u);
+    for (uint32_t k = k0 + lane; k < k1; k += 64u) atomicAdd(&sCnt[w][bucket(in[b + k])], 1u);
     __syncthreads();
     if (w == 0) {
         uint32_t v[4], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { v[k] = sum; sum += (&sCnt[0][0])[4u * lane + (uint32_t)k]; }
+        for (int k = 0; k < 4; k++) { v[k] = sum; sum += sCnt[(4u * lane + (uint32_t)k) & 15u][lane >> 2]; }      // entry e = bucket * 16 + wave, e = 4 lane + k
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
         const uint32_t excl = incl - sum;
 #pragma unroll
-        for (int k = 0; k < 4; k++) (&sCnt[0][0])[4u * lane + (uint32_t)k] = excl + v[k];
+        for (int k = 0; k < 4; k++) sCnt[(4u * lane + (uint32_t)k) & 15u][lane >> 2] = excl + v[k];
     }
     __syncthreads();
-    if (t < YD_SPLIT_NB) { subB[blockIdx.x * YD_SPLIT_NB + t] = b + sCnt[t][0]; subE[blockIdx.x * YD_SPLIT_NB + t] = t + 1u < YD_SPLIT_NB ? b + sCnt[t + 1u][0] : b + len; }
+    if (t < YD_SPLIT_NB) { subB[blockIdx.x * YD_SPLIT_NB + t] = b + sCnt[0][t]; subE[blockIdx.x * YD_SPLIT_NB + t] = t + 1u < YD_SPLIT_NB ? b + sCnt[0][t + 1u] : b + len; }
     __syncthreads();
     for (uint32_t g = k0; g < k1; g += 64u) {
         const uint32_t k = g + lane; const bool live = k < k1;
@@ -180,9 +181,9 @@ __global__ void __launch_bounds__(1024) k_seg_split_range(const unsigned long lo
 #pragma unroll
         for (int bit = 0; bit < 4; bit++) { const unsigned long long m = __ballot((bk >> bit) & 1u); peers &= ((bk >> bit) & 1u) ? m : ~m; }
         const uint32_t rank = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
-        if (live) out[b + sCnt[bk][w] + rank] = key;
+        if (live) out[b + sCnt[w][bk] + rank] = key;
         __builtin_amdgcn_wave_barrier();
-        if (live && rank == 0u) sCnt[bk][w] += (uint32_t)__builtin_popcountll(peers);
+        if (live && rank == 0u) sCnt[w][bk] += (uint32_t)__builtin_popcountll(peers);
         __builtin_amdgcn_wave_barrier();
     }
 }
