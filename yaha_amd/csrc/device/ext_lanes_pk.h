@@ -53,6 +53,12 @@ __device__ __forceinline__ uint32_t pkSignMaskAsm(uint32_t a, uint32_t c15) { ui
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }                      // v_bfi_b32
 __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) * 0x10001u; }
 
+// YD_ROWS_LDSWIN (round 5): the two nibble streams of a lane -- query codes, reference bases -- come from HBM in ALIGNED 16-BYTE PIECES (one request per lane and 32
+// rows, a 64-byte sector is visited four times instead of sixteen) that are staged in LDS ([dword][thread]: conflict-free for the one-dword reads); every 8th row a lane
+// takes its next dword of eight entries from there.  0: every refill is a dword load from HBM (rounds 2-4).
+#ifndef YD_ROWS_LDSWIN
+#define YD_ROWS_LDSWIN 1
+#endif
 #ifndef YD_ROWS_WAVES
 #define YD_ROWS_WAVES 3                        // waves per SIMD of k_ext_rows_pk (a build switch for experiments: make variant VARIANT_FLAGS=-DYD_ROWS_WAVES=2)
 #endif
@@ -60,6 +66,11 @@ template <bool SECOND>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROWS_WAVES, YD_ROWS_WAVES))) k_ext_rows_pk(ExtArgs A)
 {
     __shared__ uint32_t sBlk[256 * YD_LDS_STRIDE];   // per lane: the current block of eight 16-byte records, lane stride 33
+#if YD_ROWS_LDSWIN
+    __shared__ uint32_t sWin[8][256];                // per thread: the current 16-byte piece of its query stream (dwords 0..3) and of its reference stream (4..7)
+    yd_u32x4 GQ = {0u, 0u, 0u, 0u}, GR = {0u, 0u, 0u, 0u}; int jQ = 0, jR = 0; bool newQ = false, newR = false, freshQ = false, freshR = false;
+    const unsigned tid = threadIdx.x;
+#endif
     if (!SECOND && A.clock && threadIdx.x == 0) atomicMin(&A.clock[0], (unsigned long long)wall_clock64());
     const int lane = laneId();
     const int GO = A.P.GO, GE = A.P.GE, XC = A.P.X;
@@ -143,6 +154,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
         // the dwords the previous pass loaded go to the ends of the windows (entries in consumption order: a reverse extension's bytes, and its nibbles, swapped)
         if (insQ) {
             if (pendQ) {
+#if YD_ROWS_LDSWIN
+                if (newQ) { sWin[0][tid] = GQ.x; sWin[1][tid] = GQ.y; sWin[2][tid] = GQ.z; sWin[3][tid] = GQ.w; qLd = sWin[jQ][tid]; }      // a fresh piece: into the lane's slot; its dword jQ is the one due
+#endif
                 const uint32_t sw = ((qLd & 0x0F0F0F0Fu) << 4) | ((qLd >> 4) & 0x0F0F0F0Fu);      // forward: the even offset (high nibble) first
                 const uint32_t v = qStep < 0 ? __builtin_amdgcn_perm(0u, qLd, 0x00010203u) : sw;   // reverse: bytes swapped, each byte's low nibble (the higher offset) first
                 const unsigned long long t = (unsigned long long)v << (4 * (qHave & 15));
@@ -152,6 +166,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
         }
         if (insR) {
             if (pendR) {
+#if YD_ROWS_LDSWIN
+                if (newR) { sWin[4][tid] = GR.x; sWin[5][tid] = GR.y; sWin[6][tid] = GR.z; sWin[7][tid] = GR.w; rLd = sWin[4 + jR][tid]; }
+#endif
                 const uint32_t sw = ((rLd & 0x0F0F0F0Fu) << 4) | ((rLd >> 4) & 0x0F0F0F0Fu);      // forward: the even offset (high nibble) first
                 const uint32_t v = qStep < 0 ? __builtin_amdgcn_perm(0u, rLd, 0x00010203u) : sw;   // reverse: bytes swapped, each byte's low nibble (the higher offset) first
                 const unsigned long long t = (unsigned long long)v << (4 * (rHave & 15));
@@ -263,6 +280,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
                 rOffP = gROff; rLenP = (int)(gLens >> 16); rLeft = rLenP - bandwidth;
                 rwLo = gRwLo; rwHi = gRwHi; rHave = (int)(gHave >> 8); rNext = 11 + rHave; pendR = false;
                 pStart = (flush << 4) | (unsigned)wslot;
+#if YD_ROWS_LDSWIN
+                freshQ = true; freshR = true;                                // (the lane's staged pieces are the previous problem's)
+#endif
             }
             poolNext += nNeed < avail ? nNeed : avail;
         }
@@ -279,11 +299,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
         // refills (wave-uniform schedule): the loads are consumed at the top of the next pass
         if (wslot == 0) {
             pendQ = qHave <= 8 && qNext < qLen;
+#if YD_ROWS_LDSWIN
+            // the dword that is due: out of the lane's staged piece -- or, when it is the first dword of the next aligned 16-byte piece (the last one going down), or the
+            // first refill of a problem, that whole piece from HBM (it goes to LDS at the top of the next pass).  An aligned piece that holds a dword of the
+            // extension lies inside the arrays (they start on 256-byte boundaries and have slack behind).
+            newQ = false;
+            if (pendQ) {
+                const uint32_t n = qStep < 0 ? qPos - (uint32_t)qNext - 7u : qPos + (uint32_t)qNext, da = n >> 1; const int j = (int)((da >> 2) & 3u);      // (da: dword-aligned byte offset)
+                if (freshQ || j == (qStep < 0 ? 3 : 0)) { GQ = *(YD_GLOBAL const yd_u32x4 *)(q4 + (da & ~15u)); newQ = true; freshQ = false; jQ = j; }
+                else qLd = sWin[j][tid];
+            }
+            insQ = true;
+            pendR = rHave <= 8 && rNext < rLenP;
+            newR = false;
+            if (pendR) {
+                const uint32_t n = qStep < 0 ? rOffP - (uint32_t)rNext - 7u : rOffP + (uint32_t)rNext, da = n >> 1; const int j = (int)((da >> 2) & 3u);
+                if (freshR || j == (qStep < 0 ? 3 : 0)) { GR = *(YD_GLOBAL const yd_u32x4 *)(gBases + (da & ~15u)); newR = true; freshR = false; jR = j; }
+                else rLd = sWin[4 + j][tid];
+            }
+            insR = true;
+#else
             if (pendQ) { const uint32_t n = qStep < 0 ? qPos - (uint32_t)qNext - 7u : qPos + (uint32_t)qNext; qLd = *(YD_GLOBAL const uint32_t *)(q4 + (n >> 1)); }      // (nibble qPos + qNext * qStep is dword-aligned going up, the last nibble of a dword going down)
             insQ = true;
             pendR = rHave <= 8 && rNext < rLenP;
             if (pendR) { const uint32_t n = qStep < 0 ? rOffP - (uint32_t)rNext - 7u : rOffP + (uint32_t)rNext; rLd = *(YD_GLOBAL const uint32_t *)(gBases + (n >> 1)); }
             insR = true;
+#endif
         }
         // the iteration's stores, behind its loads: a finished problem's result and the blocks that leave
         if (pendRes >= 0) {

@@ -16,11 +16,12 @@
 #pragma once
 #include "common.h"
 
-#define YD_SCAN_BS 256
-#define YD_SCAN_IPT 16
+#define YD_SCAN_BS 1024
+#define YD_SCAN_IPT 32                       // u32 elements a thread (128 bytes; u64: 16).  The tiles' look-back is a chain that advances 64 tiles a round trip: 50 ns a
+                                             // tile, measured (4 096-element tiles: 400 us for 32 M elements) -- so a tile is as large as a workgroup can make it: 128 KB
 #define YD_SCAN_TILE (YD_SCAN_BS * YD_SCAN_IPT)
-__host__ __device__ inline uint32_t scanTiles(uint64_t n) { return (uint32_t)((n + YD_SCAN_TILE - 1) / YD_SCAN_TILE); }
-__host__ __device__ inline size_t scanStateBytes(uint64_t n) { return 8ull * ((size_t)scanTiles(n) + 4); }       // tile words, ticket, done counter
+__host__ __device__ inline uint32_t scanTiles(uint64_t n, int elemBytes = 4) { const uint64_t tile = (uint64_t)YD_SCAN_TILE * 4u / (unsigned)elemBytes; return (uint32_t)((n + tile - 1) / tile); }
+__host__ __device__ inline size_t scanStateBytes(uint64_t n) { return 8ull * ((size_t)scanTiles(n, 8) + 4); }       // tile words (at most: the u64 tiling), ticket, done counter
 
 // inclusive sum over the 64 lanes by DPP (VALU rate; __shfl_up is a trip through the LDS crossbar): row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast 15 / 31
 __device__ __forceinline__ uint32_t waveInclSumU(uint32_t v)
@@ -31,11 +32,11 @@ __device__ __forceinline__ uint32_t waveInclSumU(uint32_t v)
 }
 __device__ __forceinline__ unsigned long long shflUp64(unsigned long long v, int d)
 { return ((unsigned long long)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)v, d, 64); }
+// sum over all lanes of a 62-bit value, by DPP: three 32-bit sums (16 + 16 + 30 bits: none can overflow over 64 lanes)
 __device__ __forceinline__ unsigned long long waveSum64(unsigned long long v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
-    return v;
+    const uint32_t a = waveInclSumU((uint32_t)v & 0xFFFFu), b = waveInclSumU(((uint32_t)v >> 16) & 0xFFFFu), c = waveInclSumU((uint32_t)(v >> 32));
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)a, 63) + ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)b, 63) << 16) + ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c, 63) << 32);
 }
 // inclusive sum over the lanes in the width of T: u32 by DPP, u64 by shuffles (one or two such sums a batch)
 __device__ __forceinline__ uint32_t waveInclSumT(uint32_t v, uint32_t) { return waveInclSumU(v); }
@@ -86,13 +87,13 @@ template <class T>
 __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, uint32_t n, unsigned long long *state /* scanStateBytes(n), zero */, unsigned int *failed)
 {
     YD_HIGH_PRIO();
-    constexpr int NW = YD_SCAN_BS / 64, PER = 16 / (int)sizeof(T), NP = YD_SCAN_IPT / PER;      // elements a piece, pieces a lane
+    constexpr int NW = YD_SCAN_BS / 64, PER = 16 / (int)sizeof(T), NP = YD_SCAN_IPT / 4, IPT = NP * PER;      // elements a piece, pieces a lane (eight 16-byte pieces), elements a lane
     __shared__ T sWave[NW]; __shared__ T sPrefix; __shared__ uint32_t sTile;
     const uint32_t nTiles = gridDim.x, t = threadIdx.x, lane = t & 63u, w = t >> 6;
     if (t == 0) sTile = (uint32_t)atomicAdd(&state[nTiles], 1ull);
     __syncthreads();
     const uint32_t tile = sTile;
-    const uint64_t wbase = (uint64_t)tile * YD_SCAN_TILE + (uint64_t)w * (64u * YD_SCAN_IPT);
+    const uint64_t wbase = ((uint64_t)tile * YD_SCAN_BS + (uint64_t)w * 64u) * IPT;
     const bool aligned = ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0u;
     T v[NP][PER], pre[NP];
 #pragma unroll
@@ -120,14 +121,10 @@ __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, u
     if (lane == 0u) sWave[w] = carry;
     __syncthreads();
     if (w == 0u) {
-        T wsum[NW], agg = 0;
-#pragma unroll
-        for (int k = 0; k < NW; k++) { wsum[k] = agg; agg += sWave[k]; }     // (four waves: every lane of wave 0 adds them up itself)
+        const T mine = lane < (uint32_t)NW ? sWave[lane] : (T)0;             // lane k: wave k's sum
+        const T wincl = waveInclSumT(mine, lane), agg = readLaneT(wincl, 63);
         const unsigned long long excl = tileLookBack64(state, tile, (unsigned long long)agg, lane, failed);
-        if (lane < (uint32_t)NW) { T mine = wsum[0];
-#pragma unroll
-            for (int k = 1; k < NW; k++) mine = lane == (uint32_t)k ? wsum[k] : mine;
-            sWave[lane] = mine; }
+        if (lane < (uint32_t)NW) sWave[lane] = wincl - mine;                  // exclusive over the waves
         if (lane == 0u) sPrefix = (T)excl;
     }
     __syncthreads();

@@ -112,7 +112,7 @@ template <class T> static int ownScanT(ygpu_ctx *ctx, const T *in, T *out, uint3
         if (ctx->scanState.ensure(std::max<size_t>(need, 1u << 16))) { ctx->err = "hipMalloc(scan state)"; return YGPU_ENOMEM; }
         HIPCHK(hipMemsetAsync(ctx->scanState.p, 0, ctx->scanState.cap, st));
     }
-    hipLaunchKernelGGL((k_scan_excl<T>), dim3(scanTiles(n)), dim3(YD_SCAN_BS), 0, st, in, out, n, ctx->scanState.as<unsigned long long>(), ctx->counters.as<unsigned int>() + CNT_SCANFAIL);
+    hipLaunchKernelGGL((k_scan_excl<T>), dim3(scanTiles(n, (int)sizeof(T))), dim3(YD_SCAN_BS), 0, st, in, out, n, ctx->scanState.as<unsigned long long>(), ctx->counters.as<unsigned int>() + CNT_SCANFAIL);
     hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ctx->err = std::string("launch of k_scan_excl failed: ") + hipGetErrorString(e_); return YGPU_ENODEV; }
     return 0;
 }
