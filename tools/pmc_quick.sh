@@ -3,7 +3,7 @@
 TAG=${1:-pmcq}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-B="python3 $R/bench.py --no-cpu-baseline --no-extras"
+B="python3 $R/bench.py --no-cpu-baseline --no-extras --blocks 1"
 $B --steps 1 --warmup 0 > $OUT/warm.json 2> $OUT/warm.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats1 -o stats1 -- $B --steps 3 --warmup 1 --contexts 1 > $OUT/stats1.json 2> $OUT/stats1.err
 pass() { name=$1; shift; timeout 240 rocprofv3 --output-format csv --kernel-trace --pmc "$@" -d $OUT/$name -o $name -- $B --steps 1 --warmup 0 --contexts 1 > $OUT/$name.json 2> $OUT/$name.err || echo "pass $name failed"; }

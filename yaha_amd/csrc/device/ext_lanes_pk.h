@@ -56,8 +56,10 @@ __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) 
 // YD_ROWS_LDSWIN (round 5): the two nibble streams of a lane -- query codes, reference bases -- come from HBM in ALIGNED 16-BYTE PIECES (one request per lane and 32
 // rows, a 64-byte sector is visited four times instead of sixteen) that are staged in LDS ([dword][thread]: conflict-free for the one-dword reads); every 8th row a lane
 // takes its next dword of eight entries from there.  0: every refill is a dword load from HBM (rounds 2-4).
+// Built, bit-exact, and SLOWER (profiles/r05_rows_lds_windows.txt: k_ext_rows_pk 14.68 -> 15.62 ms a launch, 44.5 -> 46.1 ms a step with four contexts): a lane's
+// stream is private to it, so the staging buys no reuse, only larger requests -- and the kernel is bound by instruction issue, not by its requests.  Off.
 #ifndef YD_ROWS_LDSWIN
-#define YD_ROWS_LDSWIN 1
+#define YD_ROWS_LDSWIN 0
 #endif
 #ifndef YD_ROWS_WAVES
 #define YD_ROWS_WAVES 3                        // waves per SIMD of k_ext_rows_pk (a build switch for experiments: make variant VARIANT_FLAGS=-DYD_ROWS_WAVES=2)
