@@ -209,7 +209,7 @@ int runQueries(Args &a, FILE *log)
     if (fputs(S->header.c_str(), out) < 0) { fprintf(log, "Failure writing the output file.\n"); return 1; }
     ygpu_params P; paramsFromArgs(A, P);
     ygpu_index_view V; yaha_session_index_view(S.get(), &V);
-    // -gpus N devices x -ctx M contexts per device (default 3: while one context's batch is in a latency-bound device stage the others'
+    // -gpus N devices x -ctx M contexts per device (default 4 since round 5 -- the further contexts are presized from the first one, so a fourth costs nothing at the start; 3 before: while one context's batch is in a latency-bound device stage the others'
     // batches compute).  Contexts of one device share its index image.
     const int perDev = std::max(1, A.ctxPerGpu), nDev = std::max(1, A.gpus), ngpu = nDev * perDev;
     std::vector<ygpu_ctx *> ctx(ngpu, nullptr);
