@@ -188,24 +188,27 @@ def host_ceiling(ya, idx, reads_path, n_devices=8):
     with ya.Session(["-x", idx, "-q", reads_path]) as s0:
         b0 = s0.next_batch(N)
         ctx = ya.Context(s0.index, s0.params)
-        ctx.upload(b0); ctx.run(); ctx.set_postfilter(s0); f = ctx.postfilter()
-        sessions = [ya.Session(["-x", idx, "-q", reads_path, "-t", "1"]) for _ in range(n_fmt)]
-        for x in sessions:
-            assert x.next_batch(N).n_reads == N
-        reps = 12
+        sessions = []
+        try:
+            ctx.upload(b0); ctx.run(); ctx.set_postfilter(s0); f = ctx.postfilter()
+            sessions = [ya.Session(["-x", idx, "-q", reads_path, "-t", "1"]) for _ in range(n_fmt)]
+            for x in sessions:
+                assert x.next_batch(N).n_reads == N
+            reps = 12
 
-        def work(x):
-            t_, n_ = C.c_char_p(), C.c_size_t()
-            for _ in range(reps):
-                assert ya.lib().yaha_session_emit_filtered(x._h, C.byref(f), C.byref(t_), C.byref(n_)) == 0
-        th = [threading.Thread(target=work, args=(x,)) for x in sessions]
-        t = time.time()
-        for x in th: x.start()
-        for x in th: x.join()
-        res["format_reads_per_s"] = N * n_fmt * reps / (time.time() - t)
-        for x in sessions:
-            x.close()
-        ctx.close()
+            def work(x):
+                t_, n_ = C.c_char_p(), C.c_size_t()
+                for _ in range(reps):
+                    assert ya.lib().yaha_session_emit_filtered(x._h, C.byref(f), C.byref(t_), C.byref(n_)) == 0
+            th = [threading.Thread(target=work, args=(x,)) for x in sessions]
+            t = time.time()
+            for x in th: x.start()
+            for x in th: x.join()
+            res["format_reads_per_s"] = N * n_fmt * reps / (time.time() - t)
+        finally:
+            for x in sessions:
+                x.close()
+            ctx.close()
     res["host_ceiling_reads_per_s"] = min(res.get("parse_reads_per_s", 0.0), res["format_reads_per_s"])
     return res
 
@@ -392,21 +395,23 @@ def side_workload(ya, idx, reads_path, n_reads, device, contexts, steps, label, 
         offs = C.cast(b.offsets, C.POINTER(C.c_uint64))
         n, bases = b.n_reads, int(offs[b.n_reads] - offs[0])
         ctxs = [ya.Context(s.index, s.params, device=device)]
-        for _ in range(1, max(1, contexts)):
-            ctxs.append(ya.Context(s.index, s.params, device=device, parent=ctxs[0]))
-        for c in ctxs:
-            c.upload(b)
-            c.run()
-            c.run()                                     # two warm-up passes: the first one sizes the arenas, the second one runs with them
-        dts, st = [], {}
-        for _b in range(max(1, blocks)):
-            d1, s1 = run_contexts(ctxs, steps); dts.append(d1)
-            for k2, v in s1.items():
-                st[k2] = st.get(k2, 0.0) + v / max(1, blocks)
-        dt = sorted(dts)[len(dts) // 2]
-        cnt = ctxs[0].collect().counters.as_dict()
-        for c in reversed(ctxs):
-            c.close()
+        try:                                            # (whatever happens, the contexts are closed: a leg that fails must not leave ~200 GB of arenas behind for the legs after it)
+            for _ in range(1, max(1, contexts)):
+                ctxs.append(ya.Context(s.index, s.params, device=device, parent=ctxs[0]))
+            for c in ctxs:
+                c.upload(b)
+                c.run()
+                c.run()                                 # two warm-up passes: the first one sizes the arenas, the second one runs with them
+            dts, st = [], {}
+            for _b in range(max(1, blocks)):
+                d1, s1 = run_contexts(ctxs, steps); dts.append(d1)
+                for k2, v in s1.items():
+                    st[k2] = st.get(k2, 0.0) + v / max(1, blocks)
+            dt = sorted(dts)[len(dts) // 2]
+            cnt = ctxs[0].collect().counters.as_dict()
+        finally:
+            for c in reversed(ctxs):
+                c.close()
     return {"workload": label, "reads_per_step": n, "steps": steps, "blocks": len(dts), "reads_per_s": n * steps / dt, "bases_per_s": bases * steps / dt, "ms_per_step": 1e3 * dt / steps, "ms_per_step_min": 1e3 * min(dts) / steps, "ms_per_step_max": 1e3 * max(dts) / steps,
             "k_ext_rows_ms_per_step": st.get("ext_rows_device_clock", 0.0) / steps, "dp_cells_per_read": (cnt["dp_ext_cells"] + cnt["dp_gap_cells"]) / max(n, 1), "hits_per_read": cnt["hits"] / max(n, 1)}
 
