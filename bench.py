@@ -396,12 +396,25 @@ def side_workload(ya, idx, reads_path, n_reads, device, contexts, steps, label, 
         n, bases = b.n_reads, int(offs[b.n_reads] - offs[0])
         ctxs = [ya.Context(s.index, s.params, device=device)]
         try:                                            # (whatever happens, the contexts are closed: a leg that fails must not leave ~200 GB of arenas behind for the legs after it)
-            for _ in range(1, max(1, contexts)):
-                ctxs.append(ya.Context(s.index, s.params, device=device, parent=ctxs[0]))
-            for c in ctxs:
-                c.upload(b)
-                c.run()
-                c.run()                                 # two warm-up passes: the first one sizes the arenas, the second one runs with them
+            # every context takes its two warm-up passes (the first one sizes its arenas, the second one runs with them) before the next one is made: a context that
+            # does not fit beside the others (larger batches than the headline's: 10 kbp reads, the c5 set) is left out instead of squeezing all of them
+            ctxs[0].upload(b); ctxs[0].run(); ctxs[0].run()
+            for k in range(1, max(1, contexts)):
+                c = None
+                try:
+                    free_b, _tot, first = ctxs[0].memory()
+                    image = int(s.index.n_base_bytes) + 4 * int(s.index.totalMatches) + 4 * (4 ** int(s.index.wordLen) + 1)      # (the first context's figure includes the index image)
+                    if free_b < 1.1 * max(first - image, 1 << 30):
+                        log("%s: %d contexts (%.0f GB free, a context's arenas hold %.0f GB)" % (label[:24], k, free_b / 1e9, (first - image) / 1e9))
+                        break
+                    c = ya.Context(s.index, s.params, device=device, parent=ctxs[0])
+                    c.upload(b); c.run(); c.run()
+                    ctxs.append(c)
+                except Exception as e:
+                    log("%s: context %d of %d left out (%s)" % (label[:24], k + 1, contexts, str(e)[:100]))
+                    if c is not None:
+                        c.close()
+                    break
             dts, st = [], {}
             for _b in range(max(1, blocks)):
                 d1, s1 = run_contexts(ctxs, steps); dts.append(d1)
@@ -412,7 +425,7 @@ def side_workload(ya, idx, reads_path, n_reads, device, contexts, steps, label, 
         finally:
             for c in reversed(ctxs):
                 c.close()
-    return {"workload": label, "reads_per_step": n, "steps": steps, "blocks": len(dts), "reads_per_s": n * steps / dt, "bases_per_s": bases * steps / dt, "ms_per_step": 1e3 * dt / steps, "ms_per_step_min": 1e3 * min(dts) / steps, "ms_per_step_max": 1e3 * max(dts) / steps,
+    return {"workload": label, "contexts": len(ctxs), "reads_per_step": n, "steps": steps, "blocks": len(dts), "reads_per_s": n * steps / dt, "bases_per_s": bases * steps / dt, "ms_per_step": 1e3 * dt / steps, "ms_per_step_min": 1e3 * min(dts) / steps, "ms_per_step_max": 1e3 * max(dts) / steps,
             "k_ext_rows_ms_per_step": st.get("ext_rows_device_clock", 0.0) / steps, "dp_cells_per_read": (cnt["dp_ext_cells"] + cnt["dp_gap_cells"]) / max(n, 1), "hits_per_read": cnt["hits"] / max(n, 1)}
 
 
