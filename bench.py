@@ -231,7 +231,7 @@ def eight_logical_devices(ya, cache, seed, n_reads=1048576):
             same = [l for l in open(one) if not l.startswith("@PG")] == [l for l in open(eight) if not l.startswith("@PG")]
         return {"reads": n_reads, "index": "100 Mbp -L 15", "command": "YAHA_DEVICES=0,0,0,0,0,0,0,0 yaha -gpus 8 -ctx 1 -batch 4096", "seconds": dt8, "e2e_reads_per_s": n_reads / dt8, "steady_reads_per_s": st8.get("steady_reads_per_s"),
                 "contexts_up_ms": st8.get("contexts_up_ms"), "reads_per_device": st8.get("reads_per_device"), "parsers": st8.get("parsers"), "formatters": st8.get("formatters"), "ctx_left_out": st8.get("ctx_left_out"),
-                "one_device": {"command": "yaha -batch 4096 (-ctx 4)", "seconds": dt1, "steady_reads_per_s": st1.get("steady_reads_per_s")}, "output_identical_to_one_device": same}
+                "one_device": {"command": "yaha -batch 4096 (-ctx 3)", "seconds": dt1, "steady_reads_per_s": st1.get("steady_reads_per_s")}, "output_identical_to_one_device": same}
     finally:
         for f in (one, eight):
             if os.path.exists(f):
@@ -479,7 +479,7 @@ def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1, read_len=1000, div=0.0
     steady = stats[best].get("steady_reads_per_s")
     return {"reads": n_reads, "gpus": gpus, "seconds": dt, "e2e_reads_per_s": n_reads / dt, "steady_reads_per_s": steady, "contexts_up_ms": stats[best].get("contexts_up_ms"), "reads_per_device": per_dev,
             "device_steady_reads_per_s": [round(steady * n / max(1, sum(per_dev))) for n in per_dev] if steady else None, "seconds_each_run": runs, "contexts_up_ms_of_the_settling_runs": settled, "sam_records": nrec, "cli_stats": stats[best],
-            "read_len": read_len, "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam%s (defaults: -ctx 4, batches of ~16 M bases, host threads from the usable CPUs)" % (n_reads, " -gpus %d" % gpus if gpus > 1 else "")}
+            "read_len": read_len, "command": "yaha -x IDX -q %d_reads.fa -osh /dev/shm/out.sam%s (defaults: -ctx 3, batches of ~16 M bases, host threads from the usable CPUs)" % (n_reads, " -gpus %d" % gpus if gpus > 1 else "")}
 
 
 def stub_rank(args, rank, world):

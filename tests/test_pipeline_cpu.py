@@ -42,7 +42,7 @@ def _clean(p):
 @pytest.mark.parametrize("san", ["tsan", "asan"])
 @pytest.mark.parametrize("name,reads,extra", [
     ("rchim_default", "rchim.fa", ["-batch", "37", "-gpus", "2", "-ctx", "2"]),            # many small batches over 4 contexts on 2 devices: ordering, pool recycling
-    ("r1k_default", "r1k.fa", []),                                                           # defaults: one batch of ~16 M bases, -ctx 4
+    ("r1k_default", "r1k.fa", []),                                                           # defaults: one batch of ~16 M bases, -ctx 3
     ("rq_default", "rq.fq", ["-batch", "5", "-t", "3"]),                                     # FASTQ, explicit formatter count
     ("r10k_default", "r10k.fa", ["-batch", "3", "-ctx", "1"]),
     ("rchim_default", "rchim.fa", ["-batch", "29", "-dpf", "N"]),                             # the host's post-filter by option
@@ -77,7 +77,7 @@ def test_stats_line_and_stdin(exes, work, index11):
     line = [l for l in p.stderr.decode().split("\n") if l.startswith("[yaha] stats ")]
     assert len(line) == 1
     st = json.loads(line[0][len("[yaha] stats "):])
-    assert st["reads"] > 0 and st["last_batch_written_ms"] >= st["first_batch_written_ms"] > 0 and st["ctx_per_gpu"] == 4
+    assert st["reads"] > 0 and st["last_batch_written_ms"] >= st["first_batch_written_ms"] > 0 and st["ctx_per_gpu"] == 3
 
 
 def test_a_device_failure_stops_the_run_cleanly(exes, work, index11):

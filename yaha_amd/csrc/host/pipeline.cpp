@@ -209,7 +209,7 @@ int runQueries(Args &a, FILE *log)
     if (fputs(S->header.c_str(), out) < 0) { fprintf(log, "Failure writing the output file.\n"); return 1; }
     ygpu_params P; paramsFromArgs(A, P);
     ygpu_index_view V; yaha_session_index_view(S.get(), &V);
-    // -gpus N devices x -ctx M contexts per device (default 4 since round 5 -- the further contexts are presized from the first one, so a fourth costs nothing at the start; 3 before: while one context's batch is in a latency-bound device stage the others'
+    // -gpus N devices x -ctx M contexts per device (default 3 -- four contexts of ~60 GB beside the image leave a later, heavier batch no memory to grow into: measured slower; while one context's batch is in a latency-bound device stage the others'
     // batches compute).  Contexts of one device share its index image.
     const int perDev = std::max(1, A.ctxPerGpu), nDev = std::max(1, A.gpus), ngpu = nDev * perDev;
     std::vector<ygpu_ctx *> ctx(ngpu, nullptr);
@@ -325,9 +325,12 @@ int runQueries(Args &a, FILE *log)
                 one.lock();
                 // Does the device still have room for this context's arenas?  (~55 GB a context for 16 M bases of 1 kbp reads, ~75 GB for 10 kbp reads; squeezed into
                 // what is left, a first batch of 10 kbp reads at -ctx 3 took 1.8 s, cut into ranges, with every other context waiting behind it.)
+                bool roomy = false;                                          // twice a context's arenas free: room to take them in one go AND for the others to grow theirs later
                 if (!lead && W.footprint > 0 && rc0 == 0) {
                     uint64_t fb = 0, tb = 0, mine = 0;
-                    if (ygpu_memory(ctx[d], &fb, &tb, &mine) == 0 && (double)fb < 0.9 * (double)W.footprint) {
+                    const bool known = ygpu_memory(ctx[d], &fb, &tb, &mine) == 0;
+                    roomy = known && (double)fb >= 2.0 * (double)W.footprint;
+                    if (known && (double)fb < 0.9 * (double)W.footprint) {
                         if (timing || stats) fprintf(stderr, "[yaha] context %d left out: %.1f GB free on device %d, the first context's arenas hold %.1f GB\n", d, fb / 1e9, dev, W.footprint / 1e9);
                         (void)ygpu_park(ctx[d]); parked++; break;
                     }
@@ -336,7 +339,10 @@ int runQueries(Args &a, FILE *log)
                 // device's running contexts are held back for those few milliseconds; their own first batch then runs like any later batch, beside the others'.
                 // (Before: every context grew its hundred buffers during a first batch of its own, first batches ran one at a time and held the others back --
                 // 64 + 106 + 158 ms for the first three batches of a run, a fourth context cost more at the start than it gained later.)
-                if (!lead && rc0 == 0 && W.haveProfile && getenv("YAHA_NO_PRESIZE") == nullptr) {
+                // (Only while the device is roomy: presized to the brim -- four contexts of 60 GB beside a 17 GB image, three of 90 GB on 10 kbp reads -- a later batch
+                // that needs a larger arena finds no memory and is cut into ranges: 319 k -> 290 k reads/s steady, 27.6 k -> 12.4 k on 10 kbp reads, measured.  A
+                // context that starts in a tighter device grows its arenas during a first batch of its own, one at a time, as before.)
+                if (!lead && rc0 == 0 && W.haveProfile && roomy && getenv("YAHA_NO_PRESIZE") == nullptr) {
                     { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning++; }
                     const double p0 = now(); const int prc = ygpu_presize(ctx[d], &W.profile);
                     { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning--; } W.cv.notify_all();

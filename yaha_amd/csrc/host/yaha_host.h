@@ -69,7 +69,7 @@ struct Args {
     bool OQC = true; int OQCMinNonOverlap = -1, BPCost = 5, maxBPLog = 5; bool FBS = false; float FBS_PSLength = 0.90f, FBS_PSScore = 0.90f;
     int maxQueryLength = 32000; bool verbose = false, outputBlast8 = false, outputSAM = true, hardClip = true;
     // extensions of this implementation (not in the reference CLI)
-    int batchReads = 0; int device = 0; int gpus = 1; int ctxPerGpu = 4; bool cpuIndex = false; bool devicePostFilter = true;      // batchReads 0: batches of ~16 M bases
+    int batchReads = 0; int device = 0; int gpus = 1; int ctxPerGpu = 3; bool cpuIndex = false; bool devicePostFilter = true;      // batchReads 0: batches of ~16 M bases
     bool query = false, index = true, compress = false, uncompress = false;   // -c / -u: .fa -> .nib2 / .nib2 -> .fasta only (Main.c:284-293, non-user builds of the reference)
 };
 void postProcessArgs(Args &a, bool query);                                  // AlignArgs.c:108-169
