@@ -468,7 +468,10 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     static const int traceSort = getenv("YGPU_TRACE_SORT") ? atoi(getenv("YGPU_TRACE_SORT")) : 20;
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
-    const unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU), maxWavesK = maxBlocksK * 4u;
+    unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU);
+    // (YGPU_ROWS_BLOCKS: the persistent launch's workgroups as a count, for experiments between whole numbers per CU)
+    if (const char *e = getenv("YGPU_ROWS_BLOCKS")) { const long v = atol(e); if (v >= 64 && v <= (long)maxBlocksK) maxBlocksK = (unsigned)v; }
+    const unsigned maxWavesK = maxBlocksK * 4u;
     const double chunkBlocks = (double)YD_CHUNK_FLUSHES * 64.0;             // lane blocks (128 B) per chunk
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
     const int nShare = std::max(1, gCtxPerDevice[ctx->device & 63].load());
