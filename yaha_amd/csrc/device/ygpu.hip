@@ -469,8 +469,12 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU);
-    // (YGPU_ROWS_BLOCKS: the persistent launch's workgroups as a count, for experiments between whole numbers per CU)
-    if (const char *e = getenv("YGPU_ROWS_BLOCKS")) { const long v = atol(e); if (v >= 64 && v <= (long)maxBlocksK) maxBlocksK = (unsigned)v; }
+    // With other batches in flight on the device the persistent launch takes HALF of what fits (1.5 workgroups a CU): its waves hold their registers and LDS until
+    // the launch ends, and what they leave is all the other batches' latency-bound kernels get to run in meanwhile.  Four contexts, 3.1 Gbp, ms a step at 3 / 2.5 /
+    // 2 / 1.75 / 1.5 / 1.25 / 1 workgroups a CU: 44.6-45.0 / 44.3-44.4 / 44.4-44.7 / 44.0-44.2 / 43.6-43.8 / 43.8-44.0 / 43.9-44.3 (profiles/r05_rows_blocks_sweep.txt);
+    // alone on the device the full launch is 2.7 ms a step faster.  (YGPU_ROWS_BLOCKS: the workgroups as a count, for such sweeps.)
+    if (gCtxPerDevice[ctx->device & 63].load() >= 2) maxBlocksK = std::max(64u, maxBlocksK / 2u);
+    if (const char *e = getenv("YGPU_ROWS_BLOCKS")) { const long v = atol(e); if (v >= 64 && v <= (long)ctx->nCU * perCU) maxBlocksK = (unsigned)v; }
     const unsigned maxWavesK = maxBlocksK * 4u;
     const double chunkBlocks = (double)YD_CHUNK_FLUSHES * 64.0;             // lane blocks (128 B) per chunk
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
