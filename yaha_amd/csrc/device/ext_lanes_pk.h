@@ -64,12 +64,14 @@ __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) 
 #ifndef YD_ROWS_WAVES
 #define YD_ROWS_WAVES 3                        // waves per SIMD of k_ext_rows_pk (a build switch for experiments: make variant VARIANT_FLAGS=-DYD_ROWS_WAVES=2)
 #endif
-template <bool SECOND>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROWS_WAVES, YD_ROWS_WAVES))) k_ext_rows_pk(ExtArgs A)
+// BS = threads of a workgroup: 256 (a wave per SIMD), or 512 (two waves per SIMD of ONE CU: what the launch uses when it shares the device and takes a part of the
+// CUs only -- a wave that is alone on its SIMD runs at a third of the rate, so the waves of a partial launch should come in pairs; see ygpu.hip)
+template <bool SECOND, int BS = 256>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS_WAVES, YD_ROWS_WAVES))) k_ext_rows_pk(ExtArgs A)
 {
-    __shared__ uint32_t sBlk[256 * YD_LDS_STRIDE];   // per lane: the current block of eight 16-byte records, lane stride 33
+    __shared__ uint32_t sBlk[BS * YD_LDS_STRIDE];    // per lane: the current block of eight 16-byte records, lane stride 33
 #if YD_ROWS_LDSWIN
-    __shared__ uint32_t sWin[8][256];                // per thread: the current 16-byte piece of its query stream (dwords 0..3) and of its reference stream (4..7)
+    __shared__ uint32_t sWin[8][BS];                 // per thread: the current 16-byte piece of its query stream (dwords 0..3) and of its reference stream (4..7)
     yd_u32x4 GQ = {0u, 0u, 0u, 0u}, GR = {0u, 0u, 0u, 0u}; int jQ = 0, jR = 0; bool newQ = false, newR = false, freshQ = false, freshR = false;
     const unsigned tid = threadIdx.x;
 #endif
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YD_ROW
     const uint32_t maxROff = A.P.maxROff;
     YD_GLOBAL const uint8_t *gBases = toGlobal(A.bases);
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
-    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const unsigned wave = blockIdx.x * (unsigned)(BS / 64) + (threadIdx.x >> 6);
     uint32_t *const myBlk = &sBlk[threadIdx.x * YD_LDS_STRIDE];
     const uint32_t GEp = pk2(GE), GOEp = pk2(GO + GE), NEGK = pk2(-(A.P.MS + A.P.RC)), LWp = pk2(YD_LW16), ONEp = 0x00010001u, LWlo = (uint32_t)YD_LW16 & 0xFFFFu;
     // The strip keeps every cell's value as Vg = V - (GO + GE) (round 5): that is what both of a cell's later uses subtract -- the gap a neighbour opens from it, to its

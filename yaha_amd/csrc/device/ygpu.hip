@@ -67,6 +67,9 @@ enum { CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN,
 // the first T_TOP entries partition a run; the rest are sub-intervals of align_dp (lane-extension pipeline)
 enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_TOP, T_XROWS, T_XTRACE, T_P3, T_XROWS_DEV, T_XROWS_PK, T_N };
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
+// One rows launch at a time per device (YGPU_ROWS_SERIAL): a context's main rows launch waits for the one launched before it on the device, whichever context that
+// was -- two of them side by side take the whole chip between them and leave the other batches' kernels nothing, which is what the half-size launch is there to avoid.
+std::mutex gRowsMu[64]; hipEvent_t gRowsEv[64]; bool gRowsEvValid[64];
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split", "ext_rows_device_clock", "ext_rows_packed16"};      // the last one is a flag, not a time: 1 when k_ext_rows_pk ran (ext_lanes_pk.h)
 }  // namespace
 
@@ -459,23 +462,26 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     ExtArgs E; E.P = ctx->P; E.bases = ctx->dBases.as<uint8_t>(); E.fwd = ctx->dFwd.as<uint8_t>(); E.rev = ctx->dRev.as<uint8_t>(); E.fwd4 = ctx->dFwd4.as<uint8_t>(); E.rev4 = ctx->dRev4.as<uint8_t>();
     const bool caps = ctx->P.maxGap < YD_LW || ctx->P.maxIntron < YD_LW;
     const bool pk = extRowsPacked(ctx, caps); ctx->rowsPacked = pk;
-    auto rowsKernel = pk ? k_ext_rows_pk<false> : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
+    // (YGPU_ROWS_BS=512: the main rows launch in workgroups of eight waves -- two per SIMD of one CU -- when it shares the device)
+    static const int rowsBSenv = getenv("YGPU_ROWS_BS") ? atoi(getenv("YGPU_ROWS_BS")) : 256;
+    const unsigned rowsBS = (pk && rowsBSenv == 512 && gCtxPerDevice[ctx->device & 63].load() >= 2) ? 512u : 256u;
+    auto rowsKernel = pk ? (rowsBS == 512u ? k_ext_rows_pk<false, 512> : k_ext_rows_pk<false, 256>) : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
     auto rowsKernel2 = pk ? k_ext_rows_pk<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
     auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace;
     // the traceback's order: 0 = k_ext_rows' order; n > 0: by arena region of 2^n chunks, then by walk length (YGPU_TRACE_LENBITS bits).  With the wave-wide block
     // fetch of k_ext_trace_pk a wave walks in lock step, so what counts is that its lanes' walks are equally long: the default is the length alone (n = 20: one region),
     // in 128 classes -- one radix pass (3.1 Gbp, three contexts: 52.0 ms a step with regions of 128 chunks and 32 classes, 57.3 in the rows kernel's order, 51.2 so)
     static const int traceSort = getenv("YGPU_TRACE_SORT") ? atoi(getenv("YGPU_TRACE_SORT")) : 20;
-    int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, 256, 0) != hipSuccess || perCU < 1) perCU = 2;
+    int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, (int)rowsBS, 0) != hipSuccess || perCU < 1) perCU = rowsBS == 512u ? 1 : 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU);
     // With other batches in flight on the device the persistent launch takes HALF of what fits (1.5 workgroups a CU): its waves hold their registers and LDS until
     // the launch ends, and what they leave is all the other batches' latency-bound kernels get to run in meanwhile.  Four contexts, 3.1 Gbp, ms a step at 3 / 2.5 /
     // 2 / 1.75 / 1.5 / 1.25 / 1 workgroups a CU: 44.6-45.0 / 44.3-44.4 / 44.4-44.7 / 44.0-44.2 / 43.6-43.8 / 43.8-44.0 / 43.9-44.3 (profiles/r05_rows_blocks_sweep.txt);
     // alone on the device the full launch is 2.7 ms a step faster.  (YGPU_ROWS_BLOCKS: the workgroups as a count, for such sweeps.)
-    if (gCtxPerDevice[ctx->device & 63].load() >= 2) maxBlocksK = std::max(64u, maxBlocksK / 2u);
+    if (gCtxPerDevice[ctx->device & 63].load() >= 2 && rowsBS == 256u) maxBlocksK = std::max(64u, maxBlocksK / 2u);
     if (const char *e = getenv("YGPU_ROWS_BLOCKS")) { const long v = atol(e); if (v >= 64 && v <= (long)ctx->nCU * perCU) maxBlocksK = (unsigned)v; }
-    const unsigned maxWavesK = maxBlocksK * 4u;
+    const unsigned maxWavesK = maxBlocksK * (rowsBS / 64u);
     const double chunkBlocks = (double)YD_CHUNK_FLUSHES * 64.0;             // lane blocks (128 B) per chunk
     size_t freeB = 0, totB = 0; hipMemGetInfo(&freeB, &totB);
     const int nShare = std::max(1, gCtxPerDevice[ctx->device & 63].load());
@@ -577,8 +583,16 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             rc = bucketOrder(ctx, ctx->extKeys.as<uint32_t>() + p0, nullptr, 0, np, sub, shift, ((uint32_t)ctx->maxQ >> shift) + 2u, v1, ctx->stream); if (rc) return rc;
             E.order = v1;
         }
-        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + 255) / 256, (uint64_t)maxBlocksK);
-        KL(rowsKernel, dim3(blocks), dim3(256), 0, ctx->stream, E);
+        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + rowsBS - 1) / rowsBS, (uint64_t)maxBlocksK);
+        static const int rowsSerial = getenv("YGPU_ROWS_SERIAL") ? atoi(getenv("YGPU_ROWS_SERIAL")) : 0;
+        if (rowsSerial && gCtxPerDevice[ctx->device & 63].load() >= 2) {
+            std::lock_guard<std::mutex> lk(gRowsMu[ctx->device & 63]); const int dv = ctx->device & 63;
+            if (!gRowsEvValid[dv]) { if (hipEventCreateWithFlags(&gRowsEv[dv], hipEventDisableTiming) == hipSuccess) gRowsEvValid[dv] = true; }
+            else HIPCHK(hipStreamWaitEvent(ctx->stream, gRowsEv[dv], 0));
+            KL(rowsKernel, dim3(blocks), dim3(rowsBS), 0, ctx->stream, E);
+            if (gRowsEvValid[dv]) HIPCHK(hipEventRecord(gRowsEv[dv], ctx->stream));
+        } else
+        KL(rowsKernel, dim3(blocks), dim3(rowsBS), 0, ctx->stream, E);
         if (c + 1 == nRanges) EV1(T_XROWS);
         TRACE("lanes: ext_rows");
         if (c == 0) { ctx->evUsed[T_XTRACE] = true; hipEventRecord(ctx->ev[T_XTRACE][0], ctx->stream); }
