@@ -442,14 +442,17 @@ __device__ __forceinline__ bool pkContF(const PkRec &r, int k, int h) { const ui
 #define YD_TRACE_SWZ 0                          // (measured: 3.23 -> 3.39 ms a launch WITH the swizzle, profiles/r05_trace_swizzle.txt -- the XORs and six more registers cost more than the conflicts)
 #endif
 #define YD_TSWZ(problem) (YD_TRACE_SWZ ? (((problem) >> 3) & 3) : 0)
-__global__ void __launch_bounds__(256) k_ext_trace_pk(ExtArgs A)
+#ifndef YD_TRACE_BS
+#define YD_TRACE_BS 256                       // threads of a traceback workgroup (its waves are independent: the size only sets the granule of LDS -- 9 KB a wave -- a CU hands out)
+#endif
+__global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
 {
     YD_HIGH_PRIO();
     // The 64 lanes of a wave read 64 different 128-byte blocks per pass.  Read by their own lanes -- eight 8-byte pieces each -- that is 512 line requests a
     // pass, and the kernel's time followed the number of such requests, not the bytes.  Here the wave fetches the blocks TOGETHER: eight loads of 16 bytes per
     // lane, each covering eight whole blocks (eight lanes per block), through LDS ([problem][36 dwords], 36 KB a workgroup); a lane then reads its own records there, and a gap
     // run that stays inside the block needs no further load.
-    __shared__ uint32_t sBlkT[4][64 * YD_TSTRIDE];
+    __shared__ uint32_t sBlkT[YD_TRACE_BS / 64][64 * YD_TSTRIDE];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId();
     uint32_t *const wBlk = sBlkT[threadIdx.x >> 6]; const uint32_t *const myRec = wBlk + lane * YD_TSTRIDE;
     if (*toGlobal(A.errFlag) != 0) return;

@@ -70,6 +70,7 @@ std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this pro
 // One rows launch at a time per device (YGPU_ROWS_SERIAL): a context's main rows launch waits for the one launched before it on the device, whichever context that
 // was -- two of them side by side take the whole chip between them and leave the other batches' kernels nothing, which is what the half-size launch is there to avoid.
 std::mutex gRowsMu[64]; hipEvent_t gRowsEv[64]; bool gRowsEvValid[64];
+std::atomic<int> gActiveRuns[64];        // contexts of this process inside ygpu_run on the device right now: a rows launch shares the device when there are two or more
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split", "ext_rows_device_clock", "ext_rows_packed16"};      // the last one is a flag, not a time: 1 when k_ext_rows_pk ran (ext_lanes_pk.h)
 }  // namespace
 
@@ -464,10 +465,11 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     const bool pk = extRowsPacked(ctx, caps); ctx->rowsPacked = pk;
     // (YGPU_ROWS_BS=512: the main rows launch in workgroups of eight waves -- two per SIMD of one CU -- when it shares the device)
     static const int rowsBSenv = getenv("YGPU_ROWS_BS") ? atoi(getenv("YGPU_ROWS_BS")) : 256;
-    const unsigned rowsBS = (pk && rowsBSenv == 512 && gCtxPerDevice[ctx->device & 63].load() >= 2) ? 512u : 256u;
+    const bool rowsShare = gActiveRuns[ctx->device & 63].load() >= 2;      // (decided when the launch is sized: a batch that is alone in flight takes the whole device)
+    const unsigned rowsBS = (pk && rowsBSenv == 512 && rowsShare) ? 512u : 256u;
     auto rowsKernel = pk ? (rowsBS == 512u ? k_ext_rows_pk<false, 512> : k_ext_rows_pk<false, 256>) : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
     auto rowsKernel2 = pk ? k_ext_rows_pk<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
-    auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace;
+    auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace; const unsigned traceBS = pk ? (unsigned)YD_TRACE_BS : 256u;
     // the traceback's order: 0 = k_ext_rows' order; n > 0: by arena region of 2^n chunks, then by walk length (YGPU_TRACE_LENBITS bits).  With the wave-wide block
     // fetch of k_ext_trace_pk a wave walks in lock step, so what counts is that its lanes' walks are equally long: the default is the length alone (n = 20: one region),
     // in 128 classes -- one radix pass (3.1 Gbp, three contexts: 52.0 ms a step with regions of 128 chunks and 32 classes, 57.3 in the rows kernel's order, 51.2 so)
@@ -481,7 +483,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     // (profiles/r05_rows_blocks_sweep.txt): the full launch, free-running (rounds 1-4) 44.4-45.0; 384 workgroups free-running 43.6-44.0; one at a time: 352 workgroups
     // 44.2-44.3, 384 43.4-43.8, 416 42.5-43.0, 448 42.2-43.0, 480 43.5-43.9.  Alone on the device the full launch is 2.7 ms a step faster than half of it.
     // (YGPU_ROWS_BLOCKS: the workgroups as a count, for such sweeps.)
-    if (gCtxPerDevice[ctx->device & 63].load() >= 2 && rowsBS == 256u) maxBlocksK = std::max(64u, maxBlocksK * 9u / 16u);
+    if (rowsShare && rowsBS == 256u) maxBlocksK = std::max(64u, maxBlocksK * 9u / 16u);
     if (const char *e = getenv("YGPU_ROWS_BLOCKS")) { const long v = atol(e); if (v >= 64 && v <= (long)ctx->nCU * perCU) maxBlocksK = (unsigned)v; }
     const unsigned maxWavesK = maxBlocksK * (rowsBS / 64u);
     const double chunkBlocks = (double)YD_CHUNK_FLUSHES * 64.0;             // lane blocks (128 B) per chunk
@@ -587,7 +589,9 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         }
         const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)np + rowsBS - 1) / rowsBS, (uint64_t)maxBlocksK);
         static const int rowsSerial = getenv("YGPU_ROWS_SERIAL") ? atoi(getenv("YGPU_ROWS_SERIAL")) : 1;
-        if (rowsSerial && gCtxPerDevice[ctx->device & 63].load() >= 2) {
+        // (one at a time only for short reads: a launch of 10 kbp problems ends in a long tail of a few lanes, and the next one would wait for all of it -- 10 kbp reads,
+        // four contexts, ms a step: 432 workgroups free-running 29.4, one at a time 30.6, the full launch free-running 30.6)
+        if (rowsSerial && rowsShare && ctx->maxQ <= 4096) {
             std::lock_guard<std::mutex> lk(gRowsMu[ctx->device & 63]); const int dv = ctx->device & 63;
             if (!gRowsEvValid[dv]) { if (hipEventCreateWithFlags(&gRowsEv[dv], hipEventDisableTiming) == hipSuccess) gRowsEvValid[dv] = true; }
             else HIPCHK(hipStreamWaitEvent(ctx->stream, gRowsEv[dv], 0));
@@ -617,7 +621,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             rc = bucketOrder(ctx, k0, v0, 0, np, 0, std::max(0, keyBits - 12), 1u << std::min(keyBits, 12), v1, ctx->stream); if (rc) return rc;
             E.order = v1;
         }
-        KL(traceKernel, dim3(gridFor(np, 256)), dim3(256), 0, ctx->stream, E);
+        KL(traceKernel, dim3(gridFor(np, traceBS)), dim3(traceBS), 0, ctx->stream, E);
         if (c + 1 == nRanges) hipEventRecord(ctx->ev[T_XTRACE][1], ctx->stream);
         TRACE("lanes: ext_trace");
         if (kTrace) { unsigned w8[8]; hipMemcpyFromSymbol(w8, HIP_SYMBOL(gTraceDbg), sizeof w8); if (w8[0]) { ExtRes rr; hipMemcpy(&rr, E.res + w8[6], sizeof rr, hipMemcpyDeviceToHost); ExtProb pp; hipMemcpy(&pp, E.probs + w8[6], sizeof pp, hipMemcpyDeviceToHost);
@@ -663,7 +667,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                         // per SIMD runs a row 2.4x faster than three sharing it (a lone wave issues every ~5 cycles) and gives every lane more problems to balance.
                         const uint64_t blocks2 = ctx->rows2PerCU > 0 ? (uint64_t)ctx->rows2PerCU : (uint64_t)ctx->nCU;
                         KL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(std::min<uint64_t>(((uint64_t)n2 + 255) / 256, blocks2), (uint64_t)maxBlocksK)), dim3(256), 0, ctx->stream, E2); }
-                    KL(traceKernel, dim3(gridFor(n2, 256)), dim3(256), 0, ctx->stream, E2);
+                    KL(traceKernel, dim3(gridFor(n2, traceBS)), dim3(traceBS), 0, ctx->stream, E2);
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
                 SplitArgs Sx; Sx.scratch = ctx->splitScratch.as<uint8_t>(); Sx.memoKeys = ctx->memoKeys.as<uint32_t>(); Sx.memoCount = ctx->memoCount.as<unsigned int>();
@@ -1178,6 +1182,7 @@ int ygpu_run(ygpu_ctx *ctx)
 {
     if (!ctx || !ctx->stream) return YGPU_EINVAL;
     ctx->stageDone = 0; ctx->oqDone = false; const double t0 = nowMs(); ctx->statAttempts = 0; ctx->statRanges = 0;
+    struct Active { int d; explicit Active(int dv) : d(dv) { gActiveRuns[d]++; } ~Active() { gActiveRuns[d]--; } } active(ctx->device & 63);
     int rc = runTo(ctx, 3);
     if (kStats) { size_t fb = 0, tb = 0; hipMemGetInfo(&fb, &tb); fprintf(stderr, "[ygpu] ctx %p run: %u reads, rc %d, %.1f ms; align attempts %d, ranges %d, trace arena %.2f GB (ratio %.3f), free %.1f GB\n", (void *)ctx, ctx->nReads, rc, nowMs() - t0, ctx->statAttempts, ctx->statRanges, ctx->extTrace.cap / 1e9, ctx->traceRatio, fb / 1e9); }
     if (rc) return rc;
@@ -1541,7 +1546,7 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         E.ops = ctx->extOps.as<uint32_t>(); E.opsCount = ctx->traceCnt.as<unsigned int>() + 1; E.opsCap = (uint32_t)opsBound; E.res = ctx->extRes.as<ExtRes>();
         E.queue = ctx->chunkCnt.as<unsigned int>(); E.ctr = nullptr; E.errFlag = ctx->errFlag.as<int>(); E.dbgMode = 0;
         if (second) KL(rowsKernel2, dim3(blocksK), dim3(256), 0, ctx->stream, E); else KL(rowsKernel, dim3(blocksK), dim3(256), 0, ctx->stream, E);
-        KL(traceKernel, dim3(gridFor(nX, 256)), dim3(256), 0, ctx->stream, E);
+        { const unsigned tbs = pk ? (unsigned)YD_TRACE_BS : 256u; KL(traceKernel, dim3(gridFor(nX, tbs)), dim3(tbs), 0, ctx->stream, E); }
         uint32_t ef2 = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef2); if (rc) return rc;
         if (ef2 != YERR_TRACEMEM) break;                                    // (other errors are reported below)
         if (mult >= 1024) { ctx->err = "extension trace arena overflows"; return YGPU_ENOMEM; }
