@@ -69,7 +69,7 @@ enum { T_SEED = 0, T_SORT, T_FRAGS, T_CHAIN, T_ALIGN, T_LAYOUT, T_TOP, T_P1 = T_
 std::atomic<int> gCtxPerDevice[64];      // live contexts per device of this process: they share the device's free memory
 // One rows launch at a time per device (YGPU_ROWS_SERIAL): a context's main rows launch waits for the one launched before it on the device, whichever context that
 // was -- two of them side by side take the whole chip between them and leave the other batches' kernels nothing, which is what the half-size launch is there to avoid.
-std::mutex gRowsMu[64]; hipEvent_t gRowsEv[64]; bool gRowsEvValid[64];
+std::mutex gRowsMu[64]; hipEvent_t gRowsEv[64][4]; bool gRowsEvValid[64][4]; unsigned long long gRowsSeq[64];      // (a ring of events: YGPU_ROWS_SERIAL=k lets k launches overlap)
 std::atomic<int> gActiveRuns[64];        // contexts of this process inside ygpu_run on the device right now: a rows launch shares the device when there are two or more
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split", "ext_rows_device_clock", "ext_rows_packed16"};      // the last one is a flag, not a time: 1 when k_ext_rows_pk ran (ext_lanes_pk.h)
 }  // namespace
@@ -593,10 +593,11 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         // four contexts, ms a step: 432 workgroups free-running 29.4, one at a time 30.6, the full launch free-running 30.6)
         if (rowsSerial && rowsShare && ctx->maxQ <= 4096) {
             std::lock_guard<std::mutex> lk(gRowsMu[ctx->device & 63]); const int dv = ctx->device & 63;
-            if (!gRowsEvValid[dv]) { if (hipEventCreateWithFlags(&gRowsEv[dv], hipEventDisableTiming) == hipSuccess) gRowsEvValid[dv] = true; }
-            else HIPCHK(hipStreamWaitEvent(ctx->stream, gRowsEv[dv], 0));
+            const int depth = std::min(4, std::max(1, rowsSerial)); const int slot = (int)(gRowsSeq[dv]++ % (unsigned long long)depth);      // launch n waits for launch n - depth
+            if (!gRowsEvValid[dv][slot]) { if (hipEventCreateWithFlags(&gRowsEv[dv][slot], hipEventDisableTiming) == hipSuccess) gRowsEvValid[dv][slot] = true; }
+            else HIPCHK(hipStreamWaitEvent(ctx->stream, gRowsEv[dv][slot], 0));
             KL(rowsKernel, dim3(blocks), dim3(rowsBS), 0, ctx->stream, E);
-            if (gRowsEvValid[dv]) HIPCHK(hipEventRecord(gRowsEv[dv], ctx->stream));
+            if (gRowsEvValid[dv][slot]) HIPCHK(hipEventRecord(gRowsEv[dv][slot], ctx->stream));
         } else
         KL(rowsKernel, dim3(blocks), dim3(rowsBS), 0, ctx->stream, E);
         if (c + 1 == nRanges) EV1(T_XROWS);
