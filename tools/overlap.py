@@ -39,7 +39,7 @@ def merge(iv):
     return out
 
 rows = load(sys.argv[1])
-rk = [(s, e) for s, e, n in rows if n.startswith("k_ext_rows_pk<false>")]
+rk = [(s, e) for s, e, n in rows if n.startswith("k_ext_rows_pk<false")]
 nlast = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 t0, t1 = rk[-nlast][0], rk[-1][1]               # the timed steps (bench.py warms the contexts up one after the other: no overlap there)
 if len(sys.argv) > 4:                            # a window by kernel name instead: from the first to the last launch of kernels whose name contains argv[4] (e.g. k_oqc: the post-filter leg)
@@ -49,7 +49,7 @@ if len(sys.argv) > 4:                            # a window by kernel name inste
 win = [(max(s, t0), min(e, t1), n) for s, e, n in rows if e > t0 and s < t1]
 span = t1 - t0
 busy = union([(s, e) for s, e, n in win]); rowsM = merge([(s, e) for s, e, n in win if n.startswith("k_ext_rows_pk")]); rowsBusy = sum(e - s for s, e in rowsM)
-nrows = sum(1 for s, e, n in win if n.startswith("k_ext_rows_pk<false>")) - 1       # from the first launch's start to the last one's end: n - 1 batch periods, roughly
+nrows = sum(1 for s, e, n in win if n.startswith("k_ext_rows_pk<false")) - 1       # from the first launch's start to the last one's end: n - 1 batch periods, roughly
 print("window %.1f ms, %d batches: %.2f ms a batch; some kernel running %.1f%% of it, a rows kernel %.1f%%; sum of kernel durations %.1f ms a batch" % (span / 1e6, nrows, span / 1e6 / nrows, 100.0 * busy / span, 100.0 * rowsBusy / span, sum(e - s for s, e, n in win) / 1e6 / nrows))
 one = {}
 if len(sys.argv) > 2:

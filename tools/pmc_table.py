@@ -8,7 +8,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
     # a pass runs the pipeline once per launch of the dominant kernel (the context's first pass + the timed step): its counters are divided by that number
     rows = list(csv.DictReader(open(f)))
-    runs = max(1, len({r["Dispatch_Id"] for r in rows if r["Kernel_Name"].startswith("void k_ext_rows_pk<false>") or r["Kernel_Name"].startswith("void k_ext_rows<false, false>")}))
+    runs = max(1, len({r["Dispatch_Id"] for r in rows if r["Kernel_Name"].startswith("void k_ext_rows_pk<false") or r["Kernel_Name"].startswith("void k_ext_rows<false, false>")}))
     for row in rows:
         cnt[short(row["Kernel_Name"])][row["Counter_Name"]] += float(row["Counter_Value"] or 0) / runs
 dur = {}
@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(root, "stats1", "*kernel_stats.csv")):
     for row in csv.DictReader(open(f)):
         k = short(row["Name"]); o = dur.get(k, (0.0, 0, 0.0)); dur[k] = (0.0, o[1] + int(row["Calls"]), o[2] + float(row["TotalDurationNs"]))
 # steps of the --stats run: the launches of the dominant kernel there (timed steps + warm-up + the context's first pass)
-steps = float(max([v[1] for k, v in dur.items() if k.startswith("k_ext_rows_pk<false>") or k.startswith("k_ext_rows<false, false>")] or [8]))
+steps = float(max([v[1] for k, v in dur.items() if k.startswith("k_ext_rows_pk<false") or k.startswith("k_ext_rows<false, false>")] or [8]))
 print("per-kernel counters, one context, bench.py defaults (3.1 Gbp genome, 16 384 x 1 kbp reads) (rocprofv3 --pmc in separate passes with --kernel-trace only; tools/pmc_pass.sh, tools/pmc_table.py)")
 print("counters = sums over the dispatches of one step; percentages of SQ_WAVE_CYCLES; VALU ms = instructions x 4.4 cycles / (1024 SIMDs x 2.4 GHz); fetch = FETCH_SIZE x 2 KiB, write = WRITE_SIZE KiB;")
 print("LDS conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; ms/step = total duration of the kernel's launches over the %d steps of the --stats run / %d" % (steps, steps))
