@@ -80,6 +80,14 @@ __device__ __forceinline__ unsigned waveInclMaxU(unsigned v)
     t = (unsigned)dppMov<0x143, 0xc>(0, (int)v); v = v > t ? v : t;
     return v;
 }
+// inclusive sum over the 64 lanes by DPP (VALU rate; __shfl_up is a trip through the LDS crossbar): row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast 15 / 31
+__device__ __forceinline__ uint32_t waveInclSumU(uint32_t v)
+{
+    v += (uint32_t)dppMov<0x111>(0, (int)v); v += (uint32_t)dppMov<0x112>(0, (int)v); v += (uint32_t)dppMov<0x114>(0, (int)v); v += (uint32_t)dppMov<0x118>(0, (int)v);
+    v += (uint32_t)dppMov<0x142, 0xa>(0, (int)v); v += (uint32_t)dppMov<0x143, 0xc>(0, (int)v);
+    return v;
+}
+__device__ __forceinline__ uint32_t waveTotalSumU(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)waveInclSumU(v), 63); }      // the sum over all lanes, as a scalar
 // The ds_bpermute forms below are kept for code that is not on the per-row critical path.
 __device__ __forceinline__ unsigned waveMaxU(unsigned v)
 {

@@ -16,20 +16,14 @@
 #pragma once
 #include "common.h"
 
-#define YD_SCAN_BS 1024
-#define YD_SCAN_IPT 32                       // u32 elements a thread (128 bytes; u64: 16).  The tiles' look-back is a chain that advances 64 tiles a round trip: 50 ns a
-                                             // tile, measured (4 096-element tiles: 400 us for 32 M elements) -- so a tile is as large as a workgroup can make it: 128 KB
+#define YD_SCAN_BS 512                       // two waves per SIMD, ~100 registers: fits beside a rows launch that shares the device (a 1 024-thread workgroup needs four waves on
+                                             // every SIMD of one CU at once and found room on a third of the CUs only: 0.05 -> 0.61 ms a sum with four batches in flight)
+#define YD_SCAN_IPT 48                       // u32 elements a thread (192 bytes; u64: 24).  The tiles' look-back is a chain that advances 64 tiles a round trip: 50 ns a
+                                             // tile, measured (4 096-element tiles: 400 us for 32 M elements) -- so a tile is 96 KB
 #define YD_SCAN_TILE (YD_SCAN_BS * YD_SCAN_IPT)
 __host__ __device__ inline uint32_t scanTiles(uint64_t n, int elemBytes = 4) { const uint64_t tile = (uint64_t)YD_SCAN_TILE * 4u / (unsigned)elemBytes; return (uint32_t)((n + tile - 1) / tile); }
 __host__ __device__ inline size_t scanStateBytes(uint64_t n) { return 8ull * ((size_t)scanTiles(n, 8) + 4); }       // tile words (at most: the u64 tiling), ticket, done counter
 
-// inclusive sum over the 64 lanes by DPP (VALU rate; __shfl_up is a trip through the LDS crossbar): row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast 15 / 31
-__device__ __forceinline__ uint32_t waveInclSumU(uint32_t v)
-{
-    v += (uint32_t)dppMov<0x111>(0, (int)v); v += (uint32_t)dppMov<0x112>(0, (int)v); v += (uint32_t)dppMov<0x114>(0, (int)v); v += (uint32_t)dppMov<0x118>(0, (int)v);
-    v += (uint32_t)dppMov<0x142, 0xa>(0, (int)v); v += (uint32_t)dppMov<0x143, 0xc>(0, (int)v);
-    return v;
-}
 __device__ __forceinline__ unsigned long long shflUp64(unsigned long long v, int d)
 { return ((unsigned long long)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)v, d, 64); }
 // sum over all lanes of a 62-bit value, by DPP: three 32-bit sums (16 + 16 + 30 bits: none can overflow over 64 lanes)
@@ -87,7 +81,7 @@ template <class T>
 __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, uint32_t n, unsigned long long *state /* scanStateBytes(n), zero */, unsigned int *failed)
 {
     YD_HIGH_PRIO();
-    constexpr int NW = YD_SCAN_BS / 64, PER = 16 / (int)sizeof(T), NP = YD_SCAN_IPT / 4, IPT = NP * PER;      // elements a piece, pieces a lane (eight 16-byte pieces), elements a lane
+    constexpr int NW = YD_SCAN_BS / 64, PER = 16 / (int)sizeof(T), NP = YD_SCAN_IPT / 4, IPT = NP * PER;      // elements a piece, pieces a lane (twelve 16-byte pieces), elements a lane
     __shared__ T sWave[NW]; __shared__ T sPrefix; __shared__ uint32_t sTile;
     const uint32_t nTiles = gridDim.x, t = threadIdx.x, lane = t & 63u, w = t >> 6;
     if (t == 0) sTile = (uint32_t)atomicAdd(&state[nTiles], 1ull);
@@ -150,8 +144,8 @@ __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, u
 }
 
 // ---- ordering by a small key ------------------------------------------------------------------------------------------------------------------------------
-#define YD_BKT_BS 1024
-#define YD_BKT_IPT 8
+#define YD_BKT_BS 512                        // (workgroups of at most 512 threads: see YD_SCAN_BS)
+#define YD_BKT_IPT 16
 #define YD_BKT_TILE (YD_BKT_BS * YD_BKT_IPT)
 #define YD_BKT_MAX 4096                         // buckets (12 key bits)
 // work words of one ordering: hist[nb] | cursor[nb] | done; zero before the first use, left zero by k_bucket_scatter

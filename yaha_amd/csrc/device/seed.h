@@ -210,7 +210,7 @@ __device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, 
         const unsigned long long known = __ballot((st >> 32) == 2ull);
         const int stop = __builtin_ctzll(known | (1ull << 63));          // the nearest tile that knows its prefix (lane 63 at the latest if any)
         const bool use = known ? (int)lane <= stop : true;
-        excl += (uint32_t)waveSumI(use ? (int)(uint32_t)st : 0);
+        excl += waveTotalSumU(use ? (uint32_t)st : 0u);                     // (DPP: six shuffles through the LDS crossbar here were most of a look-back round, and the rounds are a chain)
         if (known) break;
         back -= 64;
     }
