@@ -468,7 +468,10 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     const bool rowsShare = gActiveRuns[ctx->device & 63].load() >= 2;      // (decided when the launch is sized: a batch that is alone in flight takes the whole device)
     const unsigned rowsBS = (pk && rowsBSenv == 512 && rowsShare) ? 512u : 256u;
     auto rowsKernel = pk ? (rowsBS == 512u ? k_ext_rows_pk<false, 512> : k_ext_rows_pk<false, 256>) : (caps ? k_ext_rows<true, false> : k_ext_rows<false, false>);
-    auto rowsKernel2 = pk ? k_ext_rows_pk<true> : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
+    // (the careful-extension round is a small launch of a wave per SIMD; YGPU_ROWS2_BS=512 pairs its waves: workgroups of eight waves on half as many CUs)
+    static const int rows2BSenv = getenv("YGPU_ROWS2_BS") ? atoi(getenv("YGPU_ROWS2_BS")) : 256;
+    const unsigned rows2BS = (pk && rows2BSenv == 512) ? 512u : 256u;
+    auto rowsKernel2 = pk ? (rows2BS == 512u ? k_ext_rows_pk<true, 512> : k_ext_rows_pk<true, 256>) : (caps ? k_ext_rows<true, true> : k_ext_rows<false, true>);
     auto traceKernel = pk ? k_ext_trace_pk : k_ext_trace; const unsigned traceBS = pk ? (unsigned)YD_TRACE_BS : 256u;
     // the traceback's order: 0 = k_ext_rows' order; n > 0: by arena region of 2^n chunks, then by walk length (YGPU_TRACE_LENBITS bits).  With the wave-wide block
     // fetch of k_ext_trace_pk a wave walks in lock step, so what counts is that its lanes' walks are equally long: the default is the length alone (n = 20: one region),
@@ -667,7 +670,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                     {   // a small launch: a few problems per lane, so its length is set by the lanes' chains of problems, not by the chip's throughput.  One wave
                         // per SIMD runs a row 2.4x faster than three sharing it (a lone wave issues every ~5 cycles) and gives every lane more problems to balance.
                         const uint64_t blocks2 = ctx->rows2PerCU > 0 ? (uint64_t)ctx->rows2PerCU : (uint64_t)ctx->nCU;
-                        KL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(std::min<uint64_t>(((uint64_t)n2 + 255) / 256, blocks2), (uint64_t)maxBlocksK)), dim3(256), 0, ctx->stream, E2); }
+                        const uint64_t b2 = rows2BS == 512u ? std::max<uint64_t>(1, blocks2 / 2) : blocks2;
+                        KL(rowsKernel2, dim3((unsigned)std::min<uint64_t>(std::min<uint64_t>(((uint64_t)n2 + rows2BS - 1) / rows2BS, b2), (uint64_t)maxBlocksK)), dim3(rows2BS), 0, ctx->stream, E2); }
                     KL(traceKernel, dim3(gridFor(n2, traceBS)), dim3(traceBS), 0, ctx->stream, E2);
                 }
                 ENSURE(ctx->splitScratch, (size_t)YD_SL_BYTES * (((size_t)nSlow + 63) / 64 * 64));
