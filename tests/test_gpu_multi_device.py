@@ -69,6 +69,39 @@ def test_context_memory_accounting(work, index11):
                 c.close()
 
 
+def test_presized_and_parked_contexts(work, index11):
+    """ygpu_get_arena_profile / ygpu_presize / ygpu_park (what the command line does with a device's further contexts): a context that takes the first one's arena
+    capacities in one go holds as much as the first one before it has seen a read, computes the same results, and grows nothing on its first batch; a parked context
+    gives its arenas back and refuses further batches."""
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r10k.fa")]) as s:
+        b = s.next_batch(12)
+        ctxs = ya.Context.on_devices(s.index, s.params, [0], ctx_per_device=3)
+        try:
+            _golden_batch_equals_oracle(s, b, ctxs[:1])
+            prof = ctxs[0].arena_profile()
+            image = s.index.n_base_bytes + 4 * s.index.totalMatches + 4 * (4 ** s.index.wordLen + 1)
+            _f, _t, own0 = ctxs[0].memory(); _f, _t, before = ctxs[1].memory()
+            ctxs[1].presize(prof)
+            _f, _t, after = ctxs[1].memory()
+            assert prof.n > 100 and prof.bases > 0
+            assert before < (own0 - image) // 4 and 0.9 * (own0 - image) <= after <= 1.1 * (own0 - image)
+            _golden_batch_equals_oracle(s, b, ctxs[1:2])
+            _f, _t, after_run = ctxs[1].memory()
+            assert after_run == after                                         # nothing grew: the first batch ran in the presized arenas
+            free0, _t, _o = ctxs[2].memory()
+            _golden_batch_equals_oracle(s, b, ctxs[2:3])                       # a context that grows its own arenas, then is parked
+            _f, _t, own2 = ctxs[2].memory()
+            ctxs[2].park()
+            free2, _t, parked = ctxs[2].memory()
+            assert parked < own2 // 8 and free2 > free0 - (own2 // 8)
+            with pytest.raises(RuntimeError, match="parked"):
+                ctxs[2].upload(b)
+            _golden_batch_equals_oracle(s, b, ctxs[:2])                        # the others are unaffected
+        finally:
+            for c in reversed(ctxs):
+                c.close()
+
+
 def test_three_images_chain_and_the_host_fall_back(work, index11, monkeypatch):
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
         b = s.next_batch(120)
