@@ -9,12 +9,18 @@ SETS = (("1kbp", ["--len", "1000", "--div", "0.017", "--chimeric", "0.05"], 1.0)
         ("fastq_N_edges_jitter", ["--len", "800", "--div", "0.05", "--fastq", "--withN", "0.3", "--edges", "--len-jitter", "700", "--chimeric", "0.1"], 0.25),
         ("30kbp", ["--len", "30000", "--div", "0.034", "--chimeric", "0.3"], 1 / 128))
 print("commit %s, index %s" % (os.environ.get("GIT_HEAD", "?"), GENOME))
+SETS = SETS + (("sv500_OQC_FBS", None, 1.0),)                          # BASELINE config 5: SV / repeat-insertion 500-mers (tools/yaha_sim.cpp `sv`), run with -OQC Y -FBS Y
 for tag, extra, frac in SETS:
-    n = max(16, int(N * frac))
-    R = "/tmp/yaha_bench_cache/parity_%s_%d.%s" % (tag, n, "fq" if "--fastq" in extra else "fa")
-    subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome", G, "--out", R, "--seed", "4242", "--n", str(n)] + extra)
-    t = time.time(); subprocess.run([os.path.join(root, "oracle/_ref/yaha"), "-x", X, "-q", R, "-osh", "/tmp/ref.sam", "-t", os.environ.get("REF_THREADS", "32")], stderr=subprocess.DEVNULL, check=True); tr = time.time() - t
-    t = time.time(); subprocess.run([os.path.join(root, "yaha_amd/csrc/yaha"), "-x", X, "-q", R, "-osh", "/tmp/mine.sam"], stderr=subprocess.DEVNULL, check=True); tm = time.time() - t
+    n = max(16, int(N * frac)); opts = []
+    R = "/tmp/yaha_bench_cache/parity_%s_%d.%s" % (tag, n, "fq" if extra and "--fastq" in extra else "fa")
+    if extra is None:
+        sys.path.insert(0, root); import bench
+        full = bench.make_sv_reads("/tmp/yaha_bench_cache", G, GENOME.split("_")[0], 4242, per=3); bench.head_reads(full, R, n); opts = ["-OQC", "Y", "-FBS", "Y"]
+        n = sum(1 for l in open(R) if l.startswith(">"))
+    else:
+        subprocess.check_call([os.path.join(root, "tools/yaha_sim"), "reads", "--genome", G, "--out", R, "--seed", "4242", "--n", str(n)] + extra)
+    t = time.time(); subprocess.run([os.path.join(root, "oracle/_ref/yaha"), "-x", X, "-q", R, "-osh", "/tmp/ref.sam", "-t", os.environ.get("REF_THREADS", "32")] + opts, stderr=subprocess.DEVNULL, check=True); tr = time.time() - t
+    t = time.time(); subprocess.run([os.path.join(root, "yaha_amd/csrc/yaha"), "-x", X, "-q", R, "-osh", "/tmp/mine.sam"] + opts, stderr=subprocess.DEVNULL, check=True); tm = time.time() - t
     a = [l for l in open("/tmp/ref.sam") if not l.startswith("@PG")]; b = [l for l in open("/tmp/mine.sam") if not l.startswith("@PG")]
     # the reference writes reads in thread-completion order with -t > 1 (Query.c:457-466): compare the header in order, the records as a multiset
     ha, hb = [l for l in a if l.startswith("@")], [l for l in b if l.startswith("@")]
