@@ -789,8 +789,8 @@ static int stageAlign(ygpu_ctx *ctx)
             if (kStats) fprintf(stderr, "[ygpu] ctx %p: align attempt %d repeated (%s); trace ratio %.3f, ops ratio %.4f\n", (void *)ctx, attempt + 1, traceOverflow ? "trace / extension-op arena" : (laneOverflow ? "phase-1 arenas (state ops, gap ops)" : "output arenas"), ctx->traceRatio, ctx->opsRatio);
             if (ef != YERR_OUT || attempt >= 24)      /* the trace estimate grows by half a time: 1.5^20 covers the floor-to-cap range */ { char b[96]; snprintf(b, sizeof b, "align stage failed with device error %u (see dp_wave.h YERR_*)", ef); ctx->err = b; return ef == YERR_OUT ? YGPU_EOVERFLOW : YGPU_EINTERNAL; }
             if (!traceOverflow) {                                            // (a full trace arena has grown its own estimate)
-                outClumpCap *= 2; outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);
-                gapOpsPerJoint *= 2; stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap);
+                outClumpCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outClumpCap); outOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * outOpsCap);      // (capped: up to 24 attempts, and a wrapped bound would never fit)
+                gapOpsPerJoint = std::min<uint32_t>(gapOpsPerJoint * 2u, 1u << 16); stateOpsCap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * stateOpsCap);
             }
             HIPCHK(hipMemcpyAsync(ctx->clumpFrags.p, ctx->clumpFrags0.p, 16ull * ctx->nClumpFrags, hipMemcpyDeviceToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->ctr.as<DevCounters>()->v + C_SCORED, 0, 8 * (16 - C_SCORED), ctx->stream));
