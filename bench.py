@@ -364,7 +364,7 @@ def verify_against_reference(ya, idx, cpu, e2e_reads_path, cache, n_e2e=16384):
 def run_contexts(ctxs, steps, collect=False, postfilter=False):
     """`steps` passes of the hot path shared out to the contexts (one host thread each, a common counter); returns (seconds, summed stage ms)."""
     import threading
-    stage_ms, lock, todo = {}, threading.Lock(), [steps]
+    stage_ms, lock, todo, flt, flt_err = {}, threading.Lock(), [steps], {}, []
 
     def stepper(c):
         while True:
@@ -374,7 +374,20 @@ def run_contexts(ctxs, steps, collect=False, postfilter=False):
                 todo[0] -= 1
             c.run()                                     # synchronous: returns when the results are complete in HBM
             if postfilter:
-                c.postfilter()                          # OQC / FBS / MAPQ on the device (oqc_stage.h) and D2H of the clumps that are printed
+                # OQC / FBS / MAPQ on the device (oqc_stage.h) and D2H of the clumps that are printed -- on a thread of its own, on the stage's snapshot of the
+                # results, while this thread runs the context's next step (as the command line does: host/pipeline.cpp FilterSide)
+                if flt.get(c) is not None:
+                    flt[c].join()
+                    if flt_err:
+                        raise flt_err[0]
+                c.postfilter_snapshot()
+
+                def filter_it(c=c):
+                    try:
+                        c.postfilter()
+                    except Exception as e:              # (reported by the thread that joins)
+                        flt_err.append(e)
+                flt[c] = threading.Thread(target=filter_it); flt[c].start()
             elif collect:
                 c.collect()                             # D2H of the clump records and edit ops into the context's host buffers
             tm = c.timing()[1]
@@ -387,6 +400,10 @@ def run_contexts(ctxs, steps, collect=False, postfilter=False):
         x.start()
     for x in th:
         x.join()
+    for x in flt.values():
+        x.join()
+    if flt_err:
+        raise flt_err[0]
     return time.time() - t0, stage_ms
 
 

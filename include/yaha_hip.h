@@ -169,8 +169,14 @@ void  ygpu_host_free(void *p);
  * for the whole batch on the device (same routine as the host's, yaha_amd/csrc/oqc_core.h) and ygpu_collect_filtered returns, per read and in PRINT order,
  * only the clumps printClumps would see (QS->clumps after the filter) with the fields the filter sets (Math.h Clump_t: status, mapQuality, numSecondaries,
  * matchedPrimary; QS->primaryCount), and only their edit ops.  Bit-identical to filtering ygpu_collect's output on the host; -OQC N runs keep the host filter.
- * A read with more clumps than the device stage takes (448: the filter's sort is sequential, and a kernel lasts as long as its slowest read) comes back
- * UNFILTERED -- all its clumps in ygpu_collect's order, primaryCount == 0xFFFF in each -- for the caller to filter (yaha_session_emit_filtered does). */
+ * A read with more clumps than the device stage takes (1 792: what its sort holds in a workgroup's 64 KB of LDS) comes back UNFILTERED -- all its clumps in
+ * ygpu_collect's order, primaryCount == 0xFFFF in each -- for the caller to filter (yaha_session_emit_filtered does).
+ * The stage works on a SNAPSHOT of the batch's results, so a context can run its next batch while another thread filters this one (the reference's threads
+ * each finish a read before they take the next, Query.c:430-470; here the two halves of a batch's life overlap):
+ *   context's thread:  ygpu_upload, ygpu_run, ygpu_postfilter_snapshot  -> hand the batch to the filter thread -> ygpu_upload, ygpu_run of the next batch ...
+ *   filter thread:     ygpu_postfilter, ygpu_filtered_size, ygpu_collect_filtered
+ * One snapshot at a time: the next ygpu_postfilter_snapshot may be called once the filtered results of the previous one have been collected.  ygpu_postfilter
+ * without a snapshot takes one itself (the sequential use: ygpu_run, ygpu_postfilter, ygpu_collect_filtered on one thread). */
 typedef struct ygpu_postfilter_params {
     int32_t  minNonOverlap, BPCost, maxBPLog, FBS;     /* AlignArgs: OQCMinNonOverlap, BPCost, maxBPLog, FBS (0/1) */
     float    FBS_PSLength, FBS_PSScore;
@@ -191,7 +197,8 @@ typedef struct ygpu_filtered_batch {
     ygpu_counters         counters;
 } ygpu_filtered_batch;
 int  ygpu_set_postfilter(ygpu_ctx *ctx, const ygpu_postfilter_params *p);     /* once per context */
-int  ygpu_postfilter(ygpu_ctx *ctx);                                           /* after ygpu_run */
+int  ygpu_postfilter_snapshot(ygpu_ctx *ctx);                                  /* after ygpu_run, on the context's thread */
+int  ygpu_postfilter(ygpu_ctx *ctx);                                           /* after ygpu_run or ygpu_postfilter_snapshot */
 int  ygpu_filtered_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops);
 int  ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump *clumps, uint32_t *ops, ygpu_filtered_batch *out);
 
@@ -201,7 +208,8 @@ int  ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump 
  * chains of overlaps) and compared with the host's on the same data. */
 int  ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r);
 /* Stage-level test entry for the exclusive sums and orderings the hot path lays its variable-size outputs out with (device/scan.h: single-pass look-back sums of
- * u32 / u64, orderings by a small key): runs them on n pseudo-random elements and compares with the plain host loops.  0, or YGPU_EINTERNAL with the first
+ * u32 / u64, orderings by a small key) and for the post-filter's sort on the wave (device/oqc_stage.h waveSort, against oqc_core.h sortRange): runs them on n
+ * pseudo-random elements (the sort: on arrays of 2 .. 1 792 entries with ties) and compares with the plain host loops.  0, or YGPU_EINTERNAL with the first
  * difference in ygpu_last_error.  (The reference needs neither: it handles one read at a time, Query.c:306-497.) */
 int  ygpu_selftest_primitives(ygpu_ctx *ctx, uint32_t n, uint32_t seed, int key_bits);
 

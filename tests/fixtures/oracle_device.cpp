@@ -13,14 +13,16 @@
 #include <thread>
 #include <chrono>
 
-struct ygpu_ctx { bool pfSet = false, pfDone = false; yoqc::Params pf; std::vector<uint32_t> thr, ss, sl; std::vector<uint32_t> fcs, fops; std::vector<ygpu_out_clump> fcl; ygpu_index_view V; ygpu_params P; std::vector<uint8_t> codes; std::vector<uint64_t> offs; uint32_t n = 0; yoracle_result res; bool have = false; int device = 0; std::string err; };
+struct ygpu_ctx { bool pfSet = false, pfDone = false; yoqc::Params pf; std::vector<uint32_t> thr, ss, sl; std::vector<uint32_t> fcs, fops; std::vector<ygpu_out_clump> fcl; ygpu_index_view V; ygpu_params P; std::vector<uint8_t> codes; std::vector<uint64_t> offs; uint32_t n = 0; yoracle_result res; bool have = false; int device = 0; std::string err;
+                  // the post-filter's snapshot of a batch (results, reads) and what its collect reports: the stage may run on a thread of its own while the context runs the next batch
+                  yoracle_result snap; std::atomic<bool> haveSnap{false}; std::vector<uint8_t> snapCodes; std::vector<uint64_t> snapOffs; uint32_t fReads = 0; ygpu_counters fCounters{}; };
 static std::atomic<int> gInits(0), gRuns(0);
 extern "C" {
 int ygpu_init(int device, const ygpu_index_view *v, const ygpu_params *p, ygpu_ctx **out)
 {
     *out = nullptr;
     const char *nd = getenv("YTEST_DEVICES"); if (device < 0 || device >= (nd ? atoi(nd) : 1)) return YGPU_ENODEV;
-    ygpu_ctx *c = new ygpu_ctx; c->V = *v; c->P = *p; c->device = device; memset(&c->res, 0, sizeof c->res); *out = c; gInits++;
+    ygpu_ctx *c = new ygpu_ctx; c->V = *v; c->P = *p; c->device = device; memset(&c->res, 0, sizeof c->res); memset(&c->snap, 0, sizeof c->snap); *out = c; gInits++;
     if (const char *ms = getenv("YTEST_INIT_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(ms)));
     return 0;
 }
@@ -33,8 +35,8 @@ int ygpu_init_multi(const int *devices, int n, int cpd, const ygpu_index_view *v
     for (int k = 0; k < n; k++) { int r = ygpu_init(devices[k], v, p, &out[k * cpd]); for (int j = 1; j < cpd && r == 0; j++) r = ygpu_clone(out[k * cpd], &out[k * cpd + j]); if (rc_each) rc_each[k] = r; if (r && !rc) rc = r; }
     return rc;
 }
-int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out) { ygpu_ctx *c = new ygpu_ctx; c->V = parent->V; c->P = parent->P; c->device = parent->device; memset(&c->res, 0, sizeof c->res); *out = c; return 0; }
-void ygpu_destroy(ygpu_ctx *c) { if (!c) return; if (c->have) yoracle_free_result(&c->res); delete c; }
+int ygpu_clone(const ygpu_ctx *parent, ygpu_ctx **out) { ygpu_ctx *c = new ygpu_ctx; c->V = parent->V; c->P = parent->P; c->device = parent->device; memset(&c->res, 0, sizeof c->res); memset(&c->snap, 0, sizeof c->snap); *out = c; return 0; }
+void ygpu_destroy(ygpu_ctx *c) { if (!c) return; if (c->have) yoracle_free_result(&c->res); if (c->haveSnap.load()) yoracle_free_result(&c->snap); delete c; }
 // (YTEST_FREE_GB / YTEST_CTX_GB: what the double reports as free on the device and as held by a context -- drives the command line's "context left out" path)
 int ygpu_memory(ygpu_ctx *, uint64_t *f, uint64_t *t, uint64_t *m)
 {
@@ -60,7 +62,6 @@ int ygpu_run(ygpu_ctx *c)
     const int k = ++gRuns;
     if (const char *f = getenv("YTEST_FAIL_RUN")) if (k == atoi(f)) { c->err = "test double: injected device failure"; return YGPU_EINTERNAL; }
     if (c->have) { yoracle_free_result(&c->res); c->have = false; }
-    c->pfDone = false;
     ygpu_read_batch b{c->n, c->codes.data(), c->offs.data()};
     if (yoracle_run(&c->V, &c->P, &b, 1, &c->res) != 0) { c->err = "oracle failed"; return YGPU_EINTERNAL; }
     c->have = true; return 0;
@@ -86,10 +87,21 @@ int ygpu_set_postfilter(ygpu_ctx *c, const ygpu_postfilter_params *p)
     yoqc::Params &P = c->pf; P.GOCost = c->P.GOCost; P.GECost = c->P.GECost; P.RCost = c->P.RCost; P.MScore = c->P.MScore; P.minNonOverlap = p->minNonOverlap; P.BPCost = p->BPCost; P.maxBPLog = p->maxBPLog; P.FBS = p->FBS;
     P.FBS_PSLength = p->FBS_PSLength; P.FBS_PSScore = p->FBS_PSScore; P.bppVmin = p->bppVmin; P.bppN = p->bppN; P.bppThr = c->thr.data(); c->pfSet = true; return 0;
 }
+int ygpu_postfilter_snapshot(ygpu_ctx *c)
+{
+    if (!c->have || !c->pfSet || c->haveSnap.load()) return YGPU_EINVAL;
+    c->snap = c->res; memset(&c->res, 0, sizeof c->res); c->have = false;      // (the double hands its results over instead of copying them)
+    c->snapCodes = c->codes; c->snapOffs = c->offs; c->pfDone = false;
+    if (const char *ms = getenv("YTEST_SNAPSHOT_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(ms)));
+    c->haveSnap.store(true); return 0;
+}
 int ygpu_postfilter(ygpu_ctx *c)
 {
-    if (!c->have || !c->pfSet) return YGPU_EINVAL;
-    const yoracle_result &R = c->res; c->fcs.assign(1, 0); c->fcl.clear(); c->fops.clear();
+    if (!c->haveSnap.load()) { const int rc = ygpu_postfilter_snapshot(c); if (rc) return rc; }
+    if (const char *ms = getenv("YTEST_POSTFILTER_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(ms)));      // (a stage that takes its time: the next batch's run overlaps it)
+    struct Done { ygpu_ctx *c; ~Done() { yoracle_free_result(&c->snap); c->haveSnap.store(false); } } done{c};
+    if (const char *f = getenv("YTEST_FAIL_POSTFILTER")) { static std::atomic<int> calls(0); if (++calls == atoi(f)) { c->err = "test double: injected post-filter failure"; return YGPU_EINTERNAL; } }
+    const yoracle_result &R = c->snap; c->fcs.assign(1, 0); c->fcl.clear(); c->fops.clear(); c->fReads = R.n_reads; c->fCounters = R.counters;
     yoqc::Seqs G{c->ss.data(), c->sl.data(), (uint32_t)c->ss.size()};
     for (uint32_t r = 0; r < R.n_reads; r++) {
         const uint32_t b = R.clump_start[r], n = R.clump_start[r + 1] - b;
@@ -103,8 +115,8 @@ int ygpu_postfilter(ygpu_ctx *c)
             size_t pool = 0; for (uint32_t i = 0; i < n; i++) pool += 2 * (size_t)R.clumps[b + i].n_ops + 3;
             std::vector<yoqc::SortKey> keys(n); std::vector<int> stack(4 * (size_t)n + 8), pfx(n), path(n), pl(pool + 1); std::vector<yoqc::CNode> nodes(n), prim(n); std::vector<yoqc::PAttr> pa(n); std::vector<yoqc::OutRec> push(n), out(n);
             yoqc::Scratch S{keys.data(), stack.data(), 0x7fffffff, nullptr, nodes.data(), pfx.data(), path.data(), pl.data(), 0x7fffffff, nullptr, prim.data(), pa.data(), push.data()};
-            int pc = 0; const int qlen = (int)(c->offs[r + 1] - c->offs[r]);
-            const int m = yoqc::run(c->pf, G, R.clumps + b, (int)n, R.ops, qlen, c->codes.data() + c->offs[r], S, out.data(), &pc);
+            int pc = 0; const int qlen = (int)(c->snapOffs[r + 1] - c->snapOffs[r]);
+            const int m = yoqc::run(c->pf, G, R.clumps + b, (int)n, R.ops, qlen, c->snapCodes.data() + c->snapOffs[r], S, out.data(), &pc);
             for (int k = 0; k < m; k++) {
                 ygpu_out_clump f; f.c = R.clumps[b + out[k].clump]; const uint32_t *src = R.ops + f.c.op_start; f.c.op_start = (uint32_t)c->fops.size(); c->fops.insert(c->fops.end(), src, src + f.c.n_ops);
                 f.status = out[k].status; f.mapQuality = out[k].mapQuality; f.numSecondaries = out[k].numSecondaries; f.matchedPrimary = out[k].matchedPrimary; f.primaryCount = (uint16_t)pc; c->fcl.push_back(f);
@@ -119,7 +131,7 @@ int ygpu_collect_filtered(ygpu_ctx *c, uint32_t *cs, ygpu_out_clump *cl, uint32_
 {
     if (!c->pfDone) return YGPU_EINVAL;
     memcpy(cs, c->fcs.data(), 4 * c->fcs.size()); if (!c->fcl.empty()) memcpy(cl, c->fcl.data(), sizeof(ygpu_out_clump) * c->fcl.size()); if (!c->fops.empty()) memcpy(ops, c->fops.data(), 4 * c->fops.size());
-    memset(r, 0, sizeof *r); r->n_reads = c->res.n_reads; r->clump_start = cs; r->clumps = cl; r->ops = ops; r->n_clumps = c->fcl.size(); r->n_ops = c->fops.size(); r->counters = c->res.counters;
+    memset(r, 0, sizeof *r); r->n_reads = c->fReads; r->clump_start = cs; r->clumps = cl; r->ops = ops; r->n_clumps = c->fcl.size(); r->n_ops = c->fops.size(); r->counters = c->fCounters;
     return 0;
 }
 static std::atomic<long> gHostAllocs(0);

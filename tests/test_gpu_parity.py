@@ -517,12 +517,13 @@ def _synthetic_results(s, b, rng, max_clumps):
     return r, (cs, cl, op)
 
 
-# The device filter against the host's on synthetic clump lists (ygpu_inject_results): ties by the hundred, duplicates, copies, nests, up to 448 clumps a read and beyond
-# (the hand-over path), under the filter's parameter sets.  What is compared is the SAM text of both.
+# The device filter against the host's on synthetic clump lists (ygpu_inject_results): ties by the hundred, duplicates, copies, nests, up to 1 792 clumps a read (the
+# largest the device stage sorts in its 64 KB of LDS) and beyond (the hand-over path), under the filter's parameter sets.  What is compared is the SAM text of both.
 @pytest.mark.parametrize("seed,max_clumps,extra", [(1, 60, []), (2, 300, []), (3, 460, ["-FBS", "Y", "-PSS", "0.5", "-PRL", "0.5"]), (4, 120, ["-BP", "11", "-MGDP", "7", "-MNO", "5"]),
                                                    (5, 200, ["-FBS", "Y", "-MNO", "60", "-GOC", "3", "-GEC", "1", "-RC", "2"]), (6, 40, ["-oss", "stdout", "-FBS", "Y", "-PSS", "0.1", "-PRL", "0.1"]),
                                                    (7, 448, []), (8, 448, ["-FBS", "Y"]), (9, 224, ["-BP", "1", "-MGDP", "2"]), (10, 112, ["-MNO", "1", "-FBS", "Y", "-PSS", "0.99", "-PRL", "0.99"]),
-                                                   (11, 30, ["-BP", "40", "-MGDP", "9", "-MS", "3", "-RC", "7"]), (12, 330, ["-MNO", "120"])])
+                                                   (11, 30, ["-BP", "40", "-MGDP", "9", "-MS", "3", "-RC", "7"]), (12, 330, ["-MNO", "120"]),
+                                                   (13, 1500, []), (14, 1792, ["-FBS", "Y"]), (15, 2100, ["-FBS", "Y", "-PSS", "0.5", "-PRL", "0.5"])])
 def test_postfilter_on_synthetic_clump_lists(work, index11, seed, max_clumps, extra):
     """Device stage vs the host's copy of the same routine (oqc_core.h) on clump lists no real read produces; as above, the pin to the reference is the host
     copy's (goldens, live reference) and the command line's with the device filter -- this test only shows that the two compilations agree where real reads do not go."""
@@ -541,6 +542,33 @@ def test_postfilter_on_synthetic_clump_lists(work, index11, seed, max_clumps, ex
             dev = s.emit_filtered(f)
             assert dev == host
             assert len(host) > 1000
+
+
+@pytest.mark.parametrize("reads,extra", [("rchim.fa", []), ("r1k.fa", ["-FBS", "Y"])])
+def test_postfilter_of_a_snapshot_while_the_next_batch_runs(work, index11, reads, extra):
+    """The stage's two-thread use (include/yaha_hip.h: ygpu_postfilter_snapshot on the context's thread, ygpu_postfilter + ygpu_collect_filtered on another while the
+    context uploads and runs the next batch -- here a DIFFERENT batch, so that a stage that read the context's live buffers instead of its snapshot would show):
+    the filtered batch == the host's filter over the same results, five rounds."""
+    import threading
+    with ya.Session(["-x", index11, "-q", os.path.join(work, reads), "-osh", "stdout"] + list(extra)) as s, ya.Session(["-x", index11, "-q", os.path.join(work, "r10k.fa")]) as other:
+        with ya.Context(s.index, s.params) as ctx:
+            ctx.set_postfilter(s)
+            b, nxt = s.next_batch(220), other.next_batch(40)
+            ctx.upload(b); ctx.run()
+            host = s.emit(ctx.collect())
+            assert len(host) > 200
+            for _ in range(5):
+                ctx.upload(b); ctx.run(); ctx.postfilter_snapshot()
+                got = {}
+                t = threading.Thread(target=lambda: got.setdefault("f", ctx.postfilter()))
+                t.start()
+                ctx.upload(nxt); ctx.run()                 # the context's buffers now hold another batch's reads and results
+                t.join()
+                assert "f" in got and got["f"].n_reads == b.n_reads
+                assert s.emit_filtered(got["f"]) == host
+            with pytest.raises(RuntimeError):               # one snapshot at a time
+                ctx.postfilter_snapshot(); ctx.postfilter_snapshot()
+            ctx.postfilter()
 
 
 def test_real_human_sequence_command_line_equals_the_reference(tmp_path):

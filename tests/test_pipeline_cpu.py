@@ -122,6 +122,29 @@ def test_left_out_contexts_never_hold_a_batch(exes, work, index11, batch):
         assert '"ctx_left_out": 2' in p.stderr.decode()
 
 
+@pytest.mark.parametrize("san", ["tsan", "asan"])
+def test_the_filter_thread_overlaps_the_next_batch(exes, work, index11, san):
+    """A context's post-filter runs on a thread of its own, on the snapshot the context's thread took, while that thread uploads and runs the next batch
+    (pipeline.cpp: FilterSide).  A stage that takes its time (20 ms a batch in the double) and a snapshot that does: same SAM, in order, with one and with several
+    contexts, and with the sequential order forced; a post-filter that fails stops the run as a failed hot path does."""
+    base = ["-x", index11, "-q", os.path.join(work, "rchim.fa"), "-osh", "stdout", "-batch", "23"]
+    for extra, env in ((["-ctx", "1"], {"YTEST_POSTFILTER_MS": "20"}), (["-ctx", "3", "-gpus", "2"], {"YTEST_POSTFILTER_MS": "7", "YTEST_SNAPSHOT_MS": "3", "YTEST_DEVICES": "2"}),
+                       (["-ctx", "2"], {"YAHA_SERIAL_FILTER": "1", "YTEST_POSTFILTER_MS": "5"}), (["-ctx", "2", "-FBS", "Y"], {"YTEST_RAW_ABOVE": "3"})):
+        args = base + extra
+        if "-FBS" in extra:
+            args[args.index("-osh")] = "-oss"                # (the golden with -FBS Y is a soft-clipped one)
+        p = _run(exes[san], args, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        _clean(p)
+        assert strip_pg(p.stdout.decode()) == golden_lines("rchim_FBS" if "-FBS" in extra else "rchim_default"), (extra, env)
+    good = _run(exes[san], base + ["-ctx", "2"])
+    bad = _run(exes[san], base + ["-ctx", "2"], env={"YTEST_FAIL_POSTFILTER": "4", "YTEST_POSTFILTER_MS": "5"})
+    _clean(bad)
+    assert good.returncode == 0 and bad.returncode == 1 and "injected post-filter failure" in bad.stderr.decode()
+    g, b = good.stdout.decode(), bad.stdout.decode()
+    assert len(b) < len(g) and g.startswith(b) and (b.endswith("\n") or b == "")
+
+
 def test_no_such_device(exes, work, index11):
     p = _run(exes["asan"], ["-x", index11, "-q", os.path.join(work, "r1k.fa"), "-osh", "stdout", "-gpus", "2"], env={"YTEST_DEVICES": "1"})
     _clean(p)

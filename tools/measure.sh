@@ -73,7 +73,7 @@ PY
   ;;
 oqc)
   TAG=${1:-oqc}
-  YGPU_OQC_PROF=1 python bench.py --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline --e2e-reads 16384 2>&1 >/dev/null | grep "post-filter class" | tail -4
+  YGPU_OQC_PROF=1 python bench.py --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline --e2e-reads 16384 2>&1 >/dev/null | grep "post-filter class" | tail -5
   O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
   rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o stats -- python3 $R/bench.py --steps 4 --warmup 1 --contexts 1 --no-cpu-baseline --e2e-reads 16384 > $O/bench.json 2> $O/bench.err
   kernel_table $O/stats 5 | grep -E "sum of|k_oqc" ;;

@@ -89,7 +89,7 @@ DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
 DP_KERNELS_AUTO, DP_KERNELS_WAVE, DP_KERNELS_LANES, DP_KERNELS_LANES_CAREFUL = 0, 1, 2, 3
 
 EXPORTS = (
-    "ygpu_device_count", "ygpu_init", "ygpu_init_multi", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_memory", "ygpu_park", "ygpu_get_arena_profile", "ygpu_presize", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter", "ygpu_inject_results", "ygpu_selftest_primitives", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
+    "ygpu_device_count", "ygpu_init", "ygpu_init_multi", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_memory", "ygpu_park", "ygpu_get_arena_profile", "ygpu_presize", "ygpu_upload", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter_snapshot", "ygpu_postfilter", "ygpu_inject_results", "ygpu_selftest_primitives", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
     "ygpu_submit", "ygpu_poll", "ygpu_wait", "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch", "ygpu_dp_batch_ex",
     "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
     "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit", "yaha_session_postfilter_params", "yaha_session_emit_filtered",
@@ -264,12 +264,23 @@ class Context:
         """Stage-level test entry: a ResultBatch placed on the device as if ygpu_run had produced it for the uploaded reads."""
         self._check(lib().ygpu_inject_results(self._h, C.byref(result)), "ygpu_inject_results")
 
+    def postfilter_snapshot(self):
+        """On the context's thread, after run(): the stage's copy of the batch's results.  The context is then free for the next upload() / run() while
+        postfilter() -- on another thread -- works on this one."""
+        self._check(lib().ygpu_postfilter_snapshot(self._h), "ygpu_postfilter_snapshot")
+        self._snap_reads = self._n_reads
+
     def postfilter(self):
-        """OQC, filter by similarity and mapping quality on the device; returns the clumps that are printed (FilteredBatch; arrays owned by this object)."""
+        """OQC, filter by similarity and mapping quality on the device; returns the clumps that are printed (FilteredBatch; arrays owned by this object).
+        Works on the snapshot taken by postfilter_snapshot(), or takes one of the last run()'s results itself."""
+        n_reads = getattr(self, "_snap_reads", None)
+        if n_reads is None:
+            n_reads = self._n_reads
+        self._snap_reads = None
         self._check(lib().ygpu_postfilter(self._h), "ygpu_postfilter")
         nc, no = C.c_uint64(), C.c_uint64()
         self._check(lib().ygpu_filtered_size(self._h, C.byref(nc), C.byref(no)), "ygpu_filtered_size")
-        self._f_cs = (C.c_uint32 * (self._n_reads + 1))(); self._f_cl = (OutClump * max(1, nc.value))(); self._f_ops = (C.c_uint32 * max(1, no.value))()
+        self._f_cs = (C.c_uint32 * (n_reads + 1))(); self._f_cl = (OutClump * max(1, nc.value))(); self._f_ops = (C.c_uint32 * max(1, no.value))()
         r = FilteredBatch()
         self._check(lib().ygpu_collect_filtered(self._h, self._f_cs, self._f_cl, self._f_ops, C.byref(r)), "ygpu_collect_filtered")
         return r

@@ -74,6 +74,13 @@ std::atomic<int> gActiveRuns[64];        // contexts of this process inside ygpu
 const char *const kStageNames[T_N] = {"seed_lookup", "hit_sort", "fragments_regions", "chain", "align_dp", "layout", "align_p1_gapfill", "ext_rows", "ext_trace", "align_p3_score_split", "ext_rows_device_clock", "ext_rows_packed16"};      // the last one is a flag, not a time: 1 when k_ext_rows_pk ran (ext_lanes_pk.h)
 }  // namespace
 
+// What the post-filter's host code works with in place of the context: the second stream, its own pinned slot, wait event, look-back words and message -- the
+// stage runs on a SNAPSHOT of a batch's results (ygpu_postfilter_snapshot) and may therefore run on a thread of its own while the context itself is already
+// uploading and running the next batch.  (Same member names as the context's, so the macros and the small helpers below serve both.)
+struct PfSide {
+    std::string err; hipStream_t stream = nullptr; uint32_t *pinned = nullptr; hipEvent_t evSync = nullptr; DevBuf scanState, counters; int device = 0;
+};
+
 struct ygpu_ctx {
     int device = 0; hipStream_t stream = nullptr; DevParams P{}; std::string err; int nCU = 256;
     DevBuf dBases, dSO, dROA, dLow;
@@ -91,6 +98,9 @@ struct ygpu_ctx {
     // post-filter stage (oqc_stage.h)
     DevBuf oqProf, oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
     bool oqSet = false, oqDone = false; yoqc::Params oqP{}; yoqc::Seqs oqG{}; uint32_t nFOut = 0, nFOps = 0;
+    // the snapshot the stage works on (taken by the context's thread) and the copy of its sizes the stage runs with (its own thread)
+    PfSide pf; std::atomic<bool> pfSnap{false}; hipEvent_t evSnap = nullptr; uint32_t snapN = 0, snapC = 0, snapOps = 0, pfN = 0; ygpu_counters snapCounters{}, pfCounters{};
+    DevBuf oqCs, oqCl, oqOpsIn, oqSeeds, oqQlen;
     // stage state
     uint32_t hOutCounts[2] = {0, 0}, hOutEf = 0; bool hOutValid = false;
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0, nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
@@ -108,7 +118,7 @@ static DevBatch devBatch(ygpu_ctx *c) { DevBatch b; b.fwd = c->dFwd.as<uint8_t>(
 static inline unsigned gridFor(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // Exclusive sums and orderings of the hot path: scan.h (own kernels; one launch a scan, two an ordering; their work words clean themselves up)
-template <class T> static int ownScanT(ygpu_ctx *ctx, const T *in, T *out, uint32_t n, hipStream_t st)
+template <class T, class C> static int ownScanT(C *ctx, const T *in, T *out, uint32_t n, hipStream_t st)
 {
     if (n == 0) return 0;
     const size_t need = scanStateBytes(n);
@@ -116,12 +126,12 @@ template <class T> static int ownScanT(ygpu_ctx *ctx, const T *in, T *out, uint3
         if (ctx->scanState.ensure(std::max<size_t>(need, 1u << 16))) { ctx->err = "hipMalloc(scan state)"; return YGPU_ENOMEM; }
         HIPCHK(hipMemsetAsync(ctx->scanState.p, 0, ctx->scanState.cap, st));
     }
-    hipLaunchKernelGGL((k_scan_excl<T>), dim3(scanTiles(n, (int)sizeof(T))), dim3(YD_SCAN_BS), 0, st, in, out, n, ctx->scanState.as<unsigned long long>(), ctx->counters.as<unsigned int>() + CNT_SCANFAIL);
+    hipLaunchKernelGGL((k_scan_excl<T>), dim3(scanTiles(n, (int)sizeof(T))), dim3(YD_SCAN_BS), 0, st, in, out, n, (unsigned long long *)ctx->scanState.p, (unsigned int *)ctx->counters.p + CNT_SCANFAIL);
     hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ctx->err = std::string("launch of k_scan_excl failed: ") + hipGetErrorString(e_); return YGPU_ENODEV; }
     return 0;
 }
-static int cubScan(ygpu_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n) { return ownScanT<uint32_t>(ctx, in, out, n, ctx->stream); }
-static int cubScan64(ygpu_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint32_t n) { return ownScanT<unsigned long long>(ctx, in, out, n, ctx->stream); }
+template <class C> static int cubScan(C *ctx, const uint32_t *in, uint32_t *out, uint32_t n) { return ownScanT<uint32_t>(ctx, in, out, n, ctx->stream); }
+template <class C> static int cubScan64(C *ctx, const unsigned long long *in, unsigned long long *out, uint32_t n) { return ownScanT<unsigned long long>(ctx, in, out, n, ctx->stream); }
 // order[] = the items' values grouped by bucket((key - sub) >> shift), ascending; vals == nullptr: the values are the items' indices + valBase
 static int bucketOrder(ygpu_ctx *ctx, const uint32_t *keys, const uint32_t *vals, uint32_t valBase, uint32_t n, uint32_t sub, int shift, uint32_t nb, uint32_t *outVals, hipStream_t st)
 {
@@ -145,7 +155,7 @@ static const bool kStats = getenv("YGPU_STATS") != nullptr;      // one line per
 
 // Waits of the host for its stream: on an event created with hipEventBlockingSync, so that the thread sleeps instead of spinning -- a context has ~15 such
 // waits per batch, each tens of milliseconds long, and a node runs (GPUs x contexts) of these threads (YGPU_SPIN_SYNC=1: plain hipStreamSynchronize).
-static hipError_t streamSync(ygpu_ctx *ctx)
+template <class C> static hipError_t streamSync(C *ctx)
 {
     static const bool spin = getenv("YGPU_SPIN_SYNC") != nullptr;
     if (spin || !ctx->evSync) return hipStreamSynchronize(ctx->stream);
@@ -154,7 +164,7 @@ static hipError_t streamSync(ygpu_ctx *ctx)
 }
 
 // the next stage's sizes cross PCIe as a few words, through a pinned slot (a pageable destination goes through a staging kernel and a second copy)
-static int fetchU32(ygpu_ctx *ctx, const void *dptr, uint32_t *out, size_t n = 1)
+template <class C> static int fetchU32(C *ctx, const void *dptr, uint32_t *out, size_t n = 1)
 {
     if (ctx->pinned && n <= 64) {
         HIPCHK(hipMemcpyAsync(ctx->pinned, dptr, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
@@ -165,7 +175,7 @@ static int fetchU32(ygpu_ctx *ctx, const void *dptr, uint32_t *out, size_t n = 1
 
 // several small pieces in ONE wait (the copies queue up behind the kernels, one event is waited for): every wait of the host is a gap on the device when one context runs alone
 struct FetchPiece { const void *src; uint32_t *dst; uint32_t n; };
-static int fetchMany(ygpu_ctx *ctx, const FetchPiece *pc, int np)
+template <class C> static int fetchMany(C *ctx, const FetchPiece *pc, int np)
 {
     uint32_t tot = 0; for (int k = 0; k < np; k++) tot += pc[k].n;
     if (!ctx->pinned || tot > 64) { for (int k = 0; k < np; k++) { int rc = fetchU32(ctx, pc[k].src, pc[k].dst, pc[k].n); if (rc) return rc; } return 0; }
@@ -831,6 +841,9 @@ static int initCommon(ygpu_ctx *ctx, int device)
     // (Measured in round 4 and dropped: the context's streams at the highest priority and the long X-drop kernels on a stream of the lowest --
     // hipStreamCreateWithPriority, range -1..1 here -- 46.2-46.4 ms a step against 45.0-45.9 with four contexts, profiles/r04_ab_prio_and_waves.txt: the rows kernel's
     // waves are persistent, a slot they hold is not handed to anybody before the launch ends.)
+    // (two streams a context and no more: the runtime spreads streams over four hardware queues, and with two a context the main streams of contexts 0 and 2, 1 and 3
+    // share one -- their kernels take turns -- which is worth 2 ms a step against a queue for every stream and 5 against all main streams on one queue:
+    // profiles/r05_hw_queues.txt)
     HIPCHK(hipStreamCreate(&ctx->stream)); HIPCHK(hipStreamCreate(&ctx->stream2));
     phase("two streams");
     for (int i = 0; i < YD_MAX_CHUNK_EV; i++) HIPCHK(hipEventCreateWithFlags(&ctx->evChunk[i], hipEventDisableTiming));
@@ -848,6 +861,13 @@ static int initCommon(ygpu_ctx *ctx, int device)
     if (hipEventCreateWithFlags(&ctx->evSync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { ctx->evSync = nullptr; (void)hipGetLastError(); }
     phase("events");
     if (hipHostMalloc((void **)&ctx->pinned, 256, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; (void)hipGetLastError(); }
+    // the post-filter's side: the second stream, a pinned slot, a wait event and look-back words of its own
+    ctx->pf.stream = ctx->stream2; ctx->pf.device = device;
+    if (hipHostMalloc((void **)&ctx->pf.pinned, 256, hipHostMallocDefault) != hipSuccess) { ctx->pf.pinned = nullptr; (void)hipGetLastError(); }
+    if (hipEventCreateWithFlags(&ctx->pf.evSync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { ctx->pf.evSync = nullptr; (void)hipGetLastError(); }
+    HIPCHK(hipEventCreateWithFlags(&ctx->evSnap, hipEventDisableTiming));
+    if (ctx->pf.counters.ensure(4 * CNT_N)) { ctx->err = "hipMalloc failed"; return YGPU_ENOMEM; }
+    HIPCHK(hipMemsetAsync(ctx->pf.counters.p, 0, 4 * CNT_N, ctx->stream2));
     phase("pinned words");
     return 0;
 }
@@ -1068,7 +1088,7 @@ static std::vector<DevBuf *> allBuffers(ygpu_ctx *ctx)
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags, &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag, &ctx->cubTemp, &ctx->scanState, &ctx->bucketWork, &ctx->scratchAlign,
                          &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->sub2B, &ctx->sub2E, &ctx->sub2Lists, &ctx->sub3B, &ctx->sub3E, &ctx->sub3Lists, &ctx->kmerParts, &ctx->scratchChain, &ctx->dpProbs, &ctx->dpRes, &ctx->dpOps, &ctx->rootState, &ctx->stateOps, &ctx->extProbs, &ctx->rowsBound, &ctx->stripOff, &ctx->extRes, &ctx->extTrace, &ctx->chunkCnt, &ctx->cubTemp2, &ctx->memoKeys, &ctx->memoCount, &ctx->probs2, &ctx->rowsBound2, &ctx->stripOff2, &ctx->extRes2, &ctx->extTrace2, &ctx->rowsClock, &ctx->splitScratch, &ctx->fallList, &ctx->keys2a, &ctx->keys2b, &ctx->vals2a, &ctx->vals2b, &ctx->extKeys, &ctx->extVals, &ctx->extKeys2, &ctx->extOrder, &ctx->slowList, &ctx->gapScratch, &ctx->jointCount, &ctx->jointBase, &ctx->joints, &ctx->sortKeys, &ctx->sortVals, &ctx->sortKeys2, &ctx->sortVals2, &ctx->gapOps, &ctx->waveChunks, &ctx->extOps, &ctx->traceCnt,
-                         &ctx->oqProf, &ctx->oqLists, &ctx->oqClsCnt, &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
+                         &ctx->oqCs, &ctx->oqCl, &ctx->oqOpsIn, &ctx->oqSeeds, &ctx->oqQlen, &ctx->pf.scanState, &ctx->pf.counters, &ctx->oqProf, &ctx->oqLists, &ctx->oqClsCnt, &ctx->oqThr, &ctx->oqSeqStart, &ctx->oqSeqLen, &ctx->oqNeed, &ctx->oqPoolOff, &ctx->oqKeys, &ctx->oqStack, &ctx->oqNodes, &ctx->oqPrim, &ctx->oqPA, &ctx->oqPfx, &ctx->oqPath, &ctx->oqPool, &ctx->oqPush, &ctx->oqOut, &ctx->oqOutCnt, &ctx->oqOutOps, &ctx->oqPrimCnt, &ctx->oqOutStart, &ctx->oqOpsStart, &ctx->oqFClumps, &ctx->oqFOps};
     return std::vector<DevBuf *>(all, all + sizeof all / sizeof all[0]);
 }
 extern "C" {
@@ -1086,6 +1106,9 @@ void ygpu_destroy(ygpu_ctx *ctx)
         for (int t = 0; t < T_N; t++) { hipEventDestroy(ctx->ev[t][0]); hipEventDestroy(ctx->ev[t][1]); }
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
         if (ctx->pinned) hipHostFree(ctx->pinned);
+        if (ctx->pf.pinned) hipHostFree(ctx->pf.pinned);
+        if (ctx->pf.evSync) hipEventDestroy(ctx->pf.evSync);
+        if (ctx->evSnap) hipEventDestroy(ctx->evSnap);
         for (int i = 0; i < YD_MAX_CHUNK_EV; i++) hipEventDestroy(ctx->evChunk[i]);
         hipEventDestroy(ctx->evTail); hipStreamDestroy(ctx->stream2);
         hipStreamDestroy(ctx->stream);
@@ -1146,7 +1169,8 @@ int ygpu_presize(ygpu_ctx *ctx, const ygpu_arena_profile *prof)
     HIPCHK(streamSync(ctx));
     return 0;
 }
-const char *ygpu_last_error(const ygpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+static thread_local const ygpu_ctx *tlsPfFailed = nullptr;                   // the context whose post-filter side failed last on this thread: ygpu_last_error then reports that side's message
+const char *ygpu_last_error(const ygpu_ctx *ctx) { return !ctx ? "null context" : (tlsPfFailed == ctx && !ctx->pf.err.empty()) ? ctx->pf.err.c_str() : ctx->err.c_str(); }
 
 int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
 {
@@ -1186,7 +1210,7 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
 int ygpu_run(ygpu_ctx *ctx)
 {
     if (!ctx || !ctx->stream) return YGPU_EINVAL;
-    ctx->stageDone = 0; ctx->oqDone = false; const double t0 = nowMs(); ctx->statAttempts = 0; ctx->statRanges = 0;
+    ctx->stageDone = 0; const double t0 = nowMs(); ctx->statAttempts = 0; ctx->statRanges = 0;
     struct Active { int d; explicit Active(int dv) : d(dv) { gActiveRuns[d]++; } ~Active() { gActiveRuns[d]--; } } active(ctx->device & 63);
     int rc = runTo(ctx, 3);
     if (kStats) { size_t fb = 0, tb = 0; hipMemGetInfo(&fb, &tb); fprintf(stderr, "[ygpu] ctx %p run: %u reads, rc %d, %.1f ms; align attempts %d, ranges %d, trace arena %.2f GB (ratio %.3f), free %.1f GB\n", (void *)ctx, ctx->nReads, rc, nowMs() - t0, ctx->statAttempts, ctx->statRanges, ctx->extTrace.cap / 1e9, ctx->traceRatio, fb / 1e9); }
@@ -1266,64 +1290,99 @@ int ygpu_set_postfilter(ygpu_ctx *ctx, const ygpu_postfilter_params *p)
     ctx->oqG.start = ctx->oqSeqStart.as<uint32_t>(); ctx->oqG.length = ctx->oqSeqLen.as<uint32_t>(); ctx->oqG.n = p->n_seqs;
     ctx->oqSet = true; return 0;
 }
-int ygpu_postfilter(ygpu_ctx *ctx)
+/* The stage works on a SNAPSHOT of the batch's results -- clump lists, edit ops, the reads' lengths and generator seeds, the work counters: 150 MB copied inside
+ * the device in ~0.1 ms -- so that the context can take its next batch (ygpu_upload, ygpu_run) while another thread filters this one: ygpu_postfilter_snapshot on
+ * the context's thread after ygpu_run, then ygpu_postfilter / ygpu_filtered_size / ygpu_collect_filtered on any thread.  (A ygpu_postfilter without a snapshot
+ * takes one itself: the sequential use.)  One snapshot at a time: the next may be taken once the filtered results of this one have been collected. */
+int ygpu_postfilter_snapshot(ygpu_ctx *ctx)
 {
     if (!ctx || !ctx->stream || ctx->stageDone < 3) return YGPU_EINVAL;
-    if (!ctx->oqSet) { ctx->err = "ygpu_postfilter: ygpu_set_postfilter has not been called on this context"; return YGPU_EINVAL; }
+    if (!ctx->oqSet) { ctx->err = "ygpu_postfilter_snapshot: ygpu_set_postfilter has not been called on this context"; return YGPU_EINVAL; }
+    if (ctx->pfSnap.load()) { ctx->err = "ygpu_postfilter_snapshot: the previous snapshot has not been filtered yet"; return YGPU_EINVAL; }
     HIPCHK(hipSetDevice(ctx->device));
-    const uint32_t n = ctx->nReads, C = ctx->nOut; ctx->nFOut = ctx->nFOps = 0; ctx->oqDone = false;
-    ENSURE(ctx->oqOutStart, 4ull * (n + 2)); ENSURE(ctx->oqOpsStart, 4ull * (n + 2));
-    if (n == 0 || C == 0) { HIPCHK(hipMemsetAsync(ctx->oqOutStart.p, 0, 4ull * (n + 2), ctx->stream)); HIPCHK(streamSync(ctx)); ctx->oqDone = true; return 0; }
-    ENSURE(ctx->oqNeed, 8ull * (n + 2)); ENSURE(ctx->oqPoolOff, 8ull * (n + 2)); ENSURE(ctx->oqLists, 4ull * YQ_NCLASS * (uint64_t)n + 64); ENSURE(ctx->oqClsCnt, 64);
-    ENSURE(ctx->oqPrim, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(ctx->oqPA, sizeof(yoqc::PAttr) * (uint64_t)C); ENSURE(ctx->oqPush, sizeof(yoqc::OutRec) * (uint64_t)C); ENSURE(ctx->oqOut, sizeof(yoqc::OutRec) * (uint64_t)C);
-    ENSURE(ctx->oqOutCnt, 4ull * (n + 2)); ENSURE(ctx->oqOutOps, 4ull * (n + 2)); ENSURE(ctx->oqPrimCnt, 4ull * (n + 2));
-    HIPCHK(hipMemsetAsync((uint32_t *)ctx->oqOutCnt.p + n, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync((uint32_t *)ctx->oqOutOps.p + n, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->oqClsCnt.p, 0, 64, ctx->stream));
-    OqcArgs A; A.P = ctx->oqP; A.G = ctx->oqG; A.cs = ctx->readStart.as<uint32_t>(); A.cl = ctx->outClumps2.as<ygpu_clump>(); A.ops = ctx->outOps.as<uint32_t>(); A.fwd = ctx->dFwd.as<uint8_t>(); A.readOff = ctx->dReadOff.as<uint32_t>(); A.nReads = n;
-    A.poolOff = ctx->oqPoolOff.as<unsigned long long>(); A.prim = ctx->oqPrim.as<yoqc::CNode>(); A.pa = ctx->oqPA.as<yoqc::PAttr>(); A.push = ctx->oqPush.as<yoqc::OutRec>(); A.out = ctx->oqOut.as<yoqc::OutRec>();
-    A.outCnt = ctx->oqOutCnt.as<uint32_t>(); A.outOpsCnt = ctx->oqOutOps.as<uint32_t>(); A.primCnt = ctx->oqPrimCnt.as<uint32_t>();
+    const uint32_t n = ctx->nReads, C = ctx->nOut, O = ctx->nOutOps;
+    ENSURE(ctx->oqCs, 4ull * (n + 2)); ENSURE(ctx->oqCl, sizeof(ygpu_clump) * ((uint64_t)C + 1)); ENSURE(ctx->oqOpsIn, 4ull * ((uint64_t)O + 1)); ENSURE(ctx->oqSeeds, 20ull * (n + 1)); ENSURE(ctx->oqQlen, 4ull * (n + 1));
+    HIPCHK(hipMemcpyAsync(ctx->oqCs.p, ctx->readStart.p, 4ull * (n + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    if (C) HIPCHK(hipMemcpyAsync(ctx->oqCl.p, ctx->outClumps2.p, sizeof(ygpu_clump) * (uint64_t)C, hipMemcpyDeviceToDevice, ctx->stream));
+    if (O) HIPCHK(hipMemcpyAsync(ctx->oqOpsIn.p, ctx->outOps.p, 4ull * O, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n) KL(k_oqc_seeds, dim3(gridFor(n, 256)), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dReadOff.as<uint32_t>(), n, ctx->oqSeeds.as<uint32_t>(), ctx->oqQlen.as<uint32_t>());
+    DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->evSnap, ctx->stream));
+    HIPCHK(streamSync(ctx));                                                // (the counters; the copies above are long done: the stream was idle after ygpu_run)
+    { const unsigned long long dropped = dc.v[C_FRAGS]; dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags + dropped; dc.v[C_REGIONS] = ctx->nRegions + dropped; }
+    memcpy(&ctx->snapCounters, dc.v, sizeof(ygpu_counters));
+    ctx->snapN = n; ctx->snapC = C; ctx->snapOps = O; ctx->oqDone = false;
+    ctx->pfSnap.store(true);
+    return 0;
+}
+static int postfilterBody(ygpu_ctx *full);
+int ygpu_postfilter(ygpu_ctx *full)
+{
+    if (!full || !full->stream) return YGPU_EINVAL;
+    if (!full->pfSnap.load()) { const int rc = ygpu_postfilter_snapshot(full); if (rc) return rc; }
+    const int rc = postfilterBody(full);
+    full->pfSnap.store(false);
+    tlsPfFailed = rc ? full : nullptr;
+    return rc;
+}
+static int postfilterBody(ygpu_ctx *full)
+{
+    PfSide *ctx = &full->pf;                                                 // (every macro and helper below: the post-filter's side)
+    HIPCHK(hipSetDevice(full->device));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, full->evSnap, 0));
+    const uint32_t n = full->snapN, C = full->snapC; full->pfN = n; full->pfCounters = full->snapCounters; full->nFOut = full->nFOps = 0; full->oqDone = false;
+    ENSURE(full->oqOutStart, 4ull * (n + 2)); ENSURE(full->oqOpsStart, 4ull * (n + 2));
+    if (n == 0 || C == 0) { HIPCHK(hipMemsetAsync(full->oqOutStart.p, 0, 4ull * (n + 2), ctx->stream)); HIPCHK(streamSync(ctx)); full->oqDone = true; return 0; }
+    ENSURE(full->oqNeed, 8ull * (n + 2)); ENSURE(full->oqPoolOff, 8ull * (n + 2)); ENSURE(full->oqLists, 4ull * YQ_NCLASS * (uint64_t)n + 64); ENSURE(full->oqClsCnt, 64);
+    ENSURE(full->oqPrim, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(full->oqPA, sizeof(yoqc::PAttr) * (uint64_t)C); ENSURE(full->oqPush, sizeof(yoqc::OutRec) * (uint64_t)C); ENSURE(full->oqOut, sizeof(yoqc::OutRec) * (uint64_t)C);
+    ENSURE(full->oqOutCnt, 4ull * (n + 2)); ENSURE(full->oqOutOps, 4ull * (n + 2)); ENSURE(full->oqPrimCnt, 4ull * (n + 2));
+    HIPCHK(hipMemsetAsync((uint32_t *)full->oqOutCnt.p + n, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync((uint32_t *)full->oqOutOps.p + n, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(full->oqClsCnt.p, 0, 64, ctx->stream));
+    OqcArgs A; A.P = full->oqP; A.G = full->oqG; A.cs = full->oqCs.as<uint32_t>(); A.cl = full->oqCl.as<ygpu_clump>(); A.ops = full->oqOpsIn.as<uint32_t>(); A.seeds = full->oqSeeds.as<uint32_t>(); A.qlen = full->oqQlen.as<uint32_t>(); A.nReads = n;
+    A.poolOff = full->oqPoolOff.as<unsigned long long>(); A.prim = full->oqPrim.as<yoqc::CNode>(); A.pa = full->oqPA.as<yoqc::PAttr>(); A.push = full->oqPush.as<yoqc::OutRec>(); A.out = full->oqOut.as<yoqc::OutRec>();
+    A.outCnt = full->oqOutCnt.as<uint32_t>(); A.outOpsCnt = full->oqOutOps.as<uint32_t>(); A.primCnt = full->oqPrimCnt.as<uint32_t>();
     A.keys = nullptr; A.stack = nullptr; A.nodes = nullptr; A.pfxOff = nullptr; A.path = nullptr; A.pool = nullptr; A.prof = nullptr;
     { const char *e = getenv("YGPU_OQC_MAX"); const int v = e ? atoi(e) : YQ_DEVICE_MAX; A.devMax = v >= 1 && v < YQ_DEVICE_MAX ? v : YQ_DEVICE_MAX; }     // (read at every call: tests lower it to send small reads down the hand-over path)
     static const bool oqProf = getenv("YGPU_OQC_PROF") != nullptr;
-    if (oqProf) { ENSURE(ctx->oqProf, 8ull * 16 * YQ_NCLASS); HIPCHK(hipMemsetAsync(ctx->oqProf.p, 0, 8ull * 16 * YQ_NCLASS, ctx->stream)); A.prof = ctx->oqProf.as<unsigned long long>(); }
-    uint32_t *lists = ctx->oqLists.as<uint32_t>();
-    KL(k_oqc_classify, dim3(gridFor(n + 1, 256)), dim3(256), 0, ctx->stream, A, ctx->oqNeed.as<unsigned long long>(), lists, ctx->oqClsCnt.as<unsigned int>());
-    int rc = cubScan64(ctx, ctx->oqNeed.as<unsigned long long>(), ctx->oqPoolOff.as<unsigned long long>(), n + 1); if (rc) return rc;
-    unsigned long long poolInts = 0; uint32_t nCls[YQ_NCLASS] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(&poolInts, ctx->oqPoolOff.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    rc = fetchU32(ctx, ctx->oqClsCnt.p, nCls, YQ_NCLASS); if (rc) return rc;
-    ENSURE(ctx->oqPool, 4ull * (poolInts + 16)); A.pool = ctx->oqPool.as<int>();
+    if (oqProf) { ENSURE(full->oqProf, 8ull * 32 * YQ_NCLASS); HIPCHK(hipMemsetAsync(full->oqProf.p, 0, 8ull * 32 * YQ_NCLASS, ctx->stream)); A.prof = full->oqProf.as<unsigned long long>(); }
+    uint32_t *lists = full->oqLists.as<uint32_t>();
+    KL(k_oqc_classify, dim3(gridFor(n + 1, 256)), dim3(256), 0, ctx->stream, A, full->oqNeed.as<unsigned long long>(), lists, full->oqClsCnt.as<unsigned int>());
+    int rc = cubScan64(ctx, full->oqNeed.as<unsigned long long>(), full->oqPoolOff.as<unsigned long long>(), n + 1); if (rc) return rc;
+    unsigned long long poolInts = 0; uint32_t nCls[YQ_NCLASS] = {0, 0, 0, 0, 0};
+    { uint32_t w[2] = {0, 0}; const FetchPiece pc[2] = {{full->oqPoolOff.as<unsigned long long>() + n, w, 2}, {full->oqClsCnt.p, nCls, YQ_NCLASS}};
+      rc = fetchMany(ctx, pc, 2); if (rc) return rc; poolInts = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32); }
+    ENSURE(full->oqPool, 4ull * (poolInts + 16)); A.pool = full->oqPool.as<int>();
     // work space of the reads in HBM: what a wave's LDS does not hold (the survivors' keys while the nodes are made; everything for the reads of the last class)
-    ENSURE(ctx->oqKeys, sizeof(yoqc::SortKey) * (uint64_t)C); ENSURE(ctx->oqStack, 4ull * (4ull * C + 8ull * n + 16)); ENSURE(ctx->oqNodes, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(ctx->oqPfx, 4ull * C); ENSURE(ctx->oqPath, 4ull * C);
-    A.keys = ctx->oqKeys.as<yoqc::SortKey>(); A.stack = ctx->oqStack.as<int>(); A.nodes = ctx->oqNodes.as<yoqc::CNode>(); A.pfxOff = ctx->oqPfx.as<int>(); A.path = ctx->oqPath.as<int>();
+    ENSURE(full->oqKeys, sizeof(yoqc::SortKey) * (uint64_t)C); ENSURE(full->oqStack, 4ull * (4ull * C + 8ull * n + 16)); ENSURE(full->oqNodes, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(full->oqPfx, 4ull * C); ENSURE(full->oqPath, 4ull * C);
+    A.keys = full->oqKeys.as<yoqc::SortKey>(); A.stack = full->oqStack.as<int>(); A.nodes = full->oqNodes.as<yoqc::CNode>(); A.pfxOff = full->oqPfx.as<int>(); A.path = full->oqPath.as<int>();
     // the classes: clumps a read may have -> LDS of its workgroup; ints of LDS pool (the first tables; later ones go to the read's slice of the HBM pool)
-    static const int capN[YQ_NCLASS] = {112, 224, YQ_DEVICE_MAX, 0};
-    // (the stream is idle here: fetchU32 waited for it.)  The classes run side by side: the few reads of the heavy classes take milliseconds each -- a kernel lasts as
-    // long as its slowest read -- and leave nearly all of the device to the thousands of light ones, which go out on the second stream.
+    static const int capN[YQ_NCLASS] = {112, 224, 448, YQ_DEVICE_MAX, 0};
+    // A wave a read, every read of a class resident at once: a launch lasts as long as its slowest read (one of 400 clumps with 280 survivors: 3 ms), and the classes
+    // follow one another on the post-filter's one stream.  That latency is off the context's path -- the next batch is running meanwhile -- and a stream of its own for
+    // every class is not worth having: streams share four hardware queues, and more than two a context put all contexts' main streams on one (profiles/r05_hw_queues.txt).
     if (nCls[YQ_NCLASS - 1]) KL(k_oqc_raw, dim3(gridFor(nCls[YQ_NCLASS - 1], 64)), dim3(64), 0, ctx->stream, A, lists + (size_t)(YQ_NCLASS - 1) * n, nCls[YQ_NCLASS - 1]);      // left to the host, marked
     for (int c = YQ_NCLASS - 2; c >= 0; c--) if (nCls[c]) {
         const unsigned lds = std::min(YQ_LDS_MAX, oqcLdsBytes(capN[c]));
-        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, c == YQ_NCLASS - 2 ? ctx->stream2 : ctx->stream, A, lists + (size_t)c * n, nCls[c], lds);
+        KL(k_oqc_wave, dim3(nCls[c]), dim3(64), lds, ctx->stream, A, lists + (size_t)c * n, nCls[c], lds);
     }
-    HIPCHK(hipEventRecord(ctx->evTail, ctx->stream2)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evTail, 0));
-    if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 224 / 448 clumps: %u / %u / %u, left to the host %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3], nCls[0], nCls[1], nCls[2], nCls[3], poolInts * 4.0 / 1e6);
-    rc = cubScan(ctx, ctx->oqOutCnt.as<uint32_t>(), ctx->oqOutStart.as<uint32_t>(), n + 1); if (rc) return rc;
-    rc = cubScan(ctx, ctx->oqOutOps.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), n + 1); if (rc) return rc;
-    uint32_t tot[2] = {0, 0};
-    rc = fetchU32(ctx, ctx->oqOutStart.as<uint32_t>() + n, &tot[0]); if (rc) return rc;
-    rc = fetchU32(ctx, ctx->oqOpsStart.as<uint32_t>() + n, &tot[1]); if (rc) return rc;
-    ctx->nFOut = tot[0]; ctx->nFOps = tot[1];
-    ENSURE(ctx->oqFClumps, sizeof(ygpu_out_clump) * ((uint64_t)tot[0] + 1)); ENSURE(ctx->oqFOps, 4ull * ((uint64_t)tot[1] + 1));
-    KL(k_oqc_gather, dim3(gridFor((uint64_t)n * 64, 256)), dim3(256), 0, ctx->stream, A, ctx->oqOutStart.as<uint32_t>(), ctx->oqOpsStart.as<uint32_t>(), ctx->oqFClumps.as<ygpu_out_clump>(), ctx->oqFOps.as<uint32_t>());
+    if (kTrace) fprintf(stderr, "[ygpu] post-filter: %u reads with two or more clumps in classes of <= 112 / 224 / 448 / %d clumps: %u / %u / %u / %u, left to the host %u; pool %.1f MB\n", nCls[0] + nCls[1] + nCls[2] + nCls[3] + nCls[4], YQ_DEVICE_MAX, nCls[0], nCls[1], nCls[2], nCls[3], nCls[4], poolInts * 4.0 / 1e6);
+    rc = cubScan(ctx, full->oqOutCnt.as<uint32_t>(), full->oqOutStart.as<uint32_t>(), n + 1); if (rc) return rc;
+    rc = cubScan(ctx, full->oqOutOps.as<uint32_t>(), full->oqOpsStart.as<uint32_t>(), n + 1); if (rc) return rc;
+    uint32_t tot[2] = {0, 0}, scanFail = 0;
+    { const FetchPiece pc[3] = {{full->oqOutStart.as<uint32_t>() + n, &tot[0], 1}, {full->oqOpsStart.as<uint32_t>() + n, &tot[1], 1}, {ctx->counters.as<uint32_t>() + CNT_SCANFAIL, &scanFail, 1}}; rc = fetchMany(ctx, pc, 3); if (rc) return rc; }
+    if (scanFail) { ctx->err = "post-filter: a look-back of an exclusive sum gave up"; return YGPU_EINTERNAL; }
+    full->nFOut = tot[0]; full->nFOps = tot[1];
+    ENSURE(full->oqFClumps, sizeof(ygpu_out_clump) * ((uint64_t)tot[0] + 1)); ENSURE(full->oqFOps, 4ull * ((uint64_t)tot[1] + 1));
+    KL(k_oqc_gather, dim3(gridFor((uint64_t)n * 64, 256)), dim3(256), 0, ctx->stream, A, full->oqOutStart.as<uint32_t>(), full->oqOpsStart.as<uint32_t>(), full->oqFClumps.as<ygpu_out_clump>(), full->oqFOps.as<uint32_t>());
     if (oqProf) {
-        unsigned long long h[16 * YQ_NCLASS]; HIPCHK(hipMemcpyAsync(h, ctx->oqProf.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+        unsigned long long h[32 * YQ_NCLASS]; HIPCHK(hipMemcpyAsync(h, full->oqProf.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
         static const char *nm[7] = {"keys", "sort", "dup scan", "nodes+tables", "path walk", "successors", "finish"};
-        for (int c = 0; c < YQ_NCLASS; c++) if (h[16 * c + 7]) {
-            const unsigned long long *q = h + 16 * c; fprintf(stderr, "[ygpu] post-filter class %d: %llu reads, %.0f clumps, %.0f survivors a read; us a read:", c, q[7], (double)q[8] / q[7], (double)q[9] / q[7]);
-            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f", nm[k], q[k] / 100.0 / q[7]);
-            fprintf(stderr, "; slowest read %.0f us\n", q[10] / 100.0);
+        for (int c = 0; c < YQ_NCLASS; c++) if (h[32 * c + 7]) {
+            const unsigned long long *q = h + 32 * c; fprintf(stderr, "[ygpu] post-filter class %d: %llu reads, %.0f clumps, %.0f survivors a read; us a read (largest of any read):", c, q[7], (double)q[8] / q[7], (double)q[9] / q[7]);
+            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f (%.0f)", nm[k], q[k] / 100.0 / q[7], q[16 + k] / 100.0);
+            fprintf(stderr, "; slowest read %.0f us: %llu clumps, %llu survivors\n", (q[10] >> 24) / 100.0, (q[10] >> 12) & 4095ull, q[10] & 4095ull);
         }
     }
-    ctx->oqDone = true;
+    full->oqDone = true;
     return 0;
 }
 /* Stage-level test entry for the path's own exclusive sums and orderings (scan.h): n pseudo-random elements from `seed` -- a u32 sum, a u64 sum whose values pass
@@ -1365,6 +1424,36 @@ int ygpu_selftest_primitives(ygpu_ctx *ctx, uint32_t n, uint32_t seed, int key_b
     { uint32_t last = 0; for (uint32_t i = 0; i < n; i++) { const uint32_t v = again[i] - 7u; if (v >= n) return fail("the second ordering", i); const uint32_t bk = std::min((h32[v] - sub) >> shift, nb - 1u); if (bk < last) return fail("the second ordering (buckets not ascending)", i); last = bk; } }
     uint32_t sf = 0; rc = fetchU32(ctx, ctx->counters.as<uint32_t>() + CNT_SCANFAIL, &sf); if (rc) return rc;
     if (sf) { ctx->err = "selftest: a look-back gave up"; return YGPU_EINTERNAL; }
+    // the post-filter's sort on the wave (oqc_stage.h waveSort) against the one-thread routine it stands for (oqc_core.h sortRange, the reference's quicksort with its
+    // random tie breaks): arrays of 2 .. YQ_DEVICE_MAX entries around the 64-lane edges, keys from 2 to 4 096 distinct values (ties by the hundred down to none), random,
+    // ascending and descending; every entry must land where the routine puts it
+    {
+        static const int fixedLen[] = {2, 3, 4, 5, 9, 17, 33, 63, 64, 65, 66, 100, 127, 128, 129, 130, 191, 192, 193, 300, 448, 449, 700, 1000, 1500, YQ_DEVICE_MAX};
+        const uint32_t nArr = 56; std::vector<uint32_t> off(nArr + 1, 0), seeds(5 * nArr); std::vector<uint64_t> ent;
+        for (uint32_t t = 0; t < nArr; t++) {
+            const int len = t < sizeof fixedLen / sizeof fixedLen[0] ? fixedLen[t] : 2 + (int)(rnd() % (YQ_DEVICE_MAX - 1));
+            const uint64_t span = 1ull << (1 + (seed * 7u + t) % 12u); const int shape = (int)(rnd() % 5);
+            for (int i = 0; i < len; i++) { uint64_t k = rnd() % span; if (shape == 3) k = (uint64_t)i * span / len; if (shape == 4) k = (uint64_t)(len - 1 - i) * span / len; ent.push_back((k << 16) | (uint64_t)i); }
+            for (int k = 0; k < 5; k++) seeds[5 * t + k] = (uint32_t)rnd();
+            off[t + 1] = off[t] + (uint32_t)len;
+        }
+        std::vector<uint64_t> want(ent.size()), got(ent.size());
+        for (uint32_t t = 0; t < nArr; t++) {
+            const int len = (int)(off[t + 1] - off[t]); std::vector<yoqc::SortKey> sk(len); std::vector<int> stk(4 * len + 16);
+            for (int i = 0; i < len; i++) { sk[i].key = ent[off[t] + i] >> 16; sk[i].clump = i; sk[i].pad = 0; }
+            yoqc::Rand rs; for (int k = 0; k < 5; k++) rs.s[k] = seeds[5 * t + k];
+            yoqc::Run::sortRange(sk.data(), len, stk.data(), (int)stk.size(), stk.data(), rs);
+            for (int i = 0; i < len; i++) want[off[t] + i] = (sk[i].key << 16) | (uint64_t)(uint32_t)sk[i].clump;
+        }
+        DevBuf dOff, dSeeds, dStack; struct Rel2 { DevBuf &a, &b, &c; ~Rel2() { a.release(); b.release(); c.release(); } } rel2{dOff, dSeeds, dStack};
+        if (a.ensure(8ull * ent.size()) || dOff.ensure(4ull * off.size()) || dSeeds.ensure(4ull * seeds.size()) || dStack.ensure(4ull * (2ull * ent.size() + 8ull * nArr + 16))) { ctx->err = "hipMalloc failed"; return YGPU_ENOMEM; }
+        HIPCHK(hipMemcpyAsync(a.p, ent.data(), 8ull * ent.size(), hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipMemcpyAsync(dOff.p, off.data(), 4ull * off.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(dSeeds.p, seeds.data(), 4ull * seeds.size(), hipMemcpyHostToDevice, ctx->stream));
+        KL(k_oqc_sort_test, dim3(nArr), dim3(64), 4u * YQ_STACK_LDS + 20u * YQ_DEVICE_MAX, ctx->stream, a.as<uint64_t>(), dOff.as<uint32_t>(), dSeeds.as<uint32_t>(), dStack.as<int>(), nArr);
+        HIPCHK(hipMemcpyAsync(got.data(), a.p, 8ull * ent.size(), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+        for (uint32_t t = 0; t < nArr; t++) for (uint32_t i = off[t]; i < off[t + 1]; i++) if (got[i] != want[i]) {
+            char m[200]; snprintf(m, sizeof m, "selftest: the sort on the wave differs from the one-thread routine: array %u (%u entries), position %u", t, off[t + 1] - off[t], i - off[t]); ctx->err = m; return YGPU_EINTERNAL; }
+    }
     return 0;
 }
 int ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r)
@@ -1377,29 +1466,28 @@ int ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r)
     if (r->n_clumps) HIPCHK(hipMemcpyAsync(ctx->outClumps2.p, r->clumps, sizeof(ygpu_clump) * r->n_clumps, hipMemcpyHostToDevice, ctx->stream));
     if (r->n_ops) HIPCHK(hipMemcpyAsync(ctx->outOps.p, r->ops, 4ull * r->n_ops, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(streamSync(ctx));
-    ctx->nOut = (uint32_t)r->n_clumps; ctx->nOutOps = (uint32_t)r->n_ops; ctx->stageDone = 3; ctx->oqDone = false;
+    ctx->nOut = (uint32_t)r->n_clumps; ctx->nOutOps = (uint32_t)r->n_ops; ctx->stageDone = 3;
     return 0;
 }
 int ygpu_filtered_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops)
 {
-    if (!ctx || ctx->stageDone < 3 || !ctx->oqDone) return YGPU_EINVAL;
+    if (!ctx || !ctx->oqDone) return YGPU_EINVAL;
     if (n_clumps) *n_clumps = ctx->nFOut; if (n_ops) *n_ops = ctx->nFOps;
     return 0;
 }
-int ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump *clumps, uint32_t *ops, ygpu_filtered_batch *out)
+int ygpu_collect_filtered(ygpu_ctx *full, uint32_t *clump_start, ygpu_out_clump *clumps, uint32_t *ops, ygpu_filtered_batch *out)
 {
-    if (!ctx || !out || !clump_start || ctx->stageDone < 3 || !ctx->oqDone || (ctx->nFOut && !clumps) || (ctx->nFOps && !ops)) return YGPU_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
-    const uint32_t n = ctx->nReads;
-    HIPCHK(hipMemcpyAsync(clump_start, ctx->oqOutStart.p, 4ull * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->nFOut) HIPCHK(hipMemcpyAsync(clumps, ctx->oqFClumps.p, sizeof(ygpu_out_clump) * (uint64_t)ctx->nFOut, hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->nFOps) HIPCHK(hipMemcpyAsync(ops, ctx->oqFOps.p, 4ull * ctx->nFOps, hipMemcpyDeviceToHost, ctx->stream));
-    DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream));
+    if (!full || !out || !clump_start || !full->oqDone || (full->nFOut && !clumps) || (full->nFOps && !ops)) return YGPU_EINVAL;
+    PfSide *ctx = &full->pf;
+    tlsPfFailed = full;
+    HIPCHK(hipSetDevice(full->device));
+    const uint32_t n = full->pfN;
+    HIPCHK(hipMemcpyAsync(clump_start, full->oqOutStart.p, 4ull * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    if (full->nFOut) HIPCHK(hipMemcpyAsync(clumps, full->oqFClumps.p, sizeof(ygpu_out_clump) * (uint64_t)full->nFOut, hipMemcpyDeviceToHost, ctx->stream));
+    if (full->nFOps) HIPCHK(hipMemcpyAsync(ops, full->oqFOps.p, 4ull * full->nFOps, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(streamSync(ctx));
-    { const unsigned long long dropped = dc.v[C_FRAGS];
-      dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags + dropped; dc.v[C_REGIONS] = ctx->nRegions + dropped; }
-    memcpy(&ctx->hCounters, dc.v, sizeof(ygpu_counters));
-    out->n_reads = n; out->clump_start = clump_start; out->clumps = clumps; out->ops = ops; out->n_clumps = ctx->nFOut; out->n_ops = ctx->nFOps; out->counters = ctx->hCounters;
+    tlsPfFailed = nullptr;
+    out->n_reads = n; out->clump_start = clump_start; out->clumps = clumps; out->ops = ops; out->n_clumps = full->nFOut; out->n_ops = full->nFOps; out->counters = full->pfCounters;
     return 0;
 }
 

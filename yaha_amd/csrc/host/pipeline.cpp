@@ -318,6 +318,36 @@ int runQueries(Args &a, FILE *log)
         // contexts that run (ygpu_park).
         bool lead = false;
         auto measured = [&]() { { std::lock_guard<std::mutex> lk(W.mu); W.measured = true; } W.cv.notify_all(); };
+        // The post-filter of batch n runs on a thread of its own, on the SNAPSHOT this thread takes of the batch's results (ygpu_postfilter_snapshot), while this
+        // thread is already uploading and running batch n + 1: the stage is a chain of waits for a few slow reads -- 5 to 9 ms in which the device is nearly idle -- and
+        // behind the hot path it made every batch of the context that much longer (the command line's steady rate 0.85 of the hot path's, round 4).  A context's first
+        // batch keeps the sequential order (its arenas are measured after it).  YAHA_SERIAL_FILTER=1: every batch in the sequential order.
+        struct FilterSide { std::mutex mu; std::condition_variable cv; BatchP b; double t0 = 0; bool busy = false, quit = false; std::thread th; } F;
+        const bool overlapFilter = deviceFilter && getenv("YAHA_SERIAL_FILTER") == nullptr;
+        auto collectFiltered = [&](BatchP &fb, ygpu_result_batch &res) -> int {  // post-filter (of the snapshot, or of the context's last run) and its results into the batch's own buffers
+            uint64_t nc = 0, no = 0;
+            int rc = ygpu_postfilter(ctx[d]); if (rc == 0) rc = ygpu_filtered_size(ctx[d], &nc, &no); if (rc != 0) return rc;
+            if (!fb->clumpStart.ensure(4 * (fb->nReads + 1)) || !fb->clumps.ensure(sizeof(ygpu_out_clump) * nc) || !fb->ops.ensure(4 * no)) return YGPU_ENOMEM;
+            ygpu_filtered_batch fr; rc = ygpu_collect_filtered(ctx[d], (uint32_t *)fb->clumpStart.p, (ygpu_out_clump *)fb->clumps.p, (uint32_t *)fb->ops.p, &fr);
+            res.n_clumps = fr.n_clumps; res.n_ops = fr.n_ops; return rc;
+        };
+        auto deliver = [&](BatchP &fb, int rc, const ygpu_result_batch &res, double t0) {
+            if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, rc == YGPU_ENOMEM && !fb->ops.p ? "host memory for the results" : ygpu_last_error(ctx[d])); fail(m); fb->nReads = 0; fmtQ.push(std::move(fb)); return; }
+            fb->nClumps = res.n_clumps; fb->nOps = res.n_ops;
+            fb->tDev = now() - t0; devReads[d / perDev] += fb->nReads;
+            fmtQ.push(std::move(fb));
+        };
+        auto filterLoop = [&]() {
+            for (;;) {
+                BatchP fb; double t0;
+                { std::unique_lock<std::mutex> lk(F.mu); F.cv.wait(lk, [&] { return F.quit || F.b; }); if (!F.b) return; fb = std::move(F.b); t0 = F.t0; }
+                ygpu_result_batch res; memset(&res, 0, sizeof res);
+                const int rc = stop ? 0 : collectFiltered(fb, res);
+                if (stop && rc == 0) { fb->nReads = 0; fmtQ.push(std::move(fb)); } else deliver(fb, rc, res, t0);
+                { std::lock_guard<std::mutex> lk(F.mu); F.busy = false; } F.cv.notify_all();
+            }
+        };
+        auto filterIdle = [&]() { std::unique_lock<std::mutex> lk(F.mu); F.cv.wait(lk, [&] { return !F.busy; }); };
         for (;;) {
             std::unique_lock<std::mutex> one(W.first, std::defer_lock);
             if (first) {
@@ -354,20 +384,23 @@ int runQueries(Args &a, FILE *log)
             if (!inQ.pop(b)) break;
             if (stop) { b->nReads = 0; fmtQ.push(std::move(b)); continue; }
             const double t0 = now();
-            ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res; memset(&res, 0, sizeof res);
+            ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res; memset(&res, 0, sizeof res); bool handedOver = false;
             auto hotPath = [&]() -> int {                                      // upload, run (+ post-filter), results straight into the batch's own buffers
                 const double h0 = now();
                 int rc = ygpu_upload(ctx[d], &rb); const double h1 = now(); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;
                 const double h2 = now();
                 uint64_t nc = 0, no = 0; b->filtered = deviceFilter;
+                if (deviceFilter && overlapFilter && !first) {                 // the filter thread takes it from here; this thread goes on with the next batch
+                    filterIdle();
+                    if (stop) return 0;
+                    rc = ygpu_postfilter_snapshot(ctx[d]); if (rc != 0) return rc;
+                    { std::lock_guard<std::mutex> lk(F.mu); F.b = std::move(b); F.t0 = t0; F.busy = true; if (!F.th.joinable()) F.th = std::thread(filterLoop); }
+                    F.cv.notify_all(); handedOver = true; return 0;
+                }
                 if (deviceFilter) {
-                    rc = ygpu_postfilter(ctx[d]); if (rc == 0) rc = ygpu_filtered_size(ctx[d], &nc, &no); if (rc != 0) return rc;
-                    const double h3 = now();
-                    if (!b->clumpStart.ensure(4 * (b->nReads + 1)) || !b->clumps.ensure(sizeof(ygpu_out_clump) * nc) || !b->ops.ensure(4 * no)) return YGPU_ENOMEM;
-                    const double h4 = now();
-                    ygpu_filtered_batch fr; rc = ygpu_collect_filtered(ctx[d], (uint32_t *)b->clumpStart.p, (ygpu_out_clump *)b->clumps.p, (uint32_t *)b->ops.p, &fr);
-                    if (timing && first) fprintf(stderr, "[yaha] context %d, first batch: upload %.1f  run %.1f  post-filter %.1f  result buffers %.1f  collect %.1f ms\n", d, h1 - h0, h2 - h1, h3 - h2, h4 - h3, now() - h4);
-                    res.n_clumps = fr.n_clumps; res.n_ops = fr.n_ops; return rc;
+                    rc = collectFiltered(b, res);
+                    if (timing && first) fprintf(stderr, "[yaha] context %d, first batch: upload %.1f  run %.1f  post-filter and collect %.1f ms\n", d, h1 - h0, h2 - h1, now() - h2);
+                    return rc;
                 }
                 rc = ygpu_result_size(ctx[d], &nc, &no); if (rc != 0) return rc;
                 if (!b->clumpStart.ensure(4 * (b->nReads + 1)) || !b->clumps.ensure(sizeof(ygpu_clump) * nc) || !b->ops.ensure(4 * no)) return YGPU_ENOMEM;
@@ -389,12 +422,11 @@ int runQueries(Args &a, FILE *log)
                 { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.firstRunning == 0; }); }
                 rc = hotPath();
             }
-            if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, rc == YGPU_ENOMEM && !b->ops.p ? "host memory for the results" : ygpu_last_error(ctx[d])); fail(m); b->nReads = 0; fmtQ.push(std::move(b)); continue; }
-            b->nClumps = res.n_clumps; b->nOps = res.n_ops;
-            b->tDev = now() - t0; devReads[d / perDev] += b->nReads;
-            fmtQ.push(std::move(b));
+            if (handedOver) continue;
+            deliver(b, rc, res, t0);
         }
         if (lead) measured();                                                 // (a leader that never saw a batch: the others must not wait for its measure)
+        if (F.th.joinable()) { filterIdle(); { std::lock_guard<std::mutex> lk(F.mu); F.quit = true; } F.cv.notify_all(); F.th.join(); }
         fmtQ.producerDone();
     };
     auto formatter = [&]() {

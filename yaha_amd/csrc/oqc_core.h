@@ -90,11 +90,13 @@ struct Run {
     { return op == 'M' ? P.MScore * len : op == 'R' ? -(P.RCost * len) : op == 'I' ? -(P.GOCost + P.GECost * len) : 0; }
 
     // ---- keys, sort ------------------------------------------------------------------------------------------------------------------------------------------
-    YQ_FN void makeKey(int i, int qlen)                                 // keys in list order head->tail (:929-934)
+    YQ_FN uint64_t clumpKey(int i, int qlen) const                      // (48 bits: SQO, -EQO, -score in 16 each)
     {
         const ygpu_clump &c = cl[i]; const bool rev = (c.status & stReversed) != 0;
-        SortKey k; k.key = compareKey(rev ? (qlen - 1) - c.eqo : c.sqo, rev ? (qlen - 1) - c.sqo : c.eqo, (int)c.totScore); k.clump = i; k.pad = 0; S.keys[i] = k;
+        return compareKey(rev ? (qlen - 1) - c.eqo : c.sqo, rev ? (qlen - 1) - c.sqo : c.eqo, (int)c.totScore);
     }
+    YQ_FN void makeKey(int i, int qlen)                                 // keys in list order head->tail (:929-934)
+    { SortKey k; k.key = clumpKey(i, qlen); k.clump = i; k.pad = 0; S.keys[i] = k; }
     // The sort (myQuickSortHelper :427-453 on getCompareKey, ties broken by the per-read generator) decides which of two equal-keyed clumps comes first -- which
     // duplicate survives, which copy of a repeat becomes the primary -- so its comparisons must happen in the reference's order.  They depend on keys and positions
     // only: the routine runs on (key, clump) pairs with the keys computed once; the reference's recursion (left part first) is an explicit stack of ranges (its first
@@ -142,14 +144,14 @@ struct Run {
     // All the scan reads of a node -- SQO, EQO, score -- is in the key (SQO<<32 | (-EQO & 0xffff)<<16 | -score & 0xffff); only two nodes of equal SQO and EQO are
     // ever compared by reference position.  A dead node is marked in its clump field (~clump).  dupKill(ck, ci, j): must the live node at j die behind the live
     // node (ck, ci)?  (The caller has checked that j's EQO does not exceed the node's: there the scan ends.)
-    YQ_FN bool dupKill(uint64_t ck, int ci, int j) const
+    YQ_FN bool dupKillK(uint64_t ck, int ci, uint64_t k, int cj) const   // (the candidate given by value: key k, clump cj)
     {
-        const uint64_t k = S.keys[j].key;
         if (keyEQO(ck) > keyEQO(k) && keyScore(k) < keyScore(ck) / 8) return true;
         if ((k >> 16) != (ck >> 16)) return false;                      // same SQO and EQO: duplicates if they are the same piece of the reference on the same strand
-        const ygpu_clump &c1 = cl[ci], &c2 = cl[S.keys[j].clump];
+        const ygpu_clump &c1 = cl[ci], &c2 = cl[cj];
         return c1.sro == c2.sro && c1.refLen == c2.refLen && ((c1.status ^ c2.status) & stReversed) == 0;
     }
+    YQ_FN bool dupKill(uint64_t ck, int ci, int j) const { return dupKillK(ck, ci, S.keys[j].key, S.keys[j].clump); }
     YQ_FN int dedup(int n)                                              // survivors compacted to keys[0..return)
     {
         SortKey *sk = S.keys; int cnt = 0;
@@ -193,22 +195,29 @@ struct Run {
         const int need = tableInts((int)cl[S.nodes[p].clump].n_ops);
         if (poolUsed + need <= S.poolCap) { S.tbl[p] = poolUsed; poolUsed += need; } else { S.tbl[p] = -2 - pool2Used; pool2Used += need; }
     }
-    YQ_FN int *tablePtr(int p) const { const int off = S.tbl[p]; return off >= 0 ? S.pool + off : S.pool2 + (-2 - off); }
-    YQ_FN void fillTable(int p)
+    // (a table is reached through `pool` or through `pool2`, never through a pointer that may be either: on the device the first is LDS, the second HBM, and each
+    // copy of the always-inlined bodies below compiles to the instructions of its address space)
+    YQ_FN YQ_INLINE void fillInto(int *T, int p) const
     {
         const int c = S.nodes[p].clump; const uint32_t *o = ops + cl[c].op_start; const int n = (int)cl[c].n_ops;
-        int *T = tablePtr(p), *Q = T + 1, *Sc = Q + n + 1; int q = 0, sc = 0; T[0] = n; Q[0] = 0; Sc[0] = 0;
+        int *Q = T + 1, *Sc = Q + n + 1; int q = 0, sc = 0; T[0] = n; Q[0] = 0; Sc[0] = 0;
         for (int k = 0; k < n; k++) {
             const char op = YGPU_OP_CODE(o[k]); const int len = (int)YGPU_OP_LEN(o[k]);
             if (op == 'D') sc -= (P.GOCost + P.GECost * len); else { q += len; sc += opScore(op, len); }
             Q[k + 1] = q | ((int)(unsigned char)op << 24); Sc[k + 1] = sc;
         }
     }
-    YQ_FN const int *table(int p) { if (S.tbl[p] == -1) { assignTable(p); fillTable(p); } return tablePtr(p); }
+    YQ_FN void fillTable(int p) { const int off = S.tbl[p]; if (off >= 0) fillInto(S.pool + off, p); else fillInto(S.pool2 + (-2 - off), p); }
     YQ_FN int scoreForLength(int p, int length, bool forward)           // node p's edit list
     {
         if (length <= 0) return 0;
-        const int *T = table(p); const int n = T[0]; if (n <= 0) return 0;
+        if (S.tbl[p] == -1) { assignTable(p); fillTable(p); }
+        const int off = S.tbl[p];
+        return off >= 0 ? scoreIn(S.pool + off, length, forward) : scoreIn(S.pool2 + (-2 - off), length, forward);
+    }
+    YQ_FN YQ_INLINE int scoreIn(const int *T, int length, bool forward) const
+    {
+        const int n = T[0]; if (n <= 0) return 0;
         const int *Q = T + 1, *Sc = Q + n + 1; const int M = 0xFFFFFF;
         if ((Q[n] & M) < length) return Sc[n];                           // the list ends first: every op counted in full
         // (host, measured: forcing these searches branch-free -- an AND with the comparison's mask -- made a call slower, 14.9 -> 18.2 us a read: the walks of one
