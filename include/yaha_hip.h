@@ -150,6 +150,9 @@ int  ygpu_presize(ygpu_ctx *ctx, const ygpu_arena_profile *profile);
 /* Stage reads into HBM (H2D).  Separate from ygpu_run so that a benchmark can time the hot path with inputs
  * already resident. */
 int  ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *batch);
+/* The same without the wait at its end: returns once the copies are queued (the reads' bytes may still be on their way).  The batch's memory must stay
+ * unchanged until the ygpu_run that follows has returned.  (The command line's context threads: their batches live until they are printed.) */
+int  ygpu_upload_nowait(ygpu_ctx *ctx, const ygpu_read_batch *batch);
 /* Run the whole hot path (A1..A10) on the resident batch; results stay in HBM. */
 int  ygpu_run(ygpu_ctx *ctx);
 /* Copy results of the last ygpu_run to host memory owned by the context. */

@@ -57,6 +57,7 @@ int ygpu_upload(ygpu_ctx *c, const ygpu_read_batch *b)
     const uint64_t o0 = c->offs[0]; for (auto &o : c->offs) o -= o0;
     return 0;
 }
+int ygpu_upload_nowait(ygpu_ctx *c, const ygpu_read_batch *b) { return ygpu_upload(c, b); }
 int ygpu_run(ygpu_ctx *c)
 {
     const int k = ++gRuns;

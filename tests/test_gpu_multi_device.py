@@ -75,7 +75,7 @@ def test_presized_and_parked_contexts(work, index11):
     gives its arenas back and refuses further batches."""
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r10k.fa")]) as s:
         b = s.next_batch(12)
-        ctxs = ya.Context.on_devices(s.index, s.params, [0], ctx_per_device=3)
+        ctxs = ya.Context.on_devices(s.index, s.params, [0], ctx_per_device=4)
         try:
             _golden_batch_equals_oracle(s, b, ctxs[:1])
             prof = ctxs[0].arena_profile()
@@ -97,6 +97,16 @@ def test_presized_and_parked_contexts(work, index11):
             with pytest.raises(RuntimeError, match="parked"):
                 ctxs[2].upload(b)
             _golden_batch_equals_oracle(s, b, ctxs[:2])                        # the others are unaffected
+            # a profile taken after the post-filter has run holds that stage's buffers too -- among them the look-back words of its exclusive sums, which their kernel
+            # expects zeroed: a context presized from it filters its first batch like the first context does (round 5: it did not -- "a look-back gave up", or a fault)
+            import ctypes as C
+            def filtered(c):
+                c.set_postfilter(s); c.upload(b); c.run(); f = c.postfilter()
+                return int(f.n_clumps), int(f.n_ops), bytes(C.string_at(c._f_cs, 4 * (b.n_reads + 1))), bytes(C.string_at(c._f_cl, 40 * int(f.n_clumps))), bytes(C.string_at(c._f_ops, 4 * int(f.n_ops)))
+            want = filtered(ctxs[0])
+            ctxs[3].presize(ctxs[0].arena_profile())
+            for _ in range(3):
+                assert filtered(ctxs[3]) == want
         finally:
             for c in reversed(ctxs):
                 c.close()

@@ -277,6 +277,17 @@ def test_cli_drop_in(work, index11, tmp_path):
     assert len(mine) == len(ref)
 
 
+def test_cli_small_batches_many_times(work, index11, tmp_path):
+    """Thirty runs of the command line over batches of 50 reads on three contexts -- every context presized from the first, dozens of hand-overs between context and
+    filter threads a run: the same SAM every time.  (Round 5: a presized context's post-filter started on unzeroed look-back words -- one run in fifty ended in a
+    device fault, another few in a different SAM with exit code 0; tools/cli_stress.sh is the longer form of this test.)"""
+    out = str(tmp_path / "o.sam"); ref = golden_lines("rchim_FBS")
+    for i in range(30):
+        p = subprocess.run([ya.CLI_PATH, "-x", index11, "-q", os.path.join(work, "rchim.fa"), "-oss", out, "-FBS", "Y", "-ctx", "3", "-batch", "50"], stderr=subprocess.PIPE)
+        assert p.returncode == 0, (i, p.stderr.decode()[-1500:])
+        assert strip_pg(open(out).read()) == ref, "run %d differs" % i
+
+
 @pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref/yaha not present")
 def test_live_reference_binary_on_fresh_human_like_reads(work, tmp_path):
     # bigger, repeat-richer genome built on the box; the reference binary itself is the referee

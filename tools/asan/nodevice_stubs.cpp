@@ -15,6 +15,7 @@ int  ygpu_get_arena_profile(ygpu_ctx *, ygpu_arena_profile *) { return YGPU_ENOD
 int  ygpu_presize(ygpu_ctx *, const ygpu_arena_profile *) { return YGPU_ENODEV; }
 const char *ygpu_last_error(const ygpu_ctx *) { return "sanitizer build of the host stages: no device code linked"; }
 int  ygpu_upload(ygpu_ctx *, const ygpu_read_batch *) { return YGPU_ENODEV; }
+int  ygpu_upload_nowait(ygpu_ctx *, const ygpu_read_batch *) { return YGPU_ENODEV; }
 int  ygpu_run(ygpu_ctx *) { return YGPU_ENODEV; }
 int  ygpu_collect(ygpu_ctx *, ygpu_result_batch *) { return YGPU_ENODEV; }
 int  ygpu_result_size(ygpu_ctx *, uint64_t *, uint64_t *) { return YGPU_ENODEV; }

@@ -54,13 +54,13 @@ cli|cli10k)
   yaha_amd/csrc/yaha -x $X -q $Q -osh /dev/shm/o.sam 2>/dev/null
   for opts in "$@"; do
     sleep 25          # (the driver scrubs what the previous process freed; a run started right away pays seconds for its first allocations)
-    YAHA_STATS=1 yaha_amd/csrc/yaha -x $X -q $Q -osh /dev/shm/o.sam $opts 2>&1 | grep "stats" | sed "s/^/[$opts] /" | cut -c1-330 | tee -a gpurun_out/$TAG.txt
+    YAHA_STATS=1 yaha_amd/csrc/yaha -x $X -q $Q -osh /dev/shm/o.sam $opts 2>&1 | grep "stats" | sed "s/^/[$opts] /" | cut -c1-700 | tee -a gpurun_out/$TAG.txt
   done
   rm -f /dev/shm/o.sam ;;
 clienv)
   TAG=${1:-clienv}; V=$2; shift; shift; warm; reads1k
   yaha_amd/csrc/yaha -x $X -q $R1 -osh /dev/shm/o.sam 2>/dev/null
-  for x in "$@"; do sleep 25; env $V=$x YAHA_STATS=1 yaha_amd/csrc/yaha -x $X -q $R1 -osh /dev/shm/o.sam 2>&1 | grep "stats" | sed "s/^/[$V=$x] /" | cut -c1-330 | tee -a gpurun_out/$TAG.txt; done
+  for x in "$@"; do sleep 25; env $V=$x YAHA_STATS=1 yaha_amd/csrc/yaha -x $X -q $R1 -osh /dev/shm/o.sam 2>&1 | grep "stats" | sed "s/^/[$V=$x] /" | cut -c1-700 | tee -a gpurun_out/$TAG.txt; done
   rm -f /dev/shm/o.sam ;;
 n2)
   TAG=${1:-n2}

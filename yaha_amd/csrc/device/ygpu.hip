@@ -99,7 +99,8 @@ struct ygpu_ctx {
     DevBuf oqProf, oqLists, oqClsCnt, oqThr, oqSeqStart, oqSeqLen, oqNeed, oqPoolOff, oqKeys, oqStack, oqNodes, oqPrim, oqPA, oqPfx, oqPath, oqPool, oqPush, oqOut, oqOutCnt, oqOutOps, oqPrimCnt, oqOutStart, oqOpsStart, oqFClumps, oqFOps;
     bool oqSet = false, oqDone = false; yoqc::Params oqP{}; yoqc::Seqs oqG{}; uint32_t nFOut = 0, nFOps = 0;
     // the snapshot the stage works on (taken by the context's thread) and the copy of its sizes the stage runs with (its own thread)
-    PfSide pf; std::atomic<bool> pfSnap{false}; hipEvent_t evSnap = nullptr; uint32_t snapN = 0, snapC = 0, snapOps = 0, pfN = 0; ygpu_counters snapCounters{}, pfCounters{};
+    PfSide pf; std::atomic<bool> pfSnap{false}; hipEvent_t evSnap = nullptr; uint32_t snapN = 0, snapC = 0, snapOps = 0, pfN = 0; ygpu_counters pfCounters{};
+    DevCounters *snapCtr = nullptr; DevCounters snapCtrPlain{}; unsigned long long snapHits = 0, snapFrags = 0, snapRegions = 0;
     DevBuf oqCs, oqCl, oqOpsIn, oqSeeds, oqQlen;
     // stage state
     uint32_t hOutCounts[2] = {0, 0}, hOutEf = 0; bool hOutValid = false;
@@ -866,6 +867,7 @@ static int initCommon(ygpu_ctx *ctx, int device)
     if (hipHostMalloc((void **)&ctx->pf.pinned, 256, hipHostMallocDefault) != hipSuccess) { ctx->pf.pinned = nullptr; (void)hipGetLastError(); }
     if (hipEventCreateWithFlags(&ctx->pf.evSync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { ctx->pf.evSync = nullptr; (void)hipGetLastError(); }
     HIPCHK(hipEventCreateWithFlags(&ctx->evSnap, hipEventDisableTiming));
+    if (hipHostMalloc((void **)&ctx->snapCtr, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) { ctx->snapCtr = nullptr; (void)hipGetLastError(); }
     if (ctx->pf.counters.ensure(4 * CNT_N)) { ctx->err = "hipMalloc failed"; return YGPU_ENOMEM; }
     HIPCHK(hipMemsetAsync(ctx->pf.counters.p, 0, 4 * CNT_N, ctx->stream2));
     phase("pinned words");
@@ -1107,6 +1109,7 @@ void ygpu_destroy(ygpu_ctx *ctx)
         if (ctx->evSync) hipEventDestroy(ctx->evSync);
         if (ctx->pinned) hipHostFree(ctx->pinned);
         if (ctx->pf.pinned) hipHostFree(ctx->pf.pinned);
+        if (ctx->snapCtr) hipHostFree(ctx->snapCtr);
         if (ctx->pf.evSync) hipEventDestroy(ctx->pf.evSync);
         if (ctx->evSnap) hipEventDestroy(ctx->evSnap);
         for (int i = 0; i < YD_MAX_CHUNK_EV; i++) hipEventDestroy(ctx->evChunk[i]);
@@ -1159,12 +1162,13 @@ int ygpu_presize(ygpu_ctx *ctx, const ygpu_arena_profile *prof)
     if (prof->n != all.size()) { ctx->err = "arena profile of another build"; return YGPU_EINVAL; }
     for (size_t k = 0; k < all.size(); k++) {
         DevBuf *b = all[k];
-        if (b == &ctx->dBases || b == &ctx->dSO || b == &ctx->dROA || b == &ctx->dLow || b == &ctx->counters || b == &ctx->ctr || b == &ctx->errFlag) continue;
+        if (b == &ctx->dBases || b == &ctx->dSO || b == &ctx->dROA || b == &ctx->dLow || b == &ctx->counters || b == &ctx->ctr || b == &ctx->errFlag || b == &ctx->pf.counters) continue;
         if (prof->cap[k] > b->cap && b->ensureExact((size_t)prof->cap[k])) { (void)hipGetLastError(); ctx->err = "hipMalloc failed while presizing the arenas"; return YGPU_ENOMEM; }
     }
     // (work words that their kernels expect zeroed when they are made)
     if (ctx->scanState.p) HIPCHK(hipMemsetAsync(ctx->scanState.p, 0, ctx->scanState.cap, ctx->stream));
     if (ctx->bucketWork.p) HIPCHK(hipMemsetAsync(ctx->bucketWork.p, 0, ctx->bucketWork.cap, ctx->stream));
+    if (ctx->pf.scanState.p) HIPCHK(hipMemsetAsync(ctx->pf.scanState.p, 0, ctx->pf.scanState.cap, ctx->stream));      // (the post-filter side's look-back words: the same rule)
     if (ctx->runsDone == 0) { ctx->traceRatio = prof->trace_ratio; ctx->opsRatio = prof->ops_ratio > 0 ? prof->ops_ratio : ctx->opsRatio; ctx->lastClumpSlots = prof->last_clump_slots; ctx->lastFall = (long long)prof->last_fall; }
     HIPCHK(streamSync(ctx));
     return 0;
@@ -1172,7 +1176,8 @@ int ygpu_presize(ygpu_ctx *ctx, const ygpu_arena_profile *prof)
 static thread_local const ygpu_ctx *tlsPfFailed = nullptr;                   // the context whose post-filter side failed last on this thread: ygpu_last_error then reports that side's message
 const char *ygpu_last_error(const ygpu_ctx *ctx) { return !ctx ? "null context" : (tlsPfFailed == ctx && !ctx->pf.err.empty()) ? ctx->pf.err.c_str() : ctx->err.c_str(); }
 
-int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
+} // extern "C"
+static int uploadBatch(ygpu_ctx *ctx, const ygpu_read_batch *b, bool wait)
 {
     if (!ctx || !ctx->stream || !b) return YGPU_EINVAL;
     if (ctx->parked) { ctx->err = "the context was parked (ygpu_park)"; return YGPU_EINVAL; }
@@ -1203,9 +1208,13 @@ int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b)
         KL(k_pack4, dim3(gridFor(nPacked, 256)), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dFwd4.as<uint8_t>(), nPacked, (uint32_t)ctx->totalBases);
         KL(k_pack4, dim3(gridFor(nPacked, 256)), dim3(256), 0, ctx->stream, ctx->dRev.as<uint8_t>(), ctx->dRev4.as<uint8_t>(), nPacked, (uint32_t)ctx->totalBases);
     }
-    HIPCHK(streamSync(ctx));
+    if (wait) HIPCHK(streamSync(ctx));
     return 0;
 }
+extern "C" {
+int ygpu_upload(ygpu_ctx *ctx, const ygpu_read_batch *b) { return uploadBatch(ctx, b, true); }
+/* ygpu_upload without its wait: returns as soon as the copies are queued.  The batch's memory must stay unchanged until the ygpu_run that follows has returned. */
+int ygpu_upload_nowait(ygpu_ctx *ctx, const ygpu_read_batch *b) { static const bool waitAnyway = getenv("YGPU_UPLOAD_WAIT") != nullptr; return uploadBatch(ctx, b, waitAnyway); }
 
 int ygpu_run(ygpu_ctx *ctx)
 {
@@ -1306,11 +1315,13 @@ int ygpu_postfilter_snapshot(ygpu_ctx *ctx)
     if (C) HIPCHK(hipMemcpyAsync(ctx->oqCl.p, ctx->outClumps2.p, sizeof(ygpu_clump) * (uint64_t)C, hipMemcpyDeviceToDevice, ctx->stream));
     if (O) HIPCHK(hipMemcpyAsync(ctx->oqOpsIn.p, ctx->outOps.p, 4ull * O, hipMemcpyDeviceToDevice, ctx->stream));
     if (n) KL(k_oqc_seeds, dim3(gridFor(n, 256)), dim3(256), 0, ctx->stream, ctx->dFwd.as<uint8_t>(), ctx->dReadOff.as<uint32_t>(), n, ctx->oqSeeds.as<uint32_t>(), ctx->oqQlen.as<uint32_t>());
-    DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream));
+    // (no wait here: the context's thread goes straight on to its next batch -- whatever it queues on this stream follows the copies -- and the work counters land
+    // in a pinned slot the filter's side reads after its own first wait; without the slot, a wait it is)
+    if (ctx->snapCtr) HIPCHK(hipMemcpyAsync(ctx->snapCtr, ctx->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
+    else { DevCounters dc; HIPCHK(hipMemcpyAsync(&dc, ctx->ctr.p, sizeof dc, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx)); memcpy(&ctx->snapCtrPlain, &dc, sizeof dc); }
     HIPCHK(hipEventRecord(ctx->evSnap, ctx->stream));
-    HIPCHK(streamSync(ctx));                                                // (the counters; the copies above are long done: the stream was idle after ygpu_run)
-    { const unsigned long long dropped = dc.v[C_FRAGS]; dc.v[C_HITS] = ctx->nHits; dc.v[C_FRAGS] = ctx->nFrags + dropped; dc.v[C_REGIONS] = ctx->nRegions + dropped; }
-    memcpy(&ctx->snapCounters, dc.v, sizeof(ygpu_counters));
+    { static const bool waitHere = getenv("YGPU_SNAPSHOT_WAIT") != nullptr; if (waitHere) HIPCHK(streamSync(ctx)); }
+    ctx->snapHits = ctx->nHits; ctx->snapFrags = ctx->nFrags; ctx->snapRegions = ctx->nRegions;
     ctx->snapN = n; ctx->snapC = C; ctx->snapOps = O; ctx->oqDone = false;
     ctx->pfSnap.store(true);
     return 0;
@@ -1330,9 +1341,14 @@ static int postfilterBody(ygpu_ctx *full)
     PfSide *ctx = &full->pf;                                                 // (every macro and helper below: the post-filter's side)
     HIPCHK(hipSetDevice(full->device));
     HIPCHK(hipStreamWaitEvent(ctx->stream, full->evSnap, 0));
-    const uint32_t n = full->snapN, C = full->snapC; full->pfN = n; full->pfCounters = full->snapCounters; full->nFOut = full->nFOps = 0; full->oqDone = false;
+    const uint32_t n = full->snapN, C = full->snapC; full->pfN = n; full->nFOut = full->nFOps = 0; full->oqDone = false;
+    auto takeCounters = [&]() {                                              // (after a wait of this side's stream: the snapshot's copies are done)
+        DevCounters dc = full->snapCtr ? *full->snapCtr : full->snapCtrPlain;
+        const unsigned long long dropped = dc.v[C_FRAGS]; dc.v[C_HITS] = full->snapHits; dc.v[C_FRAGS] = full->snapFrags + dropped; dc.v[C_REGIONS] = full->snapRegions + dropped;
+        memcpy(&full->pfCounters, dc.v, sizeof(ygpu_counters));
+    };
     ENSURE(full->oqOutStart, 4ull * (n + 2)); ENSURE(full->oqOpsStart, 4ull * (n + 2));
-    if (n == 0 || C == 0) { HIPCHK(hipMemsetAsync(full->oqOutStart.p, 0, 4ull * (n + 2), ctx->stream)); HIPCHK(streamSync(ctx)); full->oqDone = true; return 0; }
+    if (n == 0 || C == 0) { HIPCHK(hipMemsetAsync(full->oqOutStart.p, 0, 4ull * (n + 2), ctx->stream)); HIPCHK(streamSync(ctx)); takeCounters(); full->oqDone = true; return 0; }
     ENSURE(full->oqNeed, 8ull * (n + 2)); ENSURE(full->oqPoolOff, 8ull * (n + 2)); ENSURE(full->oqLists, 4ull * YQ_NCLASS * (uint64_t)n + 64); ENSURE(full->oqClsCnt, 64);
     ENSURE(full->oqPrim, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(full->oqPA, sizeof(yoqc::PAttr) * (uint64_t)C); ENSURE(full->oqPush, sizeof(yoqc::OutRec) * (uint64_t)C); ENSURE(full->oqOut, sizeof(yoqc::OutRec) * (uint64_t)C);
     ENSURE(full->oqOutCnt, 4ull * (n + 2)); ENSURE(full->oqOutOps, 4ull * (n + 2)); ENSURE(full->oqPrimCnt, 4ull * (n + 2));
@@ -1350,6 +1366,7 @@ static int postfilterBody(ygpu_ctx *full)
     unsigned long long poolInts = 0; uint32_t nCls[YQ_NCLASS] = {0, 0, 0, 0, 0};
     { uint32_t w[2] = {0, 0}; const FetchPiece pc[2] = {{full->oqPoolOff.as<unsigned long long>() + n, w, 2}, {full->oqClsCnt.p, nCls, YQ_NCLASS}};
       rc = fetchMany(ctx, pc, 2); if (rc) return rc; poolInts = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32); }
+    takeCounters();
     ENSURE(full->oqPool, 4ull * (poolInts + 16)); A.pool = full->oqPool.as<int>();
     // work space of the reads in HBM: what a wave's LDS does not hold (the survivors' keys while the nodes are made; everything for the reads of the last class)
     ENSURE(full->oqKeys, sizeof(yoqc::SortKey) * (uint64_t)C); ENSURE(full->oqStack, 4ull * (4ull * C + 8ull * n + 16)); ENSURE(full->oqNodes, sizeof(yoqc::CNode) * (uint64_t)C); ENSURE(full->oqPfx, 4ull * C); ENSURE(full->oqPath, 4ull * C);

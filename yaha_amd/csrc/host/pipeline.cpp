@@ -290,6 +290,8 @@ int runQueries(Args &a, FILE *log)
     std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < nDev; k++) warm.emplace_back(new Warm);
     std::atomic<int> ctxUp(0), parked(0); double tCtxUp = 0;
     std::vector<std::atomic<uint64_t>> devReads(nDev); for (auto &x : devReads) x = 0;       // reads each device took (the stats line: do all devices pull their weight?)
+    // where a context thread's time goes, batches after a context's first (the stats line; microseconds): upload, run, waiting for the filter thread, snapshot; and the filter thread's post-filter + collect
+    std::atomic<uint64_t> usUpload(0), usRun(0), usWaitFilter(0), usSnapshot(0), usFilter(0), usIdle(0), nLater(0);
     // The index image reaches the devices through ONE call (ygpu_init_multi): the first device takes it from the host, the others from their neighbour over xGMI,
     // piece by piece -- the reference maps its index once for all threads (Query.c:565-626); N uploads of 16.7 GB at once would share the host's memory instead.
     std::vector<int> leadRc(nDev, 0);
@@ -342,7 +344,9 @@ int runQueries(Args &a, FILE *log)
                 BatchP fb; double t0;
                 { std::unique_lock<std::mutex> lk(F.mu); F.cv.wait(lk, [&] { return F.quit || F.b; }); if (!F.b) return; fb = std::move(F.b); t0 = F.t0; }
                 ygpu_result_batch res; memset(&res, 0, sizeof res);
+                const double f0 = now();
                 const int rc = stop ? 0 : collectFiltered(fb, res);
+                usFilter += (uint64_t)((now() - f0) * 1e3);
                 if (stop && rc == 0) { fb->nReads = 0; fmtQ.push(std::move(fb)); } else deliver(fb, rc, res, t0);
                 { std::lock_guard<std::mutex> lk(F.mu); F.busy = false; } F.cv.notify_all();
             }
@@ -381,19 +385,23 @@ int runQueries(Args &a, FILE *log)
                     if (prc == 0) { first = false; one.unlock(); }
                 }
             }
+            const double w0 = now();
             if (!inQ.pop(b)) break;
             if (stop) { b->nReads = 0; fmtQ.push(std::move(b)); continue; }
-            const double t0 = now();
+            const double t0 = now(); if (!first) usIdle += (uint64_t)((t0 - w0) * 1e3);
             ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res; memset(&res, 0, sizeof res); bool handedOver = false;
             auto hotPath = [&]() -> int {                                      // upload, run (+ post-filter), results straight into the batch's own buffers
                 const double h0 = now();
-                int rc = ygpu_upload(ctx[d], &rb); const double h1 = now(); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;
+                int rc = ygpu_upload_nowait(ctx[d], &rb); const double h1 = now(); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;      // (the batch lives until it is printed: no wait for its bytes here)
                 const double h2 = now();
                 uint64_t nc = 0, no = 0; b->filtered = deviceFilter;
+                if (!first) { usUpload += (uint64_t)((h1 - h0) * 1e3); usRun += (uint64_t)((h2 - h1) * 1e3); nLater++; }
                 if (deviceFilter && overlapFilter && !first) {                 // the filter thread takes it from here; this thread goes on with the next batch
                     filterIdle();
+                    const double h3 = now();
                     if (stop) return 0;
                     rc = ygpu_postfilter_snapshot(ctx[d]); if (rc != 0) return rc;
+                    usWaitFilter += (uint64_t)((h3 - h2) * 1e3); usSnapshot += (uint64_t)((now() - h3) * 1e3);
                     { std::lock_guard<std::mutex> lk(F.mu); F.b = std::move(b); F.t0 = t0; F.busy = true; if (!F.th.joinable()) F.th = std::thread(filterLoop); }
                     F.cv.notify_all(); handedOver = true; return 0;
                 }
@@ -486,8 +494,9 @@ int runQueries(Args &a, FILE *log)
     if (stats) {    // one line for scripts (bench.py): steady = reads written after the first batch / time from the first batch's write to the last one's
         const double steady = (nWritten > nFirst && tLastOut > tFirstOut) ? (nWritten - nFirst) / ((tLastOut - tFirstOut) * 1e-3) : 0.0;
         std::string per = "["; for (int k = 0; k < nDev; k++) { char t[32]; snprintf(t, sizeof t, "%s%llu", k ? ", " : "", (unsigned long long)devReads[k].load()); per += t; } per += "]";
-        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, \"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d, \"ctx_left_out\": %d, \"reads_per_device\": %s}\n",
-                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev, parked.load(), per.c_str());
+        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, \"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d, \"ctx_left_out\": %d, \"reads_per_device\": %s, \"context_thread_ms_per_batch\": {\"wait_for_a_batch\": %.2f, \"upload\": %.2f, \"run\": %.2f, \"wait_for_filter_thread\": %.2f, \"snapshot\": %.2f}, \"filter_thread_ms_per_batch\": %.2f}\n",
+                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev, parked.load(), per.c_str(),
+                usIdle / 1e3 / std::max<uint64_t>(1, nLater), usUpload / 1e3 / std::max<uint64_t>(1, nLater), usRun / 1e3 / std::max<uint64_t>(1, nLater), usWaitFilter / 1e3 / std::max<uint64_t>(1, nLater), usSnapshot / 1e3 / std::max<uint64_t>(1, nLater), usFilter / 1e3 / std::max<uint64_t>(1, nLater));
     }
     return rcAll;
 }
