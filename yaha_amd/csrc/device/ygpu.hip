@@ -636,24 +636,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             rc = bucketOrder(ctx, k0, v0, 0, np, 0, std::max(0, keyBits - 12), 1u << std::min(keyBits, 12), v1, ctx->stream); if (rc) return rc;
             E.order = v1;
         }
-        static const int traceSerial = getenv("YGPU_TRACE_SERIAL") ? atoi(getenv("YGPU_TRACE_SERIAL")) : 0;      // (experiment: the tracebacks of the device's contexts one at a time, as the rows launches)
-        static const bool traceWithRows = getenv("YGPU_TRACE_WITH_ROWS") != nullptr;      // (experiment: tracebacks and rows launches share ONE chain)
-        if (traceWithRows && rowsShare && ctx->maxQ <= 4096) {
-            std::lock_guard<std::mutex> lk(gRowsMu[ctx->device & 63]); const int dv = ctx->device & 63;
-            const int slot = 0; gRowsSeq[dv]++;
-            if (gRowsEvValid[dv][slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, gRowsEv[dv][slot], 0));
-            KL(traceKernel, dim3(gridFor(np, traceBS)), dim3(traceBS), 0, ctx->stream, E);
-            if (gRowsEvValid[dv][slot]) HIPCHK(hipEventRecord(gRowsEv[dv][slot], ctx->stream));
-        } else
-        if (traceSerial && rowsShare && ctx->maxQ <= 4096) {
-            static std::mutex mu[64]; static hipEvent_t ev[64][4]; static bool valid[64][4]; static unsigned long long seq[64];
-            const int dv = ctx->device & 63; std::lock_guard<std::mutex> lk(mu[dv]);
-            const int depth = std::min(4, std::max(1, traceSerial)); const int slot = (int)(seq[dv]++ % (unsigned long long)depth);
-            if (!valid[dv][slot]) { if (hipEventCreateWithFlags(&ev[dv][slot], hipEventDisableTiming) == hipSuccess) valid[dv][slot] = true; }
-            else HIPCHK(hipStreamWaitEvent(ctx->stream, ev[dv][slot], 0));
-            KL(traceKernel, dim3(gridFor(np, traceBS)), dim3(traceBS), 0, ctx->stream, E);
-            if (valid[dv][slot]) HIPCHK(hipEventRecord(ev[dv][slot], ctx->stream));
-        } else
+        // (the tracebacks of the contexts one at a time, as the rows launches: 43.20 against 43.19 ms a step; in the rows launches' chain: 44.89 -- profiles/r05_trace_chain.txt, commit 8c679ac)
         KL(traceKernel, dim3(gridFor(np, traceBS)), dim3(traceBS), 0, ctx->stream, E);
         if (c + 1 == nRanges) hipEventRecord(ctx->ev[T_XTRACE][1], ctx->stream);
         TRACE("lanes: ext_trace");
