@@ -1331,7 +1331,7 @@ static int postfilterBody(ygpu_ctx *full);
 int ygpu_postfilter(ygpu_ctx *full)
 {
     if (!full || !full->stream) return YGPU_EINVAL;
-    if (!full->pfSnap.load()) { const int rc = ygpu_postfilter_snapshot(full); if (rc) return rc; }
+    if (!full->pfSnap.load()) { const int rc = ygpu_postfilter_snapshot(full); if (rc) { tlsPfFailed = nullptr; return rc; } }      // (the snapshot's message is the context's own)
     const int rc = postfilterBody(full);
     full->pfSnap.store(false);
     tlsPfFailed = rc ? full : nullptr;
