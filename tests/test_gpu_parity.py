@@ -535,11 +535,14 @@ def _synthetic_results(s, b, rng, max_clumps):
                                                    (7, 448, []), (8, 448, ["-FBS", "Y"]), (9, 224, ["-BP", "1", "-MGDP", "2"]), (10, 112, ["-MNO", "1", "-FBS", "Y", "-PSS", "0.99", "-PRL", "0.99"]),
                                                    (11, 30, ["-BP", "40", "-MGDP", "9", "-MS", "3", "-RC", "7"]), (12, 330, ["-MNO", "120"]),
                                                    (13, 1500, []), (14, 1792, ["-FBS", "Y"]), (15, 2100, ["-FBS", "Y", "-PSS", "0.5", "-PRL", "0.5"])])
-def test_postfilter_on_synthetic_clump_lists(work, index11, seed, max_clumps, extra):
+def test_postfilter_on_synthetic_clump_lists(work, index11, seed, max_clumps, extra, monkeypatch):
     """Device stage vs the host's copy of the same routine (oqc_core.h) on clump lists no real read produces; as above, the pin to the reference is the host
-    copy's (goldens, live reference) and the command line's with the device filter -- this test only shows that the two compilations agree where real reads do not go."""
+    copy's (goldens, live reference) and the command line's with the device filter -- this test only shows that the two compilations agree where real reads do not go.
+    Every third set with the reads' nodes and tables in HBM (YGPU_OQC_HBM=1): the instantiation of a read whose survivors do not fit its LDS."""
     import numpy as np
     rng = np.random.default_rng(seed)
+    if seed % 3 == 0:
+        monkeypatch.setenv("YGPU_OQC_HBM", "1")
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa"), "-osh", "stdout"] + list(extra)) as s:
         with ya.Context(s.index, s.params) as ctx:
             ctx.set_postfilter(s)

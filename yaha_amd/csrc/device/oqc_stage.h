@@ -14,6 +14,7 @@ struct OqcArgs {
     yoqc::SortKey *keys; int *stack; yoqc::CNode *nodes, *prim; yoqc::PAttr *pa; int *pfxOff, *path, *pool; yoqc::OutRec *push, *out;
     uint32_t *outCnt, *outOpsCnt; uint32_t *primCnt;
     int devMax;                        // reads with more clumps are left to the host (YQ_DEVICE_MAX; YGPU_OQC_MAX lowers it in tests)
+    int graphInHbm;                    // test hook (YGPU_OQC_HBM=1): every read's nodes and tables in HBM -- the path of a read whose survivors do not fit its LDS, which real batches hardly ever take
     unsigned long long *prof;          // YGPU_OQC_PROF=1: 100 MHz ticks per step of k_oqc_wave, summed over the reads and the largest of any read (keys, sort, duplicate scan, nodes + tables, walk along the path, successors, finish), per class
 };
 // What the routine costs on a GPU, measured: one read per lane with its work space in HBM took 75 ms a batch (a few thousand DEPENDENT accesses a read, microseconds
@@ -404,7 +405,7 @@ __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list
     }
     if (prof) tk[3] = wall_clock64();
     // nodes, table index and path take the keys' place when they fit (48 bytes a survivor: always, but for a read of the last class nearly all of whose clumps survive)
-    if (keysInLds && 48u * (unsigned)cnt <= mainBytes) oqcGraph<true>(A, P, X.S, sMain, mainBytes, b, r, n, cnt, qlen, lane, tk);
+    if (!A.graphInHbm && keysInLds && 48u * (unsigned)cnt <= mainBytes) oqcGraph<true>(A, P, X.S, sMain, mainBytes, b, r, n, cnt, qlen, lane, tk);
     else oqcGraph<false>(A, P, X.S, sMain, mainBytes, b, r, n, cnt, qlen, lane, tk);
 }
 // the printed clumps of read r, in print order, with their ops copied behind one another: out clump k of the read = fClumps[outStart[r] + k].  A wave per read, a lane

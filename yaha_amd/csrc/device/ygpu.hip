@@ -1359,6 +1359,7 @@ static int postfilterBody(ygpu_ctx *full)
     A.outCnt = full->oqOutCnt.as<uint32_t>(); A.outOpsCnt = full->oqOutOps.as<uint32_t>(); A.primCnt = full->oqPrimCnt.as<uint32_t>();
     A.keys = nullptr; A.stack = nullptr; A.nodes = nullptr; A.pfxOff = nullptr; A.path = nullptr; A.pool = nullptr; A.prof = nullptr;
     { const char *e = getenv("YGPU_OQC_MAX"); const int v = e ? atoi(e) : YQ_DEVICE_MAX; A.devMax = v >= 1 && v < YQ_DEVICE_MAX ? v : YQ_DEVICE_MAX; }     // (read at every call: tests lower it to send small reads down the hand-over path)
+    { const char *e = getenv("YGPU_OQC_HBM"); A.graphInHbm = e && atoi(e) ? 1 : 0; }      // (read at every call, as YGPU_OQC_MAX)
     static const bool oqProf = getenv("YGPU_OQC_PROF") != nullptr;
     if (oqProf) { ENSURE(full->oqProf, 8ull * 32 * YQ_NCLASS); HIPCHK(hipMemsetAsync(full->oqProf.p, 0, 8ull * 32 * YQ_NCLASS, ctx->stream)); A.prof = full->oqProf.as<unsigned long long>(); }
     uint32_t *lists = full->oqLists.as<uint32_t>();
