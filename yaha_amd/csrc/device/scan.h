@@ -18,7 +18,9 @@
 
 #define YD_SCAN_BS 512                       // two waves per SIMD, ~100 registers: fits beside a rows launch that shares the device (a 1 024-thread workgroup needs four waves on
                                              // every SIMD of one CU at once and found room on a third of the CUs only: 0.05 -> 0.61 ms a sum with four batches in flight)
+#ifndef YD_SCAN_IPT
 #define YD_SCAN_IPT 48                       // u32 elements a thread (192 bytes; u64: 24).  The tiles' look-back is a chain that advances 64 tiles a round trip: 50 ns a
+#endif
                                              // tile, measured (4 096-element tiles: 400 us for 32 M elements) -- so a tile is 96 KB
 #define YD_SCAN_TILE (YD_SCAN_BS * YD_SCAN_IPT)
 __host__ __device__ inline uint32_t scanTiles(uint64_t n, int elemBytes = 4) { const uint64_t tile = (uint64_t)YD_SCAN_TILE * 4u / (unsigned)elemBytes; return (uint32_t)((n + tile - 1) / tile); }
