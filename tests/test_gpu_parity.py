@@ -206,7 +206,7 @@ def test_trace_memory_chunks(work, index11, meta, budget, monkeypatch):
         assert mine == golden_lines(name), "chunked trace path differs from the reference on " + name
 
 
-@pytest.mark.parametrize("mode", [("2", "16384"), ("2", "700"), ("2", "3000"), ("2", "64")])
+@pytest.mark.parametrize("mode", [("2", "16384"), ("2", "700"), ("2", "3000"), ("2", "64"), ("2", "16384", "0")])
 def test_hit_sort_paths(work, index11, meta, mode, monkeypatch):
     # A2's sort: one workgroup per (read, strand) in size classes; segments above YGPU_SEGSORT_MAX hits are cut by diagonal, and a piece that still does not fit is cut
     # again over its own range of diagonals until it fits or holds one diagonal -- the limit is lowered here so that the 10 kbp reads' segments take every class, the
@@ -214,6 +214,8 @@ def test_hit_sort_paths(work, index11, meta, mode, monkeypatch):
     monkeypatch.setenv("YGPU_SEG_SORT", mode[0])
     if mode[1]:
         monkeypatch.setenv("YGPU_SEGSORT_MAX", mode[1])
+    if len(mode) > 2:
+        monkeypatch.setenv("YGPU_SORT_WIDE", mode[2])         # 0: the four largest classes in their 1 024-thread shapes (the default since round 5: 512 threads, twice the hits a thread)
     for name in ("r10k_default", "r1k_default"):
         run = meta["runs"][name]
         mine = device_pipeline(index11, os.path.join(work, run["reads"]), run["oflag"], run["extra"], batch=400)
