@@ -2,7 +2,7 @@
 //
 // The join of A2 (findFragmentsSort, QueryMatch.c:52-121 with the heap of QueryHeap.inl:70-134) is the multiset of hits in ascending
 // (diagonal, query offset) order.  k_expand_hits (seed.h) writes the hits of one (read, strand) -- one segment, a few thousand 64-bit keys --
-// in ascending query offset, so a STABLE sort on the 32 diagonal bits [15, 47) of the key finishes the job.  A segment of up to 16 384 keys
+// in ascending query offset, so a STABLE sort on the 32 diagonal bits [15, 47) of the key finishes the job.  A segment of up to 15 872 keys
 // fits in a workgroup's registers and LDS: one read and one write of HBM per key instead of the library's digit passes over global memory.
 // Longer segments (repeat-rich reads) are first cut by diagonal into buckets that fit (k_seg_split); a bucket that still does not fit is cut again by its OWN range of
 // diagonals (k_seg_split_range), level by level, until every piece fits or holds a single diagonal (then it is in order as it stands: the cuts are stable).
@@ -11,7 +11,10 @@
 #include <rocprim/block/block_radix_sort.hpp>
 #include <cstdint>
 
-#define YD_SEGSORT_MAX 16384u
+#ifndef YD_SORT_TOP
+#define YD_SORT_TOP 31                 // hits a thread of the largest class (512 threads)
+#endif
+#define YD_SEGSORT_MAX (512u * YD_SORT_TOP)            // 512 threads x 31 hits: the largest shape that finds room on a CU beside one workgroup of a rows launch (173 registers; x 32: 177, eight too many)
 
 template <unsigned BS, unsigned IPT>
 __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
@@ -76,7 +79,7 @@ __global__ void __launch_bounds__(256) k_seg_classify(const uint32_t *segB, cons
     }
 }
 
-// A long segment (more than 16 384 hits: 44 % of the hits of a repeat-rich batch) is cut by DIAGONAL into up to 16 buckets that fit the workgroup sort: one
+// A long segment (more than 15 872 hits: 44 % of the hits of a repeat-rich batch) is cut by DIAGONAL into up to 16 buckets that fit the workgroup sort: one
 // stable counting pass by a workgroup per segment -- thread t owns a contiguous run of the segment's hits (count per bucket, exclusive scan over (bucket,
 // thread), scatter in order) -- instead of the library's four digit passes.  Bucket = the diagonal's top bits (monotone, so sorting the buckets one by one
 // sorts the segment); sub-segment sb * 16 + k = bucket k of the sb-th long segment.  A bucket that still exceeds the workgroup sort is cut again (k_seg_split_range).

@@ -225,24 +225,24 @@ static int stageSeed(ygpu_ctx *ctx)
             ENSURE(ctx->segOff, 4ull * (2 * n + 2));
             KL(k_seg_offsets, dim3(gridFor(2 * n + 1, 256)), dim3(256), 0, ctx->stream, ctx->dKmerOff.as<uint32_t>(), ctx->hitOff.as<uint32_t>(), 2 * n, ctx->segOff.as<uint32_t>());
             {
-                // segments of up to 16 384 hits: one workgroup each (segsort.h), in twelve size classes, one launch per class over exactly its segments
+                // segments of up to 15 872 hits: one workgroup each (segsort.h), in twelve size classes, one launch per class over exactly its segments
                 const unsigned long long *in = ctx->keysA.as<unsigned long long>(); unsigned long long *out = ctx->keysB.as<unsigned long long>(); const uint32_t *so = ctx->segOff.as<uint32_t>();
                 ENSURE(ctx->segLists, 4ull * (YD_SEG_NCLASS + 1) * (2 * n + 1));
                 uint32_t *segCnt = ctx->counters.as<uint32_t>() + CNT_SEGC;
                 const uint32_t mx = ctx->segSortMax;                                  // YD_SEGSORT_MAX; lower only to drive the long-segment path in tests
-                // threads x hits a thread: 128 x 8, 128 x 16, 256 x 12 / 16, 512 x 10 / 12 / 14 / 16 and, for the four largest classes, 512 x 20 / 24 / 28 / 32 (384 and 768
+                // threads x hits a thread: 128 x 8, 128 x 16, 256 x 12 / 16, 512 x 10 / 12 / 14 / 16 and, for the four largest classes, 512 x 20 / 24 / 28 / 31 (384 and 768
                 // threads x 16 sorted slower than the next shape up).  The largest classes had 1 024-thread workgroups (x 10 / 12 / 14 / 16): four waves a SIMD with 72-112
                 // registers each, which beside a rows launch -- one or two waves of 152 registers on every SIMD of the device while it runs -- found room on the CUs with one
                 // rows workgroup (x 10, x 12) or NOWHERE (x 14, x 16: their launch, first in the stream, then waited for the rows launch to end -- 0.36 ms alone, 4.7 ms in
-                // the four-context run, and every smaller class behind it).  512 threads x twice the hits: two waves a SIMD of 136-184 registers, room beside one rows
-                // workgroup for all but the last; the same speed alone, 0.3-0.5 ms a step with four contexts (profiles/r05_sort_shapes.txt).  YGPU_SORT_WIDE=0: the old shapes.
-                static const uint32_t kShape[YD_SEG_NCLASS] = {1024u, 2048u, 3072u, 4096u, 5120u, 6144u, 7168u, 8192u, 10240u, 12288u, 14336u, 16384u};
+                // the four-context run, and every smaller class behind it).  512 threads x twice the hits: two waves a SIMD of 136-176 registers, room beside one rows
+                // workgroup for all four (x 32 would need 177 registers, eight a SIMD too many: hence 15 872 hits as the limit of a single workgroup's sort); the same speed alone, 0.3-0.5 ms a step with four contexts (profiles/r05_sort_shapes.txt).  YGPU_SORT_WIDE=0: the old shapes.
+                static const uint32_t kShape[YD_SEG_NCLASS] = {1024u, 2048u, 3072u, 4096u, 5120u, 6144u, 7168u, 8192u, 10240u, 12288u, 14336u, YD_SEGSORT_MAX};
                 SegClassHi HI; for (int c = 0; c < YD_SEG_NCLASS; c++) HI.hi[c] = std::min(mx, kShape[c]);
                 // one launch per class over exactly its segments: in[inB..inE) sorted into out[inB..)
                 auto sortClasses = [&](const unsigned long long *src, unsigned long long *dst, const uint32_t *sB, const uint32_t *sE, uint32_t nSeg, const uint32_t *lists, const uint32_t *nc) -> int {
 #define YD_SORT_CLASS(c, BS, IPT) if (nc[c]) KL((k_seg_sort<BS, IPT>), dim3(nc[c]), dim3(BS), 0, ctx->stream, src, dst, sB, sE, lists + (size_t)(c) * nSeg)
                     const char *ws = getenv("YGPU_SORT_WIDE"); const int wideShapes = ws ? atoi(ws) : 1;      // (read at every call: the tests run both)
-                    if (wideShapes) { YD_SORT_CLASS(11, 512, 32); YD_SORT_CLASS(10, 512, 28); YD_SORT_CLASS(9, 512, 24); YD_SORT_CLASS(8, 512, 20); }
+                    if (wideShapes) { YD_SORT_CLASS(11, 512, YD_SORT_TOP); YD_SORT_CLASS(10, 512, 28); YD_SORT_CLASS(9, 512, 24); YD_SORT_CLASS(8, 512, 20); }
                     else { YD_SORT_CLASS(11, 1024, 16); YD_SORT_CLASS(10, 1024, 14); YD_SORT_CLASS(9, 1024, 12); YD_SORT_CLASS(8, 1024, 10); }
                     YD_SORT_CLASS(7, 512, 16);
                     YD_SORT_CLASS(6, 512, 14); YD_SORT_CLASS(5, 512, 12); YD_SORT_CLASS(4, 512, 10);
