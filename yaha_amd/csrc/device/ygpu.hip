@@ -1206,6 +1206,9 @@ static int uploadBatch(ygpu_ctx *ctx, const ygpu_read_batch *b, bool wait)
     }
     ctx->hKmerOff[2 * n] = k; ctx->nKmers = k; ctx->totalBases = n ? b->offsets[n] - base0 : 0;
     if (ctx->totalBases > 0x7FFFFFF0ull) { ctx->err = "batch larger than 2 Gbases"; return YGPU_EINVAL; }
+    // (a snapshot taken without a wait may still be reading the previous batch's codes and offsets on this stream: before any of these buffers is replaced by a
+    // larger one, the stream is drained -- hipFree waits for the device by itself, this does not rely on it)
+    if (ctx->dFwd.cap < ctx->totalBases + 256 || ctx->dReadOff.cap < 4ull * (n + 2)) HIPCHK(streamSync(ctx));
     ENSURE(ctx->dFwd, ctx->totalBases + 256); ENSURE(ctx->dRev, ctx->totalBases + 256); ENSURE(ctx->dFwd4, ctx->totalBases / 2 + 256); ENSURE(ctx->dRev4, ctx->totalBases / 2 + 256);   /* slack: lane kernels read whole dwords around a segment */ ENSURE(ctx->dReadOff, 4ull * (n + 1)); ENSURE(ctx->dKmerOff, 4ull * (2 * n + 1));
     if (n) {
         HIPCHK(hipMemcpyAsync(ctx->dFwd.p, b->codes + base0, ctx->totalBases, hipMemcpyHostToDevice, ctx->stream));
