@@ -61,6 +61,16 @@ __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) 
 #ifndef YD_ROWS_LDSWIN
 #define YD_ROWS_LDSWIN 0
 #endif
+// YD_ROWS_RESBATCH (round 6): a finished problem's result -- the column of its maximum looked up in the kept strip (55 instructions), 32 bytes stored -- used to
+// be written in the pass after the problem ended: with 64 lanes and ~110 rows a problem some lane has one pending in 43 % of the passes, and the whole wave walks
+// through the block every time.  The lane is idle until the next refill anyway (its state stays its own), so the results now wait for each other: they are written
+// when YD_REFILL_MIN lanes hold one (or nothing runs any more), and a lane is not refilled before its result is out.  0: the pass after the end (rounds 2-5).
+#ifndef YD_ROWS_RESBATCH
+#define YD_ROWS_RESBATCH 1
+#endif
+#ifdef YD_PROF
+__device__ unsigned long long gRowsProf[8];      // passes, passes that wrote results, refill rounds, passes with a new maximum, busy lane-passes, flushes, pool loads
+#endif
 #ifndef YD_ROWS_WAVES
 #define YD_ROWS_WAVES 3                        // waves per SIMD of k_ext_rows_pk (a build switch for experiments: make variant VARIANT_FLAGS=-DYD_ROWS_WAVES=2)
 #endif
@@ -110,12 +120,15 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
     bool insQ = false, insR = false;                                         // wave-uniform: the previous pass ran the query / reference refill
     YD_GLOBAL const uint8_t *q4 = toGlobal(A.fwd4);                          // the strand's PACKED codes (two to the byte, as the reference: k_pack4): entry idx of the extension = nibble qPos +- idx
     unsigned calls = 0, rows = 0, cells = 0;
+#ifdef YD_PROF
+    unsigned pfPass = 0, pfRes = 0, pfRefill = 0, pfSnap = 0, pfBusy = 0, pfFlush = 0, pfPool = 0;      // (wave-uniform)
+#endif
 #pragma unroll
     for (int k = 0; k < YD_NP; k++) { PV[k] = LWg; PF[k] = LWp; rc[k] = 0x7FFF7FFFu; }      // (PV holds Vg = V - GOE throughout)
 
     int poolCount = 0, poolNext = 0; bool exhausted = false;
     uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0, eQwLo = 0, eQwHi = 0, eRwLo = 0, eRwHi = 0;      // eMisc: flags | first query code << 8 | buffered entries (query | reference << 8) << 16
-    bool pendFlush = false; int pendRes = -1; unsigned pStart = 0;      // pendRes: the problem whose result this lane stores in its next pass (its state stays untouched until then)
+    bool pendFlush = false; int pendRes = -1, rowsFin = 0; unsigned pStart = 0;      // pendRes: the problem whose result this lane has yet to store (its state stays untouched until then); rowsFin: its last row
     int wslot = 0; unsigned flush = 0; bool dirty = false, justDone = false;
     YD_GLOBAL uint32_t *chunkPtr = toGlobal(A.trace); bool noMem = false;
     auto takeChunk = [&]() {                                                 // wave-uniform: the chunk of flushes [flush, flush + 16)
@@ -146,6 +159,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
     auto nextFlush = [&]() { flush++; if (flush % YD_CHUNK_FLUSHES == 0u) takeChunk(); };     // wave-uniform
     bool firstFill = true;
     for (;;) {
+        // (Round 6, measured and dropped: every wave-uniform condition of this loop through UNI_B and every uniform counter through uni().  Left to itself the compiler
+        // takes the loop's exits for lane-dependent -- an EXEC-masked loop, the uniform state in vector registers, twenty moves and thirty mask instructions a pass --
+        // but the scalar version waits for a v_readfirstlane before every branch: 14.42 -> 15.84 ms a launch, profiles/r06_rows_kernel_passes.txt.)
         if (noMem) break;
         // What the previous iteration loaded is consumed HERE, before this iteration issues any store (the memory counter is in-order: a wait for these loads
         // further down would also wait for the stores issued in between).  Slide the reference window: pair k takes pair k+1; pair 10's low half takes what
@@ -186,9 +202,12 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
         if (wslot == 0) { flushNow = __ballot(pendFlush); pendFlush = false; if (flushNow != 0ull) { flushSlot = chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u; nextFlush(); } }
         // ---- refill (k_ext_rows') ----
         for (;;) {
-            const unsigned long long need = __ballot(p < 0 && !done && !justDone);
+            const unsigned long long need = __ballot(p < 0 && !done && !justDone && (!YD_ROWS_RESBATCH || pendRes < 0));
             if (!need) break;
             if (__builtin_popcountll(need) < YD_REFILL_MIN && __ballot(p >= 0) != 0ull && !firstFill) break;
+#ifdef YD_PROF
+            pfRefill++; if (poolNext >= poolCount) pfPool++;
+#endif
             if (poolNext >= poolCount) {
                 unsigned base = 0;
                 if (!exhausted) { if (lane == 0) base = atomicAdd(A.queue, 64u); base = uniU(base); if (base >= A.nProb) exhausted = true; }
@@ -256,7 +275,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
             }
             const int nNeed = __builtin_popcountll(need), avail = poolCount - poolNext;
             const int e = poolNext + __builtin_popcountll(need & lanesBelow);
-            const bool take = (p < 0 && !done && !justDone) && e < poolCount;
+            const bool take = (p < 0 && !done && !justDone && (!YD_ROWS_RESBATCH || pendRes < 0)) && e < poolCount;
             const int src = take ? e : lane;
             const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
             const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64);
@@ -331,10 +350,19 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
 #endif
         }
         // the iteration's stores, behind its loads: a finished problem's result and the blocks that leave
-        if (pendRes >= 0) {
-            // the problem ended in the previous pass at row i - 2 (i has been stepped since; the lane sat out the refill above, so maxScore / maxi / maxj / pStart
+#if YD_ROWS_RESBATCH
+        // (wave-uniform: the results wait until as many lanes are idle as a refill asks for -- the pass before that refill -- or nothing runs any more)
+        const bool resNow = __ballot(pendRes >= 0) != 0ull && (__builtin_popcountll(__ballot(p < 0 && !done)) >= YD_REFILL_MIN || __ballot(p >= 0) == 0ull);
+#else
+        const bool resNow = true;
+#endif
+#ifdef YD_PROF
+        pfPass++; if (resNow && __ballot(pendRes >= 0) != 0ull) pfRes++; if (flushNow != 0ull) pfFlush++;
+#endif
+        if (resNow && pendRes >= 0) {
+            // the problem ended in an earlier pass at row rowsFin (the lane sat out every refill since, so maxScore / maxi / maxj / pStart
             // are still its own).  Work of the call: row r has 21 - max(11 - r, 0) real cells.
-            const unsigned rowF = (unsigned)(i - 2), m = rowF < (unsigned)leftR ? rowF : (unsigned)leftR, nCells = __umul24((unsigned)YD_LW, rowF) - (__umul24((unsigned)(leftR + 1), m) - __umul24(m, m + 1u) / 2u);
+            const unsigned rowF = YD_ROWS_RESBATCH ? (unsigned)rowsFin : (unsigned)(i - 2), m = rowF < (unsigned)leftR ? rowF : (unsigned)leftR, nCells = __umul24((unsigned)YD_LW, rowF) - (__umul24((unsigned)(leftR + 1), m) - __umul24(m, m + 1u) / 2u);
             rows += rowF; cells += nCells;
             int maxj = 0;                                                     // the first column of the kept strip's half that holds the maximum
 #pragma unroll
@@ -408,7 +436,10 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
         justDone = fin;                                                      // the next record slot stays empty behind a finished problem (its traceback's spare record)
         // A finished lane keeps its state: the result is stored from it in the next pass; its byte streams stay inside the finished extension (clamped index,
         // rLeft <= 0), so an idle lane's loads are harmless.
-        if (fin) { pendRes = p; p = -1; }
+        if (fin) { pendRes = p; p = -1; rowsFin = row; }
+#ifdef YD_PROF
+        if (__ballot(snap) != 0ull) pfSnap++; pfBusy += (unsigned)__builtin_popcountll(__ballot(busy));
+#endif
     }
     if (wslot != 0 && dirty) pendFlush = true;
     { const unsigned long long f = __ballot(pendFlush); if (!noMem && f != 0ull) { flushBlocks(f, chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u); nextFlush(); } }
@@ -418,6 +449,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
     unsigned long long cc = cells;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { cc += (unsigned long long)__shfl_xor((long long)cc, d, 64); }
+#ifdef YD_PROF
+    if (lane == 0 && !SECOND) { const unsigned v[7] = {pfPass, pfRes, pfRefill, pfSnap, pfBusy, pfFlush, pfPool}; for (int k = 0; k < 7; k++) atomicAdd(&gRowsProf[k], (unsigned long long)v[k]); }
+#endif
     if (lane == 0 && !SECOND && A.ctr) {
         unsigned long long *c = A.ctr->v;
         atomicAdd(&c[C_EXT_CALLS], (unsigned long long)c0); atomicAdd(&c[C_EXT_ROWS], (unsigned long long)c1); atomicAdd(&c[C_EXT_CELLS], cc);

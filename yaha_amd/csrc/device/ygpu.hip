@@ -791,7 +791,7 @@ static int stageAlign(ygpu_ctx *ctx)
             A.outCounts = cnt + CNT_OUTCLUMPS; A.outClumpCap = outClumpCap; A.outOpsCap = outOpsCap; A.rootPushCount = ctx->rootPush.as<unsigned int>();
             A.ctr = ctx->ctr.as<DevCounters>(); A.errFlag = ctx->errFlag.as<int>();
 #ifdef YD_PROF
-            { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); }
+            { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); hipMemcpyToSymbol(HIP_SYMBOL(gRowsProf), z, sizeof(unsigned long long) * 8); }
 #endif
             bool laneOverflow = false, traceOverflow = false; ctx->hOutValid = false;
             if (!useLanes) KL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
@@ -799,7 +799,10 @@ static int stageAlign(ygpu_ctx *ctx)
 #ifdef YD_PROF
             { streamSync(ctx); unsigned long long z[16]; hipMemcpyFromSymbol(z, HIP_SYMBOL(gProf), sizeof z);
               const char *nm[10] = {"root_total", "dp_rows", "traceback", "perfect_ext", "score", "emit", "split", "merge", "dp_calls", "roots"};
-              fprintf(stderr, "[YD_PROF] waves %u:", waves); for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", nm[i], z[i]); fprintf(stderr, "\n"); }
+              fprintf(stderr, "[YD_PROF] waves %u:", waves); for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", nm[i], z[i]); fprintf(stderr, "\n");
+              unsigned long long q[8]; hipMemcpyFromSymbol(q, HIP_SYMBOL(gRowsProf), sizeof q);      // k_ext_rows_pk: where its passes go
+              if (q[0]) fprintf(stderr, "[YD_PROF] k_ext_rows_pk: wave passes %llu; of them writing results %.1f %%, with a new maximum in some lane %.1f %%, handing blocks over %.1f %%; refill rounds %.3f a pass (pool loads %.4f); busy lanes %.1f of 64\n",
+                                q[0], 100.0 * q[1] / q[0], 100.0 * q[3] / q[0], 100.0 * q[5] / q[0], (double)q[2] / q[0], (double)q[6] / q[0], (double)q[4] / q[0]); }
 #endif
             uint32_t got[2] = {0, 0}, ef = 0;
             if (laneOverflow || traceOverflow) ef = YERR_OUT;
