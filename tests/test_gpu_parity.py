@@ -308,7 +308,7 @@ def test_live_reference_binary_on_fresh_human_like_reads(work, tmp_path):
 
 
 # -G / -MD far beyond the goldens: gap fills whose strip is hundreds of columns wide and rows x columns exceeds the extension strip's footprint -- the wave
-# kernels' generic path with its scratch sized from the parameters (ygpu.hip alignDims).  The reference itself behaves oddly out there (16-bit fields
+# kernels' generic path with its scratch sized from the parameters (stage_align.hip alignDims).  The reference itself behaves oddly out there (16-bit fields
 # overflow); the oracle reproduces it (CPU tier: test_large_gap_parameters_match_the_live_reference) and the device has to as well.
 @pytest.mark.parametrize("extra,max_del,junk,flank", [(["-G", "1300"], 1250, 0, 3200), (["-G", "1300", "-GEC", "1", "-GOC", "2"], 1250, 0, 2000), (["-G", "450", "-MD", "200"], 420, 150, 1500),
                                                       (["-G", "3000", "-MD", "400", "-BW", "8"], 2900, 300, 3500)])

@@ -1,7 +1,7 @@
 // nodevice_stubs.cpp -- DIAGNOSTIC BUILD ONLY (make -C yaha_amd/csrc asan): the device entry points of include/yaha_hip.h answered with YGPU_ENODEV, so that
 // the HOST stages (reader, .nib2 / index formats, argument handling, OQC/FBS, SAM text, pipeline) can be linked without HIP and run under
 // AddressSanitizer / UndefinedBehaviorSanitizer on the CPU (GPU sanitizers are not available on the pool).  Never part of the
-// product: libyaha_hip.so is built from device/ygpu.hip and has no such stubs.
+// product: libyaha_hip.so is built from device/*.hip and has no such stubs.
 #include "../../yaha_amd/csrc/host/yaha_host.h"
 extern "C" {
 int  ygpu_init(int, const ygpu_index_view *, const ygpu_params *, ygpu_ctx **out) { if (out) *out = nullptr; return YGPU_ENODEV; }

@@ -33,7 +33,7 @@ struct AlignArgs {
 
 // layout of one wave's scratch
 struct WaveMem { uint16_t *trace; uint32_t *tmpOps; int *gen; uint32_t *arena; Frame *frames; };
-// traceRows: rows of 64 trace cells (>= maxQ + 2; more when -G / -MD allow gap fills whose strip does not fit that, see alignDims in ygpu.hip)
+// traceRows: rows of 64 trace cells (>= maxQ + 2; more when -G / -MD allow gap fills whose strip does not fit that, see alignDims in stage_align.hip)
 __host__ __device__ inline size_t alignScratchBytes(int maxQ, int traceRows, int listCap, int genCap)
 {
     size_t b = 0;
@@ -226,7 +226,8 @@ struct Aligner {
             uint32_t bl = (uint32_t)f.sqo < f.sro ? (uint32_t)f.sqo : f.sro; backLen = (int)bl;
             if (backLen > 0) {
                 int m = perfectBack(A.bases, q, f.sqo - 1, f.sro - 1u, backLen); perfect += m; touched += m + (m < backLen);
-                if (m > 0) { b[f.start] = opMake(opCode(b[f.start]), (opLen(b[f.start]) + m) & 0xFFFF); score += m * P.MS; backLen -= m; f.sqo -= m; f.sro -= (uint32_t)m; f.refLen = (f.refLen + m) & 0xFFFF; }
+                if (m > 0) { b[f.start] = opMake(opCode(b[f.start]), (opLen(b[f.start]) + m) & 0xFFFF); score += m * P.MS; backLen -= m; f.sqo -= m; f.sro -= (uint32_t)m;
+                    f.refLen = (f.refLen + m) & 0xFFFF; }
             }
         }
         if (goForw) {
@@ -234,7 +235,8 @@ struct Aligner {
             forwLen = (int)(ql < rl ? ql : rl);
             if (forwLen > 0) {
                 int m = perfectFwd(A.bases, q, f.eqo + 1, ero(f.sro, f.refLen) + 1u, forwLen); perfect += m; touched += m + (m < forwLen);
-                if (m > 0) { int li = f.start + f.len - 1; b[li] = opMake(opCode(b[li]), (opLen(b[li]) + m) & 0xFFFF); score += m * P.MS; forwLen -= m; f.eqo += m; f.refLen = (f.refLen + m) & 0xFFFF; }
+                if (m > 0) { int li = f.start + f.len - 1; b[li] = opMake(opCode(b[li]), (opLen(b[li]) + m) & 0xFFFF); score += m * P.MS; forwLen -= m; f.eqo += m;
+                    f.refLen = (f.refLen + m) & 0xFFFF; }
             }
         }
         f.score = score; backLen = uni(backLen); forwLen = uni(forwLen);
@@ -246,13 +248,15 @@ struct Aligner {
         if (goBack && backLen >= P.minExtLength) {
             int ns;
             if (carefully) ns = backCarefully(f, b, f.sro - 1u, (f.sqo - 1) & 0xFFFF, backLen & 0xFFFF, score, aQ, aR);
-            else { DPOut o = runDP(YGPU_DP_EXT_REV, f.sro - 1u, 0, (f.sqo - 1) & 0xFFFF, backLen & 0xFFFF); ns = o.score; aQ = o.addedQ; aR = o.addedR; if (ns > 0) mergeFront(b, f.start, f.len, o, true, 0, o.nOps); }
+            else { DPOut o = runDP(YGPU_DP_EXT_REV, f.sro - 1u, 0, (f.sqo - 1) & 0xFFFF, backLen & 0xFFFF); ns = o.score; aQ = o.addedQ; aR = o.addedR;
+                if (ns > 0) mergeFront(b, f.start, f.len, o, true, 0, o.nOps); }
             if (ns > 0) { score += ns; f.sqo = (f.sqo - aQ) & 0xFFFF; f.sro -= (uint32_t)aR; f.refLen = (f.refLen + aR) & 0xFFFF; }
         }
         if (goForw && forwLen >= P.minExtLength) {
             int ns;
             if (carefully) ns = fwdCarefully(f, b, ero(f.sro, f.refLen) + 1u, (f.eqo + 1) & 0xFFFF, forwLen & 0xFFFF, score, aQ, aR);
-            else { DPOut o = runDP(YGPU_DP_EXT_FWD, ero(f.sro, f.refLen) + 1u, 0, (f.eqo + 1) & 0xFFFF, forwLen & 0xFFFF); ns = o.score; aQ = o.addedQ; aR = o.addedR; if (ns > 0) mergeBack(b, f.start, f.len, o, false, 0, o.nOps); }
+            else { DPOut o = runDP(YGPU_DP_EXT_FWD, ero(f.sro, f.refLen) + 1u, 0, (f.eqo + 1) & 0xFFFF, forwLen & 0xFFFF); ns = o.score; aQ = o.addedQ; aR = o.addedR;
+                if (ns > 0) mergeBack(b, f.start, f.len, o, false, 0, o.nOps); }
             if (ns > 0) { score += ns; f.eqo = (f.eqo + aQ) & 0xFFFF; f.refLen = (f.refLen + aR) & 0xFFFF; }
         }
         f.score = score;
@@ -353,8 +357,10 @@ struct Aligner {
         const char codes[4] = {'M', 'R', 'D', 'I'};
         for (int k = lane; k < f.len; k += 64) { uint32_t op = b[f.start + k]; A.outOps[oi + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
         if (lane == 0) {
-            ygpu_clump c; c.sro = f.sro; c.sqo = (uint16_t)f.sqo; c.eqo = (uint16_t)f.eqo; c.refLen = (uint16_t)f.refLen; c.totScore = (uint16_t)totScore; c.totLength = (uint16_t)totLen;
-            c.matchedBases = (uint16_t)matches; c.mismatchedBases = (uint16_t)mism; c.gapBases = (uint16_t)gap; c.status = (uint8_t)f.status; c.reserved = 0; c.op_start = oi; c.n_ops = (uint32_t)f.len;
+            ygpu_clump c; c.sro = f.sro; c.sqo = (uint16_t)f.sqo; c.eqo = (uint16_t)f.eqo; c.refLen = (uint16_t)f.refLen; c.totScore = (uint16_t)totScore;
+                c.totLength = (uint16_t)totLen;
+            c.matchedBases = (uint16_t)matches; c.mismatchedBases = (uint16_t)mism; c.gapBases = (uint16_t)gap; c.status = (uint8_t)f.status; c.reserved = 0; c.op_start = oi;
+                c.n_ops = (uint32_t)f.len;
             A.outClumps[ci] = c; A.outRoot[ci] = rootRank; A.outPush[ci] = pushes;
         }
         pushes++; scored++; opsOut += (unsigned)f.len;
@@ -406,7 +412,8 @@ struct Aligner {
                         if (code == OP_M) { matches += len; ns = P.MS * len; } else if (code == OP_R) { mism += len; ns = -(P.RC * len); }
                         else if (code == OP_I) { ins += len; ns = -(P.GO + P.GE * len); } else { del += len; ns = -(P.GO + P.GE * len); }
                         AGS += ns; if (AGS < 0) AGS = 0;
-                        if (AGS > maxAGS) { maxAGS = AGS; maxItem = base + k; eQO = (f.sqo + matches + mism + ins - 1) & 0xFFFF; eRO = f.sro + (uint32_t)(matches + mism + del) - 1u; }
+                        if (AGS > maxAGS) { maxAGS = AGS; maxItem = base + k; eQO = (f.sqo + matches + mism + ins - 1) & 0xFFFF;
+                            eRO = f.sro + (uint32_t)(matches + mism + del) - 1u; }
                     }
                 }
                 AGS = maxAGS; matches = mism = ins = del = 0; int maxMatch = 0;
@@ -426,7 +433,8 @@ struct Aligner {
                         if (A.front + minItem > A.listCap) { err = YERR_ARENA; break; }
                         for (int k = lane; k < minItem; k += 64) cb[A.front + k] = b[f.start + k];
                         __threadfence_block();
-                        Frame c; c.status = f.status & stReversed; c.sqo = f.cSqo; c.eqo = (sQO - 1) & 0xFFFF; c.sro = f.cSro; c.refLen = (int)((1u + (sRO - 1u) - f.cSro) & 0xFFFFu);
+                        Frame c; c.status = f.status & stReversed; c.sqo = f.cSqo; c.eqo = (sQO - 1) & 0xFFFF; c.sro = f.cSro;
+                            c.refLen = (int)((1u + (sRO - 1u) - f.cSro) & 0xFFFFu);
                         c.score = 0; c.wS = f.wS; c.wE = f.wE; c.start = A.front; c.len = minItem; c.phase = PH_NONE;
                         f.phase = PH_AFTER_HEAD; M.frames[depth] = f; depth++; f = c; state = ST_SPLIT_ENTER; continue;
                     }
@@ -480,61 +488,3 @@ struct Aligner {
         atomicAdd(&c[C_SPLITS], (unsigned long long)splits); atomicAdd(&c[C_SCORED], (unsigned long long)scored);
     }
 };
-
-// Persistent waves pull root clumps from a queue (one 64-thread workgroup = one wavefront).
-__global__ void __launch_bounds__(64) k_align(AlignArgs A)
-{
-    YD_HIGH_PRIO();
-    const unsigned wave = blockIdx.x;
-    WaveMem M = carveScratch(A.scratch + (size_t)wave * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
-    __shared__ uint16_t sTrace[YD_LDS_CELLS];
-    Aligner al(A, M, sTrace);
-    PROF_INIT();
-    const unsigned nRoots = uniU(A.nRoots);
-    for (;;) {
-        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }     // a lane left the wave-uniform flow: fail loudly
-        unsigned t = 0;
-        if (laneId() == 0) t = atomicAdd(A.queueHead, 1u);
-        const unsigned r = uniU(t);
-        if (r >= nRoots) break;
-        { PROF_T0(); al.processRoot(r); PROF_ADD(PF_ROOT); PROF_CNT(PF_ROOTS); }
-        if (laneId() == 0) A.rootPushCount[r] = al.pushes;
-        if (UNI_B(al.err != 0)) { if (laneId() == 0) atomicCAS(A.errFlag, 0, al.err); break; }
-    }
-    al.flushCounters();
-    PROF_FLUSH();
-}
-
-// ---- stage-level test entry: a batch of independent DP calls (ygpu_dp_batch) -------------------------------------------
-struct DPBatchArgs {
-    DevParams P; const uint8_t *bases; DevBatch B; const ygpu_dp_problem *probs; uint32_t n; unsigned int *queueHead;
-    uint8_t *scratch; size_t scratchPerWave; int maxQ, listCap, genCap, traceRows;
-    ygpu_dp_result *res; uint32_t *ops; unsigned int *opsCount; uint32_t opsCap; int *errFlag;
-};
-__global__ void __launch_bounds__(64) k_dp_batch(DPBatchArgs A)
-{
-    YD_HIGH_PRIO();
-    const int lane = laneId();
-    WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
-    __shared__ uint16_t sTrace[YD_LDS_CELLS];
-    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.traceRows; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
-    const unsigned nProb = uniU(A.n);
-    for (;;) {
-        if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
-        unsigned t = 0; if (lane == 0) t = atomicAdd(A.queueHead, 1u);
-        const unsigned r = uniU(t);
-        if (r >= nProb) break;
-        const ygpu_dp_problem p = A.probs[r];
-        YDBG("k_dp_batch r %u mode %d\n", r, (int)p.mode);
-        const uint32_t r0 = A.B.readOff[p.read]; const uint8_t *q = (p.strand ? A.B.rev : A.B.fwd) + r0;
-        DPOut o = dpWave(A.P, A.bases, q, p.mode, p.rOff, p.rLen, p.qOff, p.qLen, S);
-        YDBG("dp done score %d nOps %d err %d\n", o.score, o.nOps, err);
-        if (UNI_B(err != 0)) { if (lane == 0) atomicCAS(A.errFlag, 0, err); break; }
-        const bool rev = p.mode == YGPU_DP_EXT_REV; unsigned oi = 0; const int n = uni(o.score != 0 || p.mode < YGPU_DP_EXT_FWD ? o.nOps : 0);
-        if (lane == 0) oi = atomicAdd(A.opsCount, (unsigned)n); oi = uniU(oi);
-        if (UNI_B(oi + (unsigned)n > A.opsCap)) { if (lane == 0) atomicCAS(A.errFlag, 0, (int)YERR_OUT); break; }
-        const char codes[4] = {'M', 'R', 'D', 'I'};
-        for (int k = lane; k < n; k += 64) { uint32_t op = dpOp(S, o, rev, k); A.ops[oi + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
-        if (lane == 0) { ygpu_dp_result rr; rr.score = o.score; rr.addedQLen = (uint16_t)o.addedQ; rr.addedRLen = (uint16_t)o.addedR; rr.op_start = oi; rr.n_ops = (uint32_t)n; A.res[r] = rr; }
-    }
-}

@@ -25,7 +25,8 @@ __device__ inline ChainMem carveChain(uint8_t *p, int maxN)
     m.key = (unsigned long long *)p; p += N * 8;
     m.L = (DevFrag *)p; p += N * 16;
     m.fidx = (uint32_t *)p; p += N * 4; m.sidx = (uint32_t *)p; p += N * 4; m.diag = (uint32_t *)p; p += N * 4;
-    m.sqo = (int *)p; p += N * 4; m.eqo = (int *)p; p += N * 4; m.len = (int *)p; p += N * 4; m.best = (int *)p; p += N * 4; m.prev = (int *)p; p += N * 4; m.psqo = (int *)p; p += N * 4;
+    m.sqo = (int *)p; p += N * 4; m.eqo = (int *)p; p += N * 4; m.len = (int *)p; p += N * 4; m.best = (int *)p; p += N * 4; m.prev = (int *)p; p += N * 4; m.psqo = (int *)p;
+        p += N * 4;
     m.nx = (int *)p; p += N * 4; m.pv = (int *)p; p += N * 4;
     m.ivS = (int *)p; p += (N + 2) * 4; m.ivL = (int *)p;      // one interval per extraction (at most n0 + 1)
     return m;
@@ -36,10 +37,12 @@ __device__ inline ChainMem carveChain(uint8_t *p, int maxN)
 struct ChainAlloc { unsigned cBase = 0, cLeft = 0, fBase = 0, fLeft = 0; };
 #define YD_CLUMP_CHUNK 32u
 #define YD_FRAG_CHUNK 256u
-__device__ inline bool emitChainClump(const ChainArgs &A, ChainAlloc &al, uint32_t rs, uint32_t region, uint32_t seq, int matched, const DevFrag *list, const int *nx, int head, int m, int lane)
+__device__ inline bool emitChainClump(const ChainArgs &A, ChainAlloc &al, uint32_t rs, uint32_t region, uint32_t seq, int matched, const DevFrag *list, const int *nx, int head,
+    int m, int lane)
 {
     if (al.cLeft == 0) { unsigned b = 0; if (lane == 0) b = atomicAdd(&A.counts[0], YD_CLUMP_CHUNK); al.cBase = uniU(b); al.cLeft = YD_CLUMP_CHUNK; }
-    if (al.fLeft < (unsigned)m) { const unsigned want = (unsigned)m > YD_FRAG_CHUNK ? (unsigned)m : YD_FRAG_CHUNK; unsigned b = 0; if (lane == 0) b = atomicAdd(&A.counts[1], want); al.fBase = uniU(b); al.fLeft = want; }
+    if (al.fLeft < (unsigned)m) { const unsigned want = (unsigned)m > YD_FRAG_CHUNK ? (unsigned)m : YD_FRAG_CHUNK; unsigned b = 0; if (lane == 0) b = atomicAdd(&A.counts[1], want);
+        al.fBase = uniU(b); al.fLeft = want; }
     const unsigned ci = al.cBase, fi = al.fBase;
     if (ci >= A.clumpCap || fi + (unsigned)m > A.fragCap) return false;
     al.cBase++; al.cLeft--; al.fBase += (unsigned)m; al.fLeft -= (unsigned)m;
@@ -159,7 +162,8 @@ __device__ inline uint32_t chainSmall(const ChainArgs &A, ChainAlloc &al, ChainL
         // processBestFragmentPath / insertFragment (GraphPath.cpp:134-146, AlignHelpers.c:60-90)
         int head = -1, tail = -1, m = 0, matched = 0;
         for (int cur = bestLane; cur >= 0 && m < 64; ) {
-            DevFrag f1; f1.sro = (uint32_t)bcast(fsro, cur); f1.sqo = (uint16_t)bcast(fsqo, cur); f1.eqo = (uint16_t)bcast(feqo, cur); f1.refLen = (uint16_t)bcast(frl, cur); f1.used = 0; f1.rs = rs;
+            DevFrag f1; f1.sro = (uint32_t)bcast(fsro, cur); f1.sqo = (uint16_t)bcast(fsqo, cur); f1.eqo = (uint16_t)bcast(feqo, cur); f1.refLen = (uint16_t)bcast(frl, cur);
+                f1.used = 0; f1.rs = rs;
             if (head >= 0) {
                 DevFrag f2 = T.L[head];
                 uint32_t o1 = ovlI(f1.eqo, f2.sqo), o2 = ovlU(f1.sro + f1.refLen - 1u, f2.sro); const int mo = uni((int)(o1 > o2 ? o1 : o2));
@@ -217,7 +221,8 @@ __device__ inline uint32_t chainGeneral(const ChainArgs &A, ChainAlloc &al, cons
             int k = base + lane; bool valid = false; DevFrag f;
             if (k < n0) { f = A.frags[s + k]; valid = f.used == 0; }
             unsigned long long mask = __ballot(valid);
-            if (valid) { int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull)); M.key[pos] = ((unsigned long long)f.sqo << 32) | (unsigned long long)(f.sro - (uint32_t)f.sqo); M.fidx[pos] = s + (uint32_t)k; }
+            if (valid) { int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull)); M.key[pos] = ((unsigned long long)f.sqo << 32) | (unsigned long long)(f.sro - (uint32_t)f.sqo);
+                M.fidx[pos] = s + (uint32_t)k; }
             cnt += __popcll(mask);
         }
         cnt = uni(cnt);
@@ -321,7 +326,8 @@ __device__ inline uint32_t chainGeneral(const ChainArgs &A, ChainAlloc &al, cons
                     if (EQO - SQO < minLeft) keep = false;
                     else {
                         bool aFree = true, bFree = true;
-                        for (int e2 = 0; e2 < nIv; e2++) { const int S0 = M.ivS[e2], S1 = S0 + M.ivL[e2] - 1; if (S0 <= SQO + minLeft && S1 >= SQO) aFree = false; if (S0 <= EQO && S1 >= EQO - minLeft) bFree = false; }
+                        for (int e2 = 0; e2 < nIv; e2++) { const int S0 = M.ivS[e2], S1 = S0 + M.ivL[e2] - 1; if (S0 <= SQO + minLeft && S1 >= SQO) aFree = false;
+                            if (S0 <= EQO && S1 >= EQO - minLeft) bFree = false; }
                         keep = aFree || bFree;
                     }
                     if (!keep) { f.used = 1; A.frags[s + k] = f; }
@@ -355,9 +361,11 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A)
         DevFrag fNext; fNext.sro = 0; fNext.sqo = 0; fNext.eqo = 0; fNext.refLen = 0; fNext.used = 1; fNext.rs = 0;
         { const uint32_t s0 = (uint32_t)bcast((int)hS, 0), e0 = (uint32_t)bcast((int)hE, 0); if ((uint32_t)lane < e0 - s0) fNext = A.frags[s0 + (uint32_t)lane]; }
         for (unsigned k = 0; k < cntR && !failS; k++) {
-            const uint32_t reg = (uint32_t)bcast((int)hReg, (int)k), s = (uint32_t)bcast((int)hS, (int)k), e = (uint32_t)bcast((int)hE, (int)k), rs = (uint32_t)bcast((int)hRs, (int)k); const int n0 = (int)(e - s);
+            const uint32_t reg = (uint32_t)bcast((int)hReg, (int)k), s = (uint32_t)bcast((int)hS, (int)k), e = (uint32_t)bcast((int)hE, (int)k), rs = (uint32_t)bcast((int)hRs,
+                (int)k); const int n0 = (int)(e - s);
             const DevFrag fCur = fNext;
-            if (k + 1 < cntR) { const uint32_t s1 = (uint32_t)bcast((int)hS, (int)k + 1), e1 = (uint32_t)bcast((int)hE, (int)k + 1); if ((uint32_t)lane < e1 - s1) fNext = A.frags[s1 + (uint32_t)lane]; }
+            if (k + 1 < cntR) { const uint32_t s1 = (uint32_t)bcast((int)hS, (int)k + 1), e1 = (uint32_t)bcast((int)hE, (int)k + 1);
+                if ((uint32_t)lane < e1 - s1) fNext = A.frags[s1 + (uint32_t)lane]; }
             const uint32_t seqS = chainSmall(A, al, sT, reg, s, n0, rs, fCur, failS);
             if (lane == 0) A.regionClumpCount[reg] = seqS;
             formed += seqS; failS = UNI_B(failS);
@@ -412,7 +420,8 @@ __global__ void __launch_bounds__(1024) k_regions_single(ChainArgs A)
     if (threadIdx.x == 0) {
         unsigned n = 0; for (unsigned k = 0; k < blockDim.x / 64u; k++) n += sCnt[k];
         // clump slots and fragment slots advance together: one 64-bit add on the pair of counters (counts is 8-byte aligned)
-        if (n) { const unsigned long long old = atomicAdd((unsigned long long *)&A.counts[0], (unsigned long long)n | ((unsigned long long)n << 32)); sBase[0] = (unsigned)old; sBase[1] = (unsigned)(old >> 32); atomicAdd(&A.ctr->v[C_FORMED], (unsigned long long)n); }
+        if (n) { const unsigned long long old = atomicAdd((unsigned long long *)&A.counts[0], (unsigned long long)n | ((unsigned long long)n << 32)); sBase[0] = (unsigned)old;
+            sBase[1] = (unsigned)(old >> 32); atomicAdd(&A.ctr->v[C_FORMED], (unsigned long long)n); }
     }
     __syncthreads();
     if (make) {

@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t 
         uint32_t reg = 0, s = 0, rs = 0; int n0 = 0;
         if (live) {
             reg = smallList[w]; s = A.regStart[reg]; n0 = (int)(A.regStart[reg + 1] - s);
-            for (int i = 0; i < n0; i++) { const DevFrag f = A.frags[s + (uint32_t)i]; T.fsro[i][lane] = f.sro; T.fsqo[i][lane] = f.sqo; T.feqo[i][lane] = f.eqo; T.frl[i][lane] = f.refLen; T.used[i][lane] = f.used != 0; if (i == 0) rs = f.rs; }
+            for (int i = 0; i < n0; i++) { const DevFrag f = A.frags[s + (uint32_t)i]; T.fsro[i][lane] = f.sro; T.fsqo[i][lane] = f.sqo; T.feqo[i][lane] = f.eqo;
+                T.frl[i][lane] = f.refLen; T.used[i][lane] = f.used != 0; if (i == 0) rs = f.rs; }
         }
         int nIv = 0; uint32_t seq = 0; bool active = live;
         for (int iter = 0; iter <= YD_CL; iter++) {
@@ -41,12 +42,14 @@ __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t 
                 int cnt = 0;
                 for (int i = 0; i < n0; i++) if (!T.used[i][lane]) {
                     const int q = T.fsqo[i][lane]; const uint32_t d = T.fsro[i][lane] - (uint32_t)q; int k = cnt;
-                    while (k > 0) { const int o = T.ord[k - 1][lane]; const int oq = T.fsqo[o][lane]; const uint32_t od = T.fsro[o][lane] - (uint32_t)oq; if (oq < q || (oq == q && od < d)) break; T.ord[k][lane] = (int8_t)o; k--; }
+                    while (k > 0) { const int o = T.ord[k - 1][lane]; const int oq = T.fsqo[o][lane]; const uint32_t od = T.fsro[o][lane] - (uint32_t)oq;
+                        if (oq < q || (oq == q && od < d)) break; T.ord[k][lane] = (int8_t)o; k--; }
                     T.ord[k][lane] = (int8_t)i; cnt++;
                 }
                 if (cnt == 0) active = false;
                 else {
-                    for (int a = 0; a < cnt; a++) { const int i = T.ord[a][lane]; T.best[i][lane] = (int16_t)((int)(int16_t)T.frl[i][lane] * MS); T.prev[i][lane] = -1; T.psqo[i][lane] = T.fsqo[i][lane]; }
+                    for (int a = 0; a < cnt; a++) { const int i = T.ord[a][lane]; T.best[i][lane] = (int16_t)((int)(int16_t)T.frl[i][lane] * MS); T.prev[i][lane] = -1;
+                        T.psqo[i][lane] = T.fsqo[i][lane]; }
                     int bestScore = YD_WORST, bestNode = -1, bestEQO = 0, bestPSQO = 0;
                     for (int a = 0; a < cnt; a++) {                           // chain DP, GraphPath.cpp:194-266
                         const int i = T.ord[a][lane];
@@ -69,10 +72,12 @@ __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t 
                             else if (best == newScore) {
                                 if (prevL < 0) take = false;
                                 else {
-                                    const int pq = T.fsqo[prevL][lane]; const uint32_t pdiag = T.fsro[prevL][lane] - (uint32_t)pq; const int pEQO = T.feqo[prevL][lane], pps = T.psqo[prevL][lane];
+                                    const int pq = T.fsqo[prevL][lane]; const uint32_t pdiag = T.fsro[prevL][lane] - (uint32_t)pq;
+                                        const int pEQO = T.feqo[prevL][lane], pps = T.psqo[prevL][lane];
                                     const int dc = (int)(absDiffU(ld, ndiag) - absDiffU(pdiag, ndiag));
                                     if (dc > 0) take = false;
-                                    else if (dc == 0) { const int gc = (int)(gapI(lEQO, fsqo) - gapI(pEQO, fsqo)); if (gc > 0) take = false; else if (gc == 0 && lps <= pps) take = false; }
+                                    else if (dc == 0) { const int gc = (int)(gapI(lEQO, fsqo) - gapI(pEQO, fsqo)); if (gc > 0) take = false;
+                                        else if (gc == 0 && lps <= pps) take = false; }
                                 }
                             }
                             if (take) { T.best[j][lane] = (int16_t)newScore; T.prev[j][lane] = (int8_t)i; T.psqo[j][lane] = (uint16_t)lps; }
@@ -93,12 +98,14 @@ __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t 
                                 const int l1 = fragQLen(q1, e1), l2 = fragQLen(q2, e2);
                                 const bool chop1 = (l1 != l2) ? (l1 < l2) : (T.nx[head][lane] < 0);
                                 if (chop1) { e1 = (e1 - mo) & 0xFFFF; r1 = (r1 - mo) & 0xFFFF; T.feqo[cur][lane] = (uint16_t)e1; T.frl[cur][lane] = (uint16_t)r1; }
-                                else { q2 = (q2 + mo) & 0xFFFF; s2 += (uint32_t)mo; r2 = (r2 - mo) & 0xFFFF; T.lsqo[head][lane] = (uint16_t)q2; T.lsro[head][lane] = s2; T.lrl[head][lane] = (uint16_t)r2; }
+                                else { q2 = (q2 + mo) & 0xFFFF; s2 += (uint32_t)mo; r2 = (r2 - mo) & 0xFFFF; T.lsqo[head][lane] = (uint16_t)q2; T.lsro[head][lane] = s2;
+                                    T.lrl[head][lane] = (uint16_t)r2; }
                             }
                         }
                         matched = (matched + r1) & 0xFFFF;
                         const int id = mm++;
-                        T.lsro[id][lane] = s1; T.lsqo[id][lane] = (uint16_t)q1; T.leqo[id][lane] = (uint16_t)e1; T.lrl[id][lane] = (uint16_t)r1; T.nx[id][lane] = (int8_t)head; T.pv[id][lane] = -1;
+                        T.lsro[id][lane] = s1; T.lsqo[id][lane] = (uint16_t)q1; T.leqo[id][lane] = (uint16_t)e1; T.lrl[id][lane] = (uint16_t)r1; T.nx[id][lane] = (int8_t)head;
+                            T.pv[id][lane] = -1;
                         if (head >= 0) T.pv[head][lane] = (int8_t)id; else tail = id;
                         head = id;
                         cur = T.prev[cur][lane];
@@ -109,7 +116,8 @@ __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t 
                         auto qlenOf = [&](int id) { return fragQLen(T.lsqo[id][lane], T.leqo[id][lane]); };
                         auto diagOf = [&](int id) { return T.lsro[id][lane] - (uint32_t)T.lsqo[id][lane]; };
                         auto nxt = [&](int id) { return (int)T.nx[id][lane]; };
-                        auto removeNode = [&](int id) { const int n = T.nx[id][lane], p = T.pv[id][lane]; if (p < 0) head = n; else T.nx[p][lane] = (int8_t)n; if (n < 0) tail = p; else T.pv[n][lane] = (int8_t)p; };
+                        auto removeNode = [&](int id) { const int n = T.nx[id][lane], p = T.pv[id][lane]; if (p < 0) head = n; else T.nx[p][lane] = (int8_t)n; if (n < 0) tail = p;
+                            else T.pv[n][lane] = (int8_t)p; };
                         int S1 = head, S2 = S1 >= 0 ? nxt(S1) : -1, S3 = S2 >= 0 ? nxt(S2) : -1, guard = 0;
                         while (S2 >= 0 && S3 >= 0 && ++guard < 1000) {
                             if (qlenOf(S2) < P.wordLen) {
@@ -176,7 +184,8 @@ __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t 
                     if (ci >= A.clumpCap || fi + (unsigned)mm > A.fragCap) atomicCAS(A.errFlag, 0, (int)YERR_CHAIN);
                     else {
                         int id = head;
-                        for (int k = 0; k < mm; k++) { DevFrag f; f.sro = T.lsro[id][lane]; f.sqo = T.lsqo[id][lane]; f.eqo = T.leqo[id][lane]; f.refLen = T.lrl[id][lane]; f.used = 0; f.rs = rs; A.clumpFrags[fi + (unsigned)k] = f; id = T.nx[id][lane]; }
+                        for (int k = 0; k < mm; k++) { DevFrag f; f.sro = T.lsro[id][lane]; f.sqo = T.lsqo[id][lane]; f.eqo = T.leqo[id][lane]; f.refLen = T.lrl[id][lane];
+                            f.used = 0; f.rs = rs; A.clumpFrags[fi + (unsigned)k] = f; id = T.nx[id][lane]; }
                         ChainClumpRec r; r.rs = rs; r.fragOff = fi; r.nFrags = (uint32_t)mm; r.region = reg; r.seq = seq; r.matched = (uint32_t)matched; A.clumps[ci] = r;
                         seq++;
                     }

@@ -51,7 +51,8 @@ struct DevBatch {
 };
 
 struct DevCounters { unsigned long long v[16]; };   // same order as ygpu_counters
-enum { C_KMER = 0, C_HITS, C_FRAGS, C_REGIONS, C_FORMED, C_SCORED, C_EXT_CALLS, C_EXT_ROWS, C_EXT_CELLS, C_GAP_CALLS, C_GAP_ROWS, C_GAP_CELLS, C_PERFECT, C_TOUCHED, C_OPS, C_SPLITS };
+enum { C_KMER = 0, C_HITS, C_FRAGS, C_REGIONS, C_FORMED, C_SCORED, C_EXT_CALLS, C_EXT_ROWS, C_EXT_CELLS, C_GAP_CALLS, C_GAP_ROWS, C_GAP_CELLS, C_PERFECT, C_TOUCHED, C_OPS,
+    C_SPLITS };
 
 // ---- wave64 helpers ----------------------------------------------------------------------------------------
 __device__ __forceinline__ int  laneId() { return (int)(threadIdx.x & 63); }

@@ -36,11 +36,13 @@ __global__ void k_dp_gather_ext(const ExtProb *probs, const ExtRes *res, const u
     if (r.score > 0) {
         const bool rv = (probs[p].flags & XP_REV) != 0; const uint32_t *src = extOpsPtr(extOps, r); const char codes[4] = {'M', 'R', 'D', 'I'};
         o.score = r.score; o.addedQLen = (uint16_t)r.maxi; o.addedRLen = (uint16_t)(r.maxi + (r.maxj - YD_LBAND)); o.n_ops = r.nOps;
-        for (uint32_t k = 0; k < r.nOps; k++) { const uint32_t op = src[rv ? r.nOps - 1u - k : k]; outOps[o.op_start + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
+        for (uint32_t k = 0; k < r.nOps; k++) { const uint32_t op = src[rv ? r.nOps - 1u - k : k];
+            outOps[o.op_start + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
     }
     out[dst[p]] = o;
 }
-__global__ void k_dp_gather_gap(DevParams P, const uint8_t *bases, const uint8_t *fwd, const uint8_t *rev, const JointRec *joints, const uint32_t *gapOps, const uint32_t *outOff, const uint32_t *dst,
+__global__ void k_dp_gather_gap(DevParams P, const uint8_t *bases, const uint8_t *fwd, const uint8_t *rev, const JointRec *joints, const uint32_t *gapOps, const uint32_t *outOff,
+    const uint32_t *dst,
                                 uint32_t n, ygpu_dp_result *out, uint32_t *outOps)
 {
     YD_HIGH_PRIO();
@@ -57,6 +59,7 @@ __global__ void k_dp_gather_gap(DevParams P, const uint8_t *bases, const uint8_t
             if (c == pc) pl++; else { if (pc >= 0) outOps[w++] = ((uint32_t)(uint8_t)codes[pc] << 16) | (uint32_t)pl; pc = c; pl = 1; }
         }
         if (pc >= 0) outOps[w++] = ((uint32_t)(uint8_t)codes[pc] << 16) | (uint32_t)pl;
-    } else for (uint32_t k = 0; k < j.nOps; k++) { const uint32_t op = gapOps[j.opsOff + k]; outOps[o.op_start + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
+    } else for (uint32_t k = 0; k < j.nOps; k++) { const uint32_t op = gapOps[j.opsOff + k];
+        outOps[o.op_start + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
     out[dst[t]] = o;
 }

@@ -172,7 +172,8 @@ __device__ __noinline__ DPOut dpWave(const DevParams &P, const uint8_t *__restri
     const int Wp = W <= 32 ? 32 : 64, ldsRows = YD_LDS_CELLS / Wp;      // rows [0, ldsRows) of the strip are kept in LDS
     auto loadRef = [&](int idx) -> int {
         int v = 0xFF;
-        if (idx >= 0 && idx < rLen) { uint32_t off = rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx; uint32_t b = gBases[off >> 1]; v = (int)((off & 1u) ? (b & 0xFu) : (b >> 4)); }
+        if (idx >= 0 && idx < rLen) { uint32_t off = rev ? rOff - (uint32_t)idx : rOff + (uint32_t)idx; uint32_t b = gBases[off >> 1];
+            v = (int)((off & 1u) ? (b & 0xFu) : (b >> 4)); }
         asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(v));             // consume the load here, so that no wait lands at the row-loop header
         return v; };
     auto loadQ   = [&](int t) -> int { int v = (t < qLen) ? (int)gQ[rev ? qOff - t : qOff + t] : 0xFE; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(v)); return v; };

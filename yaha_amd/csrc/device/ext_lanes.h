@@ -51,7 +51,8 @@ enum { XP_STRAND = 1, XP_REV = 2, XP_VALID = 4 };
 // a signed dword offset from the trace arena's base (the list stays where the walk staged it unless it straddles two chunks; then it is in the ops arena).
 struct ExtRes { int score, maxi, maxj; uint32_t opsOff, nOps, where, rows, cells; };
 static_assert(sizeof(ExtProb) == 16 && sizeof(ExtRes) == 32, "k_ext_rows_pk moves these as 16-byte vectors (non-temporal loads / stores)");
-__device__ __forceinline__ const uint32_t *extOpsPtr(const uint32_t *traceBase, const ExtRes &r) { return traceBase + (long long)(((unsigned long long)r.where << 32) | (unsigned long long)r.opsOff); }
+__device__ __forceinline__ const uint32_t *extOpsPtr(const uint32_t *traceBase, const ExtRes &r) {
+    return traceBase + (long long)(((unsigned long long)r.where << 32) | (unsigned long long)r.opsOff); }
 
 struct ExtArgs {
     DevParams P; const uint8_t *bases; const uint8_t *fwd, *rev;
@@ -191,7 +192,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
                         eW1 = 0; eW2 = 0;
                         for (int c = leftR; c < YD_LW; c++) {
                             const int idx = c - leftR; uint32_t nib = 15u;
-                            if (idx < (int)rl) { const uint32_t off = rv_ ? pr.rOff - (uint32_t)idx : pr.rOff + (uint32_t)idx; const uint32_t b = gBases[off >> 1]; nib = (off & 1u) ? (b & 15u) : (b >> 4); }
+                            if (idx < (int)rl) { const uint32_t off = rv_ ? pr.rOff - (uint32_t)idx : pr.rOff + (uint32_t)idx; const uint32_t b = gBases[off >> 1];
+                                nib = (off & 1u) ? (b & 15u) : (b >> 4); }
                             const uint32_t sh = (uint32_t)(c & 7) * 4u;
                             if (c < 16) eW1 |= nib << sh; else eW2 |= nib << sh;
                         }
@@ -203,7 +205,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
             const int e = poolNext + __builtin_popcountll(need & lanesBelow);
             const bool take = (p < 0 && !done && !justDone) && e < poolCount;
             const int src = take ? e : lane;
-            const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
+            const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64),
+                gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
             const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64);
             const uint32_t gPidx = (uint32_t)__shfl((int)ePidx, src, 64);
             const bool init = take && gLens != 0u;
@@ -263,7 +266,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPS ?
             const bool tF = F >= V; V = tF ? F : V;
             uint32_t nib = eq ? (uint32_t)OP_M : (uint32_t)OP_R; nib = tE ? (uint32_t)OP_D : nib; nib = tF ? (uint32_t)OP_I : nib;
             nib |= (cE ? 4u : 0u) | (cF ? 8u : 0u);
-            if (j < 8) { t0 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t0)); } else if (j < 16) { t1 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t1)); } else { t2 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t2)); }   // pinned: the condition masks die here
+            // pinned: the condition masks die here
+            if (j < 8) { t0 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t0)); } else if (j < 16) { t1 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t1));
+                } else { t2 |= nib << ((j & 7) * 4); asm volatile("" : "+v"(t2)); }
             // row-major first maximum over the real cells: key = (V + BIAS) << 5 | (31 - j)
             uint32_t key = ((uint32_t)(V + YD_BIAS)) << 5 | (uint32_t)(31 - j);
             if (j < leftR) key = j >= sc ? key : 0u;
@@ -333,7 +338,8 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 {
     YD_HIGH_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const int lane = laneId();
-    if (*toGlobal(A.errFlag) != 0) return;                                   // k_ext_rows ran out of arena (or an earlier kernel failed): the stage is redone, its strips are incomplete
+    // k_ext_rows ran out of arena (or an earlier kernel failed): the stage is redone, its strips are incomplete
+    if (*toGlobal(A.errFlag) != 0) return;
     // problems in the order k_ext_rows took them: the 64 problems of a pool ran in one wave at the same time, so the lanes of a wave here walk neighbouring blocks
     const bool live = t < A.nProb;
     const uint32_t p = live ? ((A.order && !(A.dbgMode & 2)) ? A.order[t] : t) : 0u;
@@ -356,7 +362,8 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
         auto stepUp = [&](Cur &u) {                                          // one row towards the origin
             if (u.rr != 0) { u.rr--; u.w -= 3; u.cp -= 3; return; }
             u.rr = 9; u.w -= 5; u.fb--;
-            if (u.fb % YD_CHUNK_FLUSHES == YD_CHUNK_FLUSHES - 1u) u.cp = S.arena + (size_t)S.tab[u.fb / YD_CHUNK_FLUSHES] * YD_CHUNK_DWORDS + S.laneOff + (YD_CHUNK_FLUSHES - 1u) * 32u + 27u;
+            if (u.fb % YD_CHUNK_FLUSHES == YD_CHUNK_FLUSHES - 1u) u.cp = S.arena + (size_t)S.tab[u.fb / YD_CHUNK_FLUSHES] * YD_CHUNK_DWORDS + S.laneOff + (YD_CHUNK_FLUSHES - 1u) *
+                32u + 27u;
             else u.cp -= 5;
         };
         const int row0w = extRowWord(1 + ph) - 3;                               // the logical position of row 0 (not in the strip): with the cursor there every row is consumed
@@ -372,7 +379,8 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
             int lim = (int)(c.fb % YD_CHUNK_FLUSHES) * 10 + c.rr + 1; lim = lim < y ? lim : y; lim = lim < YD_TRACE_DEPTH ? lim : YD_TRACE_DEPTH;
             { YD_GLOBAL uint32_t *up = c.cp; int ur = c.rr;
 #pragma unroll
-              for (int k = 0; k < YD_TRACE_DEPTH; k++) { d[k] = up[ws]; const bool go = k + 1 < lim; const int dec = ur == 0 ? 5 : 3; up -= go ? dec : 0; ur = go ? (ur == 0 ? 9 : ur - 1) : ur; } }
+              for (int k = 0; k < YD_TRACE_DEPTH; k++) { d[k] = up[ws]; const bool go = k + 1 < lim; const int dec = ur == 0 ? 5 : 3; up -= go ? dec : 0;
+                  ur = go ? (ur == 0 ? 9 : ur - 1) : ur; } }
             uint32_t nib = (d[0] >> sh) & 15u; int took = 0;
 #pragma unroll
             for (int k = 0; k < YD_TRACE_DEPTH; k++) {
@@ -382,9 +390,11 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
                 if (op >= OP_D || y <= 0) break;
                 if (prev != op) { if (prev >= 0) flush(); prev = op; acc = 1; } else acc++;
                 y--; took++;
-                if (took < lim) { const int dec = c.rr == 0 ? 5 : 3; c.cp -= dec; c.w -= dec; c.fb -= c.rr == 0 ? 1u : 0u; c.rr = c.rr == 0 ? 9 : c.rr - 1; }   // inside the chunk: no look-up
+                // inside the chunk: no look-up
+                if (took < lim) { const int dec = c.rr == 0 ? 5 : 3; c.cp -= dec; c.w -= dec; c.fb -= c.rr == 0 ? 1u : 0u; c.rr = c.rr == 0 ? 9 : c.rr - 1; }
             }
-            if (took == lim) { if (y > 0) stepUp(c); else c.w = row0w; continue; }          // the whole batch was a straight run: one full step (it may leave the chunk), next batch
+            // the whole batch was a straight run: one full step (it may leave the chunk), next batch
+            if (took == lim) { if (y > 0) stepUp(c); else c.w = row0w; continue; }
             if ((nib & 3u) == (uint32_t)OP_D) {                                  // deletion run: walk the continue bits along the row
                 ExtRowBits rb; rb.a = c.cp[0]; rb.b = c.cp[1]; rb.c = c.cp[2];
                 int run = 1, xx = x;
@@ -403,7 +413,8 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
         }
         if (y <= 0 && x > leftR) put(OP_D, x - leftR);                           // row 0: deletions back to the origin (SW.cpp:905-935)
         if (prev >= 0) { const int wp = E - 1 - n; if (wp < 0) bad = true; else *S.at(wp) = opMake(prev, acc); n++; }
-        if (bad || S.wild) { bad = true; atomicCAS(A.errFlag, 0, (int)YERR_TRACE); n = 0; if (S.wild && atomicCAS(&gTraceDbg[5], 0u, 1u) == 0u) { gTraceDbg[6] = p; gTraceDbg[7] = r.where; } }
+        if (bad || S.wild) { bad = true; atomicCAS(A.errFlag, 0, (int)YERR_TRACE); n = 0; if (S.wild && atomicCAS(&gTraceDbg[5], 0u, 1u) == 0u) { gTraceDbg[6] = p;
+            gTraceDbg[7] = r.where; } }
     }
     // The finished list is contiguous where it was staged unless it straddles two chunks; only then it is copied, to an exactly-sized slot of the ops arena
     // (one reservation per wave).  Either way the result carries its address as an offset from the trace arena's base.
@@ -441,7 +452,8 @@ __global__ void __launch_bounds__(256) k_ext_trace(ExtArgs A)
 // read 64 different chunks); so the problems are grouped by the ARENA CHUNK their strip starts in (the wave of k_ext_rows that ran them and the chunk it was
 // writing) and sorted by walk length, descending, inside the group: lanes of a wave read one chunk and walk paths of similar length.
 // key = arena region (physical chunk >> regionLog) | length bucket : 5 (32 buckets of the longest read's length: two radix passes for the bench batch)
-__global__ void k_trace_keys(const ExtRes *res, const uint32_t *order, uint32_t n, const uint32_t *waveChunks, uint32_t maxCh, int regionLog, int lenShift, int lenBits, uint32_t *keys, uint32_t *vals)
+__global__ void k_trace_keys(const ExtRes *res, const uint32_t *order, uint32_t n, const uint32_t *waveChunks, uint32_t maxCh, int regionLog, int lenShift, int lenBits,
+    uint32_t *keys, uint32_t *vals)
 {
     YD_HIGH_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

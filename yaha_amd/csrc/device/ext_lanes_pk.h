@@ -75,7 +75,7 @@ __device__ unsigned long long gRowsProf[8];      // passes, passes that wrote re
 #define YD_ROWS_WAVES 3                        // waves per SIMD of k_ext_rows_pk (a build switch for experiments: make variant VARIANT_FLAGS=-DYD_ROWS_WAVES=2)
 #endif
 // BS = threads of a workgroup: 256 (a wave per SIMD), or 512 (two waves per SIMD of ONE CU: what the launch uses when it shares the device and takes a part of the
-// CUs only -- a wave that is alone on its SIMD runs at a third of the rate, so the waves of a partial launch should come in pairs; see ygpu.hip)
+// CUs only -- a wave that is alone on its SIMD runs at a third of the rate, so the waves of a partial launch should come in pairs; see stage_align.hip)
 template <bool SECOND, int BS = 256>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS_WAVES, YD_ROWS_WAVES))) k_ext_rows_pk(ExtArgs A)
 {
@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
     // its multiply-add (MS + GO + GE | -RC + GO + GE), for nothing.  Eleven instructions fewer a row; all values as before (nothing here saturates: see the header).
     const uint32_t MSGp = pk2(A.P.MS + GO + GE), LWg = pk2(YD_LW16 - (GO + GE)), LWgLo = (uint32_t)(YD_LW16 - (GO + GE)) & 0xFFFFu;
 
-    uint32_t NEGKv = NEGK, MSv = MSGp, ONEv = ONEp, C15v = 0x000F000Fu;      // operands of the inline-assembly instructions: kept in VGPRs (copied from SGPRs at every use otherwise)
+    // operands of the inline-assembly instructions: kept in VGPRs (copied from SGPRs at every use otherwise)
+    uint32_t NEGKv = NEGK, MSv = MSGp, ONEv = ONEp, C15v = 0x000F000Fu;
     asm volatile("" : "+v"(NEGKv), "+v"(MSv), "+v"(ONEv), "+v"(C15v));
     uint32_t PV[YD_NP], PF[YD_NP], rc[YD_NP], carryE = LWp, nbNext = 15u;
     int p = -1, i = 0, qLen = 0, maxScore = YD_LWORST, maxi = 0, qcNext = 0, qcPrev = 0, rvLo = YD_LWORST;
@@ -118,7 +119,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
     uint32_t qwLo = 0, qwHi = 0, rwLo = 0, rwHi = 0, qLd = 0, rLd = 0, rOffP = 0, qPos = 0;
     int qHave = 0, rHave = 0, qNext = 0, rNext = 0, rLenP = 0, qStep = 0, rLeft = 0; bool pendQ = false, pendR = false, done = false;
     bool insQ = false, insR = false;                                         // wave-uniform: the previous pass ran the query / reference refill
-    YD_GLOBAL const uint8_t *q4 = toGlobal(A.fwd4);                          // the strand's PACKED codes (two to the byte, as the reference: k_pack4): entry idx of the extension = nibble qPos +- idx
+    // the strand's PACKED codes (two to the byte, as the reference: k_pack4): entry idx of the extension = nibble qPos +- idx
+    YD_GLOBAL const uint8_t *q4 = toGlobal(A.fwd4);
     unsigned calls = 0, rows = 0, cells = 0;
 #ifdef YD_PROF
     unsigned pfPass = 0, pfRes = 0, pfRefill = 0, pfSnap = 0, pfBusy = 0, pfFlush = 0, pfPool = 0;      // (wave-uniform)
@@ -127,8 +129,10 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
     for (int k = 0; k < YD_NP; k++) { PV[k] = LWg; PF[k] = LWp; rc[k] = 0x7FFF7FFFu; }      // (PV holds Vg = V - GOE throughout)
 
     int poolCount = 0, poolNext = 0; bool exhausted = false;
-    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0, eQwLo = 0, eQwHi = 0, eRwLo = 0, eRwHi = 0;      // eMisc: flags | first query code << 8 | buffered entries (query | reference << 8) << 16
-    bool pendFlush = false; int pendRes = -1, rowsFin = 0; unsigned pStart = 0;      // pendRes: the problem whose result this lane has yet to store (its state stays untouched until then); rowsFin: its last row
+    // eMisc: flags | first query code << 8 | buffered entries (query | reference << 8) << 16
+    uint32_t eLens = 0, eROff = 0, eQ = 0, eMisc = 0, eW1 = 0, eW2 = 0, ePidx = 0, eQwLo = 0, eQwHi = 0, eRwLo = 0, eRwHi = 0;
+    // pendRes: the problem whose result this lane has yet to store (its state stays untouched until then); rowsFin: its last row
+    bool pendFlush = false; int pendRes = -1, rowsFin = 0; unsigned pStart = 0;
     int wslot = 0; unsigned flush = 0; bool dirty = false, justDone = false;
     YD_GLOBAL uint32_t *chunkPtr = toGlobal(A.trace); bool noMem = false;
     auto takeChunk = [&]() {                                                 // wave-uniform: the chunk of flushes [flush, flush + 16)
@@ -175,7 +179,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
         if (insQ) {
             if (pendQ) {
 #if YD_ROWS_LDSWIN
-                if (newQ) { sWin[0][tid] = GQ.x; sWin[1][tid] = GQ.y; sWin[2][tid] = GQ.z; sWin[3][tid] = GQ.w; qLd = sWin[jQ][tid]; }      // a fresh piece: into the lane's slot; its dword jQ is the one due
+                // a fresh piece: into the lane's slot; its dword jQ is the one due
+                if (newQ) { sWin[0][tid] = GQ.x; sWin[1][tid] = GQ.y; sWin[2][tid] = GQ.z; sWin[3][tid] = GQ.w; qLd = sWin[jQ][tid]; }
 #endif
                 const uint32_t sw = ((qLd & 0x0F0F0F0Fu) << 4) | ((qLd >> 4) & 0x0F0F0F0Fu);      // forward: the even offset (high nibble) first
                 const uint32_t v = qStep < 0 ? __builtin_amdgcn_perm(0u, qLd, 0x00010203u) : sw;   // reverse: bytes swapped, each byte's low nibble (the higher offset) first
@@ -199,7 +204,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
         // the blocks the previous iteration completed: their place is fixed now (a problem that starts below notes the flush ITS first block will go out
         // with), the stores themselves are issued after this iteration's loads (program order = the order the memory counter retires in)
         unsigned long long flushNow = 0ull; YD_GLOBAL uint32_t *flushSlot = chunkPtr;
-        if (wslot == 0) { flushNow = __ballot(pendFlush); pendFlush = false; if (flushNow != 0ull) { flushSlot = chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u; nextFlush(); } }
+        if (wslot == 0) { flushNow = __ballot(pendFlush); pendFlush = false; if (flushNow != 0ull) { flushSlot = chunkPtr + (size_t)(flush % YD_CHUNK_FLUSHES) * 32u; nextFlush();
+            } }
         // ---- refill (k_ext_rows') ----
         for (;;) {
             const unsigned long long need = __ballot(p < 0 && !done && !justDone && (!YD_ROWS_RESBATCH || pendRes < 0));
@@ -217,7 +223,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
                 if (lane < poolCount) {
                     const unsigned np = A.order ? __builtin_nontemporal_load(toGlobal(&A.order[base + (unsigned)lane])) : base + (unsigned)lane;
                     ePidx = np;
-                    ExtProb pr; { const yd_u32x4 v = __builtin_nontemporal_load((YD_GLOBAL const yd_u32x4 *)toGlobal(&A.probs[np])); pr.qBase = v.x; pr.rOff = v.y; pr.qOff = (uint16_t)(v.z & 0xFFFFu); pr.qLen = (uint16_t)(v.z >> 16); pr.flags = v.w; }
+                    ExtProb pr; { const yd_u32x4 v = __builtin_nontemporal_load((YD_GLOBAL const yd_u32x4 *)toGlobal(&A.probs[np])); pr.qBase = v.x; pr.rOff = v.y;
+                        pr.qOff = (uint16_t)(v.z & 0xFFFFu); pr.qLen = (uint16_t)(v.z >> 16); pr.flags = v.w; }
                     int ql = 0; uint32_t rl = 0; const bool rv_ = (pr.flags & XP_REV) != 0;
                     if (pr.flags & XP_VALID) {                              // findAGSExtension, SW.cpp:479-516
                         isCall = true;
@@ -235,7 +242,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
                         eW1 = 0; eW2 = 0;                                     // reference indices 0..10 (nibble c - leftR of the window, as in k_ext_rows)
                         for (int c = leftR; c < YD_LW; c++) {
                             const int idx = c - leftR; uint32_t nib = 15u;
-                            if (idx < (int)rl) { const uint32_t off = rv_ ? pr.rOff - (uint32_t)idx : pr.rOff + (uint32_t)idx; const uint32_t b = gBases[off >> 1]; nib = (off & 1u) ? (b & 15u) : (b >> 4); }
+                            if (idx < (int)rl) { const uint32_t off = rv_ ? pr.rOff - (uint32_t)idx : pr.rOff + (uint32_t)idx; const uint32_t b = gBases[off >> 1];
+                                nib = (off & 1u) ? (b & 15u) : (b >> 4); }
                             const uint32_t sh = (uint32_t)(c & 7) * 4u;
                             if (c < 16) eW1 |= nib << sh; else eW2 |= nib << sh;
                         }
@@ -250,7 +258,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
                                 const uint32_t w = *d1;
                                 v1 = rv_ ? __builtin_amdgcn_perm(0u, w, 0x00010203u) >> (4u * (7u - lo3)) : (((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu)) >> (4u * lo3);
                                 qh = c1;
-                                if (ql > (int)(1u + c1)) { const uint32_t w2 = rv_ ? d1[-1] : d1[1]; v2 = rv_ ? __builtin_amdgcn_perm(0u, w2, 0x00010203u) : (((w2 & 0x0F0F0F0Fu) << 4) | ((w2 >> 4) & 0x0F0F0F0Fu)); qh = c1 + 8u; }
+                                if (ql > (int)(1u + c1)) { const uint32_t w2 = rv_ ? d1[-1] : d1[1];
+                                    v2 = rv_ ? __builtin_amdgcn_perm(0u, w2, 0x00010203u) : (((w2 & 0x0F0F0F0Fu) << 4) | ((w2 >> 4) & 0x0F0F0F0Fu)); qh = c1 + 8u; }
                             }
                             const unsigned long long t = (unsigned long long)v1 | (c1 < 16u ? ((unsigned long long)v2 << (4u * c1)) : 0ull);
                             eQwLo = (uint32_t)t; eQwHi = (uint32_t)(t >> 32);
@@ -263,7 +272,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
                                 const uint32_t w = *d1;
                                 v1 = rv_ ? __builtin_amdgcn_perm(0u, w, 0x00010203u) >> (4u * (7u - lo3)) : (((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu)) >> (4u * lo3);
                                 rh = c1;
-                                if (rl > 11u + c1) { const uint32_t w2 = rv_ ? d1[-1] : d1[1]; v2 = rv_ ? __builtin_amdgcn_perm(0u, w2, 0x00010203u) : (((w2 & 0x0F0F0F0Fu) << 4) | ((w2 >> 4) & 0x0F0F0F0Fu)); rh = c1 + 8u; }
+                                if (rl > 11u + c1) { const uint32_t w2 = rv_ ? d1[-1] : d1[1];
+                                    v2 = rv_ ? __builtin_amdgcn_perm(0u, w2, 0x00010203u) : (((w2 & 0x0F0F0F0Fu) << 4) | ((w2 >> 4) & 0x0F0F0F0Fu)); rh = c1 + 8u; }
                             }
                             const unsigned long long t = (unsigned long long)v1 | (c1 < 16u ? ((unsigned long long)v2 << (4u * c1)) : 0ull);
                             eRwLo = (uint32_t)t; eRwHi = (uint32_t)(t >> 32);
@@ -277,10 +287,12 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
             const int e = poolNext + __builtin_popcountll(need & lanesBelow);
             const bool take = (p < 0 && !done && !justDone && (!YD_ROWS_RESBATCH || pendRes < 0)) && e < poolCount;
             const int src = take ? e : lane;
-            const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64), gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
+            const uint32_t gLens = (uint32_t)__shfl((int)eLens, src, 64), gROff = (uint32_t)__shfl((int)eROff, src, 64), gQ = (uint32_t)__shfl((int)eQ, src, 64),
+                gMisc = (uint32_t)__shfl((int)eMisc, src, 64);
             const uint32_t gW1 = (uint32_t)__shfl((int)eW1, src, 64), gW2 = (uint32_t)__shfl((int)eW2, src, 64);
             const uint32_t gPidx = (uint32_t)__shfl((int)ePidx, src, 64);
-            const uint32_t gQwLo = (uint32_t)__shfl((int)eQwLo, src, 64), gQwHi = (uint32_t)__shfl((int)eQwHi, src, 64), gRwLo = (uint32_t)__shfl((int)eRwLo, src, 64), gRwHi = (uint32_t)__shfl((int)eRwHi, src, 64);
+            const uint32_t gQwLo = (uint32_t)__shfl((int)eQwLo, src, 64), gQwHi = (uint32_t)__shfl((int)eQwHi, src, 64), gRwLo = (uint32_t)__shfl((int)eRwLo, src, 64),
+                gRwHi = (uint32_t)__shfl((int)eRwHi, src, 64);
             const uint32_t gHave = gMisc >> 16;
             const bool init = take && gLens != 0u;
             // A fresh problem: low halves = row 0 of columns 0..10 (the origin (0, 10): V = 0, F = -GO; sentinel left of it), high halves = the sentinel
@@ -288,7 +300,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
             // row 1 (bit 15: not a cell; it slides out with the window), pair 10 low = index 0, pair k high = index k.
 #pragma unroll
             for (int k = 0; k < YD_NP; k++) {
-                const uint32_t iV = k == leftR ? ((LWg & 0xFFFF0000u) | ((uint32_t)(-(GO + GE)) & 0xFFFFu)) : LWg, iF = k == leftR ? ((LWp & 0xFFFF0000u) | ((uint32_t)(-GO) & 0xFFFFu)) : LWp;      // the origin: V = 0, i.e. Vg = -GOE
+                // the origin: V = 0, i.e. Vg = -GOE
+                const uint32_t iV = k == leftR ? ((LWg & 0xFFFF0000u) | ((uint32_t)(-(GO + GE)) & 0xFFFFu)) : LWg, iF = k == leftR
+                    ? ((LWp & 0xFFFF0000u) | ((uint32_t)(-GO) & 0xFFFFu)) : LWp;
                 const int c = leftR + k;                                      // window nibble of reference index k
                 const uint32_t nibHi = (((c < 16 ? gW1 : gW2) >> ((c & 7) * 4)) & 15u) | YD_RCREAL, nibLo = k == leftR ? (((gW1 >> ((leftR & 7) * 4)) & 15u) | YD_RCREAL) : 0x800Fu;
                 PV[k] = init ? iV : PV[k]; PF[k] = init ? iF : PF[k]; rc[k] = init ? (nibLo | (nibHi << 16)) : rc[k];
@@ -328,7 +342,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
             // extension lies inside the arrays (they start on 256-byte boundaries and have slack behind).
             newQ = false;
             if (pendQ) {
-                const uint32_t n = qStep < 0 ? qPos - (uint32_t)qNext - 7u : qPos + (uint32_t)qNext, da = n >> 1; const int j = (int)((da >> 2) & 3u);      // (da: dword-aligned byte offset)
+                // (da: dword-aligned byte offset)
+                const uint32_t n = qStep < 0 ? qPos - (uint32_t)qNext - 7u : qPos + (uint32_t)qNext, da = n >> 1; const int j = (int)((da >> 2) & 3u);
                 if (freshQ || j == (qStep < 0 ? 3 : 0)) { GQ = *(YD_GLOBAL const yd_u32x4 *)(q4 + (da & ~15u)); newQ = true; freshQ = false; jQ = j; }
                 else qLd = sWin[j][tid];
             }
@@ -342,7 +357,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
             }
             insR = true;
 #else
-            if (pendQ) { const uint32_t n = qStep < 0 ? qPos - (uint32_t)qNext - 7u : qPos + (uint32_t)qNext; qLd = *(YD_GLOBAL const uint32_t *)(q4 + (n >> 1)); }      // (nibble qPos + qNext * qStep is dword-aligned going up, the last nibble of a dword going down)
+            // (nibble qPos + qNext * qStep is dword-aligned going up, the last nibble of a dword going down)
+            if (pendQ) { const uint32_t n = qStep < 0 ? qPos - (uint32_t)qNext - 7u : qPos + (uint32_t)qNext; qLd = *(YD_GLOBAL const uint32_t *)(q4 + (n >> 1)); }
             insQ = true;
             pendR = rHave <= 8 && rNext < rLenP;
             if (pendR) { const uint32_t n = qStep < 0 ? rOffP - (uint32_t)rNext - 7u : rOffP + (uint32_t)rNext; rLd = *(YD_GLOBAL const uint32_t *)(gBases + (n >> 1)); }
@@ -362,15 +378,19 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
         if (resNow && pendRes >= 0) {
             // the problem ended in an earlier pass at row rowsFin (the lane sat out every refill since, so maxScore / maxi / maxj / pStart
             // are still its own).  Work of the call: row r has 21 - max(11 - r, 0) real cells.
-            const unsigned rowF = YD_ROWS_RESBATCH ? (unsigned)rowsFin : (unsigned)(i - 2), m = rowF < (unsigned)leftR ? rowF : (unsigned)leftR, nCells = __umul24((unsigned)YD_LW, rowF) - (__umul24((unsigned)(leftR + 1), m) - __umul24(m, m + 1u) / 2u);
+            const unsigned rowF = YD_ROWS_RESBATCH ? (unsigned)rowsFin : (unsigned)(i - 2), m = rowF < (unsigned)leftR ? rowF : (unsigned)leftR, nCells = __umul24((unsigned)YD_LW,
+                rowF) - (__umul24((unsigned)(leftR + 1), m) - __umul24(m, m + 1u) / 2u);
             rows += rowF; cells += nCells;
             int maxj = 0;                                                     // the first column of the kept strip's half that holds the maximum
 #pragma unroll
-            for (int k = YD_NP - 1; k >= 0; k--) { const int v = maxSide ? (int)(short)(SV[k] >> 16) : (int)(short)(SV[k] & 0xFFFFu); if (v == maxScore - (GO + GE)) maxj = k + (maxSide ? YD_NP : 0); }      // (the strip holds Vg)
+            // (the strip holds Vg)
+            for (int k = YD_NP - 1; k >= 0; k--) { const int v = maxSide ? (int)(short)(SV[k] >> 16) : (int)(short)(SV[k] & 0xFFFFu);
+                if (v == maxScore - (GO + GE)) maxj = k + (maxSide ? YD_NP : 0); }
             ExtRes r; r.score = maxScore > 0 ? maxScore : 0; r.maxi = maxi; r.maxj = maxj; r.opsOff = pStart >> 4; r.nOps = 0;
             r.where = (pStart & 15u) | ((uint32_t)lane << 4) | (wave << 10); r.rows = rowF; r.cells = nCells;
             // (the result, like the trace blocks, is stored non-temporally, and the pool's problem records are loaded so: neither comes back to this kernel's L2)
-            { const yd_u32x4 lo = {(uint32_t)r.score, (uint32_t)r.maxi, (uint32_t)r.maxj, r.opsOff}, hi = {r.nOps, r.where, r.rows, r.cells}; YD_GLOBAL yd_u32x4 *dst = (YD_GLOBAL yd_u32x4 *)toGlobal(&A.res[pendRes]); YD_STORE_NT(dst, lo); YD_STORE_NT(dst + 1, hi); } pendRes = -1;
+            { const yd_u32x4 lo = {(uint32_t)r.score, (uint32_t)r.maxi, (uint32_t)r.maxj, r.opsOff}, hi = {r.nOps, r.where, r.rows, r.cells};
+                YD_GLOBAL yd_u32x4 *dst = (YD_GLOBAL yd_u32x4 *)toGlobal(&A.res[pendRes]); YD_STORE_NT(dst, lo); YD_STORE_NT(dst + 1, hi); } pendRes = -1;
         }
         flushBlocks(flushNow, flushSlot);
         if (last) break;
@@ -391,7 +411,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
             const uint32_t dT = pkSub(PE, V);                                // >= 0: E wins over G ('>=' in extension mode, SW.cpp:1036)
             V = pkMax(V, PE);
             uint32_t upV, upF;
-            if (k + 1 < YD_NP) { upV = PV[k + 1]; upF = PF[k + 1]; } else { upV = PV[0] >> 16; upF = PF[0] >> 16; }      // column 10's upper neighbour = column 11 of row i-1, just computed
+            // column 10's upper neighbour = column 11 of row i-1, just computed
+            if (k + 1 < YD_NP) { upV = PV[k + 1]; upF = PF[k + 1]; } else { upV = PV[0] >> 16; upF = PF[0] >> 16; }
             const uint32_t CF = pkSub(upF, GEp), NF = upV;
             const uint32_t F = pkMax(CF, NF);
             const uint32_t dF = pkSub(CF, NF);
@@ -450,7 +471,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { cc += (unsigned long long)__shfl_xor((long long)cc, d, 64); }
 #ifdef YD_PROF
-    if (lane == 0 && !SECOND) { const unsigned v[7] = {pfPass, pfRes, pfRefill, pfSnap, pfBusy, pfFlush, pfPool}; for (int k = 0; k < 7; k++) atomicAdd(&gRowsProf[k], (unsigned long long)v[k]); }
+    if (lane == 0 && !SECOND) { const unsigned v[7] = {pfPass, pfRes, pfRefill, pfSnap, pfBusy, pfFlush, pfPool};
+        for (int k = 0; k < 7; k++) atomicAdd(&gRowsProf[k], (unsigned long long)v[k]); }
 #endif
     if (lane == 0 && !SECOND && A.ctr) {
         unsigned long long *c = A.ctr->v;
@@ -462,22 +484,28 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
 // ---- traceback over the packed records, lane per problem (SW.cpp:1138-1195; see k_ext_trace for the staging of the ops inside the strip) ---------------
 // Logical strip: record n (1-based, + phase) = dwords [(n-1)/8 * 32 + (n-1)%8 * 4, +4).  Cell (y, x) is pair k = x % 11 (x < 22), half h = x / 11, of record y + h.
 struct PkRec { uint32_t a, m, ab2, b; };
-__device__ __forceinline__ PkRec pkLoadRec(YD_GLOBAL const uint32_t *cp) { const yd_u32x4 v = *(YD_GLOBAL const yd_u32x4 *)cp; PkRec r; r.ab2 = v.x; r.m = v.y; r.a = v.z; r.b = v.w; return r; }
+__device__ __forceinline__ PkRec pkLoadRec(YD_GLOBAL const uint32_t *cp) { const yd_u32x4 v = *(YD_GLOBAL const yd_u32x4 *)cp; PkRec r; r.ab2 = v.x; r.m = v.y; r.a = v.z;
+    r.b = v.w; return r; }
 __device__ __forceinline__ int pkRecWord(int n) { return ((n - 1) >> 3) * 32 + ((n - 1) & 7) * 4; }
-__device__ __forceinline__ bool pkContE(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6; return ((d >> (8 * h + bit)) & 1u) == 0u; }
-__device__ __forceinline__ bool pkContF(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6; return ((d >> (16 + 8 * h + bit)) & 1u) == 0u; }
-#define YD_TSTRIDE 36          // dwords per problem in the traceback's block cache (32 + padding; 16-byte aligned).  (32 with an XOR swizzle -- a fifth workgroup per CU -- was no faster.)
+__device__ __forceinline__ bool pkContE(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6;
+    return ((d >> (8 * h + bit)) & 1u) == 0u; }
+__device__ __forceinline__ bool pkContF(const PkRec &r, int k, int h) { const uint32_t d = k < 8 ? r.b : r.ab2; const int bit = k < 8 ? k : k - 6;
+    return ((d >> (16 + 8 * h + bit)) & 1u) == 0u; }
+// dwords per problem in the traceback's block cache (32 + padding; 16-byte aligned).  (32 with an XOR swizzle -- a fifth workgroup per CU -- was no faster.)
+#define YD_TSTRIDE 36
 // Inside a problem's block the four dwords of every 16-byte record are stored XOR-ed by (problem >> 3) & 3 (YD_TSWZ).  A lane reads single dwords of its own
 // problem's records (ds_read_b32: 32 lanes a group, bank = dword address mod 32): with stride 36 and whole records in place lane l's dword c of slot s sits on bank
 // 4 (l + s) + c -- the 32 lanes of a group on the eight banks that are c modulo 4, four lanes each (33.6 % of the kernel's LDS cycles were such conflicts, rounds 3-4).
 // With the dword index XOR-ed by the lane's (l >> 3) & 3 the four lanes that shared a bank read four different ones.  The staging store writes whole records, eight
 // lanes to a problem, (problem >> 3) & 3 = g & 3 a compile-time constant of the unrolled loop: the permutation is a renaming of the four registers it stores.
 #ifndef YD_TRACE_SWZ
-#define YD_TRACE_SWZ 0                          // (measured: 3.23 -> 3.39 ms a launch WITH the swizzle, profiles/r05_trace_swizzle.txt -- the XORs and six more registers cost more than the conflicts)
+// (measured: 3.23 -> 3.39 ms a launch WITH the swizzle, profiles/r05_trace_swizzle.txt -- the XORs and six more registers cost more than the conflicts)
+#define YD_TRACE_SWZ 0
 #endif
 #define YD_TSWZ(problem) (YD_TRACE_SWZ ? (((problem) >> 3) & 3) : 0)
 #ifndef YD_TRACE_BS
-#define YD_TRACE_BS 256                       // threads of a traceback workgroup (its waves are independent: the size only sets the granule of LDS -- 9 KB a wave -- a CU hands out)
+// threads of a traceback workgroup (its waves are independent: the size only sets the granule of LDS -- 9 KB a wave -- a CU hands out)
+#define YD_TRACE_BS 256
 #endif
 __global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
 {
@@ -515,7 +543,8 @@ __global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
             c.w -= 4;
             if (c.rr != 0) { c.rr--; c.cp -= 4; return; }
             c.rr = 7; c.fb--;
-            if (c.fb % YD_CHUNK_FLUSHES == YD_CHUNK_FLUSHES - 1u) c.cp = S.arena + (size_t)S.tab[c.fb / YD_CHUNK_FLUSHES] * YD_CHUNK_DWORDS + S.laneOff + (YD_CHUNK_FLUSHES - 1u) * 32u + 28u;
+            if (c.fb % YD_CHUNK_FLUSHES == YD_CHUNK_FLUSHES - 1u) c.cp = S.arena + (size_t)S.tab[c.fb / YD_CHUNK_FLUSHES] * YD_CHUNK_DWORDS + S.laneOff + (YD_CHUNK_FLUSHES - 1u) *
+                32u + 28u;
             else c.cp -= 4;
         };
         // free for staging: the records above record (cursor + 1) -- the record after the cursor's may still hold the high half of the cursor's row
@@ -529,9 +558,12 @@ __global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
 #pragma unroll
                 for (int g = 0; g < 8; g++) {
                     const int src = g * 8 + (lane >> 3);
-                    const unsigned long long b = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(myBase >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myBase, src, 64);
+                    const unsigned long long b = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(myBase >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myBase, src,
+                        64);
                     const yd_u32x4 v = *(YD_GLOBAL const yd_u32x4 *)((YD_GLOBAL const uint32_t *)b + (lane & 7) * 4);
-                    yd_u32x4 sw; { const uint32_t c[4] = {v.x, v.y, v.z, v.w}; constexpr int z = YD_TRACE_SWZ ? 3 : 0; sw.x = c[(0 ^ g) & z]; sw.y = c[1 ^ (g & z)]; sw.z = c[2 ^ (g & z)]; sw.w = c[3 ^ (g & z)]; }      // YD_TSWZ(src) = g & 3 (a renaming: g is a constant of the unrolled loop)
+                    // YD_TSWZ(src) = g & 3 (a renaming: g is a constant of the unrolled loop)
+                    yd_u32x4 sw; { const uint32_t c[4] = {v.x, v.y, v.z, v.w}; constexpr int z = YD_TRACE_SWZ ? 3 : 0; sw.x = c[(0 ^ g) & z]; sw.y = c[1 ^ (g & z)];
+                        sw.z = c[2 ^ (g & z)]; sw.w = c[3 ^ (g & z)]; }
                     *(yd_u32x4 *)(wBlk + src * YD_TSTRIDE + (lane & 7) * 4) = sw;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -560,7 +592,8 @@ __global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
             const uint32_t inLim = (1u << lim) - 1u;
             const int took = __builtin_ctz(~diag | ~inLim);                  // rows of the run (0 .. lim)
             int op = 0;
-            if (took < lim) { const int sl = rr0 - took; const uint32_t tu = myRec[sl * 4 + iTU]; op = ((tu >> sU) & 1u) == 0u ? OP_I : OP_D; }      // what stops the run: a gap op (the row is inside the block: took < lim <= rr0 + 1)
+            // what stops the run: a gap op (the row is inside the block: took < lim <= rr0 + 1)
+            if (took < lim) { const int sl = rr0 - took; const uint32_t tu = myRec[sl * 4 + iTU]; op = ((tu >> sU) & 1u) == 0u ? OP_I : OP_D; }
             y -= took;
             if (took > 0) {                                                   // the cursor moves up took rows inside the block (the step out of it is stepUp's); before the
                 const int mv = took < lim ? took : took - 1;                  // ops are staged: every row of the run has been decoded, its records are free

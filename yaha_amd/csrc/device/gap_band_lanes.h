@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(64) k_gap_band(AlignArgs A, PhaseArgs X)
             for (int k = 0; k < RD; k++) {
                 uint32_t acc = 0;
 #pragma unroll
-                for (int b = 0; b < 4; b++) { const int c = 4 * k + b; const uint32_t cell = c == left ? TR_U8 : ((c > left && c < W) ? (uint32_t)(OP_D | ((c - left) << 2)) : 0u); acc |= cell << (8 * b); }
+                for (int b = 0; b < 4; b++) { const int c = 4 * k + b; const uint32_t cell = c == left ? TR_U8 : ((c > left && c < W) ? (uint32_t)(OP_D | ((c - left) << 2)) : 0u);
+                    acc |= cell << (8 * b); }
                 T32[k * 64] = acc;
             }
             // reference window of row 1: column c holds reference index c - left

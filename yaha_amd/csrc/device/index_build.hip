@@ -31,7 +31,8 @@ namespace {
 #define IX_SMALL 32u
 #define IX_BLOCK 8192u
 
-struct SeqTab { const uint32_t *start, *len; uint32_t n; int skip; const uint32_t *firstBad; };     // skip > 1: firstBad[s] = offset of the first code > 3 of sequence s (0xFFFFFFFF: none)
+// skip > 1: firstBad[s] = offset of the first code > 3 of sequence s (0xFFFFFFFF: none)
+struct SeqTab { const uint32_t *start, *len; uint32_t n; int skip; const uint32_t *firstBad; };
 
 __device__ __forceinline__ uint32_t nibAt(const uint8_t *b, uint64_t off) { const uint8_t v = b[off >> 1]; return (off & 1) ? (uint32_t)(v & 15u) : (uint32_t)(v >> 4); }
 
@@ -98,7 +99,8 @@ __global__ void k_ix_fill(const uint8_t *bases, SeqTab T, int k, uint64_t nOffse
     walkKmers(bases, T, k, p0, nOffsets, [&](uint32_t h, uint32_t off) { roa[so[h] + atomicAdd(&cursor[h], 1u)] = off; });
 }
 // lists of 2 .. IX_SMALL entries: in-place insertion sort by one thread; longer ones are listed for the workgroup / device sorts
-__global__ void k_ix_order_small(const uint32_t *so, uint64_t nKmers, uint32_t *roa, uint32_t *bigList, unsigned int *nBig, uint32_t bigCap, uint32_t *overList, unsigned int *nOver, uint32_t overCap, uint32_t maxHits)
+__global__ void k_ix_order_small(const uint32_t *so, uint64_t nKmers, uint32_t *roa, uint32_t *bigList, unsigned int *nBig, uint32_t bigCap, uint32_t *overList,
+    unsigned int *nOver, uint32_t overCap, uint32_t maxHits)
 {
     const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nKmers) return;
@@ -231,7 +233,8 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { err = "no such HIP device"; return false; }
     const bool timing = getenv("YAHA_TIMING") != nullptr; double tLast = wallNow();
-    auto lap = [&](const char *what) { if (timing && log) { hipDeviceSynchronize(); const double t = wallNow(); fprintf(log, "[yaha]   index on GPU: %-28s %7.2f s\n", what, t - tLast); tLast = t; } };
+    auto lap = [&](const char *what) { if (timing && log) { hipDeviceSynchronize(); const double t = wallNow();
+        fprintf(log, "[yaha]   index on GPU: %-28s %7.2f s\n", what, t - tLast); tLast = t; } };
     IXCHK(hipSetDevice(device));
     const uint64_t HT = 1ull << (2 * wordLen), nOffsets = g.nBaseBytes * 2;
     std::vector<uint32_t> st, ln; for (auto &s : g.seqs) if ((int64_t)s.length >= wordLen) { st.push_back(s.start); ln.push_back(s.length); }
@@ -259,7 +262,8 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
     // (scan.h: single pass, decoupled look-back; its state words clean themselves up, so the second sum below needs no memset)
     const size_t tb = scanStateBytes(HT + 1) + 64; IXCHK(hipMalloc(&dTemp.p, tb)); IXCHK(hipMemset(dTemp.p, 0, tb));
     unsigned int *scanFail = (unsigned int *)((char *)dTemp.p + scanStateBytes(HT + 1));
-    hipLaunchKernelGGL((k_scan_excl<uint32_t>), dim3(scanTiles(HT + 1)), dim3(YD_SCAN_BS), 0, 0, (const uint32_t *)dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (uint32_t)(HT + 1), dTemp.as<unsigned long long>(), scanFail);
+    hipLaunchKernelGGL((k_scan_excl<uint32_t>), dim3(scanTiles(HT + 1)), dim3(YD_SCAN_BS), 0, 0, (const uint32_t *)dCnt.as<uint32_t>(), dSO.as<uint32_t>(), (uint32_t)(HT + 1),
+        dTemp.as<unsigned long long>(), scanFail);
     IXCHK(hipGetLastError());
     uint32_t total = 0; IXCHK(hipMemcpy(&total, dSO.as<uint32_t>() + HT, 4, hipMemcpyDeviceToHost));
     lap("count + scan");
@@ -274,7 +278,8 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
     IXCHK(hipMalloc(&dBig.p, 4ull * bigCap)); IXCHK(hipMalloc(&dOver.p, 4ull * overCap)); IXCHK(hipMalloc(&dN.p, 8));
     for (int attempt = 0;; attempt++) {
         IXCHK(hipMemset(dN.p, 0, 8));
-        hipLaunchKernelGGL(k_ix_order_small, dim3((unsigned)((HT + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), HT, dROA.as<uint32_t>(), dBig.as<uint32_t>(), dN.as<unsigned int>(), bigCap,
+        hipLaunchKernelGGL(k_ix_order_small, dim3((unsigned)((HT + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), HT, dROA.as<uint32_t>(), dBig.as<uint32_t>(),
+            dN.as<unsigned int>(), bigCap,
                            dOver.as<uint32_t>(), dN.as<unsigned int>() + 1, overCap, (uint32_t)maxHits);
         IXCHK(hipGetLastError()); IXCHK(hipMemcpy(two, dN.p, 8, hipMemcpyDeviceToHost));
         if (two[0] <= bigCap && two[1] <= overCap) break;
@@ -287,12 +292,14 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
     std::vector<uint32_t> hSOpair;                       // startingOffs of the long lists
     if (nBig) {
         // (YAHA_IX_HUGE_MIN: a test hook -- lists above that many entries take the multi-workgroup sort, 8 192 = what a workgroup's LDS holds otherwise)
-        uint32_t hugeMin = IX_BLOCK; if (const char *e = getenv("YAHA_IX_HUGE_MIN")) { const long v = atol(e); if (v >= (long)IX_SMALL && v < (long)IX_BLOCK) hugeMin = (uint32_t)v; }
+        uint32_t hugeMin = IX_BLOCK; if (const char *e = getenv("YAHA_IX_HUGE_MIN")) { const long v = atol(e); if (v >= (long)IX_SMALL && v < (long)IX_BLOCK) hugeMin = (uint32_t)v;
+            }
         hipLaunchKernelGGL(k_ix_order_block, dim3(std::min<uint32_t>(nBig, 4096u)), dim3(256), 0, 0, dSO.as<uint32_t>(), dBig.as<uint32_t>(), nBig, dROA.as<uint32_t>(), hugeMin);
         IXCHK(hipGetLastError());
         // the few lists beyond a workgroup's LDS: a bitonic network over a padded copy each (k_ix_bitonic_*)
         Buf dHuge; IXCHK(hipMalloc(&dHuge.p, 16ull * nBig + 16)); IXCHK(hipMemset(dN.p, 0, 4));
-        hipLaunchKernelGGL(k_ix_gather, dim3((nBig + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), (const uint32_t *)nullptr, dBig.as<uint32_t>(), nBig, hugeMin, dHuge.as<uint32_t>(), dN.as<unsigned int>());
+        hipLaunchKernelGGL(k_ix_gather, dim3((nBig + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), (const uint32_t *)nullptr, dBig.as<uint32_t>(), nBig, hugeMin,
+            dHuge.as<uint32_t>(), dN.as<unsigned int>());
         IXCHK(hipGetLastError());
         unsigned int nHuge = 0; IXCHK(hipMemcpy(&nHuge, dN.p, 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> huge(4ull * nHuge); if (nHuge) IXCHK(hipMemcpy(huge.data(), dHuge.p, 16ull * nHuge, hipMemcpyDeviceToHost));
@@ -306,7 +313,8 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
             const unsigned lblocks = (m + IX_BLOCK - 1) / IX_BLOCK;
             hipLaunchKernelGGL(k_ix_bitonic_local, dim3(lblocks), dim3(256), 0, 0, alt, m, (uint32_t)IX_BLOCK, true);
             for (uint32_t size = 2 * IX_BLOCK; size <= m && size != 0; size <<= 1) {
-                for (uint32_t stride = size >> 1; stride >= IX_BLOCK; stride >>= 1) hipLaunchKernelGGL(k_ix_bitonic_global, dim3((m / 2 + 255) / 256), dim3(256), 0, 0, alt, m, size, stride);
+                for (uint32_t stride = size >> 1; stride >= IX_BLOCK; stride >>= 1) hipLaunchKernelGGL(k_ix_bitonic_global, dim3((m / 2 + 255) / 256), dim3(256), 0, 0, alt, m,
+                    size, stride);
                 hipLaunchKernelGGL(k_ix_bitonic_local, dim3(lblocks), dim3(256), 0, 0, alt, m, size, false);
             }
             IXCHK(hipGetLastError());
@@ -324,20 +332,24 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
         IXCHK(hipMalloc(&dSO2.p, 4ull * (HT + 1)));
         hipLaunchKernelGGL(k_ix_clamp, dim3((unsigned)((HT + 1 + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), HT, (uint32_t)maxHits, dCnt.as<uint32_t>());
         IXCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_scan_excl<uint32_t>), dim3(scanTiles(HT + 1)), dim3(YD_SCAN_BS), 0, 0, (const uint32_t *)dCnt.as<uint32_t>(), dSO2.as<uint32_t>(), (uint32_t)(HT + 1), dTemp.as<unsigned long long>(), scanFail);
+        hipLaunchKernelGGL((k_scan_excl<uint32_t>), dim3(scanTiles(HT + 1)), dim3(YD_SCAN_BS), 0, 0, (const uint32_t *)dCnt.as<uint32_t>(), dSO2.as<uint32_t>(), (uint32_t)(HT + 1),
+            dTemp.as<unsigned long long>(), scanFail);
         IXCHK(hipGetLastError());
         IXCHK(hipMemcpy(&newTotal, dSO2.as<uint32_t>() + HT, 4, hipMemcpyDeviceToHost));
         IXCHK(hipMalloc(&dROA2.p, 4ull * ((uint64_t)newTotal + 16)));
-        hipLaunchKernelGGL(k_ix_compact, dim3((unsigned)((HT + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), HT, (uint32_t)maxHits, dROA.as<uint32_t>(), dROA2.as<uint32_t>());
+        hipLaunchKernelGGL(k_ix_compact, dim3((unsigned)((HT + 255) / 256)), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), HT, (uint32_t)maxHits, dROA.as<uint32_t>(),
+            dROA2.as<uint32_t>());
         IXCHK(hipGetLastError());
         RandState rs; randInitDefault(rs);
         Buf dOv; IXCHK(hipMalloc(&dOv.p, 16ull * nOver + 16)); IXCHK(hipMemset(dN.p, 0, 4));
         IXCHK(hipMemcpy(dOver.p, over.data(), 4ull * nOver, hipMemcpyHostToDevice));        // ascending now
-        hipLaunchKernelGGL(k_ix_gather, dim3((nOver + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), dOver.as<uint32_t>(), nOver, 0u, dOv.as<uint32_t>(), dN.as<unsigned int>());
+        hipLaunchKernelGGL(k_ix_gather, dim3((nOver + 255) / 256), dim3(256), 0, 0, dSO.as<uint32_t>(), dSO2.as<uint32_t>(), dOver.as<uint32_t>(), nOver, 0u, dOv.as<uint32_t>(),
+            dN.as<unsigned int>());
         IXCHK(hipGetLastError());
         std::vector<uint32_t> ov(4ull * nOver); IXCHK(hipMemcpy(ov.data(), dOv.p, 16ull * nOver, hipMemcpyDeviceToHost));
         std::vector<size_t> idx(nOver); for (size_t k = 0; k < nOver; k++) idx[k] = k;
-        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ov[4 * a] < ov[4 * b]; });   // the gather's atomics shuffled them: back to k-mer order (the generator's order)
+        // the gather's atomics shuffled them: back to k-mer order (the generator's order)
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ov[4 * a] < ov[4 * b]; });
         // groups of lists of at most 64 M entries: pack on the device, one copy down, sample on the host in k-mer order (the generator is sequential by
         // definition), one copy of the samples up, scatter on the device
         const uint64_t groupCap = 64ull << 20;
@@ -352,9 +364,11 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
             }
             const uint32_t nl = (uint32_t)(g1 - g0);
             dDesc.release(); dDst.release(); dPacked.release(); dSamples.release();
-            IXCHK(hipMalloc(&dDesc.p, 16ull * nl)); IXCHK(hipMalloc(&dDst.p, 4ull * nl)); IXCHK(hipMalloc(&dPacked.p, 4ull * tot + 16)); IXCHK(hipMalloc(&dSamples.p, 4ull * (uint64_t)nl * (uint64_t)maxHits + 16));
+            IXCHK(hipMalloc(&dDesc.p, 16ull * nl)); IXCHK(hipMalloc(&dDst.p, 4ull * nl)); IXCHK(hipMalloc(&dPacked.p, 4ull * tot + 16));
+                IXCHK(hipMalloc(&dSamples.p, 4ull * (uint64_t)nl * (uint64_t)maxHits + 16));
             IXCHK(hipMemcpy(dDesc.p, desc.data(), 16ull * nl, hipMemcpyHostToDevice)); IXCHK(hipMemcpy(dDst.p, dst.data(), 4ull * nl, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_ix_pack, dim3((unsigned)(((uint64_t)nl * 64 + 255) / 256)), dim3(256), 0, 0, dROA.as<uint32_t>(), dDesc.as<uint32_t>(), nl, dPacked.as<uint32_t>());
+            hipLaunchKernelGGL(k_ix_pack, dim3((unsigned)(((uint64_t)nl * 64 + 255) / 256)), dim3(256), 0, 0, dROA.as<uint32_t>(), dDesc.as<uint32_t>(), nl,
+                dPacked.as<uint32_t>());
             IXCHK(hipGetLastError());
             packed.resize(tot); IXCHK(hipMemcpy(packed.data(), dPacked.p, 4ull * tot, hipMemcpyDeviceToHost));
             samples.resize((size_t)nl * (size_t)maxHits);
@@ -363,7 +377,8 @@ bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, in
                 randSample(rs, packed.data() + o, (int)desc[4 * l + 1], samples.data() + (size_t)l * (size_t)maxHits, maxHits);
             }
             IXCHK(hipMemcpy(dSamples.p, samples.data(), 4ull * samples.size(), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_ix_unpack, dim3((unsigned)(((uint64_t)nl * 64 + 255) / 256)), dim3(256), 0, 0, dSamples.as<uint32_t>(), dDst.as<uint32_t>(), nl, (uint32_t)maxHits, dROA2.as<uint32_t>());
+            hipLaunchKernelGGL(k_ix_unpack, dim3((unsigned)(((uint64_t)nl * 64 + 255) / 256)), dim3(256), 0, 0, dSamples.as<uint32_t>(), dDst.as<uint32_t>(), nl, (uint32_t)maxHits,
+                dROA2.as<uint32_t>());
             IXCHK(hipGetLastError());
             g0 = g1;
         }

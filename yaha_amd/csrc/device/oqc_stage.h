@@ -9,13 +9,17 @@
 
 struct OqcArgs {
     yoqc::Params P; yoqc::Seqs G;
-    const uint32_t *cs; const ygpu_clump *cl; const uint32_t *ops; const uint32_t *seeds, *qlen; uint32_t nReads;      // (the batch's results as ygpu_postfilter_snapshot copied them; five seed words and the length of every read)
+    // (the batch's results as ygpu_postfilter_snapshot copied them; five seed words and the length of every read)
+    const uint32_t *cs; const ygpu_clump *cl; const uint32_t *ops; const uint32_t *seeds, *qlen; uint32_t nReads;
     const unsigned long long *poolOff;
     yoqc::SortKey *keys; int *stack; yoqc::CNode *nodes, *prim; yoqc::PAttr *pa; int *pfxOff, *path, *pool; yoqc::OutRec *push, *out;
     uint32_t *outCnt, *outOpsCnt; uint32_t *primCnt;
     int devMax;                        // reads with more clumps are left to the host (YQ_DEVICE_MAX; YGPU_OQC_MAX lowers it in tests)
-    int graphInHbm;                    // test hook (YGPU_OQC_HBM=1): every read's nodes and tables in HBM -- the path of a read whose survivors do not fit its LDS, which real batches hardly ever take
-    unsigned long long *prof;          // YGPU_OQC_PROF=1: 100 MHz ticks per step of k_oqc_wave, summed over the reads and the largest of any read (keys, sort, duplicate scan, nodes + tables, walk along the path, successors, finish), per class
+    // test hook (YGPU_OQC_HBM=1): every read's nodes and tables in HBM -- the path of a read whose survivors do not fit its LDS, which real batches hardly ever take
+    int graphInHbm;
+    // YGPU_OQC_PROF=1: 100 MHz ticks per step of k_oqc_wave, summed over the reads and the largest of any read (keys, sort, duplicate scan, nodes + tables, walk along the path,
+    // successors, finish), per class
+    unsigned long long *prof;
 };
 // What the routine costs on a GPU, measured: one read per lane with its work space in HBM took 75 ms a batch (a few thousand DEPENDENT accesses a read, microseconds
 // each); one read per wave, first lane only, with the work space in LDS still 39 ms for the reads of 320..640 clumps -- the graph loop is quadratic in the nodes that survive the
@@ -26,7 +30,8 @@ struct OqcArgs {
 // the best path before each node's successors, the choice of the best node, the similarity filter.
 // Reads come in classes by their number of clumps (the LDS a workgroup gets is fixed at launch): keys + sort stack, then nodes + table index + path + tables share it.
 #define YQ_NCLASS 5
-#define YQ_DEVICE_MAX 1792           // clumps of the largest read the device stage filters: its sort (waveSort: 36 bytes a clump) fits the 64 KB a workgroup may ask for (see k_oqc_raw)
+// clumps of the largest read the device stage filters: its sort (waveSort: 36 bytes a clump) fits the 64 KB a workgroup may ask for (see k_oqc_raw)
+#define YQ_DEVICE_MAX 1792
 #define YQ_SORT_LDS 36u               // LDS bytes a clump during the sort: the key record (16), two packed sort entries (8 + 8), one position (4)
 #define YQ_STACK_LDS 128              // ints of the sort's stack kept in LDS (depth ~2 log2 n ranges); deeper recursion continues in HBM
 #define YQ_THR_LDS 64                 // break point thresholds copied to LDS (every lane searches them for every successor it relaxes); a longer table stays in HBM
@@ -52,7 +57,8 @@ __global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *li
     unsigned long long v = 0; int cls = -1;
     if (r < A.nReads) {
         const uint32_t b = A.cs[r], n = A.cs[r + 1] - b;
-        if (n >= 2) { for (uint32_t c = b; c < b + n; c++) v += 2ull * (unsigned long long)A.cl[c].n_ops + 3ull; cls = 0; while (n > (uint32_t)kOqcCapN[cls]) cls++; if (n > (uint32_t)A.devMax) cls = YQ_NCLASS - 1; }
+        if (n >= 2) { for (uint32_t c = b; c < b + n; c++) v += 2ull * (unsigned long long)A.cl[c].n_ops + 3ull; cls = 0; while (n > (uint32_t)kOqcCapN[cls]) cls++;
+            if (n > (uint32_t)A.devMax) cls = YQ_NCLASS - 1; }
         else {
             uint32_t m = 0, nops = 0; int pc = 0;
             if (n == 1) { m = (uint32_t)yoqc::single(A.cl + b, A.out + b, &pc); nops = A.cl[b].n_ops; }
@@ -84,7 +90,8 @@ __global__ void k_oqc_classify(OqcArgs A, unsigned long long *need, uint32_t *li
 // through an LDS copy.  The recursion is the reference's: the left part completely before the right part (the right part waits on the stack).
 // A partition costs ~1 000 cycles whatever its length, a read of 50 clumps 20 us instead of 220, one of 550 under 0.2 ms instead of 2.
 __device__ __forceinline__ uint32_t yqLanesBelow(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
-__device__ __forceinline__ uint64_t yqShfl64(uint64_t v, int src) { return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64); }
+__device__ __forceinline__ uint64_t yqShfl64(uint64_t v, int src) {
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64); }
 __device__ __forceinline__ unsigned long long yqDraw(yoqc::Rand &rs, int t)        // the next t random bits (t <= 64, uniform), bit d = draw d
 { unsigned long long m = 0; for (int d = 0; d < t; d++) m |= (unsigned long long)(yoqc::randBits(rs) & 1u) << d; return m; }
 // a[0..n): sort entries (48-bit key << 16 | clump) in LDS; a2 (n entries) and pos (n ints): scratch in LDS; stk/stk2: the stack of waiting right parts (stkCap even)
@@ -106,7 +113,8 @@ __device__ __forceinline__ void waveSort(uint64_t *a, uint64_t *a2, int *pos, in
         if (m < 64) {
             const int k = lane; const bool valid = k < m; const int idx = left + k;
             const uint64_t E = k <= m ? a[idx == pivotIdx ? right : k == m ? pivotIdx : idx] : ~0ull; const uint64_t ek = E >> 16;      // (lane m reads the pivot: one trip to LDS)
-            const uint64_t P = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(E >> 32), m) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)E, m); const uint64_t pk = P >> 16;
+            const uint64_t P = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(E >> 32), m) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)E, m);
+                const uint64_t pk = P >> 16;
             bool less = valid && ek < pk; const bool eq = valid && ek == pk;
             const unsigned long long eqMask = __ballot(eq);
             if (eqMask) { const unsigned long long bits = yqDraw(rs, __builtin_popcountll(eqMask)); if (eq) less = ((bits >> yqLanesBelow(eqMask)) & 1ull) != 0; }
@@ -155,7 +163,8 @@ __device__ __forceinline__ void waveSort(uint64_t *a, uint64_t *a2, int *pos, in
         right = store - 1;
     }
 }
-// test entry (ygpu_selftest_primitives): array t = ent[off[t] .. off[t + 1]) sorted by waveSort with the generator seeded from seeds[5 t ..]; LDS: stack | entries | copy | positions
+// test entry (ygpu_selftest_primitives): array t = ent[off[t] .. off[t + 1]) sorted by waveSort with the generator seeded from seeds[5 t ..]; LDS: stack | entries | copy |
+// positions
 __global__ void __launch_bounds__(64) k_oqc_sort_test(uint64_t *ent, const uint32_t *off, const uint32_t *seeds, int *stack2, uint32_t count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sOqc[];
@@ -180,7 +189,8 @@ __global__ void k_oqc_raw(OqcArgs A, const uint32_t *list, uint32_t count)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const uint32_t r = list[t], b = A.cs[r], n = A.cs[r + 1] - b; uint32_t nops = 0;
-    for (uint32_t k = 0; k < n; k++) { yoqc::OutRec o; o.clump = (int)k; o.status = A.cl[b + k].status; o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = 0; o.pad = 0; A.out[b + k] = o; nops += A.cl[b + k].n_ops; }
+    for (uint32_t k = 0; k < n; k++) { yoqc::OutRec o; o.clump = (int)k; o.status = A.cl[b + k].status; o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = 0; o.pad = 0;
+        A.out[b + k] = o; nops += A.cl[b + k].n_ops; }
     A.outCnt[r] = n; A.outOpsCnt[r] = nops; A.primCnt[r] = 0xFFFFu;
 }
 // filterBySimilarity + mapping quality (oqc_core.h finish, :571-692) with the wave: what a node contributes -- the primary it overlaps most and whether it is similar
@@ -215,7 +225,8 @@ __device__ __forceinline__ int waveFinish(yoqc::Run &X, int cnt, int bestNode, y
             }
             if (maxOverlap > 0) {
                 c = maxIndex | (((int)cn.nodeScore & 0xFFFF) << 12);
-                if (similarEnough(cn.nodeScore, prim[maxIndex].nodeScore, X.P.FBS_PSScore) && overlapsEnough(maxOverlap, curQLen, targetOverlap) && overlapsEnough(maxOverlap, pa[maxIndex].alignedQueryLength, targetOverlap)) c |= 1 << 30;
+                if (similarEnough(cn.nodeScore, prim[maxIndex].nodeScore, X.P.FBS_PSScore) && overlapsEnough(maxOverlap, curQLen, targetOverlap) && overlapsEnough(maxOverlap,
+                    pa[maxIndex].alignedQueryLength, targetOverlap)) c |= 1 << 30;
             }
         }
         code[i] = c;
@@ -231,7 +242,8 @@ __device__ __forceinline__ int waveFinish(yoqc::Run &X, int cnt, int bestNode, y
             if (ns > a.secondScore) { a.thirdScore = a.secondScore; a.secondScore = ns; } else if (ns > a.thirdScore) a.thirdScore = ns;      // memoPAsFromOverlappingNode :545-557
             if (c & (1 << 30)) {
                 a.numOutputSecondaries += 1;
-                if (X.P.FBS) { OutRec o; o.clump = gn[i].clump; o.status = 0; o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(mi + 1); o.pad = 0; push[nPush++] = o; }
+                if (X.P.FBS) { OutRec o; o.clump = gn[i].clump; o.status = 0; o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(mi + 1); o.pad = 0;
+                    push[nPush++] = o; }
             }
             pa[mi] = a;
         }
@@ -241,7 +253,8 @@ __device__ __forceinline__ int waveFinish(yoqc::Run &X, int cnt, int bestNode, y
     // print order = the reverse of the push order; status and (primaries) mapping quality filled in on the way
     for (int k = lane; k < nPush; k += 64) {
         OutRec o = push[k]; const ygpu_clump &c = cl[o.clump];
-        if (k < primeCount) { const PAttr a = pa[primeCount - 1 - k]; o.status = (uint8_t)(c.status | stPrimary); o.mapQuality = mapQuality((int)c.totScore, a.secondScore, a.thirdScore); o.numSecondaries = (uint16_t)a.numOutputSecondaries; }
+        if (k < primeCount) { const PAttr a = pa[primeCount - 1 - k]; o.status = (uint8_t)(c.status | stPrimary);
+            o.mapQuality = mapQuality((int)c.totScore, a.secondScore, a.thirdScore); o.numSecondaries = (uint16_t)a.numOutputSecondaries; }
         else o.status = c.status;
         out[nPush - 1 - k] = o;
     }
@@ -253,7 +266,8 @@ __device__ __forceinline__ int waveFinish(yoqc::Run &X, int cnt, int bestNode, y
 // false: everything in the read's slices of the batch-wide HBM arrays.  (One body whose pointers may be either costs a `flat` access -- it waits for all of the
 // wave's memory traffic -- at every step of the one-lane parts: the walk along the path, the tables' binary searches.)
 template <bool LDS>
-__device__ __forceinline__ void oqcGraph(const OqcArgs &A, const yoqc::Params &P, yoqc::Scratch S, unsigned char *sMain, unsigned mainBytes, uint32_t b, uint32_t r, int n, int cnt, int qlen, int lane, unsigned long long *tk)
+__device__ __forceinline__ void oqcGraph(const OqcArgs &A, const yoqc::Params &P, yoqc::Scratch S, unsigned char *sMain, unsigned mainBytes, uint32_t b, uint32_t r, int n, int cnt,
+    int qlen, int lane, unsigned long long *tk)
 {
     const bool prof = A.prof != nullptr; unsigned long long tPath = 0, tSucc = 0;
     if (LDS) {
@@ -300,7 +314,8 @@ __device__ __forceinline__ void oqcGraph(const OqcArgs &A, const yoqc::Params &P
         const unsigned at = (48u * (unsigned)cnt + 15u) & ~15u; constexpr unsigned nodeB = (unsigned)sizeof(yoqc::CNode), attrB = (unsigned)sizeof(yoqc::PAttr);
         static_assert(sizeof(yoqc::CNode) % 4 == 0 && sizeof(yoqc::CNode) <= 40, "nodes, table index and path take 48 bytes a survivor");
         if (primeCount > 4095) m = lane == 0 ? (uint32_t)X.finish(cnt, bestNode, A.out + b, &primary) : 0u;
-        else if (LDS && at + (nodeB + attrB) * (unsigned)primeCount <= mainBytes) m = (uint32_t)waveFinish(X, cnt, bestNode, (yoqc::CNode *)(sMain + at), (yoqc::PAttr *)(sMain + at + nodeB * (unsigned)primeCount), A.out + b, &primary, lane);
+        else if (LDS && at + (nodeB + attrB) * (unsigned)primeCount <= mainBytes) m = (uint32_t)waveFinish(X, cnt, bestNode, (yoqc::CNode *)(sMain + at),
+            (yoqc::PAttr *)(sMain + at + nodeB * (unsigned)primeCount), A.out + b, &primary, lane);
         else m = (uint32_t)waveFinish(X, cnt, bestNode, X.S.prim, X.S.pa, A.out + b, &primary, lane);
         m = (uint32_t)__shfl((int)m, 0, 64); primary = __shfl(primary, 0, 64);
     }
@@ -316,7 +331,8 @@ __device__ __forceinline__ void oqcGraph(const OqcArgs &A, const yoqc::Params &P
             const unsigned long long ph[7] = {tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tPath, tSucc, t6 - tk[5]};
             for (int k = 0; k < 7; k++) { atomicAdd(&pp[k], ph[k]); atomicMax(&pp[16 + k], ph[k]); }
             atomicAdd(&pp[7], 1ull); atomicAdd(&pp[8], (unsigned long long)n); atomicAdd(&pp[9], (unsigned long long)cnt);
-            atomicMax(&pp[10], ((t6 - tk[0]) << 24) | ((unsigned long long)n << 12) | (unsigned long long)(cnt < 4095 ? cnt : 4095));      // the slowest read: ticks, clumps, survivors
+            // the slowest read: ticks, clumps, survivors
+            atomicMax(&pp[10], ((t6 - tk[0]) << 24) | ((unsigned long long)n << 12) | (unsigned long long)(cnt < 4095 ? cnt : 4095));
         }
     }
 }
@@ -383,7 +399,8 @@ __global__ void __launch_bounds__(64) k_oqc_wave(OqcArgs A, const uint32_t *list
             if (ci < 0) continue;
             const uint64_t ck = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kk >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kk, l);
             const int curEQO = yoqc::keyEQO(ck);
-            if (lane == 0) { yoqc::SortKey ki; ki.key = ck; ki.clump = ci; ki.pad = 0; X.S.keys[cnt] = ki; }      // survivors compacted in place (cnt <= blk + l: a place already in registers)
+            // survivors compacted in place (cnt <= blk + l: a place already in registers)
+            if (lane == 0) { yoqc::SortKey ki; ki.key = ck; ki.clump = ci; ki.pad = 0; X.S.keys[cnt] = ki; }
             cnt++;
             {
                 const bool live = lane > l && kc >= 0, ends = live && yoqc::keyEQO(kk) > curEQO;
@@ -428,7 +445,8 @@ __global__ void __launch_bounds__(256) k_oqc_gather(OqcArgs A, const uint32_t *o
             const uint32_t dst = od + incl - nops; const uint32_t *src = A.ops + c.op_start;
             for (uint32_t i = 0; i < nops; i++) fOps[dst + i] = src[i];
             c.op_start = dst;
-            ygpu_out_clump f; f.c = c; f.status = o.status; f.mapQuality = o.mapQuality; f.numSecondaries = o.numSecondaries; f.matchedPrimary = o.matchedPrimary; f.primaryCount = pc;
+            ygpu_out_clump f; f.c = c; f.status = o.status; f.mapQuality = o.mapQuality; f.numSecondaries = o.numSecondaries; f.matchedPrimary = o.matchedPrimary;
+                f.primaryCount = pc;
             fClumps[d + k] = f;
         }
         od += total;

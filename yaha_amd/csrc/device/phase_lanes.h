@@ -147,7 +147,8 @@ __device__ __forceinline__ int gapDPLane(const DevParams &P, YD_GLOBAL const uin
         uint32_t acc = 0;
         for (int j = 0; j < W; j++) {
             uint32_t cell = 0;
-            if (j == startInit - 1) cell = TR_U8; else if (j >= startInit) { const int dc = j - startInit + 1; cell = (uint32_t)(OP_D | (dc << 2)); GPV(j) = -(GO + dc * GE); GPF(j) = YD_WORST; GPI(j) = 0; }
+            if (j == startInit - 1) cell = TR_U8; else if (j >= startInit) { const int dc = j - startInit + 1; cell = (uint32_t)(OP_D | (dc << 2)); GPV(j) = -(GO + dc * GE);
+                GPF(j) = YD_WORST; GPI(j) = 0; }
             acc |= cell << (8 * (j & 3));
             if ((j & 3) == 3 || j == W - 1) { T32[(j >> 2) * 64] = acc; acc = 0; }
         }
@@ -301,7 +302,8 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
                         for (int t = 0; t < qGap; t++) mm += (uint32_t)q[(int)cur.eqo + 1 + t] != refAt(eRO + 1u + (uint32_t)t);
                         if (mm * (P.MS + P.RC) <= P.MS + 2 * (P.GO + P.GE)) { j.kind = JK_DIAG; j.score = P.MS * (qGap - mm) - P.RC * mm; }
                     }
-                    if (j.kind == JK_DP) { key = gapJointKey(P, banded, qGap, rGap); const uint32_t cls = gapJointClass(key); nDP++; nDP16 += cls <= 2u; nB12 += cls == 0u; nB16 += cls <= 1u; }
+                    if (j.kind == JK_DP) { key = gapJointKey(P, banded, qGap, rGap); const uint32_t cls = gapJointClass(key); nDP++; nDP16 += cls <= 2u; nB12 += cls == 0u;
+                        nB16 += cls <= 1u; }
                 }
                 X.joints[jb + (uint32_t)(k - 1)] = j; X.sortKeys[jb + (uint32_t)(k - 1)] = key; X.sortVals[jb + (uint32_t)(k - 1)] = jb + (uint32_t)(k - 1);
                 cur = nxt;
@@ -369,7 +371,8 @@ __global__ void __launch_bounds__(64) k_gap_wave(AlignArgs A, PhaseArgs X)
     const int lane = laneId();
     WaveMem M = carveScratch(A.scratch + (size_t)blockIdx.x * A.scratchPerWave, A.maxQ, A.traceRows, A.listCap, A.genCap);
     __shared__ uint16_t sTrace[YD_LDS_CELLS];
-    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.traceRows; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen; S.genCap = A.genCap; S.err = &err;
+    int err = 0; WaveScratch S; S.ldsTrace = sTrace; S.trace = M.trace; S.traceRows = A.traceRows; S.tmpOps = M.tmpOps; S.tmpCap = 2 * A.maxQ + 512; S.gen = M.gen;
+        S.genCap = A.genCap; S.err = &err;
     const unsigned n = uniU(*X.slowCount);
     for (;;) {
         if (__ballot(1) != ~0ull) { atomicCAS(A.errFlag, 0, (int)YERR_EXEC); break; }
@@ -400,7 +403,8 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
     const int n = (int)rec.nFrags; const uint32_t jb = live ? X.jointBase[r] : 0u;
     // exact upper bound of the list length
     unsigned want = 0;
-    if (live) { want = (unsigned)n + 1u; for (int k = 0; k + 1 < n; k++) { const JointRec &j = X.joints[jb + (uint32_t)k]; want += j.kind == JK_DP ? (unsigned)j.nOps : (j.kind == JK_DIAG ? (unsigned)j.qGap : (j.kind != JK_NONE ? 1u : 0u)); } }
+    if (live) { want = (unsigned)n + 1u; for (int k = 0; k + 1 < n; k++) { const JointRec &j = X.joints[jb + (uint32_t)k];
+        want += j.kind == JK_DP ? (unsigned)j.nOps : (j.kind == JK_DIAG ? (unsigned)j.qGap : (j.kind != JK_NONE ? 1u : 0u)); } }
     unsigned incl = want;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { unsigned t = (unsigned)__shfl_up((int)incl, d, 64); if (lane >= d) incl += t; }
@@ -416,7 +420,8 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
             auto refAt = [&](uint32_t off) -> uint32_t { const uint32_t b = gB[off >> 1]; return (off & 1u) ? (b & 15u) : (b >> 4); };
             const DevFrag *F = A.clumpFrags + rec.fragOff;
             uint32_t *ops = X.stateOps + slot; int nOut = 0, pc = -1, pl = 0, score = 0;
-            auto put = [&](int code, int len) { if (pc == code) { pl = (pl + len) & 0xFFFF; return; } if (pc >= 0) { ops[nOut] = opMake(pc, pl); nOut++; } pc = code; pl = len & 0xFFFF; };
+            auto put = [&](int code, int len) { if (pc == code) { pl = (pl + len) & 0xFFFF; return; } if (pc >= 0) { ops[nOut] = opMake(pc, pl); nOut++; } pc = code;
+                pl = len & 0xFFFF; };
             const DevFrag firstF = F[0]; DevFrag cur = firstF;
             for (int k = 1; k <= n; k++) {
                 { const int ql = fragQLen(cur.sqo, cur.eqo); put(OP_M, ql); score += P.MS * ql; }
@@ -429,7 +434,8 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
                     const int g = qGap;
                     for (int t = 0; t < g; t++) put((uint32_t)q[(int)j.nsqo + t] == refAt(j.nsro + (uint32_t)t) ? OP_M : OP_R, 1);
                     score += j.score; gapCalls++; gapRows += (unsigned)g; touched += (unsigned)g;
-                    if (P.bandWidth * 2 + 1 < g) { const int bw = P.bandWidth, W = 2 * bw + 1; for (int i = 1; i <= g; i++) { int sc = bw + 1 - i; if (sc < 0) sc = 0; int ec = bw + g - i; if (ec > W - 1) ec = W - 1; if (ec >= sc) gapCells += (unsigned)(ec - sc + 1); } }
+                    if (P.bandWidth * 2 + 1 < g) { const int bw = P.bandWidth, W = 2 * bw + 1; for (int i = 1; i <= g; i++) { int sc = bw + 1 - i; if (sc < 0) sc = 0;
+                        int ec = bw + g - i; if (ec > W - 1) ec = W - 1; if (ec >= sc) gapCells += (unsigned)(ec - sc + 1); } }
                     else gapCells += (unsigned)(g * g);
                 } else if (j.kind == JK_DP) {
                     for (int t = 0; t < (int)j.nOps; t++) { const uint32_t op = X.gapOps[j.opsOff + (uint32_t)t]; put(opCode(op), opLen(op)); }
@@ -459,16 +465,22 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
             ops[nOut] = opMake(pc, pl); nOut++;
             if (nOut > 1 && firstAdd) ops[0] = opMake(opCode(ops[0]), (opLen(ops[0]) + firstAdd) & 0xFFFF);
             RootState s; memset(&s, 0, sizeof s);
-            s.sro = sro; s.sqo = (uint16_t)sqo; s.eqo = (uint16_t)eqo; s.refLen = (uint16_t)refLen; s.score = score; s.status = (rec.rs & 1u) ? stReversed : 0; s.len = (uint16_t)nOut;
+            s.sro = sro; s.sqo = (uint16_t)sqo; s.eqo = (uint16_t)eqo; s.refLen = (uint16_t)refLen; s.score = score; s.status = (rec.rs & 1u) ? stReversed : 0;
+                s.len = (uint16_t)nOut;
             s.listOff = slot;
             X.state[r] = s;
             const uint32_t strand = (rec.rs & 1u) ? XP_STRAND : 0u; const bool vb = backLen >= P.minExtLength, vf = forwLen >= P.minExtLength;
-            ExtProb pb; pb.qBase = r0; pb.rOff = sro - 1u; pb.qOff = (uint16_t)((sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF); pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
-            ExtProb pf; pf.qBase = r0; pf.rOff = sro + (uint32_t)refLen; pf.qOff = (uint16_t)((eqo + 1) & 0xFFFF); pf.qLen = (uint16_t)(forwLen & 0xFFFF); pf.flags = strand | (vf ? XP_VALID : 0u);
+            ExtProb pb; pb.qBase = r0; pb.rOff = sro - 1u; pb.qOff = (uint16_t)((sqo - 1) & 0xFFFF); pb.qLen = (uint16_t)(backLen & 0xFFFF);
+                pb.flags = strand | XP_REV | (vb ? XP_VALID : 0u);
+            ExtProb pf; pf.qBase = r0; pf.rOff = sro + (uint32_t)refLen; pf.qOff = (uint16_t)((eqo + 1) & 0xFFFF); pf.qLen = (uint16_t)(forwLen & 0xFFFF);
+                pf.flags = strand | (vf ? XP_VALID : 0u);
             X.probs[2 * (size_t)r] = pb; X.probs[2 * (size_t)r + 1] = pf;
-            X.extKeys[2 * (size_t)r] = vb ? 0xFFFFu - pb.qLen : 0xFFFFu; X.extKeys[2 * (size_t)r + 1] = vf ? 0xFFFFu - pf.qLen : 0xFFFFu;      // 16 bits: two radix passes (a valid problem has qLen >= 1)
+            // 16 bits: two radix passes (a valid problem has qLen >= 1)
+            X.extKeys[2 * (size_t)r] = vb ? 0xFFFFu - pb.qLen : 0xFFFFu; X.extKeys[2 * (size_t)r + 1] = vf ? 0xFFFFu - pf.qLen : 0xFFFFu;
             X.extVals[2 * (size_t)r] = 2u * r; X.extVals[2 * (size_t)r + 1] = 2u * r + 1u;
-            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)((pb.qLen + 19u) / 10u) : 0ull; X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)((pf.qLen + 19u) / 10u) : 0ull;   // trace blocks of 10 rows: up to 9 rows of phase in front, one spare row behind
+            // trace blocks of 10 rows: up to 9 rows of phase in front, one spare row behind
+            X.rowsBound[2 * (size_t)r] = vb ? (unsigned long long)((pb.qLen + 19u) / 10u) : 0ull;
+                X.rowsBound[2 * (size_t)r + 1] = vf ? (unsigned long long)((pf.qLen + 19u) / 10u) : 0ull;
         }
     }
     perfect = waveSumU(perfect); touched = waveSumU(touched); gapCalls = waveSumU(gapCalls); gapRows = waveSumU(gapRows); gapCells = waveSumU(gapCells);
@@ -544,7 +556,8 @@ __device__ inline int predictCarefulDPs(const DevParams &P, const MergedOps &L, 
                 if (minItem != 0) for (int k = 0; k < minItem && !has; k++) { const uint32_t op = L.at(f.start + k); has = opCode(op) == OP_M && opLen(op) >= P.wordLen; }
                 if (has) {
                     if (depth >= 5) return nOut;
-                    PredFrame c; c.start = f.start; c.len = minItem; c.sqo = f.sqo; c.eqo = (sQO - 1) & 0xFFFF; c.sro = f.sro; c.refLen = (int)((1u + (sRO - 1u) - f.sro) & 0xFFFFu); c.phase = 0;
+                    PredFrame c; c.start = f.start; c.len = minItem; c.sqo = f.sqo; c.eqo = (sQO - 1) & 0xFFFF; c.sro = f.sro;
+                        c.refLen = (int)((1u + (sRO - 1u) - f.sro) & 0xFFFFu); c.phase = 0;
                     st[depth++] = f; f = c;
                 }
             }
@@ -569,14 +582,16 @@ __device__ inline int predictCarefulDPs(const DevParams &P, const MergedOps &L, 
             if (goBack) {
                 int backLen = (int)((uint32_t)sqo < sro ? (uint32_t)sqo : sro);
                 if (backLen > 0) { const int m = matchRun<-1>(q, sqo - 1, gB, sro - 1u, backLen); backLen -= m; sqo -= m; sro -= (uint32_t)m; refLen = (refLen + m) & 0xFFFF; }
-                if (backLen >= P.minExtLength && nOut < YD_MEMO) { ExtProb p; p.qBase = qBase; p.rOff = sro - 1u; p.qOff = (uint16_t)((sqo - 1) & 0xFFFF); p.qLen = (uint16_t)(backLen & 0xFFFF); p.flags = strand | XP_REV | XP_VALID; out[nOut++] = p; }
+                if (backLen >= P.minExtLength && nOut < YD_MEMO) { ExtProb p; p.qBase = qBase; p.rOff = sro - 1u; p.qOff = (uint16_t)((sqo - 1) & 0xFFFF);
+                    p.qLen = (uint16_t)(backLen & 0xFFFF); p.flags = strand | XP_REV | XP_VALID; out[nOut++] = p; }
             }
             if (goForw) {
                 const uint32_t eRO = sro + (uint32_t)refLen - 1u;
                 const uint32_t qrem = (uint32_t)(((qlen - 1) - eqo) & 0xFFFF), rrem = P.maxROff - eRO;
                 int forwLen = (int)(qrem < rrem ? qrem : rrem);
                 if (forwLen > 0) { const int m = matchRun<1>(q, eqo + 1, gB, eRO + 1u, forwLen); forwLen -= m; eqo += m; refLen = (refLen + m) & 0xFFFF; }
-                if (forwLen >= P.minExtLength && nOut < YD_MEMO) { ExtProb p; p.qBase = qBase; p.rOff = sro + (uint32_t)refLen; p.qOff = (uint16_t)((eqo + 1) & 0xFFFF); p.qLen = (uint16_t)(forwLen & 0xFFFF); p.flags = strand | XP_VALID; out[nOut++] = p; }
+                if (forwLen >= P.minExtLength && nOut < YD_MEMO) { ExtProb p; p.qBase = qBase; p.rOff = sro + (uint32_t)refLen; p.qOff = (uint16_t)((eqo + 1) & 0xFFFF);
+                    p.qLen = (uint16_t)(forwLen & 0xFFFF); p.flags = strand | XP_VALID; out[nOut++] = p; }
             }
             f.phase = 4; continue;
         }
@@ -684,7 +699,8 @@ __global__ void __launch_bounds__(64) k_p3_predict(AlignArgs A, PhaseArgs X)
         if (live) {
             const uint32_t r = X.slowList[slot]; const P3Root R0 = p3Merged(X, r);
             const ChainClumpRec rec = A.clumps[A.order[r]]; const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
-            np = predictCarefulDPs(P, R0.L, R0.L.count(), R0.sqo, R0.eqo, R0.sro, R0.refLen, toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0, qlen, toGlobal(A.bases), pp, r0, (rec.rs & 1u) ? XP_STRAND : 0u);
+            np = predictCarefulDPs(P, R0.L, R0.L.count(), R0.sqo, R0.eqo, R0.sro, R0.refLen, toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0, qlen, toGlobal(A.bases), pp, r0,
+                (rec.rs & 1u) ? XP_STRAND : 0u);
         }
         int incl = np;
 #pragma unroll

@@ -4,7 +4,7 @@
 //
 //   k_scan_excl<T>      out[i] = in[0] + ... + in[i-1] over n elements of u32 or u64, ONE launch, one read and one write of HBM per element: a workgroup owns a tile
 //                       of 4 096 elements (a wave moves 1 KB of consecutive memory per instruction; sums inside 16-byte pieces, over the lanes by DPP, the four
-//                       waves' through LDS), the tile's offset comes from the tiles before it by decoupled look-back over 64-bit state words (status : 2 | value : 62).  The tile is
+// waves' through LDS), the tile's offset comes from the tiles before it by decoupled look-back over 64-bit state words (status : 2 | value : 62).  The tile is
 //                       the TICKET a workgroup draws when it starts (seed.h: tileTicket -- no assumption about dispatch order).  The state is SELF-CLEANING: the last
 //                       workgroup to finish zeroes the words the launch used, so that the next launch needs no memset (the host zeroes the buffer when it makes it and
 //                       after a launch that reported a failure).
@@ -23,7 +23,8 @@
 #endif
                                              // tile, measured (4 096-element tiles: 400 us for 32 M elements) -- so a tile is 96 KB
 #define YD_SCAN_TILE (YD_SCAN_BS * YD_SCAN_IPT)
-__host__ __device__ inline uint32_t scanTiles(uint64_t n, int elemBytes = 4) { const uint64_t tile = (uint64_t)YD_SCAN_TILE * 4u / (unsigned)elemBytes; return (uint32_t)((n + tile - 1) / tile); }
+__host__ __device__ inline uint32_t scanTiles(uint64_t n, int elemBytes = 4) { const uint64_t tile = (uint64_t)YD_SCAN_TILE * 4u / (unsigned)elemBytes;
+    return (uint32_t)((n + tile - 1) / tile); }
 __host__ __device__ inline size_t scanStateBytes(uint64_t n) { return 8ull * ((size_t)scanTiles(n, 8) + 4); }       // tile words (at most: the u64 tiling), ticket, done counter
 
 __device__ __forceinline__ unsigned long long shflUp64(unsigned long long v, int d)
@@ -32,7 +33,8 @@ __device__ __forceinline__ unsigned long long shflUp64(unsigned long long v, int
 __device__ __forceinline__ unsigned long long waveSum64(unsigned long long v)
 {
     const uint32_t a = waveInclSumU((uint32_t)v & 0xFFFFu), b = waveInclSumU(((uint32_t)v >> 16) & 0xFFFFu), c = waveInclSumU((uint32_t)(v >> 32));
-    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)a, 63) + ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)b, 63) << 16) + ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c, 63) << 32);
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)a, 63) + ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)b,
+        63) << 16) + ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c, 63) << 32);
 }
 // inclusive sum over the lanes in the width of T: u32 by DPP, u64 by shuffles (one or two such sums a batch)
 __device__ __forceinline__ uint32_t waveInclSumT(uint32_t v, uint32_t) { return waveInclSumU(v); }
@@ -43,7 +45,8 @@ __device__ __forceinline__ unsigned long long waveInclSumT(unsigned long long v,
     return v;
 }
 __device__ __forceinline__ uint32_t readLaneT(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-__device__ __forceinline__ unsigned long long readLaneT(unsigned long long v, int l) { return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l); }
+__device__ __forceinline__ unsigned long long readLaneT(unsigned long long v, int l) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l); }
 
 // decoupled look-back on 62-bit values; called by one whole wave; returns the sum of the aggregates of all tiles before `tile`
 __device__ __forceinline__ unsigned long long tileLookBack64(unsigned long long *state, uint32_t tile, unsigned long long agg, uint32_t lane, unsigned int *failed)
@@ -83,7 +86,8 @@ template <class T>
 __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, uint32_t n, unsigned long long *state /* scanStateBytes(n), zero */, unsigned int *failed)
 {
     YD_HIGH_PRIO();
-    constexpr int NW = YD_SCAN_BS / 64, PER = 16 / (int)sizeof(T), NP = YD_SCAN_IPT / 4, IPT = NP * PER;      // elements a piece, pieces a lane (twelve 16-byte pieces), elements a lane
+    // elements a piece, pieces a lane (twelve 16-byte pieces), elements a lane
+    constexpr int NW = YD_SCAN_BS / 64, PER = 16 / (int)sizeof(T), NP = YD_SCAN_IPT / 4, IPT = NP * PER;
     __shared__ T sWave[NW]; __shared__ T sPrefix; __shared__ uint32_t sTile;
     const uint32_t nTiles = gridDim.x, t = threadIdx.x, lane = t & 63u, w = t >> 6;
     if (t == 0) sTile = (uint32_t)atomicAdd(&state[nTiles], 1ull);
@@ -131,7 +135,8 @@ __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, u
         if (aligned && g0 + PER <= n) {
             uint4 a;
             if (sizeof(T) == 4) { a.x = (uint32_t)(b + v[k][0]); a.y = (uint32_t)(b + v[k][1 % PER]); a.z = (uint32_t)(b + v[k][2 % PER]); a.w = (uint32_t)(b + v[k][3 % PER]); }
-            else { const unsigned long long p = (unsigned long long)(b + v[k][0]), q = (unsigned long long)(b + v[k][1]); a.x = (uint32_t)p; a.y = (uint32_t)(p >> 32); a.z = (uint32_t)q; a.w = (uint32_t)(q >> 32); }
+            else { const unsigned long long p = (unsigned long long)(b + v[k][0]), q = (unsigned long long)(b + v[k][1]); a.x = (uint32_t)p; a.y = (uint32_t)(p >> 32);
+                a.z = (uint32_t)q; a.w = (uint32_t)(q >> 32); }
             *(uint4 *)(out + g0) = a;
         } else {
 #pragma unroll
@@ -153,7 +158,8 @@ __global__ void __launch_bounds__(YD_SCAN_BS) k_scan_excl(const T *in, T *out, u
 // work words of one ordering: hist[nb] | cursor[nb] | done; zero before the first use, left zero by k_bucket_scatter
 __host__ __device__ inline size_t bucketWorkBytes() { return 4ull * (2 * YD_BKT_MAX + 4); }
 // bucket of a key: (key - sub) >> shift, clamped to [0, nb) (keys below `sub` go to bucket 0)
-__device__ __forceinline__ uint32_t bucketOf(uint32_t key, uint32_t sub, int shift, uint32_t nb) { const uint32_t b = (key > sub ? key - sub : 0u) >> shift; return b < nb ? b : nb - 1u; }
+__device__ __forceinline__ uint32_t bucketOf(uint32_t key, uint32_t sub, int shift, uint32_t nb) { const uint32_t b = (key > sub ? key - sub : 0u) >> shift;
+    return b < nb ? b : nb - 1u; }
 
 static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_count(const uint32_t *keys, uint32_t n, uint32_t sub, int shift, uint32_t nb, unsigned int *work)
 {
@@ -168,7 +174,8 @@ static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_count(const uint32_
     for (uint32_t b = threadIdx.x; b < nb; b += YD_BKT_BS) { const unsigned c = sHist[b]; if (c) atomicAdd(&work[b], c); }
 }
 // vals == nullptr: the value of item i is i + valBase
-static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_scatter(const uint32_t *keys, const uint32_t *vals, uint32_t valBase, uint32_t n, uint32_t sub, int shift, uint32_t nb, unsigned int *work, uint32_t *outVals, uint32_t *outKeys /* or nullptr */)
+static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_scatter(const uint32_t *keys, const uint32_t *vals, uint32_t valBase, uint32_t n, uint32_t sub, int shift, uint32_t nb,
+    unsigned int *work, uint32_t *outVals, uint32_t *outKeys /* or nullptr */)
 {
     YD_HIGH_PRIO();
     __shared__ unsigned int sPos[YD_BKT_MAX]; __shared__ unsigned int sCnt[YD_BKT_MAX]; __shared__ unsigned int sWave[YD_BKT_BS / 64]; __shared__ unsigned int sLast;
@@ -180,7 +187,8 @@ static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_scatter(const uint3
     for (int k = 0; k < YD_BKT_IPT; k++) { const uint32_t i = base + (uint32_t)k * YD_BKT_BS + t; key[k] = i < n ? keys[i] : 0u; }
     const uint32_t per = (nb + YD_BKT_BS - 1u) / YD_BKT_BS;               // 1 .. 4
     unsigned int sum = 0;
-    for (uint32_t k = 0; k < per; k++) { const uint32_t b = t * per + k; const unsigned c = b < nb ? __hip_atomic_load(&work[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; if (b < nb) { sPos[b] = sum; sCnt[b] = 0u; } sum += c; }
+    for (uint32_t k = 0; k < per; k++) { const uint32_t b = t * per + k; const unsigned c = b < nb ? __hip_atomic_load(&work[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (b < nb) { sPos[b] = sum; sCnt[b] = 0u; } sum += c; }
     const unsigned int incl = waveInclSumU(sum);
     if (lane == 63u) sWave[w] = incl;
     __syncthreads();
@@ -188,7 +196,9 @@ static __global__ void __launch_bounds__(YD_BKT_BS) k_bucket_scatter(const uint3
     const unsigned int tbase = wbase + incl - sum;
     for (uint32_t k = 0; k < per; k++) { const uint32_t b = t * per + k; if (b < nb) sPos[b] += tbase; }
 #pragma unroll
-    for (int k = 0; k < YD_BKT_IPT; k++) { const uint32_t i = base + (uint32_t)k * YD_BKT_BS + t; if (i < n) { key[k] = bucketOf(key[k], sub, shift, nb); atomicAdd(&sCnt[key[k]], 1u); } }      // (key[] holds the bucket from here on)
+    // (key[] holds the bucket from here on)
+    for (int k = 0; k < YD_BKT_IPT; k++) { const uint32_t i = base + (uint32_t)k * YD_BKT_BS + t; if (i < n) { key[k] = bucketOf(key[k], sub, shift, nb);
+        atomicAdd(&sCnt[key[k]], 1u); } }
     __syncthreads();
     // one reservation per non-empty bucket: sPos[b] = where this workgroup's items of bucket b go
     for (uint32_t b = t; b < nb; b += YD_BKT_BS) { const unsigned c = sCnt[b]; if (c) sPos[b] += atomicAdd(&work[YD_BKT_MAX + b], c); }

@@ -6,6 +6,7 @@
 // identical fragment array.  HBM-bound integer/byte work: coalesced streams + random 8-byte table probes.
 #pragma once
 #include "common.h"
+#include "lookback.h"
 
 __constant__ unsigned char kComp4[16] = {2, 3, 0, 1, 4, 12, 7, 6, 9, 8, 15, 11, 5, 13, 14, 10};   // fourBitCompCodes, Math.c:156
 
@@ -110,10 +111,12 @@ __global__ void k_expand_starts(const uint32_t *hitOff, uint32_t nKmers, uint32_
     if (g == 0u) blockG0[(hitOff[nKmers] + (uint32_t)YD_EXPAND_HITS - 1u) / (uint32_t)YD_EXPAND_HITS] = nKmers;       // behind the last block: the end of the k-mers
     for (uint32_t blk = (a + (uint32_t)YD_EXPAND_HITS - 1u) / (uint32_t)YD_EXPAND_HITS; (unsigned long long)blk * YD_EXPAND_HITS < b; blk++) blockG0[blk] = g;
 }
-__global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, const uint32_t *blockG0, uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
+__global__ void __launch_bounds__(256) k_expand_hits(const uint32_t *ROA, const uint32_t *posS, const uint32_t *hitOff, const uint32_t *posRsI, const uint32_t *blockG0,
+    uint32_t nKmers, uint32_t nHits, unsigned long long *keys)
 {
     YD_HIGH_PRIO();
-    __shared__ uint32_t sOff[YD_EXPAND_HITS + 2], sS[YD_EXPAND_HITS + 2], sRsI[YD_EXPAND_HITS + 2]; __shared__ __attribute__((aligned(16))) uint32_t sK[YD_EXPAND_HITS]; __shared__ uint32_t sWave[4];
+    __shared__ uint32_t sOff[YD_EXPAND_HITS + 2], sS[YD_EXPAND_HITS + 2], sRsI[YD_EXPAND_HITS + 2]; __shared__ __attribute__((aligned(16))) uint32_t sK[YD_EXPAND_HITS];
+        __shared__ uint32_t sWave[4];
     const uint32_t t0 = blockIdx.x * YD_EXPAND_HITS, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     // the window: from this block's first k-mer to the next block's (k-mers without hits in between included), at most 1026 offsets (hitOff has nKmers + 1 entries)
     const uint32_t g0 = blockG0[blockIdx.x], span = min(min(nKmers + 1u - g0, blockG0[blockIdx.x + 1u] + 2u - g0), (uint32_t)YD_EXPAND_HITS + 2u);
@@ -174,49 +177,6 @@ __global__ void k_seg_offsets(const uint32_t *kmerOff, const uint32_t *hitOff, u
 // is dead on arrival, and on a large genome these chance hits are most fragments (3.1 Gbp: 128 M fragments a batch, ~100 M of them dead): they are counted
 // and not written.  Dropping them changes nothing for the others: the diagonals are sorted, so the fragments on either side of a dropped run are further
 // apart than the dropped fragment was from them -- every region boundary stays where it was.  maxGapDrop < 0: keep every fragment (ygpu_seed_join).
-// Decoupled look-back of a single-pass scan over tiles (one 64-bit state word per tile, zeroed before the launch: status in the high half -- 1 = the tile's own
-// count, 2 = its inclusive prefix -- and the value in the low half, so that both arrive together).  Called by one whole wave of tile `tile` with the tile's
-// count; returns the sum of the counts of all tiles before it.  A workgroup's tile is the TICKET it draws when it starts (tileTicket), not its blockIdx: every
-// tile before it has then started as well and publishes its count without waiting for anybody.  (With tile = blockIdx two such kernels running side by side --
-// two batches in flight, or two processes on one device -- can fill each other's XCD with waiting workgroups while the tile both are waiting for has not been
-// dispatched there: seen as a stall with two processes on one GPU.  *failed is raised, after a bounded wait, should a tile ever not show up.)
-__device__ __forceinline__ uint32_t tileTicket(unsigned long long *ticketWord /* zeroed with the tile states */, uint32_t *sSlot)
-{
-    if (threadIdx.x == 0) *sSlot = (uint32_t)atomicAdd(ticketWord, 1ull);
-    __syncthreads();
-    return *sSlot;
-}
-__device__ __forceinline__ uint32_t tileLookBack(unsigned long long *tileState, uint32_t tile, uint32_t agg, uint32_t lane, unsigned int *failed)
-{
-    uint32_t excl = 0;
-    if (tile == 0u) { if (lane == 0u) __hip_atomic_store(&tileState[0], (2ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0u; }
-    if (lane == 0u) __hip_atomic_store(&tileState[tile], (1ull << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int back = (int)tile - 1;                                            // lane l looks at tile back - l
-    for (;;) {
-        const int j = back - (int)lane;
-        unsigned long long st = 2ull << 32;                              // before the first tile: a known prefix of zero
-        if (j >= 0) {
-            // (every tile waited for has drawn its ticket, so its workgroup is resident and publishes without waiting for anybody: the wait is bounded by WALL TIME
-            // only -- a device that is time-sliced between processes, or stopped under a debugger, may take long -- 30 s of the 100 MHz clock, asleep between polls
-            // after the first few; the caller sees the flag)
-            st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((st >> 32) == 0ull) {
-                const unsigned long long t0 = wall_clock64(); unsigned polls = 0;
-                do { if (++polls > 64u) __builtin_amdgcn_s_sleep(32); st = __hip_atomic_load(&tileState[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                while ((st >> 32) == 0ull && wall_clock64() - t0 < 3000000000ull);
-                if ((st >> 32) == 0ull) { st = 2ull << 32; atomicMax(failed, 1u); }
-            }
-        }
-        const unsigned long long known = __ballot((st >> 32) == 2ull);
-        const int stop = __builtin_ctzll(known | (1ull << 63));          // the nearest tile that knows its prefix (lane 63 at the latest if any)
-        const bool use = known ? (int)lane <= stop : true;
-        excl += waveTotalSumU(use ? (uint32_t)st : 0u);                     // (DPP: six shuffles through the LDS crossbar here were most of a look-back round, and the rounds are a chain)
-        if (known) break;
-        back -= 64;
-    }
-    if (lane == 0u) __hip_atomic_store(&tileState[tile], (2ull << 32) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
-}
 // head / last / dead of a hit from its two neighbours in the sorted order, without branches (bit 0 head, bit 1 last hit of its fragment, bit 2 dead single)
 __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned long long b, unsigned long long c, bool first, bool end, int wordLen, int maxGapDrop)
 {
@@ -241,9 +201,11 @@ __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned lo
 #define YD_FRAG_BS 1024
 #define YD_FRAG_IPT 8
 #define YD_FRAG_TILE (YD_FRAG_BS * YD_FRAG_IPT)
-static_assert((YD_FRAG_IPT * (YD_FRAG_BS / 64)) % 64 == 0 && YD_FRAG_IPT <= 10, "k_frag_scan_build: wave 0 scans IPT x waves counts, a whole number per lane; the class bits of ten rows fit one word");
+static_assert((YD_FRAG_IPT * (YD_FRAG_BS / 64)) % 64 == 0 && YD_FRAG_IPT <= 10,
+    "k_frag_scan_build: wave 0 scans IPT x waves counts, a whole number per lane; the class bits of ten rows fit one word");
 __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap,
-                                                                unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
+                                                                unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */,
+                                                                    unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
 {
     YD_HIGH_PRIO();
     constexpr int NW = YD_FRAG_BS / 64;
@@ -266,8 +228,10 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
         const uint32_t idx = wbase + (uint32_t)k * 64u + lane; const bool in = idx < nHits;
         const unsigned long long b = key[k];
         const unsigned long long up = k > 0 ? key[k - 1] : edge, dn = k + 1 < YD_FRAG_IPT ? key[k + 1] : edge;      // rows whose lanes 63 / 0 are this row's outer neighbours
-        const uint32_t a0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)up, k > 0 ? 63 : 0), a0hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(up >> 32), k > 0 ? 63 : 0);
-        const uint32_t c0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dn, k + 1 < YD_FRAG_IPT ? 0 : 63), c0hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dn >> 32), k + 1 < YD_FRAG_IPT ? 0 : 63);
+        const uint32_t a0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)up, k > 0 ? 63 : 0), a0hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(up >> 32), k > 0
+            ? 63 : 0);
+        const uint32_t c0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dn, k + 1 < YD_FRAG_IPT ? 0 : 63),
+            c0hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dn >> 32), k + 1 < YD_FRAG_IPT ? 0 : 63);
         const unsigned long long a = ((unsigned long long)(uint32_t)laneUp1((int)(uint32_t)(b >> 32), (int)a0hi) << 32) | (uint32_t)laneUp1((int)(uint32_t)b, (int)a0lo);
         const unsigned long long c = ((unsigned long long)(uint32_t)laneDown1((int)(uint32_t)(b >> 32), (int)c0hi) << 32) | (uint32_t)laneDown1((int)(uint32_t)b, (int)c0lo);
         uint32_t cl = 0;
@@ -302,7 +266,8 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
         const bool head = (cl & 1u) != 0u, last = (cl & 2u) != 0u, dead = (cl & 4u) != 0u;
         const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
         if (idx >= nHits || dead) continue;
-        const uint32_t f = prefix + sCnt[(int)w * YD_FRAG_IPT + k] + (uint32_t)__builtin_popcountll(headMask[k] & below) + (head ? 1u : 0u) - 1u;   // the fragment this hit belongs to
+        // the fragment this hit belongs to
+        const uint32_t f = prefix + sCnt[(int)w * YD_FRAG_IPT + k] + (uint32_t)__builtin_popcountll(headMask[k] & below) + (head ? 1u : 0u) - 1u;
         if (f >= cap) continue;
         const unsigned long long kk = key[k];
         const uint32_t qo = (uint32_t)(kk & 0x7FFFu), diag = (uint32_t)(kk >> 15), rs = (uint32_t)(kk >> 47);
@@ -326,113 +291,4 @@ __global__ void k_frag_finish(DevFrag *frags, uint32_t nFrags)
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nFrags) return;
     frags[f].refLen = (uint16_t)(1 + (int)frags[f].eqo - (int)frags[f].sqo);      // setRefLen, FragsClumps.inl:44-47
-}
-
-// A3: regions = runs of consecutive fragments of one (read, strand) whose diagonals differ by <= maxGap (QueryMatch.c:146-158).  One pass over the fresh
-// fragment array: head flags, their exclusive scan (the look-back of k_frag_scan_build) and regStart[r] = first fragment of region r; the same pass sets
-// refLen (setRefLen, FragsClumps.inl:44-47), which needs the head's and the last hit's stores of the build kernel to have landed.  regStart[nRegions] = nFrags
-// is set by the host.  A tile = 4 waves x 8 rows of 64 fragments.
-#define YD_REG_IPT 8
-#define YD_REG_TILE (256 * YD_REG_IPT)
-static_assert(4 * YD_REG_IPT <= 64, "k_region_scan: one lane of wave 0 per (wave, row) count");
-__global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nFrags, int maxGap, uint32_t *regStart, unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */)
-{
-    YD_HIGH_PRIO();
-    __shared__ uint32_t sCnt[4 * YD_REG_IPT]; __shared__ uint32_t sPrefix;
-    const uint32_t tile = tileTicket(tileState + gridDim.x, &sPrefix), t = threadIdx.x, lane = t & 63u, w = t >> 6, wbase = tile * (uint32_t)YD_REG_TILE + w * (uint32_t)(64 * YD_REG_IPT);
-    uint32_t rs[YD_REG_IPT], dg[YD_REG_IPT]; unsigned long long headMask[YD_REG_IPT];
-#pragma unroll
-    for (int k = 0; k < YD_REG_IPT; k++) {
-        const uint32_t f = wbase + (uint32_t)k * 64u + lane; rs[k] = 0xFFFFFFFFu; dg[k] = 0;
-        if (f < nFrags) {
-            const uint4 v = *(const uint4 *)&frags[f];                        // sro | sqo, eqo | refLen, used | rs
-            const uint32_t sqo = v.y & 0xFFFFu, eqo = v.y >> 16;
-            rs[k] = v.w; dg[k] = v.x - sqo;
-            frags[f].refLen = (uint16_t)(1u + eqo - sqo);
-        }
-    }
-    uint32_t eRs = 0xFFFFFFFFu, eDg = 0;                                        // lane 0: the fragment before the wave's range
-    if (lane == 0u && wbase > 0u && wbase <= nFrags) { const DevFrag a = frags[wbase - 1u]; eRs = a.rs; eDg = a.sro - (uint32_t)a.sqo; }
-#pragma unroll
-    for (int k = 0; k < YD_REG_IPT; k++) {
-        const uint32_t f = wbase + (uint32_t)k * 64u + lane;
-        const uint32_t upRs = k > 0 ? rs[k - 1] : eRs, upDg = k > 0 ? dg[k - 1] : eDg;
-        const uint32_t a0rs = (uint32_t)__builtin_amdgcn_readlane((int)upRs, k > 0 ? 63 : 0), a0dg = (uint32_t)__builtin_amdgcn_readlane((int)upDg, k > 0 ? 63 : 0);
-        const uint32_t prs = (uint32_t)laneUp1((int)rs[k], (int)a0rs), pdg = (uint32_t)laneUp1((int)dg[k], (int)a0dg);
-        const bool head = f < nFrags && (f == 0u || prs != rs[k] || absDiffU(pdg, dg[k]) > (uint32_t)maxGap);
-        const unsigned long long m = __ballot(head); headMask[k] = m;
-        if (lane == 0u) sCnt[(int)w * YD_REG_IPT + k] = (uint32_t)__builtin_popcountll(m);
-    }
-    __syncthreads();
-    if (w == 0u) {
-        const uint32_t v = lane < 4u * YD_REG_IPT ? sCnt[lane] : 0u; uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += x; }
-        if (lane < 4u * YD_REG_IPT) sCnt[lane] = incl - v;
-        const uint32_t agg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t excl = tileLookBack(tileState, tile, agg, lane, total + 1);
-        if (lane == 0u) { sPrefix = excl; if (tile + 1u == gridDim.x) *total = excl + agg; }
-    }
-    __syncthreads();
-    const uint32_t prefix = sPrefix; const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int k = 0; k < YD_REG_IPT; k++)
-        if ((headMask[k] >> lane) & 1ull) regStart[prefix + sCnt[(int)w * YD_REG_IPT + k] + (uint32_t)__builtin_popcountll(headMask[k] & below)] = wbase + (uint32_t)k * 64u + lane;
-}
-// multi-fragment region list + largest region
-// smallList: regions with 2..8 fragments (k_chain_lanes); multiList: 9..64 (k_chain); bigList: more than 64 (k_chain_big)
-__global__ void __launch_bounds__(1024) k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned int *nSmall)
-{
-    YD_HIGH_PRIO();
-    __shared__ unsigned sM[16], sS[16], sBase[2];                            // one atomic per list and 1024-thread block (a single L2 word takes ~88 atomics per microsecond)
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
-    const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
-    const bool big = n > 64, small = n >= 2 && n <= 8, multi = n > 8 && !big;
-    if (big) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }        // rare
-    const unsigned long long mm = __ballot(multi), ms = __ballot(small);
-    if (lane == 0) { sM[wv] = (unsigned)__builtin_popcountll(mm); sS[wv] = (unsigned)__builtin_popcountll(ms); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned tm = 0, ts = 0; for (unsigned k = 0; k < blockDim.x / 64u; k++) { tm += sM[k]; ts += sS[k]; }
-        sBase[0] = tm ? atomicAdd(nMulti, tm) : 0u; sBase[1] = ts ? atomicAdd(nSmall, ts) : 0u;
-    }
-    __syncthreads();
-    unsigned bm = 0, bs = 0; for (int k = 0; k < wv; k++) { bm += sM[k]; bs += sS[k]; }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (multi) multiList[sBase[0] + bm + (unsigned)__builtin_popcountll(mm & below)] = r;
-    if (small) smallList[sBase[1] + bs + (unsigned)__builtin_popcountll(ms & below)] = r;
-}
-// order[base[region] + seq] = clump index  (rank of a root clump = creation order)
-__global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, const uint32_t *regionBase, uint32_t *order)
-{
-    YD_HIGH_PRIO();
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nClumps) return;
-    if (clumps[c].nFrags == 0xFFFFFFFFu) return;                              // unused slot of a wave's reservation chunk
-    order[regionBase[clumps[c].region] + clumps[c].seq] = c;
-}
-// final layout: clump ci of root r with push number p goes to rootBase[r] + (pushCount[r] - 1 - p)
-__global__ void k_out_layout(const uint32_t *outRoot, const uint32_t *outPush, const uint32_t *rootBase, const unsigned int *rootPushCount, uint32_t nOut, uint32_t *dstIdx)
-{
-    YD_HIGH_PRIO();
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nOut) return;
-    const uint32_t r = outRoot[c];
-    dstIdx[c] = rootBase[r] + (rootPushCount[r] - 1u - outPush[c]);
-}
-__global__ void k_out_scatter(const ygpu_clump *src, const uint32_t *dstIdx, uint32_t nOut, ygpu_clump *dst)
-{
-    YD_HIGH_PRIO();
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nOut) return;
-    dst[dstIdx[c]] = src[c];
-}
-// clumps per read: root r belongs to read (clumps[order[r]].rs >> 1)
-__global__ void k_read_counts(const ChainClumpRec *clumps, const uint32_t *order, const unsigned int *rootPushCount, uint32_t nRoots, unsigned int *readCount)
-{
-    YD_HIGH_PRIO();
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nRoots) return;
-    const unsigned n = rootPushCount[r];
-    if (n) atomicAdd(&readCount[clumps[order[r]].rs >> 1], n);
 }

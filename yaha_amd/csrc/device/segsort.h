@@ -14,7 +14,8 @@
 #ifndef YD_SORT_TOP
 #define YD_SORT_TOP 31                 // hits a thread of the largest class (512 threads)
 #endif
-#define YD_SEGSORT_MAX (512u * YD_SORT_TOP)            // 512 threads x 31 hits: the largest shape that finds room on a CU beside one workgroup of a rows launch (173 registers; x 32: 177, eight too many)
+// 512 threads x 31 hits: the largest shape that finds room on a CU beside one workgroup of a rows launch (173 registers; x 32: 177, eight too many)
+#define YD_SEGSORT_MAX (512u * YD_SORT_TOP)
 
 template <unsigned BS, unsigned IPT>
 __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
@@ -136,7 +137,8 @@ __global__ void __launch_bounds__(1024) k_seg_split(const unsigned long long *in
 // empty, so every bucket is shorter than the piece, and the range a bucket spans shrinks sixteen-fold a level: at most eight levels for 32-bit diagonals.  A piece of ONE
 // diagonal (mn == mx) is in order already -- k_expand_hits wrote ascending query offsets and every cut so far was stable: it is copied to `final` as it stands and
 // gets no sub-pieces.  in -> out for the cut pieces (the caller sorts them out -> final or cuts them again), sub-piece sb * 16 + k = bucket k of the sb-th listed piece.
-__global__ void __launch_bounds__(1024) k_seg_split_range(const unsigned long long *in, unsigned long long *out, unsigned long long *final, const uint32_t *segB, const uint32_t *segE, const uint32_t *list,
+__global__ void __launch_bounds__(1024) k_seg_split_range(const unsigned long long *in, unsigned long long *out, unsigned long long *final, const uint32_t *segB,
+    const uint32_t *segE, const uint32_t *list,
                                                           uint32_t *subB, uint32_t *subE)
 {
     YD_HIGH_PRIO();

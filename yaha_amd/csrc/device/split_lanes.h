@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
     YD_HIGH_PRIO();
     const int lane = laneId(); const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane; const DevParams &P = A.P;
     const bool live = slot < Sx.nSlots;
-    uint32_t *lists = (uint32_t *)(Sx.scratch + (size_t)slot * YD_SL_BYTES); uint32_t *outOps = lists + YD_SL_DEPTH * YD_SL_CAP; ygpu_clump *outCl = (ygpu_clump *)(outOps + YD_SL_OUT);
+    uint32_t *lists = (uint32_t *)(Sx.scratch + (size_t)slot * YD_SL_BYTES); uint32_t *outOps = lists + YD_SL_DEPTH * YD_SL_CAP;
+        ygpu_clump *outCl = (ygpu_clump *)(outOps + YD_SL_OUT);
     bool fall = false; int why = 0; int nCl = 0, nOutOps = 0; uint32_t r = 0;
     unsigned splits = 0, extCalls = 0, extRows = 0, extCells = 0, perfect = 0, touched = 0;
     if (live) {
@@ -40,7 +41,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
         YD_GLOBAL const uint8_t *q = toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0; YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
         // ---- the root as k_p3_lanes saw it: phase-1 list + the two extension results --------------------------------------------
-        SFrame f; { const RootState S = X.state[r]; f.sro = S.sro; f.sqo = S.sqo; f.eqo = S.eqo; f.refLen = S.refLen; f.status = S.status; f.score = S.score; f.len = S.len; f.start = 0; f.phase = 0; }
+        SFrame f; { const RootState S = X.state[r]; f.sro = S.sro; f.sqo = S.sqo; f.eqo = S.eqo; f.refLen = S.refLen; f.status = S.status; f.score = S.score; f.len = S.len;
+            f.start = 0; f.phase = 0; }
         MergedOps L; L.a = L.c = nullptr; L.na = L.nc = L.jab = L.jbc = 0; L.b = X.stateOps + X.state[r].listOff; L.nb = f.len;
         const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
         if (rb.score > 0) {
@@ -79,12 +81,14 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
             fr.status |= stScored;
             return 0;
         };
-        auto hasMaxMatch = [&](const uint32_t *b, int start, int n) { for (int k = 0; k < n; k++) { const uint32_t op = b[start + k]; if (opCode(op) == OP_M && opLen(op) >= P.wordLen) return true; } return false; };
+        auto hasMaxMatch = [&](const uint32_t *b, int start, int n) { for (int k = 0; k < n; k++) { const uint32_t op = b[start + k];
+            if (opCode(op) == OP_M && opLen(op) >= P.wordLen) return true; } return false; };
         auto emit = [&](const SFrame &fr, const uint32_t *b) {
             if (nCl >= YD_SL_CLUMPS || nOutOps + fr.len > YD_SL_OUT) { fall = true; return; }
             for (int k = 0; k < fr.len; k++) outOps[nOutOps + k] = b[fr.start + k];
             ygpu_clump c; c.sro = fr.sro; c.sqo = (uint16_t)fr.sqo; c.eqo = (uint16_t)fr.eqo; c.refLen = (uint16_t)fr.refLen; c.totScore = (uint16_t)ss; c.totLength = (uint16_t)sl;
-            c.matchedBases = (uint16_t)sm; c.mismatchedBases = (uint16_t)smm; c.gapBases = (uint16_t)sg; c.status = (uint8_t)fr.status; c.reserved = 0; c.op_start = (uint32_t)nOutOps; c.n_ops = (uint32_t)fr.len;
+            c.matchedBases = (uint16_t)sm; c.mismatchedBases = (uint16_t)smm; c.gapBases = (uint16_t)sg; c.status = (uint8_t)fr.status; c.reserved = 0;
+                c.op_start = (uint32_t)nOutOps; c.n_ops = (uint32_t)fr.len;
             outCl[nCl++] = c; nOutOps += fr.len; pushes++;
         };
         // a careful extension = the stored result of exactly this X-drop problem (runDP in align.h); ops in LIST order through opAt
@@ -107,7 +111,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         auto opAt = [&](const DPRes &o, int k) { return o.rev ? o.arr[o.nOps - 1 - k] : o.arr[k]; };      // the backward list is stored reversed (k_ext_trace)
         auto mergeBack = [&](uint32_t *b, int start, int &len, const DPRes &o, int t0, int t1) {           // mergeEOLToBack, SW.cpp:207-261
             if (t1 <= t0) return;
-            if (len > 0) { const uint32_t last = b[start + len - 1], first = opAt(o, t0); if (opCode(last) == opCode(first)) { b[start + len - 1] = opMake(opCode(last), (opLen(last) + opLen(first)) & 0xFFFF); t0++; } }
+            if (len > 0) { const uint32_t last = b[start + len - 1], first = opAt(o, t0);
+                if (opCode(last) == opCode(first)) { b[start + len - 1] = opMake(opCode(last), (opLen(last) + opLen(first)) & 0xFFFF); t0++; } }
             const int cnt = t1 - t0;
             if (start + len + cnt > YD_SL_CAP) { fall = true; return; }
             for (int k = 0; k < cnt; k++) b[start + len + k] = opAt(o, t0 + k);
@@ -115,7 +120,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         };
         auto mergeFront = [&](uint32_t *b, int &start, int &len, const DPRes &o, int t0, int t1) {         // mergeEOLToFront, SW.cpp:151-205
             if (t1 <= t0) return;
-            if (len > 0) { const uint32_t first = b[start], last = opAt(o, t1 - 1); if (opCode(first) == opCode(last)) { b[start] = opMake(opCode(first), (opLen(first) + opLen(last)) & 0xFFFF); t1--; } }
+            if (len > 0) { const uint32_t first = b[start], last = opAt(o, t1 - 1);
+                if (opCode(first) == opCode(last)) { b[start] = opMake(opCode(first), (opLen(first) + opLen(last)) & 0xFFFF); t1--; } }
             const int cnt = t1 - t0;
             if (start - cnt < 0) { fall = true; return; }
             start -= cnt;
@@ -135,7 +141,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
                 if (backLen > 0) {
                     const int m = matchRun<-1>(q, fr.sqo - 1, gB, fr.sro - 1u, backLen);
                     perfect += m; touched += m + (m < backLen);
-                    if (m > 0) { b[fr.start] = opMake(opCode(b[fr.start]), (opLen(b[fr.start]) + m) & 0xFFFF); score += m * P.MS; backLen -= m; fr.sqo -= m; fr.sro -= (uint32_t)m; fr.refLen = (fr.refLen + m) & 0xFFFF; }
+                    if (m > 0) { b[fr.start] = opMake(opCode(b[fr.start]), (opLen(b[fr.start]) + m) & 0xFFFF); score += m * P.MS; backLen -= m; fr.sqo -= m; fr.sro -= (uint32_t)m;
+                        fr.refLen = (fr.refLen + m) & 0xFFFF; }
                 }
             }
             if (goForw) {
@@ -145,7 +152,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
                 if (forwLen > 0) {
                     const int m = matchRun<1>(q, fr.eqo + 1, gB, eRO + 1u, forwLen);
                     perfect += m; touched += m + (m < forwLen);
-                    if (m > 0) { const int li = fr.start + fr.len - 1; b[li] = opMake(opCode(b[li]), (opLen(b[li]) + m) & 0xFFFF); score += m * P.MS; forwLen -= m; fr.eqo += m; fr.refLen = (fr.refLen + m) & 0xFFFF; }
+                    if (m > 0) { const int li = fr.start + fr.len - 1; b[li] = opMake(opCode(b[li]), (opLen(b[li]) + m) & 0xFFFF); score += m * P.MS; forwLen -= m; fr.eqo += m;
+                        fr.refLen = (fr.refLen + m) & 0xFFFF; }
                 }
             }
             if (goBack && backLen >= P.minExtLength) {                          // findAGSBackwardExtensionCarefully, SW.cpp:671-788
@@ -153,7 +161,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
                 int ns = 0, aQ = 0, aR = 0;
                 if (o.score > 0) {
                     int QLen = 0, RLen = 0, AGS = 0, maxAGS = 0, startItem = -1;
-                    for (int k = 0; k < o.nOps; k++) { opStep(opAt(o, k), QLen, RLen, AGS); if (AGS <= 0) { AGS = 0; maxAGS = 0; QLen = 0; RLen = 0; startItem = k; } if (AGS > maxAGS) maxAGS = AGS; }
+                    for (int k = 0; k < o.nOps; k++) { opStep(opAt(o, k), QLen, RLen, AGS); if (AGS <= 0) { AGS = 0; maxAGS = 0; QLen = 0; RLen = 0; startItem = k;
+                        } if (AGS > maxAGS) maxAGS = AGS; }
                     if (!(AGS <= 0 || maxAGS >= AGS + score)) { mergeFront(b, fr.start, fr.len, o, startItem + 1, o.nOps); aQ = QLen; aR = RLen; ns = AGS; }
                 }
                 if (ns > 0) { score += ns; fr.sqo = (fr.sqo - aQ) & 0xFFFF; fr.sro -= (uint32_t)aR; fr.refLen = (fr.refLen + aR) & 0xFFFF; }
@@ -213,7 +222,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
                     if (depth + 1 >= YD_SL_DEPTH || YD_SL_FRONT + minItem > YD_SL_CAP - 64) { fall = true; why = 3; break; }
                     uint32_t *cb = buf(depth + 1);
                     for (int k = 0; k < minItem; k++) cb[YD_SL_FRONT + k] = b[f.start + k];
-                    SFrame c = f; c.status = f.status & stReversed; c.sqo = f.cSqo; c.eqo = (sQO - 1) & 0xFFFF; c.sro = f.cSro; c.refLen = (int)((1u + (sRO - 1u) - f.cSro) & 0xFFFFu);
+                    SFrame c = f; c.status = f.status & stReversed; c.sqo = f.cSqo; c.eqo = (sQO - 1) & 0xFFFF; c.sro = f.cSro;
+                        c.refLen = (int)((1u + (sRO - 1u) - f.cSro) & 0xFFFFu);
                     c.score = 0; c.start = YD_SL_FRONT; c.len = minItem; c.phase = PH_NONE;
                     f.phase = PH_AFTER_HEAD; st[depth] = f; depth++; f = c; state = ST_SPLIT_ENTER; continue;
                 }
@@ -268,17 +278,22 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         if (nCl && (ci + (unsigned)nCl > A.outClumpCap || (unsigned long long)oi + (unsigned)nOutOps > (unsigned long long)A.outOpsCap)) atomicCAS(A.errFlag, 0, (int)YERR_OUT);
         else {
             const char codes[4] = {'M', 'R', 'D', 'I'};
-            for (int k = 0; k < nOutOps; k++) { const uint32_t op = outOps[k]; A.outOps[oi + (unsigned)k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
-            for (int k = 0; k < nCl; k++) { ygpu_clump c = outCl[k]; c.op_start += oi; A.outClumps[ci + (unsigned)k] = c; A.outRoot[ci + (unsigned)k] = r; A.outPush[ci + (unsigned)k] = (uint32_t)k; }
+            for (int k = 0; k < nOutOps; k++) { const uint32_t op = outOps[k]; A.outOps[oi + (unsigned)k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op);
+                }
+            for (int k = 0; k < nCl; k++) { ygpu_clump c = outCl[k]; c.op_start += oi; A.outClumps[ci + (unsigned)k] = c; A.outRoot[ci + (unsigned)k] = r;
+                A.outPush[ci + (unsigned)k] = (uint32_t)k; }
             A.rootPushCount[r] = (unsigned)nCl;
         }
     }
     unsigned cScored = pub ? (unsigned)nCl : 0u, cOps = pub ? (unsigned)nOutOps : 0u;
     if (!pub) { splits = extCalls = extRows = extCells = perfect = touched = 0; }
-    splits = waveSumU(splits); extCalls = waveSumU(extCalls); extRows = waveSumU(extRows); extCells = waveSumU(extCells); perfect = waveSumU(perfect); touched = waveSumU(touched); cScored = waveSumU(cScored); cOps = waveSumU(cOps);
+    splits = waveSumU(splits); extCalls = waveSumU(extCalls); extRows = waveSumU(extRows); extCells = waveSumU(extCells); perfect = waveSumU(perfect); touched = waveSumU(touched);
+        cScored = waveSumU(cScored); cOps = waveSumU(cOps);
     if (lane == 0 && (splits | extCalls | cScored)) {
         unsigned long long *c = A.ctr->v;
-        atomicAdd(&c[C_SPLITS], (unsigned long long)splits); atomicAdd(&c[C_EXT_CALLS], (unsigned long long)extCalls); atomicAdd(&c[C_EXT_ROWS], (unsigned long long)extRows); atomicAdd(&c[C_EXT_CELLS], (unsigned long long)extCells);
-        atomicAdd(&c[C_PERFECT], (unsigned long long)perfect); atomicAdd(&c[C_TOUCHED], (unsigned long long)touched); atomicAdd(&c[C_SCORED], (unsigned long long)cScored); atomicAdd(&c[C_OPS], (unsigned long long)cOps);
+        atomicAdd(&c[C_SPLITS], (unsigned long long)splits); atomicAdd(&c[C_EXT_CALLS], (unsigned long long)extCalls); atomicAdd(&c[C_EXT_ROWS], (unsigned long long)extRows);
+            atomicAdd(&c[C_EXT_CELLS], (unsigned long long)extCells);
+        atomicAdd(&c[C_PERFECT], (unsigned long long)perfect); atomicAdd(&c[C_TOUCHED], (unsigned long long)touched); atomicAdd(&c[C_SCORED], (unsigned long long)cScored);
+            atomicAdd(&c[C_OPS], (unsigned long long)cOps);
     }
 }

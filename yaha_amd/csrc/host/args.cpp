@@ -39,7 +39,8 @@ static bool parseInt(const char *s, const char *key, int &out)
 static bool parseFloat(const char *s, const char *key, float &out)
 {
     out = (float)atof(s);                                           // float on purpose: Main.c:161-171
-    if (out <= 0.0 || out > 1.0) { fprintf(stderr, "%s is not a valid value for parameter %s.\nValue must be in the range 0<value<=1.0.\n\n", s, key); usage(stderr); return false; }
+    if (out <= 0.0 || out > 1.0) { fprintf(stderr, "%s is not a valid value for parameter %s.\nValue must be in the range 0<value<=1.0.\n\n", s, key); usage(stderr); return false;
+        }
     return true;
 }
 
@@ -52,10 +53,13 @@ int parseArgs(int argc, char **argv, Args &a)
         auto val = [&]() -> const char * { x++; return x < argc ? argv[x] : ""; };
         if (is("-h") || is("-?") || is("-xh")) { usage(stderr); return 1; }
         else if (is("-g")) { a.gfileName = val(); a.haveG = true; }
-        else if (is("-q")) { const char *v = val(); a.qfileName = (!strcmp(v, "-") || !strcmp(v, "-stdin") || !strcmp(v, "stdin")) ? "stdin" : v; query = true; index = false; }   // deliberate fix of Main.c:173-178, which turns these into "stdout" and then fails to open it
+        // deliberate fix of Main.c:173-178, which turns these into "stdout" and then fails to open it
+        else if (is("-q")) { const char *v = val(); a.qfileName = (!strcmp(v, "-") || !strcmp(v, "-stdin") || !strcmp(v, "stdin")) ? "stdin" : v; query = true; index = false; }
         else if (is("-o8")) { a.outputBlast8 = true; a.outputSAM = false; const char *v = val(); a.ofileName = (!strcmp(v, "-stdout")) ? "stdout" : v; a.haveO = true; }
-        else if (is("-osh")) { a.outputBlast8 = false; a.outputSAM = true; a.hardClip = true; const char *v = val(); a.ofileName = (!strcmp(v, "-stdout")) ? "stdout" : v; a.haveO = true; }
-        else if (is("-oss")) { a.outputBlast8 = false; a.outputSAM = true; a.hardClip = false; const char *v = val(); a.ofileName = (!strcmp(v, "-stdout")) ? "stdout" : v; a.haveO = true; }
+        else if (is("-osh")) { a.outputBlast8 = false; a.outputSAM = true; a.hardClip = true; const char *v = val(); a.ofileName = (!strcmp(v, "-stdout")) ? "stdout" : v;
+            a.haveO = true; }
+        else if (is("-oss")) { a.outputBlast8 = false; a.outputSAM = true; a.hardClip = false; const char *v = val(); a.ofileName = (!strcmp(v, "-stdout")) ? "stdout" : v;
+            a.haveO = true; }
         else if (is("-t")) { if (!parseInt(val(), "-t", a.numThreads)) return 2; }
         else if (is("-v")) a.verbose = true;
         else if (is("-x")) { a.xfileName = val(); a.haveX = true; query = true; index = false; }
@@ -85,12 +89,14 @@ int parseArgs(int argc, char **argv, Args &a)
         else if (is("-c")) { a.compress = true; index = false; }                                // the two below: Main.c:284-293 (builds of the reference without COMPILE_USER_MODE)
         else if (is("-u")) { a.uncompress = true; index = false; }
         else if (is("-gpus")) { if (!parseInt(val(), "-gpus", a.gpus)) return 2; if (a.gpus < 1) { fprintf(stderr, "-gpus must be at least 1.\n\n"); usage(stderr); return 2; } }
-        else if (is("-ctx")) { if (!parseInt(val(), "-ctx", a.ctxPerGpu)) return 2; if (a.ctxPerGpu < 1 || a.ctxPerGpu > 8) { fprintf(stderr, "-ctx must be between 1 and 8.\n\n"); usage(stderr); return 2; } }
+        else if (is("-ctx")) { if (!parseInt(val(), "-ctx", a.ctxPerGpu)) return 2; if (a.ctxPerGpu < 1 || a.ctxPerGpu > 8) { fprintf(stderr, "-ctx must be between 1 and 8.\n\n");
+            usage(stderr); return 2; } }
         else if (is("-device")) { if (!parseInt(val(), "-device", a.device)) return 2; }
         else if (is("-cpuindex")) a.cpuIndex = true;
         else if (is("-dpf")) { if (!parseBool(val(), "-dpf", a.devicePostFilter)) return 2; }        // post-filter (OQC / FBS / MAPQ) on the device (default) or on the host
         else if (is("-batch")) { if (!parseInt(val(), "-batch", a.batchReads)) return 2;
-                                 if (a.batchReads < 1 || a.batchReads > 65536) { fprintf(stderr, "-batch must be between 1 and 65536 (reads per device batch).\n\n"); usage(stderr); return 2; } }
+                                 if (a.batchReads < 1 || a.batchReads > 65536) { fprintf(stderr, "-batch must be between 1 and 65536 (reads per device batch).\n\n"); usage(stderr);
+                                     return 2; } }
         else { fprintf(stderr, "%s is not a valid option.\n\n", k); usage(stderr); return 2; }
     }
     a.query = query; a.index = index && !query;
@@ -152,7 +158,8 @@ std::string samHeader(const Args &a, const Genome &g)                   // outpu
     for (auto &s : g.seqs) { h += "@SQ\tSN:" + s.name; snprintf(buf, sizeof buf, "\tLN:%u\n", s.length); h += buf; }
     h += "@PG\tID:YAHA\tVN:0.1.83\tCL:yaha";
     h += " -q " + a.qfileName + " -x " + a.xfileName; h += a.hardClip ? " -osh " : " -oss "; h += a.ofileName;
-    snprintf(buf, sizeof buf, " -t %d -BW %d -G %d -H %d -M %d -MD %d -P %4.2f -X %d", a.numThreads, a.bandWidth, a.maxGap, a.maxHits, a.minMatch, a.maxDesert, a.minIdentity, a.XCutoff); h += buf;
+    snprintf(buf, sizeof buf, " -t %d -BW %d -G %d -H %d -M %d -MD %d -P %4.2f -X %d", a.numThreads, a.bandWidth, a.maxGap, a.maxHits, a.minMatch, a.maxDesert, a.minIdentity,
+        a.XCutoff); h += buf;
     if (a.affineGapScoring) { snprintf(buf, sizeof buf, " -AGS Y -GEC %d -GOC %d -MS %d -RC %d", a.GECost, a.GOCost, a.MScore, a.RCost); h += buf; } else h += " -AGS N";
     if (a.OQC) {
         snprintf(buf, sizeof buf, " -OQC Y -BP %d -MGDP %d -MNO %d", a.BPCost, a.maxBPLog, a.OQCMinNonOverlap); h += buf;

@@ -175,7 +175,8 @@ void IndexImage::release() { if (p) munmap(p, bytes); p = nullptr; bytes = 0; wo
 
 struct HugeU32 {
     uint32_t *p = nullptr; size_t bytes = 0;
-    explicit HugeU32(size_t n) { bytes = (n * 4 + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1); void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0); if (m != MAP_FAILED) { madvise(m, bytes, MADV_HUGEPAGE); p = (uint32_t *)m; } }
+    explicit HugeU32(size_t n) { bytes = (n * 4 + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1);
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0); if (m != MAP_FAILED) { madvise(m, bytes, MADV_HUGEPAGE); p = (uint32_t *)m; } }
     ~HugeU32() { if (p) munmap(p, bytes); }
     uint32_t &operator[](size_t i) { return p[i]; }
 };

@@ -35,7 +35,8 @@ void oqcParams(const Args &a, yoqc::Params &P, BPPTable &bpp)
 {
     const bool useTable = a.BPCost >= 0 && a.maxBPLog >= 0 && a.maxBPLog * (long)a.BPCost <= 4096;     // a step function only for non-negative costs
     if (useTable && (bpp.bpCost != a.BPCost || bpp.mbpl != a.maxBPLog)) bpp.build(a.BPCost, a.maxBPLog);
-    P.GOCost = a.GOCost; P.GECost = a.GECost; P.RCost = a.RCost; P.MScore = a.MScore; P.minNonOverlap = a.OQCMinNonOverlap; P.BPCost = a.BPCost; P.maxBPLog = a.maxBPLog; P.FBS = a.FBS ? 1 : 0;
+    P.GOCost = a.GOCost; P.GECost = a.GECost; P.RCost = a.RCost; P.MScore = a.MScore; P.minNonOverlap = a.OQCMinNonOverlap; P.BPCost = a.BPCost; P.maxBPLog = a.maxBPLog;
+        P.FBS = a.FBS ? 1 : 0;
     P.FBS_PSLength = a.FBS_PSLength; P.FBS_PSScore = a.FBS_PSScore; P.bppVmin = bpp.vmin; P.bppN = useTable ? (int)bpp.thr.size() : -1; P.bppThr = bpp.thr.data();
 }
 struct DupElem { int64_t clump; uint32_t SRO; int score; };             // dupArrayElem :1099-1104 (16 bytes like the reference's)
@@ -62,7 +63,8 @@ void postFilter(const Args &a, const Genome &g, const Read &r, const ygpu_clump 
                 if (d[i].SRO < d[j].SRO) break;
                 if (d[j].clump < 0) continue;
                 const ygpu_clump &c2 = cl[d[j].clump];
-                if (c1.sro == c2.sro && c1.sqo == c2.sqo && c1.eqo == c2.eqo && (c1.sro + c1.refLen) == (c2.sro + c2.refLen) && ((c1.status ^ c2.status) & yoqc::stReversed) == 0) d[j].clump = -1;
+                if (c1.sro == c2.sro && c1.sqo == c2.sqo && c1.eqo == c2.eqo && (c1.sro + c1.refLen) == (c2.sro + c2.refLen)
+                    && ((c1.status ^ c2.status) & yoqc::stReversed) == 0) d[j].clump = -1;
             }
             keep.push_back((int)d[i].clump);
         }
@@ -73,17 +75,22 @@ void postFilter(const Args &a, const Genome &g, const Read &r, const ygpu_clump 
     // Optimal Query Coverage + filter by similarity + mapping quality: oqc_core.h, the routine the device stage runs as well
     static thread_local BPPTable bpp; static thread_local std::vector<uint32_t> tlSeqStart, tlSeqLen; static thread_local const Genome *tlGenome = nullptr;
     yoqc::Params P; oqcParams(a, P, bpp);
-    if (tlGenome != &g || tlSeqStart.size() != g.seqs.size()) { tlSeqStart.clear(); tlSeqLen.clear(); for (auto &sq : g.seqs) { tlSeqStart.push_back(sq.start); tlSeqLen.push_back(sq.length); } tlGenome = &g; }
+    if (tlGenome != &g || tlSeqStart.size() != g.seqs.size()) { tlSeqStart.clear(); tlSeqLen.clear(); for (auto &sq : g.seqs) { tlSeqStart.push_back(sq.start);
+        tlSeqLen.push_back(sq.length); } tlGenome = &g; }
     yoqc::Seqs Sq{tlSeqStart.data(), tlSeqLen.data(), (uint32_t)tlSeqStart.size()};
-    static thread_local std::vector<yoqc::SortKey> tlKeys; static thread_local std::vector<int> tlStack, tlPfx, tlPath, tlPool; static thread_local std::vector<yoqc::CNode> tlNodes, tlPrim;
+    static thread_local std::vector<yoqc::SortKey> tlKeys; static thread_local std::vector<int> tlStack, tlPfx, tlPath, tlPool;
+        static thread_local std::vector<yoqc::CNode> tlNodes, tlPrim;
     static thread_local std::vector<yoqc::PAttr> tlPA; static thread_local std::vector<yoqc::OutRec> tlPush, tlOut;      // scratch reused from read to read
     size_t poolInts = 0; for (uint32_t i = 0; i < n; i++) poolInts += 2 * (size_t)cl[i].n_ops + 3;
-    if (tlKeys.size() < n) { tlKeys.resize(n); tlStack.resize(4 * (size_t)n + 8); tlPfx.resize(n); tlPath.resize(n); tlNodes.resize(n); tlPrim.resize(n); tlPA.resize(n); tlPush.resize(n); tlOut.resize(n); }
+    if (tlKeys.size() < n) { tlKeys.resize(n); tlStack.resize(4 * (size_t)n + 8); tlPfx.resize(n); tlPath.resize(n); tlNodes.resize(n); tlPrim.resize(n); tlPA.resize(n);
+        tlPush.resize(n); tlOut.resize(n); }
     if (tlPool.size() < poolInts) tlPool.resize(poolInts);
-    yoqc::Scratch S{tlKeys.data(), tlStack.data(), 0x7fffffff, nullptr, tlNodes.data(), tlPfx.data(), tlPath.data(), tlPool.data(), 0x7fffffff, nullptr, tlPrim.data(), tlPA.data(), tlPush.data()};
+    yoqc::Scratch S{tlKeys.data(), tlStack.data(), 0x7fffffff, nullptr, tlNodes.data(), tlPfx.data(), tlPath.data(), tlPool.data(), 0x7fffffff, nullptr, tlPrim.data(), tlPA.data(),
+        tlPush.data()};
     const int m = yoqc::run(P, Sq, cl, (int)n, ops, qlen, r.fwdCodes.data(), S, tlOut.data(), &primaryCount);
     for (int k = 0; k < m; k++) {
-        const yoqc::OutRec &o = tlOut[k]; OutClump oc; oc.c = cl[o.clump]; oc.ops = ops + cl[o.clump].op_start; oc.status = o.status; oc.mapQuality = o.mapQuality; oc.numSecondaries = o.numSecondaries; oc.matchedPrimary = o.matchedPrimary;
+        const yoqc::OutRec &o = tlOut[k]; OutClump oc; oc.c = cl[o.clump]; oc.ops = ops + cl[o.clump].op_start; oc.status = o.status; oc.mapQuality = o.mapQuality;
+            oc.numSecondaries = o.numSecondaries; oc.matchedPrimary = o.matchedPrimary;
         out.push_back(oc);
     }
 }
@@ -93,7 +100,8 @@ void oqcParamsFromArgs(const Args &a, yoqc::Params &P, std::vector<uint32_t> &th
     BPPTable t; const bool useTable = a.BPCost >= 0 && a.maxBPLog >= 0 && a.maxBPLog * (long)a.BPCost <= 4096;
     if (useTable) t.build(a.BPCost, a.maxBPLog);
     thr = t.thr;
-    P.GOCost = a.GOCost; P.GECost = a.GECost; P.RCost = a.RCost; P.MScore = a.MScore; P.minNonOverlap = a.OQCMinNonOverlap; P.BPCost = a.BPCost; P.maxBPLog = a.maxBPLog; P.FBS = a.FBS ? 1 : 0;
+    P.GOCost = a.GOCost; P.GECost = a.GECost; P.RCost = a.RCost; P.MScore = a.MScore; P.minNonOverlap = a.OQCMinNonOverlap; P.BPCost = a.BPCost; P.maxBPLog = a.maxBPLog;
+        P.FBS = a.FBS ? 1 : 0;
     P.FBS_PSLength = a.FBS_PSLength; P.FBS_PSScore = a.FBS_PSScore; P.bppVmin = t.vmin; P.bppN = useTable ? (int)thr.size() : -1; P.bppThr = thr.data();
 }
 }  // namespace yaha

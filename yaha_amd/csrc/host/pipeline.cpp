@@ -108,7 +108,8 @@ static bool sessionLoad(yaha_session *s)
     if (!loadIndex(a.xfileName.c_str(), s->index, s->err)) return false;
     a.wordLen = s->index.wordLen;                                            // Query.c:603-610
     if (s->index.maxHits < a.maxHits) {
-        fprintf(stderr, "WARNING: Index file made with maxHits of %d, while %d specified for this query run.\nMimimum of two (%d) will be used.\n", s->index.maxHits, a.maxHits, s->index.maxHits);
+        fprintf(stderr, "WARNING: Index file made with maxHits of %d, while %d specified for this query run.\nMimimum of two (%d) will be used.\n", s->index.maxHits, a.maxHits,
+            s->index.maxHits);
         a.maxHits = s->index.maxHits;
     }
     s->reader.maxQueryLength = a.maxQueryLength; s->reader.wordLen = a.wordLen;
@@ -146,7 +147,8 @@ static void formatFiltered(const yaha_session *s, const ygpu_filtered_batch *r, 
         }
         for (uint32_t k = k0; k < k1; k++) {
             const ygpu_out_clump &f = r->clumps[k];
-            OutClump o; o.c = f.c; o.ops = r->ops + f.c.op_start; o.status = f.status; o.mapQuality = f.mapQuality; o.numSecondaries = f.numSecondaries; o.matchedPrimary = f.matchedPrimary;
+            OutClump o; o.c = f.c; o.ops = r->ops + f.c.op_start; o.status = f.status; o.mapQuality = f.mapQuality; o.numSecondaries = f.numSecondaries;
+                o.matchedPrimary = f.matchedPrimary;
             printClump(a, s->genome, s->reads[i], o, (int)f.primaryCount, text);
         }
     }
@@ -155,7 +157,8 @@ static void formatBatch(yaha_session *s, const ygpu_result_batch *r, Text &text,
 {
     const uint32_t n = r->n_reads;
     text.clear();
-    if (nt <= 1 || n < 2 * (uint32_t)nt) { std::vector<OutClump> oc; formatRange(s, r, 0, n, text, oc); return; }   // straight into the batch's text (its buffer is reused from batch to batch)
+    // straight into the batch's text (its buffer is reused from batch to batch)
+    if (nt <= 1 || n < 2 * (uint32_t)nt) { std::vector<OutClump> oc; formatRange(s, r, 0, n, text, oc); return; }
     std::vector<Text> parts(nt);
     auto work = [&](int t) { std::vector<OutClump> oc; formatRange(s, r, (uint32_t)((uint64_t)n * t / nt), (uint32_t)((uint64_t)n * (t + 1) / nt), parts[t], oc); };
     std::vector<std::thread> th;
@@ -171,7 +174,8 @@ template <class T> struct StageQueue {
     std::mutex mu; std::condition_variable cvPush, cvPop; std::deque<T> q; size_t cap; int producers;
     StageQueue(size_t c, int np) : cap(c), producers(np) {}
     void push(T &&v) { std::unique_lock<std::mutex> lk(mu); cvPush.wait(lk, [&] { return q.size() < cap; }); q.push_back(std::move(v)); cvPop.notify_one(); }
-    bool pop(T &v) { std::unique_lock<std::mutex> lk(mu); cvPop.wait(lk, [&] { return !q.empty() || producers == 0; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); cvPush.notify_one(); return true; }
+    bool pop(T &v) { std::unique_lock<std::mutex> lk(mu); cvPop.wait(lk, [&] { return !q.empty() || producers == 0; }); if (q.empty()) return false; v = std::move(q.front());
+        q.pop_front(); cvPush.notify_one(); return true; }
     void producerDone() { std::lock_guard<std::mutex> lk(mu); if (--producers == 0) cvPop.notify_all(); }
 };
 }  // namespace
@@ -209,7 +213,8 @@ int runQueries(Args &a, FILE *log)
     if (fputs(S->header.c_str(), out) < 0) { fprintf(log, "Failure writing the output file.\n"); return 1; }
     ygpu_params P; paramsFromArgs(A, P);
     ygpu_index_view V; yaha_session_index_view(S.get(), &V);
-    // -gpus N devices x -ctx M contexts per device (default 3 -- four contexts of ~60 GB beside the image leave a later, heavier batch no memory to grow into: measured slower; while one context's batch is in a latency-bound device stage the others'
+    // -gpus N devices x -ctx M contexts per device (default 3 -- four contexts of ~60 GB beside the image leave a later, heavier batch no memory to grow into: measured slower;
+    // while one context's batch is in a latency-bound device stage the others'
     // batches compute).  Contexts of one device share its index image.
     const int perDev = std::max(1, A.ctxPerGpu), nDev = std::max(1, A.gpus), ngpu = nDev * perDev;
     std::vector<ygpu_ctx *> ctx(ngpu, nullptr);
@@ -224,23 +229,37 @@ int runQueries(Args &a, FILE *log)
     // error) stops the run: nothing after the last complete batch before it is written, and the exit code is 1.
     // Result storage of a batch: page-locked host memory (ygpu_host_alloc) the device copies into directly (ygpu_collect_into) -- no staging copy by the context
     // thread, no copy out of the context afterwards (two passes over ~9 KB a read otherwise); plain memory when it cannot be locked.  Grows, never shrinks.
-    struct ResBuf { void *p = nullptr; size_t cap = 0; bool pinned = false;
-                    ~ResBuf() { drop(); } void drop() { if (p) { if (pinned) ygpu_host_free(p); else free(p); } p = nullptr; cap = 0; }
-                    bool ensure(size_t bytes) { if (bytes <= cap) return true; drop(); const size_t c = bytes + bytes / 4 + 4096; p = ygpu_host_alloc(c); pinned = p != nullptr; if (!p) p = malloc(c); cap = p ? c : 0; return p != nullptr; } };
+    struct ResBuf {
+        void *p = nullptr; size_t cap = 0; bool pinned = false;
+        ~ResBuf() { drop(); }
+        void drop() { if (p) { if (pinned) ygpu_host_free(p); else free(p); } p = nullptr; cap = 0; }
+        bool ensure(size_t bytes)
+        {
+            if (bytes <= cap) return true;
+            drop();
+            const size_t c = bytes + bytes / 4 + 4096;
+            p = ygpu_host_alloc(c); pinned = p != nullptr;
+            if (!p) p = malloc(c);
+            cap = p ? c : 0; return p != nullptr;
+        }
+    };
     struct Batch { uint64_t ticket = 0; std::vector<Span> spans; std::vector<Read> reads; size_t nReads = 0; std::vector<uint8_t> codes; std::vector<uint64_t> offsets;
                    ResBuf clumpStart, ops, clumps; uint64_t nClumps = 0, nOps = 0; bool filtered = false; Text text; double tRead = 0, tDev = 0, tFmt = 0; };
     typedef std::unique_ptr<Batch> BatchP;
-    struct Pool { std::mutex mu; std::vector<BatchP> free; BatchP get() { { std::lock_guard<std::mutex> lk(mu); if (!free.empty()) { BatchP b = std::move(free.back()); free.pop_back(); return b; } } return BatchP(new Batch); }
+    struct Pool { std::mutex mu; std::vector<BatchP> free; BatchP get() { { std::lock_guard<std::mutex> lk(mu); if (!free.empty()) { BatchP b = std::move(free.back());
+        free.pop_back(); return b; } } return BatchP(new Batch); }
                   void put(BatchP &&b) { std::lock_guard<std::mutex> lk(mu); free.push_back(std::move(b)); } } pool;
     // Thread counts follow the CPUs the process may use (effectiveCpus: affinity and the control group's quota).  -t is the reference's thread count and is
     // echoed in @PG; given explicitly (> 1) it is the number of formatter threads, otherwise every CPU that is not a parser, the splitter or the writer is one.
     const int cpus = effectiveCpus();
     // (a parser thread does 1.4 M reads/s, a formatter 0.1 M with the host's post-filter and 0.65 M when the filter ran on the device: with several devices
     // behind a small CPU quota the parsers are what must not run short -- one for every two devices)
-    const int nParse = std::max(1, std::min(8, std::min(std::max((cpus + 7) / 10, (nDev + 1) / 2), std::max(1, cpus / 3)))), nFmt = A.numThreads > 1 ? A.numThreads : std::max(1, cpus - nParse - 2);
+    const int nParse = std::max(1, std::min(8, std::min(std::max((cpus + 7) / 10, (nDev + 1) / 2), std::max(1, cpus / 3)))), nFmt = A.numThreads > 1 ? A.numThreads : std::max(1,
+        cpus - nParse - 2);
     StageQueue<BatchP> parseQ((size_t)nParse + 2, 1), inQ((size_t)ngpu + 2, nParse), fmtQ((size_t)nFmt + (size_t)ngpu, ngpu + nParse), outQ((size_t)nFmt + 4, nFmt);
     std::atomic<bool> stop(false); std::atomic<int> rcAll(0); std::atomic<uint64_t> ticketsIssued(0), ticketsWritten(0);
-    auto fail = [&](const char *what) { if (!stop.exchange(true)) fprintf(log, "%s -- stopping; the output ends with the last batch completed before this one.\n", what); rcAll = 1; };
+    auto fail = [&](const char *what) { if (!stop.exchange(true)) fprintf(log, "%s -- stopping; the output ends with the last batch completed before this one.\n", what); rcAll = 1;
+        };
     // batches follow the read length: about 16 M bases each (16 384 reads of 1 kbp, 1 600 of 10 kbp, 65 536 of 100 bp), unless -batch gives a read count
     const size_t maxReads = A.batchReads > 0 ? (size_t)A.batchReads : 65536, maxBases = A.batchReads > 0 ? ~(size_t)0 : ((size_t)16 << 20);
     auto splitter = [&]() {
@@ -261,13 +280,16 @@ int runQueries(Args &a, FILE *log)
                 const double t0 = now();
                 if (b->reads.size() < b->spans.size()) b->reads.resize(b->spans.size());      // Read objects keep their strings' capacity from batch to batch
                 b->offsets.assign(1, 0); size_t bases = 0, k = 0;
-                for (auto &sp : b->spans) if (parseSpan(sp, S->reader.fastq, S->reader.maxQueryLength, S->reader.wordLen, b->reads[k])) { bases += b->reads[k].fwdCodes.size(); k++; }
+                for (auto &sp : b->spans) if (parseSpan(sp, S->reader.fastq, S->reader.maxQueryLength, S->reader.wordLen, b->reads[k])) { bases += b->reads[k].fwdCodes.size(); k++;
+                    }
                 b->nReads = k; b->codes.resize(bases); size_t o = 0;
-                for (size_t i = 0; i < k; i++) { const Read &rd = b->reads[i]; memcpy(b->codes.data() + o, rd.fwdCodes.data(), rd.fwdCodes.size()); o += rd.fwdCodes.size(); b->offsets.push_back(o); }
+                for (size_t i = 0; i < k; i++) { const Read &rd = b->reads[i]; memcpy(b->codes.data() + o, rd.fwdCodes.data(), rd.fwdCodes.size()); o += rd.fwdCodes.size();
+                    b->offsets.push_back(o); }
                 b->tRead = now() - t0;
             }
             b->spans.clear();                                                  // lets go of the input chunk
-            if (b->nReads == 0) { b->nClumps = b->nOps = 0; fmtQ.push(std::move(b)); } else inQ.push(std::move(b));      // a batch whose records were all skipped still takes its place in the output order
+            // a batch whose records were all skipped still takes its place in the output order
+            if (b->nReads == 0) { b->nClumps = b->nOps = 0; fmtQ.push(std::move(b)); } else inQ.push(std::move(b));
         }
         inQ.producerDone(); fmtQ.producerDone();
     };
@@ -284,13 +306,18 @@ int runQueries(Args &a, FILE *log)
     // the way the sequential loop does, GraphPath.cpp:633-700 -- those runs keep the host filter, as ygpu_set_postfilter insists)
     const bool deviceFilter = A.OQC && A.devicePostFilter && oqP.bppN >= 0 && oqP.minNonOverlap >= 1 && getenv("YAHA_HOST_OQC") == nullptr;
     ygpu_postfilter_params PF; memset(&PF, 0, sizeof PF);
-    PF.minNonOverlap = oqP.minNonOverlap; PF.BPCost = oqP.BPCost; PF.maxBPLog = oqP.maxBPLog; PF.FBS = oqP.FBS; PF.FBS_PSLength = oqP.FBS_PSLength; PF.FBS_PSScore = oqP.FBS_PSScore;
-    PF.bppVmin = oqP.bppVmin; PF.bppN = std::max(0, oqP.bppN); PF.bppThr = oqThr.data(); PF.n_seqs = (uint32_t)oqSeqStart.size(); PF.seq_start = oqSeqStart.data(); PF.seq_length = oqSeqLen.data();
-    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; uint64_t footprint = 0; bool claimed = false, measured = false, haveProfile = false; ygpu_arena_profile profile; };              // ready: 0 = image not there yet, 1 = there, -1 = failed
+    PF.minNonOverlap = oqP.minNonOverlap; PF.BPCost = oqP.BPCost; PF.maxBPLog = oqP.maxBPLog; PF.FBS = oqP.FBS; PF.FBS_PSLength = oqP.FBS_PSLength;
+        PF.FBS_PSScore = oqP.FBS_PSScore;
+    PF.bppVmin = oqP.bppVmin; PF.bppN = std::max(0, oqP.bppN); PF.bppThr = oqThr.data(); PF.n_seqs = (uint32_t)oqSeqStart.size(); PF.seq_start = oqSeqStart.data();
+        PF.seq_length = oqSeqLen.data();
+    // ready: 0 = image not there yet, 1 = there, -1 = failed
+    struct Warm { std::mutex mu, first; std::condition_variable cv; int firstRunning = 0; int ready = 0; uint64_t footprint = 0;
+        bool claimed = false, measured = false, haveProfile = false; ygpu_arena_profile profile; };
     std::vector<std::unique_ptr<Warm>> warm; for (int k = 0; k < nDev; k++) warm.emplace_back(new Warm);
     std::atomic<int> ctxUp(0), parked(0); double tCtxUp = 0;
     std::vector<std::atomic<uint64_t>> devReads(nDev); for (auto &x : devReads) x = 0;       // reads each device took (the stats line: do all devices pull their weight?)
-    // where a context thread's time goes, batches after a context's first (the stats line; microseconds): upload, run, waiting for the filter thread, snapshot; and the filter thread's post-filter + collect
+    // where a context thread's time goes, batches after a context's first (the stats line; microseconds): upload, run, waiting for the filter thread, snapshot; and the filter
+    // thread's post-filter + collect
     std::atomic<uint64_t> usUpload(0), usRun(0), usWaitFilter(0), usSnapshot(0), usFilter(0), usIdle(0), nLater(0);
     // The index image reaches the devices through ONE call (ygpu_init_multi): the first device takes it from the host, the others from their neighbour over xGMI,
     // piece by piece -- the reference maps its index once for all threads (Query.c:565-626); N uploads of 16.7 GB at once would share the host's memory instead.
@@ -303,16 +330,21 @@ int runQueries(Args &a, FILE *log)
         const int rc = ygpu_init_multi(devs.data(), nDev, perDev, &V, &P, ctx.data(), leadRc.data());      // ctx[k * perDev + j] = context j of device k
         for (int k = 0; k < nDev; k++) if (rc != 0 && !ctx[k * perDev]) leadRc[k] = rc;
         // (the device that failed is reported before the ones that were merely not started because of it)
-        if (rc != 0) for (int k = 0; k < nDev; k++) { ygpu_ctx *c = ctx[k * perDev]; if (leadRc[k] != 0 && c && strncmp(ygpu_last_error(c), "not started", 11) != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", devs[k], leadRc[k], ygpu_last_error(c)); fail(m); break; } }
+        if (rc != 0) for (int k = 0; k < nDev; k++) { ygpu_ctx *c = ctx[k * perDev]; if (leadRc[k] != 0 && c && strncmp(ygpu_last_error(c), "not started", 11) != 0) { char m[512];
+            snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", devs[k], leadRc[k], ygpu_last_error(c)); fail(m); break; } }
     };
     auto device = [&](int d) {
         BatchP b; bool first = true; Warm &W = *warm[d / perDev]; const int dev = devs[d / perDev], leadCtx = d - d % perDev;
         int rc0;
-        if (d == 0) { bringUpDevices(); for (int k = 0; k < nDev; k++) { Warm &Wk = *warm[k]; { std::lock_guard<std::mutex> lk(Wk.mu); Wk.ready = leadRc[k] == 0 ? 1 : -1; } Wk.cv.notify_all(); } }
+        if (d == 0) { bringUpDevices(); for (int k = 0; k < nDev; k++) { Warm &Wk = *warm[k]; { std::lock_guard<std::mutex> lk(Wk.mu); Wk.ready = leadRc[k] == 0 ? 1 : -1;
+            } Wk.cv.notify_all(); } }
         { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : (leadRc[d / perDev] ? leadRc[d / perDev] : YGPU_ENODEV); }
         if (rc0 == 0 && deviceFilter) rc0 = ygpu_set_postfilter(ctx[d], &PF);
-        if (rc0 != 0) { char m[512]; snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", dev, rc0, ctx[d] ? ygpu_last_error(ctx[d]) : (d == leadCtx ? "" : "(the device's first context failed)")); fail(m); }
-        if (++ctxUp == ngpu) { tCtxUp = now(); if (timing) fprintf(stderr, "[yaha] %d device contexts up (index image on %d device%s) %.1f ms after start\n", ngpu, nDev, nDev > 1 ? "s" : "", tCtxUp - tEnter); }
+        if (rc0 != 0) { char m[512];
+            snprintf(m, sizeof m, "ygpu_init(device %d) failed: %d %s", dev, rc0, ctx[d] ? ygpu_last_error(ctx[d]) : (d == leadCtx ? "" : "(the device's first context failed)"));
+            fail(m); }
+        if (++ctxUp == ngpu) { tCtxUp = now();
+            if (timing) fprintf(stderr, "[yaha] %d device contexts up (index image on %d device%s) %.1f ms after start\n", ngpu, nDev, nDev > 1 ? "s" : "", tCtxUp - tEnter); }
         // A context's FIRST batch.  The first context of a device to get here leads: its first batch allocates its arenas, and what it then holds is the measure of what
         // a context needs.  The others wait for that measure BEFORE they take a batch, then go one at a time: a context that would start with less free memory than 0.9
         // of the measure is left out -- parked without ever holding a batch (round 4 took the batch first and pushed it back: a queue whose other consumers had already
@@ -326,7 +358,8 @@ int runQueries(Args &a, FILE *log)
         // batch keeps the sequential order (its arenas are measured after it).  YAHA_SERIAL_FILTER=1: every batch in the sequential order.
         struct FilterSide { std::mutex mu; std::condition_variable cv; BatchP b; double t0 = 0; bool busy = false, quit = false; std::thread th; } F;
         const bool overlapFilter = deviceFilter && getenv("YAHA_SERIAL_FILTER") == nullptr;
-        auto collectFiltered = [&](BatchP &fb, ygpu_result_batch &res) -> int {  // post-filter (of the snapshot, or of the context's last run) and its results into the batch's own buffers
+        // post-filter (of the snapshot, or of the context's last run) and its results into the batch's own buffers
+        auto collectFiltered = [&](BatchP &fb, ygpu_result_batch &res) -> int {
             uint64_t nc = 0, no = 0;
             int rc = ygpu_postfilter(ctx[d]); if (rc == 0) rc = ygpu_filtered_size(ctx[d], &nc, &no); if (rc != 0) return rc;
             if (!fb->clumpStart.ensure(4 * (fb->nReads + 1)) || !fb->clumps.ensure(sizeof(ygpu_out_clump) * nc) || !fb->ops.ensure(4 * no)) return YGPU_ENOMEM;
@@ -334,7 +367,9 @@ int runQueries(Args &a, FILE *log)
             res.n_clumps = fr.n_clumps; res.n_ops = fr.n_ops; return rc;
         };
         auto deliver = [&](BatchP &fb, int rc, const ygpu_result_batch &res, double t0) {
-            if (rc != 0) { char m[512]; snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, rc == YGPU_ENOMEM && !fb->ops.p ? "host memory for the results" : ygpu_last_error(ctx[d])); fail(m); fb->nReads = 0; fmtQ.push(std::move(fb)); return; }
+            if (rc != 0) { char m[512];
+                snprintf(m, sizeof m, "context %d: hot path failed (%d): %s", d, rc, rc == YGPU_ENOMEM && !fb->ops.p ? "host memory for the results" : ygpu_last_error(ctx[d]));
+                fail(m); fb->nReads = 0; fmtQ.push(std::move(fb)); return; }
             fb->nClumps = res.n_clumps; fb->nOps = res.n_ops;
             fb->tDev = now() - t0; devReads[d / perDev] += fb->nReads;
             fmtQ.push(std::move(fb));
@@ -365,7 +400,8 @@ int runQueries(Args &a, FILE *log)
                     const bool known = ygpu_memory(ctx[d], &fb, &tb, &mine) == 0;
                     roomy = known && (double)fb >= 2.0 * (double)W.footprint;
                     if (known && (double)fb < 0.9 * (double)W.footprint) {
-                        if (timing || stats) fprintf(stderr, "[yaha] context %d left out: %.1f GB free on device %d, the first context's arenas hold %.1f GB\n", d, fb / 1e9, dev, W.footprint / 1e9);
+                        if (timing || stats) fprintf(stderr, "[yaha] context %d left out: %.1f GB free on device %d, the first context's arenas hold %.1f GB\n", d, fb / 1e9, dev,
+                            W.footprint / 1e9);
                         (void)ygpu_park(ctx[d]); parked++; break;
                     }
                 }
@@ -381,7 +417,8 @@ int runQueries(Args &a, FILE *log)
                     const double p0 = now(); const int prc = ygpu_presize(ctx[d], &W.profile);
                     { std::lock_guard<std::mutex> lk(W.mu); W.firstRunning--; } W.cv.notify_all();
                     if (timing) fprintf(stderr, "[yaha] context %d: arenas presized from the device's first context in %.1f ms (rc %d)\n", d, now() - p0, prc);
-                    if (prc == YGPU_ENOMEM) { if (timing || stats) fprintf(stderr, "[yaha] context %d left out: no room for its arenas on device %d\n", d, dev); (void)ygpu_park(ctx[d]); parked++; break; }
+                    if (prc == YGPU_ENOMEM) { if (timing || stats) fprintf(stderr, "[yaha] context %d left out: no room for its arenas on device %d\n", d, dev);
+                        (void)ygpu_park(ctx[d]); parked++; break; }
                     if (prc == 0) { first = false; one.unlock(); }
                 }
             }
@@ -392,7 +429,8 @@ int runQueries(Args &a, FILE *log)
             ygpu_read_batch rb{(uint32_t)b->nReads, b->codes.data(), b->offsets.data()}; ygpu_result_batch res; memset(&res, 0, sizeof res); bool handedOver = false;
             auto hotPath = [&]() -> int {                                      // upload, run (+ post-filter), results straight into the batch's own buffers
                 const double h0 = now();
-                int rc = ygpu_upload_nowait(ctx[d], &rb); const double h1 = now(); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;      // (the batch lives until it is printed: no wait for its bytes here)
+                // (the batch lives until it is printed: no wait for its bytes here)
+                int rc = ygpu_upload_nowait(ctx[d], &rb); const double h1 = now(); if (rc == 0) rc = ygpu_run(ctx[d]); if (rc != 0) return rc;
                 const double h2 = now();
                 uint64_t nc = 0, no = 0; b->filtered = deviceFilter;
                 if (!first) { usUpload += (uint64_t)((h1 - h0) * 1e3); usRun += (uint64_t)((h2 - h1) * 1e3); nLater++; }
@@ -407,7 +445,8 @@ int runQueries(Args &a, FILE *log)
                 }
                 if (deviceFilter) {
                     rc = collectFiltered(b, res);
-                    if (timing && first) fprintf(stderr, "[yaha] context %d, first batch: upload %.1f  run %.1f  post-filter and collect %.1f ms\n", d, h1 - h0, h2 - h1, now() - h2);
+                    if (timing && first) fprintf(stderr, "[yaha] context %d, first batch: upload %.1f  run %.1f  post-filter and collect %.1f ms\n", d, h1 - h0, h2 - h1,
+                        now() - h2);
                     return rc;
                 }
                 rc = ygpu_result_size(ctx[d], &nc, &no); if (rc != 0) return rc;
@@ -438,17 +477,20 @@ int runQueries(Args &a, FILE *log)
         fmtQ.producerDone();
     };
     auto formatter = [&]() {
-        yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs; local.genome.maxROff = S->genome.maxROff;
+        yaha_session local; local.args = A; local.genome.bases = S->genome.bases; local.genome.nBaseBytes = S->genome.nBaseBytes; local.genome.seqs = S->genome.seqs;
+            local.genome.maxROff = S->genome.maxROff;
         BatchP b;
         while (fmtQ.pop(b)) {
             const double t0 = now(); b->text.clear();
             if (!stop && b->nReads && b->filtered) {
                 ygpu_filtered_batch fr; memset(&fr, 0, sizeof fr);
-                fr.n_reads = (uint32_t)b->nReads; fr.clump_start = (const uint32_t *)b->clumpStart.p; fr.clumps = (const ygpu_out_clump *)b->clumps.p; fr.ops = (const uint32_t *)b->ops.p; fr.n_clumps = b->nClumps; fr.n_ops = b->nOps;
+                fr.n_reads = (uint32_t)b->nReads; fr.clump_start = (const uint32_t *)b->clumpStart.p; fr.clumps = (const ygpu_out_clump *)b->clumps.p;
+                    fr.ops = (const uint32_t *)b->ops.p; fr.n_clumps = b->nClumps; fr.n_ops = b->nOps;
                 local.reads.swap(b->reads); formatFiltered(&local, &fr, b->text); local.reads.swap(b->reads);
             } else if (!stop && b->nReads) {
                 ygpu_result_batch res; memset(&res, 0, sizeof res);
-                res.n_reads = (uint32_t)b->nReads; res.clump_start = (const uint32_t *)b->clumpStart.p; res.clumps = (const ygpu_clump *)b->clumps.p; res.ops = (const uint32_t *)b->ops.p; res.n_clumps = b->nClumps; res.n_ops = b->nOps;
+                res.n_reads = (uint32_t)b->nReads; res.clump_start = (const uint32_t *)b->clumpStart.p; res.clumps = (const ygpu_clump *)b->clumps.p;
+                    res.ops = (const uint32_t *)b->ops.p; res.n_clumps = b->nClumps; res.n_ops = b->nOps;
                 local.reads.swap(b->reads); formatBatch(&local, &res, b->text, 1); local.reads.swap(b->reads);
             }
             b->tFmt = now() - t0;
@@ -466,7 +508,8 @@ int runQueries(Args &a, FILE *log)
                 if (!stop) {
                     if (w->text.len && fwrite(w->text.p, 1, w->text.len, out) != w->text.len) fail("Failure writing the output file");
                     else { const double t = now(); if (nWritten == 0) { tFirstOut = t; nFirst = w->nReads; } tLastOut = t; nWritten += w->nReads; }
-                    if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  parse %.1f  device (upload, run, collect) %.1f  format %.1f ms  written at %.1f\n", (unsigned long long)w->ticket, w->nReads, w->tRead, w->tDev, w->tFmt, now() - tEnter);
+                    if (timing) fprintf(stderr, "[yaha] ticket %llu: %zu reads  parse %.1f  device (upload, run, collect) %.1f  format %.1f ms  written at %.1f\n",
+                        (unsigned long long)w->ticket, w->nReads, w->tRead, w->tDev, w->tFmt, now() - tEnter);
                 }
                 pool.put(std::move(w));
             }
@@ -482,21 +525,30 @@ int runQueries(Args &a, FILE *log)
     for (auto &x : th) x.join();
     const double tDone = now();
     // every batch the splitter cut must have reached the writer, in order: a batch lost between two stages would otherwise be a shorter SAM with exit code 0
-    if (!stop && ticketsWritten.load() != ticketsIssued.load()) { fprintf(log, "internal error: %llu of %llu batches were written -- the output is incomplete.\n", (unsigned long long)ticketsWritten.load(), (unsigned long long)ticketsIssued.load()); rcAll = 1; }
+    if (!stop && ticketsWritten.load() != ticketsIssued.load()) {
+        fprintf(log, "internal error: %llu of %llu batches were written -- the output is incomplete.\n", (unsigned long long)ticketsWritten.load(),
+        (unsigned long long)ticketsIssued.load()); rcAll = 1; }
     // The command line (csrc/main.cpp) leaves right after this function: it sets YAHA_FAST_EXIT and lets the process exit release the device memory and the
     // page-locked buffers in one go, instead of a hipFree per buffer (a second of waiting at the end of every run, measured).  Library users get the orderly path.
     const bool fastExit = getenv("YAHA_FAST_EXIT") != nullptr;
     if (!fastExit) for (int d = ngpu - 1; d >= 0; d--) if (ctx[d]) ygpu_destroy(ctx[d]);     // clones before their parents
-    if (fastExit) (void)new std::vector<BatchP>(std::move(pool.free));     // (the batches -- a million small strings, the page-locked buffers -- go with the process as well: freeing them one by one was 0.3 s)
+    // (the batches -- a million small strings, the page-locked buffers -- go with the process as well: freeing them one by one was 0.3 s)
+    if (fastExit) (void)new std::vector<BatchP>(std::move(pool.free));
     if (fflush(out) != 0 || ferror(out)) { if (!stop) fprintf(log, "Failure writing the output file.\n"); rcAll = 1; }
     if (out != stdout && fclose(out) != 0) { fprintf(log, "Failure closing the output file.\n"); rcAll = 1; }
     if (timing) fprintf(stderr, "[yaha] batches done %.1f ms after start, teardown %.1f ms\n", tDone - tEnter, now() - tDone);
     if (stats) {    // one line for scripts (bench.py): steady = reads written after the first batch / time from the first batch's write to the last one's
         const double steady = (nWritten > nFirst && tLastOut > tFirstOut) ? (nWritten - nFirst) / ((tLastOut - tFirstOut) * 1e-3) : 0.0;
-        std::string per = "["; for (int k = 0; k < nDev; k++) { char t[32]; snprintf(t, sizeof t, "%s%llu", k ? ", " : "", (unsigned long long)devReads[k].load()); per += t; } per += "]";
-        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, \"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d, \"ctx_left_out\": %d, \"reads_per_device\": %s, \"context_thread_ms_per_batch\": {\"wait_for_a_batch\": %.2f, \"upload\": %.2f, \"run\": %.2f, \"wait_for_filter_thread\": %.2f, \"snapshot\": %.2f}, \"filter_thread_ms_per_batch\": %.2f}\n",
-                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev, parked.load(), per.c_str(),
-                usIdle / 1e3 / std::max<uint64_t>(1, nLater), usUpload / 1e3 / std::max<uint64_t>(1, nLater), usRun / 1e3 / std::max<uint64_t>(1, nLater), usWaitFilter / 1e3 / std::max<uint64_t>(1, nLater), usSnapshot / 1e3 / std::max<uint64_t>(1, nLater), usFilter / 1e3 / std::max<uint64_t>(1, nLater));
+        std::string per = "["; for (int k = 0; k < nDev; k++) { char t[32]; snprintf(t, sizeof t, "%s%llu", k ? ", " : "", (unsigned long long)devReads[k].load()); per += t;
+            } per += "]";
+        fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, "
+            "\"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d, \"ctx_left_out\": %d, "
+            "\"reads_per_device\": %s, \"context_thread_ms_per_batch\": {\"wait_for_a_batch\": %.2f, \"upload\": %.2f, \"run\": %.2f, \"wait_for_filter_thread\": %.2f, "
+            "\"snapshot\": %.2f}, \"filter_thread_ms_per_batch\": %.2f}\n",
+                (unsigned long long)nWritten, tCtxUp - tEnter, tFirstOut - tEnter, tLastOut - tEnter, now() - tEnter, steady, cpus, nFmt, nParse, nDev, perDev, parked.load(),
+                    per.c_str(),
+                usIdle / 1e3 / std::max<uint64_t>(1, nLater), usUpload / 1e3 / std::max<uint64_t>(1, nLater), usRun / 1e3 / std::max<uint64_t>(1, nLater),
+                    usWaitFilter / 1e3 / std::max<uint64_t>(1, nLater), usSnapshot / 1e3 / std::max<uint64_t>(1, nLater), usFilter / 1e3 / std::max<uint64_t>(1, nLater));
     }
     return rcAll;
 }
@@ -527,7 +579,8 @@ int yaha_session_next_batch(yaha_session *s, uint32_t max_reads, ygpu_read_batch
 {
     s->reads.clear(); s->codes.clear(); s->offsets.assign(1, 0);
     Read r;
-    while (s->reads.size() < max_reads && s->reader.next(r)) { s->codes.insert(s->codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); s->offsets.push_back(s->codes.size()); s->reads.push_back(std::move(r)); r = Read(); }
+    while (s->reads.size() < max_reads && s->reader.next(r)) { s->codes.insert(s->codes.end(), r.fwdCodes.begin(), r.fwdCodes.end()); s->offsets.push_back(s->codes.size());
+        s->reads.push_back(std::move(r)); r = Read(); }
     b->n_reads = (uint32_t)s->reads.size(); b->codes = s->codes.data(); b->offsets = s->offsets.data(); return 0;
 }
 int yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **text, size_t *len)
@@ -538,11 +591,13 @@ int yaha_session_emit(yaha_session *s, const ygpu_result_batch *r, const char **
 int yaha_session_postfilter_params(yaha_session *s, ygpu_postfilter_params *p)
 {
     yoqc::Params P; oqcParamsFromArgs(s->args, P, s->pfThr);
-    if (!s->args.OQC || P.bppN < 0 || P.minNonOverlap < 1) { s->err = "the device post-filter takes OQC runs with non-negative break point costs and -MNO of at least 1 only"; return YGPU_EINVAL; }
+    if (!s->args.OQC || P.bppN < 0 || P.minNonOverlap < 1) { s->err = "the device post-filter takes OQC runs with non-negative break point costs and -MNO of at least 1 only";
+        return YGPU_EINVAL; }
     s->pfSeqStart.clear(); s->pfSeqLen.clear(); for (auto &sq : s->genome.seqs) { s->pfSeqStart.push_back(sq.start); s->pfSeqLen.push_back(sq.length); }
     memset(p, 0, sizeof *p);
     p->minNonOverlap = P.minNonOverlap; p->BPCost = P.BPCost; p->maxBPLog = P.maxBPLog; p->FBS = P.FBS; p->FBS_PSLength = P.FBS_PSLength; p->FBS_PSScore = P.FBS_PSScore;
-    p->bppVmin = P.bppVmin; p->bppN = P.bppN; p->bppThr = s->pfThr.data(); p->n_seqs = (uint32_t)s->pfSeqStart.size(); p->seq_start = s->pfSeqStart.data(); p->seq_length = s->pfSeqLen.data();
+    p->bppVmin = P.bppVmin; p->bppN = P.bppN; p->bppThr = s->pfThr.data(); p->n_seqs = (uint32_t)s->pfSeqStart.size(); p->seq_start = s->pfSeqStart.data();
+        p->seq_length = s->pfSeqLen.data();
     return 0;
 }
 int yaha_session_emit_filtered(yaha_session *s, const ygpu_filtered_batch *r, const char **text, size_t *len)

@@ -179,7 +179,8 @@ bool parseSpan(const Span &s, bool fastq, int maxQueryLength, int wordLen, Read 
     if (fastq) {
         const size_t nq = copyNoNl(b + s.qual0, b + s.qualEnd, r.qual, (size_t)maxQueryLength, over);
         if (over) { fprintf(stderr, "Warning.  Quality score sequence exceeds maximum length of %d.  Query will be skipped.\n", maxQueryLength); fail = true; }
-        if (n != nq) { fprintf(stderr, "Warning.  Query sequence (%d) and quality score sequence (%d) have different lengths in fastq file.  Query will be skipped.\n", (int)n, (int)nq); fail = true; }
+        if (n != nq) { fprintf(stderr, "Warning.  Query sequence (%d) and quality score sequence (%d) have different lengths in fastq file.  Query will be skipped.\n", (int)n,
+            (int)nq); fail = true; }
     }
     if (n > 0 && (int)n < wordLen) { fprintf(stderr, "Query length must be at least wordlen bases long. Query will be skipped.\n"); fail = true; }
     if (fail || n == 0) return false;

@@ -53,7 +53,9 @@ void printClump(const Args &a, const Genome &g, const Read &r, const OutClump &o
         if (a.hardClip) { qstart = c.sqo; qend = c.eqo; }
         if (qend >= qstart) w = putS(w, queryBuf.data() + qstart, (size_t)(qend - qstart + 1));
         *w++ = '\t';
-        if (a.fastq) { if (reversed) for (int i = qend; i >= qstart; i--) *w++ = r.qual[i]; else if (qend >= qstart) w = putS(w, r.qual.data() + qstart, (size_t)(qend - qstart + 1)); }   // sic :206-212
+        // sic :206-212
+        if (a.fastq) { if (reversed) for (int i = qend; i >= qstart; i--) *w++ = r.qual[i];
+            else if (qend >= qstart) w = putS(w, r.qual.data() + qstart, (size_t)(qend - qstart + 1)); }
         else *w++ = '*';
         *w++ = '\t';
         w = putS(w, "AS:i:", 5); w = putI(w, c.totScore); w = putS(w, "\tNM:i:", 6); w = putI(w, c.gapBases + c.mismatchedBases); w = putS(w, "\tMD:Z:", 6);

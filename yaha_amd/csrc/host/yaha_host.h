@@ -51,7 +51,8 @@ struct IndexFile {
     int wordLen = 0; int maxHits = 0; uint32_t totalMatches = 0; const uint32_t *SO = nullptr; const uint32_t *ROA = nullptr;
 };
 // builds the complete file image {-1, wordLen, maxHits, total} + SO[4^L+1] + ROA[total] (huge-page backed: 4.3 GB at L=15)
-struct IndexImage { uint32_t *p = nullptr; size_t words = 0, bytes = 0; bool alloc(size_t n); void release(); uint32_t &operator[](size_t i) { return p[i]; } ~IndexImage() { release(); } };
+struct IndexImage { uint32_t *p = nullptr; size_t words = 0, bytes = 0; bool alloc(size_t n); void release(); uint32_t &operator[](size_t i) { return p[i];
+    } ~IndexImage() { release(); } };
 bool buildIndex(const Genome &g, int wordLen, int skipDist, int maxHits, IndexImage &image, FILE *log);
 // the same image built on HIP device `device` (device/index_build.hip)
 bool buildIndexDevice(int device, const Genome &g, int wordLen, int skipDist, int maxHits, IndexImage &image, FILE *log, std::string &err);

@@ -45,7 +45,8 @@ struct OutRec { int clump; uint8_t status, mapQuality; uint16_t numSecondaries, 
 //   running-sum tables: `pool` while they fit its poolCap ints, `pool2` after that (the sum over the read's clumps of 2 n_ops + 3 ints holds every table);
 //   prim, pa, push: n each (touched once at the end).
 // The device keeps keys, stack, nodes, tbl, path and a small pool in LDS (device/oqc_stage.h); the host has one of everything.
-struct Scratch { SortKey *keys; int *stack; int stackCap; int *stack2; CNode *nodes; int *tbl; int *path; int *pool; int poolCap; int *pool2; CNode *prim; PAttr *pa; OutRec *push; };
+struct Scratch { SortKey *keys; int *stack; int stackCap; int *stack2; CNode *nodes; int *tbl; int *path; int *pool; int poolCap; int *pool2; CNode *prim; PAttr *pa; OutRec *push;
+    };
 
 struct Rand { uint32_t s[5]; };                                        // Marsaglia xorshift, Math.c:257-290
 YQ_FN uint32_t randBits(Rand &r)
@@ -128,7 +129,8 @@ struct Run {
                 if (less) {
                     if (i != store) { arr[i].key = yk; arr[i].clump = yc; arr[store].key = xk; arr[store].clump = xc; }
                     store++;
-                    if (store == i + 1) { yk = nk; yc = nc; } else { yk = arr[store].key; yc = arr[store].clump; }      // (store == i: the element just written there, read back in order)
+                    // (store == i: the element just written there, read back in order)
+                    if (store == i + 1) { yk = nk; yc = nc; } else { yk = arr[store].key; yc = arr[store].clump; }
                 }
             }
             { const uint64_t sk0 = arr[store].key, rk0 = arr[right].key; const int sc0 = arr[store].clump, rc0 = arr[right].clump;
@@ -256,7 +258,13 @@ struct Run {
         if (rightBest) {
             rn.qLenInOQC = (uint16_t)(1 + rn.EQO - rn.SQO);
             int remaining = overlap, cur = left;
-            for (;;) { CNode &cn = S.nodes[cur]; int q = remaining < (int)cn.qLenInOQC ? remaining : (int)cn.qLenInOQC; cn.qLenInOQC = (uint16_t)(cn.qLenInOQC - q); remaining -= q; if (remaining <= 0) break; cur = cn.bestPrev; }
+            for (;;) {
+                CNode &cn = S.nodes[cur];
+                int q = remaining < (int)cn.qLenInOQC ? remaining : (int)cn.qLenInOQC;
+                cn.qLenInOQC = (uint16_t)(cn.qLenInOQC - q); remaining -= q;
+                if (remaining <= 0) break;
+                cur = cn.bestPrev;
+            }
         } else rn.qLenInOQC = (uint16_t)((1 + rn.EQO - rn.SQO) - overlap);
     }
     // cacheQlenInOQCPath :841-867: the reference recurses to the head of the best path to `right` and works its way back; here the path is written out first
@@ -324,7 +332,8 @@ struct Run {
             for (int p = bestNode; p >= 0; p = gn[p].bestPrev) {
                 primaries[pi] = gn[p];
                 PAttr a; a.alignedQueryLength = 1 + gn[p].EQO - gn[p].SQO; a.numOutputSecondaries = 0; a.secondScore = 0; a.thirdScore = 0; PA[pi] = a;
-                OutRec o; o.clump = gn[p].clump; o.status = (uint8_t)(cl[gn[p].clump].status | stPrimary); o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(pi + 1); o.pad = 0;
+                OutRec o; o.clump = gn[p].clump; o.status = (uint8_t)(cl[gn[p].clump].status | stPrimary); o.mapQuality = 255; o.numSecondaries = 0;
+                    o.matchedPrimary = (uint16_t)(pi + 1); o.pad = 0;
                 push[nPush++] = o;
                 gn[p].clump = -1; pi--;
             }
@@ -350,7 +359,8 @@ struct Run {
                     if (overlapsEnough(overlap, curQLen, targetOverlap) && overlapsEnough(overlap, pathQLen, targetOverlap)) {
                         pa.numOutputSecondaries += 1;
                         if (P.FBS) {
-                            OutRec o; o.clump = cn.clump; o.status = cl[cn.clump].status; o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(maxIndex + 1); o.pad = 0;
+                            OutRec o; o.clump = cn.clump; o.status = cl[cn.clump].status; o.mapQuality = 255; o.numSecondaries = 0; o.matchedPrimary = (uint16_t)(maxIndex + 1);
+                                o.pad = 0;
                             push[nPush++] = o; continue;
                         }
                     }
@@ -382,7 +392,8 @@ YQ_FN int run(const Params &P, const Seqs &g, const ygpu_clump *cl, int n, const
     for (int i = 0; i < n; i++) X.makeKey(i, qlen);
     X.sortKeys(n, fwdCodes, qlen);
     const int cnt = X.dedup(n);
-    { int last = 0; for (int p = 0; p < cnt; p++) { X.makeNode(p, g, qlen, last); const int f = S.nodes[p].seqNum; if (f != 255) last = f; } }      // (most nodes of a read lie in one or two sequences)
+    // (most nodes of a read lie in one or two sequences)
+    { int last = 0; for (int p = 0; p < cnt; p++) { X.makeNode(p, g, qlen, last); const int f = S.nodes[p].seqNum; if (f != 255) last = f; } }
     int bestScore = YQ_WORST, bestNode = -1, startj = 1;
     for (int i = 0; i < cnt; i++) {                                     // :973-1063
         X.cachePath(i);
