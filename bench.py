@@ -667,6 +667,10 @@ def main():
                 stage_ms[k2] = stage_ms.get(k2, 0.0) + v / max(1, args.blocks)      # mean over the blocks of the per-block sums
         # ---- after the timed region ----
         t = time.time(); r = ctxs[0].collect(); t_down = time.time() - t
+        try:
+            tv = ctxs[0].trace_volume()          # the trace stream of the batch's last run: records written against records a traceback can visit
+        except Exception as e:
+            tv = None; log("trace volume: %s" % str(e)[:200])
         counters = r.counters.as_dict()
         n_clumps = int(r.n_clumps); n_ops = int(r.n_ops)
         d2h = None; unshared_rows_ms = None
@@ -723,6 +727,7 @@ def main():
         kname, kernel_ms, stream_bytes = "k_align", align_ms, None
     kbytes = B * n_reads
     achieved = (kbytes / (kernel_ms * 1e-3)) / 1e9 if kernel_ms > 0 else 0.0
+    ach_un = (kbytes / (unshared_rows_ms * 1e-3)) / 1e9 if (rows_ms > 0 and unshared_rows_ms) else None      # the same launch with the chip to itself
     # HBM traffic of that launch from the PMC counters: bench.py cannot read hardware counters of its own process, so this is the figure of the last
     # profiling pass of the same command (tools/pmc_pass.sh -> profiles/pmc_latest.json), used only when it was taken on the same batch size and kernel.
     traffic, pmc = None, None
@@ -749,18 +754,26 @@ def main():
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": ("int16" if packed else "int32"), "dtype_note": "integer dynamic programming, bit-exact: the X-drop extension rows (93 % of the DP cells) in saturating packed int16 when the scores fit (else int32), everything else int32", "data": "synthetic",
         "bases_per_s": value * Lq,
-        "config": {"workload": "BASELINE config 2 shape: synthetic hg18-like genome %d Mbp (24 seqs, 45%% repeats), index -L 15 -S 1 -H 65525, %d x %d bp reads per GPU at %.1f%% divergence, defaults -BW 5 -G 50 -H 650 -M 25 -X 25, hot path A1..A10 with inputs resident in HBM"
+        # (the driver's record keeps the first 120 characters of a string: read count, read length and the options the metric is quoted on come first)
+        "config": {"workload": "%d x %d bp reads/GPU, -BW 5 -G 50, hg18-like %d Mbp index -L 15; BASELINE config 2 shape" % (n_reads, args.read_len, args.genome_mbp),
+                   "workload_detail": "synthetic hg18-like genome %d Mbp (24 seqs, 45%% repeats), index -L 15 -S 1 -H 65525, %d x %d bp reads per GPU at %.1f%% divergence, defaults -BW 5 -G 50 -H 650 -M 25 -X 25, hot path A1..A10 with inputs resident in HBM"
                    % (args.genome_mbp, n_reads, args.read_len, 100 * args.div),
+                   "genome_mbp": args.genome_mbp, "contexts_per_gpu": max(1, args.contexts), "options": "-BW 5 -G 50 -H 650 -M 25 -X 25 -L 15",
                    "reads_per_gpu": n_reads, "read_len": args.read_len, "parallelism": "reads sharded x%d, index replicated, no collective; %d contexts (batches in flight) per GPU" % (world, max(1, args.contexts))},
         "roofline": {"bound": "hbm", "kernel": kname, "unshared": ({"kernel_ms_per_launch": unshared_rows_ms, "achieved": kbytes / (unshared_rows_ms * 1e-3) / 1e9, "frac": kbytes / (unshared_rows_ms * 1e-3) / 8.0e12,
-                                                                   "note": "the same launch with one context on the GPU (two steps after the timed region): what rocprofv3 reports for the kernel in profiles/*_one_context.csv"} if (rows_ms > 0 and unshared_rows_ms) else None), "kernel_variant": ("k_ext_rows_pk (packed 16-bit, two cells per instruction)" if (rows_ms > 0 and packed) else ("k_ext_rows (32-bit)" if rows_ms > 0 else kname)), "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "whole_path_traffic": ((pmc or {}).get("whole_path") or {}).get("hbm_bytes_per_step"),
+                                                                   "note": "the same launch with one context on the GPU (two steps after the timed region): what rocprofv3 reports for the kernel in profiles/*_one_context.csv"} if (rows_ms > 0 and unshared_rows_ms) else None), "kernel_variant": ("k_ext_rows_pk (packed 16-bit, two cells per instruction)" if (rows_ms > 0 and packed) else ("k_ext_rows (32-bit)" if rows_ms > 0 else kname)), "achieved": (ach_un if ach_un else achieved), "peak": 8000.0, "unit": "GB/s", "frac": (ach_un if ach_un else achieved) / 8000.0, "traffic": traffic,
+                     "frac_basis": ("one context on the GPU (full-chip launch), measured in this run after the timed region: what profiles/*_one_context.csv reproduces" if ach_un else "in the timed region"),
+                     "frac_unshared": (ach_un / 8000.0 if ach_un else None), "kernel_ms_unshared": unshared_rows_ms, "achieved_in_run": achieved, "frac_in_run": achieved / 8000.0, "kernel_ms_in_run": kernel_ms,
+                     "trace_bytes_useful_frac": (tv["records_visitable"] / tv["records_written"] if (tv and tv["records_written"]) else None),
+                     "trace_bytes_written": (tv["records_written"] * tv["record_bytes"] if tv else None), "trace_bytes_visitable": (tv["records_visitable"] * tv["record_bytes"] if tv else None),
+                     "trace_calls": (tv["calls"] if tv else None), "trace_calls_walking": (tv["walkers"] if tv else None), "whole_path_traffic": ((pmc or {}).get("whole_path") or {}).get("hbm_bytes_per_step"),
                      "algorithmic_bytes_per_launch": kbytes, "algorithmic_bytes_per_read": B, "reads_per_launch": n_reads, "kernel_ms_per_launch": kernel_ms,
                      "kernel_ms_hip_events": rows_ms, "kernel_ms_device_clock": rows_dev_ms,
                      "kernel_stream_bytes_per_launch": stream_bytes, "kernel_stream_frac": (stream_bytes / (kernel_ms * 1e-3) / 8.0e12) if (stream_bytes and kernel_ms > 0) else None,
                      "cell_updates_per_s": counters["dp_ext_cells"] / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
                      "valu_frac_nominal": (valu * 2.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
                      "valu_frac_measured_mix": (valu * 4.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
-                     "note": "since round 5 a rows launch that shares the device with other batches takes 9/16 of the workgroups that fit and only one runs at a time (the others' latency-bound kernels run beside it): in the timed region it lasts longer BY DESIGN, `unshared` is the same launch with the device to itself (= the profiles' one-context figure); integer DP: `frac` follows SURVEY 8(d) (algorithmic bytes of the reads of one launch / kernel time / 8 TB/s) and is ~1% by construction; the kernel is bound by vector-ALU issue: valu_frac_nominal prices each wave64 VALU instruction at the nominal 2 SIMD cycles, valu_frac_measured_mix at what its mix measures: 4.4 cycles for the packed 16-bit kernel, 4.0 for the 32-bit one (DESIGN.md section 7); kernel_stream_frac counts the trace cells the kernel writes (an implementation choice, not algorithmic traffic)",
+                     "note": "a rows launch that shares the device with other batches takes 9/16 of the workgroups that fit and only one runs at a time (the others' latency-bound kernels run beside it): in the timed region it lasts longer BY DESIGN (`frac_in_run`, `kernel_ms_in_run`); `frac` / `achieved` are the same launch with the device to itself (`frac_unshared`, = the profiles' one-context figure) whenever that was measured; integer DP: `frac` follows SURVEY 8(d) (algorithmic bytes of the reads of one launch / kernel time / 8 TB/s) and is ~1% by construction; the kernel is bound by vector-ALU issue: valu_frac_nominal prices each wave64 VALU instruction at the nominal 2 SIMD cycles, valu_frac_measured_mix at what its mix measures: 4.4 cycles for the packed 16-bit kernel, 4.0 for the 32-bit one (DESIGN.md section 7); kernel_stream_frac counts the trace cells the kernel writes (an implementation choice, not algorithmic traffic)",
                      "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch", "lds_bank_conflict_frac", "gpu_busy_cycles", "git_head", "kernel_source_sha16", "source") if k2 in pmc} if pmc else None)},
         "path": {"algorithmic_bytes_per_read": B, "hbm_frac_whole_path": value * B / (8.0e12 * world),
                  "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) * steps * world / dt},
@@ -797,11 +810,18 @@ def main():
         wl.insert(1, {"workload": "c2: 1 kbp reads, r=0.05 (realised 1.7%) = the headline", "reads_per_step": n_reads, "steps": steps, "reads_per_s": value, "bases_per_s": value * Lq, "ms_per_step": 1e3 * dt / steps,
                       "k_ext_rows_ms_per_step": rows_dev_ms})
         out["workloads"] = wl
+        for w in wl:      # (flat copies: the driver's record drops nested lists)
+            tag = (w.get("workload") or "")[:2]
+            if tag in ("c1", "c3", "c5") and w.get("reads_per_s"):
+                out["value_" + tag] = w["reads_per_s"]
+                if w.get("verified") is not None: out["verified_" + tag] = bool(w["verified"].get("identical")) if isinstance(w["verified"], dict) else bool(w["verified"])
         try:
             out["end_to_end"] = end_to_end(ya, idx, fa, cache, args.e2e_reads, 3000)
             out["e2e_reads_per_s"] = out["end_to_end"]["e2e_reads_per_s"]; out["steady_reads_per_s"] = out["end_to_end"]["steady_reads_per_s"]
+            out["contexts_up_ms"] = out["end_to_end"].get("contexts_up_ms")
             if args.e2e_reads >= 262144:     # BASELINE config 3's shape through the command line as well: 32 768 reads of 10 kbp (20 batches of ~16 M bases), r = 0.10 (realised 3.4 %)
                 out["end_to_end_c3"] = end_to_end(ya, idx, fa, cache, 32768, 3100, read_len=10000, div=0.034)
+                out["e2e_c3_reads_per_s"] = out["end_to_end_c3"].get("e2e_reads_per_s"); out["steady_c3_reads_per_s"] = out["end_to_end_c3"].get("steady_reads_per_s")
         except Exception as e:
             out["end_to_end"] = {"error": str(e)[:200]}
         try:
@@ -835,6 +855,8 @@ def main():
                 out["verified"] = {"identical": False, "error": str(e)[:300]}
             for k2 in ("sample_path", "reference_sam"):
                 cb.pop(k2, None)
+            v = out["verified"]
+            out["verified_identical"] = bool(v.get("identical")); out["verified_reads"] = int(v.get("reads") or 0) + int((v.get("e2e_sample") or {}).get("reads") or 0)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier(group=cpu_group)

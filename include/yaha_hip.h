@@ -215,6 +215,11 @@ int  ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r);
  * pseudo-random elements (the sort: on arrays of 2 .. 1 792 entries with ties) and compares with the plain host loops.  0, or YGPU_EINTERNAL with the first
  * difference in ygpu_last_error.  (The reference needs neither: it handles one read at a time, Query.c:306-497.) */
 int  ygpu_selftest_primitives(ygpu_ctx *ctx, uint32_t n, uint32_t seed, int key_bits);
+/* The trace stream of the last ygpu_run -- the largest HBM stream of the path, an implementation choice and not algorithmic traffic: the X-drop rows kernel writes
+ * a record per DP row it computes, the traceback (SW.cpp:1138-1195) comes back for those of rows 0 .. maxi of the calls that end above zero (SW.cpp:1091-1111 returns
+ * before any traceback otherwise).  out[0] = records written, out[1] = records a traceback can visit, out[2] = extension calls run, out[3] = calls that walk,
+ * out[4] = bytes a record, out[5] = bytes of the trace arena.  After ygpu_run, before the next upload. */
+int  ygpu_trace_volume(ygpu_ctx *ctx, uint64_t out[6]);
 
 /* Asynchronous form: ygpu_submit hands the batch to the context and returns at once; the context's own worker thread does
  * upload + run + collect; ygpu_wait blocks until the ticket is complete and returns the results (ygpu_poll: 1 = complete, 0 = still running).

@@ -139,6 +139,7 @@ static std::atomic<long> gHostAllocs(0);
 void *ygpu_host_alloc(size_t n) { gHostAllocs++; return getenv("YTEST_NO_PINNED") ? nullptr : malloc(n ? n : 1); }      // (the double's "pinned" memory is plain memory; YTEST_NO_PINNED exercises the pipeline's fall-back to it)
 void ygpu_host_free(void *p) { free(p); }
 int  ygpu_selftest_primitives(ygpu_ctx *, uint32_t, uint32_t, int) { return YGPU_ENODEV; }
+int  ygpu_trace_volume(ygpu_ctx *, uint64_t *) { return YGPU_ENODEV; }
 int  ygpu_inject_results(ygpu_ctx *, const ygpu_result_batch *) { return YGPU_ENODEV; }
 int  ygpu_submit(ygpu_ctx *, const ygpu_read_batch *, ygpu_ticket *) { return YGPU_ENODEV; }
 int  ygpu_poll(ygpu_ctx *, ygpu_ticket) { return YGPU_ENODEV; }

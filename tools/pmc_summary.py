@@ -50,7 +50,7 @@ if emit and kernel:
     js = {"kernel": kernel, "reads_per_gpu": reads, "git_head": os.environ.get("GIT_HEAD"), "kernel_source_sha16": ksrc, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
           "valu_insts_per_launch": valu, "kernel_ns_largest_launch": dur_ns,
           "lds_bank_conflict_cycles": ldsc, "lds_idx_active_cycles": ldsa, "lds_bank_conflict_frac": (ldsc / ldsa) if ldsa else None,
-          "gpu_busy_cycles": gui, "effective_clock_ghz": (gui / dur_ns) if (gui and dur_ns) else None,
+          "gpu_busy_cycles": gui,      # (no clock derived from it: the cycles are one pass's, the duration another's)
           "lds": {c: biggest("lds", c) for c in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM")},
           "valu_cycles_per_inst": (1024 * 2.4 * dur_ns / valu) if valu else None,
           "valu_issue_frac": (valu * 4.0 / (1024 * 2.4 * dur_ns)) if dur_ns else None,

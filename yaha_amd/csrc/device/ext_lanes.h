@@ -468,6 +468,22 @@ __global__ void k_trace_keys(const ExtRes *res, const uint32_t *order, uint32_t 
     vals[t] = p;
 }
 
+// Trace volume of a batch: 16-byte (k_ext_rows_pk) / 12-byte (k_ext_rows) records the rows kernel WROTE -- one per iteration of every problem it ran: rows + 1 --
+// against the records a traceback can VISIT: those of rows 0 .. maxi of the problems that end with a score above zero (SW.cpp:1091-1111 returns before any
+// traceback otherwise; rows behind the maximum belong to the X-drop tail).  out[0] = written, out[1] = visitable, out[2] = problems run, out[3] = walkers.
+__global__ void __launch_bounds__(256) k_trace_volume(const ExtRes *res, uint32_t n, unsigned long long *out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long w = 0, v = 0, np = 0, nw = 0;
+    if (t < n) { const ExtRes r = res[t]; if (r.rows) { w = r.rows + 1ull; np = 1; if (r.score > 0) { v = (unsigned long long)r.maxi + 1ull; nw = 1; } } }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        w += (unsigned long long)__shfl_xor((long long)w, d, 64); v += (unsigned long long)__shfl_xor((long long)v, d, 64);
+        np += (unsigned long long)__shfl_xor((long long)np, d, 64); nw += (unsigned long long)__shfl_xor((long long)nw, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u && np) { atomicAdd(&out[0], w); atomicAdd(&out[1], v); atomicAdd(&out[2], np); atomicAdd(&out[3], nw); }
+}
+
 // order values are global problem indices; a chunk's kernels index from the chunk's first problem
 __global__ void k_rebase_u32(uint32_t *v, uint32_t n, uint32_t sub)
 {

@@ -663,6 +663,26 @@ int ygpu_dp_batch_ex(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n,
     if (!useLanes) { ctx->err = "the lane kernels need -BW 5 and -G >= 10"; return YGPU_EINVAL; }
     return dpBatchLanes(ctx, problems, n, kernels == YGPU_DP_KERNELS_LANES_CAREFUL, results, ops, n_ops);
 }
+/* The trace stream of the last ygpu_run (see include/yaha_hip.h): counted from the extension results, which stay on the device until the next run. */
+int ygpu_trace_volume(ygpu_ctx *ctx, uint64_t out[6])
+{
+    if (!ctx || !ctx->stream || !out || ctx->stageDone < 3) return YGPU_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    for (int k = 0; k < 6; k++) out[k] = 0;
+    const bool useLanes = ctx->laneExt && ctx->P.bandWidth == 5 && ctx->P.maxGap >= YD_LBAND;
+    const uint32_t nProb = 2u * ctx->nClumps;
+    if (!useLanes || !nProb || ctx->extRes.cap < sizeof(ExtRes) * (uint64_t)nProb) return 0;
+    ENSURE(ctx->traceCnt, 64);
+    unsigned long long *d = (unsigned long long *)((char *)ctx->traceCnt.p + 32);       // (behind the arena's three counters)
+    HIPCHK(hipMemsetAsync(d, 0, 32, ctx->stream));
+    KL(k_trace_volume, dim3(gridFor(nProb, 256)), dim3(256), 0, ctx->stream, ctx->extRes.as<ExtRes>(), nProb, d);
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, d, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
+    out[4] = ctx->rowsPacked ? 16 : 12;                                           // bytes a record
+    out[5] = ctx->extTrace.cap;                                                   // the arena the records went to
+    return 0;
+}
 int ygpu_dp_batch(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t n, const ygpu_dp_result **results, const uint32_t **ops, uint64_t *n_ops)
 { return ygpu_dp_batch_ex(ctx, problems, n, YGPU_DP_KERNELS_AUTO, results, ops, n_ops); }
 }  // extern "C"
