@@ -370,7 +370,12 @@ def make_room(cache, need_gb=40.0):
         st = os.statvfs(d)
         if st.f_bavail * st.f_frsize / 1e9 >= need_gb or glob.glob(os.path.join(cache, "g3100m_*.X15_*")):
             return
-        for old in glob.glob(os.path.join(tempfile.gettempdir(), "pytest-of-%s" % getpass.getuser(), "pytest-*")):
+        base = os.path.join(tempfile.gettempdir(), "pytest-of-%s" % getpass.getuser())
+        # (not the session pytest-current points at, nor anything touched in the last half hour: a test session of this user may be running beside the bench)
+        cur = os.path.realpath(os.path.join(base, "pytest-current")) if os.path.islink(os.path.join(base, "pytest-current")) else None
+        for old in glob.glob(os.path.join(base, "pytest-*")):
+            if os.path.islink(old) or os.path.realpath(old) == cur or time.time() - os.path.getmtime(old) < 1800:
+                continue
             shutil.rmtree(old, ignore_errors=True)
     except Exception as e:                               # (never in the way of the measurement)
         sys.stderr.write("[bench] make_room: %s\n" % e)

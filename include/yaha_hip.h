@@ -179,7 +179,9 @@ void  ygpu_host_free(void *p);
  *   context's thread:  ygpu_upload, ygpu_run, ygpu_postfilter_snapshot  -> hand the batch to the filter thread -> ygpu_upload, ygpu_run of the next batch ...
  *   filter thread:     ygpu_postfilter, ygpu_filtered_size, ygpu_collect_filtered
  * One snapshot at a time: the next ygpu_postfilter_snapshot may be called once the filtered results of the previous one have been collected.  ygpu_postfilter
- * without a snapshot takes one itself (the sequential use: ygpu_run, ygpu_postfilter, ygpu_collect_filtered on one thread). */
+ * without a snapshot takes one itself (the sequential use: ygpu_run, ygpu_postfilter, ygpu_collect_filtered on one thread).  The filtered results are handed out
+ * ONCE: after ygpu_collect_filtered, ygpu_filtered_size answers YGPU_EINVAL until the next ygpu_postfilter (it used to answer with the previous batch).  A snapshot
+ * that will not be filtered after all (an error between the two calls) is dropped with ygpu_postfilter_drop -- otherwise the next ygpu_postfilter would filter IT. */
 typedef struct ygpu_postfilter_params {
     int32_t  minNonOverlap, BPCost, maxBPLog, FBS;     /* AlignArgs: OQCMinNonOverlap, BPCost, maxBPLog, FBS (0/1) */
     float    FBS_PSLength, FBS_PSScore;
@@ -202,6 +204,7 @@ typedef struct ygpu_filtered_batch {
 int  ygpu_set_postfilter(ygpu_ctx *ctx, const ygpu_postfilter_params *p);     /* once per context */
 int  ygpu_postfilter_snapshot(ygpu_ctx *ctx);                                  /* after ygpu_run, on the context's thread */
 int  ygpu_postfilter(ygpu_ctx *ctx);                                           /* after ygpu_run or ygpu_postfilter_snapshot */
+int  ygpu_postfilter_drop(ygpu_ctx *ctx);                                      /* forget an unfiltered snapshot and uncollected results */
 int  ygpu_filtered_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops);
 int  ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump *clumps, uint32_t *ops, ygpu_filtered_batch *out);
 

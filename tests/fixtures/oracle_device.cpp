@@ -127,6 +127,7 @@ int ygpu_postfilter(ygpu_ctx *c)
     }
     c->pfDone = true; return 0;
 }
+int ygpu_postfilter_drop(ygpu_ctx *c) { if (!c) return YGPU_EINVAL; c->pfDone = false; return 0; }
 int ygpu_filtered_size(ygpu_ctx *c, uint64_t *nc, uint64_t *no) { if (!c->pfDone) return YGPU_EINVAL; *nc = c->fcl.size(); *no = c->fops.size(); return 0; }
 int ygpu_collect_filtered(ygpu_ctx *c, uint32_t *cs, ygpu_out_clump *cl, uint32_t *ops, ygpu_filtered_batch *r)
 {

@@ -614,10 +614,11 @@ def test_real_human_sequence_command_line_equals_the_reference(tmp_path):
     os.remove(idx)
 
 
-@pytest.mark.parametrize("n,bits", [(1, 3), (7, 7), (8, 8), (8191, 8), (8192, 12), (8193, 10), (100003, 16), (5000000, 7), (33000001, 10)])
+@pytest.mark.parametrize("n,bits", [(1, 3), (7, 7), (8, 8), (8191, 8), (8192, 12), (8193, 10), (12287, 9), (12288, 9), (12289, 9), (24575, 8), (24576, 12), (24577, 10), (100003, 16), (5000000, 7),
+                                    (33000001, 10)])
 def test_own_sums_and_orderings(work, index11, n, bits):
     """device/scan.h -- the exclusive sums (single pass, decoupled look-back, u32 and u64, in place) and the orderings by a small key that lay out the batch's
-    variable-size outputs -- against plain host loops: tile edges (8 192 elements a tile), one element, tens of millions (4 029 tiles), sums beyond 2^32, keys with an
+    variable-size outputs -- against plain host loops: tile edges (a tile is 512 threads x 48 u32 = 24 576 elements, 12 288 of u64; an ordering's 8 192), one element, tens of millions (1 343 tiles), sums beyond 2^32, keys with an
     offset and a shift, crowded buckets; every call twice over the same work words (they clean themselves up)."""
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
         with ya.Context(s.index, s.params) as c:

@@ -26,6 +26,7 @@ int  ygpu_postfilter_snapshot(ygpu_ctx *) { return YGPU_ENODEV; }
 int  ygpu_selftest_primitives(ygpu_ctx *, uint32_t, uint32_t, int) { return YGPU_ENODEV; }
 int  ygpu_trace_volume(ygpu_ctx *, uint64_t *) { return YGPU_ENODEV; }
 int  ygpu_inject_results(ygpu_ctx *, const ygpu_result_batch *) { return YGPU_ENODEV; }
+int  ygpu_postfilter_drop(ygpu_ctx *) { return YGPU_ENODEV; }
 int  ygpu_filtered_size(ygpu_ctx *, uint64_t *, uint64_t *) { return YGPU_ENODEV; }
 int  ygpu_collect_filtered(ygpu_ctx *, uint32_t *, ygpu_out_clump *, uint32_t *, ygpu_filtered_batch *) { return YGPU_ENODEV; }
 void *ygpu_host_alloc(size_t) { return nullptr; }

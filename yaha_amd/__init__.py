@@ -89,7 +89,7 @@ DP_FULL, DP_BANDED, DP_EXT_FWD, DP_EXT_REV = 0, 1, 2, 3
 DP_KERNELS_AUTO, DP_KERNELS_WAVE, DP_KERNELS_LANES, DP_KERNELS_LANES_CAREFUL = 0, 1, 2, 3
 
 EXPORTS = (
-    "ygpu_device_count", "ygpu_init", "ygpu_init_multi", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_memory", "ygpu_park", "ygpu_get_arena_profile", "ygpu_presize", "ygpu_upload", "ygpu_upload_nowait", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter_snapshot", "ygpu_postfilter", "ygpu_inject_results", "ygpu_selftest_primitives", "ygpu_trace_volume", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
+    "ygpu_device_count", "ygpu_init", "ygpu_init_multi", "ygpu_clone", "ygpu_destroy", "ygpu_last_error", "ygpu_memory", "ygpu_park", "ygpu_get_arena_profile", "ygpu_presize", "ygpu_upload", "ygpu_upload_nowait", "ygpu_run", "ygpu_collect", "ygpu_result_size", "ygpu_collect_into", "ygpu_host_alloc", "ygpu_host_free", "ygpu_set_postfilter", "ygpu_postfilter_snapshot", "ygpu_postfilter", "ygpu_postfilter_drop", "ygpu_inject_results", "ygpu_selftest_primitives", "ygpu_trace_volume", "ygpu_filtered_size", "ygpu_collect_filtered", "ygpu_last_timing",
     "ygpu_submit", "ygpu_poll", "ygpu_wait", "ygpu_seed_join", "ygpu_chain", "ygpu_dp_batch", "ygpu_dp_batch_ex",
     "yaha_session_open", "yaha_session_close", "yaha_session_error", "yaha_session_params",
     "yaha_session_index_view", "yaha_session_header", "yaha_session_next_batch", "yaha_session_emit", "yaha_session_postfilter_params", "yaha_session_emit_filtered",

@@ -341,6 +341,11 @@ void ygpu_destroy(ygpu_ctx *ctx)
     if (ctx->counted) gCtxPerDevice[ctx->device & 63]--;
     if (ctx->stream) {
         hipSetDevice(ctx->device);
+        {   // the device's ring of rows-launch events was recorded on streams of its contexts: with the last of them it goes too (a later context starts a fresh one)
+            const int dv = ctx->device & 63; std::lock_guard<std::mutex> lk(gRowsMu[dv]);
+            (void)hipStreamSynchronize(ctx->stream);
+            if (gCtxPerDevice[dv].load() <= 0) for (int k = 0; k < 4; k++) if (gRowsEvValid[dv][k]) { (void)hipEventDestroy(gRowsEv[dv][k]); gRowsEvValid[dv][k] = false; }
+        }
         if (ctx->sharedIndex) { ctx->dBases.p = nullptr; ctx->dBases.cap = 0; ctx->dSO.p = nullptr; ctx->dSO.cap = 0; ctx->dROA.p = nullptr; ctx->dROA.cap = 0;
             ctx->dLow.p = nullptr; ctx->dLow.cap = 0; }
         const std::vector<DevBuf *> all = allBuffers(ctx);
@@ -432,7 +437,8 @@ int ygpu_run(ygpu_ctx *ctx)
     if (kStats) { size_t fb = 0, tb = 0; hipMemGetInfo(&fb, &tb);
         fprintf(stderr, "[ygpu] ctx %p run: %u reads, rc %d, %.1f ms; align attempts %d, ranges %d, trace arena %.2f GB (ratio %.3f), free %.1f GB\n", (void *)ctx, ctx->nReads, rc,
         nowMs() - t0, ctx->statAttempts, ctx->statRanges, ctx->extTrace.cap / 1e9, ctx->traceRatio, fb / 1e9); }
-    if (rc) return rc;
+    // (a failed run may leave the batch's host-to-device copies queued -- ygpu_upload_nowait -- and the caller recycles the batch's memory next: drained here)
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); return rc; }
     ctx->runsDone++;
     ctx->totalMs = 0;
     for (int t = 0; t < T_N; t++) {

@@ -171,7 +171,12 @@ static int postfilterBody(ygpu_ctx *full)
     uint32_t tot[2] = {0, 0}, scanFail = 0;
     { const FetchPiece pc[3] = {{full->oqOutStart.as<uint32_t>() + n, &tot[0], 1}, {full->oqOpsStart.as<uint32_t>() + n, &tot[1], 1}, {ctx->counters.as<uint32_t>() + CNT_SCANFAIL,
         &scanFail, 1}}; rc = fetchMany(ctx, pc, 3); if (rc) return rc; }
-    if (scanFail) { ctx->err = "post-filter: a look-back of an exclusive sum gave up"; return YGPU_EINTERNAL; }
+    if (scanFail) {      // (not sticky: the flag and the look-back words -- stale tickets and statuses -- are made clean again for the next batch, as runTo does on its side)
+        HIPCHK(hipMemsetAsync(ctx->counters.as<uint32_t>() + CNT_SCANFAIL, 0, 4, ctx->stream));
+        if (ctx->scanState.p) HIPCHK(hipMemsetAsync(ctx->scanState.p, 0, ctx->scanState.cap, ctx->stream));
+        HIPCHK(streamSync(ctx));
+        ctx->err = "post-filter: a look-back of an exclusive sum gave up"; return YGPU_EINTERNAL;
+    }
     full->nFOut = tot[0]; full->nFOps = tot[1];
     ENSURE(full->oqFClumps, sizeof(ygpu_out_clump) * ((uint64_t)tot[0] + 1)); ENSURE(full->oqFOps, 4ull * ((uint64_t)tot[1] + 1));
     KL(k_oqc_gather, dim3(gridFor((uint64_t)n * 64, 256)), dim3(256), 0, ctx->stream, A, full->oqOutStart.as<uint32_t>(), full->oqOpsStart.as<uint32_t>(),
@@ -205,6 +210,12 @@ int ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r)
     ctx->nOut = (uint32_t)r->n_clumps; ctx->nOutOps = (uint32_t)r->n_ops; ctx->stageDone = 3;
     return 0;
 }
+int ygpu_postfilter_drop(ygpu_ctx *ctx)
+{
+    if (!ctx || !ctx->stream) return YGPU_EINVAL;
+    ctx->pfSnap.store(false); ctx->oqDone = false; ctx->nFOut = ctx->nFOps = 0;
+    return 0;
+}
 int ygpu_filtered_size(ygpu_ctx *ctx, uint64_t *n_clumps, uint64_t *n_ops)
 {
     if (!ctx || !ctx->oqDone) return YGPU_EINVAL;
@@ -223,6 +234,7 @@ int ygpu_collect_filtered(ygpu_ctx *full, uint32_t *clump_start, ygpu_out_clump 
     if (full->nFOps) HIPCHK(hipMemcpyAsync(ops, full->oqFOps.p, 4ull * full->nFOps, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(streamSync(ctx));
     tlsPfFailed = nullptr;
+    full->oqDone = false;                                                    // (collected: a later ygpu_filtered_size without a new ygpu_postfilter is an error, not the previous batch once more)
     out->n_reads = n; out->clump_start = clump_start; out->clumps = clumps; out->ops = ops; out->n_clumps = full->nFOut; out->n_ops = full->nFOps; out->counters = full->pfCounters;
     return 0;
 }
