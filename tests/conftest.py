@@ -18,6 +18,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+    # The whole tier runs with the state-word check on (device/prims.hip: every ygpu_run / ygpu_postfilter ends with a pass over the look-back and bucket words
+    # on the device and fails unless all are zero again) -- the library reads the switch once, and the command lines the tests start inherit it.
+    os.environ.setdefault("YGPU_CHECK_STATE", "1")
 
 
 def _build():

@@ -11,6 +11,7 @@ through the whole device path; then, for every clump that comes back:
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -114,3 +115,31 @@ def test_subsample_is_bit_exact_against_the_oracle(big):
             got, exp = r.counters.as_dict(), ro.counters.as_dict()
             for key in ("kmer_lookups", "hits", "fragments", "regions", "clumps_formed", "clumps_scored", "dp_ext_calls", "dp_gap_calls", "splits", "ops_out", "perfect_ext_bases"):
                 assert got[key] == exp[key], (key, got[key], exp[key])
+
+
+@pytest.mark.gpu
+def test_state_words_are_checked_after_every_run(work, index11):
+    """YGPU_CHECK_STATE=1 (on for the whole tier, tests/conftest.py): "the look-back and bucket words clean themselves up" is verified on the device at the end of
+    every ygpu_run and ygpu_postfilter.  Here the check itself is checked, in a process of its own: a run is clean, a run that leaves one word dirty
+    (YGPU_CHECK_STATE_INJECT) fails with YGPU_EINTERNAL and names the buffer -- and the run after it is clean again (the words are re-zeroed on failure)."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import yaha_amd as ya
+with ya.Session(["-x", %r, "-q", %r]) as s:
+    b = s.next_batch(48)
+    with ya.Context(s.index, s.params) as c:
+        c.upload(b); c.run(); first = ya.result_records(c.collect())
+        c.set_postfilter(s); c.postfilter()
+        os.environ["YGPU_CHECK_STATE_INJECT"] = "1"
+        try:
+            c.run(); print("NOT DETECTED")
+        except Exception as e:
+            print("DETECTED:", str(e)[:300])
+        del os.environ["YGPU_CHECK_STATE_INJECT"]
+        c.upload(b); c.run(); print("SAME" if ya.result_records(c.collect()) == first else "DIFFERENT")
+""" % (ROOT, index11, os.path.join(work, "r1k.fa"))
+    env = dict(os.environ, YGPU_CHECK_STATE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600).stdout.decode()
+    assert "DETECTED:" in out and "YGPU_CHECK_STATE" in out and "look-back" in out, out
+    assert "NOT DETECTED" not in out and out.strip().endswith("SAME"), out

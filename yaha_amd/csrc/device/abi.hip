@@ -439,6 +439,12 @@ int ygpu_run(ygpu_ctx *ctx)
         nowMs() - t0, ctx->statAttempts, ctx->statRanges, ctx->extTrace.cap / 1e9, ctx->traceRatio, fb / 1e9); }
     // (a failed run may leave the batch's host-to-device copies queued -- ygpu_upload_nowait -- and the caller recycles the batch's memory next: drained here)
     if (rc) { (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); return rc; }
+    if (ydCheckStateOn()) {                                                  // (debug switch, on in the whole GPU tier: prims.hip)
+        if (getenv("YGPU_CHECK_STATE_INJECT") && ctx->scanState.p) (void)hipMemsetAsync((char *)ctx->scanState.p + 8, 0x01, 4, ctx->stream);      // (tests: a word left dirty)
+        const DevBuf *const bufs[2] = {&ctx->scanState, &ctx->bucketWork}; static const char *const names[2] = {"the sums' look-back state", "the orderings' bucket counters"};
+        rc = ydCheckZero(ctx->stream, ctx->err, (unsigned int *)ctx->errFlag.p + 2, bufs, names, 2, "after ygpu_run");
+        if (rc) { if (ctx->scanState.p) (void)hipMemsetAsync(ctx->scanState.p, 0, ctx->scanState.cap, ctx->stream); return rc; }
+    }
     ctx->runsDone++;
     ctx->totalMs = 0;
     for (int t = 0; t < T_N; t++) {

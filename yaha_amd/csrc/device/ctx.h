@@ -281,6 +281,8 @@ template <class C> static int cubScan64(C *ctx, const unsigned long long *in, un
 int bucketOrder(ygpu_ctx *ctx, const uint32_t *keys, const uint32_t *vals, uint32_t valBase, uint32_t n, uint32_t sub, int shift, uint32_t nb,
                 uint32_t *outVals, hipStream_t st);
 size_t ydBucketWorkBytes();
+bool ydCheckStateOn();                                        // YGPU_CHECK_STATE=1
+int ydCheckZero(hipStream_t st, std::string &err, unsigned int *scratch, const DevBuf *const *bufs, const char *const *names, int n, const char *when);
 enum { kBucketMax = 4096 };                                   // buckets of an ordering (scan.h YD_BKT_MAX: 12 key bits)
 
 // ---- the stages (runTo in abi.hip drives them) -------------------------------------------------------------------------------------------------------------

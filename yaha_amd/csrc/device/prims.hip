@@ -42,3 +42,36 @@ int bucketOrder(ygpu_ctx *ctx, const uint32_t *keys, const uint32_t *vals, uint3
     if (e_ != hipSuccess) { ctx->err = std::string("launch of k_bucket_count / k_bucket_scatter failed: ") + hipGetErrorString(e_); return YGPU_ENODEV; }
     return 0;
 }
+
+// ---- YGPU_CHECK_STATE=1: "the work words clean themselves up" as a checked invariant ----------------------------------------------------------------------------
+// The look-back words of the sums (scanState: tile words, ticket, done counter) and the work words of the orderings (bucketWork) are zeroed ONCE, when they are
+// made, and every launch is trusted to leave them zero.  A launch that does not -- or a buffer that was made without being zeroed (round 5: a presized context's)
+// -- gives wrong sums in the NEXT call and nothing notices: wrong SAM, exit code 0.  With the switch on, every ygpu_run / ygpu_postfilter ends with a pass over
+// those words on the device and fails when one is not zero.  (The reference has no such state: one read at a time, Query.c:306-497.)
+__global__ void __launch_bounds__(256) k_check_zero(const uint32_t *p, uint32_t nWords, unsigned int *bad /* [0] count, [1] first index + 1 */)
+{
+    uint32_t cnt = 0, first = 0xFFFFFFFFu;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nWords; i += gridDim.x * blockDim.x) if (p[i] != 0u) { cnt++; first = min(first, i); }
+    if (cnt) { atomicAdd(&bad[0], cnt); atomicMin(&bad[1], first); }
+}
+bool ydCheckStateOn() { static const bool on = getenv("YGPU_CHECK_STATE") != nullptr && atoi(getenv("YGPU_CHECK_STATE")) != 0; return on; }
+// 0: every word of every buffer is zero; YGPU_EINTERNAL with `err` naming the first buffer and word otherwise.  `scratch`: 8 bytes of device memory.
+int ydCheckZero(hipStream_t st, std::string &err, unsigned int *scratch, const DevBuf *const *bufs, const char *const *names, int n, const char *when)
+{
+    for (int k = 0; k < n; k++) {
+        if (!bufs[k]->p || bufs[k]->cap < 4) continue;
+        const uint32_t nWords = (uint32_t)std::min<size_t>(bufs[k]->cap / 4, 0xFFFFFFF0u);
+        const unsigned int init[2] = {0u, 0xFFFFFFFFu}; unsigned int got[2] = {0u, 0u};
+        if (hipMemcpyAsync(scratch, init, 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "state check: copy failed"; return YGPU_ENODEV; }
+        hipLaunchKernelGGL(k_check_zero, dim3((unsigned)std::min<uint32_t>(1024u, (nWords + 255u) / 256u)), dim3(256), 0, st, (const uint32_t *)bufs[k]->p, nWords, scratch);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(got, scratch, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            err = "state check: launch failed"; (void)hipGetLastError(); return YGPU_ENODEV;
+        }
+        if (got[0]) {
+            char m[256]; snprintf(m, sizeof m, "YGPU_CHECK_STATE: %u of the %u work words of %s are not zero %s (the first: word %u): the next call on them would be wrong",
+                                  got[0], nWords, names[k], when, got[1]);
+            err = m; return YGPU_EINTERNAL;
+        }
+    }
+    return 0;
+}

@@ -103,7 +103,13 @@ int ygpu_postfilter(ygpu_ctx *full)
 {
     if (!full || !full->stream) return YGPU_EINVAL;
     if (!full->pfSnap.load()) { const int rc = ygpu_postfilter_snapshot(full); if (rc) { tlsPfFailed = nullptr; return rc; } }      // (the snapshot's message is the context's own)
-    const int rc = postfilterBody(full);
+    int rc = postfilterBody(full);
+    if (rc == 0 && ydCheckStateOn()) {                                       // (debug switch: the post-filter side's own look-back words)
+        const DevBuf *const bufs[1] = {&full->pf.scanState}; static const char *const names[1] = {"the post-filter side's look-back state"};
+        if (full->oqClsCnt.ensure(64)) { full->pf.err = "hipMalloc failed"; rc = YGPU_ENOMEM; }
+        else rc = ydCheckZero(full->pf.stream, full->pf.err, (unsigned int *)full->oqClsCnt.p + 8, bufs, names, 1, "after ygpu_postfilter");
+        if (rc) full->oqDone = false;
+    }
     full->pfSnap.store(false);
     tlsPfFailed = rc ? full : nullptr;
     return rc;
