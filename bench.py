@@ -700,7 +700,9 @@ def main():
             c.close()
     block_dt = [max_over_ranks(x, dist, device="cpu" if os.environ.get("YAHA_BENCH_BACKEND") == "gloo" else "cuda") for x in block_dt]     # a block lasts as long as its slowest rank
     dt = sorted(block_dt)[len(block_dt) // 2]
+    ranks_seen = 1
     if dist is not None:
+        one = torch.ones(1); dist.all_reduce(one, group=cpu_group); ranks_seen = int(one.item())      # every rank that reached the end of its timed region
         dist.barrier(group=cpu_group)                    # every rank has closed its contexts: the devices are free for the command-line leg below
     if rank != 0:
         if dist is not None:
@@ -754,7 +756,7 @@ def main():
     simd_cycles = 1024 * 2.4e9 * (unshared_rows_ms if (rows_ms > 0 and unshared_rows_ms) else kernel_ms) * 1e-3   # 256 CUs x 4 SIMDs at 2.4 GHz over the launch (the counters are a one-context profile's: priced against the unshared duration when it was measured)
     out = {
         "metric": "aligned reads/s (whole node), 1 000 bp reads, OQC mode hot path", "value": value, "unit": "reads/s",
-        "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "ms_per_step_min": 1e3 * min(block_dt) / steps, "ms_per_step_max": 1e3 * max(block_dt) / steps, "blocks": len(block_dt), "ms_per_step_blocks": [round(1e3 * x / steps, 3) for x in block_dt],
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "ms_per_step_min": 1e3 * min(block_dt) / steps, "ms_per_step_max": 1e3 * max(block_dt) / steps, "blocks": len(block_dt), "ms_per_step_blocks": [round(1e3 * x / steps, 3) for x in block_dt],
         "timing_note": "%d back-to-back blocks of exactly %d steps, each bracketed by barrier + synchronize, max over ranks per block; value and ms_per_step are the MEDIAN block's" % (len(block_dt), steps),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": ("int16" if packed else "int32"), "dtype_note": "integer dynamic programming, bit-exact: the X-drop extension rows (93 % of the DP cells) in saturating packed int16 when the scores fit (else int32), everything else int32", "data": "synthetic",

@@ -125,6 +125,25 @@ def test_three_images_chain_and_the_host_fall_back(work, index11, monkeypatch):
                     c.close()
 
 
+@pytest.mark.parametrize("fail_at", ["0", "1", "2", "1:2"])
+def test_a_broken_peer_copy_falls_back_to_the_host(work, index11, monkeypatch, capfd, fail_at):
+    """YGPU_PEER_FAIL_AT=k[:j]: piece k of the chain of device-to-device copies fails (on every chained device, or on the j-th device of the call only).  The device
+    it fails on keeps the pieces it has, takes the others from the host, goes on serving the device behind it -- and every image is the reference's index: the
+    batch's results equal the oracle's on all three.  (What a second GPU that refuses a hipMemcpyPeerAsync would look like; no second GPU is needed to test it.)"""
+    monkeypatch.setenv("YGPU_PEER_FAIL_AT", fail_at)
+    with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
+        b = s.next_batch(120)
+        ctxs = ya.Context.on_devices(s.index, s.params, [0, 0, 0])
+        try:
+            err = capfd.readouterr().err
+            assert "broke at piece %s" % fail_at.split(":")[0] in err and "the rest comes from the host" in err, err
+            assert err.count("broke at piece") == (1 if ":" in fail_at else 2), err
+            _golden_batch_equals_oracle(s, b, ctxs)
+        finally:
+            for c in reversed(ctxs):
+                c.close()
+
+
 def test_init_multi_reports_the_device_that_does_not_exist(work, index11):
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
         with pytest.raises(RuntimeError, match="device 63: -2 device index out of range"):
@@ -229,3 +248,21 @@ def test_bench_two_gpus_over_rccl(tmp_path):
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0
     e = j["end_to_end"]
     assert "error" not in e and e["gpus"] == 2 and len(e["reads_per_device"]) == 2 and all(n > 0 for n in e["reads_per_device"])
+
+
+def test_bench_eight_ranks_on_one_gpu_over_gloo(tmp_path):
+    """`python bench.py --gpus 8` as the driver starts it on an 8-GPU node -- eight ranks started by the bench itself, rendezvous on 127.0.0.1, barrier and
+    max-over-ranks, rank 0's single JSON line -- on the ONE GPU of this box: YAHA_BENCH_BACKEND=gloo puts torch.distributed on the CPU and the ranks on device
+    rank % device_count.  Nothing is stubbed: every rank builds its own context on the 100 Mbp index and runs the real hot path on its own shard of reads.  Not a
+    measurement (eight processes share one device) -- what it proves is that the N = 8 launch path cannot fail for a trivial reason on first contact with real
+    hardware: ranks_seen == 8, one line, reads of all ranks counted."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(YAHA_BENCH_CACHE=os.environ.get("YAHA_BENCH_CACHE", str(tmp_path / "cache")), HSA_ENABLE_IPC_MODE_LEGACY="0", YAHA_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--genome-mbp", "100", "--contexts", "1", "--reads-per-gpu", "2048",
+                        "--blocks", "1", "--no-extras", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["reads_per_gpu"] == 2048 and abs(j["value"] * j["ms_per_step"] * 1e-3 - 8 * 2048) < 1.0      # whole-job rate: the reads of all eight ranks over the slowest rank's time

@@ -109,6 +109,7 @@ static void uploadFromHost(int device, const ImagePlan &plan, ImageState &me, in
         }
         for (int k = 0; !me.failed; k ^= 1) {
             const size_t i = next.fetch_add(1); if (i >= plan.pieces.size()) break;
+            if (me.done[i].load(std::memory_order_acquire)) continue;          // (already here: the pieces a broken peer chain delivered before it broke)
             const ImagePiece &q = plan.pieces[i]; char *d = me.dst[q.part] + q.off; const char *sp = plan.src[q.part] + q.off;
             if (!staged) { if (hipMemcpyAsync(d, sp, q.bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) me.failed = 1;
                 else me.done[i].store(1, std::memory_order_release); continue; }
@@ -127,28 +128,35 @@ static void uploadFromHost(int device, const ImagePlan &plan, ImageState &me, in
     if (me.failed) (void)hipGetLastError();
 }
 // pieces from the neighbour's image, each as soon as the neighbour has it
-static void copyFromPeer(int device, int srcDevice, const ImagePlan &plan, ImageState &me, ImageState &from)
+// Returns the piece at which the chain broke (a copy the runtime refused, a source device that failed, YGPU_PEER_FAIL_AT), or -1: the pieces published so far stay,
+// the caller takes the rest from the host.  Only a failure of THIS device's own set-up is final (me.failed).
+static long copyFromPeer(int device, int srcDevice, const ImagePlan &plan, ImageState &me, ImageState &from, long failAt)
 {
-    if (hipSetDevice(device) != hipSuccess) { me.failed = 1; return; }
-    hipStream_t st; if (hipStreamCreate(&st) != hipSuccess) { me.failed = 1; return; }
+    if (hipSetDevice(device) != hipSuccess) { me.failed = 1; return -1; }
+    hipStream_t st; if (hipStreamCreate(&st) != hipSuccess) { me.failed = 1; return -1; }
+    long broke = -1;
     // (a window of copies in flight: the events of the last W pieces; a piece is published once its event has completed)
     const int W = 4; hipEvent_t ev[W]; size_t pend[W]; bool used[W]; for (int k = 0; k < W; k++) { used[k] = false;
         if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) me.failed = 1; }
     for (size_t i = 0; i < plan.pieces.size() && !me.failed; i++) {
         const int k = (int)(i % W);
-        if (used[k]) { if (hipEventSynchronize(ev[k]) != hipSuccess) { me.failed = 1; break; } me.done[pend[k]].store(1, std::memory_order_release); used[k] = false; }
-        while (!from.done[i].load(std::memory_order_acquire)) { if (from.failed) { me.failed = 1; break; } std::this_thread::yield(); }
-        if (me.failed) break;
+        if (used[k]) { if (hipEventSynchronize(ev[k]) != hipSuccess) { used[k] = false; broke = (long)pend[k]; break; } me.done[pend[k]].store(1, std::memory_order_release); used[k] = false; }
+        while (!from.done[i].load(std::memory_order_acquire)) { if (from.failed) { broke = (long)i; break; } std::this_thread::yield(); }
+        if (broke >= 0) break;
         const ImagePiece &q = plan.pieces[i];
-        const hipError_t e = device == srcDevice ? hipMemcpyAsync(me.dst[q.part] + q.off, from.dst[q.part] + q.off, q.bytes, hipMemcpyDeviceToDevice, st)
+        const hipError_t e = (long)i == failAt ? hipErrorUnknown      // (YGPU_PEER_FAIL_AT: the fault a test injects)
+                           : device == srcDevice ? hipMemcpyAsync(me.dst[q.part] + q.off, from.dst[q.part] + q.off, q.bytes, hipMemcpyDeviceToDevice, st)
                                                  : hipMemcpyPeerAsync(me.dst[q.part] + q.off, device, from.dst[q.part] + q.off, srcDevice, q.bytes, st);
-        if (e != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { me.failed = 1; break; }
+        if (e != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { broke = (long)i; break; }
         used[k] = true; pend[k] = i;
     }
-    if (hipStreamSynchronize(st) != hipSuccess) me.failed = 1;
-    for (int k = 0; k < W; k++) { if (used[k] && !me.failed) me.done[pend[k]].store(1, std::memory_order_release); (void)hipEventDestroy(ev[k]); }
+    // what is in flight either lands (and is published) or is taken again from the host
+    const bool landed = hipStreamSynchronize(st) == hipSuccess;
+    for (int k = 0; k < W; k++) { if (used[k] && landed && !me.failed) me.done[pend[k]].store(1, std::memory_order_release); (void)hipEventDestroy(ev[k]); }
+    if (!landed && broke < 0) broke = 0;
     (void)hipStreamDestroy(st);
-    if (me.failed) (void)hipGetLastError();
+    (void)hipGetLastError();
+    return me.failed ? -1 : broke;
 }
 static int checkParams(ygpu_ctx *ctx, const ygpu_index_view *ix, const ygpu_params *p)
 {
@@ -208,8 +216,17 @@ static int initDevice(ygpu_ctx *ctx, int device, int srcIndex /* -1: the host */
         if (v >= 1 && v <= 32) nt = v; } }
     std::thread copier;
     if (srcIndex < 0) copier = std::thread([&, nt, staged]() { uploadFromHost(device, plan, me, nt, staged); });
-    else copier = std::thread([&]() { while (imageReady[srcIndex].load() == 0) std::this_thread::yield(); if (imageReady[srcIndex].load() < 0) { me.failed = 1; return; }
-        copyFromPeer(device, srcDevice, plan, me, states[srcIndex]); });
+    else copier = std::thread([&, nt, staged]() {
+        // (YGPU_PEER_FAIL_AT=k or k:j -- piece k of the chain fails, on every chained device or on the j-th device of the call only: the fall-back's test)
+        long failAt = -1; if (const char *e = getenv("YGPU_PEER_FAIL_AT")) { const char *c = strchr(e, ':'); if (!c || atoi(c + 1) == self) failAt = atol(e); }
+        while (imageReady[srcIndex].load() == 0) std::this_thread::yield();
+        long broke = imageReady[srcIndex].load() < 0 ? 0 : copyFromPeer(device, srcDevice, plan, me, states[srcIndex], failAt);
+        if (broke >= 0 && !me.failed) {      // the chain broke: this device takes what it still lacks from the host (and goes on serving the device behind it)
+            fprintf(stderr, "[ygpu] device %d: the copy of the index image from device %d broke at piece %ld of %zu; the rest comes from the host\n",
+                    device, srcDevice, broke, plan.pieces.size());
+            uploadFromHost(device, plan, me, nt, staged);
+        }
+    });
     int rc0 = initCommon(ctx, device);
     if (rc0 == 0) { if (ctx->counters.ensure(4 * CNT_N) || ctx->ctr.ensure(sizeof(DevCounters)) || ctx->errFlag.ensure(64) || ctx->dLow.ensure(ydLowTableBytes())) {
         ctx->err = "hipMalloc failed"; rc0 = YGPU_ENOMEM; } }
