@@ -69,3 +69,23 @@ def strip_pg(text):
 
 def oflag_args(oflag):
     return [oflag, "stdout"]
+
+
+def nib2_v1_copy(work, dst_dir):
+    """The golden genome's `.nib2` rewritten as a VERSION 1 file (Compress.c:89-128: 12-byte sequence entries {start, length, nameOffset << 16 | nameLength} instead of
+    version 2's 16-byte ones; the reference still loads both, nothing writes version 1 any more) with its index beside it.  Returns the index path."""
+    import struct
+    src = open(os.path.join(work, "genome_small.nib2"), "rb").read()
+    magic, version, base_off, n = struct.unpack_from("<4I", src, 0)
+    assert magic == 0x01020304 and version == 2
+    ent = [struct.unpack_from("<4I", src, 16 + 16 * i) for i in range(n)]
+    names_at = 16 + 16 * n + 4
+    names = src[names_at:base_off]                                            # the name block, zero padded to 4 bytes
+    assert all(e[2] < 65536 and e[3] < 65536 for e in ent)
+    head = b"".join(struct.pack("<3I", e[0], e[1], (e[2] << 16) | e[3]) for e in ent) + struct.pack("<I", 0) + names
+    v1 = struct.pack("<4I", magic, 1, 16 + len(head), n) + head + src[base_off:]
+    os.makedirs(dst_dir, exist_ok=True)
+    open(os.path.join(dst_dir, "genome_small.nib2"), "wb").write(v1)
+    idx = [f for f in os.listdir(work) if f.startswith("genome_small.X11_")][0]
+    shutil.copyfile(os.path.join(work, idx), os.path.join(dst_dir, idx))
+    return os.path.join(dst_dir, idx)

@@ -279,6 +279,17 @@ def test_cli_drop_in(work, index11, tmp_path):
     assert len(mine) == len(ref)
 
 
+
+@pytest.mark.gpu
+def test_cli_on_a_version_1_nib2(work, tmp_path):
+    """The command line on a `.nib2` of VERSION 1 (12-byte sequence entries, 16-bit name fields: Compress.c:89-128, host/formats.cpp parseNib2) gives the SAM of the
+    version-2 file -- the reference's golden."""
+    from conftest import nib2_v1_copy
+    idx1 = nib2_v1_copy(work, str(tmp_path / "v1")); out = str(tmp_path / "o.sam")
+    subprocess.check_call([ya.CLI_PATH, "-x", idx1, "-q", os.path.join(work, "rchim.fa"), "-osh", out], stderr=subprocess.DEVNULL)
+    assert strip_pg(open(out).read()) == golden_lines("rchim_default")
+
+
 def test_cli_small_batches_many_times(work, index11, tmp_path):
     """Thirty runs of the command line over batches of 50 reads on three contexts -- every context presized from the first, dozens of hand-overs between context and
     filter threads a run: the same SAM every time.  (Round 5: a presized context's post-filter started on unzeroed look-back words -- one run in fifty ended in a

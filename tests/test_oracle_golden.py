@@ -73,6 +73,18 @@ def test_batch_size_and_threads_do_not_change_output(work, index11):
     assert a == b == golden_lines("rchim_default")
 
 
+def test_nib2_version_1_files_load(work, tmp_path):
+    """host/formats.cpp:parseNib2 restates both header layouts of loadBaseSequences (Compress.c:89-128); only version 2 is ever written.  A version-1 file made from
+    the golden genome's must give the same sequences, the same header and the same alignments -- and the reference itself must accept the file the test makes."""
+    from conftest import nib2_v1_copy
+    idx1 = nib2_v1_copy(work, str(tmp_path / "v1"))
+    assert run_oracle_pipeline(idx1, os.path.join(work, "rchim.fa"), "-osh", []) == golden_lines("rchim_default")
+    if oracle.have_reference():
+        ref_out = str(tmp_path / "ref.sam")
+        oracle.run_reference(["-x", idx1, "-q", os.path.join(work, "rchim.fa"), "-osh", ref_out])
+        assert strip_pg(open(ref_out).read()) == golden_lines("rchim_default")
+
+
 @pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref/yaha not built")
 def test_live_reference_on_fresh_reads(work, index11, tmp_path):
     # a read set that is not in the goldens, checked against the reference binary run right now

@@ -265,8 +265,21 @@ __device__ __forceinline__ int waveFinish(yoqc::Run &X, int cnt, int bestNode, y
 // live in the workgroup's LDS (the surviving keys wait in HBM, the read's slice of the key array) and every access below is compiled as an LDS instruction; LDS =
 // false: everything in the read's slices of the batch-wide HBM arrays.  (One body whose pointers may be either costs a `flat` access -- it waits for all of the
 // wave's memory traffic -- at every step of the one-lane parts: the walk along the path, the tables' binary searches.)
+// YQ_GRAPH_INLINE=0 (round 6, measured and dropped): the graph stage as a FUNCTION the kernel calls once a read instead of a part of its body.  Inlined twice (LDS /
+// HBM work space) behind the sort and the duplicate scan it makes one body of 12 000 instructions whose wave-uniform state -- the parameters, thirteen work-space
+// pointers, the arguments -- does not fit the scalar registers: 245 of them spill to lanes of vector registers (v_writelane / v_readlane, no memory).  As a function:
+// no spill, but 616 bytes of scratch a lane for what is passed by reference, and k_oqc_wave 2.47 -> 2.93 ms a launch, the batch's slowest read 3.05 -> 3.37 ms
+// (profiles/r06_postfilter_graph_noinline.txt): a spilled scalar costs one v_readlane, a scratch access a trip to memory.
+#ifndef YQ_GRAPH_INLINE
+#define YQ_GRAPH_INLINE 1
+#endif
+#if YQ_GRAPH_INLINE
+#define YQ_GRAPH_FN __device__ __forceinline__
+#else
+#define YQ_GRAPH_FN __device__ __attribute__((noinline))
+#endif
 template <bool LDS>
-__device__ __forceinline__ void oqcGraph(const OqcArgs &A, const yoqc::Params &P, yoqc::Scratch S, unsigned char *sMain, unsigned mainBytes, uint32_t b, uint32_t r, int n, int cnt,
+YQ_GRAPH_FN void oqcGraph(const OqcArgs &A, const yoqc::Params &P, yoqc::Scratch S, unsigned char *sMain, unsigned mainBytes, uint32_t b, uint32_t r, int n, int cnt,
     int qlen, int lane, unsigned long long *tk)
 {
     const bool prof = A.prof != nullptr; unsigned long long tPath = 0, tSucc = 0;
