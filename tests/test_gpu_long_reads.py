@@ -111,6 +111,43 @@ def test_cgr_like_30kbp_contigs_oqc_fbs(g40, tmp_path, div):
     assert multi >= 20
 
 
+def test_reads_from_inside_repeat_families_reach_the_filters_last_class(g40, tmp_path):
+    """Reads drawn straight from the genome around copies of its Alu-like families (16 families of ~900 copies at 4-13 % divergence): a read that holds one or two
+    copies chains with hundreds of the others -- 450 to 1 000 clumps -- which is the device post-filter's LAST class (449 .. 1 792 clumps: the sort on the wave in 64 KB
+    of LDS, oqc_stage.h).  Until round 6 that class was only ever compared with the host's compilation of the same routine; here the reads go through the command line
+    (-OQC Y -FBS Y, the filter on the device) against the reference itself, after the API has shown that such reads are in the set and that none was handed back to
+    the host unfiltered."""
+    import random
+    d, g, index = g40
+    seqs, name = {}, None
+    for l in open(g):
+        if l.startswith(">"):
+            name = l[1:].split()[0]; seqs[name] = []
+        else:
+            seqs[name].append(l.strip())
+    seqs = {k: "".join(v) for k, v in seqs.items()}
+    bed = [l.split("\t") for l in open(os.path.join(d, "repeats.bed")).read().split("\n") if l]
+    rnd = random.Random(6)
+    reads = str(tmp_path / "inside_repeats.fa"); n_written = 0
+    with open(reads, "w") as f:
+        for i, (c, s0, e0, _st, fam, _dv) in enumerate(rnd.sample(bed, 260)):
+            mid = (int(s0) + int(e0)) // 2; a = max(0, mid - rnd.randrange(300, 700)); r = seqs[c][a:a + 1000]
+            if len(r) == 1000 and "N" not in r:
+                f.write(">w%d_%s\n%s\n" % (i, fam, r)); n_written += 1
+    assert n_written >= 200
+    with ya.Session(["-x", index, "-q", reads, "-FBS", "Y"]) as s:
+        b = s.next_batch(4096)
+        with ya.Context(s.index, s.params) as c:
+            c.upload(b); c.run(); r = c.collect()
+            n = [r.clump_start[i + 1] - r.clump_start[i] for i in range(r.n_reads)]
+            c.set_postfilter(s); f = c.postfilter()
+            unfiltered = sum(1 for k in range(int(f.n_clumps)) if f.clumps[k].primaryCount == 0xFFFF)
+    big = [x for x in n if x >= 449]
+    assert len(big) >= 5 and max(n) <= 1792, "clumps a read: %s" % sorted(n)[-12:]
+    assert unfiltered == 0                                                       # every read, the largest included, was filtered on the device
+    check(index, reads, ["-OQC", "Y", "-FBS", "Y"], tmp_path, min_records=n_written)
+
+
 def test_10kbp_reads_at_default_seed_length(g40, tmp_path):
     d, g, index = g40
     reads = str(tmp_path / "r10k.fa")
