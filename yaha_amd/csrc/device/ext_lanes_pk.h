@@ -71,6 +71,16 @@ __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) 
 #ifdef YD_PROF
 __device__ unsigned long long gRowsProf[8];      // passes, passes that wrote results, refill rounds, passes with a new maximum, busy lane-passes, flushes, pool loads
 #endif
+// YD_ROWS_UNI_EXIT=1: only the pass loop's two exits as scalar branches -- 14.38 -> 14.32 ms a launch (everything at once was slower, see the loop's head); and a
+// scalar exit is the safe form of a wave-uniform one
+#ifndef YD_ROWS_UNI_EXIT
+#define YD_ROWS_UNI_EXIT 1
+#endif
+#if YD_ROWS_UNI_EXIT
+#define YD_ROWS_EXIT(c) UNI_B(c)
+#else
+#define YD_ROWS_EXIT(c) (c)
+#endif
 #ifndef YD_ROWS_WAVES
 #define YD_ROWS_WAVES 3                        // waves per SIMD of k_ext_rows_pk (a build switch for experiments: make variant VARIANT_FLAGS=-DYD_ROWS_WAVES=2)
 #endif
@@ -169,7 +179,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
         // (Round 6, measured and dropped: every wave-uniform condition of this loop through UNI_B and every uniform counter through uni().  Left to itself the compiler
         // takes the loop's exits for lane-dependent -- an EXEC-masked loop, the uniform state in vector registers, twenty moves and thirty mask instructions a pass --
         // but the scalar version waits for a v_readfirstlane before every branch: 14.42 -> 15.84 ms a launch, profiles/r06_rows_kernel_passes.txt.)
-        if (noMem) break;
+        if (YD_ROWS_EXIT(noMem)) break;
         // What the previous iteration loaded is consumed HERE, before this iteration issues any store (the memory counter is in-order: a wait for these loads
         // further down would also wait for the stores issued in between).  Slide the reference window: pair k takes pair k+1; pair 10's low half takes what
         // was pair 1's high half, its high half the new base.  (A lane that starts a problem below overwrites the window.)
@@ -397,7 +407,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(YD_ROWS
                 YD_GLOBAL yd_u32x4 *dst = (YD_GLOBAL yd_u32x4 *)toGlobal(&A.res[pendRes]); YD_STORE_NT(dst, lo); YD_STORE_NT(dst + 1, hi); } pendRes = -1;
         }
         flushBlocks(flushNow, flushSlot);
-        if (last) break;
+        if (YD_ROWS_EXIT(last)) break;
         const uint32_t qcP = ((uint32_t)qc | ((uint32_t)qcPrev << 16)) ^ (YD_RCREAL * 0x10001u);      // code ^ qcP = nibble ^ query code
         qcPrev = qc;
         uint32_t qcPv = qcP; asm volatile("" : "+v"(qcPv));                   // (opaque: else the constant is re-applied in every pair)
