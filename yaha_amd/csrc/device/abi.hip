@@ -334,7 +334,7 @@ std::vector<DevBuf *> allBuffers(ygpu_ctx *ctx)
     DevBuf *all[] = {&ctx->dBases, &ctx->dSO, &ctx->dROA, &ctx->dLow, &ctx->dFwd, &ctx->dRev, &ctx->dFwd4, &ctx->dRev4, &ctx->dReadOff, &ctx->dKmerOff, &ctx->posS, &ctx->posC,
         &ctx->posRsI, &ctx->hitOff, &ctx->expandStart, &ctx->keysA, &ctx->keysB, &ctx->segOff, &ctx->bigB, &ctx->bigE, &ctx->isHead, &ctx->tileState,
                          &ctx->frags, &ctx->regStart, &ctx->multiList, &ctx->smallList, &ctx->bigList, &ctx->regionCount, &ctx->regionBase, &ctx->clumps, &ctx->clumpFrags,
-                             &ctx->clumpFrags0, &ctx->order, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
+                             &ctx->clumpFrags0, &ctx->order, &ctx->clumpsSorted, &ctx->rootPush, &ctx->rootBase, &ctx->outClumps,
                          &ctx->outClumps2, &ctx->outOps, &ctx->outRoot, &ctx->outPush, &ctx->dstIdx, &ctx->readCount, &ctx->readStart, &ctx->counters, &ctx->ctr, &ctx->errFlag,
                              &ctx->scanState, &ctx->bucketWork, &ctx->scratchAlign,
                          &ctx->segLists, &ctx->subB, &ctx->subE, &ctx->subLists, &ctx->subBigB, &ctx->subBigE, &ctx->sub2B, &ctx->sub2E, &ctx->sub2Lists, &ctx->sub3B, &ctx->sub3E,

@@ -11,6 +11,9 @@
 #include "dp_wave.h"
 
 struct ChainClumpRec { uint32_t rs, fragOff, nFrags, region, seq, matched; };
+// root r's record: the records in RANK order (round 6: k_clump_order writes a copy in the order of the roots, so that a wave's 64 roots are one stretch of 1.5 KB --
+// six kernels start their chain of dependent fetches here) -- order == nullptr -- or, for the arena as the chain stage left it, through the rank table
+#define YD_ROOT_REC(A, r) ((A).order ? (A).clumps[(A).order[(r)]] : (A).clumps[(r)])
 
 #define YD_DEPTH 24
 
@@ -370,7 +373,7 @@ struct Aligner {
     // The whole life of one root clump.
     __device__ void processRoot(uint32_t rank)
     {
-        const ChainClumpRec rec = A.clumps[A.order[rank]];
+        const ChainClumpRec rec = YD_ROOT_REC(A, rank);
         const uint32_t read = rec.rs >> 1; const uint32_t r0 = A.B.readOff[read];
         qlen = (int)(A.B.readOff[read + 1] - r0); q = ((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0;
         rootRank = rank; pushes = 0;

@@ -134,7 +134,7 @@ struct ygpu_ctx {
     DevBuf segLists, subB, subE, subLists, subBigB, subBigE, sub2B, sub2E, sub2Lists, sub3B, sub3E, sub3Lists, kmerParts;
     // chain stage
     DevBuf regStart, multiList, smallList, bigList, regionCount, regionBase;
-    DevBuf clumps, clumpFrags, clumpFrags0, order, scratchChain;
+    DevBuf clumps, clumpFrags, clumpFrags0, order, clumpsSorted, scratchChain;
     // align stage
     DevBuf rootPush, rootBase, outClumps, outClumps2, outOps, outRoot, outPush, dstIdx, readCount, readStart;
     DevBuf scratchAlign, dpProbs, dpRes, dpOps;

@@ -19,12 +19,12 @@ __global__ void k_out_scatter(const ygpu_clump *src, const uint32_t *dstIdx, uin
     if (c >= nOut) return;
     dst[dstIdx[c]] = src[c];
 }
-// clumps per read: root r belongs to read (clumps[order[r]].rs >> 1)
-__global__ void k_read_counts(const ChainClumpRec *clumps, const uint32_t *order, const unsigned int *rootPushCount, uint32_t nRoots, unsigned int *readCount)
+// clumps per read: root r belongs to read (sorted[r].rs >> 1) (the records in rank order, k_clump_order)
+__global__ void k_read_counts(const ChainClumpRec *sorted, const unsigned int *rootPushCount, uint32_t nRoots, unsigned int *readCount)
 {
     YD_HIGH_PRIO();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nRoots) return;
     const unsigned n = rootPushCount[r];
-    if (n) atomicAdd(&readCount[clumps[order[r]].rs >> 1], n);
+    if (n) atomicAdd(&readCount[sorted[r].rs >> 1], n);
 }

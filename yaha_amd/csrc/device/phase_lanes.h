@@ -212,7 +212,7 @@ __global__ void k_joint_counts(AlignArgs A, PhaseArgs X)
 {
     YD_HIGH_PRIO();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < A.nRoots) X.jointCount[r] = A.clumps[A.order[r]].nFrags - 1u;
+    if (r < A.nRoots) X.jointCount[r] = YD_ROOT_REC(A, r).nFrags - 1u;
     if (r == A.nRoots) X.jointCount[r] = 0u;
 }
 
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
     const bool live = r < A.nRoots; const DevParams &P = A.P;
     unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0, nB12 = 0, nB16 = 0;
     if (live) {
-        const ChainClumpRec rec = A.clumps[A.order[r]]; const int n = (int)rec.nFrags;
+        const ChainClumpRec rec = YD_ROOT_REC(A, r); const int n = (int)rec.nFrags;
         if (n > 1) {
             const uint32_t read = rec.rs >> 1, r0 = A.B.readOff[read];
             YD_GLOBAL const uint8_t *q = toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0; YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
     const int lane = laneId(); const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
     ChainClumpRec rec; rec.nFrags = 0; rec.rs = 0; rec.fragOff = 0;
-    if (live) rec = A.clumps[A.order[r]];
+    if (live) rec = YD_ROOT_REC(A, r);
     const int n = (int)rec.nFrags; const uint32_t jb = live ? X.jointBase[r] : 0u;
     // exact upper bound of the list length
     unsigned want = 0;
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(64) k_p3_predict(AlignArgs A, PhaseArgs X)
         ExtProb pp[YD_MEMO]; int np = 0;
         if (live) {
             const uint32_t r = X.slowList[slot]; const P3Root R0 = p3Merged(X, r);
-            const ChainClumpRec rec = A.clumps[A.order[r]]; const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
+            const ChainClumpRec rec = YD_ROOT_REC(A, r); const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
             np = predictCarefulDPs(P, R0.L, R0.L.count(), R0.sqo, R0.eqo, R0.sro, R0.refLen, toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0, qlen, toGlobal(A.bases), pp, r0,
                 (rec.rs & 1u) ? XP_STRAND : 0u);
         }
@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(64) k_align_p3(AlignArgs A, PhaseArgs X)
         const unsigned r1 = min(r0 + 4u, nRoots);
         for (unsigned ri = r0; ri < r1; ri++) {
             const unsigned r = X.useList ? uniU(X.slowList[ri]) : ri;
-            const ChainClumpRec rec = A.clumps[A.order[r]];
+            const ChainClumpRec rec = YD_ROOT_REC(A, r);
             al.setRead(rec); al.rootRank = r; al.pushes = 0;
             const RootState S0 = X.state[r]; const uint32_t listOff = uniU(S0.listOff);
             Frame f; memset(&f, 0, sizeof f); f.sro = S0.sro; f.sqo = S0.sqo; f.eqo = S0.eqo; f.refLen = S0.refLen; f.score = S0.score; f.status = S0.status; f.phase = PH_NONE;

@@ -81,11 +81,14 @@ __global__ void __launch_bounds__(1024) k_region_classify(const uint32_t *regSta
     if (small) smallList[sBase[1] + bs + (unsigned)__builtin_popcountll(ms & below)] = r;
 }
 // order[base[region] + seq] = clump index  (rank of a root clump = creation order)
-__global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, const uint32_t *regionBase, uint32_t *order)
+// ... and sorted[rank] = the record itself: what the align stage reads (a wave's 64 roots in one stretch; through `order` they are 64 places of the arena)
+__global__ void k_clump_order(const ChainClumpRec *clumps, uint32_t nClumps, const uint32_t *regionBase, uint32_t *order, ChainClumpRec *sorted)
 {
     YD_HIGH_PRIO();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nClumps) return;
-    if (clumps[c].nFrags == 0xFFFFFFFFu) return;                              // unused slot of a wave's reservation chunk
-    order[regionBase[clumps[c].region] + clumps[c].seq] = c;
+    const ChainClumpRec rec = clumps[c];
+    if (rec.nFrags == 0xFFFFFFFFu) return;                                    // unused slot of a wave's reservation chunk
+    const uint32_t rank = regionBase[rec.region] + rec.seq;
+    order[rank] = c; sorted[rank] = rec;
 }

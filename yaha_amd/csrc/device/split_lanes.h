@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
     unsigned splits = 0, extCalls = 0, extRows = 0, extCells = 0, perfect = 0, touched = 0;
     if (live) {
         r = X.slowList[slot];
-        const ChainClumpRec rec = A.clumps[A.order[r]];
+        const ChainClumpRec rec = YD_ROOT_REC(A, r);
         const uint32_t r0 = A.B.readOff[rec.rs >> 1]; const int qlen = (int)(A.B.readOff[(rec.rs >> 1) + 1] - r0);
         YD_GLOBAL const uint8_t *q = toGlobal((rec.rs & 1u) ? A.B.rev : A.B.fwd) + r0; YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
         // ---- the root as k_p3_lanes saw it: phase-1 list + the two extension results --------------------------------------------

@@ -440,8 +440,8 @@ int stageAlign(ygpu_ctx *ctx)
             HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 12, ctx->stream));      // qalign, outclumps, outops
             HIPCHK(hipMemsetAsync(ctx->rootPush.p, 0, 4ull * (NC + 1), ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
-            AlignArgs A; A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = B; A.order = ctx->order.as<uint32_t>(); A.nRoots = NC;
-            A.clumps = ctx->clumps.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.queueHead = cnt + CNT_QALIGN;
+            AlignArgs A; A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = B; A.order = nullptr; A.nRoots = NC;      // (the roots' records in rank order: clumpsSorted, below)
+            A.clumps = ctx->clumpsSorted.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.queueHead = cnt + CNT_QALIGN;
             A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per; A.maxQ = ctx->maxQ; A.listCap = listCap; A.front = front; A.genCap = genCap;
                 A.traceRows = traceRows;
             A.outClumps = ctx->outClumps.as<ygpu_clump>(); A.outOps = ctx->outOps.as<uint32_t>(); A.outRoot = ctx->outRoot.as<uint32_t>(); A.outPush = ctx->outPush.as<uint32_t>();
@@ -492,7 +492,7 @@ int stageAlign(ygpu_ctx *ctx)
             KL(k_out_scatter, dim3(gridFor(ctx->nOut, 256)), dim3(256), 0, ctx->stream, ctx->outClumps.as<ygpu_clump>(), ctx->dstIdx.as<uint32_t>(), ctx->nOut,
                 ctx->outClumps2.as<ygpu_clump>());
         }
-        KL(k_read_counts, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->order.as<uint32_t>(), ctx->rootPush.as<unsigned int>(), NC,
+        KL(k_read_counts, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, ctx->clumpsSorted.as<ChainClumpRec>(), ctx->rootPush.as<unsigned int>(), NC,
             ctx->readCount.as<unsigned int>());
     }
     rc = cubScan(ctx, ctx->readCount.as<uint32_t>(), ctx->readStart.as<uint32_t>(), n + 1); if (rc) return rc;

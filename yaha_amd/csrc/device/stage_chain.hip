@@ -78,9 +78,9 @@ int stageChain(ygpu_ctx *ctx)
         rc = buildFrags(ctx, true); if (rc) return rc;
     }
     // (ctx->nClumps: clumps actually formed -- slots minus chunk slack)
-    ENSURE(ctx->order, 4ull * (ctx->nClumps + 1));
+    ENSURE(ctx->order, 4ull * (ctx->nClumps + 1)); ENSURE(ctx->clumpsSorted, sizeof(ChainClumpRec) * ((uint64_t)ctx->nClumps + 1));
     if (ctx->nClumpSlots) KL(k_clump_order, dim3(gridFor(ctx->nClumpSlots, 256)), dim3(256), 0, ctx->stream, ctx->clumps.as<ChainClumpRec>(), ctx->nClumpSlots,
-        ctx->regionBase.as<uint32_t>(), ctx->order.as<uint32_t>());
+        ctx->regionBase.as<uint32_t>(), ctx->order.as<uint32_t>(), ctx->clumpsSorted.as<ChainClumpRec>());
     EV1(T_CHAIN);
     return 0;
 }
