@@ -780,7 +780,7 @@ def main():
                      "cell_updates_per_s": counters["dp_ext_cells"] / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
                      "valu_frac_nominal": (valu * 2.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
                      "valu_frac_measured_mix": (valu * 4.0 / simd_cycles) if (valu and kernel_ms > 0) else None,
-                     "note": "a rows launch that shares the device with other batches takes 9/16 of the workgroups that fit and only one runs at a time (the others' latency-bound kernels run beside it): in the timed region it lasts longer BY DESIGN (`frac_in_run`, `kernel_ms_in_run`); `frac` / `achieved` are the same launch with the device to itself (`frac_unshared`, = the profiles' one-context figure) whenever that was measured; integer DP: `frac` follows SURVEY 8(d) (algorithmic bytes of the reads of one launch / kernel time / 8 TB/s) and is ~1% by construction; the kernel is bound by vector-ALU issue: valu_frac_nominal prices each wave64 VALU instruction at the nominal 2 SIMD cycles, valu_frac_measured_mix at what its mix measures: 4.4 cycles for the packed 16-bit kernel, 4.0 for the 32-bit one (DESIGN.md section 7); kernel_stream_frac counts the trace cells the kernel writes (an implementation choice, not algorithmic traffic)",
+                     "note": "a rows launch that shares the device with other batches takes 3/5 of the workgroups that fit and only one runs at a time (the others' latency-bound kernels run beside it): in the timed region it lasts longer BY DESIGN (`frac_in_run`, `kernel_ms_in_run`); `frac` / `achieved` are the same launch with the device to itself (`frac_unshared`, = the profiles' one-context figure) whenever that was measured; integer DP: `frac` follows SURVEY 8(d) (algorithmic bytes of the reads of one launch / kernel time / 8 TB/s) and is ~1% by construction; the kernel is bound by vector-ALU issue: valu_frac_nominal prices each wave64 VALU instruction at the nominal 2 SIMD cycles, valu_frac_measured_mix at what its mix measures: 4.4 cycles for the packed 16-bit kernel, 4.0 for the 32-bit one (DESIGN.md section 7); kernel_stream_frac counts the trace cells the kernel writes (an implementation choice, not algorithmic traffic)",
                      "pmc": ({k2: pmc[k2] for k2 in ("valu_insts_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch", "lds_bank_conflict_frac", "gpu_busy_cycles", "git_head", "kernel_source_sha16", "source") if k2 in pmc} if pmc else None)},
         "path": {"algorithmic_bytes_per_read": B, "hbm_frac_whole_path": value * B / (8.0e12 * world),
                  "dp_cell_updates_per_s": (counters["dp_ext_cells"] + counters["dp_gap_cells"]) * steps * world / dt},

@@ -120,13 +120,14 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     int perCU = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, rowsKernel, (int)rowsBS, 0) != hipSuccess || perCU < 1) perCU = rowsBS == 512u ? 1 : 2;
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU);
-    // With other batches in flight on the device the persistent launch takes 9/16 of what fits (1.7 workgroups a CU), and only ONE such launch runs at a time on the
+    // With other batches in flight on the device the persistent launch takes 3/5 of what fits (1.8 workgroups a CU; 9/16 until round 6: the kernel got 3 % shorter and
+    // the optimum moved -- 432 workgroups 41.82, 448 41.71, 464 41.43, 480 41.45 ms a step, three alternating rounds, profiles/r06_rows_blocks_sweep.txt), and only ONE such launch runs at a time on the
     // device (below: gRowsEv).  Its waves hold their registers and LDS until the launch ends; what they leave is all the other batches' latency-bound kernels get to
     // run in meanwhile -- and two rows launches side by side would take the whole chip between them again.  Four contexts, 3.1 Gbp, ms a step
     // (profiles/r05_rows_blocks_sweep.txt): the full launch, free-running (rounds 1-4) 44.4-45.0; 384 workgroups free-running 43.6-44.0; one at a time: 352 workgroups
     // 44.2-44.3, 384 43.4-43.8, 416 42.5-43.0, 448 42.2-43.0, 480 43.5-43.9.  Alone on the device the full launch is 2.7 ms a step faster than half of it.
     // (YGPU_ROWS_BLOCKS: the workgroups as a count, for such sweeps.)
-    if (rowsShare && rowsBS == 256u) maxBlocksK = std::max(64u, maxBlocksK * 9u / 16u);
+    if (rowsShare && rowsBS == 256u) maxBlocksK = std::max(64u, maxBlocksK * 3u / 5u);
     if (const char *e = getenv("YGPU_ROWS_BLOCKS")) { const long v = atol(e); if (v >= 64 && v <= (long)ctx->nCU * perCU) maxBlocksK = (unsigned)v; }
     const unsigned maxWavesK = maxBlocksK * (rowsBS / 64u);
     const double chunkBlocks = (double)YD_CHUNK_FLUSHES * 64.0;             // lane blocks (128 B) per chunk
