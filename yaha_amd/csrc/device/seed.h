@@ -198,11 +198,15 @@ __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned lo
 // done) and publishes before it waits for anything -- no assumption about the order in which workgroups are dispatched.  Before: the library's scan over the
 // flags (2.6 GB of keys read, 1.3 GB of indices written) and a build kernel that read both again.  Records beyond cap are not written: the caller reads *total
 // and comes back with room.
+#ifndef YD_FRAG_BS
 #define YD_FRAG_BS 1024
+#endif
+#ifndef YD_FRAG_IPT
 #define YD_FRAG_IPT 8
+#endif
 #define YD_FRAG_TILE (YD_FRAG_BS * YD_FRAG_IPT)
-static_assert((YD_FRAG_IPT * (YD_FRAG_BS / 64)) % 64 == 0 && YD_FRAG_IPT <= 10,
-    "k_frag_scan_build: wave 0 scans IPT x waves counts, a whole number per lane; the class bits of ten rows fit one word");
+static_assert((YD_FRAG_IPT * (YD_FRAG_BS / 64)) % 64 == 0 && YD_FRAG_IPT <= 16,
+    "k_frag_scan_build: wave 0 scans IPT x waves counts, a whole number per lane; the class bits of sixteen rows fit two words");
 __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap,
                                                                 unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */,
                                                                     unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
