@@ -39,6 +39,7 @@ struct PhaseArgs {
     uint32_t *slowList; unsigned int *slowCount;        // roots (k_p3_lanes) or joints (k_gap_lanes) handed to the wave kernels
     int useList;                                        // k_align_p3: take roots from slowList[0 .. *slowCount)
     uint32_t rootBegin;                                 // k_p3_lanes: first root of the chunk (A.nRoots = its end)
+    const uint32_t *p3Order;                            // k_p3_lanes: the chunk's roots by descending length of their merged edit list (k_p3_keys), or nullptr
     // splitClump in lanes (split_lanes.h): the careful extensions of the split roots are listed by k_p3_lanes, computed by a second
     // k_ext_rows / k_ext_trace round, and consumed by k_split_lanes
     uint32_t *memoKeys; unsigned int *memoCount; ExtProb *probs2; unsigned long long *rowsBound2; unsigned int *nProb2; uint32_t probs2Cap;
@@ -623,11 +624,26 @@ __device__ __forceinline__ P3Root p3Merged(const PhaseArgs &X, uint32_t r)
     return o;
 }
 
+// k_p3_lanes walks every root's merged edit list op by op, and a wave walks as long as its longest list: 57 ops a root on average, ~240 for the longest of 64 roots in
+// rank order -- three quarters of the lane slots of its loop idle (round 6: 11 100 vector instructions a wave for 64 x 57 ops).  So the roots are taken by
+// descending list length (one key per root, one bucket pass, scan.h): 4 095 - min(ops, 4 095).  The order of the roots does not matter to anything the kernel
+// writes -- accepted clumps and split roots take their places by atomic reservation, and the final layout orders by (root rank, push number).
+__global__ void __launch_bounds__(256) k_p3_keys(PhaseArgs X, uint32_t rootEnd, uint32_t *keys)
+{
+    YD_HIGH_PRIO();
+    const uint32_t r = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rootEnd) return;
+    const RootState S = X.state[r]; const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
+    const uint32_t n = (uint32_t)S.len + (rb.score > 0 ? rb.nOps : 0u) + (rf.score > 0 ? rf.nOps : 0u);
+    keys[r - X.rootBegin] = 4095u - min(n, 4095u);
+}
+
 __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
 {
     YD_HIGH_PRIO();
-    const int lane = laneId(); const uint32_t r = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = r < A.nRoots; const DevParams &P = A.P;
+    const int lane = laneId(); const uint32_t t = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < A.nRoots; const DevParams &P = A.P;
+    const uint32_t r = (live && X.p3Order) ? X.p3Order[t - X.rootBegin] : t;
     int verdict = -1;                                  // -1 none, 0 rejected, 1 split needed, 2 scored
     MergedOps L; L.a = L.b = L.c = nullptr; L.na = L.nb = L.nc = L.jab = L.jbc = 0;
     uint32_t sro = 0; int sqo = 0, eqo = 0, refLen = 0, status = 0, n = 0;

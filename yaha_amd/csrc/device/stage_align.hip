@@ -48,7 +48,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->rowsBound.p + nProb, 0, 8, ctx->stream));
     PhaseArgs X; X.state = ctx->rootState.as<RootState>(); X.stateOps = ctx->stateOps.as<uint32_t>(); X.stateOpsCount = cnt + CNT_STATEOPS; X.stateOpsCap = stateOpsCap;
-    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = nullptr; X.rootBegin = 0;
+    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = nullptr; X.rootBegin = 0; X.p3Order = nullptr;
     TRACE("lanes: ensure");
     X.slowList = ctx->slowList.as<uint32_t>(); X.slowCount = cnt + CNT_SLOW; X.useList = 1;
     EV0(T_P1);
@@ -304,6 +304,18 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                 Xc.rowsBound2 = ctx->rowsBound2.as<unsigned long long>();
             Xc.nProb2 = cc + 8 * c + 3; Xc.probs2Cap = cap2;
         } else { Xc.memoKeys = nullptr; Xc.memoCount = nullptr; Xc.probs2 = nullptr; Xc.rowsBound2 = nullptr; Xc.nProb2 = nullptr; Xc.probs2Cap = 0; }
+        {   // the roots by descending length of their merged lists (phase_lanes.h k_p3_keys): keys and order in the traceback's key arrays, which are free by now
+            // (YGPU_P3_SORT=1; measured in round 6 and OFF: k_p3_lanes 3.07 -> 2.76 ms, but the key and ordering kernels cost 0.22 and k_split_lanes, which takes the split
+            // roots in the order k_p3_lanes lists them, goes 1.46 -> 1.97 ms: the kernels are bound by their scattered fetches, not by the idle lanes of the loop)
+            static const bool p3Sort = getenv("YGPU_P3_SORT") && atoi(getenv("YGPU_P3_SORT")) != 0;
+            Xc.p3Order = nullptr;
+            if (p3Sort && nr > 4096u) {
+                uint32_t *kk = ctx->extKeys.as<uint32_t>() + p0, *oo = ctx->extVals.as<uint32_t>() + p0;
+                KL(k_p3_keys, dim3(gridFor(nr, 256)), dim3(256), 0, ctx->stream, Xc, r1, kk);
+                rc = bucketOrder(ctx, kk, nullptr, r0, nr, 0, 0, 4096u, oo, ctx->stream); if (rc) return rc;
+                Xc.p3Order = oo;
+            }
+        }
         KL(k_p3_lanes, dim3(gridFor(nr, 256)), dim3(256), 0, ctx->stream, Ac, Xc);
         if (ctx->splitLanes) KL(k_p3_predict, dim3((unsigned)std::min<uint64_t>(gridFor(nr, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, Ac, Xc);
         PhaseArgs Xw = Xc;                                                    // what k_align_p3 gets: all split roots, or only those k_split_lanes gives back
