@@ -581,6 +581,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="CPU-baseline budget (wall seconds of the reference over all its thread counts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-extras", action="store_true", help="of the legs after the timed region only the D2H- and post-filter-inclusive rates (for A/Bs of the filter stage)")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs measured after the timed region (other read lengths, D2H-inclusive rate, command line)")
     ap.add_argument("--e2e-reads", type=int, default=1048576, help="reads of the end-to-end command-line leg (BASELINE config 4: 1 M x 1 kbp)")
     ap.add_argument("--contexts", type=int, default=4, help="device contexts (batches in flight) per GPU")
@@ -792,7 +793,7 @@ def main():
         out["value_with_d2h"] = d2h["value_with_d2h"]; out["d2h"] = d2h
         if "value_with_postfilter" in d2h:
             out["value_with_postfilter"] = d2h["value_with_postfilter"]
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not args.quick_extras:
         # the same step on BASELINE's other read lengths (configs 1 and 3), and the whole command line (config 2 end to end)
         wl = []
         for label, n, length, div, nsteps in (("c1: 100 bp reads, r=0.02 (realised 0.7%)", 65536, 100, 0.007, 4), ("c3: 10 kbp reads, r=0.10 (realised 3.4%)", 1024, 10000, 0.034, 3)):
