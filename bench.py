@@ -572,8 +572,8 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads-per-gpu", type=int, default=16384)
     ap.add_argument("--read-len", type=int, default=1000)
     ap.add_argument("--genome-mbp", type=int, default=0, help="synthetic genome size; 0 = G-hg18scale (3 100 Mbp: the index the metric is quoted on) when the box has the disk and memory for it, else 100")
