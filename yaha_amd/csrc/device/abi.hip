@@ -140,7 +140,8 @@ static long copyFromPeer(int device, int srcDevice, const ImagePlan &plan, Image
         if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) me.failed = 1; }
     for (size_t i = 0; i < plan.pieces.size() && !me.failed; i++) {
         const int k = (int)(i % W);
-        if (used[k]) { if (hipEventSynchronize(ev[k]) != hipSuccess) { used[k] = false; broke = (long)pend[k]; break; } me.done[pend[k]].store(1, std::memory_order_release); used[k] = false; }
+        if (used[k]) { if (hipEventSynchronize(ev[k]) != hipSuccess) { used[k] = false; broke = (long)pend[k]; break; } me.done[pend[k]].store(1, std::memory_order_release);
+            used[k] = false; }
         while (!from.done[i].load(std::memory_order_acquire)) { if (from.failed) { broke = (long)i; break; } std::this_thread::yield(); }
         if (broke >= 0) break;
         const ImagePiece &q = plan.pieces[i];
@@ -264,8 +265,14 @@ int ygpu_init_multi(const int *devices, int n, int ctx_per_device, const ygpu_in
     std::vector<ygpu_ctx *> out(n); for (int k = 0; k < n; k++) out[k] = all[k * cpd];      // every device's first context: the one that owns its image
     std::vector<int> rcs(n, 0);
     // a failure before anything was started: the devices it is about say why, the others that they were not started
-    auto notStarted = [&](int rc) { for (int k = 0; k < n; k++) { if (!rcs[k]) { rcs[k] = YGPU_EINVAL; out[k]->err = "not started: another device of the call failed";
-        } if (rc_each) rc_each[k] = rcs[k]; for (int j = 1; j < cpd; j++) all[k * cpd + j]->err = out[k]->err; } return rc; };
+    auto notStarted = [&](int rc) {
+        for (int k = 0; k < n; k++) {
+            if (!rcs[k]) { rcs[k] = YGPU_EINVAL; out[k]->err = "not started: another device of the call failed"; }
+            if (rc_each) rc_each[k] = rcs[k];
+            for (int j = 1; j < cpd; j++) all[k * cpd + j]->err = out[k]->err;
+        }
+        return rc;
+    };
     const double t0 = nowMs();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { for (int k = 0; k < n; k++) { rcs[k] = YGPU_ENODEV;
@@ -474,8 +481,12 @@ int ygpu_run(ygpu_ctx *ctx)
     }
     return 0;
 }
-void *ygpu_host_alloc(size_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr;
-    } return p; }
+void *ygpu_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
 void ygpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
 static void asyncWorker(ygpu_ctx *ctx)
 {

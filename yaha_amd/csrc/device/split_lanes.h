@@ -161,8 +161,11 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
                 int ns = 0, aQ = 0, aR = 0;
                 if (o.score > 0) {
                     int QLen = 0, RLen = 0, AGS = 0, maxAGS = 0, startItem = -1;
-                    for (int k = 0; k < o.nOps; k++) { opStep(opAt(o, k), QLen, RLen, AGS); if (AGS <= 0) { AGS = 0; maxAGS = 0; QLen = 0; RLen = 0; startItem = k;
-                        } if (AGS > maxAGS) maxAGS = AGS; }
+                    for (int k = 0; k < o.nOps; k++) {
+                        opStep(opAt(o, k), QLen, RLen, AGS);
+                        if (AGS <= 0) { AGS = 0; maxAGS = 0; QLen = 0; RLen = 0; startItem = k; }
+                        if (AGS > maxAGS) maxAGS = AGS;
+                    }
                     if (!(AGS <= 0 || maxAGS >= AGS + score)) { mergeFront(b, fr.start, fr.len, o, startItem + 1, o.nOps); aQ = QLen; aR = RLen; ns = AGS; }
                 }
                 if (ns > 0) { score += ns; fr.sqo = (fr.sqo - aQ) & 0xFFFF; fr.sro -= (uint32_t)aR; fr.refLen = (fr.refLen + aR) & 0xFFFF; }

@@ -48,7 +48,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->rowsBound.p + nProb, 0, 8, ctx->stream));
     PhaseArgs X; X.state = ctx->rootState.as<RootState>(); X.stateOps = ctx->stateOps.as<uint32_t>(); X.stateOpsCount = cnt + CNT_STATEOPS; X.stateOpsCap = stateOpsCap;
-    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = nullptr; X.rootBegin = 0; X.p3Order = nullptr;
+    X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = nullptr; X.rootBegin = 0;
+        X.p3Order = nullptr;
     TRACE("lanes: ensure");
     X.slowList = ctx->slowList.as<uint32_t>(); X.slowCount = cnt + CNT_SLOW; X.useList = 1;
     EV0(T_P1);
@@ -121,7 +122,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     if (const char *e = getenv("YGPU_ROWS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < perCU) perCU = v; }
     unsigned maxBlocksK = (unsigned)((uint64_t)ctx->nCU * perCU);
     // With other batches in flight on the device the persistent launch takes 3/5 of what fits (1.8 workgroups a CU; 9/16 until round 6: the kernel got 3 % shorter and
-    // the optimum moved -- 432 workgroups 41.82, 448 41.71, 464 41.43, 480 41.45 ms a step, three alternating rounds, profiles/r06_rows_blocks_sweep.txt), and only ONE such launch runs at a time on the
+    // the optimum moved -- 432 workgroups 41.82, 448 41.71, 464 41.43, 480 41.45 ms a step, three alternating rounds, profiles/r06_rows_blocks_sweep.txt), and only ONE such launch
+    // runs at a time on the
     // device (below: gRowsEv).  Its waves hold their registers and LDS until the launch ends; what they leave is all the other batches' latency-bound kernels get to
     // run in meanwhile -- and two rows launches side by side would take the whole chip between them again.  Four contexts, 3.1 Gbp, ms a step
     // (profiles/r05_rows_blocks_sweep.txt): the full launch, free-running (rounds 1-4) 44.4-45.0; 384 workgroups free-running 43.6-44.0; one at a time: 352 workgroups
@@ -453,7 +455,8 @@ int stageAlign(ygpu_ctx *ctx)
             HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 12, ctx->stream));      // qalign, outclumps, outops
             HIPCHK(hipMemsetAsync(ctx->rootPush.p, 0, 4ull * (NC + 1), ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->errFlag.p, 0, 4, ctx->stream));
-            AlignArgs A; A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = B; A.order = nullptr; A.nRoots = NC;      // (the roots' records in rank order: clumpsSorted, below)
+            // (the roots' records in rank order: clumpsSorted, below)
+            AlignArgs A; A.P = ctx->P; A.bases = ctx->dBases.as<uint8_t>(); A.B = B; A.order = nullptr; A.nRoots = NC;
             A.clumps = ctx->clumpsSorted.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.queueHead = cnt + CNT_QALIGN;
             A.scratch = ctx->scratchAlign.as<uint8_t>(); A.scratchPerWave = per; A.maxQ = ctx->maxQ; A.listCap = listCap; A.front = front; A.genCap = genCap;
                 A.traceRows = traceRows;

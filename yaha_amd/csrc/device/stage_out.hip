@@ -240,7 +240,8 @@ int ygpu_collect_filtered(ygpu_ctx *full, uint32_t *clump_start, ygpu_out_clump 
     if (full->nFOps) HIPCHK(hipMemcpyAsync(ops, full->oqFOps.p, 4ull * full->nFOps, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(streamSync(ctx));
     tlsPfFailed = nullptr;
-    full->oqDone = false;                                                    // (collected: a later ygpu_filtered_size without a new ygpu_postfilter is an error, not the previous batch once more)
+    // (collected: a later ygpu_filtered_size without a new ygpu_postfilter is an error, not the previous batch once more)
+    full->oqDone = false;
     out->n_reads = n; out->clump_start = clump_start; out->clumps = clumps; out->ops = ops; out->n_clumps = full->nFOut; out->n_ops = full->nFOps; out->counters = full->pfCounters;
     return 0;
 }

@@ -336,8 +336,10 @@ int runQueries(Args &a, FILE *log)
     auto device = [&](int d) {
         BatchP b; bool first = true; Warm &W = *warm[d / perDev]; const int dev = devs[d / perDev], leadCtx = d - d % perDev;
         int rc0;
-        if (d == 0) { bringUpDevices(); for (int k = 0; k < nDev; k++) { Warm &Wk = *warm[k]; { std::lock_guard<std::mutex> lk(Wk.mu); Wk.ready = leadRc[k] == 0 ? 1 : -1;
-            } Wk.cv.notify_all(); } }
+        if (d == 0) {
+            bringUpDevices();
+            for (int k = 0; k < nDev; k++) { Warm &Wk = *warm[k]; { std::lock_guard<std::mutex> lk(Wk.mu); Wk.ready = leadRc[k] == 0 ? 1 : -1; } Wk.cv.notify_all(); }
+        }
         { std::unique_lock<std::mutex> lk(W.mu); W.cv.wait(lk, [&] { return W.ready != 0; }); rc0 = W.ready == 1 ? 0 : (leadRc[d / perDev] ? leadRc[d / perDev] : YGPU_ENODEV); }
         if (rc0 == 0 && deviceFilter) rc0 = ygpu_set_postfilter(ctx[d], &PF);
         if (rc0 != 0) { char m[512];
@@ -539,8 +541,9 @@ int runQueries(Args &a, FILE *log)
     if (timing) fprintf(stderr, "[yaha] batches done %.1f ms after start, teardown %.1f ms\n", tDone - tEnter, now() - tDone);
     if (stats) {    // one line for scripts (bench.py): steady = reads written after the first batch / time from the first batch's write to the last one's
         const double steady = (nWritten > nFirst && tLastOut > tFirstOut) ? (nWritten - nFirst) / ((tLastOut - tFirstOut) * 1e-3) : 0.0;
-        std::string per = "["; for (int k = 0; k < nDev; k++) { char t[32]; snprintf(t, sizeof t, "%s%llu", k ? ", " : "", (unsigned long long)devReads[k].load()); per += t;
-            } per += "]";
+        std::string per = "[";
+        for (int k = 0; k < nDev; k++) { char t[32]; snprintf(t, sizeof t, "%s%llu", k ? ", " : "", (unsigned long long)devReads[k].load()); per += t; }
+        per += "]";
         fprintf(stderr, "[yaha] stats {\"reads\": %llu, \"contexts_up_ms\": %.1f, \"first_batch_written_ms\": %.1f, \"last_batch_written_ms\": %.1f, \"total_ms\": %.1f, "
             "\"steady_reads_per_s\": %.0f, \"cpus\": %d, \"formatters\": %d, \"parsers\": %d, \"gpus\": %d, \"ctx_per_gpu\": %d, \"ctx_left_out\": %d, "
             "\"reads_per_device\": %s, \"context_thread_ms_per_batch\": {\"wait_for_a_batch\": %.2f, \"upload\": %.2f, \"run\": %.2f, \"wait_for_filter_thread\": %.2f, "
