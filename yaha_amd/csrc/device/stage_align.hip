@@ -4,6 +4,7 @@
 #include "ctx.h"
 #include "phase_lanes.h"
 #include "gap_band_lanes.h"
+#include "gap_band_pk.h"
 #include "ext_lanes_pk.h"
 #include "split_lanes.h"
 #include "dp_stage.h"
@@ -20,6 +21,14 @@ static bool extRowsPacked(const ygpu_ctx *ctx, bool caps)
     const DevParams &P = ctx->P;
     return !force32 && !caps && P.MS >= 0 && (long long)P.MS * std::max(1, ctx->maxQ) <= 15000 && P.RC >= 0 && P.GO >= 0 && P.GE >= 0 && P.X >= 0
         && (long long)P.RC + P.X + P.GO + 21ll * P.GE <= 4000;
+}
+
+// banded gap fills in packed 16-bit arithmetic (gap_band_pk.h) when every score of a joint of at most 64 bases fits with room for the sentinel; YGPU_EXT32=1 forces the
+// 32-bit kernels here as it does for the extensions
+static bool gapBandPacked(const ygpu_ctx *ctx)
+{
+    const DevParams &P = ctx->P;
+    return getenv("YGPU_EXT32") == nullptr && getenv("YGPU_GAP32") == nullptr && P.MS >= 0 && P.RC >= 0 && P.GO >= 0 && P.GE >= 0 && 64ll * std::max(P.MS, P.RC) + P.GO + 64ll * P.GE <= 12000;
 }
 
 static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap, int &traceRows)
@@ -76,8 +85,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(J, 64),
             (uint64_t)ctx->nCU * 6);
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
-        KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
-        KL(k_gap_band<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        if (gapBandPacked(ctx)) { KL(k_gap_band_pk<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band_pk<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); }
+        else { KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); }
         KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_wave, dim3(std::min(waves, 512u)), dim3(64), 0, ctx->stream, A, X);
@@ -632,8 +641,8 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(nJ, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(nJ, 64),
             (uint64_t)ctx->nCU * 6);
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
-        KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
-        KL(k_gap_band<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        if (gapBandPacked(ctx)) { KL(k_gap_band_pk<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band_pk<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); }
+        else { KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); }
         KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_wave, dim3(waves), dim3(64), 0, ctx->stream, A, X);
