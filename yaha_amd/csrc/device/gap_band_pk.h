@@ -104,9 +104,11 @@ __device__ __forceinline__ int gapBandPkRows(const DevParams &P, int qGap, int l
                 D[0] = __builtin_amdgcn_perm(X[1], X[0], 0x05040100u);                                          // lo 0 1 2 3
                 D[1] = __builtin_amdgcn_perm(X[0], X[2], 0x07060100u);                                          // lo 4 5, hi 0 1
                 D[2] = __builtin_amdgcn_perm(X[2], X[1], 0x07060302u);                                          // hi 2 3 4 5
-            } else {
-                D[0] = __builtin_amdgcn_perm(X[1], X[0], 0x05040100u); D[1] = __builtin_amdgcn_perm(X[3], X[2], 0x05040100u);      // lo 0 .. 3, lo 4 .. 7
-                D[2] = __builtin_amdgcn_perm(X[1], X[0], 0x07060302u); D[3] = __builtin_amdgcn_perm(X[3], X[2], 0x07060302u);      // hi 0 .. 3, hi 4 .. 7
+            } else {                                                                                            // (H a multiple of four: the low cells' dwords, then the high cells')
+#pragma unroll
+                for (int d = 0; d < RD / 2; d++) {
+                    D[d] = __builtin_amdgcn_perm(X[2 * d + 1], X[2 * d], 0x05040100u); D[RD / 2 + d] = __builtin_amdgcn_perm(X[2 * d + 1], X[2 * d], 0x07060302u);
+                }
             }
 #pragma unroll
             for (int d = 0; d < RD; d++) T32[(t * RD + d) * 64] = D[d];
@@ -139,14 +141,17 @@ template <int GW>
 __global__ void __launch_bounds__(64) k_gap_band_pk(AlignArgs A, PhaseArgs X)
 {
     YD_HIGH_PRIO();
-    static_assert(GW == 12 || GW == 16, "two instances");
+    static_assert(GW == 12 || GW == 16 || GW == 24, "three instances");
     constexpr int H = GW / 2;
     const int lane = laneId(); const DevParams &P = A.P;
     const int bw = P.bandWidth;
     uint32_t *sp = (uint32_t *)(X.gapScratch + (size_t)blockIdx.x * 64u * YD_GAP_SCRATCH) + lane;
     YD_GLOBAL uint32_t *T32 = toGlobal(sp); uint32_t *tmp = sp + (size_t)((YD_GROWS + 1) * 32 / 4) * 64;
     YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
-    const uint32_t tBegin = GW == 12 ? 0u : X.nDPb[0], tEnd = GW == 12 ? X.nDPb[0] : X.nDPb[1];
+    // GW = 12, 16: the joints of class 0 / 1 (gapJointKey: banded, W <= 12 / 16, within the limits).  GW = 24: the joints of the LAST class -- everything wider than 16 --
+    // that are banded with W <= 24 inside the same limits: the order key puts them first in their class (96 % of it on the bench batch; k_gap_lanes<32> ran them at 60
+    // instructions a cell with its strip in LDS), X.nDPb[2] counts them.
+    const uint32_t tBegin = GW == 12 ? 0u : (GW == 16 ? X.nDPb[0] : X.nDP[1]), tEnd = GW == 12 ? X.nDPb[0] : (GW == 16 ? X.nDPb[1] : X.nDP[1] + X.nDPb[2]);
     __shared__ uint32_t sQ[16 * 64], sR[13 * 64];                                                              // the joint's query codes and reference bytes, [dword][lane] (k_gap_band)
     typedef uint32_t yd_u32u __attribute__((aligned(1)));
     for (uint32_t base = tBegin + blockIdx.x * 64u; base < tEnd; base += gridDim.x * 64u) {
@@ -154,6 +159,7 @@ __global__ void __launch_bounds__(64) k_gap_band_pk(AlignArgs A, PhaseArgs X)
         int nT = 0, score = 0; unsigned cells = 0; uint32_t ji = 0;
         JointRec j; j.qGap = 0; j.rGap = 0; j.nsro = 0; j.flags = 0; j.qBase = 0; j.nsqo = 0;
         if (live) { ji = X.sortedVals[t]; j = X.joints[ji]; }
+
         // (wave-uniform: can a run cap bind for any joint of this wave?  an E run spans at most GW - 1 columns, an F run at most qGap rows)
         const bool caps = __ballot(live && ((int)j.qGap > P.maxGap || P.maxIntron < GW)) != 0ull;
         if (live) {

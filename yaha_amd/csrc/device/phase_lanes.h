@@ -45,7 +45,7 @@ struct PhaseArgs {
     uint32_t *memoKeys; unsigned int *memoCount; ExtProb *probs2; unsigned long long *rowsBound2; unsigned int *nProb2; uint32_t probs2Cap;
     // joints
     uint32_t *jointCount; const uint32_t *jointBase; JointRec *joints; uint32_t nJoints;
-    uint32_t *sortKeys, *sortVals; const uint32_t *sortedVals; unsigned int *nDP, *nDPb;
+    uint32_t *sortKeys, *sortVals; const uint32_t *sortedVals; unsigned int *nDP, *nDPb; uint32_t band24;      // band24: k_gap_band_pk<24> runs (see k_gap_lanes)
     uint32_t *gapOps; unsigned int *gapOpsCount; uint32_t gapOpsCap;
     uint32_t *extKeys, *extVals;                        // k_ext_rows takes the problems longest-bound first (keys = 0xFFFF - qLen)
     uint8_t *gapScratch;                                // YD_GAP_SCRATCH bytes per k_gap_lanes thread (trace strip + op list of gapDPLane)
@@ -251,14 +251,20 @@ __device__ __forceinline__ int matchRun(YD_GLOBAL const uint8_t *q, int qi, YD_G
 #define YD_JKEY_NONE 0xFFFu
 #define YD_JKEY_BITS 12
 __host__ __device__ __forceinline__ uint32_t gapJointClass(uint32_t key) { return key >> 10; }
-__device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, bool banded, int qGap, int rGap)
+__host__ __device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, bool banded, int qGap, int rGap)
 {
     const int lenDiff = qGap > rGap ? qGap - rGap : rGap - qGap;
     const int W = banded ? 2 * P.bandWidth + lenDiff + 1 : rGap + 1;
     uint32_t cls = W <= 16 ? 2u : 3u;
-    if (banded && W <= 16 && P.bandWidth >= 5 && P.maxGap >= 16 && qGap <= YD_GROWS && rGap <= YD_GREF) cls = W <= 12 ? 0u : 1u;
-    return (cls << 10) | ((uint32_t)min(W, 31) << 5) | (uint32_t)min(qGap >> 1, 30);      // (0xFFF = class 3, W 31, rows 31 is kept for YD_JKEY_NONE)
+    const bool lim = banded && P.bandWidth >= 5 && P.maxGap >= 16 && qGap <= YD_GROWS && rGap <= YD_GREF;      // what the register-strip band kernels take
+    if (lim && W <= 16) cls = W <= 12 ? 0u : 1u;
+    // the width field: W itself -- except in the last class, where the banded joints of W <= 24 inside the limits come FIRST (0 .. 7 = W - 17: k_gap_band_pk<24>,
+    // gap_band_pk.h) and everything else behind them (8 .. 31)
+    uint32_t wf = (uint32_t)(W < 31 ? W : 31);
+    if (cls == 3u) wf = (lim && W <= 24) ? (uint32_t)(W - 17) : 8u + (uint32_t)(W - 17 < 23 ? W - 17 : 23);
+    return (cls << 10) | (wf << 5) | (uint32_t)((qGap >> 1) < 30 ? (qGap >> 1) : 30);      // (0xFFF = class 3, width 31, rows 31 is kept for YD_JKEY_NONE)
 }
+__host__ __device__ __forceinline__ bool gapJointBand24(uint32_t key) { return (key >> 10) == 3u && ((key >> 5) & 31u) < 8u; }
 
 // lane per root: exact-match extensions of every joint (AlignHelpers.c:216-232), then the gap's kind (AlignExtFrag.cpp:190-231)
 __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
@@ -266,7 +272,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
     YD_HIGH_PRIO();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
-    unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0, nB12 = 0, nB16 = 0;
+    unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0, nB12 = 0, nB16 = 0, nB24 = 0;
     if (live) {
         const ChainClumpRec rec = YD_ROOT_REC(A, r); const int n = (int)rec.nFrags;
         if (n > 1) {
@@ -304,7 +310,7 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
                         if (mm * (P.MS + P.RC) <= P.MS + 2 * (P.GO + P.GE)) { j.kind = JK_DIAG; j.score = P.MS * (qGap - mm) - P.RC * mm; }
                     }
                     if (j.kind == JK_DP) { key = gapJointKey(P, banded, qGap, rGap); const uint32_t cls = gapJointClass(key); nDP++; nDP16 += cls <= 2u; nB12 += cls == 0u;
-                        nB16 += cls <= 1u; }
+                        nB16 += cls <= 1u; nB24 += gapJointBand24(key) ? 1u : 0u; }
                 }
                 X.joints[jb + (uint32_t)(k - 1)] = j; X.sortKeys[jb + (uint32_t)(k - 1)] = key; X.sortVals[jb + (uint32_t)(k - 1)] = jb + (uint32_t)(k - 1);
                 cur = nxt;
@@ -312,14 +318,15 @@ __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
             F[n - 1] = cur;
         }
     }
-    perfect = waveSumU(perfect); touched = waveSumU(touched); nDP = waveSumU(nDP); nDP16 = waveSumU(nDP16); nB12 = waveSumU(nB12); nB16 = waveSumU(nB16);
+    perfect = waveSumU(perfect); touched = waveSumU(touched); nDP = waveSumU(nDP); nDP16 = waveSumU(nDP16); nB12 = waveSumU(nB12); nB16 = waveSumU(nB16); nB24 = waveSumU(nB24);
     { unsigned long long *const dst[2] = {&A.ctr->v[C_PERFECT], &A.ctr->v[C_TOUCHED]}; const unsigned val[2] = {perfect, touched}; blockCounters<2>(dst, val); }
-    { unsigned int *const dst[4] = {X.nDP, X.nDP + 1, X.nDPb, X.nDPb + 1}; const unsigned val[4] = {nDP, nDP16, nB12, nB16}; blockCountersU32<4>(dst, val); }
+    { unsigned int *const dst[5] = {X.nDP, X.nDP + 1, X.nDPb, X.nDPb + 1, X.nDPb + 2}; const unsigned val[5] = {nDP, nDP16, nB12, nB16, nB24}; blockCountersU32<5>(dst, val); }
 }
 
 // lane per DP joint, in size order (key = class, strip width, rows).  Persistent 64-thread blocks.  The sorted joints are [0, nB12) banded with W <= 12 and
 // [nB12, nB16) banded with W <= 16: k_gap_band<12|16> (gap_band_lanes.h);  [nB16, n16) the other W <= 16: the GW = 16 instance of this kernel;  [n16, nDP): GW = 32
-// (X.nDP[0] = nDP, X.nDP[1] = n16, X.nDPb[0] = nB12, X.nDPb[1] = nB16, counted by k_p1_joints).
+// (X.nDP[0] = nDP, X.nDP[1] = n16, X.nDPb[0] = nB12, X.nDPb[1] = nB16, counted by k_p1_joints); with X.band24 the first X.nDPb[2] joints of [n16, nDP) -- banded, W <= 24 --
+// are k_gap_band_pk<24>'s (gap_band_pk.h) and GW = 32 starts behind them.
 template <int GW>
 __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
 {
@@ -331,7 +338,7 @@ __global__ void __launch_bounds__(64) k_gap_lanes(AlignArgs A, PhaseArgs X)
     { uint32_t *sp = (uint32_t *)(X.gapScratch + (size_t)blockIdx.x * 64u * YD_GAP_SCRATCH) + lane; GM.T = (uint8_t *)sp; GM.tmp = sp + (size_t)((YD_GROWS + 1) * 32 / 4) * 64; }
     YD_GLOBAL const uint8_t *gB = toGlobal(A.bases);
     const uint32_t nAll = X.nDP[0], n16 = X.nDP[1];
-    const uint32_t tBegin = GW == 16 ? X.nDPb[1] : n16, tEnd = GW == 16 ? n16 : nAll;
+    const uint32_t tBegin = GW == 16 ? X.nDPb[1] : n16 + (X.band24 ? X.nDPb[2] : 0u), tEnd = GW == 16 ? n16 : nAll;
     for (uint32_t base = tBegin + blockIdx.x * 64u; base < tEnd; base += gridDim.x * 64u) {
         const uint32_t t = base + (uint32_t)lane; const bool live = t < tEnd;
         int nT = 0, score = 0; unsigned cells = 0; bool tooBig = false; uint32_t ji = 0;

@@ -58,7 +58,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->rowsBound.p + nProb, 0, 8, ctx->stream));
     PhaseArgs X; X.state = ctx->rootState.as<RootState>(); X.stateOps = ctx->stateOps.as<uint32_t>(); X.stateOpsCount = cnt + CNT_STATEOPS; X.stateOpsCap = stateOpsCap;
     X.probs = ctx->extProbs.as<ExtProb>(); X.rowsBound = ctx->rowsBound.as<unsigned long long>(); X.res = ctx->extRes.as<ExtRes>(); X.extOps = nullptr; X.rootBegin = 0;
-        X.p3Order = nullptr;
+        X.p3Order = nullptr; X.band24 = 0;
     TRACE("lanes: ensure");
     X.slowList = ctx->slowList.as<uint32_t>(); X.slowCount = cnt + CNT_SLOW; X.useList = 1;
     EV0(T_P1);
@@ -76,7 +76,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     X.joints = ctx->joints.as<JointRec>(); X.nJoints = J; X.sortKeys = ctx->sortKeys.as<uint32_t>(); X.sortVals = ctx->sortVals.as<uint32_t>();
         X.sortedVals = ctx->sortVals2.as<uint32_t>();
     X.nDP = cnt + CNT_NDP; X.nDPb = cnt + CNT_NB12; X.gapOps = ctx->gapOps.as<uint32_t>(); X.gapOpsCount = cnt + CNT_GAPOPS; X.gapOpsCap = gapOpsCap;
-    HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 12, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NB12, 0, 8, ctx->stream));      // ndp, ndp16, gapops; nb12, nb16
+    HIPCHK(hipMemsetAsync(cnt + CNT_NDP, 0, 12, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NB12, 0, 12, ctx->stream));      // ndp, ndp16, gapops; nb12, nb16, nb24
     if (J) {
         KL(k_p1_joints, dim3(gridFor(NC, 256)), dim3(256), 0, ctx->stream, A, X);
         // joints of one (class, width, rows / 2) together
@@ -85,7 +85,11 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(J, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(J, 64),
             (uint64_t)ctx->nCU * 6);
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
-        if (gapBandPacked(ctx)) { KL(k_gap_band_pk<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band_pk<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); }
+        X.band24 = (gapBandPacked(ctx) && !getenv("YGPU_GAP24_OFF")) ? 1u : 0u;
+        if (gapBandPacked(ctx)) {
+            KL(k_gap_band_pk<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band_pk<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+            if (X.band24) KL(k_gap_band_pk<24>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        }
         else { KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); }
         KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
@@ -99,6 +103,18 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
     TRACE("lanes: p1+scan");
     if (kTrace) { uint32_t v[3] = {0, 0, 0}; fetchU32(ctx, cnt + CNT_SLOW, &v[0]); uint32_t w[3] = {0, 0, 0}; fetchU32(ctx, cnt + CNT_NDP, w, 3); v[1] = w[0]; v[2] = w[2];
         fprintf(stderr, "[ygpu] roots %u, joints %u, DP joints %u (W<=16: %u, wave fallback %u), gap ops %u\n", NC, J, v[1], w[1], v[0], v[2]); }
+    if (kTrace && getenv("YGPU_JOINT_HIST")) {      // diagnostics: the DP joints by kernel class and shape (which kernel takes what: gapJointKey)
+        std::vector<JointRec> hj(J); hipMemcpy(hj.data(), ctx->joints.p, sizeof(JointRec) * (size_t)J, hipMemcpyDeviceToHost);
+        unsigned long long nj[4] = {0, 0, 0, 0}, cj[4] = {0, 0, 0, 0}, b3 = 0, b3lim = 0, c3lim = 0, f3 = 0, wh[5] = {0, 0, 0, 0, 0};
+        for (auto &j : hj) if (j.kind == JK_DP) {
+            const bool banded = (j.flags & 2u) != 0; const int q = j.qGap, r = j.rGap, ld = q > r ? q - r : r - q, W = banded ? 2 * ctx->P.bandWidth + ld + 1 : r + 1;
+            const uint32_t cls = gapJointClass(gapJointKey(ctx->P, banded, q, r)); nj[cls]++; cj[cls] += (unsigned long long)q * (unsigned long long)std::min(W, r + 1);
+            if (cls == 3) { if (banded) { b3++; if (W <= 32 && q <= YD_GROWS - 1 && r <= YD_GREF) { b3lim++; c3lim += (unsigned long long)q * W; } } else f3++; wh[std::min(4, (W - 17) / 8)]++; }
+        }
+        fprintf(stderr, "[ygpu] DP joints by class (band <= 12 / band <= 16 / other W <= 16 / the rest): %llu %llu %llu %llu; strip cells %llu %llu %llu %llu; the rest: banded %llu (W <= 32 within "
+                        "the band kernels' limits: %llu, %llu cells), full %llu; W 17-24 / 25-32 / 33-40 / 41-48 / more: %llu %llu %llu %llu %llu\n",
+                nj[0], nj[1], nj[2], nj[3], cj[0], cj[1], cj[2], cj[3], b3, b3lim, c3lim, f3, wh[0], wh[1], wh[2], wh[3], wh[4]);
+    }
     unsigned long long boundBlocks = 0;                                      // sum over the problems of the 10-row blocks each may reach (its row BOUND)
     HIPCHK(hipMemcpyAsync(&boundBlocks, ctx->stripOff.as<unsigned long long>() + nProb, 8, hipMemcpyDeviceToHost, ctx->stream));
     uint32_t ef = 0; rc = fetchU32(ctx, ctx->errFlag.p, &ef); if (rc) return rc;
@@ -622,9 +638,9 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         for (uint32_t k = 0; k < nJ; k++) idx[k] = k;
         // the production path sorts the DP joints by (strip width, rows) as well
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
-        uint32_t nd[3] = {0, 0, 0}, nb[2] = {0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != YD_JKEY_NONE) { const uint32_t cls = gapJointClass(keys[k]); nd[0]++;
-            nd[1] += cls <= 2u; nb[0] += cls == 0u; nb[1] += cls <= 1u; }
-        HIPCHK(hipMemcpyAsync(cnt + CNT_NB12, nb, 8, hipMemcpyHostToDevice, ctx->stream));
+        uint32_t nd[3] = {0, 0, 0}, nb[3] = {0, 0, 0}; for (uint32_t k = 0; k < nJ; k++) if (keys[k] != YD_JKEY_NONE) { const uint32_t cls = gapJointClass(keys[k]); nd[0]++;
+            nd[1] += cls <= 2u; nb[0] += cls == 0u; nb[1] += cls <= 1u; nb[2] += gapJointBand24(keys[k]) ? 1u : 0u; }
+        HIPCHK(hipMemcpyAsync(cnt + CNT_NB12, nb, 12, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->sortVals2.p, idx.data(), 4ull * nJ, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(cnt + CNT_NDP, nd, 12, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemsetAsync(cnt + CNT_SLOW, 0, 4, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_QALIGN, 0, 4, ctx->stream));
@@ -641,7 +657,11 @@ static int dpBatchLanes(ygpu_ctx *ctx, const ygpu_dp_problem *problems, uint32_t
         const unsigned gBlocks16 = (unsigned)std::min<uint64_t>(gridFor(nJ, 64), (uint64_t)ctx->nCU * 9), gBlocks32 = (unsigned)std::min<uint64_t>(gridFor(nJ, 64),
             (uint64_t)ctx->nCU * 6);
         ENSURE(ctx->gapScratch, (size_t)YD_GAP_SCRATCH * 64 * std::max(gBlocks16, gBlocks32)); X.gapScratch = ctx->gapScratch.as<uint8_t>();
-        if (gapBandPacked(ctx)) { KL(k_gap_band_pk<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band_pk<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); }
+        X.band24 = (gapBandPacked(ctx) && !getenv("YGPU_GAP24_OFF")) ? 1u : 0u;
+        if (gapBandPacked(ctx)) {
+            KL(k_gap_band_pk<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band_pk<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+            if (X.band24) KL(k_gap_band_pk<24>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
+        }
         else { KL(k_gap_band<12>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); KL(k_gap_band<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X); }
         KL(k_gap_lanes<16>, dim3(gBlocks16), dim3(64), 0, ctx->stream, A, X);
         KL(k_gap_lanes<32>, dim3(gBlocks32), dim3(64), 0, ctx->stream, A, X);
