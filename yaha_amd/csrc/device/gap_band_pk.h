@@ -65,7 +65,8 @@ __device__ __forceinline__ int gapBandPkRows(const DevParams &P, int qGap, int l
 #pragma unroll
         for (int k = 0; k < H; k++) {
             const uint32_t mm = pkMinU(rc[k] ^ qcPv, ONEv);                                                    // 0 = match, 1 = mismatch = OP_M / OP_R
-            const uint32_t G = pkAdd(PVg[k], pkMad(mm, NEGKv, MSGv));                                           // the diagonal's Vg (the pair's own old value) + (MS + GOE | -RC + GOE)
+            // the diagonal's Vg (the pair's own old value) + (MS + GOE | -RC + GOE)
+            const uint32_t G = pkAdd(PVg[k], pkMad(mm, NEGKv, MSGv));
             // E: the deletion run along the row
             const uint32_t CE = pkSub(PE, GEp), NE = PVCol;
             const uint32_t PD1 = pkAdd(PD, ONEp);
@@ -104,7 +105,8 @@ __device__ __forceinline__ int gapBandPkRows(const DevParams &P, int qGap, int l
                 D[0] = __builtin_amdgcn_perm(X[1], X[0], 0x05040100u);                                          // lo 0 1 2 3
                 D[1] = __builtin_amdgcn_perm(X[0], X[2], 0x07060100u);                                          // lo 4 5, hi 0 1
                 D[2] = __builtin_amdgcn_perm(X[2], X[1], 0x07060302u);                                          // hi 2 3 4 5
-            } else {                                                                                            // (H a multiple of four: the low cells' dwords, then the high cells')
+            // (H a multiple of four: the low cells' dwords, then the high cells')
+            } else {
 #pragma unroll
                 for (int d = 0; d < RD / 2; d++) {
                     D[d] = __builtin_amdgcn_perm(X[2 * d + 1], X[2 * d], 0x05040100u); D[RD / 2 + d] = __builtin_amdgcn_perm(X[2 * d + 1], X[2 * d], 0x07060302u);
@@ -152,7 +154,8 @@ __global__ void __launch_bounds__(64) k_gap_band_pk(AlignArgs A, PhaseArgs X)
     // that are banded with W <= 24 inside the same limits: the order key puts them first in their class (96 % of it on the bench batch; k_gap_lanes<32> ran them at 60
     // instructions a cell with its strip in LDS), X.nDPb[2] counts them.
     const uint32_t tBegin = GW == 12 ? 0u : (GW == 16 ? X.nDPb[0] : X.nDP[1]), tEnd = GW == 12 ? X.nDPb[0] : (GW == 16 ? X.nDPb[1] : X.nDP[1] + X.nDPb[2]);
-    __shared__ uint32_t sQ[16 * 64], sR[13 * 64];                                                              // the joint's query codes and reference bytes, [dword][lane] (k_gap_band)
+    // the joint's query codes and reference bytes, [dword][lane] (k_gap_band)
+    __shared__ uint32_t sQ[16 * 64], sR[13 * 64];
     typedef uint32_t yd_u32u __attribute__((aligned(1)));
     for (uint32_t base = tBegin + blockIdx.x * 64u; base < tEnd; base += gridDim.x * 64u) {
         const uint32_t t = base + (uint32_t)lane; const bool live = t < tEnd;
@@ -181,7 +184,8 @@ __global__ void __launch_bounds__(64) k_gap_band_pk(AlignArgs A, PhaseArgs X)
                 const uint32_t off = j.nsro + (uint32_t)idx, rel = (off >> 1) - rB0; const uint32_t b = (sR[(rel >> 2) * 64 + lane] >> (8u * (rel & 3u))) & 0xFFu;
                 return (off & 1u) ? (b & 15u) : (b >> 4);
             };
-            for (int i = 1; i <= qGap; i++) { int sc = left + 1 - i; if (sc < 0) sc = 0; int ec = left + rGap - i; if (ec > W - 1) ec = W - 1; if (ec >= sc) cells += (unsigned)(ec - sc + 1); }
+            for (int i = 1; i <= qGap; i++) { int sc = left + 1 - i; if (sc < 0) sc = 0; int ec = left + rGap - i; if (ec > W - 1) ec = W - 1;
+                if (ec >= sc) cells += (unsigned)(ec - sc + 1); }
             score = caps ? gapBandPkRows<GW, true>(P, qGap, left, right, W, qAt, refAt, T32) : gapBandPkRows<GW, false>(P, qGap, left, right, W, qAt, refAt, T32);
             // traceback from the end cell (SW.cpp:1138-1195), as k_gap_band's: cell (y, x) is byte x of record y + (x >= H)
             int x = right, y = qGap;

@@ -28,7 +28,8 @@ static bool extRowsPacked(const ygpu_ctx *ctx, bool caps)
 static bool gapBandPacked(const ygpu_ctx *ctx)
 {
     const DevParams &P = ctx->P;
-    return getenv("YGPU_EXT32") == nullptr && getenv("YGPU_GAP32") == nullptr && P.MS >= 0 && P.RC >= 0 && P.GO >= 0 && P.GE >= 0 && 64ll * std::max(P.MS, P.RC) + P.GO + 64ll * P.GE <= 12000;
+    return getenv("YGPU_EXT32") == nullptr && getenv("YGPU_GAP32") == nullptr && P.MS >= 0 && P.RC >= 0 && P.GO >= 0 && P.GE >= 0 && 64ll * std::max(P.MS,
+        P.RC) + P.GO + 64ll * P.GE <= 12000;
 }
 
 static void alignDims(ygpu_ctx *ctx, int &listCap, int &front, int &genCap, int &traceRows)
@@ -109,7 +110,8 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
         for (auto &j : hj) if (j.kind == JK_DP) {
             const bool banded = (j.flags & 2u) != 0; const int q = j.qGap, r = j.rGap, ld = q > r ? q - r : r - q, W = banded ? 2 * ctx->P.bandWidth + ld + 1 : r + 1;
             const uint32_t cls = gapJointClass(gapJointKey(ctx->P, banded, q, r)); nj[cls]++; cj[cls] += (unsigned long long)q * (unsigned long long)std::min(W, r + 1);
-            if (cls == 3) { if (banded) { b3++; if (W <= 32 && q <= YD_GROWS - 1 && r <= YD_GREF) { b3lim++; c3lim += (unsigned long long)q * W; } } else f3++; wh[std::min(4, (W - 17) / 8)]++; }
+            if (cls == 3) { if (banded) { b3++; if (W <= 32 && q <= YD_GROWS - 1 && r <= YD_GREF) { b3lim++; c3lim += (unsigned long long)q * W; } } else f3++;
+                wh[std::min(4, (W - 17) / 8)]++; }
         }
         fprintf(stderr, "[ygpu] DP joints by class (band <= 12 / band <= 16 / other W <= 16 / the rest): %llu %llu %llu %llu; strip cells %llu %llu %llu %llu; the rest: banded %llu (W <= 32 within "
                         "the band kernels' limits: %llu, %llu cells), full %llu; W 17-24 / 25-32 / 33-40 / 41-48 / more: %llu %llu %llu %llu %llu\n",
