@@ -113,8 +113,9 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
             if (cls == 3) { if (banded) { b3++; if (W <= 32 && q <= YD_GROWS - 1 && r <= YD_GREF) { b3lim++; c3lim += (unsigned long long)q * W; } } else f3++;
                 wh[std::min(4, (W - 17) / 8)]++; }
         }
-        fprintf(stderr, "[ygpu] DP joints by class (band <= 12 / band <= 16 / other W <= 16 / the rest): %llu %llu %llu %llu; strip cells %llu %llu %llu %llu; the rest: banded %llu (W <= 32 within "
-                        "the band kernels' limits: %llu, %llu cells), full %llu; W 17-24 / 25-32 / 33-40 / 41-48 / more: %llu %llu %llu %llu %llu\n",
+        fprintf(stderr, "[ygpu] DP joints by class (band <= 12 / band <= 16 / other W <= 16 / the rest): %llu %llu %llu %llu; strip cells %llu %llu %llu %llu; "
+                        "the rest: banded %llu (W <= 32 within the band kernels' limits: %llu, %llu cells), full %llu; "
+                        "W 17-24 / 25-32 / 33-40 / 41-48 / more: %llu %llu %llu %llu %llu\n",
                 nj[0], nj[1], nj[2], nj[3], cj[0], cj[1], cj[2], cj[3], b3, b3lim, c3lim, f3, wh[0], wh[1], wh[2], wh[3], wh[4]);
     }
     unsigned long long boundBlocks = 0;                                      // sum over the problems of the 10-row blocks each may reach (its row BOUND)
