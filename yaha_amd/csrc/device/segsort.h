@@ -16,12 +16,24 @@
 #endif
 // 512 threads x 31 hits: the largest shape that finds room on a CU beside one workgroup of a rows launch (173 registers; x 32: 177, eight too many)
 #define YD_SEGSORT_MAX (512u * YD_SORT_TOP)
+#ifndef YD_SORT_MATCH_BITS
+#define YD_SORT_MATCH_BITS 0           // n > 0: the match ranking with n-bit digits instead of 8 (11: three passes over the 32 diagonal bits instead of four)
+#endif
+#ifndef YD_SORT_BASIC
+#define YD_SORT_BASIC 0                // n > 0: the library's per-thread-counter ranking with n-bit digits (blocked arrangement) instead of its match ranking with 8
+#endif
 
 template <unsigned BS, unsigned IPT>
 __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
 {
     YD_HIGH_PRIO();
+#if YD_SORT_BASIC
+    using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t, 1, 1, YD_SORT_BASIC, rocprim::block_radix_rank_algorithm::basic_memoize>;
+#elif YD_SORT_MATCH_BITS
+    using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t, 1, 1, YD_SORT_MATCH_BITS, rocprim::block_radix_rank_algorithm::match>;
+#else
     using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t>;
+#endif
     __shared__ typename Sort::storage_type st;
     const uint32_t seg = list[blockIdx.x];                                   // the segments of this launch's size class (k_seg_classify)
     const uint32_t b = segB[seg], len = segE[seg] - b;
@@ -33,15 +45,25 @@ __global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, u
     // stable, stay behind real keys with the same bits.
     // What moves through the sort's LDS passes is the 32-bit diagonal with the 15-bit query offset as payload (6 bytes a hit instead of 8).
     uint32_t dg[IPT]; uint16_t qo[IPT];
+#if YD_SORT_BASIC
+    const uint32_t w0 = threadIdx.x * IPT;                                   // blocked arrangement: item k of thread t = t * IPT + k
+    constexpr uint32_t wstep = 1u;
+#else
     const uint32_t w0 = (threadIdx.x >> 6) * (64u * IPT) + (threadIdx.x & 63u);
+    constexpr uint32_t wstep = 64u;
+#endif
 #pragma unroll
     for (unsigned k = 0; k < IPT; k++) {
-        const uint32_t idx = w0 + k * 64u;
+        const uint32_t idx = w0 + k * wstep;
         const unsigned long long key = idx < len ? in[b + idx] : ~0ull;
         dg[k] = (uint32_t)(key >> 15); qo[k] = (uint16_t)(key & 0x7FFFull);
     }
     __syncthreads();
+#if YD_SORT_BASIC
+    Sort().sort_to_striped(dg, qo, st, 0, 32);
+#else
     Sort().sort_warp_striped_to_striped(dg, qo, st, 0, 32);
+#endif
 #pragma unroll
     for (unsigned k = 0; k < IPT; k++) {
         const uint32_t idx = k * BS + threadIdx.x;
