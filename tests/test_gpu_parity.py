@@ -206,7 +206,8 @@ def test_trace_memory_chunks(work, index11, meta, budget, monkeypatch):
         assert mine == golden_lines(name), "chunked trace path differs from the reference on " + name
 
 
-@pytest.mark.parametrize("mode", [("2", "16384"), ("2", "700"), ("2", "3000"), ("2", "64"), ("2", "16384", "0")])
+@pytest.mark.parametrize("mode", [("2", "16384"), ("2", "700"), ("2", "3000"), ("2", "64"), ("2", "16384", "0"), ("2", "16384", "1", "ballots"), ("2", "700", "0", "ballots"),
+                                  ("2", "3000", "1", "atomic")])
 def test_hit_sort_paths(work, index11, meta, mode, monkeypatch):
     # A2's sort: one workgroup per (read, strand) in size classes; segments above YGPU_SEGSORT_MAX hits are cut by diagonal, and a piece that still does not fit is cut
     # again over its own range of diagonals until it fits or holds one diagonal -- the limit is lowered here so that the 10 kbp reads' segments take every class, the
@@ -216,6 +217,8 @@ def test_hit_sort_paths(work, index11, meta, mode, monkeypatch):
         monkeypatch.setenv("YGPU_SEGSORT_MAX", mode[1])
     if len(mode) > 2:
         monkeypatch.setenv("YGPU_SORT_WIDE", mode[2])         # 0: the four largest classes in their 1 024-thread shapes (the default since round 5: 512 threads, twice the hits a thread)
+    if len(mode) > 3:
+        monkeypatch.setenv("YGPU_SORT_RANK", mode[3])         # the workgroup sort's ranking (wgsort.h): LDS atomics (the default; "atomic": no fallback) or ballots
     for name in ("r10k_default", "r1k_default"):
         run = meta["runs"][name]
         mine = device_pipeline(index11, os.path.join(work, run["reads"]), run["oflag"], run["extra"], batch=400)
@@ -288,6 +291,22 @@ def test_cli_on_a_version_1_nib2(work, tmp_path):
     idx1 = nib2_v1_copy(work, str(tmp_path / "v1")); out = str(tmp_path / "o.sam")
     subprocess.check_call([ya.CLI_PATH, "-x", idx1, "-q", os.path.join(work, "rchim.fa"), "-osh", out], stderr=subprocess.DEVNULL)
     assert strip_pg(open(out).read()) == golden_lines("rchim_default")
+
+
+def test_a_failed_order_check_behind_the_sort_falls_back_to_the_ballots(work, index11, tmp_path):
+    """The workgroup sort ranks with LDS atomics, whose lane order no manual promises; k_frag_scan_build checks every batch's keys against their predecessors, and a
+    batch that fails is sorted again with the ranking by ballots, which the process then keeps (stage_seed.hip).  YGPU_SORT_CHECK_INJECT=1 fails the first check: the
+    run says so once, and its SAM is the reference's; with YGPU_SORT_RANK=atomic there is no fallback, and nothing is injected."""
+    out = str(tmp_path / "o.sam"); ref = golden_lines("rchim_FBS")
+    cmd = [ya.CLI_PATH, "-x", index11, "-q", os.path.join(work, "rchim.fa"), "-oss", out, "-FBS", "Y", "-ctx", "2", "-batch", "50"]
+    p = subprocess.run(cmd, stderr=subprocess.PIPE, env=dict(os.environ, YGPU_SORT_CHECK_INJECT="1"))
+    assert p.returncode == 0, p.stderr.decode()[-1500:]
+    assert p.stderr.decode().count("stays with the ranking by ballots") == 1
+    assert strip_pg(open(out).read()) == ref
+    p = subprocess.run(cmd, stderr=subprocess.PIPE, env=dict(os.environ, YGPU_SORT_CHECK_INJECT="1", YGPU_SORT_RANK="atomic"))
+    assert p.returncode == 0 and b"ballots" not in p.stderr and strip_pg(open(out).read()) == ref
+    p = subprocess.run(cmd, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"ballots" not in p.stderr and strip_pg(open(out).read()) == ref
 
 
 def test_cli_small_batches_many_times(work, index11, tmp_path):
@@ -630,7 +649,9 @@ def test_real_human_sequence_command_line_equals_the_reference(tmp_path):
 def test_own_sums_and_orderings(work, index11, n, bits):
     """device/scan.h -- the exclusive sums (single pass, decoupled look-back, u32 and u64, in place) and the orderings by a small key that lay out the batch's
     variable-size outputs -- against plain host loops: tile edges (a tile is 512 threads x 48 u32 = 24 576 elements, 12 288 of u64; an ordering's 8 192), one element, tens of millions (1 343 tiles), sums beyond 2^32, keys with an
-    offset and a shift, crowded buckets; every call twice over the same work words (they clean themselves up)."""
+    offset and a shift, crowded buckets; every call twice over the same work words (they clean themselves up).  The same call runs A2's workgroup sort (device/wgsort.h) in
+    five shapes and both rankings -- LDS atomics and ballots -- over segments of every fill and of diagonals made to tie (one value, two alternating lane by lane, equal
+    inside a row, crowded neighbourhoods) against std::stable_sort, and wants the sort's own order check silent."""
     with ya.Session(["-x", index11, "-q", os.path.join(work, "r1k.fa")]) as s:
         with ya.Context(s.index, s.params) as c:
             for seed in (1, 2):

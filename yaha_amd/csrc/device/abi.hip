@@ -19,7 +19,16 @@ int runTo(ygpu_ctx *ctx, int stage)
 {
     int rc;
     HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->stageDone < 1) { rc = stageSeed(ctx); if (rc) return rc; EV0(T_FRAGS); rc = buildFrags(ctx); if (rc) return rc; if (!ctx->nFrags) EV1(T_FRAGS); ctx->stageDone = 1; }
+    if (ctx->stageDone < 1) {
+        rc = stageSeed(ctx); if (rc) return rc;
+        EV0(T_FRAGS); rc = buildFrags(ctx);
+        // (the order check behind the sort failed with the ranking by LDS atomics: once more from the k-mers, now -- and from now on -- with the ballots; wgsort.h)
+        if (rc == YD_RESORT) { rc = stageSeed(ctx); if (rc) return rc; EV0(T_FRAGS); rc = buildFrags(ctx);
+            if (rc == YD_RESORT) { ctx->err = "hit sort: the sorted keys are not in ascending order"; rc = YGPU_EINTERNAL; } }
+        if (rc) return rc;
+        if (!ctx->nFrags) EV1(T_FRAGS);
+        ctx->stageDone = 1;
+    }
     if (stage >= 2 && ctx->stageDone < 2) { if (ctx->nFrags) { rc = stageChain(ctx); if (rc) return rc; } ctx->stageDone = 2; }
     if (stage >= 3 && ctx->stageDone < 3) { rc = stageAlign(ctx); if (rc) return rc; ctx->stageDone = 3; }
     // (the stream is drained by this fetch: the flag a look-back of scan.h raises when a tile never showed up -- the state words are then made clean again)
@@ -578,6 +587,7 @@ int ygpu_selftest_primitives(ygpu_ctx *ctx, uint32_t n, uint32_t seed, int key_b
         const uint32_t bk = std::min((h32[v] - sub) >> shift, nb - 1u); if (bk < last) return fail("the second ordering (buckets not ascending)", i); last = bk; } }
     uint32_t sf = 0; rc = fetchU32(ctx, ctx->counters.as<uint32_t>() + CNT_SCANFAIL, &sf); if (rc) return rc;
     if (sf) { ctx->err = "selftest: a look-back gave up"; return YGPU_EINTERNAL; }
+    rc = ydSelftestSegSort(ctx, x); if (rc) return rc;
     return ydSelftestWaveSort(ctx, seed, x);
 }
 }  // extern "C"

@@ -80,8 +80,8 @@ enum {
     CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG,
     CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_NSMALL, CNT_NB12, CNT_NB16, CNT_NB24,
     CNT_SEGC,                            // YD_SEG_NCLASS + 1 words: the segments of the workgroup-sort classes, the long ones
-    CNT_NFRAGS = CNT_SEGC + 16,          // + the look-back's flag
-    CNT_NREG = CNT_NFRAGS + 2,           // + flag
+    CNT_NFRAGS = CNT_SEGC + 16,          // + the look-back's flag + the order check's (seed.h: a key that is not above its predecessor)
+    CNT_NREG = CNT_NFRAGS + 3,           // + flag
     CNT_SCANFAIL = CNT_NREG + 2,         // raised by a look-back of scan.h that gave up
     CNT_N = CNT_NREG + 4
 };
@@ -189,6 +189,8 @@ struct ygpu_ctx {
     uint32_t hOutCounts[2] = {0, 0}, hOutEf = 0;
     bool hOutValid = false;
     uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nBig = 0, maxN = 0;
+    int sortRankUsed = 0;                // the ranking the batch's hits were sorted with (stage_seed.hip: 0 = LDS atomics, 1 = ballots)
+    bool sortRankForced = false;         // ... because YGPU_SORT_RANK said so
     uint32_t nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;
     int stageDone = 0;     // 0 none, 1 fragments, 2 chain, 3 all
     // host results
@@ -287,6 +289,9 @@ enum { kBucketMax = 4096 };                                   // buckets of an o
 
 // ---- the stages (runTo in abi.hip drives them) -------------------------------------------------------------------------------------------------------------
 int stageSeed(ygpu_ctx *ctx);                                 // stage_seed.hip: A1 + A2
+int ydSortRank();                                             //                 the ranking the workgroup sort uses now: 0 = LDS atomics, 1 = ballots
+// buildFrags: the keys were not in order behind the atomic ranking; the caller runs stageSeed again (never leaves the library)
+enum { YD_RESORT = 1000 };
 int buildFrags(ygpu_ctx *ctx, bool redo = false);             //                 the fragment array from the sorted keys (redo: the regions stand, the records are rebuilt)
 int uploadBatch(ygpu_ctx *ctx, const ygpu_read_batch *b, bool wait);
 int ydLowOffsets(ygpu_ctx *ctx, const ygpu_index_view *ix);   //                 the bit table of k_kmer_lookup (once per image)
@@ -296,6 +301,7 @@ size_t ydLowTableBytes();
 int stageChain(ygpu_ctx *ctx);                                // stage_chain.hip: A3 + A4
 int stageAlign(ygpu_ctx *ctx);                                // stage_align.hip: A5..A8, layout
 int runTo(ygpu_ctx *ctx, int stage);                          // abi.hip
+int ydSelftestSegSort(ygpu_ctx *ctx, uint64_t &x);                    // stage_seed.hip: the workgroup sort of A2, both rankings, against std::stable_sort
 int ydSelftestWaveSort(ygpu_ctx *ctx, uint32_t seed, uint64_t &x);      // stage_out.hip: the post-filter's sort on the wave against the one-thread routine
 std::vector<DevBuf *> allBuffers(ygpu_ctx *ctx);              // abi.hip: every device buffer of a context, in the order of the arena profile
 extern thread_local const ygpu_ctx *tlsPfFailed;              // the context whose post-filter side failed last on this thread: ygpu_last_error then reports that side's message

@@ -8,67 +8,43 @@
 // diagonals (k_seg_split_range), level by level, until every piece fits or holds a single diagonal (then it is in order as it stands: the cuts are stable).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rocprim/block/block_radix_sort.hpp>
 #include <cstdint>
+#include "wgsort.h"
 
 #ifndef YD_SORT_TOP
 #define YD_SORT_TOP 31                 // hits a thread of the largest class (512 threads)
 #endif
-// 512 threads x 31 hits: the largest shape that finds room on a CU beside one workgroup of a rows launch (173 registers; x 32: 177, eight too many)
+// 512 threads x 31 hits: 62 KB of LDS for the diagonals -- the most a workgroup may have -- and two registers a hit
 #define YD_SEGSORT_MAX (512u * YD_SORT_TOP)
-#ifndef YD_SORT_MATCH_BITS
-#define YD_SORT_MATCH_BITS 0           // n > 0: the match ranking with n-bit digits instead of 8 (11: three passes over the 32 diagonal bits instead of four)
-#endif
-#ifndef YD_SORT_BASIC
-#define YD_SORT_BASIC 0                // n > 0: the library's per-thread-counter ranking with n-bit digits (blocked arrangement) instead of its match ranking with 8
-#endif
 
-template <unsigned BS, unsigned IPT>
-__global__ void __launch_bounds__(BS) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segB, const uint32_t *segE, const uint32_t *list)
+// One workgroup sorts one segment (wgsort.h: four 8-bit passes over LDS, this file's only dependency).  ATOMIC: the ranking of a pass by LDS atomics (the default) or by
+// ballots (the fallback that needs nothing the manuals do not promise; stage_seed.hip switches to it for good when the order check of k_frag_scan_build ever fails).
+// (four waves a SIMD: two workgroups of 512 threads a CU -- 128 registers, which two registers a hit leave room for)
+template <unsigned BS, unsigned IPT, bool ATOMIC>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4))) k_seg_sort(const unsigned long long *in, unsigned long long *out, const uint32_t *segB,
+                                                                                         const uint32_t *segE, const uint32_t *list, unsigned int *outOfOrder)
 {
     YD_HIGH_PRIO();
-#if YD_SORT_BASIC
-    using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t, 1, 1, YD_SORT_BASIC, rocprim::block_radix_rank_algorithm::basic_memoize>;
-#elif YD_SORT_MATCH_BITS
-    using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t, 1, 1, YD_SORT_MATCH_BITS, rocprim::block_radix_rank_algorithm::match>;
-#else
-    using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint16_t>;
-#endif
-    __shared__ typename Sort::storage_type st;
+    using Sort = WgSort<BS, IPT, ATOMIC>;
+    __shared__ typename Sort::Storage st;
     const uint32_t seg = list[blockIdx.x];                                   // the segments of this launch's size class (k_seg_classify)
     const uint32_t b = segB[seg], len = segE[seg] - b;
-    const unsigned long long rs = in[b] & ~((1ull << 47) - 1ull);            // the (read, strand) bits: the same in every key of a segment
-    // The library's ranking works on a wave-striped arrangement (wave w holds the items [w * 64 * IPT, (w + 1) * 64 * IPT), item k of lane l = k * 64 + l of
-    // them) and can leave the result striped over the workgroup (item k of thread t = k * BS + t): both are what coalesced loads and stores give, so the keys
-    // go from HBM to registers to HBM without the two transpositions through LDS that the blocked arrangement needs (in == out is fine: the workgroup has
-    // read its whole segment before it stores).  The order of the hits = the index in that arrangement; the padding keys sort last and, the sort being
-    // stable, stay behind real keys with the same bits.
-    // What moves through the sort's LDS passes is the 32-bit diagonal with the 15-bit query offset as payload (6 bytes a hit instead of 8).
-    uint32_t dg[IPT]; uint16_t qo[IPT];
-#if YD_SORT_BASIC
-    const uint32_t w0 = threadIdx.x * IPT;                                   // blocked arrangement: item k of thread t = t * IPT + k
-    constexpr uint32_t wstep = 1u;
-#else
+    // the (read, strand) bits [47, 64): the same in every key of a segment (a scalar)
+    const uint32_t rsHi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(in[b] >> 32)) & 0xFFFF8000u;
+    // HBM -> registers (wave-striped: coalesced) -> four digit passes over LDS -> HBM (striped over the workgroup: coalesced); in == out is fine: the workgroup has read
+    // its whole segment before it stores.  What moves through LDS is the 32-bit diagonal with the 15-bit query offset as payload (6 bytes a hit).
+    uint32_t dg[IPT], qo[IPT];
     const uint32_t w0 = (threadIdx.x >> 6) * (64u * IPT) + (threadIdx.x & 63u);
-    constexpr uint32_t wstep = 64u;
-#endif
 #pragma unroll
     for (unsigned k = 0; k < IPT; k++) {
-        const uint32_t idx = w0 + k * wstep;
-        const unsigned long long key = idx < len ? in[b + idx] : ~0ull;
-        dg[k] = (uint32_t)(key >> 15); qo[k] = (uint16_t)(key & 0x7FFFull);
+        const uint32_t idx = w0 + k * 64u;
+        const unsigned long long key = idx < len ? in[b + idx] : 0ull;
+        dg[k] = (uint32_t)(key >> 15); qo[k] = (uint32_t)(key & 0x7FFFull);
     }
-    __syncthreads();
-#if YD_SORT_BASIC
-    Sort().sort_to_striped(dg, qo, st, 0, 32);
-#else
-    Sort().sort_warp_striped_to_striped(dg, qo, st, 0, 32);
-#endif
-#pragma unroll
-    for (unsigned k = 0; k < IPT; k++) {
-        const uint32_t idx = k * BS + threadIdx.x;
-        if (idx < len) out[b + idx] = rs | ((unsigned long long)dg[k] << 15) | (unsigned long long)qo[k];
-    }
+    bool bad = false;
+    Sort::sort(dg, qo, len, st, [&](uint32_t pos, uint32_t d, uint32_t q) { out[b + pos] = ((unsigned long long)(rsHi | (d >> 17)) << 32) | (unsigned long long)((d << 15) | q); },
+        bad);
+    if (ATOMIC && bad) atomicOr(outOfOrder, 1u);
 }
 
 // Size classes of the segments [segB[s], segE[s]): class c (0..YD_SEG_NCLASS-1) = at most hi[c] hits -> lists[c] (the workgroup sorts above: one launch per class

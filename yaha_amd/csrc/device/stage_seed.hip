@@ -20,6 +20,18 @@ __global__ void k_touch(unsigned int *p) { if (p && threadIdx.x == 1000) *p = 0;
 int ydFirstLaunch(ygpu_ctx *ctx) { KL(k_touch, dim3(1), dim3(64), 0, ctx->stream, (unsigned int *)nullptr); return 0; }
 
 // ---- A1 + A2 (+ fragment array) --------------------------------------------------------------------------------
+// The ranking of the workgroup sort's passes (wgsort.h): 0 = LDS atomics, 1 = ballots.  Atomics are the default; their stability rests on the order in which the LDS
+// serves the lanes of one instruction, so every batch's keys are checked by k_frag_scan_build, and the first batch that fails the check switches the process to the
+// ballots for good (buildFrags below; the batch is sorted again).  YGPU_SORT_RANK=ballots | atomic (read at every batch) overrides both the default and the switch -- with
+// "atomic" a failed check is an error; YGPU_SORT_CHECK_INJECT=1 makes the check of the process' first batch sorted with atomics fail (the tests' way into the fallback).
+static std::atomic<int> gSortFell{0}, gSortInject{-1};
+static int sortRank(bool *forced = nullptr)
+{
+    const char *e = getenv("YGPU_SORT_RANK"); const bool b = e && (e[0] == 'b' || e[0] == 'B'), a = e && (e[0] == 'a' || e[0] == 'A');
+    if (forced) *forced = a || b;
+    return b ? 1 : (a ? 0 : gSortFell.load());
+}
+int ydSortRank() { return sortRank(); }
 // maxGap for the dead-single test of seed.h, or -1: every fragment is kept (the fragments themselves are asked for, or one word can be a whole match)
 static int fragDropGap(const ygpu_ctx *ctx) { return (ctx->keepAllFrags || ctx->P.wordLen >= ctx->P.minMatch) ? -1 : ctx->P.maxGap; }
 int stageSeed(ygpu_ctx *ctx)
@@ -45,6 +57,7 @@ int stageSeed(ygpu_ctx *ctx)
     if (H == 0) return 0;
     if (H > 0x7FFFFFF0u) { ctx->err = "too many seed hits in one batch; use a smaller batch"; return YGPU_EOVERFLOW; }
     EV0(T_SORT);
+    ctx->sortRankUsed = sortRank(&ctx->sortRankForced);
     ENSURE(ctx->keysA, 8ull * H); ENSURE(ctx->keysB, 8ull * H);
     ENSURE(ctx->expandStart, 4ull * (gridFor(H, YD_EXPAND_HITS) + 1));
     KL(k_expand_starts, dim3(gridFor(K, 256)), dim3(256), 0, ctx->stream, ctx->hitOff.as<uint32_t>(), K, ctx->expandStart.as<uint32_t>());
@@ -78,8 +91,12 @@ int stageSeed(ygpu_ctx *ctx)
                 // one launch per class over exactly its segments: in[inB..inE) sorted into out[inB..)
                 auto sortClasses = [&](const unsigned long long *src, unsigned long long *dst, const uint32_t *sB, const uint32_t *sE, uint32_t nSeg, const uint32_t *lists,
                     const uint32_t *nc) -> int {
-#define YD_SORT_CLASS(c, BS, IPT) if (nc[c]) KL((k_seg_sort<BS, IPT>), dim3(nc[c]), dim3(BS), 0, ctx->stream, src, dst, sB, sE, lists + (size_t)(c) * nSeg)
+#define YD_SORT_CLASS(c, BS, IPT) if (nc[c]) { const uint32_t *cl = lists + (size_t)(c) * nSeg; \
+                    if (byBallots) KL((k_seg_sort<BS, IPT, false>), dim3(nc[c]), dim3(BS), 0, ctx->stream, src, dst, sB, sE, cl, ooo); \
+                    else KL((k_seg_sort<BS, IPT, true>), dim3(nc[c]), dim3(BS), 0, ctx->stream, src, dst, sB, sE, cl, ooo); }
                     const char *ws = getenv("YGPU_SORT_WIDE"); const int wideShapes = ws ? atoi(ws) : 1;      // (read at every call: the tests run both)
+                    const bool byBallots = ctx->sortRankUsed == 1;
+                    unsigned int *ooo = ctx->counters.as<unsigned int>() + CNT_NFRAGS + 2;      // raised by the sort's order check, read with the fragment count (buildFrags)
                     if (wideShapes) { YD_SORT_CLASS(11, 512, YD_SORT_TOP); YD_SORT_CLASS(10, 512, 28); YD_SORT_CLASS(9, 512, 24); YD_SORT_CLASS(8, 512, 20); }
                     else { YD_SORT_CLASS(11, 1024, 16); YD_SORT_CLASS(10, 1024, 14); YD_SORT_CLASS(9, 1024, 12); YD_SORT_CLASS(8, 1024, 10); }
                     YD_SORT_CLASS(7, 512, 16);
@@ -142,6 +159,75 @@ int stageSeed(ygpu_ctx *ctx)
     EV1(T_SORT);
     return 0;
 }
+// The workgroup sort against std::stable_sort on the host, both rankings, four shapes: segments of every fill (one hit, a partial last row, full), diagonals that are
+// random, all equal, two values alternating lane by lane, equal inside a row and in runs across rows (what the lane order of the LDS atomics has to get right),
+// query offsets ascending in input order.  (ygpu_selftest_primitives)
+template <unsigned BS, unsigned IPT>
+static int selftestSegSortShape(ygpu_ctx *ctx, uint64_t &x, char *why, size_t whyLen)
+{
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    constexpr uint32_t N = BS * IPT; const uint32_t nSeg = 24;
+    std::vector<uint32_t> segB(nSeg), segE(nSeg), list(nSeg); std::vector<unsigned long long> keys;
+    for (uint32_t sI = 0; sI < nSeg; sI++) {
+        const uint32_t pat = sI % 6u;
+        uint32_t len = sI == 0 ? 1u : (sI == 1 ? N : (sI == 2 ? N - 63u : (sI == 3 ? 65u : 1u + (uint32_t)(rnd() % N))));
+        segB[sI] = (uint32_t)keys.size(); list[sI] = sI;
+        const uint32_t base = (uint32_t)rnd(), alt = (uint32_t)rnd();
+        for (uint32_t i = 0; i < len; i++) {
+            uint32_t d;
+            switch (pat) {
+            case 0: d = (uint32_t)rnd(); break;                                               // random
+            case 1: d = base; break;                                                          // one diagonal
+            case 2: d = (i & 1u) ? base : alt; break;                                         // two values, lane by lane
+            case 3: d = base + ((i / 64u) % 3u) * 0x01010101u; break;                          // equal inside a row, three values over the rows
+            case 4: d = (rnd() % 4u) ? base + (uint32_t)(rnd() % 5u) : (uint32_t)rnd(); break;  // a crowded neighbourhood and scattered singles
+            default: d = base ^ ((uint32_t)(rnd() % 3u) << (8u * (uint32_t)(rnd() % 4u))); break; // ties in three of the four digits
+            }
+            keys.push_back(((unsigned long long)(sI & 0x1FFFFu) << 47) | ((unsigned long long)d << 15) | (unsigned long long)(i & 0x7FFFu));
+        }
+        segE[sI] = (uint32_t)keys.size();
+    }
+    std::vector<unsigned long long> want(keys);
+    for (uint32_t sI = 0; sI < nSeg; sI++)
+        std::stable_sort(want.begin() + segB[sI], want.begin() + segE[sI], [](unsigned long long a, unsigned long long b) { return (uint32_t)(a >> 15) < (uint32_t)(b >> 15); });
+    DevBuf in, out, meta; struct Rel { DevBuf &a, &b, &c; ~Rel() { a.release(); b.release(); c.release(); } } rel{in, out, meta};
+    if (in.ensure(8ull * keys.size() + 64) || out.ensure(8ull * keys.size() + 64) || meta.ensure(16ull * nSeg + 64)) { ctx->err = "hipMalloc failed"; return YGPU_ENOMEM; }
+    HIPCHK(hipMemcpyAsync(in.p, keys.data(), 8ull * keys.size(), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *m = meta.as<uint32_t>();
+    HIPCHK(hipMemcpyAsync(m, segB.data(), 4ull * nSeg, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(m + nSeg, segE.data(), 4ull * nSeg, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(m + 2 * nSeg, list.data(), 4ull * nSeg, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<unsigned long long> got(keys.size());
+    for (int ballots = 0; ballots < 2; ballots++) {
+        HIPCHK(hipMemsetAsync(out.p, 0xFF, 8ull * keys.size(), ctx->stream)); HIPCHK(hipMemsetAsync(m + 3 * nSeg, 0, 4, ctx->stream));
+        if (ballots) KL((k_seg_sort<BS, IPT, false>), dim3(nSeg), dim3(BS), 0, ctx->stream, in.as<unsigned long long>(), out.as<unsigned long long>(), m, m + nSeg, m + 2 * nSeg,
+            m + 3 * nSeg);
+        else KL((k_seg_sort<BS, IPT, true>), dim3(nSeg), dim3(BS), 0, ctx->stream, in.as<unsigned long long>(), out.as<unsigned long long>(), m, m + nSeg, m + 2 * nSeg,
+            m + 3 * nSeg);
+        uint32_t flag = 0; HIPCHK(hipMemcpyAsync(&flag, m + 3 * nSeg, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(got.data(), out.p, 8ull * keys.size(), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(streamSync(ctx));
+        for (size_t i = 0; i < keys.size(); i++) if (got[i] != want[i]) {
+            uint32_t sI = 0; while (sI + 1 < nSeg && segB[sI + 1] <= i) sI++;
+            snprintf(why, whyLen, "selftest: the workgroup sort (%u threads x %u, ranking by %s) differs from a stable sort at hit %zu of segment %u (pattern %u, %u hits)", BS,
+                IPT,
+                     ballots ? "ballots" : "LDS atomics", i - segB[sI], sI, sI % 6u, segE[sI] - segB[sI]);
+            ctx->err = why; return YGPU_EINTERNAL;
+        }
+        if (flag) { snprintf(why, whyLen, "selftest: the workgroup sort (%u threads x %u) raised its order check on keys that came out in order", BS, IPT); ctx->err = why;
+            return YGPU_EINTERNAL; }
+    }
+    return 0;
+}
+int ydSelftestSegSort(ygpu_ctx *ctx, uint64_t &x)
+{
+    static thread_local char why[256]; int rc;
+    rc = selftestSegSortShape<128, 8>(ctx, x, why, sizeof why); if (rc) return rc;
+    rc = selftestSegSortShape<256, 16>(ctx, x, why, sizeof why); if (rc) return rc;
+    rc = selftestSegSortShape<512, 20>(ctx, x, why, sizeof why); if (rc) return rc;
+    rc = selftestSegSortShape<512, YD_SORT_TOP>(ctx, x, why, sizeof why); if (rc) return rc;
+    return selftestSegSortShape<1024, 16>(ctx, x, why, sizeof why);
+}
+
 // (Re)creates the fragment array from the sorted keys -- the chain stage trims it in place, so a redo of that stage comes back here.  One kernel (seed.h:
 // k_frag_scan_build) counts and writes; the array is sized from the last batch's count, and a batch that needs more is run again with room (the first batch of
 // a context always is: its first pass only counts).
@@ -162,8 +248,23 @@ int buildFrags(ygpu_ctx *ctx, bool redo)      // redo: the regions stand, only t
         KL(k_frag_scan_build, dim3(nTiles), dim3(YD_FRAG_BS), 0, ctx->stream, ctx->keysB.as<unsigned long long>(), H, ctx->P.wordLen, fragDropGap(ctx), ctx->frags.as<DevFrag>(),
             cap,
            ctx->tileState.as<unsigned long long>(), total, ctx->kmerParts.as<unsigned int>());
-        uint32_t two[2] = {0, 0}; int rc = fetchU32(ctx, total, two, 2); if (rc) return rc;
+        uint32_t two[3] = {0, 0, 0}; int rc = fetchU32(ctx, total, two, 3); if (rc) return rc;
         if (two[1]) { ctx->err = "fragment scan: a tile was not published within 30 s (look-back gave up)"; return YGPU_EINTERNAL; }
+        if (!redo && ctx->sortRankUsed == 0 && !ctx->sortRankForced) {
+            if (gSortInject.load() < 0) { const char *e = getenv("YGPU_SORT_CHECK_INJECT"); gSortInject.store(e && atoi(e) ? 1 : 0); }
+            int one = 1; if (gSortInject.compare_exchange_strong(one, 0)) two[2] = 1;
+        }
+        if (two[2]) {
+            // (the words of the look-back are clean again -- every tile was published and read --, the count is not used)
+            HIPCHK(hipMemsetAsync(total, 0, 12, ctx->stream));
+            if (ctx->sortRankUsed == 0 && !ctx->sortRankForced && !redo) {
+                if (gSortFell.exchange(1) != 1)
+                    fprintf(stderr, "[ygpu] hit sort: keys out of order behind the ranking by LDS atomics; this batch is sorted again and the process "
+                                    "stays with the ranking by ballots\n");
+                return YD_RESORT;
+            }
+            ctx->err = "hit sort: the sorted keys are not in ascending order"; return YGPU_EINTERNAL;
+        }
         const uint32_t F = two[0];
         if (F <= cap) { ctx->nFrags = F; break; }
         if (pass >= 2) { ctx->err = "fragment build: the count changed between passes"; return YGPU_EINTERNAL; }
