@@ -284,7 +284,9 @@ def cpu_baseline(idx, fa, reads_path, n_reads, cache, target_s, read_len, div):
         head_reads(reads_path, probe, n_probe)
         t = time.time(); oracle.run_reference(["-x", idx, "-q", probe, "-osh", "/dev/null", "-t", str(2 * q)]); t_probe = max(time.time() - t - t_zero, 1e-3)
         threads = sorted(set(min(t, cores) for t in (q, 2 * q, 4 * q)))
-        n = int(min(262144, max(n_probe, (target_s / len(threads)) * n_probe / t_probe)))
+        # (the probe's rate is capped at 250 reads/s a usable CPU -- twice what the reference reaches on this workload: a probe that came out too fast, its one-read
+        # run having paid for the index's page-in, once sized the sample for ten minutes of reference runs)
+        n = int(min(262144, max(n_probe, (target_s / len(threads)) * min(n_probe / t_probe, 250.0 * q))))
         n = (n + 1023) // 1024 * 1024
         sample = make_reads(cache, fa, "cpu", n, read_len, div, 4000)
         by_t = {}
