@@ -177,18 +177,6 @@ __global__ void k_seg_offsets(const uint32_t *kmerOff, const uint32_t *hitOff, u
 // is dead on arrival, and on a large genome these chance hits are most fragments (3.1 Gbp: 128 M fragments a batch, ~100 M of them dead): they are counted
 // and not written.  Dropping them changes nothing for the others: the diagonals are sorted, so the fragments on either side of a dropped run are further
 // apart than the dropped fragment was from them -- every region boundary stays where it was.  maxGapDrop < 0: keep every fragment (ygpu_seed_join).
-// head / last / dead of a hit from its two neighbours in the sorted order, without branches (bit 0 head, bit 1 last hit of its fragment, bit 2 dead single)
-__device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned long long b, unsigned long long c, bool first, bool end, int wordLen, int maxGapDrop)
-{
-    const uint32_t qa = (uint32_t)(a & 0x7FFFu), qb = (uint32_t)(b & 0x7FFFu), qc = (uint32_t)(c & 0x7FFFu);
-    const uint32_t da = (uint32_t)(a >> 15), db = (uint32_t)(b >> 15), dc = (uint32_t)(c >> 15);
-    const bool sameA = (uint32_t)(a >> 47) == (uint32_t)(b >> 47), sameC = (uint32_t)(c >> 47) == (uint32_t)(b >> 47);
-    const bool head = first | !sameA | (da != db) | (qb > qa + (uint32_t)wordLen);
-    const bool last = end | !sameC | (dc != db) | (qc > qb + (uint32_t)wordLen);
-    const bool nearA = !first & sameA & (absDiffU(da, db) <= (uint32_t)maxGapDrop), nearC = !end & sameC & (absDiffU(dc, db) <= (uint32_t)maxGapDrop);
-    const bool dead = (maxGapDrop >= 0) & head & last & !nearA & !nearC;
-    return (head ? 1u : 0u) | (last ? 2u : 0u) | (dead ? 4u : 0u);
-}
 // A2b in one pass over the sorted keys: head flags, their batch-wide exclusive scan (= the fragment index of every hit) and the fragment records.  A workgroup
 // of 16 waves owns a tile of 8 192 consecutive hits, each of its waves 8 rows of 64: a hit's neighbours are in the neighbouring lanes (or the edge lanes of the
 // rows above and below), the rank of a head inside the tile comes from the ballots of the 16 x 8 (wave, row) groups -- their 128 counts scanned by one wave, two
@@ -205,46 +193,79 @@ __device__ __forceinline__ uint32_t hitClassOf(unsigned long long a, unsigned lo
 #define YD_FRAG_IPT 8
 #endif
 #define YD_FRAG_TILE (YD_FRAG_BS * YD_FRAG_IPT)
-static_assert((YD_FRAG_IPT * (YD_FRAG_BS / 64)) % 64 == 0 && YD_FRAG_IPT <= 16,
-    "k_frag_scan_build: wave 0 scans IPT x waves counts, a whole number per lane; the class bits of sixteen rows fit two words");
-__global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap,
-                                                                unsigned long long *tileState, unsigned int *total /* [0] the count, [1] raised when the look-back gave up */,
-                                                                    unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
+// What links a hit to the one before it in the sorted order, from the two keys: `cont` -- the same fragment goes on (same (read, strand) and diagonal, the k-mer overlaps
+// or abuts: QueryMatch.c:84-121) -- and `near` -- same (read, strand), at most maxGap diagonals apart (QueryMatch.c:146-158).  A hit is a fragment's head where cont is
+// false, its last hit where the NEXT hit's cont is false, and a dead single (see above) where it is both and neither its own near nor the next hit's holds.
+static_assert((YD_FRAG_IPT * (YD_FRAG_BS / 64)) % 64 == 0 && YD_FRAG_IPT <= 16, "k_frag_scan_build: wave 0 scans IPT x waves counts, a whole number per lane");
+// The classes of a row of 64 hits are LANE MASKS in scalar registers: the two links of every hit come from six compares, everything after that -- the shift by one hit
+// (a 64-bit shift with the next row's bit 0 coming in), head / last / dead, the counts -- is scalar arithmetic, and the masks come back as the conditions of the stores.
+// (Round 3's form kept three class bits a hit in vector registers and worked out both neighbours of every hit: 132 vector instructions a hit, 668 M a step.)
+// (80 scalar registers: with more than 96 -- the compiler takes what it is given -- eight waves no longer fit a SIMD and the workgroup of sixteen is alone on its CU)
+__global__ void __launch_bounds__(YD_FRAG_BS) __attribute__((amdgpu_num_sgpr(80)))
+k_frag_scan_build(const unsigned long long *keys, uint32_t nHits, int wordLen, int maxGapDrop, DevFrag *frags, uint32_t cap, unsigned long long *tileState,
+                  unsigned int *total /* [0] the count, [1] raised when the look-back gave up */, unsigned int *deadParts /* [1024] partial counts of dropped fragments */)
 {
     YD_HIGH_PRIO();
+    typedef unsigned long long u64;
     constexpr int NW = YD_FRAG_BS / 64;
     __shared__ uint32_t sCnt[YD_FRAG_IPT * NW]; __shared__ uint32_t sPrefix; __shared__ unsigned sDead;
-    const uint32_t tile = tileTicket(tileState + gridDim.x, &sPrefix), base = tile * (uint32_t)YD_FRAG_TILE, t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const uint32_t tile = tileTicket(tileState + gridDim.x, &sPrefix), base = tile * (uint32_t)YD_FRAG_TILE, t = threadIdx.x, lane = t & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
     if (t == 0) sDead = 0;
-    unsigned long long key[YD_FRAG_IPT]; uint32_t cls = 0, cls2 = 0;           // three class bits per hit: ten in cls, six in cls2
-    unsigned long long headMask[YD_FRAG_IPT];                                  // wave-uniform: the live heads of row k in this wave
-    unsigned nDead = 0;
-    // wave w owns the hits wbase + k * 64 + lane: all its loads are issued together (its rows and the two hits around the wave's range), a row's outer neighbours
-    // are the edge lanes of the rows above and below
+    // wave w owns the hits wbase + k * 64 + lane: all its loads are issued together (its rows and the two hits around the wave's range)
     const uint32_t wbase = base + w * (uint32_t)(64 * YD_FRAG_IPT);
+    uint32_t klo[YD_FRAG_IPT], khi[YD_FRAG_IPT];
+    {
+        unsigned long long key[YD_FRAG_IPT];
 #pragma unroll
-    for (int k = 0; k < YD_FRAG_IPT; k++) { const uint32_t idx = wbase + (uint32_t)k * 64u + lane; key[k] = idx < nHits ? keys[idx] : 0ull; }
+        for (int k = 0; k < YD_FRAG_IPT; k++) { const uint32_t idx = wbase + (uint32_t)k * 64u + lane; key[k] = idx < nHits ? keys[idx] : 0ull; }
+#pragma unroll
+        for (int k = 0; k < YD_FRAG_IPT; k++) { klo[k] = (uint32_t)key[k]; khi[k] = (uint32_t)(key[k] >> 32); }
+    }
     unsigned long long edge = 0ull;                                            // lane 0: the hit before the wave's range; lane 63: the one behind it
     if (lane == 0u && wbase > 0u && wbase <= nHits) edge = keys[wbase - 1u];
     if (lane == 63u && wbase + (uint32_t)(64 * YD_FRAG_IPT) < nHits) edge = keys[wbase + (uint32_t)(64 * YD_FRAG_IPT)];
+    const uint32_t elo = (uint32_t)edge, ehi = (uint32_t)(edge >> 32), wl = (uint32_t)wordLen, G = (uint32_t)maxGapDrop;
+    const bool drop = maxGapDrop >= 0;
+    // the links of one row as masks (bit l = the hit of lane l against the hit before it), straight from the compares (v_cmp writes a lane mask; no predicate is
+    // ever a vector register); the valid lanes of a row and "has a hit before it" are scalar arithmetic
+    enum { CMP_EQ = 32, CMP_ULT = 36, CMP_ULE = 37 };                           // (LLVM's integer predicates)
+    auto rowLinks = [&](int k, u64 &cM, u64 &nM, u64 &vM) {
+        const uint32_t row = wbase + (uint32_t)k * 64u;
+        const uint32_t nv = row < nHits ? (nHits - row < 64u ? nHits - row : 64u) : 0u;
+        vM = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
+        const u64 hasM = row == 0u ? (vM & ~1ull) : vM;
+        const uint32_t flo = (uint32_t)__builtin_amdgcn_readlane((int)(k > 0 ? klo[k > 0 ? k - 1 : 0] : elo), k > 0 ? 63 : 0),
+                       fhi = (uint32_t)__builtin_amdgcn_readlane((int)(k > 0 ? khi[k > 0 ? k - 1 : 0] : ehi), k > 0 ? 63 : 0);
+        const uint32_t alo = (uint32_t)laneUp1((int)klo[k], (int)flo), ahi = (uint32_t)laneUp1((int)khi[k], (int)fhi), blo = klo[k], bhi = khi[k];
+        const uint32_t xh = ahi ^ bhi, xl = alo ^ blo;
+        const uint32_t da = (uint32_t)__builtin_amdgcn_alignbit(ahi, alo, 15), db = (uint32_t)__builtin_amdgcn_alignbit(bhi, blo, 15);
+        // (the keys ascend: inside one (read, strand) db >= da, and with the bits from 15 up equal the difference of the low words is that of the query offsets)
+        cM = __builtin_amdgcn_uicmp(xh, 0u, CMP_EQ) & __builtin_amdgcn_uicmp(xl, 32768u, CMP_ULT) & __builtin_amdgcn_uicmp(blo - alo, wl, CMP_ULE) & hasM;
+        nM = __builtin_amdgcn_uicmp(xh, 32768u, CMP_ULT) & __builtin_amdgcn_uicmp(db - da, G, CMP_ULE) & hasM;
+    };
+    // per row: the heads and the last hits of the fragments that are written -- the only hits that store anything (two masks a row: at 106 scalar registers a workgroup of
+    // sixteen waves is alone on its CU, and the kernel a fifth slower than the form it replaces)
+    u64 headM[YD_FRAG_IPT], lastM[YD_FRAG_IPT];
+    unsigned nDead = 0;
+    u64 cM, nM, vM; rowLinks(0, cM, nM, vM);
 #pragma unroll
     for (int k = 0; k < YD_FRAG_IPT; k++) {
-        const uint32_t idx = wbase + (uint32_t)k * 64u + lane; const bool in = idx < nHits;
-        const unsigned long long b = key[k];
-        const unsigned long long up = k > 0 ? key[k - 1] : edge, dn = k + 1 < YD_FRAG_IPT ? key[k + 1] : edge;      // rows whose lanes 63 / 0 are this row's outer neighbours
-        const uint32_t a0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)up, k > 0 ? 63 : 0), a0hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(up >> 32), k > 0
-            ? 63 : 0);
-        const uint32_t c0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dn, k + 1 < YD_FRAG_IPT ? 0 : 63),
-            c0hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dn >> 32), k + 1 < YD_FRAG_IPT ? 0 : 63);
-        const unsigned long long a = ((unsigned long long)(uint32_t)laneUp1((int)(uint32_t)(b >> 32), (int)a0hi) << 32) | (uint32_t)laneUp1((int)(uint32_t)b, (int)a0lo);
-        const unsigned long long c = ((unsigned long long)(uint32_t)laneDown1((int)(uint32_t)(b >> 32), (int)c0hi) << 32) | (uint32_t)laneDown1((int)(uint32_t)b, (int)c0lo);
-        uint32_t cl = 0;
-        if (in) cl = hitClassOf(a, b, c, idx == 0u, idx + 1u >= nHits, wordLen, maxGapDrop);
-        if (k < 10) cls |= cl << (3 * k); else cls2 |= cl << (3 * (k - 10));
-        const bool liveHead = (cl & 5u) == 1u;
-        const unsigned long long m = __ballot(liveHead); headMask[k] = m;
-        if (lane == 0u) sCnt[(int)w * YD_FRAG_IPT + k] = (uint32_t)__builtin_popcountll(m);
-        nDead += (cl >> 2) & 1u;
+        u64 cN, nN, vN = 0ull;
+        if (k + 1 < YD_FRAG_IPT) rowLinks(k + 1, cN, nN, vN);
+        else {                                                                 // the hit behind the wave's range against the wave's last: scalars
+            const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)klo[YD_FRAG_IPT - 1], 63), ahi = (uint32_t)__builtin_amdgcn_readlane((int)khi[YD_FRAG_IPT - 1], 63),
+                           blo = (uint32_t)__builtin_amdgcn_readlane((int)elo, 63), bhi = (uint32_t)__builtin_amdgcn_readlane((int)ehi, 63);
+            const uint32_t xh = ahi ^ bhi, xl = alo ^ blo, da = (ahi << 17) | (alo >> 15), db = (bhi << 17) | (blo >> 15);
+            const bool has = wbase + (uint32_t)(64 * YD_FRAG_IPT) < nHits;
+            cN = (has && xh == 0u && xl < 32768u && blo - alo <= wl) ? 1ull : 0ull; nN = (has && xh < 32768u && db - da <= G) ? 1ull : 0ull;
+        }
+        const u64 nextC = (cM >> 1) | (cN << 63), nextN = (nM >> 1) | (nN << 63);
+        const u64 head = vM & ~cM, last = vM & ~nextC, dead = drop ? (head & last & ~nM & ~nextN) : 0ull;
+        headM[k] = head & ~dead; lastM[k] = last & ~dead;
+        if (lane == 0u) sCnt[(int)w * YD_FRAG_IPT + k] = (uint32_t)__builtin_popcountll(headM[k]);
+        nDead += (unsigned)__builtin_popcountll(dead);
+        cM = cN; nM = nN; vM = vN;
     }
     __syncthreads();
     if (w == 0u) {
@@ -263,28 +284,25 @@ __global__ void __launch_bounds__(YD_FRAG_BS) k_frag_scan_build(const unsigned l
         if (lane == 0u) { sPrefix = excl; if (tile + 1u == gridDim.x) *total = excl + agg; }
     }
     __syncthreads();
-    const uint32_t prefix = sPrefix; const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t prefix = sPrefix;
 #pragma unroll
     for (int k = 0; k < YD_FRAG_IPT; k++) {
-        const uint32_t cl = (k < 10 ? cls >> (3 * k) : cls2 >> (3 * (k - 10))) & 7u;
-        const bool head = (cl & 1u) != 0u, last = (cl & 2u) != 0u, dead = (cl & 4u) != 0u;
-        const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
-        if (idx >= nHits || dead) continue;
-        // the fragment this hit belongs to
-        const uint32_t f = prefix + sCnt[(int)w * YD_FRAG_IPT + k] + (uint32_t)__builtin_popcountll(headMask[k] & below) + (head ? 1u : 0u) - 1u;
-        if (f >= cap) continue;
-        const unsigned long long kk = key[k];
-        const uint32_t qo = (uint32_t)(kk & 0x7FFFu), diag = (uint32_t)(kk >> 15), rs = (uint32_t)(kk >> 47);
+        if ((headM[k] | lastM[k]) == 0ull) continue;                             // wave-uniform
+        const bool head = __builtin_amdgcn_inverse_ballot_w64(headM[k]), last = __builtin_amdgcn_inverse_ballot_w64(lastM[k]), live = head | last;
+        // the fragment this hit belongs to: the live heads before it in the tile, itself included
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(headM[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)headM[k], 0u));
+        const uint32_t f = prefix + sCnt[(int)w * YD_FRAG_IPT + k] + below + (head ? 1u : 0u) - 1u;
+        if (!live || f >= cap) continue;
+        const uint32_t qo = klo[k] & 0x7FFFu, diag = (uint32_t)__builtin_amdgcn_alignbit(khi[k], klo[k], 15), rs = khi[k] >> 15;
         if (head && last) {                                                  // a fragment of one hit: the whole record in one 16-byte store
-            const uint32_t eqo = qo + (uint32_t)wordLen - 1u;
-            uint4 v; v.x = diag + qo; v.y = qo | (eqo << 16); v.z = (uint32_t)wordLen /* refLen, used = 0 */; v.w = rs;
+            const uint32_t eqo = qo + wl - 1u;
+            uint4 v; v.x = diag + qo; v.y = qo | (eqo << 16); v.z = wl /* refLen, used = 0 */; v.w = rs;
             *(uint4 *)&frags[f] = v;
         } else {
             if (head) { frags[f].sro = diag + qo; frags[f].sqo = (uint16_t)qo; frags[f].rs = rs; frags[f].used = 0; }
-            if (last) frags[f].eqo = (uint16_t)(qo + (uint32_t)wordLen - 1u);
+            if (last) frags[f].eqo = (uint16_t)(qo + wl - 1u);
         }
     }
-    nDead = (unsigned)waveSumI((int)nDead);
     if (lane == 0u && nDead) atomicAdd(&sDead, nDead);
     __syncthreads();
     if (t == 0 && sDead) atomicAdd(&deadParts[blockIdx.x & 1023u], sDead);

@@ -26,8 +26,11 @@ struct WgSort {
     static constexpr unsigned NW = BS / 64u, N = BS * IPT, CNT = NW * 256u;
     static_assert(BS % 64u == 0 && BS >= 128u, "whole waves, and at least one thread per two digits");
     static_assert(CNT <= N && N <= 16384u, "the counters may alias the head of the exchange area; a rank has 14 bits");
-    static constexpr bool FUSED = 6u * N + 16u <= 65536u;
-    static constexpr bool SEPCNT = (FUSED ? 6u : 4u) * N + 4u * CNT + 16u <= 65536u;
+#ifndef YD_SORT_LDS_MAX
+#define YD_SORT_LDS_MAX 65536u
+#endif
+    static constexpr bool FUSED = 6u * N + 16u <= YD_SORT_LDS_MAX;
+    static constexpr bool SEPCNT = (FUSED ? 6u : 4u) * N + 4u * CNT + 16u <= YD_SORT_LDS_MAX;
     struct Storage { uint32_t x[N]; uint16_t p[FUSED ? N : 2u]; uint32_t c[SEPCNT ? CNT : 4u]; uint32_t wt[4]; };
 
     // the lanes of the row (among vlo | vhi) whose digit equals this lane's
