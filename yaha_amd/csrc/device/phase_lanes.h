@@ -645,12 +645,48 @@ __global__ void __launch_bounds__(256) k_p3_keys(PhaseArgs X, uint32_t rootEnd, 
     keys[r - X.rootBegin] = 4095u - min(n, 4095u);
 }
 
+#ifndef YD_P3_LOCAL_SORT
+#define YD_P3_LOCAL_SORT 1
+#endif
 __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
 {
     YD_HIGH_PRIO();
     const int lane = laneId(); const uint32_t t = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < A.nRoots; const DevParams &P = A.P;
+    const DevParams &P = A.P;
+#if YD_P3_LOCAL_SORT
+    // A wave walks as long as its longest list (57 ops a root on average, ~240 for the longest of 64 in rank order).  The workgroup's 256 roots are therefore dealt to
+    // its lanes by descending list length -- a counting sort on the length in fours, 64 classes, in LDS -- so that three of the four waves are done early; the roots stay
+    // the workgroup's own (their records are in the lines its lanes have just read), and nothing the kernel writes depends on which lane a root sits in (places are taken
+    // by atomic reservation, the final layout orders by root rank).
+    __shared__ uint32_t sHist[65], sOrder[256];
+    uint32_t r; bool live;
+    {
+        const bool in = t < A.nRoots;
+        uint32_t cls = 64u;                                                  // (no root: behind all)
+        if (in) {
+            const RootState S = X.state[t]; const ExtRes rb = X.res[2 * (size_t)t], rf = X.res[2 * (size_t)t + 1];
+            const uint32_t n0 = (uint32_t)S.len + (rb.score > 0 ? rb.nOps : 0u) + (rf.score > 0 ? rf.nOps : 0u);
+            cls = 63u - min(n0 >> 2, 63u);
+        }
+        if (threadIdx.x < 65u) sHist[threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t inCls = atomicAdd(&sHist[cls], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64u) {                                             // exclusive sums of the 65 counts (lane 63 takes the last two)
+            const uint32_t c = sHist[lane]; uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += y; }
+            sHist[lane] = incl - c; if (lane == 63) sHist[64] = incl;
+        }
+        __syncthreads();
+        sOrder[sHist[cls] + inCls] = in ? t : 0xFFFFFFFFu;
+        __syncthreads();
+        r = sOrder[threadIdx.x]; live = r != 0xFFFFFFFFu;
+    }
+#else
+    const bool live = t < A.nRoots;
     const uint32_t r = (live && X.p3Order) ? X.p3Order[t - X.rootBegin] : t;
+#endif
     int verdict = -1;                                  // -1 none, 0 rejected, 1 split needed, 2 scored
     MergedOps L; L.a = L.b = L.c = nullptr; L.na = L.nb = L.nc = L.jab = L.jbc = 0;
     uint32_t sro = 0; int sqo = 0, eqo = 0, refLen = 0, status = 0, n = 0;
@@ -678,6 +714,8 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
         }
     }
     // a root that needs splitClump goes to the split list; k_p3_predict lists its careful extensions
+    // (the split list in the order the workgroup's lanes hold the roots; giving the verdicts back to the roots' own lanes -- the list order of round 5 -- takes a barrier
+    // at the end of the walk, behind which the early waves wait for the longest: 2.62 -> 3.23 ms for this kernel, and the step loses what the dealing gained)
     { const unsigned long long sm = __ballot(verdict == 1); const unsigned slot = waveReserve(sm, X.slowCount, lane); if (verdict == 1) X.slowList[slot] = r; }
     // emit the accepted clumps (emit() in align.h)
     const bool acc = verdict == 2;
