@@ -266,10 +266,37 @@ __host__ __device__ __forceinline__ uint32_t gapJointKey(const DevParams &P, boo
 }
 __host__ __device__ __forceinline__ bool gapJointBand24(uint32_t key) { return (key >> 10) == 3u && ((key >> 5) & 31u) < 8u; }
 
+// A lane-per-root kernel walks, in every wave, as long as the wave's longest root.  wgDeal hands the 256 roots of a workgroup to its lanes by ascending class (0 = the longest
+// walk ... 63; 64 = no root): a counting sort in LDS, so that the waves of a workgroup hold roots of like length and three of four are done early.  The roots stay the
+// workgroup's own (their records are in the lines its lanes have just read); nothing such a kernel writes may depend on which lane a root sits in.  Every thread of the
+// workgroup calls it; returns the root for this lane, or 0xFFFFFFFF.  (Round 6: the step is bound by the sum of vector instructions, and the instructions idle lanes sit
+// through are issued all the same -- k_p3_lanes 3.06 -> 2.62 ms, -0.55 ms a step, profiles/r06_rows_kernel_passes.txt.)
+__device__ __forceinline__ uint32_t wgDeal(uint32_t root, uint32_t cls)
+{
+    __shared__ uint32_t sHist[65], sOrder[256];
+    const int lane = laneId();
+    if (threadIdx.x < 65u) sHist[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t inCls = atomicAdd(&sHist[cls], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64u) {                                                 // exclusive sums of the 65 counts (the last class needs none behind it)
+        const uint32_t c = sHist[lane]; uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += y; }
+        sHist[lane] = incl - c; if (lane == 63) sHist[64] = incl;
+    }
+    __syncthreads();
+    sOrder[sHist[cls] + inCls] = cls < 64u ? root : 0xFFFFFFFFu;
+    __syncthreads();
+    return sOrder[threadIdx.x];
+}
+
 // lane per root: exact-match extensions of every joint (AlignHelpers.c:216-232), then the gap's kind (AlignExtFrag.cpp:190-231)
 __global__ void __launch_bounds__(256) k_p1_joints(AlignArgs A, PhaseArgs X)
 {
     YD_HIGH_PRIO();
+    // (wgDeal by the number of fragments, measured: 1.64 -> 1.61 ms here, 2.39 -> 2.66 ms in k_p1_assemble -- their per-root records are written side by side by
+    // neighbouring lanes -- and the step 0.2 ms slower: not used)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < A.nRoots; const DevParams &P = A.P;
     unsigned perfect = 0, touched = 0, nDP = 0, nDP16 = 0, nB12 = 0, nB16 = 0, nB24 = 0;
@@ -654,34 +681,17 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
     const int lane = laneId(); const uint32_t t = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
     const DevParams &P = A.P;
 #if YD_P3_LOCAL_SORT
-    // A wave walks as long as its longest list (57 ops a root on average, ~240 for the longest of 64 in rank order).  The workgroup's 256 roots are therefore dealt to
-    // its lanes by descending list length -- a counting sort on the length in fours, 64 classes, in LDS -- so that three of the four waves are done early; the roots stay
-    // the workgroup's own (their records are in the lines its lanes have just read), and nothing the kernel writes depends on which lane a root sits in (places are taken
-    // by atomic reservation, the final layout orders by root rank).
-    __shared__ uint32_t sHist[65], sOrder[256];
+    // (wgDeal: by descending length of the merged edit list -- 57 ops a root on average, ~240 for the longest of 64 in rank order -- in fours)
     uint32_t r; bool live;
     {
         const bool in = t < A.nRoots;
-        uint32_t cls = 64u;                                                  // (no root: behind all)
+        uint32_t cls = 64u;
         if (in) {
             const RootState S = X.state[t]; const ExtRes rb = X.res[2 * (size_t)t], rf = X.res[2 * (size_t)t + 1];
             const uint32_t n0 = (uint32_t)S.len + (rb.score > 0 ? rb.nOps : 0u) + (rf.score > 0 ? rf.nOps : 0u);
             cls = 63u - min(n0 >> 2, 63u);
         }
-        if (threadIdx.x < 65u) sHist[threadIdx.x] = 0u;
-        __syncthreads();
-        const uint32_t inCls = atomicAdd(&sHist[cls], 1u);
-        __syncthreads();
-        if (threadIdx.x < 64u) {                                             // exclusive sums of the 65 counts (lane 63 takes the last two)
-            const uint32_t c = sHist[lane]; uint32_t incl = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += y; }
-            sHist[lane] = incl - c; if (lane == 63) sHist[64] = incl;
-        }
-        __syncthreads();
-        sOrder[sHist[cls] + inCls] = in ? t : 0xFFFFFFFFu;
-        __syncthreads();
-        r = sOrder[threadIdx.x]; live = r != 0xFFFFFFFFu;
+        r = wgDeal(t, cls); live = r != 0xFFFFFFFFu;
     }
 #else
     const bool live = t < A.nRoots;
