@@ -271,9 +271,10 @@ __host__ __device__ __forceinline__ bool gapJointBand24(uint32_t key) { return (
 // workgroup's own (their records are in the lines its lanes have just read); nothing such a kernel writes may depend on which lane a root sits in.  Every thread of the
 // workgroup calls it; returns the root for this lane, or 0xFFFFFFFF.  (Round 6: the step is bound by the sum of vector instructions, and the instructions idle lanes sit
 // through are issued all the same -- k_p3_lanes 3.06 -> 2.62 ms, -0.55 ms a step, profiles/r06_rows_kernel_passes.txt.)
+template <int BS = 256>
 __device__ __forceinline__ uint32_t wgDeal(uint32_t root, uint32_t cls)
 {
-    __shared__ uint32_t sHist[65], sOrder[256];
+    __shared__ uint32_t sHist[65], sOrder[BS];
     const int lane = laneId();
     if (threadIdx.x < 65u) sHist[threadIdx.x] = 0u;
     __syncthreads();
@@ -675,7 +676,10 @@ __global__ void __launch_bounds__(256) k_p3_keys(PhaseArgs X, uint32_t rootEnd, 
 #ifndef YD_P3_LOCAL_SORT
 #define YD_P3_LOCAL_SORT 1
 #endif
-__global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
+#ifndef YD_P3_BS
+#define YD_P3_BS 256
+#endif
+__global__ void __launch_bounds__(YD_P3_BS) k_p3_lanes(AlignArgs A, PhaseArgs X)
 {
     YD_HIGH_PRIO();
     const int lane = laneId(); const uint32_t t = X.rootBegin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -691,7 +695,7 @@ __global__ void __launch_bounds__(256) k_p3_lanes(AlignArgs A, PhaseArgs X)
             const uint32_t n0 = (uint32_t)S.len + (rb.score > 0 ? rb.nOps : 0u) + (rf.score > 0 ? rf.nOps : 0u);
             cls = 63u - min(n0 >> 2, 63u);
         }
-        r = wgDeal(t, cls); live = r != 0xFFFFFFFFu;
+        r = wgDeal<YD_P3_BS>(t, cls); live = r != 0xFFFFFFFFu;
     }
 #else
     const bool live = t < A.nRoots;

@@ -346,7 +346,7 @@ static int alignWithLaneExtensions(ygpu_ctx *ctx, AlignArgs &A, unsigned waves, 
                 Xc.p3Order = oo;
             }
         }
-        KL(k_p3_lanes, dim3(gridFor(nr, 256)), dim3(256), 0, ctx->stream, Ac, Xc);
+        KL(k_p3_lanes, dim3(gridFor(nr, YD_P3_BS)), dim3(YD_P3_BS), 0, ctx->stream, Ac, Xc);
         if (ctx->splitLanes) KL(k_p3_predict, dim3((unsigned)std::min<uint64_t>(gridFor(nr, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, Ac, Xc);
         PhaseArgs Xw = Xc;                                                    // what k_align_p3 gets: all split roots, or only those k_split_lanes gives back
         // the range's use of the arena (for the next batch's estimate), then the careful-extension round starts it afresh
