@@ -8,19 +8,22 @@
 #pragma once
 #include "chain.h"
 
-#define YD_CL 8                                   // fragments per region handled here
+#define YD_CL 8                                   // fragments per region of the small class ...
+#define YD_CLM 16                                 // ... and of the middle class (9 .. 16: 84 % of what k_chain took, a wave-wide instruction for a dozen fragments)
 
+template <int YD_CLT>
 struct ChainLaneLds {
-    uint32_t fsro[YD_CL][64]; uint16_t fsqo[YD_CL][64], feqo[YD_CL][64], frl[YD_CL][64]; uint8_t used[YD_CL][64];
-    int16_t best[YD_CL][64]; int8_t prev[YD_CL][64], ord[YD_CL][64]; uint16_t psqo[YD_CL][64];
-    uint32_t lsro[YD_CL][64]; uint16_t lsqo[YD_CL][64], leqo[YD_CL][64], lrl[YD_CL][64]; int8_t nx[YD_CL][64], pv[YD_CL][64];
-    uint16_t ivS[YD_CL + 1][64], ivL[YD_CL + 1][64];
+    uint32_t fsro[YD_CLT][64]; uint16_t fsqo[YD_CLT][64], feqo[YD_CLT][64], frl[YD_CLT][64]; uint8_t used[YD_CLT][64];
+    int16_t best[YD_CLT][64]; int8_t prev[YD_CLT][64], ord[YD_CLT][64]; uint16_t psqo[YD_CLT][64];
+    uint32_t lsro[YD_CLT][64]; uint16_t lsqo[YD_CLT][64], leqo[YD_CLT][64], lrl[YD_CLT][64]; int8_t nx[YD_CLT][64], pv[YD_CLT][64];
+    uint16_t ivS[YD_CLT + 1][64], ivL[YD_CLT + 1][64];
 };
 
+template <int YD_CLT>
 __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t *smallList, uint32_t nSmall)
 {
     YD_HIGH_PRIO();
-    __shared__ ChainLaneLds T;
+    __shared__ ChainLaneLds<YD_CLT> T;
     const int lane = laneId(); const DevParams &P = A.P;
     const int MS = P.MS, GO = P.GO, GE = P.GE, maxGap = P.maxGap, maxDesert = P.maxDesert, minMatch = P.minMatch, minLeft = P.minNonOverlap - 1;
     unsigned formed = 0;
@@ -34,7 +37,7 @@ __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t 
                 T.frl[i][lane] = f.refLen; T.used[i][lane] = f.used != 0; if (i == 0) rs = f.rs; }
         }
         int nIv = 0; uint32_t seq = 0; bool active = live;
-        for (int iter = 0; iter <= YD_CL; iter++) {
+        for (int iter = 0; iter <= YD_CLT; iter++) {
             if (iter > n0) active = false;
             int head = -1, tail = -1, mm = 0, matched = 0; bool emit = false;
             if (active) {
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(64) k_chain_lanes(ChainArgs A, const uint32_t 
                         }
                     }
                     // processBestFragmentPath / insertFragment (GraphPath.cpp:134-146, AlignHelpers.c:60-90)
-                    for (int cur = bestNode; cur >= 0 && mm < YD_CL; ) {
+                    for (int cur = bestNode; cur >= 0 && mm < YD_CLT; ) {
                         uint32_t s1 = T.fsro[cur][lane]; int q1 = T.fsqo[cur][lane], e1 = T.feqo[cur][lane], r1 = T.frl[cur][lane];
                         if (head >= 0) {
                             uint32_t s2 = T.lsro[head][lane]; int q2 = T.lsqo[head][lane], e2 = T.leqo[head][lane], r2 = T.lrl[head][lane];

@@ -56,29 +56,34 @@ __global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nF
     for (int k = 0; k < YD_REG_IPT; k++)
         if ((headMask[k] >> lane) & 1ull) regStart[prefix + sCnt[(int)w * YD_REG_IPT + k] + (uint32_t)__builtin_popcountll(headMask[k] & below)] = wbase + (uint32_t)k * 64u + lane;
 }
-// multi-fragment region list + largest region
-// smallList: regions with 2..8 fragments (k_chain_lanes); multiList: 9..64 (k_chain); bigList: more than 64 (k_chain_big)
+// multi-fragment region lists + largest region
+// smallList: regions with 2..8 fragments (k_chain_lanes<8>); the middle class, 9..16, fills the same array from its top downwards (midTop[-1 - i]: k_chain_lanes<16>; the
+// two lists together are no longer than the regions are many); multiList: 17..64 (k_chain); bigList: more than 64 (k_chain_big)
 __global__ void __launch_bounds__(1024) k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN,
-    uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned int *nSmall)
+    uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned long long *nSmallMid /* low half: the small regions, high half: the middle ones */, uint32_t *midTop)
 {
     YD_HIGH_PRIO();
-    __shared__ unsigned sM[16], sS[16], sBase[2];                            // one atomic per list and 1024-thread block (a single L2 word takes ~88 atomics per microsecond)
+    __shared__ unsigned sM[16], sS[16], sD[16], sBase[3];                    // one atomic per list and 1024-thread block (a single L2 word takes ~88 atomics per microsecond)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
     const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
-    const bool big = n > 64, small = n >= 2 && n <= 8, multi = n > 8 && !big;
+    const bool big = n > 64, small = n >= 2 && n <= 8, mid = n > 8 && n <= 16, multi = n > 16 && !big;
     if (big) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }        // rare
-    const unsigned long long mm = __ballot(multi), ms = __ballot(small);
-    if (lane == 0) { sM[wv] = (unsigned)__builtin_popcountll(mm); sS[wv] = (unsigned)__builtin_popcountll(ms); }
+    const unsigned long long mm = __ballot(multi), ms = __ballot(small), md = __ballot(mid);
+    if (lane == 0) { sM[wv] = (unsigned)__builtin_popcountll(mm); sS[wv] = (unsigned)__builtin_popcountll(ms); sD[wv] = (unsigned)__builtin_popcountll(md); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned tm = 0, ts = 0; for (unsigned k = 0; k < blockDim.x / 64u; k++) { tm += sM[k]; ts += sS[k]; }
-        sBase[0] = tm ? atomicAdd(nMulti, tm) : 0u; sBase[1] = ts ? atomicAdd(nSmall, ts) : 0u;
+        unsigned tm = 0, ts = 0, td = 0; for (unsigned k = 0; k < blockDim.x / 64u; k++) { tm += sM[k]; ts += sS[k]; td += sD[k]; }
+        sBase[0] = tm ? atomicAdd(nMulti, tm) : 0u;
+        // (the two lists of the lane kernels in one atomic: a block's atomics on the batch's counters are what this kernel waits for)
+        const unsigned long long b = (ts | td) ? atomicAdd(nSmallMid, (unsigned long long)ts | ((unsigned long long)td << 32)) : 0ull;
+        sBase[1] = (unsigned)b; sBase[2] = (unsigned)(b >> 32);
     }
     __syncthreads();
-    unsigned bm = 0, bs = 0; for (int k = 0; k < wv; k++) { bm += sM[k]; bs += sS[k]; }
+    unsigned bm = 0, bs = 0, bd = 0; for (int k = 0; k < wv; k++) { bm += sM[k]; bs += sS[k]; bd += sD[k]; }
     const unsigned long long below = (1ull << lane) - 1ull;
     if (multi) multiList[sBase[0] + bm + (unsigned)__builtin_popcountll(mm & below)] = r;
     if (small) smallList[sBase[1] + bs + (unsigned)__builtin_popcountll(ms & below)] = r;
+    if (mid) midTop[-1 - (long)(sBase[2] + bd + (unsigned)__builtin_popcountll(md & below))] = r;
 }
 // order[base[region] + seq] = clump index  (rank of a root clump = creation order)
 // ... and sorted[rank] = the record itself: what the align stage reads (a wave's 64 roots in one stretch; through `order` they are 64 places of the arena)

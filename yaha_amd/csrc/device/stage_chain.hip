@@ -26,12 +26,22 @@ int stageChain(ygpu_ctx *ctx)
     ctx->nRegions = R;
     HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NBIG, 0, 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(cnt + CNT_NSMALL, 0, 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(cnt + CNT_NSMALL, 0, 8, ctx->stream));          // (and CNT_NMID behind it)
+    static_assert(CNT_NMID == CNT_NSMALL + 1 && CNT_NSMALL % 2 == 0, "one memset, one fetch, one 64-bit atomic");
     KL(k_region_classify, dim3(gridFor(R, 1024)), dim3(1024), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN,
-        ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG, ctx->smallList.as<uint32_t>(), cnt + CNT_NSMALL);
-    uint32_t two[2] = {0, 0};
-    { const FetchPiece pc[3] = {{cnt + CNT_NMULTI, two, 2}, {cnt + CNT_NBIG, &ctx->nBig, 1}, {cnt + CNT_NSMALL, &ctx->nSmall, 1}}; rc = fetchMany(ctx, pc, 3); if (rc) return rc; }
+        ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG, ctx->smallList.as<uint32_t>(), (unsigned long long *)(cnt + CNT_NSMALL), ctx->smallList.as<uint32_t>() + F);
+    uint32_t two[2] = {0, 0}, sm[2] = {0, 0};
+    { const FetchPiece pc[3] = {{cnt + CNT_NMULTI, two, 2}, {cnt + CNT_NBIG, &ctx->nBig, 1}, {cnt + CNT_NSMALL, sm, 2}}; rc = fetchMany(ctx, pc, 3); if (rc) return rc; }
+    ctx->nSmall = sm[0]; ctx->nMid = sm[1];
     ctx->nMulti = two[0]; ctx->maxN = two[1];
+    if (kTrace && getenv("YGPU_REGION_HIST")) {                                  // fragments a region: how the three chain kernels' shares lie (diagnostic)
+        std::vector<uint32_t> rs((size_t)R + 1); hipMemcpy(rs.data(), ctx->regStart.p, 4ull * (R + 1), hipMemcpyDeviceToHost);
+        unsigned long long h[12] = {0}, fr[12] = {0}; static const uint32_t hi[12] = {1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 512, 0xFFFFFFFFu};
+        for (uint32_t r = 0; r < R; r++) { const uint32_t n = rs[r + 1] - rs[r]; for (int c = 0; c < 12; c++) if (n <= hi[c]) { h[c]++; fr[c] += n; break; } }
+        fprintf(stderr, "[ygpu] regions by fragments (count / fragments):");
+        for (int c = 0; c < 12; c++) fprintf(stderr, " <=%u: %llu / %llu", hi[c], h[c], fr[c]);
+        fprintf(stderr, "\n");
+    }
     EV1(T_FRAGS);
 
     EV0(T_CHAIN);
@@ -62,8 +72,11 @@ int stageChain(ygpu_ctx *ctx)
         A.clumps = ctx->clumps.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.counts = cnt + CNT_CLUMPS; A.clumpCap = clumpCap; A.fragCap = fragCap;
         A.regionClumpCount = ctx->regionCount.as<uint32_t>(); A.errFlag = ctx->errFlag.as<int>(); A.ctr = ctx->ctr.as<DevCounters>();
         KL(k_regions_single, dim3(gridFor(R, 1024)), dim3(1024), 0, ctx->stream, A);
-        if (ctx->nSmall) KL(k_chain_lanes, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nSmall, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, A,
+        if (ctx->nSmall) KL(k_chain_lanes<YD_CL>, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nSmall, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, A,
             ctx->smallList.as<uint32_t>(), ctx->nSmall);
+        // (the middle class, 9 .. 16 fragments, a region a lane as well: 34 KB of LDS a wave)
+        if (ctx->nMid) KL(k_chain_lanes<YD_CLM>, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nMid, 64), (uint64_t)ctx->nCU * 4)), dim3(64), 0, ctx->stream, A,
+            ctx->smallList.as<uint32_t>() + F - ctx->nMid, ctx->nMid);
         if (ctx->nMulti) KL(k_chain, dim3(waves), dim3(64), 0, ctx->stream, A);
         if (ctx->nBig) KL(k_chain_big, dim3(wavesBig), dim3(64), 0, ctx->stream, A, ctx->bigList.as<uint32_t>(), ctx->nBig, cnt + CNT_QBIG);
         // creation-order rank of every root clump: the sum over the regions' counts is launched before anybody knows whether the attempt fitted -- an attempt that did not
