@@ -78,7 +78,8 @@ struct DevBuf {
 // words of ygpu_ctx::counters (device): queue heads, arena counts, list lengths of one batch
 enum {
     CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG,
-    CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_PAD_EVEN, CNT_NSMALL, CNT_NMID /* one 64-bit word with CNT_NSMALL */, CNT_NB12, CNT_NB16, CNT_NB24,
+    CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_PAD_EVEN, CNT_NSMALL, CNT_NMID /* one 64-bit word with CNT_NSMALL */, CNT_NB12, CNT_NB16,
+        CNT_NB24,
     CNT_SEGC,                            // YD_SEG_NCLASS + 1 words: the segments of the workgroup-sort classes, the long ones
     CNT_NFRAGS = CNT_SEGC + 16,          // + the look-back's flag + the order check's (seed.h: a key that is not above its predecessor)
     CNT_NREG = CNT_NFRAGS + 3,           // + flag
