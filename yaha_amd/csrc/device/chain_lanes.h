@@ -8,7 +8,9 @@
 #pragma once
 #include "chain.h"
 
-#define YD_CL 8                                   // fragments per region of the small class ...
+// A wave of this kernel takes as long as its region with the most fragments, squared: three instances over three lists (regions.h: k_region_classify)
+#define YD_CLT4 4                                 // fragments per region of the smallest class (2 .. 4: 72 % of the regions with more than one fragment) ...
+#define YD_CL 8                                   // ... of the small class (5 .. 8) ...
 #define YD_CLM 16                                 // ... and of the middle class (9 .. 16: 84 % of what k_chain took, a wave-wide instruction for a dozen fragments)
 
 template <int YD_CLT>

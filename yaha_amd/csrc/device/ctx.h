@@ -78,7 +78,8 @@ struct DevBuf {
 // words of ygpu_ctx::counters (device): queue heads, arena counts, list lengths of one batch
 enum {
     CNT_NMULTI = 0, CNT_MAXN, CNT_CLUMPS, CNT_CFRAGS, CNT_QCHAIN, CNT_QALIGN, CNT_OUTCLUMPS, CNT_OUTOPS, CNT_QDP, CNT_DPOPS, CNT_NBIG, CNT_QBIG,
-    CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_PAD_EVEN, CNT_NSMALL, CNT_NMID /* one 64-bit word with CNT_NSMALL */, CNT_NB12, CNT_NB16,
+    CNT_STATEOPS, CNT_EXTOPS, CNT_QEXT, CNT_SLOW, CNT_NDP, CNT_NDP16, CNT_GAPOPS, CNT_PAD_EVEN, CNT_NMULTI2 /* (multi | tiny << 32), (small | middle << 32): two 64-bit words */,
+        CNT_NTINY, CNT_NSMALL, CNT_NMID, CNT_NB12, CNT_NB16,
         CNT_NB24,
     CNT_SEGC,                            // YD_SEG_NCLASS + 1 words: the segments of the workgroup-sort classes, the long ones
     CNT_NFRAGS = CNT_SEGC + 16,          // + the look-back's flag + the order check's (seed.h: a key that is not above its predecessor)
@@ -189,7 +190,7 @@ struct ygpu_ctx {
     // stage state
     uint32_t hOutCounts[2] = {0, 0}, hOutEf = 0;
     bool hOutValid = false;
-    uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nSmall = 0, nMid = 0, nBig = 0, maxN = 0;
+    uint32_t nHits = 0, nFrags = 0, nRegions = 0, nMulti = 0, nTiny = 0, nSmall = 0, nMid = 0, nBig = 0, maxN = 0;
     int sortRankUsed = 0;                // the ranking the batch's hits were sorted with (stage_seed.hip: 0 = LDS atomics, 1 = ballots)
     bool sortRankForced = false;         // ... because YGPU_SORT_RANK said so
     uint32_t nClumpSlots = 0, nClumps = 0, nClumpFrags = 0, nOut = 0, nOutOps = 0;

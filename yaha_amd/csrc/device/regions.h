@@ -57,33 +57,58 @@ __global__ void __launch_bounds__(256) k_region_scan(DevFrag *frags, uint32_t nF
         if ((headMask[k] >> lane) & 1ull) regStart[prefix + sCnt[(int)w * YD_REG_IPT + k] + (uint32_t)__builtin_popcountll(headMask[k] & below)] = wbase + (uint32_t)k * 64u + lane;
 }
 // multi-fragment region lists + largest region
-// smallList: regions with 2..8 fragments (k_chain_lanes<8>); the middle class, 9..16, fills the same array from its top downwards (midTop[-1 - i]: k_chain_lanes<16>; the
-// two lists together are no longer than the regions are many); multiList: 17..64 (k_chain); bigList: more than 64 (k_chain_big)
-__global__ void __launch_bounds__(1024) k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, unsigned int *nMulti, unsigned int *maxN,
-    uint32_t *bigList, unsigned int *nBig, uint32_t *smallList, unsigned long long *nSmallMid /* low half: the small regions, high half: the middle ones */, uint32_t *midTop)
+// Four lists in two arrays (a list from the bottom and one from the top of each: the lists together are no longer than the regions are many): 2..4 fragments from
+// the top of multiList (multiTop[-1 - i]: k_chain_lanes<4>), 5..8 in smallList (k_chain_lanes<8>), 9..16 from its top (smallTop[-1 - i]: k_chain_lanes<16>), 17..64 in
+// multiList (k_chain); bigList: more than 64 (k_chain_big).  cnt2: two 64-bit words, (multi | tiny << 32) and (small | middle << 32).
+// (regions a thread: a block's two atomics on the batch's counters are what the kernel waits for -- one L2 word takes ~88 a microsecond)
+#define YD_RCLS_IPT 4
+__global__ void __launch_bounds__(1024) k_region_classify(const uint32_t *regStart, uint32_t nRegions, uint32_t *multiList, uint32_t *multiTop, uint32_t *smallList,
+    uint32_t *smallTop, unsigned long long *cnt2, unsigned int *maxN, uint32_t *bigList, unsigned int *nBig)
 {
     YD_HIGH_PRIO();
-    __shared__ unsigned sM[16], sS[16], sD[16], sBase[3];                    // one atomic per list and 1024-thread block (a single L2 word takes ~88 atomics per microsecond)
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
-    const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
-    const bool big = n > 64, small = n >= 2 && n <= 8, mid = n > 8 && n <= 16, multi = n > 16 && !big;
-    if (big) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }        // rare
-    const unsigned long long mm = __ballot(multi), ms = __ballot(small), md = __ballot(mid);
-    if (lane == 0) { sM[wv] = (unsigned)__builtin_popcountll(mm); sS[wv] = (unsigned)__builtin_popcountll(ms); sD[wv] = (unsigned)__builtin_popcountll(md); }
+    __shared__ unsigned sC[4][16], sBase[4];
+    const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+    const uint32_t r0 = blockIdx.x * (1024u * YD_RCLS_IPT) + threadIdx.x;
+    int cls[YD_RCLS_IPT]; unsigned long long m[YD_RCLS_IPT][4]; unsigned tot[4] = {0, 0, 0, 0};      // (the masks and counts are wave-uniform: scalar registers)
+#pragma unroll
+    for (int k = 0; k < YD_RCLS_IPT; k++) {
+        const uint32_t r = r0 + (uint32_t)k * 1024u;
+        const uint32_t n = r < nRegions ? regStart[r + 1] - regStart[r] : 0u;
+        const bool big = n > 64;
+        cls[k] = n < 2 || big ? -1 : (n > 16 ? 0 : (n <= 4 ? 1 : (n <= 8 ? 2 : 3)));          // multi, tiny, small, middle
+        if (big) { unsigned p = atomicAdd(nBig, 1u); bigList[p] = r; atomicMax(maxN, n); }    // rare
+#pragma unroll
+        for (int c = 0; c < 4; c++) { m[k][c] = __ballot(cls[k] == c); tot[c] += (unsigned)__builtin_popcountll(m[k][c]); }
+    }
+    if (lane == 0) { sC[0][wv] = tot[0]; sC[1][wv] = tot[1]; sC[2][wv] = tot[2]; sC[3][wv] = tot[3]; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned tm = 0, ts = 0, td = 0; for (unsigned k = 0; k < blockDim.x / 64u; k++) { tm += sM[k]; ts += sS[k]; td += sD[k]; }
-        sBase[0] = tm ? atomicAdd(nMulti, tm) : 0u;
-        // (the two lists of the lane kernels in one atomic: a block's atomics on the batch's counters are what this kernel waits for)
-        const unsigned long long b = (ts | td) ? atomicAdd(nSmallMid, (unsigned long long)ts | ((unsigned long long)td << 32)) : 0ull;
-        sBase[1] = (unsigned)b; sBase[2] = (unsigned)(b >> 32);
+    // lane = class * 16 + wave: exclusive sums over the waves of a class, the class totals to the batch's counters
+    if (threadIdx.x < 64u) {
+        const unsigned c = sC[lane >> 4][lane & 15]; unsigned incl = c;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const unsigned y = (unsigned)__shfl_up((int)incl, d, 16); if ((lane & 15) >= d) incl += y; }
+        sC[lane >> 4][lane & 15] = incl - c;
+        const unsigned t0 = (unsigned)__shfl((int)incl, 15, 64), t1 = (unsigned)__shfl((int)incl, 31, 64), t2 = (unsigned)__shfl((int)incl, 47, 64),
+            t3 = (unsigned)__shfl((int)incl, 63, 64);
+        if (lane == 0) {
+            const unsigned long long a = (t0 | t1) ? atomicAdd(cnt2, (unsigned long long)t0 | ((unsigned long long)t1 << 32)) : 0ull;
+            const unsigned long long b = (t2 | t3) ? atomicAdd(cnt2 + 1, (unsigned long long)t2 | ((unsigned long long)t3 << 32)) : 0ull;
+            sBase[0] = (unsigned)a; sBase[1] = (unsigned)(a >> 32); sBase[2] = (unsigned)b; sBase[3] = (unsigned)(b >> 32);
+        }
     }
     __syncthreads();
-    unsigned bm = 0, bs = 0, bd = 0; for (int k = 0; k < wv; k++) { bm += sM[k]; bs += sS[k]; bd += sD[k]; }
+    unsigned at[4]; for (int c = 0; c < 4; c++) at[c] = sBase[c] + sC[c][wv];
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (multi) multiList[sBase[0] + bm + (unsigned)__builtin_popcountll(mm & below)] = r;
-    if (small) smallList[sBase[1] + bs + (unsigned)__builtin_popcountll(ms & below)] = r;
-    if (mid) midTop[-1 - (long)(sBase[2] + bd + (unsigned)__builtin_popcountll(md & below))] = r;
+#pragma unroll
+    for (int k = 0; k < YD_RCLS_IPT; k++) {
+        const uint32_t r = r0 + (uint32_t)k * 1024u;
+        if (cls[k] == 0) multiList[at[0] + (unsigned)__builtin_popcountll(m[k][0] & below)] = r;
+        else if (cls[k] == 1) multiTop[-1 - (long)(at[1] + (unsigned)__builtin_popcountll(m[k][1] & below))] = r;
+        else if (cls[k] == 2) smallList[at[2] + (unsigned)__builtin_popcountll(m[k][2] & below)] = r;
+        else if (cls[k] == 3) smallTop[-1 - (long)(at[3] + (unsigned)__builtin_popcountll(m[k][3] & below))] = r;
+#pragma unroll
+        for (int c = 0; c < 4; c++) at[c] += (unsigned)__builtin_popcountll(m[k][c]);
+    }
 }
 // order[base[region] + seq] = clump index  (rank of a root clump = creation order)
 // ... and sorted[rank] = the record itself: what the align stage reads (a wave's 64 roots in one stretch; through `order` they are 64 places of the arena)

@@ -26,13 +26,15 @@ int stageChain(ygpu_ctx *ctx)
     ctx->nRegions = R;
     HIPCHK(hipMemcpyAsync((uint32_t *)ctx->regStart.p + R, &ctx->nFrags, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI, 0, 8, ctx->stream)); HIPCHK(hipMemsetAsync(cnt + CNT_NBIG, 0, 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(cnt + CNT_NSMALL, 0, 8, ctx->stream));          // (and CNT_NMID behind it)
-    static_assert(CNT_NMID == CNT_NSMALL + 1 && CNT_NSMALL % 2 == 0, "one memset, one fetch, one 64-bit atomic");
-    KL(k_region_classify, dim3(gridFor(R, 1024)), dim3(1024), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(), cnt + CNT_NMULTI, cnt + CNT_MAXN,
-        ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG, ctx->smallList.as<uint32_t>(), (unsigned long long *)(cnt + CNT_NSMALL), ctx->smallList.as<uint32_t>() + F);
-    uint32_t two[2] = {0, 0}, sm[2] = {0, 0};
-    { const FetchPiece pc[3] = {{cnt + CNT_NMULTI, two, 2}, {cnt + CNT_NBIG, &ctx->nBig, 1}, {cnt + CNT_NSMALL, sm, 2}}; rc = fetchMany(ctx, pc, 3); if (rc) return rc; }
-    ctx->nSmall = sm[0]; ctx->nMid = sm[1];
+        HIPCHK(hipMemsetAsync(cnt + CNT_NMULTI2, 0, 16, ctx->stream));
+    static_assert(CNT_NMULTI2 % 2 == 0 && CNT_NTINY == CNT_NMULTI2 + 1 && CNT_NSMALL == CNT_NMULTI2 + 2 && CNT_NMID == CNT_NMULTI2 + 3, "two 64-bit words: one memset, one fetch");
+    KL(k_region_classify, dim3(gridFor(R, 1024 * YD_RCLS_IPT)), dim3(1024), 0, ctx->stream, ctx->regStart.as<uint32_t>(), R, ctx->multiList.as<uint32_t>(),
+        ctx->multiList.as<uint32_t>() + F,
+        ctx->smallList.as<uint32_t>(), ctx->smallList.as<uint32_t>() + F, (unsigned long long *)(cnt + CNT_NMULTI2), cnt + CNT_MAXN, ctx->bigList.as<uint32_t>(), cnt + CNT_NBIG);
+    uint32_t four[4] = {0, 0, 0, 0}, mx = 0;
+    { const FetchPiece pc[3] = {{cnt + CNT_NMULTI2, four, 4}, {cnt + CNT_NBIG, &ctx->nBig, 1}, {cnt + CNT_MAXN, &mx, 1}}; rc = fetchMany(ctx, pc, 3); if (rc) return rc; }
+    uint32_t two[2] = {four[0], mx};
+    ctx->nTiny = four[1]; ctx->nSmall = four[2]; ctx->nMid = four[3];
     ctx->nMulti = two[0]; ctx->maxN = two[1];
     if (kTrace && getenv("YGPU_REGION_HIST")) {                                  // fragments a region: how the three chain kernels' shares lie (diagnostic)
         std::vector<uint32_t> rs((size_t)R + 1); hipMemcpy(rs.data(), ctx->regStart.p, 4ull * (R + 1), hipMemcpyDeviceToHost);
@@ -72,9 +74,11 @@ int stageChain(ygpu_ctx *ctx)
         A.clumps = ctx->clumps.as<ChainClumpRec>(); A.clumpFrags = ctx->clumpFrags.as<DevFrag>(); A.counts = cnt + CNT_CLUMPS; A.clumpCap = clumpCap; A.fragCap = fragCap;
         A.regionClumpCount = ctx->regionCount.as<uint32_t>(); A.errFlag = ctx->errFlag.as<int>(); A.ctr = ctx->ctr.as<DevCounters>();
         KL(k_regions_single, dim3(gridFor(R, 1024)), dim3(1024), 0, ctx->stream, A);
+        // (the lane kernels: 2 .. 4, 5 .. 8 and 9 .. 16 fragments a region -- 8.5, 17 and 34 KB of LDS a wave)
+        if (ctx->nTiny) KL(k_chain_lanes<YD_CLT4>, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nTiny, 64), (uint64_t)ctx->nCU * 16)), dim3(64), 0, ctx->stream, A,
+            ctx->multiList.as<uint32_t>() + F - ctx->nTiny, ctx->nTiny);
         if (ctx->nSmall) KL(k_chain_lanes<YD_CL>, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nSmall, 64), (uint64_t)ctx->nCU * 8)), dim3(64), 0, ctx->stream, A,
             ctx->smallList.as<uint32_t>(), ctx->nSmall);
-        // (the middle class, 9 .. 16 fragments, a region a lane as well: 34 KB of LDS a wave)
         if (ctx->nMid) KL(k_chain_lanes<YD_CLM>, dim3((unsigned)std::min<uint64_t>(gridFor(ctx->nMid, 64), (uint64_t)ctx->nCU * 4)), dim3(64), 0, ctx->stream, A,
             ctx->smallList.as<uint32_t>() + F - ctx->nMid, ctx->nMid);
         if (ctx->nMulti) KL(k_chain, dim3(waves), dim3(64), 0, ctx->stream, A);
