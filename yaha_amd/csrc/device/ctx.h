@@ -82,7 +82,7 @@ enum {
         CNT_NTINY, CNT_NSMALL, CNT_NMID, CNT_NB12, CNT_NB16,
         CNT_NB24,
     CNT_SEGC,                            // YD_SEG_NCLASS + 1 words: the segments of the workgroup-sort classes, the long ones
-    CNT_NFRAGS = CNT_SEGC + 16,          // + the look-back's flag + the order check's (seed.h: a key that is not above its predecessor)
+    CNT_NFRAGS = CNT_SEGC + 16,          // + the look-back's flag + the order check's (wgsort.h: a sorted hit that is not above the hit before it)
     CNT_NREG = CNT_NFRAGS + 3,           // + flag
     CNT_SCANFAIL = CNT_NREG + 2,         // raised by a look-back of scan.h that gave up
     CNT_N = CNT_NREG + 4
