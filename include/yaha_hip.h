@@ -215,8 +215,10 @@ int  ygpu_collect_filtered(ygpu_ctx *ctx, uint32_t *clump_start, ygpu_out_clump 
 int  ygpu_inject_results(ygpu_ctx *ctx, const ygpu_result_batch *r);
 /* Stage-level test entry for the exclusive sums and orderings the hot path lays its variable-size outputs out with (device/scan.h: single-pass look-back sums of
  * u32 / u64, orderings by a small key) and for the post-filter's sort on the wave (device/oqc_stage.h waveSort, against oqc_core.h sortRange): runs them on n
- * pseudo-random elements (the sort: on arrays of 2 .. 1 792 entries with ties) and compares with the plain host loops.  0, or YGPU_EINTERNAL with the first
- * difference in ygpu_last_error.  (The reference needs neither: it handles one read at a time, Query.c:306-497.) */
+ * pseudo-random elements (the sort: on arrays of 2 .. 1 792 entries with ties) and compares with the plain host loops; and for A2's workgroup sort (device/wgsort.h: five
+ * shapes, both rankings -- LDS atomics and ballots -- over segments of every fill whose diagonals are made to tie, against std::stable_sort; its own order check must
+ * stay silent).  0, or YGPU_EINTERNAL with the first difference in ygpu_last_error.  (The reference needs none of them: it handles one read at a time and merges
+ * sorted k-mer lists, Query.c:306-497, QueryMatch.c:52-121.) */
 int  ygpu_selftest_primitives(ygpu_ctx *ctx, uint32_t n, uint32_t seed, int key_bits);
 /* The trace stream of the last ygpu_run -- the largest HBM stream of the path, an implementation choice and not algorithmic traffic: the X-drop rows kernel writes
  * a record per DP row it computes, the traceback (SW.cpp:1138-1195) comes back for those of rows 0 .. maxi of the calls that end above zero (SW.cpp:1091-1111 returns

@@ -224,7 +224,8 @@ class Context:
         return int(f.value), int(t.value), int(m.value)
 
     def selftest_primitives(self, n, seed=1, key_bits=8):
-        """The path's own exclusive sums and orderings (device/scan.h) against the host's loops (ygpu_selftest_primitives); raises on a difference."""
+        """The path's own exclusive sums and orderings (device/scan.h), the post-filter's sort on the wave and A2's workgroup sort (device/wgsort.h, both rankings)
+        against the host's loops (ygpu_selftest_primitives); raises on a difference."""
         self._check(lib().ygpu_selftest_primitives(self._h, C.c_uint32(n), C.c_uint32(seed), C.c_int(key_bits)), "ygpu_selftest_primitives")
 
     def arena_profile(self):
