@@ -470,7 +470,7 @@ def side_workload(ya, idx, reads_path, n_reads, device, contexts, steps, label, 
             "k_ext_rows_ms_per_step": st.get("ext_rows_device_clock", 0.0) / steps, "dp_cells_per_read": (cnt["dp_ext_cells"] + cnt["dp_gap_cells"]) / max(n, 1), "hits_per_read": cnt["hits"] / max(n, 1)}
 
 
-def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1, read_len=1000, div=0.017):
+def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1, read_len=1000, div=0.017, settle_s=20.0):
     """The whole `yaha` command line with its defaults (process start, index mmap + upload to every device, input parsing, device, OQC, SAM text to a file in
     /dev/shm) on n_reads x 1 kbp reads -- BASELINE config 4's size by default -- over `gpus` devices.  `steady_reads_per_s` is the command line's own figure
     (YAHA_STATS=1): reads written after the first batch / time between the first and the last batch's write, i.e. without start-up."""
@@ -493,7 +493,10 @@ def end_to_end(ya, idx, fa, cache, n_reads, seed, gpus=1, read_len=1000, div=0.0
         """The driver scrubs device memory a process has freed in the background, and a process that allocates meanwhile waits for it: a command line started right
         after the bench contexts (or the previous command line) freed ~200 GB spends seconds in its first allocations -- a property of what ran before it.  Tiny
         runs, 5 s apart, after 20 s of waiting, until the contexts are up within a second again (another 45 s at most)."""
-        time.sleep(20)                                   # (the arenas of a full run ask for ten times what the tiny run's index does: give the scrubbing its head start)
+        # (the arenas of a full run ask for ten times what the tiny run's index does: give the scrubbing its head start.  The scrubbing also runs ON the device: a command
+        # line that starts while 240 GB of the previous one's arenas are still being cleared runs beside it -- the 10 kbp leg, whose arenas are the largest, took 2.6 s
+        # instead of 1.6 s twenty seconds behind its predecessor, 3.0 s five seconds behind, 1.6 s after 28 s: tools/r06/cli_c3_after_load.sh -- so that leg waits 40 s)
+        time.sleep(settle_s)
         t0 = time.time(); ups = []
         while True:
             p = subprocess.run([ya.CLI_PATH, "-x", idx, "-q", tiny, "-osh", out] + more, stderr=subprocess.PIPE, check=True, env=env)
@@ -830,7 +833,7 @@ def main():
             out["e2e_reads_per_s"] = out["end_to_end"]["e2e_reads_per_s"]; out["steady_reads_per_s"] = out["end_to_end"]["steady_reads_per_s"]
             out["contexts_up_ms"] = out["end_to_end"].get("contexts_up_ms")
             if args.e2e_reads >= 262144:     # BASELINE config 3's shape through the command line as well: 32 768 reads of 10 kbp (20 batches of ~16 M bases), r = 0.10 (realised 3.4 %)
-                out["end_to_end_c3"] = end_to_end(ya, idx, fa, cache, 32768, 3100, read_len=10000, div=0.034)
+                out["end_to_end_c3"] = end_to_end(ya, idx, fa, cache, 32768, 3100, read_len=10000, div=0.034, settle_s=40.0)
                 out["e2e_c3_reads_per_s"] = out["end_to_end_c3"].get("e2e_reads_per_s"); out["steady_c3_reads_per_s"] = out["end_to_end_c3"].get("steady_reads_per_s")
         except Exception as e:
             out["end_to_end"] = {"error": str(e)[:200]}
