@@ -543,6 +543,15 @@ struct MergedOps {
         return sl == 0 ? w0 : (sl == 1 ? w1 : (sl == 2 ? w2 : w3));
     }
     __device__ int count() const { return (na - jab) + nb + (nc - jbc); }
+    // (no branches but the window's: segment and index by selects, the junctions' lengths -- lenA0 / lenC0, set by setJunctions -- added where they belong.  With the
+    // three segment cases as branches an op cost ~70 vector and ~120 scalar instructions in forty basic blocks: k_p3_lanes 2.61 -> 2.01 ms with this form, round 6)
+    int lenA0 = 0, lenC0 = 0;
+    __device__ __forceinline__ void setJunctions()
+    {
+        jab = (na > 0 && opCode(a[0]) == opCode(b[0])) ? 1 : 0; lenA0 = jab ? opLen(a[0]) : 0;
+        jbc = (nc > 0 && opCode(c[0]) == opCode(b[nb - 1])) ? 1 : 0; lenC0 = jbc ? opLen(c[0]) : 0;
+    }
+    // the same with a branch a case: what predictCarefulDPs keeps (k_p3_predict: 1.27 ms with this form, 1.46 with the selects)
     __device__ uint32_t at(int k) const
     {
         const int ka = na - jab;
@@ -550,11 +559,20 @@ struct MergedOps {
         k -= ka;
         if (k < nb) {
             uint32_t op = fetch(b, k); int len = opLen(op);
-            if (k == 0 && jab) len += opLen(a[0]);
-            if (k == nb - 1 && jbc) len += opLen(c[0]);
+            if (k == 0 && jab) len += lenA0;
+            if (k == nb - 1 && jbc) len += lenC0;
             return opMake(opCode(op), len & 0xFFFF);
         }
         return fetch(c, k - nb + jbc);
+    }
+    __device__ __forceinline__ uint32_t atLean(int k) const
+    {
+        const int ka = na - jab, kb = ka + nb;
+        const bool inA = k < ka, inB = !inA & (k < kb);
+        const int idx = inA ? na - 1 - k : (inB ? k - ka : k - kb + jbc);
+        const uint32_t op = fetch(inA ? a : (inB ? b : c), idx);
+        const int add = ((inB & (k == ka)) ? lenA0 : 0) + ((inB & (k == kb - 1)) ? lenC0 : 0);
+        return (op & 0xFFFF0000u) | ((op + (uint32_t)add) & 0xFFFFu);
     }
 };
 // Which careful extensions will splitClump ask for?  The frames it visits (the root, then recursively the head and tail
@@ -648,14 +666,15 @@ __device__ __forceinline__ P3Root p3Merged(const PhaseArgs &X, uint32_t r)
     const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
     if (rb.score > 0) {                                                  // AlignExtFrag.cpp:112-125
         const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-        L.a = extOpsPtr(X.extOps, rb); L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
+        L.a = extOpsPtr(X.extOps, rb); L.na = (int)rb.nOps;
         o.score += rb.score; o.sqo = (o.sqo - aQ) & 0xFFFF; o.sro -= (uint32_t)aR; o.refLen = (o.refLen + aR) & 0xFFFF;
     }
     if (rf.score > 0) {                                                  // AlignExtFrag.cpp:128-141
         const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-        L.c = extOpsPtr(X.extOps, rf); L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
+        L.c = extOpsPtr(X.extOps, rf); L.nc = (int)rf.nOps;
         o.score += rf.score; o.eqo = (o.eqo + aQ) & 0xFFFF; o.refLen = (o.refLen + aR) & 0xFFFF;
     }
+    L.setJunctions();
     return o;
 }
 
@@ -675,6 +694,9 @@ __global__ void __launch_bounds__(256) k_p3_keys(PhaseArgs X, uint32_t rootEnd, 
 
 #ifndef YD_P3_LOCAL_SORT
 #define YD_P3_LOCAL_SORT 1
+#endif
+#ifndef YD_P3_LEAN_WALK
+#define YD_P3_LEAN_WALK 1
 #endif
 #ifndef YD_P3_BS
 #define YD_P3_BS 256
@@ -711,6 +733,19 @@ __global__ void __launch_bounds__(YD_P3_BS) k_p3_lanes(AlignArgs A, PhaseArgs X)
         status |= stAligned;
         // scoreClump
         n = L.count(); const int aligned = score; int maxAGS = 0; verdict = 0;
+#if YD_P3_LEAN_WALK
+        // (the walk without branches but the window's: MergedOps::at by selects, the four counts and the score by selects)
+        {
+            const int MS = P.MS, nRC = -P.RC, nGE = -P.GE, nGO = -P.GO;
+            for (int k = 0; k < n; k++) {
+                const uint32_t op = L.atLean(k); const int code = opCode(op), len = opLen(op);
+                matches += code == OP_M ? len : 0; mism += code == OP_R ? len : 0; ins += code == OP_I ? len : 0; del += code == OP_D ? len : 0;
+                AGS += len * (code == OP_M ? MS : (code == OP_R ? nRC : nGE)) + (code >= OP_D ? nGO : 0);
+                if (AGS <= 0 || (AGS >= aligned && k != n - 1)) { verdict = 1; break; }
+                maxAGS = AGS > maxAGS ? AGS : maxAGS;
+            }
+        }
+#else
         for (int k = 0; k < n; k++) {
             const uint32_t op = L.at(k); const int code = opCode(op), len = opLen(op);
             if (code == OP_M) { matches += len; AGS += P.MS * len; } else if (code == OP_R) { mism += len; AGS -= P.RC * len; }
@@ -718,6 +753,7 @@ __global__ void __launch_bounds__(YD_P3_BS) k_p3_lanes(AlignArgs A, PhaseArgs X)
             if (AGS <= 0 || (AGS >= aligned && k != n - 1)) { verdict = 1; break; }
             if (AGS > maxAGS) maxAGS = AGS;
         }
+#endif
         if (verdict == 0) {
             if (matches >= P.minRawScore && maxAGS > AGS) verdict = 1;
             else if (matches >= P.minRawScore) {
@@ -748,7 +784,7 @@ __global__ void __launch_bounds__(YD_P3_BS) k_p3_lanes(AlignArgs A, PhaseArgs X)
             if (ci >= A.outClumpCap || (unsigned long long)oi + (unsigned)n > (unsigned long long)A.outOpsCap) atomicCAS(A.errFlag, 0, (int)YERR_OUT);
             else {
                 const char codes[4] = {'M', 'R', 'D', 'I'};
-                for (int k = 0; k < n; k++) { const uint32_t op = L.at(k); A.outOps[oi + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
+                for (int k = 0; k < n; k++) { const uint32_t op = L.atLean(k); A.outOps[oi + k] = ((uint32_t)(uint8_t)codes[opCode(op) & 3] << 16) | (uint32_t)opLen(op); }
                 ygpu_clump c; c.sro = sro; c.sqo = (uint16_t)sqo; c.eqo = (uint16_t)eqo; c.refLen = (uint16_t)refLen; c.totScore = (uint16_t)(AGS & 0xFFFF);
                 c.totLength = (uint16_t)((matches + mism + ins + del) & 0xFFFF); c.matchedBases = (uint16_t)(matches & 0xFFFF); c.mismatchedBases = (uint16_t)(mism & 0xFFFF);
                 c.gapBases = (uint16_t)((ins + del) & 0xFFFF); c.status = (uint8_t)(status | stScored); c.reserved = 0; c.op_start = oi; c.n_ops = (uint32_t)n;

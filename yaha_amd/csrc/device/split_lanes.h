@@ -47,18 +47,19 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         const ExtRes rb = X.res[2 * (size_t)r], rf = X.res[2 * (size_t)r + 1];
         if (rb.score > 0) {
             const int aQ = rb.maxi, aR = rb.maxi + (rb.maxj - YD_LBAND);
-            L.a = extOpsPtr(X.extOps, rb); L.na = (int)rb.nOps; L.jab = (L.na > 0 && opCode(L.a[0]) == opCode(L.b[0])) ? 1 : 0;
+            L.a = extOpsPtr(X.extOps, rb); L.na = (int)rb.nOps;
             f.score += rb.score; f.sqo = (f.sqo - aQ) & 0xFFFF; f.sro -= (uint32_t)aR; f.refLen = (f.refLen + aR) & 0xFFFF;
         }
         if (rf.score > 0) {
             const int aQ = rf.maxi, aR = rf.maxi + (rf.maxj - YD_LBAND);
-            L.c = extOpsPtr(X.extOps, rf); L.nc = (int)rf.nOps; L.jbc = (L.nc > 0 && opCode(L.c[0]) == opCode(L.b[L.nb - 1])) ? 1 : 0;
+            L.c = extOpsPtr(X.extOps, rf); L.nc = (int)rf.nOps;
             f.score += rf.score; f.eqo = (f.eqo + aQ) & 0xFFFF; f.refLen = (f.refLen + aR) & 0xFFFF;
         }
         f.status |= stAligned;
+        L.setJunctions();
         const int n0 = L.count();
         if (YD_SL_FRONT + n0 > YD_SL_CAP - 64) fall = true;
-        else { for (int k = 0; k < n0; k++) lists[YD_SL_FRONT + k] = L.at(k); f.start = YD_SL_FRONT; f.len = n0; }
+        else { for (int k = 0; k < n0; k++) lists[YD_SL_FRONT + k] = L.atLean(k); f.start = YD_SL_FRONT; f.len = n0; }
         // ---- helpers on a frame's list buffer ---------------------------------------------------------------------------------------
         int depth = 0; SFrame st[YD_SL_DEPTH]; unsigned pushes = 0;
         int sm = -1, smm = 0, sg = 0, sl = 0, ss = 0;                          // results of the last scoreList
