@@ -527,6 +527,11 @@ __global__ void __launch_bounds__(256) k_p1_assemble(AlignArgs A, PhaseArgs X)
 // Phase 3 for roots that scoreClump accepts or rejects without a split (AlignHelpers.c:302-366): the merged edit list
 // [backward extension ops][phase-1 ops][forward extension ops] is scanned in place; accepted clumps are written out by
 // their lane.  A root that needs splitClump goes to slowList for k_align_p3.
+// score and counts of one edit op without a branch a code (the lanes of a wave hold different codes: four branches were four masked passes over the same three
+// instructions, and as many jumps)
+__device__ __forceinline__ int opScore(const DevParams &P, int code, int len) { return len * (code == OP_M ? P.MS : (code == OP_R ? -P.RC : -P.GE)) + (code >= OP_D ? -P.GO : 0); }
+#define YD_OP_COUNT(code, len, m, r, i, d) \
+    do { m += (code) == OP_M ? (len) : 0; r += (code) == OP_R ? (len) : 0; i += (code) == OP_I ? (len) : 0; d += (code) == OP_D ? (len) : 0; } while (0)
 typedef uint32_t yd_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 struct MergedOps {
     const uint32_t *a, *b, *c; int na, nb, nc; int jab, jbc;      // junction merges (mergeEOLToFront / mergeEOLToBack, SW.cpp:151-261)
@@ -590,17 +595,16 @@ __device__ inline int predictCarefulDPs(const DevParams &P, const MergedOps &L, 
         if (f.phase == 0) {                                                  // splitClumpHelper: the best-scoring core
             int matches = 0, mism = 0, ins = 0, del = 0, AGS = 0, maxAGS = -10000, maxItem = -1, minItem = -1, eQO = 0, sQO = 0; uint32_t eRO = 0, sRO = 0;
             for (int k = 0; k < f.len; k++) {
-                const uint32_t op = L.at(f.start + k); const int code = opCode(op), len = opLen(op); int ns;
-                if (code == OP_M) { matches += len; ns = P.MS * len; } else if (code == OP_R) { mism += len; ns = -(P.RC * len); }
-                else if (code == OP_I) { ins += len; ns = -(P.GO + P.GE * len); } else { del += len; ns = -(P.GO + P.GE * len); }
-                AGS += ns; if (AGS < 0) AGS = 0;
+                const uint32_t op = L.at(f.start + k); const int code = opCode(op), len = opLen(op);
+                YD_OP_COUNT(code, len, matches, mism, ins, del);
+                AGS += opScore(P, code, len); if (AGS < 0) AGS = 0;
                 if (AGS > maxAGS) { maxAGS = AGS; maxItem = k; eQO = (f.sqo + matches + mism + ins - 1) & 0xFFFF; eRO = f.sro + (uint32_t)(matches + mism + del) - 1u; }
             }
             AGS = maxAGS; matches = mism = ins = del = 0; int maxMatch = 0;
             for (int k = maxItem; k >= 0; k--) {
                 const uint32_t op = L.at(f.start + k); const int code = opCode(op), len = opLen(op);
-                if (code == OP_M) { matches += len; AGS -= P.MS * len; if (len > maxMatch) maxMatch = len; } else if (code == OP_R) { mism += len; AGS += P.RC * len; }
-                else if (code == OP_I) { ins += len; AGS += (P.GO + P.GE * len); } else { del += len; AGS += (P.GO + P.GE * len); }
+                YD_OP_COUNT(code, len, matches, mism, ins, del);
+                AGS -= opScore(P, code, len); maxMatch = (code == OP_M && len > maxMatch) ? len : maxMatch;
                 if (AGS <= 0) { minItem = k; sQO = (eQO - (matches + mism + ins - 1)) & 0xFFFF; sRO = eRO - (uint32_t)(matches + mism + del - 1); break; }
             }
             if (maxMatch < P.wordLen || minItem < 0) f.phase = 4;
@@ -695,9 +699,6 @@ __global__ void __launch_bounds__(256) k_p3_keys(PhaseArgs X, uint32_t rootEnd, 
 #ifndef YD_P3_LOCAL_SORT
 #define YD_P3_LOCAL_SORT 1
 #endif
-#ifndef YD_P3_LEAN_WALK
-#define YD_P3_LEAN_WALK 1
-#endif
 #ifndef YD_P3_BS
 #define YD_P3_BS 256
 #endif
@@ -733,27 +734,16 @@ __global__ void __launch_bounds__(YD_P3_BS) k_p3_lanes(AlignArgs A, PhaseArgs X)
         status |= stAligned;
         // scoreClump
         n = L.count(); const int aligned = score; int maxAGS = 0; verdict = 0;
-#if YD_P3_LEAN_WALK
         // (the walk without branches but the window's: MergedOps::at by selects, the four counts and the score by selects)
         {
-            const int MS = P.MS, nRC = -P.RC, nGE = -P.GE, nGO = -P.GO;
             for (int k = 0; k < n; k++) {
                 const uint32_t op = L.atLean(k); const int code = opCode(op), len = opLen(op);
-                matches += code == OP_M ? len : 0; mism += code == OP_R ? len : 0; ins += code == OP_I ? len : 0; del += code == OP_D ? len : 0;
-                AGS += len * (code == OP_M ? MS : (code == OP_R ? nRC : nGE)) + (code >= OP_D ? nGO : 0);
+                YD_OP_COUNT(code, len, matches, mism, ins, del);
+                AGS += opScore(P, code, len);
                 if (AGS <= 0 || (AGS >= aligned && k != n - 1)) { verdict = 1; break; }
                 maxAGS = AGS > maxAGS ? AGS : maxAGS;
             }
         }
-#else
-        for (int k = 0; k < n; k++) {
-            const uint32_t op = L.at(k); const int code = opCode(op), len = opLen(op);
-            if (code == OP_M) { matches += len; AGS += P.MS * len; } else if (code == OP_R) { mism += len; AGS -= P.RC * len; }
-            else if (code == OP_I) { ins += len; AGS -= (P.GO + P.GE * len); } else { del += len; AGS -= (P.GO + P.GE * len); }
-            if (AGS <= 0 || (AGS >= aligned && k != n - 1)) { verdict = 1; break; }
-            if (AGS > maxAGS) maxAGS = AGS;
-        }
-#endif
         if (verdict == 0) {
             if (matches >= P.minRawScore && maxAGS > AGS) verdict = 1;
             else if (matches >= P.minRawScore) {

@@ -68,8 +68,8 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
             int AGS = 0, maxAGS = 0, matches = 0, mism = 0, ins = 0, del = 0; const int n = fr.len, aligned = fr.score;
             for (int k = 0; k < n; k++) {
                 const uint32_t op = b[fr.start + k]; const int code = opCode(op), len = opLen(op);
-                if (code == OP_M) { matches += len; AGS += P.MS * len; } else if (code == OP_R) { mism += len; AGS -= P.RC * len; }
-                else if (code == OP_I) { ins += len; AGS -= (P.GO + P.GE * len); } else { del += len; AGS -= (P.GO + P.GE * len); }
+                YD_OP_COUNT(code, len, matches, mism, ins, del);
+                AGS += opScore(P, code, len);
                 if (AGS <= 0 || (AGS >= aligned && k != n - 1)) return 1;
                 if (AGS > maxAGS) maxAGS = AGS;
             }
@@ -131,8 +131,7 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
         };
         auto opStep = [&](uint32_t op, int &QLen, int &RLen, int &AGS) {
             const int code = opCode(op), len = opLen(op);
-            if (code == OP_M) { QLen += len; RLen += len; AGS += P.MS * len; } else if (code == OP_R) { QLen += len; RLen += len; AGS -= P.RC * len; }
-            else if (code == OP_I) { QLen += len; AGS -= (P.GO + P.GE * len); } else { RLen += len; AGS -= (P.GO + P.GE * len); }
+            QLen += code != OP_D ? len : 0; RLen += code != OP_I ? len : 0; AGS += opScore(P, code, len);
         };
         // extendClump<goBack, goForw, carefully> (AlignExtFrag.cpp:64-156) with the careful variants of SW.cpp:553-788
         auto extendCarefully = [&](SFrame &fr, uint32_t *b, bool goBack, bool goForw) {
@@ -206,17 +205,16 @@ __global__ void __launch_bounds__(64) k_split_lanes(AlignArgs A, PhaseArgs X, Sp
             if (state == ST_SPLIT_ENTER) {                                    // splitClumpHelper, AlignHelpers.c:374-557
                 int matches = 0, mism = 0, ins = 0, del = 0, AGS = 0, maxAGS = -10000, maxItem = -1, minItem = -1, eQO = 0, sQO = 0; uint32_t eRO = 0, sRO = 0; const int n = f.len;
                 for (int k = 0; k < n; k++) {
-                    const uint32_t op = b[f.start + k]; const int code = opCode(op), len = opLen(op); int ns;
-                    if (code == OP_M) { matches += len; ns = P.MS * len; } else if (code == OP_R) { mism += len; ns = -(P.RC * len); }
-                    else if (code == OP_I) { ins += len; ns = -(P.GO + P.GE * len); } else { del += len; ns = -(P.GO + P.GE * len); }
-                    AGS += ns; if (AGS < 0) AGS = 0;
+                    const uint32_t op = b[f.start + k]; const int code = opCode(op), len = opLen(op);
+                    YD_OP_COUNT(code, len, matches, mism, ins, del);
+                    AGS += opScore(P, code, len); if (AGS < 0) AGS = 0;
                     if (AGS > maxAGS) { maxAGS = AGS; maxItem = k; eQO = (f.sqo + matches + mism + ins - 1) & 0xFFFF; eRO = f.sro + (uint32_t)(matches + mism + del) - 1u; }
                 }
                 AGS = maxAGS; matches = mism = ins = del = 0; int maxMatch = 0;
                 for (int k = maxItem; k >= 0; k--) {
                     const uint32_t op = b[f.start + k]; const int code = opCode(op), len = opLen(op);
-                    if (code == OP_M) { matches += len; AGS -= P.MS * len; if (len > maxMatch) maxMatch = len; } else if (code == OP_R) { mism += len; AGS += P.RC * len; }
-                    else if (code == OP_I) { ins += len; AGS += (P.GO + P.GE * len); } else { del += len; AGS += (P.GO + P.GE * len); }
+                    YD_OP_COUNT(code, len, matches, mism, ins, del);
+                    AGS -= opScore(P, code, len); maxMatch = (code == OP_M && len > maxMatch) ? len : maxMatch;
                     if (AGS <= 0) { minItem = k; sQO = (eQO - (matches + mism + ins - 1)) & 0xFFFF; sRO = eRO - (uint32_t)(matches + mism + del - 1); break; }
                 }
                 if (maxMatch < P.wordLen || minItem < 0) { state = ST_RETURN; continue; }
