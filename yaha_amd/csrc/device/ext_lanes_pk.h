@@ -69,6 +69,7 @@ __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) 
 #define YD_ROWS_RESBATCH 1
 #endif
 #ifdef YD_PROF
+__device__ unsigned long long gTraceProf[8];     // k_ext_trace_pk (YD_PROF): waves that walk, passes, active lane-passes, group-loop rounds, rounds with a flush, passes with a deletion run, with an insertion run, rows
 __device__ unsigned long long gRowsProf[8];      // passes, passes that wrote results, refill rounds, passes with a new maximum, busy lane-passes, flushes, pool loads
 #endif
 // YD_ROWS_UNI_EXIT=1: only the pass loop's two exits as scalar branches -- 14.38 -> 14.32 ms a launch (everything at once was slower, see the loop's head); and a
@@ -565,9 +566,15 @@ __global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
         // free for staging: the records above record (cursor + 1) -- the record after the cursor's may still hold the high half of the cursor's row
         auto flush = [&]() { const int wp = E - 1 - n; if (wp < u.w + 8) bad = true; else *S.at(wp) = opMake(prev, acc); n++; };
         auto put = [&](int code, int len) { if (prev != code) { if (prev >= 0) flush(); prev = code; acc = len; } else acc += len; };
+#ifdef YD_PROF
+        unsigned tpPass = 0, tpAct = 0, tpRounds = 0, tpFlushR = 0, tpDel = 0, tpIns = 0, tpRows = 0; const bool tpWalks = __ballot(walk) != 0ull;
+#endif
         for (int guard = 0;; guard++) {
             const bool act = walk && guard < 70000 && y > 0 && x >= 0 && x < YD_LW;
             if (__ballot(act) == 0ull) break;                                  // wave-uniform
+#ifdef YD_PROF
+            tpPass++; tpAct += (unsigned)__builtin_popcountll(__ballot(act));
+#endif
             {   // the wave's 64 current blocks -> LDS
                 const unsigned long long myBase = (unsigned long long)(act ? u.cp - u.rr * 4 : S.arena);
 #pragma unroll
@@ -617,6 +624,9 @@ __global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
             {
                 const uint32_t m = mis & ((1u << took) - 1u); int pos = 0;
                 while (pos < took) {
+#ifdef YD_PROF
+                    tpRounds++;                                                    // (per lane here; summed over the wave below: lane-rounds)
+#endif
                     const uint32_t cur = (m >> pos) & 1u;
                     const uint32_t same = (cur ? ~m : m) >> pos;              // zeros where the following rows have the same bit
                     const int g = __builtin_ctz(same | (1u << (took - pos)));
@@ -625,6 +635,10 @@ __global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
                     pos += g;
                 }
             }
+#ifdef YD_PROF
+            tpRows += (unsigned)took;
+            if (took != lim) { if (op == OP_D) tpDel++; else tpIns++; }
+#endif
             if (took == lim) { if (y > 0) stepUp(u); else u.w = row0w; continue; }
             if (op == OP_D) {                                                    // deletion run: the continue bits along the row, leftwards (the row's low half is one record up)
                 int sl = rr0 - took;                                             // the cursor's slot in the fetched block
@@ -653,6 +667,15 @@ __global__ void __launch_bounds__(YD_TRACE_BS) k_ext_trace_pk(ExtArgs A)
                 if (y > 0) { for (int s = 0; s < steps; s++) stepUp(u); } else u.w = row0w;
             }
         }
+#ifdef YD_PROF
+        if (tpWalks) {
+            const unsigned r4 = (unsigned)waveSumI((int)tpRounds), d4 = (unsigned)waveSumI((int)tpDel), i4 = (unsigned)waveSumI((int)tpIns), w4 = (unsigned)waveSumI((int)tpRows);
+            if (lane == 0) { atomicAdd(&gTraceProf[0], 1ull); atomicAdd(&gTraceProf[1], (unsigned long long)tpPass); atomicAdd(&gTraceProf[2], (unsigned long long)tpAct);
+                atomicAdd(&gTraceProf[3], (unsigned long long)r4); atomicAdd(&gTraceProf[5], (unsigned long long)d4); atomicAdd(&gTraceProf[6], (unsigned long long)i4);
+                atomicAdd(&gTraceProf[7], (unsigned long long)w4); }
+        }
+        (void)tpFlushR;
+#endif
         if (walk) {
         if (y <= 0 && x > leftR) put(OP_D, x - leftR);                           // row 0: deletions back to the origin (SW.cpp:905-935)
         if (prev >= 0) { const int wp = E - 1 - n; if (wp < 0) bad = true; else *S.at(wp) = opMake(prev, acc); n++; }

@@ -492,7 +492,8 @@ int stageAlign(ygpu_ctx *ctx)
             A.outCounts = cnt + CNT_OUTCLUMPS; A.outClumpCap = outClumpCap; A.outOpsCap = outOpsCap; A.rootPushCount = ctx->rootPush.as<unsigned int>();
             A.ctr = ctx->ctr.as<DevCounters>(); A.errFlag = ctx->errFlag.as<int>();
 #ifdef YD_PROF
-            { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); hipMemcpyToSymbol(HIP_SYMBOL(gRowsProf), z, sizeof(unsigned long long) * 8); }
+            { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof z); hipMemcpyToSymbol(HIP_SYMBOL(gRowsProf), z, sizeof(unsigned long long) * 8);
+              hipMemcpyToSymbol(HIP_SYMBOL(gTraceProf), z, sizeof(unsigned long long) * 8); }
 #endif
             bool laneOverflow = false, traceOverflow = false; ctx->hOutValid = false;
             if (!useLanes) KL(k_align, dim3(waves), dim3(64), 0, ctx->stream, A);
@@ -506,7 +507,11 @@ int stageAlign(ygpu_ctx *ctx)
               if (q[0]) fprintf(stderr,
                   "[YD_PROF] k_ext_rows_pk: wave passes %llu; of them writing results %.1f %%, with a new maximum in some lane %.1f %%, handing blocks over %.1f %%; "
                       "refill rounds %.3f a pass (pool loads %.4f); busy lanes %.1f of 64\n",
-                                q[0], 100.0 * q[1] / q[0], 100.0 * q[3] / q[0], 100.0 * q[5] / q[0], (double)q[2] / q[0], (double)q[6] / q[0], (double)q[4] / q[0]); }
+                                q[0], 100.0 * q[1] / q[0], 100.0 * q[3] / q[0], 100.0 * q[5] / q[0], (double)q[2] / q[0], (double)q[6] / q[0], (double)q[4] / q[0]);
+              unsigned long long t[8]; hipMemcpyFromSymbol(t, HIP_SYMBOL(gTraceProf), sizeof t);      // k_ext_trace_pk: where its passes go
+              if (t[0]) fprintf(stderr, "[YD_PROF] k_ext_trace_pk: %llu waves that walk, %.1f passes a wave, %.1f active lanes a pass, %.2f rows a lane and pass; op groups %.2f a "
+                                        "lane-pass; lane-passes that end in a deletion run %.1f %%, in an insertion run %.1f %%\n",
+                                t[0], (double)t[1] / t[0], (double)t[2] / t[1], (double)t[7] / t[2], (double)t[3] / t[2], 100.0 * t[5] / t[2], 100.0 * t[6] / t[2]); }
 #endif
             uint32_t got[2] = {0, 0}, ef = 0;
             if (laneOverflow || traceOverflow) ef = YERR_OUT;
