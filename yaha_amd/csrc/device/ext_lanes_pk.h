@@ -69,7 +69,8 @@ __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xFFFFu) 
 #define YD_ROWS_RESBATCH 1
 #endif
 #ifdef YD_PROF
-__device__ unsigned long long gTraceProf[8];     // k_ext_trace_pk (YD_PROF): waves that walk, passes, active lane-passes, group-loop rounds, rounds with a flush, passes with a deletion run, with an insertion run, rows
+// k_ext_trace_pk (YD_PROF): waves that walk, passes, active lane-passes, group-loop rounds, rounds with a flush, passes with a deletion run, with an insertion run, rows
+__device__ unsigned long long gTraceProf[8];
 __device__ unsigned long long gRowsProf[8];      // passes, passes that wrote results, refill rounds, passes with a new maximum, busy lane-passes, flushes, pool loads
 #endif
 // YD_ROWS_UNI_EXIT=1: only the pass loop's two exits as scalar branches -- 14.38 -> 14.32 ms a launch (everything at once was slower, see the loop's head); and a
