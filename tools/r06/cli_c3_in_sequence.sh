@@ -7,7 +7,7 @@ Q=$C/e2e_n32768_l10000_s3100.fa; [ -f $Q ] || tools/yaha_sim reads --genome $C/g
 st() { grep -o "total_ms[^,]*, \"steady_reads_per_s\": [0-9]*\|\"run\": [0-9.]*\|filter_thread_ms_per_batch\": [0-9.]*" /tmp/err.txt | tr '\n' ' '; echo; }
 YAHA_STATS=1 yaha_amd/csrc/yaha -x $X -q $R1 -osh /dev/shm/o.sam 2> /tmp/err.txt; echo "1 kbp x 1M: $(st)"
 sleep 20
-for i in 1 2; do /usr/bin/time -f "wall %e s" env YAHA_STATS=1 yaha_amd/csrc/yaha -x $X -q $Q -osh /dev/shm/o.sam 2> /tmp/err.txt; echo "10 kbp run $i: $(st) $(grep wall /tmp/err.txt)"; sleep 20; done
+for i in 1 2; do YAHA_STATS=1 yaha_amd/csrc/yaha -x $X -q $Q -osh /dev/shm/o.sam 2> /tmp/err.txt; echo "10 kbp run $i: $(st)"; sleep 20; done
 # and under a parent that has imported torch and initialised the device (as bench.py has)
 python3 - <<PY
 import subprocess, os, time, torch
